@@ -1,0 +1,628 @@
+// awsm_hip.cpp — context, device-memory management and the C-ABI entry points of include/awsm_hip.h.
+//
+// Sits where the reference's `AwsmRendererWebGpu` wrapper sits (crates/renderer-core/src/methods.rs:
+// create_buffer :239, write_buffer :339-431, submit_commands :283-287) but knows the two passes of the hot
+// path (crates/renderer/src/render.rs:144-221).  No torch, no WebGPU, no CPU fallback: every entry point
+// either drives the HIP kernels or fails with a status code.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "frame_params.hpp"
+
+using namespace awsm;
+
+extern "C" {
+void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
+void awsm_launch_bin_count(const FrameDev* f, hipStream_t s);
+void awsm_launch_bin_scan(const FrameDev* f, hipStream_t s);
+void awsm_launch_bin_fill(const FrameDev* f, hipStream_t s);
+void awsm_launch_raster(const FrameDev* f, hipStream_t s);
+void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
+void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s);
+void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n, hipStream_t s);
+}
+
+namespace {
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t size = 0;
+};
+
+enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE, EV_COUNT };
+
+}  // namespace
+
+struct AwsmHipCtx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+
+    DevBuf bufs[AWSM_BUF_COUNT];
+    DevScene scene{};            // host copy
+    DevScene* scene_dev = nullptr;
+    bool scene_dirty = true;
+    DevBuf tex[kMaxTexArrays];
+    DevBuf lut;
+
+    // frame targets
+    uint32_t width = 0, height = 0;
+    uint32_t y0 = 0, y1 = 0;     // shard rows (0,0 = full)
+    DevBuf vis, out16, out32;
+    void* bound_out = nullptr;
+    size_t bound_out_bytes = 0;
+
+    // geometry-pass resources
+    DevBuf clip, nrm, tan, tri_flags, draws_dev, tile_count, tile_offset, tile_cursor, bin_list, counters;
+    std::vector<DrawDev> draws_host;
+    std::vector<AwsmDraw> draws_api;
+    uint32_t total_tris = 0, total_verts = 0, n_blocks = 0;
+    uint32_t bin_capacity = 0;
+    bool geometry_done = false, opaque_done = false;
+    AwsmOpaqueParams last_opaque{};
+    uint32_t overflow_retries = 0;
+
+    // pinned staging ring for buffer_write / small uploads
+    uint8_t* stage = nullptr;
+    size_t stage_cap = 0, stage_head = 0;
+    uint32_t* counters_host = nullptr;   // pinned, 8 u32
+
+    hipEvent_t ev[EV_COUNT] = {};
+    bool ev_valid[EV_COUNT] = {};
+};
+
+namespace {
+
+int fail(AwsmHipCtx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((c), e_ == hipErrorOutOfMemory ? AWSM_ERR_OUT_OF_MEMORY : AWSM_ERR_DEVICE, \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int dev_realloc(AwsmHipCtx* c, DevBuf& b, size_t bytes, bool zero) {
+    if (b.ptr && b.size == bytes) {
+        if (zero) HIPCHK(c, hipMemsetAsync(b.ptr, 0, bytes, c->stream));
+        return AWSM_OK;
+    }
+    if (b.ptr) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.ptr));
+        b.ptr = nullptr; b.size = 0;
+    }
+    if (bytes == 0) return AWSM_OK;
+    HIPCHK(c, hipMalloc(&b.ptr, bytes));
+    b.size = bytes;
+    if (zero) HIPCHK(c, hipMemsetAsync(b.ptr, 0, bytes, c->stream));
+    return AWSM_OK;
+}
+
+int dev_reserve(AwsmHipCtx* c, DevBuf& b, size_t bytes) {   // grow-only, contents not preserved
+    if (b.size >= bytes && b.ptr) return AWSM_OK;
+    size_t want = std::max(bytes, b.size + b.size / 2);
+    return dev_realloc(c, b, want, false);
+}
+
+// returns a pinned pointer valid until the copy enqueued from it has executed
+int stage_alloc(AwsmHipCtx* c, size_t len, uint8_t** out) {
+    len = (len + 255) & ~size_t(255);
+    if (len > c->stage_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->stage) HIPCHK(c, hipHostFree(c->stage));
+        c->stage = nullptr;
+        size_t cap = std::max<size_t>(len * 2, 8u << 20);
+        HIPCHK(c, hipHostMalloc((void**)&c->stage, cap, hipHostMallocDefault));
+        c->stage_cap = cap; c->stage_head = 0;
+    }
+    if (c->stage_head + len > c->stage_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // everything enqueued from the ring has been consumed
+        c->stage_head = 0;
+    }
+    *out = c->stage + c->stage_head;
+    c->stage_head += len;
+    return AWSM_OK;
+}
+
+int upload_small(AwsmHipCtx* c, void* dst, const void* src, size_t len) {
+    uint8_t* st;
+    int rc = stage_alloc(c, len, &st);
+    if (rc) return rc;
+    memcpy(st, src, len);
+    HIPCHK(c, hipMemcpyAsync(dst, st, len, hipMemcpyHostToDevice, c->stream));
+    return AWSM_OK;
+}
+
+void shard(const AwsmHipCtx* c, uint32_t* y0, uint32_t* y1) {
+    *y0 = c->y0; *y1 = c->y1;
+    if (*y1 == 0 || *y1 > c->height) *y1 = c->height;
+    if (*y0 > *y1) *y0 = *y1;
+}
+
+int sync_scene(AwsmHipCtx* c) {
+    if (!c->scene_dirty) return AWSM_OK;
+    for (int i = 0; i < AWSM_BUF_COUNT; i++) c->scene.buf[i] = (const uint8_t*)c->bufs[i].ptr;
+    c->scene.lut_rg16f = (const uint16_t*)c->lut.ptr;
+    int rc = upload_small(c, c->scene_dev, &c->scene, sizeof(DevScene));
+    if (rc) return rc;
+    c->scene_dirty = false;
+    return AWSM_OK;
+}
+
+void fill_frame(AwsmHipCtx* c, FrameDev* f) {
+    memset(f, 0, sizeof *f);
+    uint32_t y0, y1;
+    shard(c, &y0, &y1);
+    f->width = c->width; f->height = c->height; f->y0 = y0; f->y1 = y1;
+    f->tiles_x = (c->width + kTile - 1) / kTile;
+    f->tile_row0 = y0 >> kTileShift;
+    f->tiles_y = (y1 > y0) ? ((y1 + kTile - 1) / kTile - f->tile_row0) : 0;
+    f->n_draws = (uint32_t)c->draws_host.size();
+    f->total_tris = c->total_tris; f->total_verts = c->total_verts;
+    f->bin_capacity = c->bin_capacity;
+    f->draws = (const DrawDev*)c->draws_dev.ptr;
+    f->clip = (float4*)c->clip.ptr; f->nrm = (float4*)c->nrm.ptr; f->tan = (float4*)c->tan.ptr;
+    f->tri_flags = (uint8_t*)c->tri_flags.ptr;
+    f->tile_count = (uint32_t*)c->tile_count.ptr; f->tile_offset = (uint32_t*)c->tile_offset.ptr;
+    f->tile_cursor = (uint32_t*)c->tile_cursor.ptr; f->bin_list = (uint32_t*)c->bin_list.ptr;
+    f->counters = (uint32_t*)c->counters.ptr;
+    f->vis = (unsigned long long*)c->vis.ptr;
+    f->out_rgba16f = (uint16_t*)(c->bound_out ? c->bound_out : c->out16.ptr);
+    f->out_rgba32f = (float*)c->out32.ptr;
+}
+
+int record(AwsmHipCtx* c, int which) {
+    HIPCHK(c, hipEventRecord(c->ev[which], c->stream));
+    c->ev_valid[which] = true;
+    return AWSM_OK;
+}
+
+int enqueue_geometry(AwsmHipCtx* c) {
+    FrameDev f;
+    fill_frame(c, &f);
+    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
+    int rc = sync_scene(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
+    if (n_tiles) {
+        HIPCHK(c, hipMemsetAsync(c->tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tile_cursor.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
+    }
+    if ((rc = record(c, EV_START))) return rc;
+    if (c->total_tris && n_tiles) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
+    if ((rc = record(c, EV_TRANSFORM))) return rc;
+    if (n_tiles) {
+        if (c->total_tris) awsm_launch_bin_count(&f, c->stream);
+        awsm_launch_bin_scan(&f, c->stream);
+        if (c->total_tris) awsm_launch_bin_fill(&f, c->stream);
+    }
+    if ((rc = record(c, EV_BIN))) return rc;
+    if (n_tiles) awsm_launch_raster(&f, c->stream);
+    if ((rc = record(c, EV_RASTER))) return rc;
+    HIPCHK(c, hipGetLastError());
+    return AWSM_OK;
+}
+
+int enqueue_opaque(AwsmHipCtx* c) {
+    FrameDev f;
+    fill_frame(c, &f);
+    f.has_opaque = c->last_opaque.has_opaque;
+    int rc = sync_scene(c);
+    if (rc) return rc;
+    if (f.y1 > f.y0) awsm_launch_shade(c->scene_dev, &f, c->stream);
+    if ((rc = record(c, EV_SHADE))) return rc;
+    HIPCHK(c, hipGetLastError());
+    return AWSM_OK;
+}
+
+int ensure_bin_capacity(AwsmHipCtx* c, uint32_t entries) {
+    if (entries <= c->bin_capacity && c->bin_list.ptr) return AWSM_OK;
+    uint32_t cap = std::max(entries, c->bin_capacity + c->bin_capacity / 2);
+    int rc = dev_realloc(c, c->bin_list, (size_t)cap * 4, false);
+    if (rc) return rc;
+    c->bin_capacity = cap;
+    return AWSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t awsm_hip_abi_version(void) { return AWSM_HIP_ABI_VERSION; }
+
+const char* awsm_hip_last_error(const AwsmHipCtx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
+    if (!cfg || !out || cfg->struct_size < sizeof(AwsmConfig) || cfg->abi_version != AWSM_HIP_ABI_VERSION)
+        return AWSM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || cfg->device < 0 || cfg->device >= n_dev) return AWSM_ERR_NO_DEVICE;
+    AwsmHipCtx* c = new (std::nothrow) AwsmHipCtx();
+    if (!c) return AWSM_ERR_OUT_OF_MEMORY;
+    c->device = cfg->device;
+    c->flags = cfg->flags;
+    auto bail = [&](int code) { awsm_hip_destroy(c); return code; };
+    if (hipSetDevice(c->device) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "awsm_hip: device %d is %s; this library carries gfx950 code objects only\n", c->device, prop.gcnArchName);
+        return bail(AWSM_ERR_NO_DEVICE);
+    }
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE); c->own_stream = true; }
+    for (int i = 0; i < EV_COUNT; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+    if (hipMalloc((void**)&c->scene_dev, sizeof(DevScene)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    if (hipMalloc(&c->counters.ptr, 8 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    c->counters.size = 8 * sizeof(uint32_t);
+    if (hipHostMalloc((void**)&c->counters_host, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    memset(&c->scene, 0, sizeof c->scene);
+    // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
+    c->scene.skybox_rgba[3] = 1.0f;
+    for (int i = 0; i < 3; i++) { c->scene.prefiltered_rgb[i] = 1.0f; c->scene.irradiance_rgb[i] = 1.0f; }
+    *out = c;
+    return AWSM_OK;
+}
+
+int awsm_hip_destroy(AwsmHipCtx* c) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
+    for (auto& b : c->bufs) fr(b);
+    for (auto& b : c->tex) fr(b);
+    fr(c->lut); fr(c->vis); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_flags);
+    fr(c->draws_dev); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->bin_list); fr(c->counters);
+    if (c->scene_dev) (void)hipFree(c->scene_dev);
+    if (c->stage) (void)hipHostFree(c->stage);
+    if (c->counters_host) (void)hipHostFree(c->counters_host);
+    for (int i = 0; i < EV_COUNT; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return AWSM_OK;
+}
+
+int awsm_hip_device_info(AwsmHipCtx* c, char* name_out, size_t name_cap, uint32_t* cu_count, uint64_t* hbm_bytes) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (name_out && name_cap) snprintf(name_out, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count) *cu_count = (uint32_t)prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return AWSM_OK;
+}
+
+int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
+    if (!c || (int)which < 0 || which >= AWSM_BUF_COUNT) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "buffer_create: bad buffer id %d", (int)which);
+    HIPCHK(c, hipSetDevice(c->device));
+    // +16 bytes of slack so 16-byte vector loads of the last record never leave the allocation
+    int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
+    if (rc) return rc;
+    if (bytes) c->bufs[which].size = bytes;
+    c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf which, size_t dst_off, const void* src, size_t len) {
+    if (!c || (int)which < 0 || which >= AWSM_BUF_COUNT || (!src && len)) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "buffer_write: bad argument");
+    if ((dst_off & 3) || (len & 3)) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "buffer_write: offset %zu / size %zu not 4-byte aligned", dst_off, len);
+    DevBuf& b = c->bufs[which];
+    if (!b.ptr) return fail(c, AWSM_ERR_NOT_READY, "buffer_write: buffer %d was never created", (int)which);
+    if (dst_off > b.size || len > b.size - dst_off) return fail(c, AWSM_ERR_OUT_OF_RANGE, "buffer_write: [%zu,+%zu) outside buffer %d of %zu bytes", dst_off, len, (int)which, b.size);
+    if (len == 0) return AWSM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t* dst = (uint8_t*)b.ptr + dst_off;
+    if (len <= (1u << 20)) return upload_small(c, dst, src, len);
+    // large (resize-time) uploads: the runtime stages pageable memory itself; wait so `src` is not retained
+    HIPCHK(c, hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AWSM_OK;
+}
+
+int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msaa) {
+    if (!c || width == 0 || height == 0 || width > 16384 || height > 16384) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "resize: bad size %ux%u", width, height);
+    if (msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "resize: MSAA x%u is not implemented (single-sample only; SURVEY §8f)", msaa);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t px = (size_t)width * height;
+    int rc;
+    if ((rc = dev_realloc(c, c->vis, px * 8, false))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->vis.ptr, 0xFF, px * 8, c->stream));
+    if ((rc = dev_realloc(c, c->out16, px * 8, true))) return rc;
+    if (c->flags & AWSM_CFG_PARITY_TAP) { if ((rc = dev_realloc(c, c->out32, px * 16, true))) return rc; }
+    c->width = width; c->height = height;
+    c->y0 = c->y1 = 0;
+    c->geometry_done = c->opaque_done = false;
+    return AWSM_OK;
+}
+
+int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_rows before resize");
+    if (y0 == 0 && y1 == 0) { c->y0 = c->y1 = 0; return AWSM_OK; }
+    if (y0 >= y1 || y1 > c->height || (y0 % kTile) != 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need 32-aligned y0 < y1 <= height (got %u,%u)", y0, y1);
+    c->y0 = y0; c->y1 = y1;
+    return AWSM_OK;
+}
+
+int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t array_idx, uint32_t width, uint32_t height, uint32_t layers,
+                                  uint32_t mips, AwsmTexFormat fmt, const void* texels) {
+    if (!c || array_idx >= (uint32_t)kMaxTexArrays || !texels || width == 0 || height == 0 || layers == 0)
+        return fail(c, AWSM_ERR_INVALID_ARGUMENT, "texture_array_upload: bad argument");
+    if (fmt != AWSM_TEX_RGBA8_UNORM) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: only RGBA8_UNORM");
+    if (mips > 1) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: mip chains need MipmapMode::Gradient (SURVEY §8f)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)width * height * layers * 4;
+    int rc = dev_realloc(c, c->tex[array_idx], bytes, false);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->tex[array_idx].ptr, texels, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    TexArrayDev& t = c->scene.tex[array_idx];
+    t.texels = (const uint8_t*)c->tex[array_idx].ptr; t.width = width; t.height = height; t.layers = layers;
+    c->scene.n_tex = std::max(c->scene.n_tex, array_idx + 1);
+    c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_sampler_set(AwsmHipCtx* c, uint32_t idx, const AwsmSampler* s) {
+    if (!c || !s || idx >= (uint32_t)kMaxSamplers) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "sampler_set: bad argument");
+    if (s->address_mode_u > 2 || s->address_mode_v > 2 || s->mag_filter > 1) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "sampler_set: bad enum value");
+    c->scene.samplers[idx] = *s;
+    c->scene.n_samplers = std::max(c->scene.n_samplers, idx + 1);
+    c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_env_upload(AwsmHipCtx* c, const AwsmEnv* env) {
+    if (!c || !env) return AWSM_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    memcpy(c->scene.skybox_rgba, env->skybox_rgba, 16);
+    memcpy(c->scene.prefiltered_rgb, env->prefiltered_rgb, 16);
+    memcpy(c->scene.irradiance_rgb, env->irradiance_rgb, 16);
+    if (env->brdf_lut_rgba16f) {
+        if (env->brdf_lut_width == 0 || env->brdf_lut_height == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_upload: LUT size 0");
+        const uint32_t n = env->brdf_lut_width * env->brdf_lut_height;
+        DevBuf tmp;
+        int rc = dev_realloc(c, tmp, (size_t)n * 8, false);
+        if (rc) return rc;
+        if ((rc = dev_realloc(c, c->lut, (size_t)n * 4, false))) { (void)hipFree(tmp.ptr); return rc; }
+        HIPCHK(c, hipMemcpyAsync(tmp.ptr, env->brdf_lut_rgba16f, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        awsm_launch_rgba16f_to_rg16f((const uint16_t*)tmp.ptr, (uint32_t*)c->lut.ptr, n, c->stream);   // only .rg is sampled (brdf.wgsl:301)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(tmp.ptr));
+        c->scene.lut_w = env->brdf_lut_width; c->scene.lut_h = env->brdf_lut_height;
+    }
+    c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_brdf_lut_generate(AwsmHipCtx* c, uint32_t width, uint32_t height) {
+    if (!c || width == 0 || height == 0 || width > 8192 || height > 8192) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "brdf_lut_generate: bad size");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dev_realloc(c, c->lut, (size_t)width * height * 4, false);
+    if (rc) return rc;
+    awsm_launch_brdf_lut((uint32_t*)c->lut.ptr, width, height, c->stream);
+    HIPCHK(c, hipGetLastError());
+    c->scene.lut_w = width; c->scene.lut_h = height;
+    c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_read_brdf_lut(AwsmHipCtx* c, uint16_t* out) {
+    if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->lut.ptr) return fail(c, AWSM_ERR_NOT_READY, "no BRDF LUT");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->lut.ptr, (size_t)c->scene.lut_w * c->scene.lut_h * 4, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
+    if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
+    if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "geometry_pass before resize");
+    static const AwsmBuf need[] = {AWSM_BUF_TRANSFORMS, AWSM_BUF_CAMERA, AWSM_BUF_GEOM_META, AWSM_BUF_VIS_GEOM_DATA};
+    if (n) for (AwsmBuf b : need) if (!c->bufs[b].ptr) return fail(c, AWSM_ERR_NOT_READY, "geometry_pass: buffer %d missing", (int)b);
+    HIPCHK(c, hipSetDevice(c->device));
+
+    c->draws_host.clear(); c->draws_api.assign(draws, draws + n);
+    uint64_t tris = 0, blocks = 0;
+    bool any_morph_skin_checked = false; (void)any_morph_skin_checked;
+    for (uint32_t i = 0; i < n; i++) {
+        const AwsmDraw& d = draws[i];
+        if (d.inst_count != 0 || d.inst_off != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "draw %u: instancing is not implemented (SURVEY §8f)", i);
+        if (d.vis_data_off & 15u) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "draw %u: vis_data_off %u not 16-byte aligned", i, d.vis_data_off);
+        if ((uint64_t)d.vis_data_off + 168ull * d.tri_count > c->bufs[AWSM_BUF_VIS_GEOM_DATA].size)
+            return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: %u triangles at %u exceed the visibility-geometry buffer", i, d.tri_count, d.vis_data_off);
+        if ((uint64_t)d.geom_meta_off + 40 > c->bufs[AWSM_BUF_GEOM_META].size || (d.geom_meta_off & 3u))
+            return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: geometry meta offset %u out of range", i, d.geom_meta_off);
+        if (d.tri_count == 0) continue;   // draw_indexed(0) draws nothing; keeps first_block strictly increasing
+        DrawDev dd{};
+        dd.geom_meta_off = d.geom_meta_off; dd.vis_data_off = d.vis_data_off; dd.tri_count = d.tri_count; dd.flags = d.flags;
+        dd.first_tri = (uint32_t)tris; dd.first_block = (uint32_t)blocks;
+        c->draws_host.push_back(dd);
+        tris += d.tri_count;
+        blocks += (3ull * d.tri_count + 255) / 256;
+        if (tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one pass");
+    }
+    c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
+
+    int rc;
+    const size_t nd = std::max<size_t>(c->draws_host.size(), 1);
+    if ((rc = dev_reserve(c, c->draws_dev, nd * sizeof(DrawDev)))) return rc;
+    if ((rc = dev_reserve(c, c->clip, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
+    if ((rc = dev_reserve(c, c->nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
+    if ((rc = dev_reserve(c, c->tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
+    if ((rc = dev_reserve(c, c->tri_flags, std::max<size_t>(c->total_tris, 1)))) return rc;
+    const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
+    const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
+    if ((rc = dev_reserve(c, c->tile_count, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, c->tile_offset, (n_tiles_full + 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, c->tile_cursor, n_tiles_full * 4))) return rc;
+    if ((rc = ensure_bin_capacity(c, std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
+    if (!c->draws_host.empty()) {
+        const size_t bytes = c->draws_host.size() * sizeof(DrawDev);
+        if (bytes <= (1u << 20)) { if ((rc = upload_small(c, c->draws_dev.ptr, c->draws_host.data(), bytes))) return rc; }
+        else { HIPCHK(c, hipMemcpyAsync(c->draws_dev.ptr, c->draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    }
+    if ((rc = enqueue_geometry(c))) return rc;
+    c->geometry_done = true; c->opaque_done = false;
+    return AWSM_OK;
+}
+
+int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
+    if (!c || !p) return AWSM_ERR_INVALID_ARGUMENT;
+    if (p->mipmap != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "opaque_pass: MipmapMode::Gradient is not implemented (SURVEY §8f)");
+    if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass before resize");
+    if (p->has_opaque) {
+        if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass before geometry_pass");
+        static const AwsmBuf need[] = {AWSM_BUF_CAMERA, AWSM_BUF_GEOM_META, AWSM_BUF_MATERIAL_META, AWSM_BUF_MATERIALS, AWSM_BUF_ATTR_INDEX,
+                                       AWSM_BUF_ATTR_DATA, AWSM_BUF_TEXTURE_TRANSFORMS, AWSM_BUF_LIGHTS_INFO, AWSM_BUF_LIGHTS};
+        for (AwsmBuf b : need) if (!c->bufs[b].ptr) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass: buffer %d missing", (int)b);
+        if (!c->lut.ptr) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass: no BRDF LUT (env_upload or brdf_lut_generate)");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->last_opaque = *p;
+    int rc = enqueue_opaque(c);
+    if (rc) return rc;
+    c->opaque_done = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_frame_flush(AwsmHipCtx* c) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    return AWSM_OK;   // everything is already enqueued on the stream; nothing is batched host-side
+}
+
+int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(c, hipMemcpyAsync(c->counters_host, c->counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->geometry_done || c->counters_host[2] == 0 || attempt >= 4) break;
+        // (triangle, tile) list overflowed: grow to the measured need and replay the frame
+        int rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024);
+        if (rc) return rc;
+        c->overflow_retries++;
+        if ((rc = enqueue_geometry(c))) return rc;
+        if (c->opaque_done && (rc = enqueue_opaque(c))) return rc;
+    }
+    if (c->geometry_done && c->counters_host[2] != 0) return fail(c, AWSM_ERR_DEVICE, "bin list overflow persisted after retries");
+    if (out) {
+        memset(out, 0, sizeof *out);
+        auto ms = [&](int a, int b) { float t = 0.0f; if (c->ev_valid[a] && c->ev_valid[b] && hipEventElapsedTime(&t, c->ev[a], c->ev[b]) == hipSuccess) return t; return 0.0f; };
+        if (c->geometry_done) {
+            out->ms_transform = ms(EV_START, EV_TRANSFORM);
+            out->ms_bin = ms(EV_TRANSFORM, EV_BIN);
+            out->ms_raster = ms(EV_BIN, EV_RASTER);
+        }
+        if (c->opaque_done) out->ms_shade = ms(c->geometry_done ? EV_RASTER : EV_SHADE, EV_SHADE);
+        out->ms_total = ms(c->geometry_done ? EV_START : EV_SHADE, c->opaque_done ? EV_SHADE : EV_RASTER);
+        out->triangles_in = c->total_tris;
+        out->triangles_binned = c->counters_host[0];
+        out->bin_entries = c->counters_host[1];
+        out->covered_pixels = c->counters_host[3];
+        out->bin_overflow_retries = c->overflow_retries;
+    }
+    return AWSM_OK;
+}
+
+int awsm_hip_bind_output(AwsmHipCtx* c, void* device_ptr, size_t bytes) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (device_ptr && bytes < (size_t)c->width * c->height * 8) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_output: %zu bytes < width*height*8", bytes);
+    c->bound_out = device_ptr; c->bound_out_bytes = bytes;
+    return AWSM_OK;
+}
+
+void* awsm_hip_output_device_ptr(AwsmHipCtx* c) { return c ? (c->bound_out ? c->bound_out : c->out16.ptr) : nullptr; }
+
+int awsm_hip_read_visibility(AwsmHipCtx* c, uint64_t* keys_out) {
+    if (!c || !keys_out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(keys_out, c->vis.ptr, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_read_visibility_unpacked(AwsmHipCtx* c, uint32_t* tri_id, uint32_t* meta_off, float* depth) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
+    const size_t n = (size_t)c->width * c->height;
+    std::vector<uint64_t> keys(n);
+    int rc = awsm_hip_read_visibility(c, keys.data());
+    if (rc) return rc;
+    std::vector<uint32_t> meta(c->draws_host.size());
+    for (size_t d = 0; d < c->draws_host.size(); d++)
+        HIPCHK(c, hipMemcpy(&meta[d], (const uint8_t*)c->bufs[AWSM_BUF_GEOM_META].ptr + c->draws_host[d].geom_meta_off + 36, 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        if (keys[i] == ~0ull) {   // cleared texel: 0xFFFF per channel -> join32 == U32_MAX (geometry/render_pass.rs:22-30)
+            if (tri_id) tri_id[i] = 0xFFFFFFFFu;
+            if (meta_off) meta_off[i] = 0xFFFFFFFFu;
+            if (depth) depth[i] = 1.0f;
+            continue;
+        }
+        const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull);
+        size_t lo = 0, hi = c->draws_host.size();
+        while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (c->draws_host[mid].first_tri <= rank) lo = mid; else hi = mid; }
+        if (tri_id) tri_id[i] = rank - c->draws_host[lo].first_tri;
+        if (meta_off) meta_off[i] = meta[lo];
+        if (depth) { uint32_t b = (uint32_t)(keys[i] >> 32); memcpy(&depth[i], &b, 4); }
+    }
+    return AWSM_OK;
+}
+
+int awsm_hip_read_opaque(AwsmHipCtx* c, uint16_t* out) {
+    if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    void* src = awsm_hip_output_device_ptr(c);
+    if (!src) return fail(c, AWSM_ERR_NOT_READY, "read_opaque before resize");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, src, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_read_opaque_f32(AwsmHipCtx* c, float* out) {
+    if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->out32.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_opaque_f32 needs AWSM_CFG_PARITY_TAP and a resize");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->out32.ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_read_transformed(AwsmHipCtx* c, float* clip_out, float* nt_out, uint32_t max_vertices) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "read_transformed before geometry_pass");
+    const uint32_t n = std::min(max_vertices, c->total_verts);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n == 0) return AWSM_OK;
+    if (clip_out) HIPCHK(c, hipMemcpy(clip_out, c->clip.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (nt_out) {
+        std::vector<float> nn((size_t)n * 4), tt((size_t)n * 4);
+        HIPCHK(c, hipMemcpy(nn.data(), c->nrm.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tt.data(), c->tan.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) { memcpy(nt_out + i * 8, &nn[i * 4], 16); memcpy(nt_out + i * 8 + 4, &tt[i * 4], 16); }
+    }
+    return AWSM_OK;
+}
+
+}  // extern "C"

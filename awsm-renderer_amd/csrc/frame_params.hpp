@@ -1,0 +1,70 @@
+// frame_params.hpp — structs shared by the host context (awsm_hip.cpp) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/awsm_hip.h"
+
+namespace awsm {
+
+constexpr int kTile = 32;            // screen tile edge in pixels (one workgroup rasterises one tile out of LDS)
+constexpr int kTileShift = 5;
+constexpr int kMaxTexArrays = 64;
+constexpr int kMaxSamplers = 32;
+
+// One draw as the kernels see it (AwsmDraw + prefix sums computed on the host in draw order).
+struct DrawDev {
+    uint32_t geom_meta_off;
+    uint32_t vis_data_off;
+    uint32_t tri_count;
+    uint32_t flags;
+    uint32_t first_tri;     // global triangle rank of this draw's triangle 0
+    uint32_t first_block;   // first k_deform_transform block of this draw
+    uint32_t pad0, pad1;
+};
+
+struct TexArrayDev {
+    const uint8_t* texels;
+    uint32_t width, height, layers, pad;
+};
+
+struct DevScene {
+    const uint8_t* buf[AWSM_BUF_COUNT];
+    TexArrayDev tex[kMaxTexArrays];
+    AwsmSampler samplers[kMaxSamplers];
+    uint32_t n_tex, n_samplers;
+    float skybox_rgba[4];
+    float prefiltered_rgb[4];
+    float irradiance_rgb[4];
+    const uint16_t* lut_rg16f;
+    uint32_t lut_w, lut_h;
+};
+
+struct FrameDev {
+    uint32_t width, height;
+    uint32_t y0, y1;              // shard rows [y0,y1)
+    uint32_t tiles_x, tiles_y;    // tiles covering the shard: rows [y0>>5, ceil(y1/32))
+    uint32_t tile_row0;           // y0 >> 5
+    uint32_t n_draws;
+    uint32_t total_tris;
+    uint32_t total_verts;
+    uint32_t bin_capacity;        // entries in the (triangle,tile) list
+    uint32_t has_opaque;
+    const DrawDev* draws;
+    // transformed vertices (k_deform_transform outputs)
+    float4* clip;                 // total_verts
+    float4* nrm;                  // total_verts  (world normal xyz, 0)
+    float4* tan;                  // total_verts  (world tangent xyz, handedness)
+    uint8_t* tri_flags;           // total_tris   (AWSM_DRAW_* of the owning draw)
+    // binning
+    uint32_t* tile_count;         // n_tiles
+    uint32_t* tile_offset;        // n_tiles + 1
+    uint32_t* tile_cursor;        // n_tiles
+    uint32_t* bin_list;           // bin_capacity
+    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels
+    // targets
+    unsigned long long* vis;      // width*height packed keys
+    uint16_t* out_rgba16f;        // width*height*4
+    float* out_rgba32f;           // optional parity tap (may be null)
+};
+
+}  // namespace awsm

@@ -1,0 +1,361 @@
+// kernels_geometry.hip — Geometry Pass on gfx950: deform/transform, tile binning, LDS tile rasteriser.
+//
+// Replaces (paths relative to /root/reference/crates/renderer/src/):
+//   render_passes/geometry/shader/geometry_wgsl/vertex.wgsl:36-63     vert_main        -> k_deform_transform
+//   render_passes/shared/shared_wgsl/vertex/apply_vertex.wgsl:24-118  apply_vertex
+//   render_passes/shared/shared_wgsl/vertex/morph.wgsl:4-168, skin.wgsl:7-157
+//   (fixed-function raster, render_passes/geometry/pipeline.rs:337-344)               -> k_bin + k_raster_tile
+//   render_passes/geometry/render_pass.rs:51-157  (clears + one draw per renderable, in order)
+//
+// Design (MI355X-first): the reference issues one draw per mesh; here ALL draws of a frame go through
+// three launches.  Visibility is one packed 64-bit key per pixel, (depth_bits << 32) | ~rank, resolved with
+// ds_min_u64 inside a 32x32 LDS tile that exactly one workgroup owns, so no global atomics touch the
+// image and the tile is written to HBM once, coalesced.
+#include "frame_params.hpp"
+#include "raster_setup.hpp"
+
+namespace awsm {
+
+// Consecutive workgroup ids are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
+// work items so neighbouring tiles (which share triangles) hit the same L2.  Speed only.
+AWSM_DI uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    uint32_t per = (n + 7u) >> 3;
+    return (b & 7u) * per + (b >> 3);
+}
+
+struct GeomMetaDev {
+    uint32_t mesh_key_high, mesh_key_low;
+    uint32_t morph_len, morph_weights_off, morph_values_off;
+    uint32_t skin_sets, skin_matrices_off, skin_index_weights_off;
+    uint32_t transform_off, material_meta_off;
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_deform_transform: one thread per exploded vertex, 256 vertices per workgroup.  The 56-byte vertex
+// records of a workgroup are one contiguous 14 KB run: staged through LDS with 16-byte coalesced loads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[256 * 14];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    uint32_t lo = 0, hi = f.n_draws;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (f.draws[mid].first_block <= b) lo = mid; else hi = mid;
+    }
+    const DrawDev d = f.draws[lo];
+    const uint32_t nverts = 3u * d.tri_count;
+    const uint32_t local0 = (b - d.first_block) * 256u;
+    const uint32_t count = min(256u, nverts - local0);
+
+    const uint8_t* src = sc->buf[AWSM_BUF_VIS_GEOM_DATA] + (size_t)d.vis_data_off + (size_t)local0 * 56u;
+    const uint32_t bytes = count * 56u;
+    const uint32_t n16 = bytes >> 4;
+    const uint4* src16 = reinterpret_cast<const uint4*>(src);
+    uint4* lds16 = reinterpret_cast<uint4*>(lds_vtx);
+    for (uint32_t i = tid; i < n16; i += 256u) lds16[i] = src16[i];
+    const uint32_t tail0 = n16 << 2;          // remaining dwords (0 or 2)
+    if (tid < (bytes >> 2) - tail0) lds_vtx[tail0 + tid] = reinterpret_cast<const uint32_t*>(src)[tail0 + tid];
+    __syncthreads();
+    if (tid >= count) return;
+
+    const uint32_t* gmp = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + d.geom_meta_off);
+    GeomMetaDev gm;
+    gm.morph_len = gmp[2]; gm.morph_weights_off = gmp[3]; gm.morph_values_off = gmp[4];
+    gm.skin_sets = gmp[5]; gm.skin_matrices_off = gmp[6]; gm.skin_index_weights_off = gmp[7];
+    gm.transform_off = gmp[8];
+
+    const uint32_t* v = lds_vtx + tid * 14u;
+    f3 pos = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])};
+    f3 normal = {__uint_as_float(v[6]), __uint_as_float(v[7]), __uint_as_float(v[8])};
+    f4 tangent = {__uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]), __uint_as_float(v[12])};
+    const uint32_t vertex_index = v[13];    // original_vertex_index
+
+    if (gm.morph_len != 0u) {               // morph.wgsl: weights at [off/4 + 1 + i]
+        const float* mw = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_MORPH_WEIGHTS]);
+        const float* mv = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_MORPH_VALUES]);
+        const uint32_t wbase = gm.morph_weights_off / 4u + 1u;
+        const uint32_t vbase = gm.morph_values_off / 4u + vertex_index * (gm.morph_len * 10u);
+        f3 txyz = {tangent.x, tangent.y, tangent.z};
+        for (uint32_t i = 0; i < gm.morph_len; i++) {
+            const float w = mw[wbase + i];
+            const float* dlt = mv + vbase + i * 10u;
+            pos = {pos.x + w * dlt[0], pos.y + w * dlt[1], pos.z + w * dlt[2]};
+            normal = {normal.x + w * dlt[3], normal.y + w * dlt[4], normal.z + w * dlt[5]};
+            txyz = {txyz.x + w * dlt[6], txyz.y + w * dlt[7], txyz.z + w * dlt[8]};
+        }
+        tangent = {txyz.x, txyz.y, txyz.z, tangent.w};
+    }
+    if (gm.skin_sets != 0u) {               // skin.wgsl: M = sum_sets (w0*J0 + w1*J1 + w2*J2 + w3*J3)
+        const float* iw = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_SKIN_INDEX_WEIGHTS]);
+        const float* jm = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_SKIN_MATRICES]);
+        const uint32_t base = gm.skin_index_weights_off / 4u + vertex_index * gm.skin_sets * 8u;
+        const uint32_t moff = gm.skin_matrices_off / 64u;
+        float sk[16];
+        for (uint32_t set = 0; set < gm.skin_sets; set++) {
+            const float4* p = reinterpret_cast<const float4*>(iw + base + set * 8u);   // 32-B records, 16-B aligned
+            const float4 q0 = p[0], q1 = p[1];
+            const uint32_t j0 = __float_as_uint(q0.x), j1 = __float_as_uint(q0.z), j2 = __float_as_uint(q1.x), j3 = __float_as_uint(q1.z);
+            const float w0 = q0.y, w1 = q0.w, w2 = q1.y, w3 = q1.w;
+            const float4* m0 = reinterpret_cast<const float4*>(jm + (size_t)(j0 + moff) * 16u);
+            const float4* m1 = reinterpret_cast<const float4*>(jm + (size_t)(j1 + moff) * 16u);
+            const float4* m2 = reinterpret_cast<const float4*>(jm + (size_t)(j2 + moff) * 16u);
+            const float4* m3 = reinterpret_cast<const float4*>(jm + (size_t)(j3 + moff) * 16u);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float4 a = m0[c], bq = m1[c], cq = m2[c], dq = m3[c];
+                float e0 = ((w0 * a.x + w1 * bq.x) + w2 * cq.x) + w3 * dq.x;
+                float e1 = ((w0 * a.y + w1 * bq.y) + w2 * cq.y) + w3 * dq.y;
+                float e2 = ((w0 * a.z + w1 * bq.z) + w2 * cq.z) + w3 * dq.z;
+                float e3 = ((w0 * a.w + w1 * bq.w) + w2 * cq.w) + w3 * dq.w;
+                if (set == 0) { sk[c * 4 + 0] = e0; sk[c * 4 + 1] = e1; sk[c * 4 + 2] = e2; sk[c * 4 + 3] = e3; }
+                else { sk[c * 4 + 0] += e0; sk[c * 4 + 1] += e1; sk[c * 4 + 2] += e2; sk[c * 4 + 3] += e3; }
+            }
+        }
+        m4 skin;
+#pragma unroll
+        for (int c = 0; c < 4; c++) skin.c[c] = {sk[c * 4], sk[c * 4 + 1], sk[c * 4 + 2], sk[c * 4 + 3]};
+        const f4 p = mul(skin, {pos.x, pos.y, pos.z, 1.0f});
+        pos = {p.x, p.y, p.z};
+        const m3 nm = upper3(skin);        // skin.wgsl:150-156: raw 3x3, no inverse-transpose
+        normal = mul(nm, normal);
+        const f3 t = mul(nm, {tangent.x, tangent.y, tangent.z});
+        tangent = {t.x, t.y, t.z, tangent.w};
+    }
+
+    const m4 model = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TRANSFORMS] + (size_t)(gm.transform_off / 64u) * 64u));
+    const m4 view_proj = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_CAMERA] + 128));
+    const f4 world_pos = mul(model, {pos.x, pos.y, pos.z, 1.0f});
+    const f4 clip = mul(view_proj, world_pos);
+
+    const m3 mm = upper3(model);
+    const f3 c0 = mm.c[0], c1 = mm.c[1], c2 = mm.c[2];
+    const f3 r0 = {c0.x, c1.x, c2.x}, r1 = {c0.y, c1.y, c2.y}, r2 = {c0.z, c1.z, c2.z};
+    const f3 cof0 = cross(r1, r2), cof1 = cross(r2, r0), cof2 = cross(r0, r1);
+    const float det_model = dot(r0, cof0);
+    f3 wn_un;
+    if (fabsf(det_model) > 1e-8f) wn_un = {dot(cof0, normal) / det_model, dot(cof1, normal) / det_model, dot(cof2, normal) / det_model};
+    else wn_un = mul(mm, normal);
+    const f3 world_normal = normalize(wn_un);
+
+    const f3 tangent_raw = mul(mm, {tangent.x, tangent.y, tangent.z});
+    f3 tangent_ortho = tangent_raw - world_normal * dot(tangent_raw, world_normal);
+    const float tlen_sq = dot(tangent_ortho, tangent_ortho);
+    if (tlen_sq > 1e-8f) {
+        tangent_ortho = tangent_ortho * inverse_sqrt(tlen_sq);
+    } else {
+        const f3 axis = (fabsf(world_normal.z) > 0.999f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f);
+        tangent_ortho = normalize(cross(axis, world_normal));
+    }
+
+    const uint32_t lv = local0 + tid;
+    const size_t gv = (size_t)3u * d.first_tri + lv;
+    f.clip[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    f.nrm[gv] = make_float4(world_normal.x, world_normal.y, world_normal.z, 0.0f);
+    f.tan[gv] = make_float4(tangent_ortho.x, tangent_ortho.y, tangent_ortho.z, tangent.w);
+    if (lv % 3u == 0u) f.tri_flags[d.first_tri + lv / 3u] = (uint8_t)d.flags;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bin<FILL>: one thread per triangle.  Pass 1 counts (triangle, tile) pairs per tile, pass 2 (after
+// the scan) writes the triangle ranks into each tile's list.  Triangles covering many tiles are walked
+// by the whole wavefront, 64 tiles per step.
+// ------------------------------------------------------------------------------------------------
+template <bool FILL>
+AWSM_DI void bin_emit(const FrameDev& f, int tx, int ty, uint32_t rank) {
+    const uint32_t idx = (uint32_t)(ty - (int)f.tile_row0) * f.tiles_x + (uint32_t)tx;
+    if (!FILL) {
+        atomicAdd(&f.tile_count[idx], 1u);
+    } else {
+        const uint32_t slot = atomicAdd(&f.tile_cursor[idx], 1u);
+        const uint32_t pos = f.tile_offset[idx] + slot;
+        if (pos < f.bin_capacity) f.bin_list[pos] = rank;
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(FrameDev f) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    TriSetup t;
+    bool ok = false;
+    if (r < f.total_tris) {
+        const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
+        const bool cull_back = (f.tri_flags[r] & AWSM_DRAW_CULL_BACK) != 0;
+        ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, t);
+    }
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (ok) { tx0 = t.minx >> kTileShift; tx1 = t.maxx >> kTileShift; ty0 = t.miny >> kTileShift; ty1 = t.maxy >> kTileShift; }
+    const int wdt = tx1 - tx0 + 1;
+    const int ntiles = ok ? wdt * (ty1 - ty0 + 1) : 0;
+    if (!FILL && ok) atomicAdd(&f.counters[0], 1u);
+
+    const bool big = ntiles > 16;
+    if (ok && !big) {
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++)
+                if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift))
+                    bin_emit<FILL>(f, tx, ty, r);
+    }
+    unsigned long long mask = __ballot(big);
+    const int lane = threadIdx.x & 63;
+    while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        TriSetup s;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { s.a[i] = __shfl(t.a[i], src); s.b[i] = __shfl(t.b[i], src); s.c[i] = __shfl(t.c[i], src); }
+        const int sx0 = __shfl(tx0, src), sy0 = __shfl(ty0, src), swd = __shfl(wdt, src), sn = __shfl(ntiles, src);
+        const uint32_t sr = __shfl(r, src);
+        for (int i = lane; i < sn; i += 64) {
+            const int ty = sy0 + i / swd, tx = sx0 + i % swd;
+            if (tile_may_overlap(s, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift))
+                bin_emit<FILL>(f, tx, ty, sr);
+        }
+    }
+}
+
+// Exclusive scan of tile_count -> tile_offset (single workgroup; n_tiles is a few thousand).
+__global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
+    uint32_t sum = 0;
+    for (uint32_t i = b0; i < b1; i++) sum += f.tile_count[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's chunk
+    for (uint32_t i = b0; i < b1; i++) { f.tile_offset[i] = run; run += f.tile_count[i]; }
+    if (tid == 1023u) {
+        const uint32_t total = part[1023];
+        f.tile_offset[n_tiles] = total;
+        f.counters[1] = total;
+        if (total > f.bin_capacity) f.counters[2] = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_raster_tile: one 256-thread workgroup owns one 32x32 tile whose packed keys live in LDS (8 KB).
+//   - triangles whose bbox inside the tile is <= 16 pixels: the loading thread walks its own pixels;
+//   - everything else goes to an LDS work list that the four wavefronts drain, one triangle per
+//     wavefront at a time, 64 lanes = one 8x8 pixel block per step.
+// Both paths resolve depth + order with ds_min_u64 on the LDS tile.
+// ------------------------------------------------------------------------------------------------
+struct BigTri {
+    float a[3], b[3], c[3];
+    float z[3];
+    float det;
+    uint32_t rank;
+    uint32_t bbox;   // x0 | x1<<8 | y0<<16 | y1<<24, tile-local, inclusive
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
+    __shared__ unsigned long long keys[kTile * kTile];
+    __shared__ BigTri big[256];
+    __shared__ uint32_t big_count;
+
+    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
+    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const uint32_t tid = threadIdx.x;
+    const int tpx = (int)(tile % f.tiles_x) << kTileShift;
+    const int tpy = (int)(tile / f.tiles_x + f.tile_row0) << kTileShift;
+
+#pragma unroll
+    for (int i = 0; i < 4; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
+    const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, f.tile_offset[tile]));
+    const uint32_t off = f.tile_offset[tile];
+    const int lane = tid & 63, wave = tid >> 6;
+
+    for (uint32_t base = 0; base < count; base += 256u) {
+        if (tid == 0) big_count = 0;
+        __syncthreads();
+        const uint32_t idx = base + tid;
+        if (idx < count) {
+            const uint32_t r = f.bin_list[off + idx];
+            const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
+            TriSetup t;
+            // culling already happened in k_bin; setup only normalises orientation here
+            if (tri_setup(v0, v1, v2, false, f.width, f.height, f.y0, f.y1, t)) {
+                const int x0 = max(t.minx, tpx), x1 = min(t.maxx, tpx + kTile - 1);
+                const int y0 = max(t.miny, tpy), y1 = min(t.maxy, tpy + kTile - 1);
+                if (x0 <= x1 && y0 <= y1) {
+                    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+                    if (area <= 16) {
+                        for (int py = y0; py <= y1; py++)
+                            for (int px = x0; px <= x1; px++) {
+                                const unsigned long long k = tri_sample_key(t, px, py, r);
+                                if (k != ~0ull) atomicMin(&keys[(py - tpy) * kTile + (px - tpx)], k);
+                            }
+                    } else {
+                        const uint32_t slot = atomicAdd(&big_count, 1u);
+                        BigTri& g = big[slot];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.z[i] = t.z[i]; }
+                        g.det = t.det; g.rank = r;
+                        g.bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nb = big_count;
+        for (uint32_t j = wave; j < nb; j += 4u) {
+            const BigTri& g = big[j];
+            TriSetup t;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.z[i] = g.z[i]; }
+            t.det = g.det;
+            const uint32_t bb = g.bbox, r = g.rank;
+            const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+            const int lx = lane & 7, ly = lane >> 3;
+            for (int by = y0 & ~7; by <= y1; by += 8)
+                for (int bx = x0 & ~7; bx <= x1; bx += 8) {
+                    const int px = bx + lx, py = by + ly;
+                    if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+                        const unsigned long long k = tri_sample_key(t, tpx + px, tpy + py, r);
+                        if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // tile -> HBM, once, row-major image: each wavefront writes two 32-pixel rows per step (256 B runs)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = (int)tid + i * 256;
+        const int px = tpx + (p & (kTile - 1)), py = tpy + (p >> kTileShift);
+        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) f.vis[(size_t)py * f.width + px] = keys[p];
+    }
+}
+
+}  // namespace awsm
+
+// ---- launch wrappers (called from awsm_hip.cpp) ----
+extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
+    if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform, dim3(n_blocks), dim3(256), 0, s, sc, *f);
+}
+extern "C" void awsm_launch_bin_count(const awsm::FrameDev* f, hipStream_t s) {
+    const uint32_t nb = (f->total_tris + 255u) / 256u;
+    if (nb) hipLaunchKernelGGL(awsm::k_bin<false>, dim3(nb), dim3(256), 0, s, *f);
+}
+extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_bin_scan, dim3(1), dim3(1024), 0, s, *f, f->tiles_x * f->tiles_y);
+}
+extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
+    const uint32_t nb = (f->total_tris + 255u) / 256u;
+    if (nb) hipLaunchKernelGGL(awsm::k_bin<true>, dim3(nb), dim3(256), 0, s, *f);
+}
+extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
+    const uint32_t n_tiles = f->tiles_x * f->tiles_y;
+    const uint32_t nb = ((n_tiles + 7u) / 8u) * 8u;   // xcd_remap needs a multiple of 8
+    if (nb) hipLaunchKernelGGL(awsm::k_raster_tile, dim3(nb), dim3(256), 0, s, *f);
+}

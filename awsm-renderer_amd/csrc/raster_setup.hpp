@@ -1,0 +1,115 @@
+// raster_setup.hpp — triangle setup + per-pixel coverage for the software rasteriser (device side).
+//
+// Replaces WebGPU's fixed-function rasteriser as configured by
+//   crates/renderer/src/render_passes/geometry/pipeline.rs:337-344
+//   (TriangleList, FrontFace::Ccw, CullMode::{None,Back}, depth write, CompareFunction::LessEqual).
+// The raster contract (DESIGN.md §"Raster contract"): homogeneous edge functions in f32, evaluated at
+// pixel centres, top-left rule, per-pixel 0 <= z_ndc <= 1 clip, z_ndc = (e0*z0 + e1*z1 + e2*z2) / det.
+// Used by the binning, raster and shade kernels so that all three see bit-identical edge values.
+#pragma once
+#include "device_math.hpp"
+
+namespace awsm {
+
+struct TriSetup {
+    float a[3], b[3], c[3];   // e_i(X,Y) = (a*X + b*Y) + c ; inside >= 0 ; e_i is the weight of vertex i
+    float z[3];
+    float det;                // > 0 after orientation normalisation
+    int minx, maxx, miny, maxy;   // inclusive, conservative, clamped to the target rect
+};
+
+AWSM_DI bool finite4(float4 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w); }
+
+// Returns false if the triangle cannot produce a fragment (culled, degenerate, outside, empty bbox).
+AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t width, uint32_t height,
+                       uint32_t ry0, uint32_t ry1, TriSetup& t) {
+    if (!finite4(v0) || !finite4(v1) || !finite4(v2)) return false;
+    if (v0.x < -v0.w && v1.x < -v1.w && v2.x < -v2.w) return false;
+    if (v0.x > v0.w && v1.x > v1.w && v2.x > v2.w) return false;
+    if (v0.y < -v0.w && v1.y < -v1.w && v2.y < -v2.w) return false;
+    if (v0.y > v0.w && v1.y > v1.w && v2.y > v2.w) return false;
+    if (v0.z < 0.0f && v1.z < 0.0f && v2.z < 0.0f) return false;
+    if (v0.z > v0.w && v1.z > v1.w && v2.z > v2.w) return false;
+
+    float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
+    float X0 = (v0.x + v0.w) * hw, Y0 = (v0.w - v0.y) * hh, w0 = v0.w;
+    float X1 = (v1.x + v1.w) * hw, Y1 = (v1.w - v1.y) * hh, w1 = v1.w;
+    float X2 = (v2.x + v2.w) * hw, Y2 = (v2.w - v2.y) * hh, w2 = v2.w;
+
+    float a0 = Y1 * w2 - Y2 * w1, b0 = X2 * w1 - X1 * w2, c0 = X1 * Y2 - X2 * Y1;
+    float a1 = Y2 * w0 - Y0 * w2, b1 = X0 * w2 - X2 * w0, c1 = X2 * Y0 - X0 * Y2;
+    float a2 = Y0 * w1 - Y1 * w0, b2 = X1 * w0 - X0 * w1, c2 = X0 * Y1 - X1 * Y0;
+    float det = (X0 * a0 + Y0 * b0) + w0 * c0;
+    if (!(det != 0.0f) || !isfinite(det)) return false;
+    if (cull_back && det > 0.0f) return false;      // y-down framebuffer: det < 0 <=> CCW on screen <=> front
+    if (det < 0.0f) {
+        a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
+        det = -det;
+    }
+    t.a[0] = a0; t.b[0] = b0; t.c[0] = c0;
+    t.a[1] = a1; t.b[1] = b1; t.c[1] = c1;
+    t.a[2] = a2; t.b[2] = b2; t.c[2] = c2;
+    t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
+    t.det = det;
+
+    int minx = 0, maxx = (int)width - 1, miny = (int)ry0, maxy = (int)ry1 - 1;
+    if (w0 > 0.0f && w1 > 0.0f && w2 > 0.0f) {
+        float sx0 = X0 / w0, sx1 = X1 / w1, sx2 = X2 / w2;
+        float sy0 = Y0 / w0, sy1 = Y1 / w1, sy2 = Y2 / w2;
+        float fminx = fminf(fminf(sx0, sx1), sx2), fmaxx = fmaxf(fmaxf(sx0, sx1), sx2);
+        float fminy = fminf(fminf(sy0, sy1), sy2), fmaxy = fmaxf(fmaxf(sy0, sy1), sy2);
+        fminx = fminf(fmaxf(fminx, -16777216.0f), 16777216.0f);
+        fmaxx = fminf(fmaxf(fmaxx, -16777216.0f), 16777216.0f);
+        fminy = fminf(fmaxf(fminy, -16777216.0f), 16777216.0f);
+        fmaxy = fminf(fmaxf(fmaxy, -16777216.0f), 16777216.0f);
+        int bx0 = (int)floorf(fminx) - 1, bx1 = (int)floorf(fmaxx) + 1;
+        int by0 = (int)floorf(fminy) - 1, by1 = (int)floorf(fmaxy) + 1;
+        minx = max(minx, bx0); maxx = min(maxx, bx1);
+        miny = max(miny, by0); maxy = min(maxy, by1);
+    }
+    if (minx > maxx || miny > maxy) return false;
+    t.minx = minx; t.maxx = maxx; t.miny = miny; t.maxy = maxy;
+    return true;
+}
+
+AWSM_DI bool edge_inside(float e, float a, float b) {
+    return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));   // top-left rule
+}
+
+AWSM_DI void tri_edges(const TriSetup& t, int px, int py, float& e0, float& e1, float& e2) {
+    float X = (float)px + 0.5f, Y = (float)py + 0.5f;
+    e0 = (t.a[0] * X + t.b[0] * Y) + t.c[0];
+    e1 = (t.a[1] * X + t.b[1] * Y) + t.c[1];
+    e2 = (t.a[2] * X + t.b[2] * Y) + t.c[2];
+}
+
+// Coverage + depth at a pixel centre.  Returns the packed 64-bit key or ~0 if not covered.
+AWSM_DI unsigned long long tri_sample_key(const TriSetup& t, int px, int py, uint32_t rank) {
+    float e0, e1, e2;
+    tri_edges(t, px, py, e0, e1, e2);
+    if (!edge_inside(e0, t.a[0], t.b[0]) || !edge_inside(e1, t.a[1], t.b[1]) || !edge_inside(e2, t.a[2], t.b[2]))
+        return ~0ull;
+    float zn = ((e0 * t.z[0] + e1 * t.z[1]) + e2 * t.z[2]) / t.det;
+    if (!(zn >= 0.0f && zn <= 1.0f)) return ~0ull;
+    if (zn == 0.0f) zn = 0.0f;   // -0 -> +0 so the bits order as an unsigned integer
+    // depth LessEqual + submission order: smaller depth wins, equal depth -> LATER primitive wins
+    return ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
+}
+
+// Conservative "tile can contain a covered pixel centre" test: evaluates every edge at the tile corner
+// that maximises it.  A half-pixel margin separates the corners from the outermost pixel centres, which
+// dwarfs the rounding error of the evaluation, so no covered pixel is ever rejected.
+AWSM_DI bool tile_may_overlap(const TriSetup& t, int tx0, int ty0, int tx1, int ty1 /* pixel bounds, exclusive max */) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float X = t.a[i] > 0.0f ? (float)tx1 : (float)tx0;
+        float Y = t.b[i] > 0.0f ? (float)ty1 : (float)ty0;
+        float ax = t.a[i] * X, by = t.b[i] * Y;
+        float e = (ax + by) + t.c[i];
+        float slack = 4e-7f * ((fabsf(ax) + fabsf(by)) + fabsf(t.c[i]));   // > 3 ulp of the largest term
+        if (e < -slack) return false;
+    }
+    return true;
+}
+
+}  // namespace awsm

@@ -1,0 +1,263 @@
+"""
+hip_backend.py — thin ctypes binding of libawsm_hip.so (include/awsm_hip.h).  No fallback: if the HIP library
+is missing or fails to load, importing callers get an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import PACKAGE_DIR
+
+LIB_PATH = os.path.join(PACKAGE_DIR, "libawsm_hip.so")
+BUF_COUNT = 18
+AWSM_CFG_PARITY_TAP = 1
+
+BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", "CAMERA", "SKIN_MATRICES", "SKIN_INDEX_WEIGHTS",
+             "MORPH_WEIGHTS", "MORPH_VALUES", "GEOM_META", "MATERIAL_META", "VIS_GEOM_DATA", "VIS_GEOM_INDEX", "ATTR_DATA", "ATTR_INDEX",
+             "TEXTURE_TRANSFORMS", "INSTANCES"]
+
+# every symbol include/awsm_hip.h declares (tests/test_abi_symbols.py checks the header against this list too)
+EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
+           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_texture_array_upload", "awsm_hip_sampler_set",
+           "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
+           "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
+           "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
+           "awsm_hip_device_info"]
+
+
+class AwsmConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class AwsmDraw(C.Structure):
+    _fields_ = [("geom_meta_off", C.c_uint32), ("vis_data_off", C.c_uint32), ("tri_count", C.c_uint32), ("flags", C.c_uint32),
+                ("inst_off", C.c_uint32), ("inst_count", C.c_uint32)]
+
+
+class AwsmOpaqueParams(C.Structure):
+    _fields_ = [("mipmap", C.c_uint32), ("has_opaque", C.c_uint32)]
+
+
+class AwsmSampler(C.Structure):
+    _fields_ = [("address_mode_u", C.c_uint32), ("address_mode_v", C.c_uint32), ("mag_filter", C.c_uint32), ("min_filter", C.c_uint32),
+                ("mipmap_filter", C.c_uint32), ("max_anisotropy", C.c_uint32)]
+
+
+class AwsmEnv(C.Structure):
+    _fields_ = [("skybox_rgba", C.c_float * 4), ("prefiltered_rgb", C.c_float * 4), ("irradiance_rgb", C.c_float * 4),
+                ("brdf_lut_width", C.c_uint32), ("brdf_lut_height", C.c_uint32), ("brdf_lut_rgba16f", C.c_void_p)]
+
+
+class AwsmFrameStats(C.Structure):
+    _fields_ = [("ms_transform", C.c_float), ("ms_bin", C.c_float), ("ms_raster", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
+                ("triangles_in", C.c_uint32), ("triangles_binned", C.c_uint32), ("bin_entries", C.c_uint32), ("covered_pixels", C.c_uint32),
+                ("bin_overflow_retries", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class AwsmHipError(RuntimeError):
+    def __init__(self, code: int, where: str, text: str):
+        super().__init__(f"{where} failed with status {code}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libawsm_hip.so.  Raises if it is missing — there is no CPU fallback for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950); awsm-renderer_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.awsm_hip_last_error.restype = C.c_char_p
+    lib.awsm_hip_last_error.argtypes = [C.c_void_p]
+    lib.awsm_hip_abi_version.restype = C.c_uint32
+    lib.awsm_hip_output_device_ptr.restype = C.c_void_p
+    lib.awsm_hip_output_device_ptr.argtypes = [C.c_void_p]
+    lib.awsm_hip_buffer_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    lib.awsm_hip_buffer_write.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.awsm_hip_bind_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.awsm_hip_geometry_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.awsm_hip_opaque_pass.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_frame_end.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_frame_flush.argtypes = [C.c_void_p]
+    lib.awsm_hip_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.awsm_hip_set_shard_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.awsm_hip_texture_array_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    lib.awsm_hip_sampler_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.awsm_hip_env_upload.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_brdf_lut_generate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.awsm_hip_read_brdf_lut.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_read_visibility.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_read_visibility_unpacked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.awsm_hip_read_opaque.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_read_opaque_f32.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_read_transformed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.awsm_hip_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.awsm_hip_destroy.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class HipDevice:
+    """One AwsmHipCtx: one HIP device + stream."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False):
+        self.lib = load_library()
+        cfg = AwsmConfig(C.sizeof(AwsmConfig), self.lib.awsm_hip_abi_version(), device, AWSM_CFG_PARITY_TAP if parity_tap else 0, stream)
+        ctx = C.c_void_p()
+        rc = self.lib.awsm_hip_create(C.byref(cfg), C.byref(ctx))
+        if rc != 0:
+            raise AwsmHipError(rc, "awsm_hip_create", "no usable gfx950 device" if rc == -4 else "see status code")
+        self.ctx = ctx
+        self.width = self.height = 0
+        self.lut_size = (0, 0)
+
+    def _chk(self, rc: int, where: str):
+        if rc != 0:
+            raise AwsmHipError(rc, where, (self.lib.awsm_hip_last_error(self.ctx) or b"").decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.awsm_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- buffers ----
+    def buffer_create(self, which: int, nbytes: int):
+        self._chk(self.lib.awsm_hip_buffer_create(self.ctx, which, nbytes), f"buffer_create({BUF_NAMES[which]})")
+
+    def buffer_write(self, which: int, offset: int, data):
+        arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        self._chk(self.lib.awsm_hip_buffer_write(self.ctx, which, offset, arr.ctypes.data_as(C.c_void_p), arr.nbytes), f"buffer_write({BUF_NAMES[which]})")
+
+    def upload_mirrors(self, mirrors: Dict[int, bytes]):
+        """create + full write of every mirror (what the reference does on the first frame / after a resize)."""
+        for which, data in mirrors.items():
+            n = (len(data) + 3) & ~3
+            self.buffer_create(which, n)
+            if len(data):
+                self.buffer_write(which, 0, np.frombuffer(bytes(data) + bytes(n - len(data)), dtype=np.uint8))
+
+    # ---- targets / environment ----
+    def resize(self, width: int, height: int, msaa: int = 0):
+        self._chk(self.lib.awsm_hip_resize(self.ctx, width, height, msaa), "resize")
+        self.width, self.height = width, height
+
+    def set_shard_rows(self, y0: int, y1: int):
+        self._chk(self.lib.awsm_hip_set_shard_rows(self.ctx, y0, y1), "set_shard_rows")
+
+    def texture_array_upload(self, index: int, texels: np.ndarray):
+        layers, h, w, _ = texels.shape
+        t = np.ascontiguousarray(texels, dtype=np.uint8)
+        self._chk(self.lib.awsm_hip_texture_array_upload(self.ctx, index, w, h, layers, 1, 0, t.ctypes.data_as(C.c_void_p)), "texture_array_upload")
+
+    def sampler_set(self, index: int, s: dict):
+        smp = AwsmSampler(s.get("address_mode_u", 1), s.get("address_mode_v", 1), s.get("mag_filter", 1), s.get("min_filter", 1),
+                          s.get("mipmap_filter", 1), s.get("max_anisotropy", 1))
+        self._chk(self.lib.awsm_hip_sampler_set(self.ctx, index, C.byref(smp)), "sampler_set")
+
+    def env_upload(self, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), lut_rgba16f: Optional[np.ndarray] = None):
+        env = AwsmEnv()
+        for i in range(4):
+            env.skybox_rgba[i] = skybox[i]
+        for i in range(3):
+            env.prefiltered_rgb[i] = prefiltered[i]
+            env.irradiance_rgb[i] = irradiance[i]
+        keep = None
+        if lut_rgba16f is not None:
+            keep = np.ascontiguousarray(lut_rgba16f, dtype=np.uint16)
+            env.brdf_lut_height, env.brdf_lut_width = keep.shape[0], keep.shape[1]
+            env.brdf_lut_rgba16f = keep.ctypes.data
+            self.lut_size = (keep.shape[1], keep.shape[0])
+        self._chk(self.lib.awsm_hip_env_upload(self.ctx, C.byref(env)), "env_upload")
+
+    def brdf_lut_generate(self, width: int, height: int):
+        self._chk(self.lib.awsm_hip_brdf_lut_generate(self.ctx, width, height), "brdf_lut_generate")
+        self.lut_size = (width, height)
+
+    def read_brdf_lut(self) -> np.ndarray:
+        w, h = self.lut_size
+        out = np.zeros((h, w, 2), dtype=np.uint16)
+        self._chk(self.lib.awsm_hip_read_brdf_lut(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_brdf_lut")
+        return out
+
+    # ---- passes ----
+    @staticmethod
+    def make_draws(draws: Sequence[dict]):
+        arr = (AwsmDraw * max(1, len(draws)))()
+        for i, d in enumerate(draws):
+            arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], 0, 0)
+        return arr
+
+    def geometry_pass(self, draws, n: Optional[int] = None):
+        if not isinstance(draws, C.Array):
+            n = len(draws)
+            draws = self.make_draws(draws)
+        self._chk(self.lib.awsm_hip_geometry_pass(self.ctx, draws, n if n is not None else len(draws)), "geometry_pass")
+
+    def opaque_pass(self, has_opaque: bool = True, mipmap: int = 0):
+        p = AwsmOpaqueParams(mipmap, 1 if has_opaque else 0)
+        self._chk(self.lib.awsm_hip_opaque_pass(self.ctx, C.byref(p)), "opaque_pass")
+
+    def frame_end(self) -> dict:
+        st = AwsmFrameStats()
+        self._chk(self.lib.awsm_hip_frame_end(self.ctx, C.byref(st)), "frame_end")
+        return st.as_dict()
+
+    def bind_output(self, device_ptr: Optional[int], nbytes: int = 0):
+        self._chk(self.lib.awsm_hip_bind_output(self.ctx, device_ptr, nbytes), "bind_output")
+
+    def output_device_ptr(self) -> int:
+        return self.lib.awsm_hip_output_device_ptr(self.ctx)
+
+    # ---- readback ----
+    def read_visibility(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width), dtype=np.uint64)
+        self._chk(self.lib.awsm_hip_read_visibility(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_visibility")
+        return out
+
+    def read_visibility_unpacked(self):
+        tri = np.zeros((self.height, self.width), dtype=np.uint32)
+        meta = np.zeros((self.height, self.width), dtype=np.uint32)
+        depth = np.zeros((self.height, self.width), dtype=np.float32)
+        self._chk(self.lib.awsm_hip_read_visibility_unpacked(self.ctx, tri.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
+                                                             depth.ctypes.data_as(C.c_void_p)), "read_visibility_unpacked")
+        return tri, meta, depth
+
+    def read_opaque(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint16)
+        self._chk(self.lib.awsm_hip_read_opaque(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_opaque")
+        return out
+
+    def read_opaque_f32(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._chk(self.lib.awsm_hip_read_opaque_f32(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_opaque_f32")
+        return out
+
+    def read_transformed(self, n_vertices: int):
+        clip = np.zeros((max(1, n_vertices), 4), dtype=np.float32)
+        nt = np.zeros((max(1, n_vertices), 8), dtype=np.float32)
+        self._chk(self.lib.awsm_hip_read_transformed(self.ctx, clip.ctypes.data_as(C.c_void_p), nt.ctypes.data_as(C.c_void_p), n_vertices), "read_transformed")
+        return clip, nt
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_uint32(), C.c_uint64()
+        self._chk(self.lib.awsm_hip_device_info(self.ctx, name, 256, C.byref(cus), C.byref(mem)), "device_info")
+        return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": mem.value}

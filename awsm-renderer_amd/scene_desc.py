@@ -1,0 +1,102 @@
+"""
+scene_desc.py — the scene description the synthetic-scene generators produce and the host layer consumes.
+
+It plays the role of the reference's `GltfData` after `GltfLoader::into_data` (crates/renderer/src/gltf/data.rs):
+decoded accessors per primitive, node TRS tree, skins, materials, decoded RGBA8 images.  No glTF files exist in
+this environment (SURVEY.md §7 "Assets"), so scenes are generated in-repo (scenes.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+
+@dataclass
+class TextureRef:
+    texture: int                     # index into SceneDesc.textures
+    sampler: int = 0                 # index into SceneDesc.samplers
+    uv_index: int = 0
+    transform: Optional[dict] = None  # {offset, origin, rotation, scale} -> TextureTransform
+
+
+@dataclass
+class MaterialDesc:
+    kind: str = "pbr"                # "pbr" | "unlit"
+    base_color_factor: Tuple[float, float, float, float] = (1, 1, 1, 1)
+    metallic_factor: float = 1.0
+    roughness_factor: float = 1.0
+    normal_scale: float = 1.0
+    occlusion_strength: float = 1.0
+    emissive_factor: Tuple[float, float, float] = (0, 0, 0)
+    base_color_tex: Optional[TextureRef] = None
+    metallic_roughness_tex: Optional[TextureRef] = None
+    normal_tex: Optional[TextureRef] = None
+    occlusion_tex: Optional[TextureRef] = None
+    emissive_tex: Optional[TextureRef] = None
+    double_sided: bool = False
+    debug_bitmask: int = 0
+    vertex_color_set: Optional[int] = None
+    emissive_strength: Optional[float] = None
+    ior: Optional[float] = None
+    specular: Optional[dict] = None       # {tex, factor, color_tex, color_factor}
+    transmission: Optional[dict] = None   # never reaches the opaque pass when factor > 0 (routed to transparency)
+    volume: Optional[dict] = None         # {thickness_tex, thickness_factor, attenuation_distance, attenuation_color}
+    clearcoat: Optional[dict] = None      # {tex, factor, roughness_tex, roughness_factor, normal_tex, normal_scale}
+    sheen: Optional[dict] = None          # {roughness_tex, roughness_factor, color_tex, color_factor}
+
+
+@dataclass
+class PrimitiveDesc:
+    positions: np.ndarray            # (V,3) f32
+    normals: np.ndarray              # (V,3) f32
+    indices: np.ndarray              # (T,3) u32
+    material: int = 0
+    tangents: Optional[np.ndarray] = None    # (V,4) f32
+    uvs: List[np.ndarray] = field(default_factory=list)      # each (V,2) f32
+    colors: List[np.ndarray] = field(default_factory=list)   # each (V,4) f32
+    joints: List[np.ndarray] = field(default_factory=list)   # per set (V,4) u32
+    weights: List[np.ndarray] = field(default_factory=list)  # per set (V,4) f32
+    morph_targets: List[dict] = field(default_factory=list)  # {positions?, normals?, tangents?} each (V,3) f32
+    morph_weights: Optional[np.ndarray] = None               # (targets,) f32  (glTF mesh.weights)
+    animated_morph_weights: Optional[np.ndarray] = None      # written through the animation path ([1..n+1))
+
+
+@dataclass
+class NodeDesc:
+    translation: Tuple[float, float, float] = (0, 0, 0)
+    rotation: Tuple[float, float, float, float] = (0, 0, 0, 1)   # xyzw
+    scale: Tuple[float, float, float] = (1, 1, 1)
+    parent: Optional[int] = None
+    primitives: List[PrimitiveDesc] = field(default_factory=list)
+    skin: Optional[int] = None
+
+
+@dataclass
+class SkinDesc:
+    joints: List[int]                # node indices
+    inverse_bind: np.ndarray         # (J,4,4) f32, [j][col][row]
+
+
+@dataclass
+class SceneDesc:
+    nodes: List[NodeDesc]
+    materials: List[MaterialDesc]
+    textures: List[np.ndarray] = field(default_factory=list)   # (h,w,4) u8, already linear-converted where sRGB
+    samplers: List[dict] = field(default_factory=list)         # AwsmSampler fields
+    skins: List[SkinDesc] = field(default_factory=list)
+    lights: List[dict] = field(default_factory=list)           # {kind, color, intensity, direction/position/...}
+    width: int = 640
+    height: int = 360
+    view: np.ndarray = None          # (4,4) f32 [col][row]
+    proj: np.ndarray = None
+    camera_position: Tuple[float, float, float] = (0, 0, 0)
+    skybox_rgba: Tuple[float, float, float, float] = (0, 0, 0, 1)
+    prefiltered_rgb: Tuple[float, float, float] = (1, 1, 1)
+    irradiance_rgb: Tuple[float, float, float] = (1, 1, 1)
+    prefiltered_mip_count: int = 9   # 256^2 cube with a full chain
+    irradiance_mip_count: int = 9
+    lut_size: int = 64
+
+

@@ -1,0 +1,214 @@
+/*
+ * awsm_hip.h — C-ABI drop-in boundary for awsm-renderer's per-frame hot path on MI355X (gfx950).
+ *
+ * The reference (dakom/awsm-renderer, Rust -> wasm32 -> browser WebGPU) has no FFI/plugin interface;
+ * its device seam is the Rust type `AwsmRendererWebGpu` (crates/renderer-core/src/renderer.rs:36-41)
+ * and the ~10 methods the hot path calls on it.  Every entry point below replaces one of those call
+ * sites for the Geometry Pass + Opaque Pass only.  Reference paths are relative to
+ * /root/reference/.
+ *
+ * Conventions
+ *   - plain C: opaque context pointer, plain pointers + sizes, no C++/torch types.
+ *   - every function returns 0 (AWSM_OK) or a negative AwsmStatus; never aborts.  The text of the
+ *     last failure on a context is available from awsm_hip_last_error().
+ *     (reference: Result<_, AwsmCoreError>, crates/renderer-core/src/error.rs)
+ *   - thread-compatible, not thread-safe: one ctx <-> one host thread <-> one HIP device + stream
+ *     (the reference is single-threaded wasm).
+ *   - no pointer handed across the boundary is retained after the call returns, except the
+ *     optional externally-owned output image (awsm_hip_bind_output).
+ *   - all byte offsets/sizes given to awsm_hip_buffer_write must be 4-byte aligned
+ *     (crates/renderer/src/buffer/dynamic_storage.rs:196-211).
+ */
+#ifndef AWSM_HIP_H
+#define AWSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWSM_HIP_ABI_VERSION 1u
+
+typedef struct AwsmHipCtx AwsmHipCtx;
+
+typedef enum AwsmStatus {
+    AWSM_OK = 0,
+    AWSM_ERR_INVALID_ARGUMENT = -1,
+    AWSM_ERR_OUT_OF_MEMORY = -2,
+    AWSM_ERR_DEVICE = -3,          /* a HIP runtime call failed (text in last_error) */
+    AWSM_ERR_NO_DEVICE = -4,       /* no gfx950 device visible */
+    AWSM_ERR_NOT_READY = -5,       /* a required buffer / size / env was never provided */
+    AWSM_ERR_UNSUPPORTED = -6,     /* MSAA, gradient mip sampling, texel cubemaps: SURVEY §8f "next" */
+    AWSM_ERR_OUT_OF_RANGE = -7     /* an offset/size points outside the destination buffer */
+} AwsmStatus;
+
+/* Device buffers, one per CPU mirror the reference uploads.
+ * The record layout of each is exactly the reference's; file:line of the writer is given. */
+typedef enum AwsmBuf {
+    AWSM_BUF_TRANSFORMS = 0,        /* mat4 col-major, stride 64          crates/renderer/src/transforms.rs:68-72,396-410 */
+    AWSM_BUF_NORMAL_MATS = 1,       /* mat3, stride 36 (uploaded, unread) crates/renderer/src/transforms.rs:412-422 */
+    AWSM_BUF_MATERIALS = 2,         /* u32 word stream per material       crates/renderer/src/materials/pbr.rs:258-589 */
+    AWSM_BUF_LIGHTS = 3,            /* 64 B / light, dense                crates/renderer/src/lights.rs:354-473 */
+    AWSM_BUF_LIGHTS_INFO = 4,       /* 16 B                                crates/renderer/src/lights.rs:293-305 */
+    AWSM_BUF_CAMERA = 5,            /* 512 B                               crates/renderer/src/camera.rs:72-87,169-219 */
+    AWSM_BUF_SKIN_MATRICES = 6,     /* mat4 / joint                        crates/renderer/src/meshes/skins.rs:162-194 */
+    AWSM_BUF_SKIN_INDEX_WEIGHTS = 7,/* {u32 joint,f32 weight}x4 / set / vertex  crates/renderer/src/gltf/buffers/skin.rs:22-113 */
+    AWSM_BUF_MORPH_WEIGHTS = 8,     /* f32 / target (+1 quirk)             crates/renderer/src/meshes/morphs.rs:148-217 */
+    AWSM_BUF_MORPH_VALUES = 9,      /* 10 f32 / target / vertex            crates/renderer/src/gltf/buffers/morph.rs:31-190 */
+    AWSM_BUF_GEOM_META = 10,        /* 40 B in 256-B slots                 crates/renderer/src/meshes/meta/geometry_meta.rs:44-113 */
+    AWSM_BUF_MATERIAL_META = 11,    /* 68 B in 256-B slots                 crates/renderer/src/meshes/meta/material_meta.rs:96-185 */
+    AWSM_BUF_VIS_GEOM_DATA = 12,    /* 56 B / exploded vertex              crates/renderer/src/gltf/buffers/mesh/visibility.rs:35-165 */
+    AWSM_BUF_VIS_GEOM_INDEX = 13,   /* identity u32 (accepted, unread: redundant for a SW rasteriser) crates/renderer/src/meshes.rs:514-520 */
+    AWSM_BUF_ATTR_DATA = 14,        /* interleaved f32 custom attributes   crates/renderer/src/gltf/buffers/attributes.rs:113-160 */
+    AWSM_BUF_ATTR_INDEX = 15,       /* 3 x u32 / triangle                  crates/renderer/src/meshes.rs:434-446 */
+    AWSM_BUF_TEXTURE_TRANSFORMS = 16,/* 32 B records                       crates/renderer/src/textures.rs:247-284 */
+    AWSM_BUF_INSTANCES = 17,        /* mat4 / instance (accepted, unread: instancing is SURVEY §8f "next") */
+    AWSM_BUF_COUNT = 18
+} AwsmBuf;
+
+/* Replaces AwsmRendererBuilder::build() (crates/renderer/src/lib.rs:213-259) for the two passes. */
+typedef struct AwsmConfig {
+    uint32_t struct_size;   /* sizeof(AwsmConfig), for forward compatibility */
+    uint32_t abi_version;   /* AWSM_HIP_ABI_VERSION */
+    int32_t  device;        /* HIP device ordinal */
+    uint32_t flags;         /* AWSM_CFG_* */
+    void*    stream;        /* hipStream_t to run on; NULL = the library creates its own */
+} AwsmConfig;
+#define AWSM_CFG_PARITY_TAP 1u   /* also keep the shaded RGBA in f32 (readable via awsm_hip_read_opaque_f32) */
+
+/* One geometry-pass draw == Mesh::push_geometry_pass_commands (crates/renderer/src/meshes/mesh.rs:70-126):
+ * set_bind_group(2, meta, [geom_meta_off]); set_vertex_buffer(0, vis_data, vis_data_off);
+ * draw_indexed(3*tri_count); cull mode from the pipeline key (mesh.rs:54-67).
+ * Order of the array == the reference's sorted renderable order (crates/renderer/src/renderable.rs:38-150). */
+typedef struct AwsmDraw {
+    uint32_t geom_meta_off;   /* byte offset of the 256-B GeometryMeshMeta slot */
+    uint32_t vis_data_off;    /* byte offset of the first exploded vertex in AWSM_BUF_VIS_GEOM_DATA */
+    uint32_t tri_count;
+    uint32_t flags;           /* AWSM_DRAW_* */
+    uint32_t inst_off;        /* instancing: reserved, must be 0 */
+    uint32_t inst_count;      /* instancing: reserved, must be 0 */
+} AwsmDraw;
+#define AWSM_DRAW_CULL_BACK 1u   /* CullMode::Back (single-sided); 0 = CullMode::None */
+
+/* MaterialOpaqueRenderPass::render (crates/renderer/src/render_passes/material_opaque/render_pass.rs:47-96). */
+typedef struct AwsmOpaqueParams {
+    uint32_t mipmap;        /* MipmapMode: 0 = None (textureSampleLevel 0). 1 = Gradient -> AWSM_ERR_UNSUPPORTED */
+    uint32_t has_opaque;    /* 0 -> the "empty" pipeline: skybox only (render_pass.rs:64-71) */
+} AwsmOpaqueParams;
+
+typedef enum AwsmTexFormat { AWSM_TEX_RGBA8_UNORM = 0 } AwsmTexFormat;
+
+/* GPUSamplerDescriptor subset used by the texture pool (crates/renderer/src/materials/writer.rs:53-63). */
+typedef struct AwsmSampler {
+    uint32_t address_mode_u;  /* 0 clamp-to-edge, 1 repeat, 2 mirror-repeat */
+    uint32_t address_mode_v;
+    uint32_t mag_filter;      /* 0 nearest, 1 linear (level-0 sampling uses the mag filter) */
+    uint32_t min_filter;
+    uint32_t mipmap_filter;
+    uint32_t max_anisotropy;  /* accepted, unused while mipmap == None */
+} AwsmSampler;
+
+/* Environment: skybox + IBL cubes + BRDF LUT (opaque bind group 0, bindings 14-21:
+ * crates/renderer/src/render_passes/material_opaque/shader/material_opaque_wgsl/bind_groups.wgsl:22-29).
+ * Round 1 supports uniform-colour cubes (what AwsmRendererBuilder creates by default,
+ * crates/renderer/src/lib.rs:176-207); texel cubemaps return AWSM_ERR_UNSUPPORTED. */
+typedef struct AwsmEnv {
+    float skybox_rgba[4];
+    float prefiltered_rgb[4];
+    float irradiance_rgb[4];
+    uint32_t brdf_lut_width, brdf_lut_height;
+    const uint16_t* brdf_lut_rgba16f;  /* width*height*4 halfs, row 0 first; NULL = keep the current LUT */
+} AwsmEnv;
+
+typedef struct AwsmFrameStats {
+    float ms_transform;   /* k_deform_transform */
+    float ms_bin;         /* k_bin_count + scan + k_bin_fill */
+    float ms_raster;      /* k_raster_tile */
+    float ms_shade;       /* k_shade */
+    float ms_total;       /* first kernel start -> last kernel end */
+    uint32_t triangles_in;      /* sum of tri_count over draws */
+    uint32_t triangles_binned;  /* survived cull */
+    uint32_t bin_entries;       /* (triangle, tile) pairs */
+    uint32_t covered_pixels;    /* pixels with a hit (inside the shard rect) */
+    uint32_t bin_overflow_retries;
+    uint32_t reserved[3];
+} AwsmFrameStats;
+
+/* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */
+int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out);
+int awsm_hip_destroy(AwsmHipCtx* ctx);
+const char* awsm_hip_last_error(const AwsmHipCtx* ctx);
+uint32_t awsm_hip_abi_version(void);
+
+/* ---- gpu.create_buffer(desc{size,..}) (crates/renderer-core/src/methods.rs:239; callers e.g.
+ * crates/renderer/src/meshes.rs:1313-1322): the new buffer replaces the old wholesale, contents are NOT
+ * preserved — the host re-uploads the full mirror right after.  Idempotent for an unchanged size. ---- */
+int awsm_hip_buffer_create(AwsmHipCtx* ctx, AwsmBuf which, size_t bytes);
+
+/* ---- gpu.write_buffer(buf, Some(offset), &raw[off..off+len]) (crates/renderer-core/src/methods.rs:339-431,
+ * via write_buffer_with_dirty_ranges, crates/renderer/src/buffer/helpers.rs:170-193).  Ordered before the
+ * next pass on the ctx stream; `src` is copied to a pinned staging ring before the call returns. ---- */
+int awsm_hip_buffer_write(AwsmHipCtx* ctx, AwsmBuf which, size_t dst_off, const void* src, size_t len);
+
+/* ---- render_textures.views() realloc on size/AA change (crates/renderer/src/render_textures.rs:103-147).
+ * msaa: 0 = single sample; 4 -> AWSM_ERR_UNSUPPORTED this round. ---- */
+int awsm_hip_resize(AwsmHipCtx* ctx, uint32_t width, uint32_t height, uint32_t msaa);
+
+/* ---- multi-GPU screen sharding (new; no reference counterpart): this ctx rasterises and shades only
+ * pixel rows [y0, y1) (full width).  y0 == y1 == 0 restores the full frame.  y0 must be tile aligned (32). ---- */
+int awsm_hip_set_shard_rows(AwsmHipCtx* ctx, uint32_t y0, uint32_t y1);
+
+/* ---- texture pool bind (crates/renderer/src/render_passes/material_opaque/bind_group.rs:331-360):
+ * array `array_idx` is a texture_2d_array of `layers` w x h images; texels = layers*h*w*4 bytes, layer-major. ---- */
+int awsm_hip_texture_array_upload(AwsmHipCtx* ctx, uint32_t array_idx, uint32_t width, uint32_t height,
+                                  uint32_t layers, uint32_t mips, AwsmTexFormat fmt, const void* texels);
+int awsm_hip_sampler_set(AwsmHipCtx* ctx, uint32_t sampler_idx, const AwsmSampler* sampler);
+int awsm_hip_env_upload(AwsmHipCtx* ctx, const AwsmEnv* env);
+
+/* ---- BrdfLut::new (crates/renderer-core/src/brdf_lut/generate.rs:47-96 + shader.wgsl): renders the
+ * split-sum LUT on the device into the ctx's LUT slot (RGBA16F semantics, RG kept). ---- */
+int awsm_hip_brdf_lut_generate(AwsmHipCtx* ctx, uint32_t width, uint32_t height);
+int awsm_hip_read_brdf_lut(AwsmHipCtx* ctx, uint16_t* rg16f_out /* width*height*2 halfs */);
+
+/* ---- GeometryRenderPass::render (crates/renderer/src/render_passes/geometry/render_pass.rs:51-157):
+ * clear (vis = "no hit", depth = 1.0) + one draw per entry, depth LessEqual, later primitive wins ties. ---- */
+int awsm_hip_geometry_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
+
+/* ---- render_textures.clear_opaque() + MaterialOpaqueRenderPass::render
+ * (crates/renderer/src/render.rs:209,219-221): one dispatch over the screen. ---- */
+int awsm_hip_opaque_pass(AwsmHipCtx* ctx, const AwsmOpaqueParams* params);
+
+/* ---- gpu.submit_commands(encoder.finish()) (crates/renderer/src/render.rs:370): waits for the frame,
+ * fills per-kernel times.  `out` may be NULL. ---- */
+int awsm_hip_frame_end(AwsmHipCtx* ctx, AwsmFrameStats* out);
+
+/* ---- frame loop without a host sync (bench / multi-frame pipelines): enqueue only. ---- */
+int awsm_hip_frame_flush(AwsmHipCtx* ctx);
+
+/* ---- output image: RGBA16F, row-major, width*height*8 bytes == the reference's `opaque` render
+ * texture (crates/renderer/src/render_textures.rs:49-54).  bind_output lets the caller own the memory
+ * (e.g. a torch tensor that RCCL all-gathers); NULL returns to the internal image. ---- */
+int awsm_hip_bind_output(AwsmHipCtx* ctx, void* device_ptr, size_t bytes);
+void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
+
+/* ---- readback for parity (new).  keys: width*height u64 = (depth_f32_bits << 32) | (0xFFFFFFFF - rank),
+ * rank = index of the triangle in draw order over the whole draw list; all ones = no hit.
+ * unpack gives the reference's visibility_data texel: triangle_index (primitive-local) and
+ * material_mesh_meta_offset, plus the Depth32Float value. ---- */
+int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
+int awsm_hip_read_visibility_unpacked(AwsmHipCtx* ctx, uint32_t* tri_id_out, uint32_t* meta_off_out, float* depth_out);
+int awsm_hip_read_opaque(AwsmHipCtx* ctx, uint16_t* rgba16f_out);
+int awsm_hip_read_opaque_f32(AwsmHipCtx* ctx, float* rgba32f_out);  /* needs AWSM_CFG_PARITY_TAP */
+/* transformed vertices of the last geometry pass: per exploded vertex clip xyzw (16 B) and
+ * {world N xyz, pad, world T xyzw} (32 B) == vert_main outputs (geometry_wgsl/vertex.wgsl:36-63). */
+int awsm_hip_read_transformed(AwsmHipCtx* ctx, float* clip_out, float* normal_tangent_out, uint32_t max_vertices);
+
+/* ---- device information for the measurement harness ---- */
+int awsm_hip_device_info(AwsmHipCtx* ctx, char* name_out, size_t name_cap, uint32_t* cu_count, uint64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWSM_HIP_H */

@@ -1,0 +1,81 @@
+/*
+ * oracle.h — TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C, scalar f32) of awsm-renderer's
+ * Geometry Pass + Opaque Pass, used as the parity oracle for the HIP kernels and as the timed
+ * "port" CPU baseline in bench.py.  Nothing in the product path may include, link or call this.
+ *
+ * PARITY STATUS: the reference holds no golden vectors for its rendering arithmetic (SURVEY.md §4,
+ * §8c) and cannot be built or run here (Rust -> wasm32 + browser WebGPU; no cargo/rustc, no WGSL
+ * runtime).  For everything in this directory's C code **parity is unpinned**: the only authority
+ * is the WGSL/Rust source text each function cites.  (The buffer allocators and the frustum test,
+ * which the reference's own unit tests do pin, are restated in oracle/host_mirror.py.)
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/awsm_hip.h"   /* ABI structs/enums only: AwsmBuf, AwsmDraw, AwsmSampler */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_MAX_TEX_ARRAYS 64
+#define ORACLE_MAX_SAMPLERS 32
+
+typedef struct OracleTexArray {
+    const uint8_t* texels;   /* layers*h*w*4 RGBA8 */
+    uint32_t width, height, layers;
+} OracleTexArray;
+
+typedef struct OracleScene {
+    const uint8_t* buf[AWSM_BUF_COUNT];
+    uint64_t buf_size[AWSM_BUF_COUNT];
+    uint32_t width, height;
+    uint32_t y0, y1;                 /* shard rows; y1 == 0 -> full frame */
+    const AwsmDraw* draws;
+    uint32_t n_draws;
+    uint32_t has_opaque;             /* 0 -> "empty" pipeline (skybox only) */
+    uint32_t n_tex_arrays;
+    OracleTexArray tex_arrays[ORACLE_MAX_TEX_ARRAYS];
+    uint32_t n_samplers;
+    AwsmSampler samplers[ORACLE_MAX_SAMPLERS];
+    float skybox_rgba[4];
+    float prefiltered_rgb[4];
+    float irradiance_rgb[4];
+    const uint16_t* brdf_lut_rg16f;  /* lut_w*lut_h*2 halfs */
+    uint32_t lut_width, lut_height;
+} OracleScene;
+
+/* vert_main for every exploded vertex of every draw, in draw order.
+ * clip_out: 4 floats / vertex; nt_out: 8 floats / vertex {N.xyz, 0, T.xyzw}. */
+int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out);
+
+/* Rasterise all draws (clip_in from oracle_transform) into keys[width*height]:
+ * (depth_bits << 32) | (0xFFFFFFFF - rank); all ones = no hit. */
+int oracle_raster(const OracleScene* s, const float* clip_in, uint64_t* keys_out, int threads);
+
+/* Opaque compute pass over keys; writes rgba32f (4 floats / pixel) and rgba16f (4 halfs / pixel).
+ * Either output may be NULL. */
+int oracle_shade(const OracleScene* s, const float* clip_in, const float* nt_in, const uint64_t* keys,
+                 float* rgba32f_out, uint16_t* rgba16f_out, int threads);
+
+/* key -> reference visibility texel (primitive-local triangle id, material-mesh-meta byte offset) + depth */
+int oracle_unpack_visibility(const OracleScene* s, const uint64_t* keys, uint32_t* tri_id_out,
+                             uint32_t* meta_off_out, float* depth_out);
+
+/* BRDF LUT: rg16f_out[h*w*2].  Row j, column i == fragment (i+0.5, j+0.5) of the reference's
+ * full-screen triangle (renderer-core/src/brdf_lut/shader.wgsl). */
+int oracle_brdf_lut(uint32_t width, uint32_t height, uint16_t* rg16f_out, int threads);
+
+uint32_t oracle_total_vertices(const OracleScene* s);
+
+/* exposed for unit tests */
+float oracle_det_atan2f(float y, float x);
+uint16_t oracle_f32_to_f16(float f);
+float oracle_f16_to_f32(uint16_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

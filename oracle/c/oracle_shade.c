@@ -1,0 +1,780 @@
+/*
+ * oracle_shade.c — TEST INFRASTRUCTURE ONLY (parity oracle; "parity unpinned", see oracle.h).
+ *
+ * Opaque Pass restated on the CPU, single-sample, MipmapMode::None.  Paths relative to
+ * /root/reference/crates/renderer/src/render_passes/ :
+ *   material_opaque/shader/material_opaque_wgsl/compute.wgsl:100-322            main
+ *   material_opaque/shader/material_opaque_wgsl/empty.wgsl:38-59                main (no opaque renderables)
+ *   material_opaque/shader/material_opaque_wgsl/helpers/standard.wgsl:11-62     get_standard_coordinates
+ *   material_opaque/shader/material_opaque_wgsl/helpers/skybox.wgsl:1-41        sample_skybox
+ *   material_opaque/shader/material_opaque_wgsl/helpers/texture_uvs.wgsl:40-84,144-187
+ *   material_opaque/shader/material_opaque_wgsl/helpers/vertex_color_attrib.wgsl:1-21
+ *   material_opaque/shader/material_opaque_wgsl/helpers/material_color_calc.wgsl:25-530
+ *   geometry/shader/geometry_wgsl/fragment.wgsl:23-54                           fs_main (G-buffer packing)
+ *   shared/shared_wgsl/material_mesh_meta.wgsl:3-28, material.wgsl:15-46, textures.wgsl:75-150
+ *   shared/shared_wgsl/pbr/pbr_material.wgsl:110-415, unlit/unlit_material.wgsl:28-73
+ *   shared/shared_wgsl/lighting/lights.wgsl:38-152, lighting/brdf.wgsl:16-576
+ *
+ * G-buffer emulation: the reference stores barycentric.xy in RG16F and the packed normal/tangent in
+ * RGBA16F (crates/renderer/src/render_textures.rs:49-54) and the opaque pass reads those quantised
+ * values (compute.wgsl:185-186,207-208).  This restatement never materialises those targets; it
+ * recomputes the interpolants for the visible triangle and rounds them to f16 before use.
+ */
+#include "oracle.h"
+#include "oracle_math.h"
+#include <stdlib.h>
+
+int oracle_tri_edges_at(const float* v0, const float* v1, const float* v2, uint32_t width, uint32_t height,
+                        int px, int py, float* e_out);
+
+static inline uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+/* ---------------- textures.wgsl ---------------- */
+typedef struct {
+    int exists;
+    uint32_t width, height, array_index, layer_index, uv_set_index, sampler_index;
+    int mipmapped;
+    uint32_t address_mode_u, address_mode_v, uv_transform_index;
+} TexInfo;
+
+static TexInfo tex_info_none(void) { TexInfo t; memset(&t, 0, sizeof t); return t; }   /* textures.wgsl:116-129 */
+
+/* textures.wgsl:75-114 convert_texture_info(material_load_texture_info_raw(index)) */
+static TexInfo tex_info_load(const uint32_t* mat, uint32_t index) {
+    uint32_t size = mat[index + 0], array_and_layer = mat[index + 1], uv_and_sampler = mat[index + 2];
+    uint32_t extra = mat[index + 3], transform_offset = mat[index + 4];
+    TexInfo t;
+    t.width = size & 0xFFFFu; t.height = size >> 16;
+    t.array_index = array_and_layer & 0xFFFu; t.layer_index = array_and_layer >> 12;
+    t.uv_set_index = uv_and_sampler & 0xFFu; t.sampler_index = uv_and_sampler >> 8;
+    uint32_t flags = extra & 0xFFu;
+    t.exists = (flags & 1u) != 0u; t.mipmapped = (flags & 2u) != 0u;
+    t.address_mode_u = (extra >> 8) & 0xFFu; t.address_mode_v = (extra >> 16) & 0xFFu;
+    t.uv_transform_index = transform_offset / 32u;
+    return t;
+}
+
+static inline int wrap_index(int i, int n, uint32_t mode) {
+    if (mode == 1u) { int m = i % n; return m < 0 ? m + n : m; }                 /* repeat */
+    if (mode == 2u) { int p = 2 * n; int m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; } /* mirror */
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);                                  /* clamp-to-edge */
+}
+static inline ovec4 texel_rgba8(const uint8_t* p) {
+    return ov4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
+}
+static inline float safe_floor(float x, float* frac) {
+    float f = floorf(x);
+    if (!(f >= -1073741824.0f && f <= 1073741824.0f)) { *frac = 0.0f; return 0.0f; }
+    *frac = x - f;
+    return f;
+}
+/* textureSampleLevel(tex, sampler, uv, layer, 0) — sampling contract, DESIGN.md §"Texture sampling" */
+static ovec4 sample_array_level0(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer) {
+    int W = (int)arr->width, H = (int)arr->height;
+    if (layer >= arr->layers) layer = arr->layers - 1u;
+    const uint8_t* base = arr->texels + (size_t)layer * (size_t)W * (size_t)H * 4u;
+    if (smp->mag_filter == 0u) {
+        float fx, fy;
+        int i = wrap_index((int)safe_floor(uv.x * (float)W, &fx), W, smp->address_mode_u);
+        int j = wrap_index((int)safe_floor(uv.y * (float)H, &fy), H, smp->address_mode_v);
+        return texel_rgba8(base + ((size_t)j * W + i) * 4u);
+    }
+    float fx, fy;
+    float x0f = safe_floor(uv.x * (float)W - 0.5f, &fx);
+    float y0f = safe_floor(uv.y * (float)H - 0.5f, &fy);
+    int i0 = wrap_index((int)x0f, W, smp->address_mode_u), i1 = wrap_index((int)x0f + 1, W, smp->address_mode_u);
+    int j0 = wrap_index((int)y0f, H, smp->address_mode_v), j1 = wrap_index((int)y0f + 1, H, smp->address_mode_v);
+    ovec4 c00 = texel_rgba8(base + ((size_t)j0 * W + i0) * 4u), c10 = texel_rgba8(base + ((size_t)j0 * W + i1) * 4u);
+    ovec4 c01 = texel_rgba8(base + ((size_t)j1 * W + i0) * 4u), c11 = texel_rgba8(base + ((size_t)j1 * W + i1) * 4u);
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    ovec4 top = ov4(c00.x * gx + c10.x * fx, c00.y * gx + c10.y * fx, c00.z * gx + c10.z * fx, c00.w * gx + c10.w * fx);
+    ovec4 bot = ov4(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
+    return ov4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
+}
+
+/* texture_uvs.wgsl:144-187 + textures.wgsl:131-150 */
+static ovec4 texture_pool_sample_no_mips(const OracleScene* s, const TexInfo* info, ovec2 uv) {
+    const float* t = (const float*)(s->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)info->uv_transform_index * 32u);
+    ovec2 uvt = ov2((t[0] * uv.x + t[1] * uv.y) + t[4], (t[2] * uv.x + t[3] * uv.y) + t[5]);
+    if (info->array_index >= s->n_tex_arrays) return ov4(0, 0, 0, 0);
+    if (info->sampler_index >= s->n_samplers) return ov4(0, 0, 0, 0);
+    return sample_array_level0(&s->tex_arrays[info->array_index], &s->samplers[info->sampler_index], uvt, info->layer_index);
+}
+
+/* ---------------- per-pixel attribute context ---------------- */
+typedef struct {
+    const OracleScene* s;
+    uint32_t tri[3];                 /* attribute_indices of the triangle */
+    uint32_t attribute_data_offset;  /* in floats */
+    uint32_t stride;                 /* in floats */
+    uint32_t uv_sets_index;
+    ovec3 bary;
+} AttrCtx;
+
+/* texture_uvs.wgsl:64-84 */
+static ovec2 texture_uv(const AttrCtx* a, const TexInfo* info) {
+    const float* ad = (const float*)a->s->buf[AWSM_BUF_ATTR_DATA];
+    ovec2 uv[3];
+    for (int k = 0; k < 3; k++) {
+        uint32_t idx = a->attribute_data_offset + a->tri[k] * a->stride + a->uv_sets_index + info->uv_set_index * 2u;
+        uv[k] = ov2(ad[idx], ad[idx + 1]);
+    }
+    return ov2((a->bary.x * uv[0].x + a->bary.y * uv[1].x) + a->bary.z * uv[2].x,
+               (a->bary.x * uv[0].y + a->bary.y * uv[1].y) + a->bary.z * uv[2].y);
+}
+/* vertex_color_attrib.wgsl:1-21 */
+static ovec4 vertex_color(const AttrCtx* a, uint32_t set_index) {
+    const float* ad = (const float*)a->s->buf[AWSM_BUF_ATTR_DATA];
+    float c[3][4];
+    for (int k = 0; k < 3; k++) {
+        uint32_t idx = a->attribute_data_offset + a->tri[k] * a->stride + set_index * 4u;
+        for (int j = 0; j < 4; j++) c[k][j] = ad[idx + j];
+    }
+    float r[4];
+    for (int j = 0; j < 4; j++) r[j] = (a->bary.x * c[0][j] + a->bary.y * c[1][j]) + a->bary.z * c[2][j];
+    return ov4(r[0], r[1], r[2], r[3]);
+}
+static ovec4 sample_tex(const AttrCtx* a, const TexInfo* info) {
+    return texture_pool_sample_no_mips(a->s, info, texture_uv(a, info));
+}
+
+/* ---------------- pbr_material.wgsl ---------------- */
+typedef struct { TexInfo tex; float factor; TexInfo color_tex; ovec3 color_factor; } PbrSpecular;
+typedef struct { TexInfo tex; float factor; } PbrTransmission;
+typedef struct { TexInfo thickness_tex; float thickness_factor, attenuation_distance; ovec3 attenuation_color; } PbrVolume;
+typedef struct { TexInfo tex; float factor; TexInfo roughness_tex; float roughness_factor; TexInfo normal_tex; float normal_scale; } PbrClearcoat;
+typedef struct { TexInfo roughness_tex; float roughness_factor; TexInfo color_tex; ovec3 color_factor; } PbrSheen;
+
+typedef struct {
+    uint32_t alpha_mode; float alpha_cutoff;
+    TexInfo base_color_tex; ovec4 base_color_factor;
+    TexInfo mr_tex; float metallic_factor, roughness_factor;
+    TexInfo normal_tex; float normal_scale;
+    TexInfo occlusion_tex; float occlusion_strength;
+    TexInfo emissive_tex; ovec3 emissive_factor;
+    uint32_t debug_bitmask;
+    uint32_t idx_vertex_color, idx_emissive_strength, idx_ior, idx_specular, idx_transmission,
+             idx_diffuse_transmission, idx_volume, idx_clearcoat, idx_sheen, idx_dispersion, idx_anisotropy, idx_iridescence;
+} PbrMaterial;
+
+static inline float mat_f32(const uint32_t* m, uint32_t i) { return o_bits_f32(m[i]); }
+
+/* pbr_material.wgsl:110-216 */
+static PbrMaterial pbr_get_material(const uint32_t* m, uint32_t byte_offset) {
+    uint32_t b = byte_offset / 4u + 1u;
+    PbrMaterial p;
+    p.alpha_mode = m[b + 0]; p.alpha_cutoff = mat_f32(m, b + 1);
+    p.base_color_tex = tex_info_load(m, b + 2);
+    p.base_color_factor = ov4(mat_f32(m, b + 7), mat_f32(m, b + 8), mat_f32(m, b + 9), mat_f32(m, b + 10));
+    p.mr_tex = tex_info_load(m, b + 11);
+    p.metallic_factor = mat_f32(m, b + 16); p.roughness_factor = mat_f32(m, b + 17);
+    p.normal_tex = tex_info_load(m, b + 18); p.normal_scale = mat_f32(m, b + 23);
+    p.occlusion_tex = tex_info_load(m, b + 24); p.occlusion_strength = mat_f32(m, b + 29);
+    p.emissive_tex = tex_info_load(m, b + 30);
+    p.emissive_factor = ov3(mat_f32(m, b + 35), mat_f32(m, b + 36), mat_f32(m, b + 37));
+    p.debug_bitmask = m[b + 38];
+    uint32_t fi = b + 39u;
+    p.idx_vertex_color = o_abs_index(b, m[fi + 0]); p.idx_emissive_strength = o_abs_index(b, m[fi + 1]);
+    p.idx_ior = o_abs_index(b, m[fi + 2]); p.idx_specular = o_abs_index(b, m[fi + 3]);
+    p.idx_transmission = o_abs_index(b, m[fi + 4]); p.idx_diffuse_transmission = o_abs_index(b, m[fi + 5]);
+    p.idx_volume = o_abs_index(b, m[fi + 6]); p.idx_clearcoat = o_abs_index(b, m[fi + 7]);
+    p.idx_sheen = o_abs_index(b, m[fi + 8]); p.idx_dispersion = o_abs_index(b, m[fi + 9]);
+    p.idx_anisotropy = o_abs_index(b, m[fi + 10]); p.idx_iridescence = o_abs_index(b, m[fi + 11]);
+    return p;
+}
+/* pbr_material.wgsl:243-415 */
+static PbrSpecular load_specular(const uint32_t* m, uint32_t i) {
+    PbrSpecular r;
+    if (i == 0u) { r.tex = tex_info_none(); r.factor = 1.0f; r.color_tex = tex_info_none(); r.color_factor = ov3(1, 1, 1); return r; }
+    r.tex = tex_info_load(m, i); r.factor = mat_f32(m, i + 5); r.color_tex = tex_info_load(m, i + 6);
+    r.color_factor = ov3(mat_f32(m, i + 11), mat_f32(m, i + 12), mat_f32(m, i + 13));
+    return r;
+}
+static PbrTransmission load_transmission(const uint32_t* m, uint32_t i) {
+    PbrTransmission r;
+    if (i == 0u) { r.tex = tex_info_none(); r.factor = 0.0f; return r; }
+    r.tex = tex_info_load(m, i); r.factor = mat_f32(m, i + 5);
+    return r;
+}
+static PbrVolume load_volume(const uint32_t* m, uint32_t i) {
+    PbrVolume r;
+    if (i == 0u) { r.thickness_tex = tex_info_none(); r.thickness_factor = 0.0f; r.attenuation_distance = 0.0f; r.attenuation_color = ov3(1, 1, 1); return r; }
+    r.thickness_tex = tex_info_load(m, i); r.thickness_factor = mat_f32(m, i + 5); r.attenuation_distance = mat_f32(m, i + 6);
+    r.attenuation_color = ov3(mat_f32(m, i + 7), mat_f32(m, i + 8), mat_f32(m, i + 9));
+    return r;
+}
+static PbrClearcoat load_clearcoat(const uint32_t* m, uint32_t i) {
+    PbrClearcoat r;
+    if (i == 0u) {
+        r.tex = tex_info_none(); r.factor = 0.0f; r.roughness_tex = tex_info_none(); r.roughness_factor = 0.0f;
+        r.normal_tex = tex_info_none(); r.normal_scale = 1.0f; return r;
+    }
+    r.tex = tex_info_load(m, i); r.factor = mat_f32(m, i + 5);
+    r.roughness_tex = tex_info_load(m, i + 6); r.roughness_factor = mat_f32(m, i + 11);
+    r.normal_tex = tex_info_load(m, i + 12); r.normal_scale = mat_f32(m, i + 17);
+    return r;
+}
+static PbrSheen load_sheen(const uint32_t* m, uint32_t i) {
+    PbrSheen r;
+    if (i == 0u) { r.roughness_tex = tex_info_none(); r.roughness_factor = 0.0f; r.color_tex = tex_info_none(); r.color_factor = ov3(0, 0, 0); return r; }
+    r.roughness_tex = tex_info_load(m, i); r.roughness_factor = mat_f32(m, i + 5);
+    r.color_tex = tex_info_load(m, i + 6);
+    r.color_factor = ov3(mat_f32(m, i + 11), mat_f32(m, i + 12), mat_f32(m, i + 13));
+    return r;
+}
+
+/* pbr_material_color.wgsl:4-32 */
+typedef struct {
+    ovec4 base; ovec2 metallic_roughness; ovec3 normal; float occlusion; ovec3 emissive;
+    float specular; ovec3 specular_color; float ior; float transmission;
+    float volume_thickness, volume_attenuation_distance; ovec3 volume_attenuation_color;
+    float clearcoat, clearcoat_roughness; ovec3 clearcoat_normal;
+    ovec3 sheen_color; float sheen_roughness;
+} PbrColor;
+
+/* material_color_calc.wgsl:301-322 / :457-478 */
+static ovec3 normal_map(const AttrCtx* a, const TexInfo* tex, float scale, const o_tbn* tbn) {
+    if (!tex->exists) return tbn->N;
+    ovec4 t = sample_tex(a, tex);
+    ovec3 tn = ov3((t.x * 2.0f - 1.0f) * scale, (t.y * 2.0f - 1.0f) * scale, t.z * 2.0f - 1.0f);
+    omat3 m; m.c[0] = tbn->T; m.c[1] = tbn->B; m.c[2] = tbn->N;
+    return ov3_normalize(omat3_mul_v3(&m, tn));
+}
+
+/* material_color_calc.wgsl:25-265 pbr_get_material_color_no_mips */
+static PbrColor pbr_get_material_color(const AttrCtx* a, const uint32_t* m, const PbrMaterial* mat, const o_tbn* tbn) {
+    float emissive_strength = mat->idx_emissive_strength == 0u ? 1.0f : mat_f32(m, mat->idx_emissive_strength);
+    float ior = mat->idx_ior == 0u ? 1.5f : mat_f32(m, mat->idx_ior);
+    PbrSpecular specular = load_specular(m, mat->idx_specular);
+    PbrTransmission transmission = load_transmission(m, mat->idx_transmission);
+    PbrVolume volume = load_volume(m, mat->idx_volume);
+    PbrClearcoat clearcoat = load_clearcoat(m, mat->idx_clearcoat);
+    PbrSheen sheen = load_sheen(m, mat->idx_sheen);
+    PbrColor c;
+
+    /* :267-283 base colour; alpha forced to 1 (opaque pass) */
+    ovec4 base = mat->base_color_factor;
+    if (mat->base_color_tex.exists) {
+        ovec4 t = sample_tex(a, &mat->base_color_tex);
+        base = ov4(base.x * t.x, base.y * t.y, base.z * t.z, base.w * t.w);
+    }
+    base.w = 1.0f;
+    if (mat->idx_vertex_color != 0u) {            /* :56-66 */
+        uint32_t set_index = m[mat->idx_vertex_color];
+        ovec4 vc = vertex_color(a, set_index);
+        base = ov4(base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w);
+    }
+    c.base = base;
+
+    /* :285-299 metallic (B) / roughness (G) */
+    ovec2 mr = ov2(mat->metallic_factor, mat->roughness_factor);
+    if (mat->mr_tex.exists) { ovec4 t = sample_tex(a, &mat->mr_tex); mr = ov2(mr.x * t.z, mr.y * t.y); }
+    c.metallic_roughness = mr;
+
+    c.normal = normal_map(a, &mat->normal_tex, mat->normal_scale, tbn);
+
+    /* :324-337 occlusion */
+    float occlusion = 1.0f;
+    if (mat->occlusion_tex.exists) { ovec4 t = sample_tex(a, &mat->occlusion_tex); occlusion = o_mix(1.0f, t.x, mat->occlusion_strength); }
+    c.occlusion = occlusion;
+
+    /* :339-352 emissive */
+    ovec3 em = mat->emissive_factor;
+    if (mat->emissive_tex.exists) { ovec4 t = sample_tex(a, &mat->emissive_tex); em = ov3(em.x * t.x, em.y * t.y, em.z * t.z); }
+    c.emissive = ov3_scale(em, emissive_strength);
+
+    /* :354-380 specular */
+    float sf = specular.factor;
+    if (specular.tex.exists) sf = sf * sample_tex(a, &specular.tex).w;
+    c.specular = sf;
+    ovec3 sc = specular.color_factor;
+    if (specular.color_tex.exists) { ovec4 t = sample_tex(a, &specular.color_tex); sc = ov3(sc.x * t.x, sc.y * t.y, sc.z * t.z); }
+    c.specular_color = sc;
+    c.ior = ior;
+
+    /* :382-398 transmission */
+    float tf;
+    if (!transmission.tex.exists && transmission.factor == 0.0f) tf = 0.0f;
+    else { tf = transmission.factor; if (transmission.tex.exists) tf = tf * sample_tex(a, &transmission.tex).x; }
+    c.transmission = tf;
+
+    /* :400-417 volume thickness (G) */
+    float th;
+    if (!volume.thickness_tex.exists && volume.thickness_factor == 0.0f) th = 0.0f;
+    else { th = volume.thickness_factor; if (volume.thickness_tex.exists) th = th * sample_tex(a, &volume.thickness_tex).y; }
+    c.volume_thickness = th;
+    c.volume_attenuation_distance = volume.attenuation_distance;
+    c.volume_attenuation_color = volume.attenuation_color;
+
+    /* :423-478 clearcoat */
+    float ccf;
+    if (!clearcoat.tex.exists && clearcoat.factor == 0.0f) ccf = 0.0f;
+    else { ccf = clearcoat.factor; if (clearcoat.tex.exists) ccf = ccf * sample_tex(a, &clearcoat.tex).x; }
+    c.clearcoat = ccf;
+    float ccr = clearcoat.roughness_factor;
+    if (clearcoat.roughness_tex.exists) ccr = ccr * sample_tex(a, &clearcoat.roughness_tex).y;
+    c.clearcoat_roughness = ccr;
+    c.clearcoat_normal = normal_map(a, &clearcoat.normal_tex, clearcoat.normal_scale, tbn);
+
+    /* :484-510 sheen */
+    ovec3 shc = sheen.color_factor;
+    if (sheen.color_tex.exists) { ovec4 t = sample_tex(a, &sheen.color_tex); shc = ov3(shc.x * t.x, shc.y * t.y, shc.z * t.z); }
+    c.sheen_color = shc;
+    float shr = sheen.roughness_factor;
+    if (sheen.roughness_tex.exists) shr = shr * sample_tex(a, &sheen.roughness_tex).w;
+    c.sheen_roughness = shr;
+    return c;
+}
+
+/* pbr_material_color.wgsl:34-60 */
+static ovec3 pbr_debug_material_color(uint32_t bitmask, const PbrColor* c) {
+    if (bitmask & 1u) return ov3(c->base.x, c->base.y, c->base.z);
+    if (bitmask & 2u) return ov3(c->metallic_roughness.x, c->metallic_roughness.y, 0.0f);
+    if (bitmask & 4u) return ov3(c->normal.x * 0.5f + 0.5f, c->normal.y * 0.5f + 0.5f, c->normal.z * 0.5f + 0.5f);
+    if (bitmask & 8u) return ov3s(c->occlusion);
+    if (bitmask & 16u) return c->emissive;
+    if (bitmask & 32u) return ov3_scale(c->specular_color, c->specular);
+    return ov3(1.0f, 0.0f, 1.0f);
+}
+
+/* ---------------- brdf.wgsl ---------------- */
+static float effective_ior(float ior) { return ior < 1.0f ? 1.5f : ior; }                    /* :16-18 */
+static float ior_to_f0(float ior) { float v = effective_ior(ior); float r = (v - 1.0f) / (v + 1.0f); return r * r; }  /* :22-26 */
+static ovec3 refract_direction(ovec3 incident, ovec3 normal, float eta) {                      /* :30-47 */
+    if (fabsf(eta - 1.0f) < 0.001f) return incident;
+    float cos_i = -ov3_dot(incident, normal);
+    float sin_t2 = (eta * eta) * (1.0f - cos_i * cos_i);
+    if (sin_t2 > 1.0f) return ov3(0, 0, 0);
+    float cos_t = sqrtf(1.0f - sin_t2);
+    return ov3_add(ov3_scale(incident, eta), ov3_scale(normal, eta * cos_i - cos_t));
+}
+static ovec3 volume_attenuation(float distance, ovec3 color, float att_distance) {           /* :55-74 */
+    if (distance <= 0.0f) return ov3s(1.0f);
+    if (att_distance <= 0.0f || att_distance > 1e10f) return ov3s(1.0f);
+    if (color.x >= 0.999f && color.y >= 0.999f && color.z >= 0.999f) return ov3s(1.0f);
+    float e = distance / att_distance;
+    return ov3(powf(color.x, e), powf(color.y, e), powf(color.z, e));
+}
+static int should_apply_volume_attenuation(float thickness, float att_distance, ovec3 color) { /* :77-85 */
+    return thickness > 0.0f && att_distance < 1e10f && (color.x < 1.0f || color.y < 1.0f || color.z < 1.0f);
+}
+static ovec3 safe_half_vector(ovec3 v, ovec3 l) {                                              /* :94-101 */
+    ovec3 sum = ov3_add(v, l);
+    float len_sq = ov3_dot(sum, sum);
+    if (len_sq > 1e-8f) return ov3_scale(sum, o_inverse_sqrt(len_sq));
+    return ov3(0, 0, 0);
+}
+static ovec3 fresnel_schlick(float cos_theta, ovec3 F0) {                                      /* :104-108 */
+    float one_minus = 1.0f - o_saturate(cos_theta);
+    float p = powf(one_minus, 5.0f);
+    return ov3(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
+}
+static ovec3 fresnel_schlick_f90(float cos_theta, ovec3 F0, float f90) {                       /* :111-115 */
+    float one_minus = 1.0f - o_saturate(cos_theta);
+    float p = powf(one_minus, 5.0f);
+    return ov3(F0.x + (f90 - F0.x) * p, F0.y + (f90 - F0.y) * p, F0.z + (f90 - F0.z) * p);
+}
+static float distribution_ggx(float n_dot_h, float alpha) {                                    /* :118-124 */
+    float a = fmaxf(alpha, 0.001f);
+    float a2 = a * a;
+    float ndh = o_saturate(n_dot_h);
+    float d = (ndh * ndh) * (a2 - 1.0f) + 1.0f;
+    return a2 / ((O_PI * d) * d + O_EPSILON);
+}
+static float geometry_schlick_ggx(float n_dot_x, float alpha) {                                /* :127-132 */
+    float a = fmaxf(alpha, 0.001f);
+    float k = ((a + 1.0f) * (a + 1.0f)) * 0.125f;
+    float ndx = o_saturate(n_dot_x);
+    return ndx / (ndx * (1.0f - k) + k);
+}
+static float geometry_smith(ovec3 n, ovec3 v, ovec3 l, float alpha) {                          /* :135-139 */
+    float n_dot_v = o_saturate(ov3_dot(n, v));
+    float n_dot_l = o_saturate(ov3_dot(n, l));
+    return geometry_schlick_ggx(n_dot_v, alpha) * geometry_schlick_ggx(n_dot_l, alpha);
+}
+#define CLEARCOAT_F0 0.04f
+static float clearcoat_brdf_direct(float clearcoat, float cc_roughness, ovec3 cc_normal, ovec3 v, ovec3 l) { /* :149-181 */
+    if (clearcoat <= 0.0f) return 0.0f;
+    ovec3 cc_n = o_safe_normalize(cc_normal);
+    ovec3 h = safe_half_vector(v, l);
+    if (ov3_dot(h, h) == 0.0f) return 0.0f;
+    float cc_n_dot_l = fmaxf(ov3_dot(cc_n, l), 0.0f);
+    float cc_n_dot_v = fmaxf(ov3_dot(cc_n, v), 1e-4f);
+    float cc_n_dot_h = fmaxf(ov3_dot(cc_n, h), 0.0f);
+    float cc_v_dot_h = fmaxf(ov3_dot(v, h), 0.0f);
+    float cc_alpha = fmaxf(cc_roughness * cc_roughness, 0.001f);
+    float Fc = fresnel_schlick(cc_v_dot_h, ov3s(CLEARCOAT_F0)).x;
+    float Dc = distribution_ggx(cc_n_dot_h, cc_alpha);
+    float Gc = geometry_smith(cc_n, v, l, cc_alpha);
+    return (((clearcoat * Fc) * Dc) * Gc) / fmaxf((4.0f * cc_n_dot_l) * cc_n_dot_v, O_EPSILON);
+}
+static float clearcoat_fresnel(float clearcoat, float v_dot_h) {                               /* :184-189 */
+    if (clearcoat <= 0.0f) return 0.0f;
+    return clearcoat * fresnel_schlick(v_dot_h, ov3s(CLEARCOAT_F0)).x;
+}
+static float distribution_charlie(float n_dot_h, float roughness) {                            /* :198-205 */
+    float alpha = roughness * roughness;
+    float inv_alpha = 1.0f / alpha;
+    float cos2h = n_dot_h * n_dot_h;
+    float sin2h = 1.0f - cos2h;
+    return ((2.0f + inv_alpha) * powf(sin2h, inv_alpha * 0.5f)) / (2.0f * O_PI);
+}
+static float visibility_ashikhmin(float n_dot_v, float n_dot_l) {                              /* :208-210 */
+    return 1.0f / (4.0f * ((n_dot_l + n_dot_v) - n_dot_l * n_dot_v));
+}
+static ovec3 sheen_brdf_direct(ovec3 sheen_color, float sheen_roughness, ovec3 n, ovec3 v, ovec3 l) { /* :213-240 */
+    if (sheen_color.x <= 0.0f && sheen_color.y <= 0.0f && sheen_color.z <= 0.0f) return ov3(0, 0, 0);
+    ovec3 h = safe_half_vector(v, l);
+    if (ov3_dot(h, h) == 0.0f) return ov3(0, 0, 0);
+    float n_dot_l = fmaxf(ov3_dot(n, l), 0.0f);
+    float n_dot_v = fmaxf(ov3_dot(n, v), 1e-4f);
+    float n_dot_h = fmaxf(ov3_dot(n, h), 0.0f);
+    float roughness = fmaxf(sheen_roughness, 0.07f);
+    float D = distribution_charlie(n_dot_h, roughness);
+    float V = visibility_ashikhmin(n_dot_v, n_dot_l);
+    return ov3_scale(ov3_scale(sheen_color, D), V);
+}
+static float sheen_albedo_scaling(ovec3 sheen_color, float sheen_roughness, float n_dot_v) {    /* :245-262 */
+    float sheen_max = fmaxf(fmaxf(sheen_color.x, sheen_color.y), sheen_color.z);
+    if (sheen_max <= 0.0f) return 1.0f;
+    float alpha = sheen_roughness * sheen_roughness;
+    float E = alpha * (0.18f + 0.06f * (1.0f - n_dot_v));
+    return 1.0f - sheen_max * E;
+}
+
+/* textureSampleLevel on the uniform-colour cubes the builder creates (crates/renderer/src/lib.rs:176-207) */
+static ovec3 sample_irradiance(const OracleScene* s) { return ov3(s->irradiance_rgb[0], s->irradiance_rgb[1], s->irradiance_rgb[2]); }
+static ovec3 sample_prefiltered(const OracleScene* s) { return ov3(s->prefiltered_rgb[0], s->prefiltered_rgb[1], s->prefiltered_rgb[2]); }
+
+/* brdf.wgsl:293-302 sampleBRDFLUT: linear filter, clamp-to-edge (renderer-core/src/brdf_lut/generate.rs:150-170) */
+static ovec2 sample_brdf_lut(const OracleScene* s, float n_dot_v, float roughness) {
+    float u = o_saturate(n_dot_v), v = o_saturate(roughness);
+    int W = (int)s->lut_width, H = (int)s->lut_height;
+    float fx, fy;
+    float x0f = safe_floor(u * (float)W - 0.5f, &fx);
+    float y0f = safe_floor(v * (float)H - 0.5f, &fy);
+    int i0 = wrap_index((int)x0f, W, 0u), i1 = wrap_index((int)x0f + 1, W, 0u);
+    int j0 = wrap_index((int)y0f, H, 0u), j1 = wrap_index((int)y0f + 1, H, 0u);
+    const uint16_t* L = s->brdf_lut_rg16f;
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    float r[2];
+    for (int c = 0; c < 2; c++) {
+        float c00 = o_f16_to_f32(L[((size_t)j0 * W + i0) * 2 + c]), c10 = o_f16_to_f32(L[((size_t)j0 * W + i1) * 2 + c]);
+        float c01 = o_f16_to_f32(L[((size_t)j1 * W + i0) * 2 + c]), c11 = o_f16_to_f32(L[((size_t)j1 * W + i1) * 2 + c]);
+        float top = c00 * gx + c10 * fx, bot = c01 * gx + c11 * fx;
+        r[c] = top * gy + bot * fy;
+    }
+    return ov2(r[0], r[1]);
+}
+
+typedef struct { ovec3 normal; float n_dot_l; ovec3 light_dir; ovec3 radiance; } LightBrdf;
+
+/* brdf.wgsl:308-381 */
+static ovec3 brdf_direct(const PbrColor* color, const LightBrdf* lb, ovec3 surface_to_camera) {
+    ovec3 n = o_safe_normalize(lb->normal);
+    ovec3 v = o_safe_normalize(surface_to_camera);
+    ovec3 l = o_safe_normalize(lb->light_dir);
+    ovec3 h = safe_half_vector(v, l);
+    ovec3 base_color = ov3(color->base.x, color->base.y, color->base.z);
+    float metallic = o_clamp(color->metallic_roughness.x, 0.0f, 1.0f);
+    float roughness = fmaxf(o_clamp(color->metallic_roughness.y, 0.0f, 1.0f), 0.04f);
+    float alpha = roughness * roughness;
+    float n_dot_l = fmaxf(ov3_dot(n, l), 0.0f);
+    float n_dot_v = fmaxf(ov3_dot(n, v), 1e-4f);
+    int has_half = ov3_dot(h, h) > 0.0f;
+    float n_dot_h = has_half ? fmaxf(ov3_dot(n, h), 0.0f) : 0.0f;
+    float v_dot_h = has_half ? fmaxf(ov3_dot(v, h), 0.0f) : 0.0f;
+    float f0b = ior_to_f0(color->ior);
+    ovec3 dielectric_f0 = ov3_scale(ov3_min(ov3_mul(ov3s(f0b), color->specular_color), ov3s(1.0f)), color->specular);
+    ovec3 F0 = ov3_mix(dielectric_f0, base_color, metallic);
+    float f90 = o_mix(color->specular, 1.0f, metallic);
+    ovec3 F = has_half ? fresnel_schlick_f90(v_dot_h, F0, f90) : fresnel_schlick_f90(n_dot_v, F0, f90);
+    float D = distribution_ggx(n_dot_h, alpha);
+    float G = geometry_smith(n, v, l, alpha);
+    ovec3 specular = ov3(0, 0, 0);
+    if (has_half) specular = ov3_div(ov3_scale(F, D * G), fmaxf((4.0f * n_dot_l) * n_dot_v, O_EPSILON));
+    float F_max = fmaxf(fmaxf(F.x, F.y), F.z);
+    float k_d = (1.0f - F_max) * (1.0f - metallic);
+    ovec3 diffuse = ov3_scale(ov3_scale(base_color, k_d), 1.0f / O_PI);
+    ovec3 result = ov3_scale(ov3_scale(ov3_mul(ov3_add(diffuse, specular), lb->radiance), n_dot_l), color->occlusion);
+    ovec3 sheen = sheen_brdf_direct(color->sheen_color, color->sheen_roughness, n, v, l);
+    float sheen_scaling = sheen_albedo_scaling(color->sheen_color, color->sheen_roughness, n_dot_v);
+    result = ov3_add(ov3_scale(result, sheen_scaling),
+                     ov3_scale(ov3_scale(ov3_mul(sheen, lb->radiance), n_dot_l), color->occlusion));
+    float clearcoat_spec = clearcoat_brdf_direct(color->clearcoat, color->clearcoat_roughness, color->clearcoat_normal, v, l);
+    float cc_fresnel = clearcoat_fresnel(color->clearcoat, v_dot_h);
+    result = ov3_add(ov3_scale(result, 1.0f - cc_fresnel), ov3_scale(ov3_scale(lb->radiance, clearcoat_spec), n_dot_l));
+    return result;
+}
+
+static ovec3 o_reflect(ovec3 i, ovec3 n) { return ov3_sub(i, ov3_scale(n, 2.0f * ov3_dot(n, i))); }
+
+/* brdf.wgsl:389-514 */
+static ovec3 brdf_ibl_with_transmission(const OracleScene* s, const PbrColor* color, ovec3 normal, ovec3 surface_to_camera,
+                                        ovec3 transmission_background) {
+    ovec3 n = o_safe_normalize(normal);
+    ovec3 v = o_safe_normalize(surface_to_camera);
+    ovec3 base_color = ov3(color->base.x, color->base.y, color->base.z);
+    float metallic = o_clamp(color->metallic_roughness.x, 0.0f, 1.0f);
+    float roughness = fmaxf(o_clamp(color->metallic_roughness.y, 0.0f, 1.0f), 0.04f);
+    float n_dot_v = o_saturate(ov3_dot(n, v));
+    float f0b = ior_to_f0(color->ior);
+    ovec3 dielectric_f0 = ov3_scale(ov3_min(ov3_mul(ov3s(f0b), color->specular_color), ov3s(1.0f)), color->specular);
+    ovec3 F0 = ov3_mix(dielectric_f0, base_color, metallic);
+    float f90 = o_mix(color->specular, 1.0f, metallic);
+    ovec3 F_view = fresnel_schlick_f90(n_dot_v, F0, f90);
+    float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
+    float effective_transmission = color->transmission * (1.0f - metallic);
+    ovec3 base_layer;
+    ovec3 irradiance = sample_irradiance(s);
+    if (effective_transmission > 0.0f) {
+        ovec3 diffuse_brdf = ov3_mul(ov3_scale(base_color, 1.0f / O_PI), irradiance);
+        ovec3 attenuation = ov3s(1.0f);
+        if (should_apply_volume_attenuation(color->volume_thickness, color->volume_attenuation_distance, color->volume_attenuation_color))
+            attenuation = volume_attenuation(color->volume_thickness, color->volume_attenuation_color, color->volume_attenuation_distance);
+        ovec3 transmission_btdf = ov3_mul(ov3_mul(transmission_background, base_color), attenuation);
+        base_layer = ov3_mix(diffuse_brdf, transmission_btdf, effective_transmission);
+    } else {
+        base_layer = ov3_mul(ov3_scale(base_color, 1.0f / O_PI), irradiance);
+    }
+    float k_d = (1.0f - F_view_max) * (1.0f - metallic);
+    ovec3 base_contribution = ov3_scale(ov3_scale(base_layer, k_d), color->occlusion);
+    (void)o_reflect;   /* R only selects the cube texel; the cubes are uniform */
+    ovec3 prefiltered = sample_prefiltered(s);
+    ovec2 lut = sample_brdf_lut(s, n_dot_v, roughness);
+    ovec3 spec_term = ov3_add(ov3_scale(F0, lut.x), ov3s(f90 * lut.y));
+    ovec3 specular = ov3_scale(ov3_mul(prefiltered, spec_term), o_mix(1.0f, color->occlusion, 0.5f));
+    float sheen_scaling = sheen_albedo_scaling(color->sheen_color, color->sheen_roughness, n_dot_v);
+    ovec3 base_with_sheen = ov3_scale(base_contribution, sheen_scaling);
+    if (color->sheen_color.x > 0.0f || color->sheen_color.y > 0.0f || color->sheen_color.z > 0.0f) {
+        ovec3 irradiance_sheen = sample_irradiance(s);
+        float alpha = color->sheen_roughness * color->sheen_roughness;
+        float fresnel_sheen = powf(1.0f - n_dot_v, 3.0f);
+        ovec3 sheen_contrib = ov3_scale(ov3_scale(ov3_scale(ov3_mul(color->sheen_color, irradiance_sheen), alpha), fresnel_sheen), color->occlusion);
+        base_with_sheen = ov3_add(base_with_sheen, sheen_contrib);
+    }
+    ovec3 result = ov3_add(ov3_add(base_with_sheen, specular), color->emissive);
+    if (color->clearcoat > 0.0f) {
+        ovec3 cc_n = o_safe_normalize(color->clearcoat_normal);
+        float cc_n_dot_v = o_saturate(ov3_dot(cc_n, v));
+        float cc_roughness = fmaxf(color->clearcoat_roughness, 0.04f);
+        ovec3 cc_prefiltered = sample_prefiltered(s);
+        ovec2 cc_lut = sample_brdf_lut(s, cc_n_dot_v, cc_roughness);
+        ovec3 cc_specular = ov3_scale(cc_prefiltered, CLEARCOAT_F0 * cc_lut.x + cc_lut.y);
+        float cc_fresnel = clearcoat_fresnel(color->clearcoat, n_dot_v);
+        result = ov3_add(ov3_scale(result, 1.0f - cc_fresnel), ov3_scale(cc_specular, color->clearcoat));
+    }
+    return result;
+}
+
+/* brdf.wgsl:517-576 */
+static ovec3 brdf_ibl(const OracleScene* s, const PbrColor* color, ovec3 normal, ovec3 surface_to_camera) {
+    ovec3 transmission_background = ov3(0, 0, 0);
+    float effective_transmission = color->transmission * (1.0f - o_clamp(color->metallic_roughness.x, 0.0f, 1.0f));
+    if (effective_transmission > 0.0f) {
+        /* direction only selects the texel of a uniform cube; refract_direction kept for completeness */
+        ovec3 n = o_safe_normalize(normal), v = o_safe_normalize(surface_to_camera);
+        float ior_val = effective_ior(color->ior);
+        if (color->volume_thickness > 0.0f && ior_val != 1.0f) (void)refract_direction(v, n, 1.0f / ior_val);
+        transmission_background = sample_prefiltered(s);
+    }
+    return brdf_ibl_with_transmission(s, color, normal, surface_to_camera, transmission_background);
+}
+
+/* lights.wgsl:70-118 */
+static float spot_falloff(float inner_cos, float outer_cos, float cos_l) {
+    float sm = o_saturate((cos_l - outer_cos) / (inner_cos - outer_cos));
+    return sm * sm;
+}
+static LightBrdf light_to_brdf(const float* lp, ovec3 normal, ovec3 world_position) {
+    /* LightPacked: pos_range, dir_inner, color_intensity, kind_outer_pad (lights.wgsl:15-24,49-62) */
+    uint32_t kind = (uint32_t)lp[12];
+    ovec3 color = ov3(lp[8], lp[9], lp[10]); float intensity = lp[11];
+    ovec3 position = ov3(lp[0], lp[1], lp[2]); float range = lp[3];
+    ovec3 direction = ov3(lp[4], lp[5], lp[6]); float inner_cone = lp[7]; float outer_cone = lp[13];
+    LightBrdf r; r.normal = normal; r.n_dot_l = 0.0f; r.light_dir = ov3(0, 0, 0); r.radiance = ov3(0, 0, 0);
+    if (kind == 1u) {
+        r.light_dir = ov3_normalize(ov3_neg(direction));
+        r.radiance = ov3_scale(color, intensity);
+        r.n_dot_l = fmaxf(ov3_dot(normal, r.light_dir), 0.0f);
+    } else if (kind == 2u) {
+        ovec3 stl = ov3_sub(position, world_position);
+        float dist = ov3_length(stl);
+        r.light_dir = ov3_div(stl, dist);
+        float att = o_inverse_square(range, dist);
+        r.radiance = ov3_scale(ov3_scale(color, intensity), att);
+        r.n_dot_l = fmaxf(ov3_dot(normal, r.light_dir), 0.0f);
+    } else if (kind == 3u) {
+        ovec3 stl = ov3_sub(position, world_position);
+        float dist = ov3_length(stl);
+        r.light_dir = ov3_div(stl, dist);
+        float cos_l = ov3_dot(r.light_dir, ov3_neg(ov3_normalize(direction)));
+        float spot = spot_falloff(inner_cone, outer_cone, cos_l);
+        float att = o_inverse_square(range, dist) * spot;
+        r.radiance = ov3_scale(ov3_scale(color, intensity), att);
+        r.n_dot_l = fmaxf(ov3_dot(normal, r.light_dir), 0.0f);
+    }
+    return r;
+}
+
+/* lights.wgsl:121-152 */
+static ovec3 apply_lighting(const OracleScene* s, const PbrColor* mc, ovec3 surface_to_camera, ovec3 world_position, uint32_t n_lights) {
+    ovec3 color = brdf_ibl(s, mc, mc->normal, surface_to_camera);
+    const float* lights = (const float*)s->buf[AWSM_BUF_LIGHTS];
+    for (uint32_t i = 0; i < n_lights; i++) {
+        LightBrdf lb = light_to_brdf(lights + (size_t)i * 16, mc->normal, world_position);
+        color = ov3_add(color, brdf_direct(mc, &lb, surface_to_camera));
+    }
+    return color;
+}
+
+/* ---------------- material_mesh_meta.wgsl:6-28 (17 live words in a 256-B slot) ---------------- */
+typedef struct {
+    uint32_t material_offset, transform_offset, normal_matrix_offset, attr_indices_offset, attr_data_offset,
+             attr_stride, uv_sets_index, uv_set_count, color_set_count, vis_geom_data_offset, is_hud;
+} MaterialMeta;
+static MaterialMeta load_material_meta(const OracleScene* s, uint32_t byte_off) {
+    const uint8_t* p = s->buf[AWSM_BUF_MATERIAL_META] + (size_t)(byte_off / 256u) * 256u;
+    MaterialMeta m;
+    m.material_offset = rd_u32(p + 24); m.transform_offset = rd_u32(p + 28); m.normal_matrix_offset = rd_u32(p + 32);
+    m.attr_indices_offset = rd_u32(p + 36); m.attr_data_offset = rd_u32(p + 40); m.attr_stride = rd_u32(p + 44);
+    m.uv_sets_index = rd_u32(p + 48); m.uv_set_count = rd_u32(p + 52); m.color_set_count = rd_u32(p + 56);
+    m.vis_geom_data_offset = rd_u32(p + 60); m.is_hud = rd_u32(p + 64);
+    return m;
+}
+
+static void store_pixel(float* rgba32f, uint16_t* rgba16f, size_t p, ovec4 c) {
+    if (rgba32f) { rgba32f[p * 4 + 0] = c.x; rgba32f[p * 4 + 1] = c.y; rgba32f[p * 4 + 2] = c.z; rgba32f[p * 4 + 3] = c.w; }
+    if (rgba16f) {
+        rgba16f[p * 4 + 0] = o_f32_to_f16(c.x); rgba16f[p * 4 + 1] = o_f32_to_f16(c.y);
+        rgba16f[p * 4 + 2] = o_f32_to_f16(c.z); rgba16f[p * 4 + 3] = o_f32_to_f16(c.w);
+    }
+}
+
+static uint32_t find_draw(const OracleScene* s, uint32_t rank, uint32_t* first_rank) {
+    uint32_t acc = 0;
+    for (uint32_t d = 0; d < s->n_draws; d++) {
+        if (rank < acc + s->draws[d].tri_count) { *first_rank = acc; return d; }
+        acc += s->draws[d].tri_count;
+    }
+    *first_rank = acc;
+    return s->n_draws;
+}
+
+/* compute.wgsl:100-322 for one pixel */
+static void shade_pixel(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
+                        int cx, int cy, float* rgba32f, uint16_t* rgba16f) {
+    uint32_t W = s->width, H = s->height;
+    size_t p = (size_t)cy * W + (size_t)cx;
+    ovec4 sky = ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
+    uint64_t key = keys[p];
+    if (!s->has_opaque || key == ~0ull) { store_pixel(rgba32f, rgba16f, p, sky); return; }   /* compute.wgsl:149-153; empty.wgsl */
+
+    uint32_t rank = O_U32_MAX - (uint32_t)(key & 0xFFFFFFFFull);
+    float depth_sample = o_bits_f32((uint32_t)(key >> 32));
+    uint32_t first;
+    uint32_t d = find_draw(s, rank, &first);
+    uint32_t triangle_index = rank - first;
+    uint32_t material_meta_offset = rd_u32(s->buf[AWSM_BUF_GEOM_META] + s->draws[d].geom_meta_off + 36);
+    MaterialMeta meta = load_material_meta(s, material_meta_offset);
+    if (meta.is_hud == 1u) return;   /* compute.wgsl:176-179: pixel stays as cleared */
+
+    /* ---- what fs_main wrote for this pixel (fragment.wgsl:23-54), rounded to the G-buffer formats ---- */
+    const float* v0 = clip + (size_t)rank * 12;
+    float e[3];
+    if (!oracle_tri_edges_at(v0, v0 + 4, v0 + 8, W, H, cx, cy, e)) { store_pixel(rgba32f, rgba16f, p, sky); return; }
+    float esum = (e[0] + e[1]) + e[2];
+    float b0 = e[0] / esum, b1 = e[1] / esum, b2 = e[2] / esum;
+    const float* n0 = nt + (size_t)rank * 24;
+    /* perspective-correct varyings: (b0*A0 + b1*A1) + b2*A2 */
+    ovec3 Ni = ov3((b0 * n0[0] + b1 * n0[8]) + b2 * n0[16], (b0 * n0[1] + b1 * n0[9]) + b2 * n0[17],
+                   (b0 * n0[2] + b1 * n0[10]) + b2 * n0[18]);
+    ovec4 Ti = ov4((b0 * n0[4] + b1 * n0[12]) + b2 * n0[20], (b0 * n0[5] + b1 * n0[13]) + b2 * n0[21],
+                   (b0 * n0[6] + b1 * n0[14]) + b2 * n0[22], (b0 * n0[7] + b1 * n0[15]) + b2 * n0[23]);
+    ovec3 Nn = ov3_normalize(Ni);
+    ovec3 Tn = ov3_normalize(ov3(Ti.x, Ti.y, Ti.z));
+    ovec4 packed = o_pack_normal_tangent(Nn, Tn, Ti.w);
+    packed = ov4(o_round_f16(packed.x), o_round_f16(packed.y), o_round_f16(packed.z), o_round_f16(packed.w));   /* RGBA16F */
+    float bx = o_round_f16(b0), by = o_round_f16(b1);                                                             /* RG16F */
+
+    /* ---- compute.wgsl:182-211 ---- */
+    ovec3 barycentric = ov3(bx, by, (1.0f - bx) - by);
+    const uint32_t* materials = (const uint32_t*)s->buf[AWSM_BUF_MATERIALS];
+    uint32_t material_offset = meta.material_offset;
+    uint32_t shader_id = materials[material_offset / 4u];
+    AttrCtx a;
+    a.s = s;
+    a.stride = meta.attr_stride / 4u;
+    a.attribute_data_offset = meta.attr_data_offset / 4u;
+    a.uv_sets_index = meta.uv_sets_index;
+    a.bary = barycentric;
+    const uint32_t* attr_idx = (const uint32_t*)s->buf[AWSM_BUF_ATTR_INDEX];
+    uint32_t base_tri = meta.attr_indices_offset / 4u + triangle_index * 3u;
+    a.tri[0] = attr_idx[base_tri]; a.tri[1] = attr_idx[base_tri + 1]; a.tri[2] = attr_idx[base_tri + 2];
+
+    /* ---- standard.wgsl:11-62 ---- */
+    const uint8_t* cam = s->buf[AWSM_BUF_CAMERA];
+    omat4 proj = omat4_load((const float*)(cam + 64));
+    omat4 inv_proj = omat4_load((const float*)(cam + 256));
+    omat4 inv_view = omat4_load((const float*)(cam + 320));
+    const float* cam_pos = (const float*)(cam + 384);
+    ovec2 uv = ov2(((float)cx + 0.5f) / (float)W, ((float)cy + 0.5f) / (float)H);
+    ovec4 clip_position = ov4(uv.x * 2.0f - 1.0f, 1.0f - uv.y * 2.0f, depth_sample, 1.0f);
+    ovec4 view_h = omat4_mul_v4(&inv_proj, clip_position);
+    float vw = fmaxf(view_h.w, 1e-8f);
+    ovec3 view_position = ov3(view_h.x / vw, view_h.y / vw, view_h.z / vw);
+    ovec4 wp = omat4_mul_v4(&inv_view, ov4(view_position.x, view_position.y, view_position.z, 1.0f));
+    ovec3 world_position = ov3(wp.x, wp.y, wp.z);
+    int is_ortho = proj.c[3].w > 0.9f;
+    ovec3 surface_to_camera;
+    if (is_ortho) {
+        surface_to_camera = ov3_normalize(ov3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
+    } else {
+        ovec3 to_camera = ov3_sub(ov3(cam_pos[0], cam_pos[1], cam_pos[2]), world_position);
+        surface_to_camera = ov3_dot(to_camera, to_camera) > 0.0f ? o_safe_normalize(to_camera) : ov3(0.0f, 0.0f, 1.0f);
+    }
+
+    o_tbn tbn = o_unpack_normal_tangent(packed);
+    uint32_t n_lights = rd_u32(s->buf[AWSM_BUF_LIGHTS_INFO]);   /* lights.wgsl:38-47 */
+
+    ovec3 color; float base_alpha;
+    if (shader_id == 2u) {
+        /* unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580 */
+        uint32_t b = material_offset / 4u + 1u;
+        TexInfo base_tex = tex_info_load(materials, b + 2);
+        ovec4 base = ov4(mat_f32(materials, b + 7), mat_f32(materials, b + 8), mat_f32(materials, b + 9), mat_f32(materials, b + 10));
+        TexInfo em_tex = tex_info_load(materials, b + 11);
+        ovec3 em = ov3(mat_f32(materials, b + 16), mat_f32(materials, b + 17), mat_f32(materials, b + 18));
+        if (base_tex.exists) { ovec4 t = sample_tex(&a, &base_tex); base = ov4(base.x * t.x, base.y * t.y, base.z * t.z, base.w * t.w); }
+        if (em_tex.exists) { ovec4 t = sample_tex(&a, &em_tex); em = ov3(em.x * t.x, em.y * t.y, em.z * t.z); }
+        base.w = 1.0f;
+        color = ov3(base.x + em.x, base.y + em.y, base.z + em.z);
+        base_alpha = base.w;
+    } else {
+        PbrMaterial mat = pbr_get_material(materials, material_offset);
+        PbrColor mc = pbr_get_material_color(&a, materials, &mat, &tbn);
+        if (mat.debug_bitmask != 0u) {
+            ovec3 dc = pbr_debug_material_color(mat.debug_bitmask, &mc);
+            store_pixel(rgba32f, rgba16f, p, ov4(dc.x, dc.y, dc.z, 1.0f));
+            return;
+        }
+        color = apply_lighting(s, &mc, surface_to_camera, world_position, n_lights);
+        base_alpha = mc.base.w;
+    }
+    store_pixel(rgba32f, rgba16f, p, ov4(color.x, color.y, color.z, base_alpha));
+}
+
+int oracle_shade(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
+                 float* rgba32f, uint16_t* rgba16f, int threads) {
+    uint32_t W = s->width, H = s->height;
+    uint32_t y0 = s->y0, y1 = s->y1;
+    if (y1 == 0 || y1 > H) y1 = H;
+    if (threads < 1) threads = 1;
+    /* render_textures.clear_opaque() (crates/renderer/src/render.rs:209): the whole target is zeroed first */
+    if (rgba32f) memset(rgba32f, 0, (size_t)W * H * 16);
+    if (rgba16f) memset(rgba16f, 0, (size_t)W * H * 8);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+    for (int cy = (int)y0; cy < (int)y1; cy++)
+        for (int cx = 0; cx < (int)W; cx++) shade_pixel(s, clip, nt, keys, cx, cy, rgba32f, rgba16f);
+    return 0;
+}

@@ -1,0 +1,162 @@
+"""
+oracle_lib.py — TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liboracle.so (oracle/c/*.c) plus a helper that
+runs a full oracle frame from the mirrors of oracle.scene_model.HostModel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, List, Optional
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_DIR, "liboracle.so")
+BUF_COUNT = 18
+MAX_TEX = 64
+MAX_SAMPLERS = 32
+
+
+class AwsmDraw(C.Structure):
+    _fields_ = [("geom_meta_off", C.c_uint32), ("vis_data_off", C.c_uint32), ("tri_count", C.c_uint32), ("flags", C.c_uint32),
+                ("inst_off", C.c_uint32), ("inst_count", C.c_uint32)]
+
+
+class AwsmSampler(C.Structure):
+    _fields_ = [("address_mode_u", C.c_uint32), ("address_mode_v", C.c_uint32), ("mag_filter", C.c_uint32), ("min_filter", C.c_uint32),
+                ("mipmap_filter", C.c_uint32), ("max_anisotropy", C.c_uint32)]
+
+
+class OracleTexArray(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("layers", C.c_uint32)]
+
+
+class OracleScene(C.Structure):
+    _fields_ = [("buf", C.c_void_p * BUF_COUNT), ("buf_size", C.c_uint64 * BUF_COUNT), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("y0", C.c_uint32), ("y1", C.c_uint32), ("draws", C.POINTER(AwsmDraw)), ("n_draws", C.c_uint32), ("has_opaque", C.c_uint32),
+                ("n_tex_arrays", C.c_uint32), ("tex_arrays", OracleTexArray * MAX_TEX), ("n_samplers", C.c_uint32),
+                ("samplers", AwsmSampler * MAX_SAMPLERS), ("skybox_rgba", C.c_float * 4), ("prefiltered_rgb", C.c_float * 4),
+                ("irradiance_rgb", C.c_float * 4), ("brdf_lut_rg16f", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/c/*.c -> liboracle.so (gcc, -ffp-contract=off)."""
+    srcs = [os.path.join(_DIR, "c", f) for f in os.listdir(os.path.join(_DIR, "c"))] + [os.path.join(_DIR, "..", "include", "awsm_hip.h")]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", _DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_total_vertices.restype = C.c_uint32
+        _lib.oracle_det_atan2f.restype = C.c_float
+        _lib.oracle_det_atan2f.argtypes = [C.c_float, C.c_float]
+        _lib.oracle_f32_to_f16.restype = C.c_uint16
+        _lib.oracle_f32_to_f16.argtypes = [C.c_float]
+        _lib.oracle_f16_to_f32.restype = C.c_float
+        _lib.oracle_f16_to_f32.argtypes = [C.c_uint16]
+    return _lib
+
+
+def brdf_lut(width: int, height: int, threads: int = 8) -> np.ndarray:
+    out = np.zeros((height, width, 2), dtype=np.uint16)
+    rc = lib().oracle_brdf_lut(C.c_uint32(width), C.c_uint32(height), out.ctypes.data_as(C.c_void_p), C.c_int(threads))
+    assert rc == 0
+    return out
+
+
+def lut_rg_to_rgba16f(rg: np.ndarray) -> np.ndarray:
+    """RG16F -> the reference's RGBA16F texel (b = 0, a = 1.0)."""
+    h, w, _ = rg.shape
+    out = np.zeros((h, w, 4), dtype=np.uint16)
+    out[..., :2] = rg
+    out[..., 3] = 0x3C00
+    return out
+
+
+class OracleFrame:
+    """Holds the numpy arrays an OracleScene points at and runs the three oracle stages."""
+
+    def __init__(self, mirrors: Dict[int, bytes], draws: List[dict], width: int, height: int, tex_arrays: List[dict], samplers: List[dict],
+                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True):
+        self._keep = []
+        s = OracleScene()
+        for i in range(BUF_COUNT):
+            data = mirrors.get(i)
+            if data is None:
+                continue
+            arr = np.frombuffer(bytes(data) + bytes(16), dtype=np.uint8).copy()
+            self._keep.append(arr)
+            s.buf[i] = arr.ctypes.data
+            s.buf_size[i] = len(data)
+        s.width, s.height, s.y0, s.y1 = width, height, rows[0], rows[1]
+        self.draw_arr = (AwsmDraw * max(1, len(draws)))()
+        for i, d in enumerate(draws):
+            self.draw_arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], 0, 0)
+        s.draws = C.cast(self.draw_arr, C.POINTER(AwsmDraw))
+        s.n_draws = len(draws)
+        s.has_opaque = 1 if has_opaque else 0
+        s.n_tex_arrays = len(tex_arrays)
+        for i, t in enumerate(tex_arrays):
+            arr = np.ascontiguousarray(t["texels"], dtype=np.uint8)
+            self._keep.append(arr)
+            s.tex_arrays[i] = OracleTexArray(arr.ctypes.data, t["width"], t["height"], t["layers"])
+        s.n_samplers = len(samplers)
+        for i, sm in enumerate(samplers):
+            s.samplers[i] = AwsmSampler(sm.get("address_mode_u", 1), sm.get("address_mode_v", 1), sm.get("mag_filter", 1), sm.get("min_filter", 1),
+                                        sm.get("mipmap_filter", 1), sm.get("max_anisotropy", 1))
+        for i in range(4):
+            s.skybox_rgba[i] = skybox[i]
+        for i in range(3):
+            s.prefiltered_rgb[i] = prefiltered[i]
+            s.irradiance_rgb[i] = irradiance[i]
+        self.lut = np.ascontiguousarray(lut_rg16f, dtype=np.uint16)
+        s.brdf_lut_rg16f = self.lut.ctypes.data
+        s.lut_height, s.lut_width = self.lut.shape[0], self.lut.shape[1]
+        self.scene = s
+        self.width, self.height = width, height
+        self.n_verts = int(lib().oracle_total_vertices(C.byref(s)))
+        self.clip = np.zeros((max(1, self.n_verts), 4), dtype=np.float32)
+        self.nt = np.zeros((max(1, self.n_verts), 8), dtype=np.float32)
+        self.keys = np.zeros((height, width), dtype=np.uint64)
+        self.rgba32f = np.zeros((height, width, 4), dtype=np.float32)
+        self.rgba16f = np.zeros((height, width, 4), dtype=np.uint16)
+
+    def transform(self):
+        assert lib().oracle_transform(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.nt.ctypes.data_as(C.c_void_p)) == 0
+        return self
+
+    def raster(self, threads=8):
+        assert lib().oracle_raster(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.keys.ctypes.data_as(C.c_void_p), C.c_int(threads)) == 0
+        return self
+
+    def shade(self, threads=8):
+        assert lib().oracle_shade(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.nt.ctypes.data_as(C.c_void_p),
+                                  self.keys.ctypes.data_as(C.c_void_p), self.rgba32f.ctypes.data_as(C.c_void_p),
+                                  self.rgba16f.ctypes.data_as(C.c_void_p), C.c_int(threads)) == 0
+        return self
+
+    def run(self, threads=8):
+        return self.transform().raster(threads).shade(threads)
+
+    def unpack_visibility(self):
+        tri = np.zeros((self.height, self.width), dtype=np.uint32)
+        meta = np.zeros((self.height, self.width), dtype=np.uint32)
+        depth = np.zeros((self.height, self.width), dtype=np.float32)
+        assert lib().oracle_unpack_visibility(C.byref(self.scene), self.keys.ctypes.data_as(C.c_void_p), tri.ctypes.data_as(C.c_void_p),
+                                              meta.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p)) == 0
+        return tri, meta, depth
+
+
+def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True) -> OracleFrame:
+    sc = model.scene
+    return OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,
+                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque)

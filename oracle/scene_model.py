@@ -1,0 +1,621 @@
+"""
+scene_model.py — TEST INFRASTRUCTURE ONLY (parity oracle for the C++ host layer, "parity unpinned").
+
+Python/numpy model of the reference's scene stores and packers: everything between the key-based update API and
+the bytes that reach the device.  It is the checker for awsm-renderer_amd/host (C++): the same scene description
+must yield byte-identical mirrors, offsets, write plans and draw lists.
+Paths relative to /root/reference/crates/renderer/src/ :
+
+  transforms.rs:43-446                       Transforms (TRS tree, world mat4 + normal mat3 mirrors)
+  camera.rs:111-227,285-306                  CameraBuffer::update (512-B UBO), compute_view_frustum_rays
+  lights.rs:226-310,354-473                  Lights (dense 64-B records + 16-B info)
+  textures.rs:226-284,311-320                TextureTransform::as_gpu_bytes, identity slot
+  materials/pbr.rs:258-589, unlit.rs:72-105, writer.rs:65-197   material word streams
+  meshes.rs:455-674,872-939                  Meshes::insert (5 DynamicStorageBuffers), update_world
+  meshes/meta.rs:89-146, meta/geometry_meta.rs:44-113, meta/material_meta.rs:53-185
+  meshes/skins.rs:84-194, meshes/morphs.rs:121-217
+  gltf/buffers/mesh/visibility.rs:35-165     create_visibility_vertices (56 B / exploded vertex)
+  gltf/buffers/attributes.rs:113-160         pack_vertex_attributes; ordering meshes/buffer_info.rs:392-414
+  gltf/buffers/skin.rs:22-113, morph.rs:31-190
+  gltf/populate.rs:185-205, populate/mesh.rs:36-311   insertion order
+  renderable.rs:38-150                       collect_renderables + geometry_sort_renderable
+  render.rs:73-97                            write_gpu order
+"""
+from __future__ import annotations
+
+import functools
+import math
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import host_mirror as hm
+from .host_mirror import (Aabb, DynamicStorageBuffer, DynamicUniformBuffer, Frustum, SlotMap, F, key_as_ffi)
+
+# AwsmBuf ids (include/awsm_hip.h)
+(BUF_TRANSFORMS, BUF_NORMAL_MATS, BUF_MATERIALS, BUF_LIGHTS, BUF_LIGHTS_INFO, BUF_CAMERA, BUF_SKIN_MATRICES,
+ BUF_SKIN_INDEX_WEIGHTS, BUF_MORPH_WEIGHTS, BUF_MORPH_VALUES, BUF_GEOM_META, BUF_MATERIAL_META, BUF_VIS_GEOM_DATA,
+ BUF_VIS_GEOM_INDEX, BUF_ATTR_DATA, BUF_ATTR_INDEX, BUF_TEXTURE_TRANSFORMS, BUF_INSTANCES) = range(18)
+BUF_COUNT = 18
+
+from awsm_renderer_amd.scene_desc import (MaterialDesc, NodeDesc, PrimitiveDesc, SceneDesc, SkinDesc, TextureRef)  # noqa: E402,F401
+
+# ------------------------------------------------------------------------------------------------ packers (gltf/buffers)
+
+_BARY = np.array([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0]], dtype=F)
+
+
+def create_visibility_vertices(positions, normals, tangents, indices, front_face_cw=False) -> bytes:
+    """gltf/buffers/mesh/visibility.rs:35-165 — 56 bytes per exploded vertex."""
+    idx = np.asarray(indices, dtype=np.uint32).reshape(-1, 3)
+    T = idx.shape[0]
+    bary = _BARY
+    if front_face_cw:
+        idx = idx[:, [0, 2, 1]]
+        bary = _BARY[[0, 2, 1]]
+    flat = idx.reshape(-1)
+    rec = np.zeros(T * 3, dtype=np.dtype([("pos", "<f4", 3), ("tri", "<u4"), ("bary", "<f4", 2), ("nrm", "<f4", 3),
+                                           ("tan", "<f4", 4), ("orig", "<u4")]))
+    assert rec.dtype.itemsize == 56
+    rec["pos"] = np.asarray(positions, dtype=F)[flat]
+    rec["tri"] = np.repeat(np.arange(T, dtype=np.uint32), 3)
+    rec["bary"] = np.tile(bary, (T, 1))
+    rec["nrm"] = np.asarray(normals, dtype=F)[flat]
+    if tangents is not None:
+        rec["tan"] = np.asarray(tangents, dtype=F)[flat]
+    else:
+        rec["tan"] = np.array([0, 0, 0, 1], dtype=F)
+    rec["orig"] = flat
+    return rec.tobytes()
+
+
+def pack_vertex_attributes(colors: List[np.ndarray], uvs: List[np.ndarray]) -> Tuple[bytes, int]:
+    """gltf/buffers/attributes.rs:113-160; BTreeMap order = COLOR_n (by n) then TEXCOORD_n (buffer_info.rs:392-414).
+    Returns (bytes, stride_bytes)."""
+    cols = [np.asarray(c, dtype=F).reshape(-1, 4) for c in colors] + [np.asarray(u, dtype=F).reshape(-1, 2) for u in uvs]
+    if not cols:
+        return b"", 0
+    inter = np.concatenate(cols, axis=1).astype(F)
+    return inter.tobytes(), inter.shape[1] * 4
+
+
+def convert_skin(joints: List[np.ndarray], weights: List[np.ndarray]) -> bytes:
+    """gltf/buffers/skin.rs:22-113 — per original vertex, per set: 4 x {u32 joint, f32 weight} interleaved."""
+    V = joints[0].shape[0]
+    sets = len(joints)
+    out = np.zeros((V, sets, 4, 2), dtype=np.uint32)
+    for s in range(sets):
+        out[:, s, :, 0] = np.asarray(joints[s], dtype=np.uint32)
+        out[:, s, :, 1] = np.asarray(weights[s], dtype=F).view(np.uint32)
+    return out.tobytes()
+
+
+def convert_morph_targets(targets: List[dict], vertex_count: int) -> bytes:
+    """gltf/buffers/morph.rs:31-190 — per vertex, per target: pos3, nrm3, tan3 + pad = 10 floats."""
+    out = np.zeros((vertex_count, len(targets), 10), dtype=F)
+    for t, tg in enumerate(targets):
+        if tg.get("positions") is not None:
+            out[:, t, 0:3] = tg["positions"]
+        if tg.get("normals") is not None:
+            out[:, t, 3:6] = tg["normals"]
+        if tg.get("tangents") is not None:
+            out[:, t, 6:9] = tg["tangents"]
+    return out.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ stores
+
+
+class Transforms:
+    INITIAL_CAPACITY = 32
+
+    def __init__(self):
+        self.locals = SlotMap()
+        self.world: Dict = {}
+        self.children: Dict = {}
+        self.parents: Dict = {}
+        self.dirties = set()
+        self.dirty_meshes: List = []
+        self.gpu_dirty = True
+        self.buffer = DynamicUniformBuffer(self.INITIAL_CAPACITY, 64)
+        self.normals_buffer = DynamicUniformBuffer(self.INITIAL_CAPACITY, 36)
+        self.root = self.locals.insert(((0, 0, 0), (0, 0, 0, 1), (1, 1, 1)))
+        self.world[self.root] = hm.mat4_identity()
+        self.children[self.root] = []
+
+    def insert(self, trs, parent=None):
+        t, r, s = trs
+        key = self.locals.insert((t, r, s))
+        self.world[key] = hm.mat4_from_srt(s, r, t)
+        self.children[key] = []
+        self.dirties.add(key)
+        self.buffer.update(key, bytes(64))
+        self.normals_buffer.update(key, bytes(36))
+        self.set_parent(key, parent)
+        return key
+
+    def set_parent(self, child, parent):
+        if child == self.root:
+            return
+        parent = parent if parent is not None else self.root
+        if child in self.parents:
+            if self.parents[child] == parent:
+                return
+            self.children[self.parents.pop(child)].remove(child)
+        self.children[parent].append(child)
+        self.parents[child] = parent
+
+    def get_parent(self, child):
+        return self.parents.get(child)
+
+    def set_local(self, key, trs):
+        if key == self.root:
+            raise ValueError("cannot modify root node")
+        self.locals.set(key, trs)
+        self.dirties.add(key)
+
+    def update_world(self):
+        self.gpu_dirty = self.gpu_dirty or bool(self.dirties)
+        self._update(self.root, False)
+        self.dirties.clear()
+
+    def _update(self, key, dirty_tracker):
+        dirty = (key in self.dirties) or dirty_tracker
+        if dirty:
+            t, r, s = self.locals.get(key)
+            local = hm.mat4_from_srt(s, r, t)
+            if key in self.parents:
+                world = hm.mat4_mul(self.world[self.parents[key]], local)
+            else:
+                world = local
+            self.world[key] = world
+            self.buffer.update(key, world.astype(F).tobytes())
+            nm = hm.mat4_transpose(hm.mat4_inverse(world))
+            self.normals_buffer.update(key, np.ascontiguousarray(nm[:3, :3]).astype(F).tobytes())
+            self.dirty_meshes.append(key)
+        for child in list(self.children[key]):
+            self._update(child, dirty)
+        return dirty
+
+    def take_dirty_meshes(self):
+        out = {k: self.world[k] for k in self.dirty_meshes}
+        self.dirty_meshes = []
+        return out
+
+
+def camera_ubo(view, proj, position, frame_count, width, height, focus_distance=0.0, aperture=0.0) -> bytes:
+    """camera.rs:111-227 — 512 bytes."""
+    view, proj = np.asarray(view, dtype=F), np.asarray(proj, dtype=F)
+    inv_proj = hm.mat4_inverse(proj)
+    view_proj = hm.mat4_mul(proj, view)
+    inv_view_proj = hm.mat4_inverse(view_proj)
+    inv_view = hm.mat4_inverse(view)
+    out = bytearray()
+    for m in (view, proj, view_proj, inv_view_proj, inv_proj, inv_view):
+        out += m.astype(F).tobytes()
+    out += np.array([position[0], position[1], position[2], 0.0], dtype=F).tobytes()
+    out += struct.pack("<4I", frame_count, 0, 0, 0)
+    for corner in ((-1, -1, 0, 1), (1, -1, 0, 1), (-1, 1, 0, 1), (1, 1, 0, 1)):   # camera.rs:285-306
+        vs = hm.mat4_mul_vec4(inv_proj, np.array(corner, dtype=F))
+        vs = (vs / vs[3]).astype(F)
+        d = hm._normalize3(vs[:3])
+        out += np.array([d[0], d[1], d[2], 0.0], dtype=F).tobytes()
+    out += np.array([0.0, 0.0, width, height], dtype=F).tobytes()
+    out += np.array([focus_distance, aperture, 0.0, 0.0], dtype=F).tobytes()
+    assert len(out) == 512
+    return bytes(out)
+
+
+def light_bytes(light: dict) -> bytes:
+    """lights.rs:354-473."""
+    f = np.zeros(16, dtype=F)
+    kind = light["kind"]
+    if kind == "directional":
+        f[4:7] = light["direction"]
+        f[8:11] = light["color"]
+        f[11] = light["intensity"]
+        f[12] = 1.0
+    elif kind == "point":
+        f[0:3] = light["position"]
+        f[3] = light["range"]
+        f[8:11] = light["color"]
+        f[11] = light["intensity"]
+        f[12] = 2.0
+    elif kind == "spot":
+        f[0:3] = light["position"]
+        f[3] = light["range"]
+        f[4:7] = light["direction"]
+        f[7] = light["inner_angle"]
+        f[8:11] = light["color"]
+        f[11] = light["intensity"]
+        f[12] = 3.0
+        f[13] = light["outer_angle"]
+    else:
+        raise ValueError(kind)
+    return f.tobytes()
+
+
+def texture_transform_bytes(offset=(0, 0), origin=(0, 0), rotation=0.0, scale=(1, 1)) -> bytes:
+    """textures.rs:247-284."""
+    sx, sy, ox, oy, px, py = (F(v) for v in (scale[0], scale[1], offset[0], offset[1], origin[0], origin[1]))
+    c, s = F(math.cos(float(F(rotation)))), F(math.sin(float(F(rotation))))
+    m00, m01, m10, m11 = c * sx, s * sy, -s * sx, c * sy
+    bx = ox + px - (m00 * px + m01 * py)
+    by = oy + py - (m10 * px + m11 * py)
+    return np.array([m00, m01, m10, m11, bx, by, 0, 0], dtype=F).tobytes()
+
+
+class TexturePool:
+    """renderer-core texture_pool: one texture_2d_array per (w,h,format); layer index = insertion order in the array."""
+
+    def __init__(self):
+        self.arrays: List[dict] = []          # {width,height,layers:[np.ndarray]}
+        self.entries: Dict[int, Tuple[int, int]] = {}   # texture index -> (array_index, layer_index)
+
+    def insert(self, tex_index: int, image: np.ndarray):
+        h, w = image.shape[:2]
+        for ai, a in enumerate(self.arrays):
+            if a["width"] == w and a["height"] == h:
+                a["layers"].append(image)
+                self.entries[tex_index] = (ai, len(a["layers"]) - 1)
+                return
+        self.arrays.append({"width": w, "height": h, "layers": [image]})
+        self.entries[tex_index] = (len(self.arrays) - 1, 0)
+
+
+def encode_address_mode(mode: int) -> int:
+    return mode  # AwsmSampler uses the same 0 clamp / 1 repeat / 2 mirror encoding as writer.rs:53-63
+
+
+class MaterialPacker:
+    def __init__(self, pool: TexturePool, samplers: List[dict], tex_transforms: "TextureTransforms"):
+        self.pool, self.samplers, self.tt = pool, samplers, tex_transforms
+
+    def _tex(self, ref: Optional[TextureRef]) -> bytes:
+        """writer.rs:100-197: 5 words, or 20 zero bytes when absent."""
+        if ref is None or ref.texture not in self.pool.entries:
+            return bytes(20)
+        ai, li = self.pool.entries[ref.texture]
+        arr = self.pool.arrays[ai]
+        smp = self.samplers[ref.sampler]
+        size = (arr["height"] << 16) | (arr["width"] & 0xFFFF)
+        array_and_layer = (li << 12) | (ai & 0xFFF)
+        uv_and_sampler = (ref.sampler << 8) | (ref.uv_index & 0xFF)
+        flags = 1  # exists; bit1 (mipmaps) off: MipmapMode::None configs
+        extra = flags | ((encode_address_mode(smp.get("address_mode_u", 1)) & 0xFF) << 8) | ((encode_address_mode(smp.get("address_mode_v", 1)) & 0xFF) << 16)
+        toff = self.tt.offset_for(ref.transform)
+        return struct.pack("<5I", size, array_and_layer, uv_and_sampler, extra, toff)
+
+    @staticmethod
+    def _f(*v) -> bytes:
+        return np.array(v, dtype=F).tobytes()
+
+    def pbr(self, m: MaterialDesc) -> bytes:
+        """materials/pbr.rs:258-589."""
+        d = bytearray()
+        d += struct.pack("<I", 1)                       # MaterialShaderId::Pbr
+        d += struct.pack("<I", 0) + self._f(0.0)        # alpha_mode Opaque, alpha_cutoff 0
+        d += self._tex(m.base_color_tex) + self._f(*m.base_color_factor)
+        d += self._tex(m.metallic_roughness_tex) + self._f(m.metallic_factor, m.roughness_factor)
+        d += self._tex(m.normal_tex) + self._f(m.normal_scale)
+        d += self._tex(m.occlusion_tex) + self._f(m.occlusion_strength)
+        d += self._tex(m.emissive_tex) + self._f(*m.emissive_factor)
+        d += struct.pack("<I", m.debug_bitmask)
+        indices_offset = len(d)
+        d += bytes(48)
+        fi = [0] * 12
+        cur = lambda: len(d) // 4 - 1   # noqa: E731  (pbr.rs:358-362)
+        if m.vertex_color_set is not None:
+            fi[0] = cur(); d += struct.pack("<I", m.vertex_color_set)
+        if m.emissive_strength is not None:
+            fi[1] = cur(); d += self._f(m.emissive_strength)
+        if m.ior is not None:
+            fi[2] = cur(); d += self._f(m.ior)
+        if m.specular is not None:
+            s = m.specular
+            fi[3] = cur(); d += self._tex(s.get("tex")) + self._f(s.get("factor", 1.0)) + self._tex(s.get("color_tex")) + self._f(*s.get("color_factor", (1, 1, 1)))
+        if m.transmission is not None:
+            s = m.transmission
+            fi[4] = cur(); d += self._tex(s.get("tex")) + self._f(s.get("factor", 0.0))
+        if m.volume is not None:
+            s = m.volume
+            fi[6] = cur(); d += self._tex(s.get("thickness_tex")) + self._f(s.get("thickness_factor", 0.0), s.get("attenuation_distance", 0.0)) + self._f(*s.get("attenuation_color", (1, 1, 1)))
+        if m.clearcoat is not None:
+            s = m.clearcoat
+            fi[7] = cur(); d += (self._tex(s.get("tex")) + self._f(s.get("factor", 0.0)) + self._tex(s.get("roughness_tex")) + self._f(s.get("roughness_factor", 0.0))
+                                 + self._tex(s.get("normal_tex")) + self._f(s.get("normal_scale", 1.0)))
+        if m.sheen is not None:
+            s = m.sheen
+            fi[8] = cur(); d += self._tex(s.get("roughness_tex")) + self._f(s.get("roughness_factor", 0.0)) + self._tex(s.get("color_tex")) + self._f(*s.get("color_factor", (0, 0, 0)))
+        d[indices_offset:indices_offset + 48] = struct.pack("<12I", *fi)
+        return bytes(d)
+
+    def unlit(self, m: MaterialDesc) -> bytes:
+        """materials/unlit.rs:72-105."""
+        d = bytearray()
+        d += struct.pack("<I", 2) + struct.pack("<I", 0) + self._f(0.0)
+        d += self._tex(m.base_color_tex) + self._f(*m.base_color_factor)
+        d += self._tex(m.emissive_tex) + self._f(*m.emissive_factor)
+        return bytes(d)
+
+    def pack(self, m: MaterialDesc) -> bytes:
+        return self.unlit(m) if m.kind == "unlit" else self.pbr(m)
+
+
+class TextureTransforms:
+    """textures.rs:35-37,311-320: DynamicUniformBuffer of 32-B records, identity pre-inserted at slot 0."""
+
+    def __init__(self):
+        self.keys = SlotMap()
+        self.buffer = DynamicUniformBuffer(32, 32)
+        k = self.keys.insert(())
+        self.buffer.update(k, texture_transform_bytes())
+        self.identity_offset = self.buffer.offset(k)
+        self._cache: Dict[tuple, int] = {}
+
+    def offset_for(self, transform: Optional[dict]) -> int:
+        if not transform:
+            return self.identity_offset
+        sig = (tuple(transform.get("offset", (0, 0))), tuple(transform.get("origin", (0, 0))), float(transform.get("rotation", 0.0)),
+               tuple(transform.get("scale", (1, 1))))
+        if sig not in self._cache:
+            k = self.keys.insert(())
+            self.buffer.update(k, texture_transform_bytes(*sig))
+            self._cache[sig] = self.buffer.offset(k)
+        return self._cache[sig]
+
+
+MESH_META_INITIAL_CAPACITY = 512
+INDICES_INITIAL_SIZE = MESH_META_INITIAL_CAPACITY * 3 * 1000
+
+
+@dataclass
+class MeshRec:
+    transform_key: tuple
+    material_key: tuple
+    double_sided: bool
+    local_aabb: Aabb
+    world_aabb: Optional[Aabb]
+    tri_count: int
+    resource_key: tuple
+    hidden: bool = False
+    hud: bool = False
+
+
+class HostModel:
+    """The reference's AwsmRenderer state for the hot path, fed by a SceneDesc (populate_gltf order)."""
+
+    def __init__(self, scene: SceneDesc):
+        self.scene = scene
+        self.transforms = Transforms()
+        self.tex_transforms = TextureTransforms()
+        self.pool = TexturePool()
+        for i, t in enumerate(scene.textures):
+            self.pool.insert(i, t)
+        self.mat_packer = MaterialPacker(self.pool, scene.samplers, self.tex_transforms)
+        self.materials_keys = SlotMap()
+        self.materials = DynamicStorageBuffer(8192)
+        self.material_keys_by_index: Dict[int, tuple] = {}
+        # meshes.rs:353-364
+        self.vis_data = DynamicStorageBuffer(INDICES_INITIAL_SIZE * 56)
+        self.vis_index = DynamicStorageBuffer(INDICES_INITIAL_SIZE)
+        self.attr_data = DynamicStorageBuffer(INDICES_INITIAL_SIZE * 16)
+        self.attr_index = DynamicStorageBuffer(INDICES_INITIAL_SIZE)
+        self.geom_meta = DynamicUniformBuffer(MESH_META_INITIAL_CAPACITY, 40, 256)
+        self.material_meta = DynamicUniformBuffer(MESH_META_INITIAL_CAPACITY, 68, 256)
+        self.resources = SlotMap()
+        self.meshes = SlotMap()            # DenseSlotMap<MeshKey, Mesh>
+        self.transform_to_meshes: Dict[tuple, List[tuple]] = {}
+        # skins.rs:40-42 / morphs.rs:84-86
+        self.skin_keys = SlotMap()
+        self.skin_matrices = DynamicStorageBuffer(16 * 4 * 32)
+        self.skin_index_weights = DynamicStorageBuffer(4096 * 2)
+        self.skin_joints: Dict[tuple, List[tuple]] = {}
+        self.inverse_bind: Dict[tuple, np.ndarray] = {}
+        self.skin_sets: Dict[tuple, int] = {}
+        self.morph_keys = SlotMap()
+        self.morph_weights = DynamicStorageBuffer(4096)
+        self.morph_values = DynamicStorageBuffer(4096)
+        self.morph_targets_len: Dict[tuple, int] = {}
+        self.light_list = list(scene.lights)
+        self.frame_count = 0
+        self.camera_bytes = bytes(512)
+        self._populate()
+
+    # ---- populate_gltf order: transforms -> skins -> meshes ----
+    def _populate(self):
+        sc = self.scene
+        self.node_keys: List[Optional[tuple]] = [None] * len(sc.nodes)
+        children: Dict[Optional[int], List[int]] = {}
+        for i, n in enumerate(sc.nodes):
+            children.setdefault(n.parent, []).append(i)
+
+        def add_transform(i, parent_key):
+            n = sc.nodes[i]
+            self.node_keys[i] = self.transforms.insert((n.translation, n.rotation, n.scale), parent_key)
+            for c in children.get(i, []):
+                add_transform(c, self.node_keys[i])
+
+        for r in children.get(None, []):
+            add_transform(r, None)
+
+        joint_nodes = set()
+        for sk in sc.skins:
+            joint_nodes.update(sk.joints)
+
+        def add_meshes(i):
+            n = sc.nodes[i]
+            if n.primitives:
+                tk = self.node_keys[i]
+                if i in joint_nodes:   # populate/mesh.rs:36-52
+                    tk = self.transforms.insert(((0, 0, 0), (0, 0, 0, 1), (1, 1, 1)), self.transforms.get_parent(tk))
+                for p in n.primitives:
+                    self._add_primitive(p, tk, n.skin)
+            for c in children.get(i, []):
+                add_meshes(c)
+
+        for r in children.get(None, []):
+            add_meshes(r)
+
+    def _add_primitive(self, p: PrimitiveDesc, transform_key, skin_index):
+        sc = self.scene
+        V = p.positions.shape[0]
+        morph_key = None
+        if p.morph_targets:
+            morph_key = self.morph_keys.insert(())
+            weights = np.asarray(p.morph_weights if p.morph_weights is not None else np.zeros(len(p.morph_targets)), dtype=F)
+            self.morph_weights.update(morph_key, weights.tobytes())                   # morphs.rs:148-170 insert_raw
+            self.morph_values.update(morph_key, convert_morph_targets(p.morph_targets, V))
+            self.morph_targets_len[morph_key] = len(p.morph_targets)
+            if p.animated_morph_weights is not None:                                  # morphs.rs:197-217: [1..n+1)
+                aw = np.asarray(p.animated_morph_weights, dtype=F).tobytes()
+
+                def fn(_, view, aw=aw):
+                    view[4:4 + len(aw)] = aw
+
+                self.morph_weights.update_with_unchecked(morph_key, fn)
+        skin_key = None
+        if skin_index is not None and p.joints:
+            sk = sc.skins[skin_index]
+            joints = [self.node_keys[j] for j in sk.joints]
+            fill = bytearray()
+            for j, jk in enumerate(joints):
+                m = np.asarray(sk.inverse_bind[j], dtype=F)
+                fill += m.tobytes()
+                self.inverse_bind[jk] = m
+            skin_key = self.skin_keys.insert(())
+            self.skin_joints[skin_key] = joints
+            self.skin_matrices.update(skin_key, bytes(fill))                          # skins.rs:84-143
+            self.skin_sets[skin_key] = len(p.joints)
+            self.skin_index_weights.update(skin_key, convert_skin(p.joints, p.weights))
+        if p.material not in self.material_keys_by_index:
+            mk = self.materials_keys.insert(())
+            self.materials.update(mk, self.mat_packer.pack(sc.materials[p.material]))
+            self.material_keys_by_index[p.material] = mk
+        material_key = self.material_keys_by_index[p.material]
+        mdesc = sc.materials[p.material]
+
+        vis = create_visibility_vertices(p.positions, p.normals, p.tangents, p.indices)
+        attr, stride = pack_vertex_attributes(p.colors, p.uvs)
+        T = int(np.asarray(p.indices).reshape(-1, 3).shape[0])
+        rk = self.resources.insert(())
+        self.vis_index.update(rk, np.arange(T * 3, dtype=np.uint32).tobytes())        # meshes.rs:514-520
+        vis_off = self.vis_data.update(rk, vis)
+        attr_index_off = self.attr_index.update(rk, np.asarray(p.indices, dtype=np.uint32).tobytes())
+        attr_data_off = self.attr_data.update(rk, attr)
+        local = Aabb(p.positions.min(axis=0), p.positions.max(axis=0))
+        rec = MeshRec(transform_key, material_key, mdesc.double_sided, local, Aabb(local.min, local.max), T, rk)
+        mesh_key = self.meshes.insert(rec)
+        self.transform_to_meshes.setdefault(transform_key, []).append(mesh_key)
+        rec.vis_off, rec.skin_key, rec.morph_key = vis_off, skin_key, morph_key
+
+        # meta.rs:89-146: material meta first, then geometry meta
+        hi, lo = key_as_ffi(mesh_key) >> 32, key_as_ffi(mesh_key) & 0xFFFFFFFF
+        uv_sets_index = sum(4 for _ in p.colors)
+        mm = struct.pack("<17I", hi, lo, 0, 0, 0, 0, self.materials.offset(material_key), self.transforms.buffer.offset(transform_key),
+                         self.transforms.normals_buffer.offset(transform_key), attr_index_off, attr_data_off, stride, uv_sets_index,
+                         len(p.uvs), len(p.colors), vis_off, 0)
+        self.material_meta.update(mesh_key, mm)
+        if morph_key is not None:
+            morph = (self.morph_targets_len[morph_key], self.morph_weights.offset(morph_key), self.morph_values.offset(morph_key))
+        else:
+            morph = (0, 0, 0)
+        if skin_key is not None:
+            skin = (self.skin_sets[skin_key], self.skin_matrices.offset(skin_key), self.skin_index_weights.offset(skin_key))
+        else:
+            skin = (0, 0, 0)
+        gm = struct.pack("<10I", hi, lo, *morph, *skin, self.transforms.buffer.offset(transform_key), self.material_meta.offset(mesh_key))
+        self.geom_meta.update(mesh_key, gm)
+
+    # ---- update_all (update.rs:8-18) ----
+    def update_transforms(self):
+        self.transforms.update_world()
+        dirty = self.transforms.take_dirty_meshes()
+        for tk, world in dirty.items():
+            for mk in self.transform_to_meshes.get(tk, []):
+                rec = self.meshes.get(mk)
+                rec.world_aabb = rec.local_aabb.transformed(world)
+        for sk, joints in self.skin_joints.items():       # skins.rs:162-194
+            for index, jk in enumerate(joints):
+                if jk in dirty:
+                    wm = dirty[jk]
+                    if jk in self.inverse_bind:
+                        wm = hm.mat4_mul(wm, self.inverse_bind[jk])
+                    b = wm.astype(F).tobytes()
+
+                    def fn(_, view, b=b, index=index):
+                        view[index * 64:index * 64 + 64] = b
+
+                    self.skin_matrices.update_with_unchecked(sk, fn)
+
+    def update_camera(self):
+        sc = self.scene
+        self.camera_bytes = camera_ubo(sc.view, sc.proj, sc.camera_position, self.frame_count, float(sc.width), float(sc.height))
+
+    # ---- renderable.rs:38-150 ----
+    def collect_draws(self) -> List[dict]:
+        sc = self.scene
+        view_proj = hm.mat4_mul(np.asarray(sc.proj, dtype=F), np.asarray(sc.view, dtype=F))
+        frustum = Frustum(view_proj)
+        opaque = []
+        for mk, rec in self.meshes.items():
+            if rec.hidden:
+                continue
+            if rec.world_aabb is not None and not frustum.intersects_aabb(rec.world_aabb):
+                continue
+            opaque.append((mk, rec))
+
+        def pipeline_rank(rec):   # G/pipeline.rs:179-265 creation order: no_cull < back_cull
+            return 0 if rec.double_sided else 1
+
+        def closest(rec):
+            a = hm.mat4_transform_point3(view_proj, rec.world_aabb.min)[2]
+            b = hm.mat4_transform_point3(view_proj, rec.world_aabb.max)[2]
+            return min(a, b)
+
+        def total_key(x):   # f32::total_cmp
+            b = struct.unpack("<i", struct.pack("<f", float(x)))[0]
+            return b ^ ((b >> 31) & 0x7FFFFFFF)
+
+        def cmp(a, b):
+            ra, rb = pipeline_rank(a[1]), pipeline_rank(b[1])
+            if ra != rb:
+                return -1 if ra < rb else 1
+            ka, kb = total_key(closest(a[1])), total_key(closest(b[1]))
+            return -1 if ka < kb else (1 if ka > kb else 0)
+
+        opaque.sort(key=functools.cmp_to_key(cmp))   # Python's sort is stable, like slice::sort_by
+        draws = []
+        for mk, rec in opaque:
+            draws.append({"geom_meta_off": self.geom_meta.offset(mk), "vis_data_off": rec.vis_off, "tri_count": rec.tri_count,
+                          "flags": 0 if rec.double_sided else 1, "mesh_key": mk})
+        return draws
+
+    # ---- mirrors as the device must see them ----
+    def lights_bytes(self) -> bytes:
+        return b"".join(light_bytes(l) for l in self.light_list)
+
+    def lights_info_bytes(self) -> bytes:
+        return struct.pack("<4I", len(self.light_list), self.scene.prefiltered_mip_count, self.scene.irradiance_mip_count, 0)
+
+    def mirrors(self) -> Dict[int, bytes]:
+        lights = self.lights_bytes()
+        return {
+            BUF_TRANSFORMS: bytes(self.transforms.buffer.raw), BUF_NORMAL_MATS: bytes(self.transforms.normals_buffer.raw),
+            BUF_MATERIALS: bytes(self.materials.raw), BUF_LIGHTS: lights if lights else bytes(64), BUF_LIGHTS_INFO: self.lights_info_bytes(),
+            BUF_CAMERA: self.camera_bytes, BUF_SKIN_MATRICES: bytes(self.skin_matrices.raw),
+            BUF_SKIN_INDEX_WEIGHTS: bytes(self.skin_index_weights.raw), BUF_MORPH_WEIGHTS: bytes(self.morph_weights.raw),
+            BUF_MORPH_VALUES: bytes(self.morph_values.raw), BUF_GEOM_META: bytes(self.geom_meta.raw),
+            BUF_MATERIAL_META: bytes(self.material_meta.raw), BUF_VIS_GEOM_DATA: bytes(self.vis_data.raw),
+            BUF_VIS_GEOM_INDEX: bytes(self.vis_index.raw), BUF_ATTR_DATA: bytes(self.attr_data.raw), BUF_ATTR_INDEX: bytes(self.attr_index.raw),
+            BUF_TEXTURE_TRANSFORMS: bytes(self.tex_transforms.buffer.raw),
+        }
+
+    def texture_arrays(self) -> List[dict]:
+        out = []
+        for a in self.pool.arrays:
+            out.append({"width": a["width"], "height": a["height"], "layers": len(a["layers"]),
+                        "texels": np.ascontiguousarray(np.stack(a["layers"]).astype(np.uint8))})
+        return out

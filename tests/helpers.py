@@ -1,0 +1,70 @@
+"""Shared helpers for the parity tests (test infrastructure: may use oracle/)."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import oracle_lib, scene_model
+
+NO_HIT = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def build_model(scene):
+    m = scene_model.HostModel(scene)
+    m.update_transforms()
+    m.update_camera()
+    return m
+
+
+def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8):
+    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque).run(threads)
+
+
+def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None):
+    """Drive one frame through the C-ABI exactly as the host layer does: create+write every mirror, then the passes."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    sc = model.scene
+    dev = dev or HipDevice(parity_tap=True)
+    dev.resize(sc.width, sc.height, 0)
+    dev.upload_mirrors(model.mirrors())
+    for i, t in enumerate(model.texture_arrays()):
+        dev.texture_array_upload(i, t["texels"])
+    for i, s in enumerate(sc.samplers):
+        dev.sampler_set(i, s)
+    dev.env_upload(sc.skybox_rgba, sc.prefiltered_rgb, sc.irradiance_rgb, oracle_lib.lut_rg_to_rgba16f(lut))
+    if rows != (0, 0):
+        dev.set_shard_rows(*rows)
+    draws = model.collect_draws()
+    dev.geometry_pass(draws)
+    dev.opaque_pass(has_opaque=has_opaque)
+    stats = dev.frame_end()
+    return dev, stats
+
+
+def f16_ulp_distance(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
+    """distance in representable f16 values (sign-magnitude -> monotonic integer)"""
+    def mono(x):
+        x = x.astype(np.int32)
+        return np.where(x & 0x8000, -(x & 0x7FFF), x & 0x7FFF)
+    return np.abs(mono(a_bits) - mono(b_bits))
+
+
+def compare_frames(orc, dev, rows=None, rgb_tol=1e-4):
+    """Returns a dict of mismatch counts / max errors between an OracleFrame and a HipDevice frame."""
+    H = orc.height
+    y0, y1 = rows if rows else (0, H)
+    out = {}
+    clip, nt = dev.read_transformed(orc.n_verts)
+    out["clip_mismatch"] = int((clip.view(np.uint32) != orc.clip.view(np.uint32)).any(axis=1).sum()) if orc.n_verts else 0
+    out["nt_mismatch"] = int((nt.view(np.uint32) != orc.nt.view(np.uint32)).any(axis=1).sum()) if orc.n_verts else 0
+    keys = dev.read_visibility()
+    out["key_mismatch"] = int((keys[y0:y1] != orc.keys[y0:y1]).sum())
+    out["covered"] = int((orc.keys[y0:y1] != NO_HIT).sum())
+    f32 = dev.read_opaque_f32()
+    diff = np.abs(f32[y0:y1].astype(np.float64) - orc.rgba32f[y0:y1].astype(np.float64))
+    diff = np.where(np.isfinite(diff), diff, np.inf)
+    out["rgb_max_abs"] = float(diff[..., :3].max()) if diff.size else 0.0
+    out["rgb_over_tol"] = int((diff[..., :3] > rgb_tol).any(axis=-1).sum())
+    out["alpha_mismatch"] = int((f32[y0:y1, :, 3] != orc.rgba32f[y0:y1, :, 3]).sum())
+    h16 = dev.read_opaque()
+    out["f16_max_ulp"] = int(f16_ulp_distance(h16[y0:y1], orc.rgba16f[y0:y1]).max()) if h16.size else 0
+    return out
