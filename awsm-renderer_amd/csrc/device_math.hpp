@@ -36,14 +36,14 @@ AWSM_DI f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 AWSM_DI f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 AWSM_DI float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 AWSM_DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-AWSM_DI float length(f3 a) { return __fsqrt_rn(dot(a, a)); }
+AWSM_DI float length(f3 a) { return sqrtf(dot(a, a)); }
 AWSM_DI f3 normalize(f3 a) { return a / length(a); }
 AWSM_DI float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 AWSM_DI f3 mix3(f3 a, f3 b, float t) { float s = 1.0f - t; return {a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t}; }
 AWSM_DI f3 min3(f3 a, f3 b) { return {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
 AWSM_DI float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 AWSM_DI float saturate(float x) { return clampf(x, 0.0f, 1.0f); }
-AWSM_DI float inverse_sqrt(float x) { return 1.0f / __fsqrt_rn(x); }
+AWSM_DI float inverse_sqrt(float x) { return 1.0f / sqrtf(x); }
 AWSM_DI float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 AWSM_DI f4 mul(const m4& m, f4 v) {

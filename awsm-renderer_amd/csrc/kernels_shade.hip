@@ -568,15 +568,15 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t* __restrict__ out_rg1
     const float uvx = ((float)i + 0.5f) / (float)width, uvy = 1.0f - ((float)j + 0.5f) / (float)height;
     const float no_v = clampf(uvx, 1e-3f, 1.0f - 1e-3f);
     const float roughness = clampf(uvy, 1e-3f, 1.0f - 1e-3f);
-    const f3 v = {__fsqrt_rn(fmaxf(0.0f, 1.0f - no_v * no_v)), 0.0f, no_v};
+    const f3 v = {sqrtf(fmaxf(0.0f, 1.0f - no_v * no_v)), 0.0f, no_v};
     const float alpha = roughness * roughness;
     float a = 0.0f, bsum = 0.0f;
     for (uint32_t s = 0; s < 1024u; s++) {
         const float xi_x = (float)s / 1024.0f, xi_y = radical_inverse_vdc(s);
         const float a2 = alpha * alpha;
         const float phi = 6.28318530718f * xi_x;
-        const float cos_theta = __fsqrt_rn((1.0f - xi_y) / (1.0f + (a2 - 1.0f) * xi_y));
-        const float sin_theta = __fsqrt_rn(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+        const float cos_theta = sqrtf((1.0f - xi_y) / (1.0f + (a2 - 1.0f) * xi_y));
+        const float sin_theta = sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
         const f3 h = {cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta};
         const float vdh = dot(v, h);
         const f3 l = normalize(h * (2.0f * vdh) - v);
