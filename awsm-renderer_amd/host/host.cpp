@@ -1,0 +1,983 @@
+// host.cpp — C++ host layer: the reference's key-based scene API + dirty-upload semantics over the C-ABI.
+//
+// Mirrors, for the hot path only (paths relative to /root/reference/crates/renderer/src/):
+//   transforms.rs:43-446          Transforms (TRS tree, dirty propagation, world mat4 + normal mat3 mirrors)
+//   camera.rs:111-227,285-306     CameraBuffer::update
+//   lights.rs:160-310,354-473     Lights
+//   textures.rs:226-320           texture transforms (identity slot), pool bookkeeping
+//   materials.rs:60-241, materials/{pbr,unlit,writer}.rs   material word streams in a DynamicStorageBuffer
+//   meshes.rs:317-674,872-939,1241-1346   Meshes (4 hot-path DynamicStorageBuffers), update_world, write_gpu
+//   meshes/meta.rs, meta/{geometry,material}_meta.rs       40-B / 68-B metas in 256-B slots
+//   meshes/skins.rs:84-194, meshes/morphs.rs:121-217
+//   gltf/buffers/mesh/visibility.rs:35-165, attributes.rs:113-160, skin.rs:22-113, morph.rs:31-190   packers
+//   renderable.rs:38-150, frustum.rs:42-89, bounds.rs:38-61   cull + sort -> draw list
+//   render.rs:71-97,144-221,370   write_gpu order, geometry pass, opaque pass, submit
+//   buffer/helpers.rs:124-220     write_buffer_with_dirty_ranges
+// The device is reached only through the awsm_hip_* C-ABI, resolved with dlsym from the backend library.
+#include "../../include/awsm_host.h"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "buffers.hpp"
+#include "glam.hpp"
+
+using namespace awsm_host;
+
+namespace {
+
+struct Backend {
+    void* dl = nullptr;
+    int (*create)(const AwsmConfig*, AwsmHipCtx**) = nullptr;
+    int (*destroy)(AwsmHipCtx*) = nullptr;
+    const char* (*last_error)(const AwsmHipCtx*) = nullptr;
+    uint32_t (*abi_version)(void) = nullptr;
+    int (*buffer_create)(AwsmHipCtx*, AwsmBuf, size_t) = nullptr;
+    int (*buffer_write)(AwsmHipCtx*, AwsmBuf, size_t, const void*, size_t) = nullptr;
+    int (*resize)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t) = nullptr;
+    int (*set_shard_rows)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
+    int (*texture_array_upload)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, AwsmTexFormat, const void*) = nullptr;
+    int (*sampler_set)(AwsmHipCtx*, uint32_t, const AwsmSampler*) = nullptr;
+    int (*env_upload)(AwsmHipCtx*, const AwsmEnv*) = nullptr;
+    int (*brdf_lut_generate)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
+    int (*geometry_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
+    int (*opaque_pass)(AwsmHipCtx*, const AwsmOpaqueParams*) = nullptr;
+    int (*frame_end)(AwsmHipCtx*, AwsmFrameStats*) = nullptr;
+};
+
+struct Transform { Vec3 t; Quat r; Vec3 s; };
+struct Aabb { Vec3 min, max; };
+
+Aabb aabb_transformed(const Aabb& a, const Mat4& m) {   // bounds.rs:38-61
+    const Vec3 mn = a.min, mx = a.max;
+    const Vec3 corners[8] = {{mn.x, mn.y, mn.z}, {mx.x, mn.y, mn.z}, {mn.x, mx.y, mn.z}, {mx.x, mx.y, mn.z},
+                             {mn.x, mn.y, mx.z}, {mx.x, mn.y, mx.z}, {mn.x, mx.y, mx.z}, {mx.x, mx.y, mx.z}};
+    Vec3 first = mat4_transform_point3(m, corners[0]);
+    Aabb out{first, first};
+    for (int i = 1; i < 8; i++) {
+        Vec3 t = mat4_transform_point3(m, corners[i]);
+        out.min = v3_min(out.min, t);
+        out.max = v3_max(out.max, t);
+    }
+    return out;
+}
+
+struct Plane { Vec3 n; float d; };
+struct Frustum {   // frustum.rs:42-89
+    Plane planes[6];
+    explicit Frustum(const Mat4& vp) {
+        const Vec4 row0 = {vp.c[0].x, vp.c[1].x, vp.c[2].x, vp.c[3].x}, row1 = {vp.c[0].y, vp.c[1].y, vp.c[2].y, vp.c[3].y};
+        const Vec4 row2 = {vp.c[0].z, vp.c[1].z, vp.c[2].z, vp.c[3].z}, row3 = {vp.c[0].w, vp.c[1].w, vp.c[2].w, vp.c[3].w};
+        const Vec4 raw[6] = {v4_add(row3, row0), v4_sub(row3, row0), v4_add(row3, row1), v4_sub(row3, row1), row2, v4_sub(row3, row2)};
+        for (int i = 0; i < 6; i++) {
+            Vec3 n = {raw[i].x, raw[i].y, raw[i].z};
+            float d = raw[i].w;
+            const float len = std::sqrt((n.x * n.x + n.y * n.y) + n.z * n.z);
+            if (len > 0.0f) { n = {n.x / len, n.y / len, n.z / len}; d = d / len; }
+            planes[i] = {n, d};
+        }
+    }
+    bool intersects(const Aabb& a) const {
+        for (const Plane& p : planes) {
+            const Vec3 pt = {p.n.x >= 0.0f ? a.max.x : a.min.x, p.n.y >= 0.0f ? a.max.y : a.min.y, p.n.z >= 0.0f ? a.max.z : a.min.z};
+            if (v3_dot(p.n, pt) + p.d < 0.0f) return false;
+        }
+        return true;
+    }
+};
+
+void push_f32(std::vector<uint8_t>& d, float v) { uint8_t b[4]; memcpy(b, &v, 4); d.insert(d.end(), b, b + 4); }
+void push_u32(std::vector<uint8_t>& d, uint32_t v) { uint8_t b[4]; memcpy(b, &v, 4); d.insert(d.end(), b, b + 4); }
+
+struct MeshRec {
+    SlotKey transform_key = 0, material_key = 0, resource_key = 0, skin_key = 0, morph_key = 0;
+    bool double_sided = false, hidden = false, hud = false, has_world_aabb = true;
+    Aabb local_aabb{}, world_aabb{};
+    uint32_t tri_count = 0;
+    size_t vis_off = 0;
+};
+
+}  // namespace
+
+struct AwsmHost {
+    Backend be;
+    AwsmHipCtx* ctx = nullptr;
+    std::string last_error;
+
+    // ---- transforms.rs ----
+    SlotMap<Transform> locals;
+    std::unordered_map<SlotKey, Mat4> world;
+    std::unordered_map<SlotKey, std::vector<SlotKey>> children;
+    std::unordered_map<SlotKey, SlotKey> parents;
+    std::unordered_set<SlotKey> dirties;
+    std::vector<SlotKey> dirty_meshes;
+    bool transforms_gpu_dirty = true;
+    SlotKey root = 0;
+    DynamicUniformBuffer transforms_buf{32, 64};
+    DynamicUniformBuffer normals_buf{32, 36};
+
+    // ---- textures.rs ----
+    struct PoolArray { uint32_t w, h; std::vector<uint8_t> texels; uint32_t layers = 0; bool dirty = true; };
+    std::vector<PoolArray> pool;
+    std::vector<std::pair<uint32_t, uint32_t>> tex_entries;   // texture id -> (array, layer)
+    std::vector<AwsmSampler> samplers;
+    SlotMap<int> tex_transform_keys;
+    DynamicUniformBuffer tex_transforms_buf{32, 32};
+    size_t tex_transform_identity_offset = 0;
+    bool tex_transforms_dirty = true;
+
+    // ---- materials.rs ----
+    SlotMap<AwsmHostMaterial> materials;
+    DynamicStorageBuffer materials_buf{8192};
+    bool materials_dirty = true;
+
+    // ---- lights.rs ----
+    SlotMap<AwsmHostLight> lights;
+    size_t punctual_gpu_size = 64;
+    bool punctual_dirty = true, lights_info_dirty = true, lights_created = false, lights_info_created = false;
+    uint32_t prefiltered_mips = 9, irradiance_mips = 9;
+
+    // ---- meshes.rs / meta / skins / morphs ----
+    static constexpr size_t kIndicesInitial = 512 * 3 * 1000;
+    SlotMap<MeshRec> meshes;              // DenseSlotMap<MeshKey, Mesh>
+    SlotMap<int> resources;
+    std::unordered_map<SlotKey, std::vector<SlotKey>> transform_to_meshes;
+    DynamicStorageBuffer vis_data{kIndicesInitial * 56}, vis_index{kIndicesInitial}, attr_data{kIndicesInitial * 16}, attr_index{kIndicesInitial};
+    bool vis_data_dirty = true, vis_index_dirty = true, attr_data_dirty = true, attr_index_dirty = true;
+    DynamicUniformBuffer geom_meta{512, 40, 256}, material_meta{512, 68, 256};
+    bool geom_meta_dirty = true, material_meta_dirty = true;
+    SlotMap<std::vector<SlotKey>> skins;   // skeleton joint transforms
+    std::unordered_map<SlotKey, Mat4> inverse_bind;
+    std::unordered_map<SlotKey, uint32_t> skin_sets;
+    DynamicStorageBuffer skin_matrices{16 * 4 * 32}, skin_index_weights{4096 * 2};
+    bool skin_matrices_dirty = true, skin_iw_dirty = true;
+    SlotMap<uint32_t> morphs;             // targets_len
+    DynamicStorageBuffer morph_weights{4096}, morph_values{4096};
+    bool morph_weights_dirty = true, morph_values_dirty = true;
+
+    // ---- camera.rs ----
+    uint8_t camera_raw[512] = {};
+    bool camera_dirty = true, camera_created = false, have_camera = false;
+    Mat4 cam_view = mat4_identity(), cam_proj = mat4_identity();
+    uint32_t frame_count = 0;
+    uint32_t width = 0, height = 0;
+
+    bool created[AWSM_BUF_COUNT] = {};
+    uint64_t upload_bytes = 0;
+    std::vector<AwsmDraw> last_draws;
+};
+
+namespace {
+
+int fail(AwsmHost* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->last_error = buf;
+    return code;
+}
+
+int dev_fail(AwsmHost* h, int rc, const char* where) {
+    return fail(h, rc, "%s: %s", where, h->be.last_error ? h->be.last_error(h->ctx) : "device error");
+}
+
+// ---- write_gpu for a mirror with dirty ranges (e.g. transforms.rs:255-328, meshes.rs:1241-1346) ----
+template <typename Buf>
+int flush_buffer(AwsmHost* h, Buf& b, AwsmBuf which, bool& dirty) {
+    if (!dirty) return AWSM_OK;
+    bool resized = false;
+    long long new_size = b.take_gpu_needs_resize();
+    if (new_size >= 0 || !h->created[which]) {
+        int rc = h->be.buffer_create(h->ctx, which, b.raw().size());   // gpu.create_buffer: replaces the old buffer wholesale
+        if (rc) return dev_fail(h, rc, "buffer_create");
+        h->created[which] = true;
+        resized = true;
+    }
+    if (resized) {
+        b.clear_dirty_ranges();
+        if (!b.raw().empty()) {
+            int rc = h->be.buffer_write(h->ctx, which, 0, b.raw().data(), b.raw().size());
+            if (rc) return dev_fail(h, rc, "buffer_write(full)");
+            h->upload_bytes += b.raw().size();
+        }
+    } else {
+        for (const DirtyRange& r : write_plan(b.raw().size(), b.take_dirty_ranges())) {
+            int rc = h->be.buffer_write(h->ctx, which, r.first, b.raw().data() + r.first, r.second);
+            if (rc) return dev_fail(h, rc, "buffer_write(range)");
+            h->upload_bytes += r.second;
+        }
+    }
+    dirty = false;
+    return AWSM_OK;
+}
+
+Mat4 to_matrix(const Transform& t) { return mat4_from_srt(t.s, t.r, t.t); }
+
+void unset_parent(AwsmHost* h, SlotKey child) {
+    auto it = h->parents.find(child);
+    if (it == h->parents.end()) return;
+    auto& ch = h->children[it->second];
+    ch.erase(std::remove(ch.begin(), ch.end(), child), ch.end());
+    h->parents.erase(it);
+}
+
+void set_parent(AwsmHost* h, SlotKey child, SlotKey parent) {   // transforms.rs:196-216
+    if (child == h->root) return;
+    if (parent == 0) parent = h->root;
+    auto it = h->parents.find(child);
+    if (it != h->parents.end()) {
+        if (it->second == parent) return;
+        unset_parent(h, child);
+    }
+    h->children[parent].push_back(child);
+    h->parents[child] = parent;
+}
+
+bool update_inner(AwsmHost* h, SlotKey key, bool dirty_tracker) {   // transforms.rs:390-435
+    const bool dirty = h->dirties.count(key) != 0 || dirty_tracker;
+    if (dirty) {
+        const Mat4 local = to_matrix(*h->locals.get(key));
+        Mat4 w = local;
+        auto pit = h->parents.find(key);
+        if (pit != h->parents.end()) w = mat4_mul(h->world[pit->second], local);
+        h->world[key] = w;
+        h->transforms_buf.update(key, reinterpret_cast<const uint8_t*>(&w), 64);
+        const Mat4 nm = mat4_transpose(mat4_inverse(w));
+        const float n9[9] = {nm.c[0].x, nm.c[0].y, nm.c[0].z, nm.c[1].x, nm.c[1].y, nm.c[1].z, nm.c[2].x, nm.c[2].y, nm.c[2].z};
+        h->normals_buf.update(key, reinterpret_cast<const uint8_t*>(n9), 36);
+        h->dirty_meshes.push_back(key);
+    }
+    const std::vector<SlotKey> kids = h->children[key];
+    for (SlotKey c : kids) update_inner(h, c, dirty);
+    return dirty;
+}
+
+// ---- writer.rs:100-197 ----
+void write_tex(AwsmHost* h, std::vector<uint8_t>& d, const AwsmHostTexRef& r) {
+    if (r.texture < 0 || (size_t)r.texture >= h->tex_entries.size() || r.sampler >= h->samplers.size()) {
+        d.insert(d.end(), 20, 0);   // Value::SkipTexture
+        return;
+    }
+    const auto [ai, li] = h->tex_entries[r.texture];
+    const AwsmHost::PoolArray& arr = h->pool[ai];
+    const AwsmSampler& smp = h->samplers[r.sampler];
+    push_u32(d, (arr.h << 16) | (arr.w & 0xFFFFu));
+    push_u32(d, (li << 12) | (ai & 0xFFFu));
+    push_u32(d, (r.sampler << 8) | (r.uv_index & 0xFFu));
+    const uint32_t flags = 1u;   // exists; mip bit stays clear (MipmapMode::None)
+    push_u32(d, flags | ((smp.address_mode_u & 0xFFu) << 8) | ((smp.address_mode_v & 0xFFu) << 16));
+    long long toff = r.transform ? h->tex_transforms_buf.offset(r.transform) : -1;
+    push_u32(d, (uint32_t)(toff >= 0 ? (size_t)toff : h->tex_transform_identity_offset));
+}
+
+std::vector<uint8_t> material_bytes(AwsmHost* h, const AwsmHostMaterial& m) {
+    std::vector<uint8_t> d;
+    d.reserve(256);
+    if (m.shader == 2u) {   // unlit.rs:72-105
+        push_u32(d, 2u); push_u32(d, 0u); push_f32(d, 0.0f);
+        write_tex(h, d, m.base_color_tex);
+        for (int i = 0; i < 4; i++) push_f32(d, m.base_color_factor[i]);
+        write_tex(h, d, m.emissive_tex);
+        for (int i = 0; i < 3; i++) push_f32(d, m.emissive_factor[i]);
+        return d;
+    }
+    // pbr.rs:258-589
+    push_u32(d, 1u); push_u32(d, 0u); push_f32(d, 0.0f);   // shader id, alpha_mode Opaque, alpha_cutoff
+    write_tex(h, d, m.base_color_tex);
+    for (int i = 0; i < 4; i++) push_f32(d, m.base_color_factor[i]);
+    write_tex(h, d, m.metallic_roughness_tex);
+    push_f32(d, m.metallic_factor); push_f32(d, m.roughness_factor);
+    write_tex(h, d, m.normal_tex); push_f32(d, m.normal_scale);
+    write_tex(h, d, m.occlusion_tex); push_f32(d, m.occlusion_strength);
+    write_tex(h, d, m.emissive_tex);
+    for (int i = 0; i < 3; i++) push_f32(d, m.emissive_factor[i]);
+    push_u32(d, m.debug_bitmask);
+    const size_t indices_offset = d.size();
+    d.insert(d.end(), 48, 0);
+    uint32_t fi[12] = {};
+    auto cur = [&]() { return (uint32_t)(d.size() / 4 - 1); };   // pbr.rs:358-362: word index relative to the header
+    if (m.has_vertex_color) { fi[0] = cur(); push_u32(d, m.vertex_color_set); }
+    if (m.has_emissive_strength) { fi[1] = cur(); push_f32(d, m.emissive_strength); }
+    if (m.has_ior) { fi[2] = cur(); push_f32(d, m.ior); }
+    if (m.has_specular) {
+        fi[3] = cur();
+        write_tex(h, d, m.specular_tex); push_f32(d, m.specular_factor); write_tex(h, d, m.specular_color_tex);
+        for (int i = 0; i < 3; i++) push_f32(d, m.specular_color_factor[i]);
+    }
+    if (m.has_transmission) { fi[4] = cur(); write_tex(h, d, m.transmission_tex); push_f32(d, m.transmission_factor); }
+    if (m.has_volume) {
+        fi[6] = cur();
+        write_tex(h, d, m.volume_thickness_tex); push_f32(d, m.volume_thickness_factor); push_f32(d, m.volume_attenuation_distance);
+        for (int i = 0; i < 3; i++) push_f32(d, m.volume_attenuation_color[i]);
+    }
+    if (m.has_clearcoat) {
+        fi[7] = cur();
+        write_tex(h, d, m.clearcoat_tex); push_f32(d, m.clearcoat_factor);
+        write_tex(h, d, m.clearcoat_roughness_tex); push_f32(d, m.clearcoat_roughness_factor);
+        write_tex(h, d, m.clearcoat_normal_tex); push_f32(d, m.clearcoat_normal_scale);
+    }
+    if (m.has_sheen) {
+        fi[8] = cur();
+        write_tex(h, d, m.sheen_roughness_tex); push_f32(d, m.sheen_roughness_factor); write_tex(h, d, m.sheen_color_tex);
+        for (int i = 0; i < 3; i++) push_f32(d, m.sheen_color_factor[i]);
+    }
+    memcpy(d.data() + indices_offset, fi, 48);
+    return d;
+}
+
+void light_bytes(const AwsmHostLight& l, uint8_t out[64]) {   // lights.rs:354-473
+    float f[16] = {};
+    if (l.kind == 1u) { f[4] = l.direction[0]; f[5] = l.direction[1]; f[6] = l.direction[2]; }
+    else { f[0] = l.position[0]; f[1] = l.position[1]; f[2] = l.position[2]; f[3] = l.range; }
+    if (l.kind == 3u) { f[4] = l.direction[0]; f[5] = l.direction[1]; f[6] = l.direction[2]; f[7] = l.inner_angle; f[13] = l.outer_angle; }
+    f[8] = l.color[0]; f[9] = l.color[1]; f[10] = l.color[2]; f[11] = l.intensity;
+    f[12] = (float)l.kind;
+    memcpy(out, f, 64);
+}
+
+void texture_transform_bytes(const float offset[2], const float origin[2], float rotation, const float scale[2], uint8_t out[32]) {   // textures.rs:247-284
+    const float sx = scale[0], sy = scale[1], ox = offset[0], oy = offset[1], px = origin[0], py = origin[1];
+    const float c = (float)std::cos((double)rotation), s = (float)std::sin((double)rotation);
+    const float m00 = c * sx, m01 = s * sy, m10 = -s * sx, m11 = c * sy;
+    const float bx = ox + px - (m00 * px + m01 * py);
+    const float by = oy + py - (m10 * px + m11 * py);
+    const float f[8] = {m00, m01, m10, m11, bx, by, 0.0f, 0.0f};
+    memcpy(out, f, 32);
+}
+
+// f32::total_cmp key
+int32_t total_key(float x) { int32_t b; memcpy(&b, &x, 4); return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1); }
+
+void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out) {   // renderable.rs:38-150
+    out.clear();
+    struct Item { SlotKey key; const MeshRec* rec; int pipeline; float closest; bool has_aabb; };
+    std::vector<Item> items;
+    const Mat4 view_proj = mat4_mul(h->cam_proj, h->cam_view);
+    std::unique_ptr<Frustum> fr;
+    if (h->have_camera) fr.reset(new Frustum(view_proj));
+    const auto& keys = h->meshes.keys();
+    const auto& vals = h->meshes.values();
+    for (size_t i = 0; i < keys.size(); i++) {
+        const MeshRec& m = vals[i];
+        if (m.hidden) continue;
+        if (fr && m.has_world_aabb && !fr->intersects(m.world_aabb)) continue;
+        if (m.hud) continue;   // HUD meshes go to their own pass (out of scope)
+        Item it{keys[i], &m, m.double_sided ? 0 : 1, 0.0f, m.has_world_aabb};   // pipeline key order: no_cull < back_cull (G/pipeline.rs:179-265)
+        if (m.has_world_aabb) {
+            const float a = mat4_transform_point3(view_proj, m.world_aabb.min).z, b = mat4_transform_point3(view_proj, m.world_aabb.max).z;
+            it.closest = std::fmin(a, b);
+        }
+        items.push_back(it);
+    }
+    if (h->have_camera) {
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+            if (a.pipeline != b.pipeline) return a.pipeline < b.pipeline;
+            if (a.has_aabb && b.has_aabb) return total_key(a.closest) < total_key(b.closest);   // front to back
+            if (a.has_aabb != b.has_aabb) return a.has_aabb;                                     // (Some, None) => Less
+            return false;
+        });
+    }
+    for (const Item& it : items) {
+        AwsmDraw d{};
+        d.geom_meta_off = (uint32_t)h->geom_meta.offset(it.key);
+        d.vis_data_off = (uint32_t)it.rec->vis_off;
+        d.tri_count = it.rec->tri_count;
+        d.flags = it.rec->double_sided ? 0u : AWSM_DRAW_CULL_BACK;
+        out.push_back(d);
+    }
+}
+
+template <typename T>
+bool load_sym(AwsmHost* h, T& fn, const char* name) {
+    fn = reinterpret_cast<T>(dlsym(h->be.dl, name));
+    if (!fn) { fail(h, AWSM_ERR_NOT_READY, "backend library lacks symbol %s", name); return false; }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int awsm_host_create(const char* backend_path, int device, void* stream, uint32_t cfg_flags, AwsmHost** out) {
+    if (!backend_path || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<AwsmHost> h(new AwsmHost());
+    h->be.dl = dlopen(backend_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h->be.dl) { fprintf(stderr, "awsm_host: cannot load backend %s: %s\n", backend_path, dlerror()); return AWSM_ERR_NOT_READY; }
+    Backend& b = h->be;
+    bool ok = load_sym(h.get(), b.create, "awsm_hip_create") && load_sym(h.get(), b.destroy, "awsm_hip_destroy") &&
+              load_sym(h.get(), b.last_error, "awsm_hip_last_error") && load_sym(h.get(), b.abi_version, "awsm_hip_abi_version") &&
+              load_sym(h.get(), b.buffer_create, "awsm_hip_buffer_create") && load_sym(h.get(), b.buffer_write, "awsm_hip_buffer_write") &&
+              load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") &&
+              load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
+              load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
+              load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") &&
+              load_sym(h.get(), b.frame_end, "awsm_hip_frame_end");
+    if (!ok) { fprintf(stderr, "awsm_host: %s\n", h->last_error.c_str()); dlclose(b.dl); return AWSM_ERR_NOT_READY; }
+    if (b.abi_version() != AWSM_HIP_ABI_VERSION) { dlclose(b.dl); return AWSM_ERR_INVALID_ARGUMENT; }
+    AwsmConfig cfg{};
+    cfg.struct_size = sizeof cfg; cfg.abi_version = AWSM_HIP_ABI_VERSION; cfg.device = device; cfg.flags = cfg_flags; cfg.stream = stream;
+    int rc = b.create(&cfg, &h->ctx);
+    if (rc) { dlclose(b.dl); return rc; }
+    // Transforms::new (transforms.rs:64-110): root node, identity world, no buffer slot
+    h->root = h->locals.insert(Transform{{0, 0, 0}, {0, 0, 0, 1}, {1, 1, 1}});
+    h->world[h->root] = mat4_identity();
+    h->children[h->root] = {};
+    // Textures::new (textures.rs:311-320): identity texture transform pre-inserted
+    {
+        SlotKey k = h->tex_transform_keys.insert(0);
+        const float z2[2] = {0, 0}, o2[2] = {1, 1};
+        uint8_t bytes[32];
+        texture_transform_bytes(z2, z2, 0.0f, o2, bytes);
+        h->tex_transforms_buf.update(k, bytes, 32);
+        h->tex_transform_identity_offset = (size_t)h->tex_transforms_buf.offset(k);
+    }
+    *out = h.release();
+    return AWSM_OK;
+}
+
+int awsm_host_destroy(AwsmHost* h) {
+    if (!h) return AWSM_ERR_INVALID_ARGUMENT;
+    if (h->ctx) h->be.destroy(h->ctx);
+    if (h->be.dl) dlclose(h->be.dl);
+    delete h;
+    return AWSM_OK;
+}
+
+const char* awsm_host_last_error(const AwsmHost* h) { return h ? h->last_error.c_str() : "null host"; }
+void* awsm_host_device_ctx(AwsmHost* h) { return h ? h->ctx : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ transforms
+AwsmKey awsm_host_transform_root(AwsmHost* h) { return h->root; }
+
+AwsmKey awsm_host_transform_insert(AwsmHost* h, const float t[3], const float r[4], const float s[3], AwsmKey parent) {   // transforms.rs:112-127
+    Transform tr{{t[0], t[1], t[2]}, {r[0], r[1], r[2], r[3]}, {s[0], s[1], s[2]}};
+    SlotKey key = h->locals.insert(tr);
+    h->world[key] = to_matrix(tr);
+    h->children[key] = {};
+    h->dirties.insert(key);
+    const uint8_t zeros[64] = {};
+    h->transforms_buf.update(key, zeros, 64);
+    h->normals_buf.update(key, zeros, 36);
+    set_parent(h, key, parent);
+    return key;
+}
+
+int awsm_host_transform_set_local(AwsmHost* h, AwsmKey key, const float t[3], const float r[4], const float s[3]) {   // transforms.rs:176-190
+    if (key == h->root) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] cannot modify root node");
+    Transform* tr = h->locals.get(key);
+    if (!tr) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] local transform does not exist");
+    *tr = Transform{{t[0], t[1], t[2]}, {r[0], r[1], r[2], r[3]}, {s[0], s[1], s[2]}};
+    h->dirties.insert(key);
+    return AWSM_OK;
+}
+
+int awsm_host_transform_set_parent(AwsmHost* h, AwsmKey child, AwsmKey parent) {
+    if (!h->locals.contains(child) || (parent && !h->locals.contains(parent))) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] unknown key");
+    set_parent(h, child, parent);   // like the reference, re-parenting alone does not mark the node dirty
+    return AWSM_OK;
+}
+
+int awsm_host_transform_remove(AwsmHost* h, AwsmKey key) {   // transforms.rs:137-151
+    if (key == h->root) return AWSM_OK;
+    if (!h->locals.contains(key)) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] unknown key");
+    unset_parent(h, key);
+    h->locals.remove(key);
+    h->world.erase(key);
+    h->children.erase(key);
+    h->dirties.erase(key);
+    h->transforms_buf.remove(key);
+    h->normals_buf.remove(key);
+    h->transforms_gpu_dirty = true;
+    return AWSM_OK;
+}
+
+AwsmKey awsm_host_transform_parent(AwsmHost* h, AwsmKey child) { auto it = h->parents.find(child); return it == h->parents.end() ? 0 : it->second; }
+
+int awsm_host_transform_world(AwsmHost* h, AwsmKey key, float out[16]) {
+    auto it = h->world.find(key);
+    if (it == h->world.end()) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] world transform does not exist");
+    memcpy(out, &it->second, 64);
+    return AWSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ textures
+int awsm_host_texture_insert(AwsmHost* h, const uint8_t* rgba8, uint32_t w, uint32_t ht) {
+    if (!rgba8 || !w || !ht || w > 0xFFFF || ht > 0xFFFF) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "texture_insert: bad image");
+    uint32_t ai = 0;
+    for (; ai < h->pool.size(); ai++) if (h->pool[ai].w == w && h->pool[ai].h == ht) break;
+    if (ai == h->pool.size()) {
+        if (h->pool.size() >= 64) return fail(h, AWSM_ERR_UNSUPPORTED, "more than 64 pool arrays");
+        h->pool.push_back({w, ht, {}, 0, true});
+    }
+    AwsmHost::PoolArray& a = h->pool[ai];
+    a.texels.insert(a.texels.end(), rgba8, rgba8 + (size_t)w * ht * 4);
+    a.dirty = true;
+    h->tex_entries.push_back({ai, a.layers});
+    a.layers++;
+    return (int)h->tex_entries.size() - 1;
+}
+
+int awsm_host_sampler_insert(AwsmHost* h, const AwsmSampler* s) {
+    if (!s || h->samplers.size() >= 32) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "sampler_insert: bad argument / more than 32 samplers");
+    int rc = h->be.sampler_set(h->ctx, (uint32_t)h->samplers.size(), s);
+    if (rc) return dev_fail(h, rc, "sampler_set");
+    h->samplers.push_back(*s);
+    return (int)h->samplers.size() - 1;
+}
+
+AwsmKey awsm_host_texture_transform_insert(AwsmHost* h, const float offset[2], const float origin[2], float rotation, const float scale[2]) {
+    SlotKey k = h->tex_transform_keys.insert(0);
+    uint8_t bytes[32];
+    texture_transform_bytes(offset, origin, rotation, scale, bytes);
+    h->tex_transforms_buf.update(k, bytes, 32);
+    h->tex_transforms_dirty = true;
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------ materials
+AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m) {   // materials.rs:120-128
+    if (!m || (m->shader != 1u && m->shader != 2u)) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "material_insert: bad shader id"); return 0; }
+    SlotKey k = h->materials.insert(*m);
+    const std::vector<uint8_t> d = material_bytes(h, *m);
+    h->materials_buf.update(k, d.data(), d.size());
+    h->materials_dirty = true;
+    return k;
+}
+
+int awsm_host_material_update(AwsmHost* h, AwsmKey key, const AwsmHostMaterial* m) {   // materials.rs:147-186
+    AwsmHostMaterial* cur = h->materials.get(key);
+    if (!cur || !m) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[material] not found");
+    *cur = *m;
+    const std::vector<uint8_t> d = material_bytes(h, *m);
+    h->materials_buf.update(key, d.data(), d.size());
+    h->materials_dirty = true;
+    return AWSM_OK;
+}
+
+int64_t awsm_host_material_offset(AwsmHost* h, AwsmKey key) { return h->materials_buf.offset(key); }
+
+// ------------------------------------------------------------------------------------------------ skins
+AwsmKey awsm_host_skin_insert(AwsmHost* h, const AwsmKey* joints, uint32_t n_joints, const float* inverse_bind, uint32_t set_count,
+                              const uint32_t* const* joints_per_set, const float* const* weights_per_set, uint32_t vertex_count) {
+    if (!joints || !n_joints || !set_count || !joints_per_set || !weights_per_set) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "skin_insert: bad argument"); return 0; }
+    std::vector<uint8_t> fill;
+    std::vector<SlotKey> jv(joints, joints + n_joints);
+    for (uint32_t j = 0; j < n_joints; j++) {   // skins.rs:84-143
+        Mat4 m = mat4_identity();
+        if (inverse_bind) memcpy(&m, inverse_bind + (size_t)j * 16, 64);
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(&m);
+        fill.insert(fill.end(), p, p + 64);
+        h->inverse_bind[joints[j]] = m;
+    }
+    SlotKey sk = h->skins.insert(jv);
+    h->skin_matrices.update(sk, fill.data(), fill.size());
+    h->skin_sets[sk] = set_count;
+    // gltf/buffers/skin.rs:22-113: per vertex, per set, 4 x {u32 joint, f32 weight}
+    std::vector<uint8_t> iw((size_t)vertex_count * set_count * 32);
+    for (uint32_t v = 0; v < vertex_count; v++)
+        for (uint32_t s = 0; s < set_count; s++)
+            for (int k = 0; k < 4; k++) {
+                uint8_t* dst = iw.data() + (((size_t)v * set_count + s) * 4 + k) * 8;
+                memcpy(dst, &joints_per_set[s][(size_t)v * 4 + k], 4);
+                memcpy(dst + 4, &weights_per_set[s][(size_t)v * 4 + k], 4);
+            }
+    h->skin_index_weights.update(sk, iw.data(), iw.size());
+    h->skin_matrices_dirty = h->skin_iw_dirty = true;
+    return sk;
+}
+
+// ------------------------------------------------------------------------------------------------ meshes
+AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden) {
+    if (!p || !p->positions || !p->normals || !p->indices || !p->vertex_count) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "mesh_insert: bad primitive"); return 0; }
+    if (!h->locals.contains(transform) || transform == h->root) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] buffer slot missing"); return 0; }
+    const AwsmHostMaterial* mat = h->materials.get(material);
+    if (!mat) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "[material] not found"); return 0; }
+    if (skin && !h->skins.contains(skin)) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "[skin] not found"); return 0; }
+    if (p->n_uv_sets > 8 || p->n_color_sets > 4) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "mesh_insert: too many attribute sets"); return 0; }
+    const uint32_t V = p->vertex_count, T = p->triangle_count;
+    for (size_t i = 0; i < (size_t)T * 3; i++) if (p->indices[i] >= V) { fail(h, AWSM_ERR_OUT_OF_RANGE, "mesh_insert: index %u >= vertex count %u", p->indices[i], V); return 0; }
+
+    // ---- populate/mesh.rs:107-160: morph first, then (already inserted) skin ----
+    SlotKey morph_key = 0;
+    if (p->n_morph_targets) {
+        const uint32_t nt = p->n_morph_targets;
+        std::vector<float> weights(nt, 0.0f);
+        if (p->morph_weights) memcpy(weights.data(), p->morph_weights, nt * 4);
+        std::vector<float> values((size_t)V * nt * 10, 0.0f);   // gltf/buffers/morph.rs:31-190
+        for (uint32_t v = 0; v < V; v++)
+            for (uint32_t t = 0; t < nt; t++) {
+                float* dst = values.data() + ((size_t)v * nt + t) * 10;
+                const AwsmHostMorphTarget& mt = p->morph_targets[t];
+                if (mt.positions) memcpy(dst, mt.positions + (size_t)v * 3, 12);
+                if (mt.normals) memcpy(dst + 3, mt.normals + (size_t)v * 3, 12);
+                if (mt.tangents) memcpy(dst + 6, mt.tangents + (size_t)v * 3, 12);
+            }
+        morph_key = h->morphs.insert(nt);
+        h->morph_weights.update(morph_key, reinterpret_cast<const uint8_t*>(weights.data()), nt * 4);   // morphs.rs:148-170 insert_raw
+        h->morph_values.update(morph_key, reinterpret_cast<const uint8_t*>(values.data()), values.size() * 4);
+        if (p->animated_morph_weights) {   // morphs.rs:197-217: the callback sees [1..n+1) of the block
+            const float* aw = p->animated_morph_weights;
+            h->morph_weights.update_with_unchecked(morph_key, [&](size_t, uint8_t* blk, size_t) { memcpy(blk + 4, aw, nt * 4); });
+        }
+        h->morph_weights_dirty = h->morph_values_dirty = true;
+    }
+
+    // ---- gltf/buffers/mesh/visibility.rs:35-165: vertex explosion, 56 B / corner ----
+    std::vector<uint8_t> vis((size_t)T * 3 * 56);
+    static const float kBary[3][2] = {{1.0f, 0.0f}, {0.0f, 1.0f}, {0.0f, 0.0f}};
+    const float default_tangent[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    for (uint32_t t = 0; t < T; t++) {
+        uint32_t vi[3] = {p->indices[t * 3], p->indices[t * 3 + 1], p->indices[t * 3 + 2]};
+        int bi[3] = {0, 1, 2};
+        if (p->front_face_cw) { std::swap(vi[1], vi[2]); std::swap(bi[1], bi[2]); }
+        for (int c = 0; c < 3; c++) {
+            uint8_t* dst = vis.data() + ((size_t)t * 3 + c) * 56;
+            memcpy(dst, p->positions + (size_t)vi[c] * 3, 12);
+            memcpy(dst + 12, &t, 4);
+            memcpy(dst + 16, kBary[bi[c]], 8);
+            memcpy(dst + 24, p->normals + (size_t)vi[c] * 3, 12);
+            memcpy(dst + 36, p->tangents ? p->tangents + (size_t)vi[c] * 4 : default_tangent, 16);
+            memcpy(dst + 52, &vi[c], 4);
+        }
+    }
+    // ---- gltf/buffers/attributes.rs:113-160: COLOR_n then TEXCOORD_n, per original vertex ----
+    const uint32_t stride_f = p->n_color_sets * 4 + p->n_uv_sets * 2;
+    std::vector<float> attr((size_t)V * stride_f);
+    for (uint32_t v = 0; v < V; v++) {
+        float* dst = attr.data() + (size_t)v * stride_f;
+        for (uint32_t c = 0; c < p->n_color_sets; c++) { memcpy(dst, p->color_sets[c] + (size_t)v * 4, 16); dst += 4; }
+        for (uint32_t u = 0; u < p->n_uv_sets; u++) { memcpy(dst, p->uv_sets[u] + (size_t)v * 2, 8); dst += 2; }
+    }
+    // ---- meshes.rs:486-560 insert_resource: vis index, vis data, attr index, attr data ----
+    SlotKey rk = h->resources.insert(0);
+    std::vector<uint32_t> ident((size_t)T * 3);
+    for (size_t i = 0; i < ident.size(); i++) ident[i] = (uint32_t)i;
+    h->vis_index.update(rk, reinterpret_cast<const uint8_t*>(ident.data()), ident.size() * 4);
+    const size_t vis_off = h->vis_data.update(rk, vis.data(), vis.size());
+    const size_t attr_index_off = h->attr_index.update(rk, reinterpret_cast<const uint8_t*>(p->indices), (size_t)T * 12);
+    const size_t attr_data_off = h->attr_data.update(rk, reinterpret_cast<const uint8_t*>(attr.data()), attr.size() * 4);
+    h->vis_index_dirty = h->vis_data_dirty = h->attr_index_dirty = h->attr_data_dirty = true;
+
+    MeshRec rec;
+    rec.transform_key = transform; rec.material_key = material; rec.resource_key = rk; rec.skin_key = skin; rec.morph_key = morph_key;
+    rec.double_sided = mat->double_sided != 0; rec.hidden = hidden != 0; rec.tri_count = T; rec.vis_off = vis_off;
+    Vec3 mn = {p->positions[0], p->positions[1], p->positions[2]}, mx = mn;   // accessor min/max (populate/mesh.rs try_position_aabb)
+    for (uint32_t v = 1; v < V; v++) {
+        const Vec3 q = {p->positions[(size_t)v * 3], p->positions[(size_t)v * 3 + 1], p->positions[(size_t)v * 3 + 2]};
+        mn = v3_min(mn, q); mx = v3_max(mx, q);
+    }
+    rec.local_aabb = {mn, mx};
+    rec.world_aabb = rec.local_aabb;   // meshes.rs:596-598: until the next update_world
+    SlotKey mk = h->meshes.insert(rec);
+    h->transform_to_meshes[transform].push_back(mk);
+
+    // ---- meta.rs:89-146: material meta first, then geometry meta ----
+    const uint32_t hi = (uint32_t)(mk >> 32), lo = (uint32_t)(mk & 0xFFFFFFFFull);
+    const uint32_t mm[17] = {hi, lo, 0, 0, 0, 0, (uint32_t)h->materials_buf.offset(material), (uint32_t)h->transforms_buf.offset(transform),
+                             (uint32_t)h->normals_buf.offset(transform), (uint32_t)attr_index_off, (uint32_t)attr_data_off, stride_f * 4,
+                             p->n_color_sets * 4, p->n_uv_sets, p->n_color_sets, (uint32_t)vis_off, 0u};
+    h->material_meta.update(mk, reinterpret_cast<const uint8_t*>(mm), 68);
+    uint32_t gm[10] = {hi, lo, 0, 0, 0, 0, 0, 0, (uint32_t)h->transforms_buf.offset(transform), (uint32_t)h->material_meta.offset(mk)};
+    if (morph_key) { gm[2] = p->n_morph_targets; gm[3] = (uint32_t)h->morph_weights.offset(morph_key); gm[4] = (uint32_t)h->morph_values.offset(morph_key); }
+    if (skin) { gm[5] = h->skin_sets[skin]; gm[6] = (uint32_t)h->skin_matrices.offset(skin); gm[7] = (uint32_t)h->skin_index_weights.offset(skin); }
+    h->geom_meta.update(mk, reinterpret_cast<const uint8_t*>(gm), 40);
+    h->geom_meta_dirty = h->material_meta_dirty = true;
+    return mk;
+}
+
+int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh) {
+    MeshRec* rec = h->meshes.get(mesh);
+    if (!rec) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[mesh] not found");
+    const SlotKey rk = rec->resource_key, tk = rec->transform_key, mk = rec->morph_key;
+    h->vis_index.remove(rk); h->vis_data.remove(rk); h->attr_index.remove(rk); h->attr_data.remove(rk);
+    h->resources.remove(rk);
+    if (mk) { h->morph_weights.remove(mk); h->morph_values.remove(mk); h->morphs.remove(mk); h->morph_weights_dirty = h->morph_values_dirty = true; }
+    auto& v = h->transform_to_meshes[tk];
+    v.erase(std::remove(v.begin(), v.end(), mesh), v.end());
+    if (h->geom_meta.remove(mesh)) h->geom_meta_dirty = true;
+    if (h->material_meta.remove(mesh)) h->material_meta_dirty = true;
+    h->meshes.remove(mesh);
+    h->vis_index_dirty = h->vis_data_dirty = h->attr_index_dirty = h->attr_data_dirty = true;
+    return AWSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ lights / camera / env
+AwsmKey awsm_host_light_insert(AwsmHost* h, const AwsmHostLight* l) {
+    if (!l || l->kind < 1 || l->kind > 3) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "light_insert: bad kind"); return 0; }
+    h->punctual_dirty = h->lights_info_dirty = true;
+    return h->lights.insert(*l);
+}
+int awsm_host_light_remove(AwsmHost* h, AwsmKey key) {
+    if (!h->lights.remove(key)) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[light] not found");
+    h->punctual_dirty = h->lights_info_dirty = true;
+    return AWSM_OK;
+}
+int awsm_host_set_ibl_mip_counts(AwsmHost* h, uint32_t prefiltered, uint32_t irradiance) {
+    h->prefiltered_mips = prefiltered; h->irradiance_mips = irradiance; h->lights_info_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_host_camera_update(AwsmHost* h, const float view[16], const float projection[16], const float pos[3]) {   // camera.rs:111-227
+    Mat4 v, p;
+    memcpy(&v, view, 64); memcpy(&p, projection, 64);
+    const Mat4 inv_proj = mat4_inverse(p);
+    const Mat4 view_proj = mat4_mul(p, v);
+    const Mat4 inv_view_proj = mat4_inverse(view_proj);
+    const Mat4 inv_view = mat4_inverse(v);
+    uint8_t* o = h->camera_raw;
+    memcpy(o, &v, 64); memcpy(o + 64, &p, 64); memcpy(o + 128, &view_proj, 64);
+    memcpy(o + 192, &inv_view_proj, 64); memcpy(o + 256, &inv_proj, 64); memcpy(o + 320, &inv_view, 64);
+    const float posw[4] = {pos[0], pos[1], pos[2], 0.0f};
+    memcpy(o + 384, posw, 16);
+    const uint32_t fc[4] = {h->frame_count, 0, 0, 0};
+    memcpy(o + 400, fc, 16);
+    const Vec4 corners[4] = {{-1, -1, 0, 1}, {1, -1, 0, 1}, {-1, 1, 0, 1}, {1, 1, 0, 1}};   // camera.rs:285-306
+    for (int i = 0; i < 4; i++) {
+        Vec4 vs = mat4_mul_vec4(inv_proj, corners[i]);
+        vs = {vs.x / vs.w, vs.y / vs.w, vs.z / vs.w, vs.w / vs.w};
+        const Vec3 d = v3_normalize({vs.x, vs.y, vs.z});
+        const float ray[4] = {d.x, d.y, d.z, 0.0f};
+        memcpy(o + 416 + i * 16, ray, 16);
+    }
+    const float viewport[4] = {0.0f, 0.0f, (float)h->width, (float)h->height};
+    memcpy(o + 480, viewport, 16);
+    const float dof[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    memcpy(o + 496, dof, 16);
+    h->cam_view = v; h->cam_proj = p; h->have_camera = true; h->camera_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_host_env(AwsmHost* h, const AwsmEnv* env) { int rc = h->be.env_upload(h->ctx, env); return rc ? dev_fail(h, rc, "env_upload") : AWSM_OK; }
+int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t ht) { int rc = h->be.brdf_lut_generate(h->ctx, w, ht); return rc ? dev_fail(h, rc, "brdf_lut_generate") : AWSM_OK; }
+int awsm_host_resize(AwsmHost* h, uint32_t w, uint32_t ht) {
+    int rc = h->be.resize(h->ctx, w, ht, 0);
+    if (rc) return dev_fail(h, rc, "resize");
+    h->width = w; h->height = ht;
+    return AWSM_OK;
+}
+int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1) { int rc = h->be.set_shard_rows(h->ctx, y0, y1); return rc ? dev_fail(h, rc, "set_shard_rows") : AWSM_OK; }
+
+// ------------------------------------------------------------------------------------------------ frame
+int awsm_host_update_transforms(AwsmHost* h) {   // transforms.rs:29-39 + meshes.rs:872-939
+    h->transforms_gpu_dirty = h->transforms_gpu_dirty || !h->dirties.empty();
+    update_inner(h, h->root, false);
+    h->dirties.clear();
+    std::unordered_map<SlotKey, Mat4> dirty;
+    for (SlotKey k : h->dirty_meshes) dirty[k] = h->world[k];
+    h->dirty_meshes.clear();
+    for (auto& kv : dirty) {
+        auto it = h->transform_to_meshes.find(kv.first);
+        if (it == h->transform_to_meshes.end()) continue;
+        for (SlotKey mk : it->second) {
+            MeshRec* m = h->meshes.get(mk);
+            if (m) { m->world_aabb = aabb_transformed(m->local_aabb, kv.second); m->has_world_aabb = true; }
+        }
+    }
+    const auto& skeys = h->skins.keys();   // skins.rs:162-194
+    for (size_t i = 0; i < skeys.size(); i++) {
+        const std::vector<SlotKey>& joints = h->skins.values()[i];
+        for (size_t j = 0; j < joints.size(); j++) {
+            auto dit = dirty.find(joints[j]);
+            if (dit == dirty.end()) continue;
+            Mat4 wm = dit->second;
+            auto ib = h->inverse_bind.find(joints[j]);
+            if (ib != h->inverse_bind.end()) wm = mat4_mul(wm, ib->second);
+            h->skin_matrices.update_with_unchecked(skeys[i], [&](size_t, uint8_t* blk, size_t) { memcpy(blk + j * 64, &wm, 64); });
+            h->skin_matrices_dirty = true;
+        }
+    }
+    return AWSM_OK;
+}
+
+int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render.rs:53-383 (hot path only)
+    if (!h->width) return fail(h, AWSM_ERR_NOT_READY, "render before resize");
+    h->upload_bytes = 0;
+    h->frame_count += 1;   // render_textures.next_frame()
+    int rc;
+    // ---- write_gpu, in the reference's order (render.rs:73-97) ----
+    if (h->transforms_gpu_dirty) {
+        bool d1 = true, d2 = true;
+        if ((rc = flush_buffer(h, h->transforms_buf, AWSM_BUF_TRANSFORMS, d1))) return rc;
+        if ((rc = flush_buffer(h, h->normals_buf, AWSM_BUF_NORMAL_MATS, d2))) return rc;
+        h->transforms_gpu_dirty = false;
+    }
+    if ((rc = flush_buffer(h, h->materials_buf, AWSM_BUF_MATERIALS, h->materials_dirty))) return rc;
+    if (h->punctual_dirty) {   // lights.rs:226-291: dense rebuild
+        std::vector<uint8_t> buf(h->lights.size() * 64);
+        for (size_t i = 0; i < h->lights.size(); i++) light_bytes(h->lights.values()[i], buf.data() + i * 64);
+        size_t target = h->punctual_gpu_size;
+        if (buf.size() > h->punctual_gpu_size) target = std::max<size_t>(buf.size() * 2, 64);
+        else if (buf.size() < h->punctual_gpu_size / 2) target = std::max<size_t>(buf.size(), 64);
+        if (target != h->punctual_gpu_size || !h->lights_created) {
+            if ((rc = h->be.buffer_create(h->ctx, AWSM_BUF_LIGHTS, target))) return dev_fail(h, rc, "buffer_create(lights)");
+            h->punctual_gpu_size = target; h->lights_created = true;
+        }
+        if (!buf.empty()) { if ((rc = h->be.buffer_write(h->ctx, AWSM_BUF_LIGHTS, 0, buf.data(), buf.size()))) return dev_fail(h, rc, "buffer_write(lights)"); h->upload_bytes += buf.size(); }
+        h->punctual_dirty = false;
+    }
+    if (h->lights_info_dirty) {   // lights.rs:293-305
+        const uint32_t info[4] = {(uint32_t)h->lights.size(), h->prefiltered_mips, h->irradiance_mips, 0};
+        if (!h->lights_info_created) { if ((rc = h->be.buffer_create(h->ctx, AWSM_BUF_LIGHTS_INFO, 16))) return dev_fail(h, rc, "buffer_create(lights info)"); h->lights_info_created = true; }
+        if ((rc = h->be.buffer_write(h->ctx, AWSM_BUF_LIGHTS_INFO, 0, info, 16))) return dev_fail(h, rc, "buffer_write(lights info)");
+        h->upload_bytes += 16;
+        h->lights_info_dirty = false;
+    }
+    if ((rc = flush_buffer(h, h->skin_matrices, AWSM_BUF_SKIN_MATRICES, h->skin_matrices_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->skin_index_weights, AWSM_BUF_SKIN_INDEX_WEIGHTS, h->skin_iw_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->morph_weights, AWSM_BUF_MORPH_WEIGHTS, h->morph_weights_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->morph_values, AWSM_BUF_MORPH_VALUES, h->morph_values_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->geom_meta, AWSM_BUF_GEOM_META, h->geom_meta_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->material_meta, AWSM_BUF_MATERIAL_META, h->material_meta_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->tex_transforms_buf, AWSM_BUF_TEXTURE_TRANSFORMS, h->tex_transforms_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->vis_data, AWSM_BUF_VIS_GEOM_DATA, h->vis_data_dirty))) return rc;
+    // VisGeomIndex (identity indices) stays a host mirror only: a software rasteriser has no index fetch.  The
+    // mirror still tracks the reference's allocation; nothing is uploaded (SURVEY Appendix A "redundant").
+    h->vis_index.take_dirty_ranges(); h->vis_index.take_gpu_needs_resize(); h->vis_index_dirty = false;
+    if ((rc = flush_buffer(h, h->attr_data, AWSM_BUF_ATTR_DATA, h->attr_data_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->attr_index, AWSM_BUF_ATTR_INDEX, h->attr_index_dirty))) return rc;
+    if (h->camera_dirty) {   // camera.rs:232-251
+        if (!h->camera_created) { if ((rc = h->be.buffer_create(h->ctx, AWSM_BUF_CAMERA, 512))) return dev_fail(h, rc, "buffer_create(camera)"); h->camera_created = true; }
+        if ((rc = h->be.buffer_write(h->ctx, AWSM_BUF_CAMERA, 0, h->camera_raw, 512))) return dev_fail(h, rc, "buffer_write(camera)");
+        h->upload_bytes += 512;
+        h->camera_dirty = false;
+    }
+    for (uint32_t i = 0; i < h->pool.size(); i++) {   // finalize_gpu_textures: (re)upload arrays that gained layers
+        AwsmHost::PoolArray& a = h->pool[i];
+        if (!a.dirty) continue;
+        if ((rc = h->be.texture_array_upload(h->ctx, i, a.w, a.h, a.layers, 1, AWSM_TEX_RGBA8_UNORM, a.texels.data()))) return dev_fail(h, rc, "texture_array_upload");
+        a.dirty = false;
+    }
+    // ---- collect_renderables -> geometry pass -> opaque pass (render.rs:144-221) ----
+    collect_draws(h, h->last_draws);
+    if ((rc = h->be.geometry_pass(h->ctx, h->last_draws.data(), (uint32_t)h->last_draws.size()))) return dev_fail(h, rc, "geometry_pass");
+    AwsmOpaqueParams op{};
+    op.mipmap = 0; op.has_opaque = h->last_draws.empty() ? 0u : 1u;   // material_opaque/render_pass.rs:64-71
+    if ((rc = h->be.opaque_pass(h->ctx, &op))) return dev_fail(h, rc, "opaque_pass");
+    if (sync) { if ((rc = h->be.frame_end(h->ctx, stats))) return dev_fail(h, rc, "frame_end"); }   // gpu.submit_commands (render.rs:370)
+    return AWSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ introspection
+int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* len) {
+    const std::vector<uint8_t>* v = nullptr;
+    switch (which) {
+        case AWSM_BUF_TRANSFORMS: v = &h->transforms_buf.raw(); break;
+        case AWSM_BUF_NORMAL_MATS: v = &h->normals_buf.raw(); break;
+        case AWSM_BUF_MATERIALS: v = &h->materials_buf.raw(); break;
+        case AWSM_BUF_SKIN_MATRICES: v = &h->skin_matrices.raw(); break;
+        case AWSM_BUF_SKIN_INDEX_WEIGHTS: v = &h->skin_index_weights.raw(); break;
+        case AWSM_BUF_MORPH_WEIGHTS: v = &h->morph_weights.raw(); break;
+        case AWSM_BUF_MORPH_VALUES: v = &h->morph_values.raw(); break;
+        case AWSM_BUF_GEOM_META: v = &h->geom_meta.raw(); break;
+        case AWSM_BUF_MATERIAL_META: v = &h->material_meta.raw(); break;
+        case AWSM_BUF_VIS_GEOM_DATA: v = &h->vis_data.raw(); break;
+        case AWSM_BUF_VIS_GEOM_INDEX: v = &h->vis_index.raw(); break;
+        case AWSM_BUF_ATTR_DATA: v = &h->attr_data.raw(); break;
+        case AWSM_BUF_ATTR_INDEX: v = &h->attr_index.raw(); break;
+        case AWSM_BUF_TEXTURE_TRANSFORMS: v = &h->tex_transforms_buf.raw(); break;
+        case AWSM_BUF_CAMERA: *data = h->camera_raw; *len = 512; return AWSM_OK;
+        default: return fail(h, AWSM_ERR_INVALID_ARGUMENT, "mirror: buffer %d has no persistent mirror", (int)which);
+    }
+    *data = v->data(); *len = v->size();
+    return AWSM_OK;
+}
+
+int awsm_host_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n) {
+    std::vector<AwsmDraw> d;
+    collect_draws(h, d);
+    *n = (uint32_t)d.size();
+    if (out) memcpy(out, d.data(), std::min<size_t>(cap, d.size()) * sizeof(AwsmDraw));
+    return AWSM_OK;
+}
+
+uint32_t awsm_host_texture_array_count(AwsmHost* h) { return (uint32_t)h->pool.size(); }
+int awsm_host_texture_array_info(AwsmHost* h, uint32_t i, uint32_t* w, uint32_t* ht, uint32_t* layers, const uint8_t** texels) {
+    if (i >= h->pool.size()) return AWSM_ERR_OUT_OF_RANGE;
+    *w = h->pool[i].w; *ht = h->pool[i].h; *layers = h->pool[i].layers; *texels = h->pool[i].texels.data();
+    return AWSM_OK;
+}
+uint64_t awsm_host_upload_bytes_last_frame(AwsmHost* h) { return h->upload_bytes; }
+
+// ------------------------------------------------------------------------------------------------ raw allocators (unit tests)
+struct AwsmHostDub { DynamicUniformBuffer b; };
+struct AwsmHostDsb { DynamicStorageBuffer b; };
+
+AwsmHostDub* awsm_host_dub_new(size_t cap, size_t byte_size, size_t aligned, uint8_t zero) { return new AwsmHostDub{DynamicUniformBuffer(cap, byte_size, aligned, zero)}; }
+void awsm_host_dub_free(AwsmHostDub* b) { delete b; }
+int awsm_host_dub_update(AwsmHostDub* b, AwsmKey k, const uint8_t* d, size_t n) { return b->b.update(k, d, n) ? 0 : -1; }
+int awsm_host_dub_update_offset(AwsmHostDub* b, AwsmKey k, size_t off, const uint8_t* d, size_t n) { return b->b.update_offset(k, off, d, n) ? 0 : -1; }
+int awsm_host_dub_remove(AwsmHostDub* b, AwsmKey k) { return b->b.remove(k) ? 1 : 0; }
+int64_t awsm_host_dub_offset(AwsmHostDub* b, AwsmKey k) { return b->b.offset(k); }
+int64_t awsm_host_dub_slot(AwsmHostDub* b, AwsmKey k) { return b->b.slot_index(k); }
+size_t awsm_host_dub_size(AwsmHostDub* b) { return b->b.size(); }
+size_t awsm_host_dub_len(AwsmHostDub* b) { return b->b.len(); }
+size_t awsm_host_dub_capacity(AwsmHostDub* b) { return b->b.capacity(); }
+size_t awsm_host_dub_next_slot(AwsmHostDub* b) { return b->b.next_slot(); }
+size_t awsm_host_dub_free_slots(AwsmHostDub* b, size_t* out, size_t cap) {
+    const auto& f = b->b.free_slots();
+    for (size_t i = 0; i < f.size() && i < cap; i++) out[i] = f[i];
+    return f.size();
+}
+const uint8_t* awsm_host_dub_raw(AwsmHostDub* b) { return b->b.raw().data(); }
+int64_t awsm_host_dub_take_resize(AwsmHostDub* b) { return b->b.take_gpu_needs_resize(); }
+size_t awsm_host_dub_take_dirty(AwsmHostDub* b, size_t* out, size_t cap) {
+    auto r = b->b.take_dirty_ranges();
+    for (size_t i = 0; i < r.size() && i < cap; i++) { out[2 * i] = r[i].first; out[2 * i + 1] = r[i].second; }
+    return r.size();
+}
+void awsm_host_dub_force_state(AwsmHostDub* b, size_t next_slot) { b->b.test_force_state(next_slot); }
+
+AwsmHostDsb* awsm_host_dsb_new(size_t initial_bytes, uint8_t zero) { return new AwsmHostDsb{DynamicStorageBuffer(initial_bytes, zero)}; }
+void awsm_host_dsb_free(AwsmHostDsb* b) { delete b; }
+size_t awsm_host_dsb_update(AwsmHostDsb* b, AwsmKey k, const uint8_t* d, size_t n) { return b->b.update(k, d, n); }
+int awsm_host_dsb_patch(AwsmHostDsb* b, AwsmKey k, size_t at, const uint8_t* d, size_t n) {
+    return b->b.update_with_unchecked(k, [&](size_t, uint8_t* blk, size_t size) { if (at + n <= size) memcpy(blk + at, d, n); }) ? 0 : -1;
+}
+void awsm_host_dsb_remove(AwsmHostDsb* b, AwsmKey k) { b->b.remove(k); }
+int64_t awsm_host_dsb_offset(AwsmHostDsb* b, AwsmKey k) { return b->b.offset(k); }
+int64_t awsm_host_dsb_size_of(AwsmHostDsb* b, AwsmKey k) { return b->b.size_of(k); }
+size_t awsm_host_dsb_used_size(AwsmHostDsb* b) { return b->b.used_size(); }
+size_t awsm_host_dsb_len(AwsmHostDsb* b) { return b->b.len(); }
+size_t awsm_host_dsb_capacity(AwsmHostDsb* b) { return b->b.capacity(); }
+size_t awsm_host_dsb_tree_root(AwsmHostDsb* b) { return b->b.tree_root(); }
+const uint8_t* awsm_host_dsb_raw(AwsmHostDsb* b) { return b->b.raw().data(); }
+int64_t awsm_host_dsb_take_resize(AwsmHostDsb* b) { return b->b.take_gpu_needs_resize(); }
+size_t awsm_host_dsb_take_dirty(AwsmHostDsb* b, size_t* out, size_t cap) {
+    auto r = b->b.take_dirty_ranges();
+    for (size_t i = 0; i < r.size() && i < cap; i++) { out[2 * i] = r[i].first; out[2 * i + 1] = r[i].second; }
+    return r.size();
+}
+size_t awsm_host_round_pow2(size_t n) { return DynamicStorageBuffer::round_pow2(n); }
+size_t awsm_host_index_to_offset(size_t idx, size_t leaves) { return DynamicStorageBuffer::index_to_offset(idx, leaves); }
+size_t awsm_host_offset_to_index(size_t off, size_t leaves) { return DynamicStorageBuffer::offset_to_index(off, leaves); }
+size_t awsm_host_write_plan(size_t raw_len, const size_t* in_pairs, size_t n_in, size_t* out_pairs, size_t cap) {
+    std::vector<DirtyRange> r;
+    for (size_t i = 0; i < n_in; i++) r.push_back({in_pairs[2 * i], in_pairs[2 * i + 1]});
+    auto plan = write_plan(raw_len, r);
+    for (size_t i = 0; i < plan.size() && i < cap; i++) { out_pairs[2 * i] = plan[i].first; out_pairs[2 * i + 1] = plan[i].second; }
+    return plan.size();
+}
+int awsm_host_frustum_intersects(const float vp[16], const float mn[3], const float mx[3]) {
+    Mat4 m; memcpy(&m, vp, 64);
+    return Frustum(m).intersects(Aabb{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}}) ? 1 : 0;
+}
+void awsm_host_aabb_transformed(const float mat[16], const float mn[3], const float mx[3], float omn[3], float omx[3]) {
+    Mat4 m; memcpy(&m, mat, 64);
+    Aabb o = aabb_transformed(Aabb{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}}, m);
+    omn[0] = o.min.x; omn[1] = o.min.y; omn[2] = o.min.z; omx[0] = o.max.x; omx[1] = o.max.y; omx[2] = o.max.z;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+/*
+ * awsm_host.h — flat C API of the C++ host layer (libawsm_host.so).
+ *
+ * The host layer is the MI355X build's counterpart of the reference's Rust scene state: it keeps the
+ * key-based update API (TransformKey / MeshKey / MaterialKey ...) and the DynamicUniformBuffer /
+ * DynamicStorageBuffer dirty-upload semantics, and drives the kernels ONLY through the C-ABI of
+ * include/awsm_hip.h (loaded at run time from the library path given to awsm_host_create).
+ * The reference has no C interface; each function names the Rust method it mirrors
+ * (paths relative to /root/reference/crates/renderer/src/).  Rust is not available in this environment,
+ * so the host is C++ and this header is how Python (ctypes) and the tests reach it.
+ *
+ * Keys are slotmap `KeyData::as_ffi()` values: (version << 32) | idx, never 0.  0 means "none"/"root".
+ * All functions return 0 or a negative AwsmStatus (include/awsm_hip.h) unless stated otherwise.
+ */
+#ifndef AWSM_HOST_H
+#define AWSM_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "awsm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct AwsmHost AwsmHost;
+typedef uint64_t AwsmKey;
+
+/* AwsmRendererBuilder::build (lib.rs:213-259).  backend_path = shared library exporting the awsm_hip_* C-ABI
+ * (libawsm_hip.so).  There is no built-in device fallback: a missing library or symbol fails here. */
+int awsm_host_create(const char* backend_path, int device, void* stream, uint32_t cfg_flags, AwsmHost** out);
+int awsm_host_destroy(AwsmHost* h);
+const char* awsm_host_last_error(const AwsmHost* h);
+void* awsm_host_device_ctx(AwsmHost* h);     /* the AwsmHipCtx*, for readback helpers */
+
+/* ---- Transforms (transforms.rs:43-446) ---- */
+AwsmKey awsm_host_transform_root(AwsmHost* h);
+AwsmKey awsm_host_transform_insert(AwsmHost* h, const float translation[3], const float rotation_xyzw[4], const float scale[3], AwsmKey parent);
+int awsm_host_transform_set_local(AwsmHost* h, AwsmKey key, const float translation[3], const float rotation_xyzw[4], const float scale[3]);
+int awsm_host_transform_set_parent(AwsmHost* h, AwsmKey child, AwsmKey parent);
+int awsm_host_transform_remove(AwsmHost* h, AwsmKey key);
+AwsmKey awsm_host_transform_parent(AwsmHost* h, AwsmKey child);          /* 0 if none */
+int awsm_host_transform_world(AwsmHost* h, AwsmKey key, float out_mat4[16]);
+
+/* ---- Textures (textures.rs; renderer-core texture_pool): decoded RGBA8 images, one array per (w,h) ---- */
+int awsm_host_texture_insert(AwsmHost* h, const uint8_t* rgba8, uint32_t width, uint32_t height);   /* returns texture id >= 0 */
+int awsm_host_sampler_insert(AwsmHost* h, const AwsmSampler* sampler);                                /* returns sampler id >= 0 */
+AwsmKey awsm_host_texture_transform_insert(AwsmHost* h, const float offset[2], const float origin[2], float rotation, const float scale[2]);
+
+/* ---- Materials (materials.rs:60-241, materials/pbr.rs, materials/unlit.rs) ---- */
+typedef struct AwsmHostTexRef {
+    int32_t texture;          /* texture id, -1 = none */
+    uint32_t sampler;         /* sampler id */
+    uint32_t uv_index;
+    uint32_t pad;
+    AwsmKey transform;        /* texture-transform key, 0 = identity */
+} AwsmHostTexRef;
+
+typedef struct AwsmHostMaterial {
+    uint32_t shader;          /* 1 = PBR, 2 = unlit (MaterialShaderId) */
+    uint32_t double_sided;
+    float base_color_factor[4];
+    float metallic_factor, roughness_factor, normal_scale, occlusion_strength;
+    float emissive_factor[3];
+    uint32_t debug_bitmask;
+    AwsmHostTexRef base_color_tex, metallic_roughness_tex, normal_tex, occlusion_tex, emissive_tex;
+    /* optional features: has_* selects whether the block is written (pbr.rs:364-573) */
+    uint32_t has_vertex_color, vertex_color_set;
+    uint32_t has_emissive_strength; float emissive_strength;
+    uint32_t has_ior; float ior;
+    uint32_t has_specular; float specular_factor; float specular_color_factor[3]; AwsmHostTexRef specular_tex, specular_color_tex;
+    uint32_t has_transmission; float transmission_factor; AwsmHostTexRef transmission_tex;
+    uint32_t has_volume; float volume_thickness_factor, volume_attenuation_distance; float volume_attenuation_color[3]; AwsmHostTexRef volume_thickness_tex;
+    uint32_t has_clearcoat; float clearcoat_factor, clearcoat_roughness_factor, clearcoat_normal_scale;
+    AwsmHostTexRef clearcoat_tex, clearcoat_roughness_tex, clearcoat_normal_tex;
+    uint32_t has_sheen; float sheen_roughness_factor; float sheen_color_factor[3]; AwsmHostTexRef sheen_roughness_tex, sheen_color_tex;
+} AwsmHostMaterial;
+
+AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m);
+int awsm_host_material_update(AwsmHost* h, AwsmKey key, const AwsmHostMaterial* m);   /* AwsmRenderer::update_material */
+int64_t awsm_host_material_offset(AwsmHost* h, AwsmKey key);
+
+/* ---- Skins / morphs (meshes/skins.rs:84-194, meshes/morphs.rs:121-217) ---- */
+AwsmKey awsm_host_skin_insert(AwsmHost* h, const AwsmKey* joint_transforms, uint32_t n_joints, const float* inverse_bind_mat4s,
+                              uint32_t set_count, const uint32_t* const* joints_per_set, const float* const* weights_per_set, uint32_t vertex_count);
+
+/* ---- Meshes (meshes.rs:455-674; the gltf/buffers packers run inside) ---- */
+typedef struct AwsmHostMorphTarget { const float* positions; const float* normals; const float* tangents; } AwsmHostMorphTarget;  /* each vertex_count*3 or NULL */
+typedef struct AwsmHostPrimitive {
+    uint32_t vertex_count, triangle_count;
+    const float* positions;        /* vertex_count*3 */
+    const float* normals;          /* vertex_count*3 */
+    const float* tangents;         /* vertex_count*4 or NULL */
+    const uint32_t* indices;       /* triangle_count*3 */
+    uint32_t n_uv_sets; const float* uv_sets[8];        /* each vertex_count*2 */
+    uint32_t n_color_sets; const float* color_sets[4];  /* each vertex_count*4 */
+    uint32_t n_morph_targets; const AwsmHostMorphTarget* morph_targets;
+    const float* morph_weights;            /* n_morph_targets (glTF mesh.weights) or NULL */
+    const float* animated_morph_weights;   /* optional: written through update_morph_weights_with ([1..n+1)) */
+    uint32_t front_face_cw;
+} AwsmHostPrimitive;
+
+AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* prim, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden);
+int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh);
+
+/* ---- Lights (lights.rs:160-310) ---- */
+typedef struct AwsmHostLight {
+    uint32_t kind;            /* 1 directional, 2 point, 3 spot */
+    float color[3]; float intensity;
+    float position[3]; float range;
+    float direction[3]; float inner_angle, outer_angle;
+} AwsmHostLight;
+AwsmKey awsm_host_light_insert(AwsmHost* h, const AwsmHostLight* l);
+int awsm_host_light_remove(AwsmHost* h, AwsmKey key);
+int awsm_host_set_ibl_mip_counts(AwsmHost* h, uint32_t prefiltered, uint32_t irradiance);
+
+/* ---- Camera (camera.rs:17-28,111-227): column-major mat4s ---- */
+int awsm_host_camera_update(AwsmHost* h, const float view[16], const float projection[16], const float position_world[3]);
+
+/* ---- environment pass-through + targets ---- */
+int awsm_host_env(AwsmHost* h, const AwsmEnv* env);
+int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t height);
+int awsm_host_resize(AwsmHost* h, uint32_t width, uint32_t height);
+int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1);
+
+/* ---- frame: update_all (update.rs:8-18) + AwsmRenderer::render (render.rs:53-383, hot path only) ---- */
+int awsm_host_update_transforms(AwsmHost* h);
+/* sync != 0: ends with awsm_hip_frame_end (stats filled if non-NULL); sync == 0: enqueue only */
+int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats);
+
+/* ---- introspection (tests, parity, INTEGRATION) ---- */
+int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* len);
+int awsm_host_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);   /* the list render() would submit */
+uint32_t awsm_host_texture_array_count(AwsmHost* h);
+int awsm_host_texture_array_info(AwsmHost* h, uint32_t array_idx, uint32_t* width, uint32_t* height, uint32_t* layers, const uint8_t** texels);
+uint64_t awsm_host_upload_bytes_last_frame(AwsmHost* h);
+
+/* ---- raw allocators for the restated reference unit tests ---- */
+typedef struct AwsmHostDub AwsmHostDub;   /* DynamicUniformBuffer */
+typedef struct AwsmHostDsb AwsmHostDsb;   /* DynamicStorageBuffer */
+AwsmHostDub* awsm_host_dub_new(size_t initial_capacity, size_t byte_size, size_t aligned_slice_size /*0 = byte_size*/, uint8_t zero);
+void awsm_host_dub_free(AwsmHostDub* b);
+int awsm_host_dub_update(AwsmHostDub* b, AwsmKey key, const uint8_t* data, size_t len);          /* -1 if oversized */
+int awsm_host_dub_update_offset(AwsmHostDub* b, AwsmKey key, size_t offset, const uint8_t* data, size_t len);
+int awsm_host_dub_remove(AwsmHostDub* b, AwsmKey key);                                             /* 1 removed, 0 absent */
+int64_t awsm_host_dub_offset(AwsmHostDub* b, AwsmKey key);                                         /* -1 absent */
+int64_t awsm_host_dub_slot(AwsmHostDub* b, AwsmKey key);
+size_t awsm_host_dub_size(AwsmHostDub* b);
+size_t awsm_host_dub_len(AwsmHostDub* b);
+size_t awsm_host_dub_capacity(AwsmHostDub* b);
+size_t awsm_host_dub_next_slot(AwsmHostDub* b);
+size_t awsm_host_dub_free_slots(AwsmHostDub* b, size_t* out, size_t cap);                          /* returns count */
+const uint8_t* awsm_host_dub_raw(AwsmHostDub* b);
+int64_t awsm_host_dub_take_resize(AwsmHostDub* b);                                                 /* -1 = None */
+size_t awsm_host_dub_take_dirty(AwsmHostDub* b, size_t* out_pairs, size_t cap_pairs);
+void awsm_host_dub_force_state(AwsmHostDub* b, size_t next_slot);                                  /* free_slots.clear(); next_slot = n */
+
+AwsmHostDsb* awsm_host_dsb_new(size_t initial_bytes, uint8_t zero);
+void awsm_host_dsb_free(AwsmHostDsb* b);
+size_t awsm_host_dsb_update(AwsmHostDsb* b, AwsmKey key, const uint8_t* data, size_t len);         /* returns offset */
+int awsm_host_dsb_patch(AwsmHostDsb* b, AwsmKey key, size_t at, const uint8_t* data, size_t len);  /* update_with_unchecked; -1 = missing key */
+void awsm_host_dsb_remove(AwsmHostDsb* b, AwsmKey key);
+int64_t awsm_host_dsb_offset(AwsmHostDsb* b, AwsmKey key);
+int64_t awsm_host_dsb_size_of(AwsmHostDsb* b, AwsmKey key);
+size_t awsm_host_dsb_used_size(AwsmHostDsb* b);
+size_t awsm_host_dsb_len(AwsmHostDsb* b);
+size_t awsm_host_dsb_capacity(AwsmHostDsb* b);
+size_t awsm_host_dsb_tree_root(AwsmHostDsb* b);
+const uint8_t* awsm_host_dsb_raw(AwsmHostDsb* b);
+int64_t awsm_host_dsb_take_resize(AwsmHostDsb* b);
+size_t awsm_host_dsb_take_dirty(AwsmHostDsb* b, size_t* out_pairs, size_t cap_pairs);
+size_t awsm_host_round_pow2(size_t n);
+size_t awsm_host_index_to_offset(size_t idx, size_t leaves);
+size_t awsm_host_offset_to_index(size_t off, size_t leaves);
+/* write_buffer_with_dirty_ranges plan: pairs in, pairs out; returns number of output pairs */
+size_t awsm_host_write_plan(size_t raw_len, const size_t* in_pairs, size_t n_in, size_t* out_pairs, size_t cap_pairs);
+/* Frustum::from_view_projection(...).intersects_aabb (frustum.rs:42-89) */
+int awsm_host_frustum_intersects(const float view_projection[16], const float aabb_min[3], const float aabb_max[3]);
+/* Aabb::transformed (bounds.rs:38-61) */
+void awsm_host_aabb_transformed(const float mat4[16], const float aabb_min[3], const float aabb_max[3], float out_min[3], float out_max[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWSM_HOST_H */
