@@ -357,7 +357,7 @@ int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_rows before resize");
     if (y0 == 0 && y1 == 0) { c->y0 = c->y1 = 0; return AWSM_OK; }
-    if (y0 >= y1 || y1 > c->height || (y0 % kTile) != 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need 32-aligned y0 < y1 <= height (got %u,%u)", y0, y1);
+    if (y0 >= y1 || y1 > c->height) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need y0 < y1 <= height (got %u,%u)", y0, y1);
     c->y0 = y0; c->y1 = y1;
     return AWSM_OK;
 }

@@ -120,17 +120,26 @@ class HipDevice:
         if rc != 0:
             raise AwsmHipError(rc, "awsm_hip_create", "no usable gfx950 device" if rc == -4 else "see status code")
         self.ctx = ctx
+        self.owns = True
         self.width = self.height = 0
         self.lut_size = (0, 0)
+
+    @classmethod
+    def from_ctx(cls, ctx: int, width: int, height: int) -> "HipDevice":
+        """Non-owning view over an AwsmHipCtx created elsewhere (the host layer's), for the readback helpers."""
+        self = cls.__new__(cls)
+        self.lib, self.ctx, self.owns = load_library(), C.c_void_p(ctx), False
+        self.width, self.height, self.lut_size = width, height, (0, 0)
+        return self
 
     def _chk(self, rc: int, where: str):
         if rc != 0:
             raise AwsmHipError(rc, where, (self.lib.awsm_hip_last_error(self.ctx) or b"").decode())
 
     def close(self):
-        if self.ctx:
+        if self.ctx and self.owns:
             self.lib.awsm_hip_destroy(self.ctx)
-            self.ctx = None
+        self.ctx = None
 
     def __del__(self):
         try:

@@ -157,7 +157,8 @@ int awsm_hip_buffer_write(AwsmHipCtx* ctx, AwsmBuf which, size_t dst_off, const 
 int awsm_hip_resize(AwsmHipCtx* ctx, uint32_t width, uint32_t height, uint32_t msaa);
 
 /* ---- multi-GPU screen sharding (new; no reference counterpart): this ctx rasterises and shades only
- * pixel rows [y0, y1) (full width).  y0 == y1 == 0 restores the full frame.  y0 must be tile aligned (32). ---- */
+ * pixel rows [y0, y1) (full width).  y0 == y1 == 0 restores the full frame.  Any row boundary is allowed: tiles that
+ * straddle it are clipped per pixel, so a shard's rows are bit-identical to the same rows of the full frame. ---- */
 int awsm_hip_set_shard_rows(AwsmHipCtx* ctx, uint32_t y0, uint32_t y1);
 
 /* ---- texture pool bind (crates/renderer/src/render_passes/material_opaque/bind_group.rs:331-360):

@@ -40,6 +40,18 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None):
     return dev, stats
 
 
+def host_frame(scene, lut, rows=(0, 0)):
+    """The product path: SceneDesc -> C++ host layer (key API, mirrors, dirty uploads) -> C-ABI -> HIP kernels."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    from awsm_renderer_amd.host import Renderer
+    r = Renderer(scene, parity_tap=True, lut_rgba16f=oracle_lib.lut_rg_to_rgba16f(lut))
+    if rows != (0, 0):
+        r.host.set_shard_rows(*rows)
+    stats = r.render(sync=True)
+    dev = HipDevice.from_ctx(r.host.device_ctx, scene.width, scene.height)
+    return r, dev, stats
+
+
 def f16_ulp_distance(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
     """distance in representable f16 values (sign-magnitude -> monotonic integer)"""
     def mono(x):

@@ -32,6 +32,38 @@ def _check(scene, lut, rows=(0, 0)):
     return r, stats
 
 
+def _check_host(scene, lut, rows=(0, 0)):
+    """Same bar, but through the C++ host layer (the path bench.py and smoke() use)."""
+    model = helpers.build_model(scene)
+    orc = helpers.oracle_frame(model, lut, rows=rows)
+    r, dev, stats = helpers.host_frame(scene, lut, rows=rows)
+    res = helpers.compare_frames(orc, dev, rows=None if rows == (0, 0) else rows, rgb_tol=RGB_TOL)
+    # a second frame with nothing changed uploads nothing and renders the same image
+    st2 = r.render(sync=True)
+    uploaded = r.host.upload_bytes_last_frame()
+    res2 = helpers.compare_frames(orc, dev, rows=None if rows == (0, 0) else rows, rgb_tol=RGB_TOL)
+    dev.close()
+    r.close()
+    for x in (res, res2):
+        assert x["clip_mismatch"] == 0 and x["nt_mismatch"] == 0 and x["key_mismatch"] == 0, x
+        assert x["rgb_over_tol"] == 0 and x["alpha_mismatch"] == 0 and x["f16_max_ulp"] <= 1, x
+    assert uploaded == 0, uploaded
+    assert st2["covered_pixels"] == stats["covered_pixels"] == res["covered"]
+
+
+@pytest.mark.parametrize("name", ["box", "helmet", "skinned_morph", "atrium"])
+def test_through_host_layer(name, oracle_lut):
+    scene = {"box": lambda: scenes.box_scene(200, 160),
+             "helmet": lambda: scenes.helmet_scene(400, 240, segments=48, rings=36, tex_size=64),
+             "skinned_morph": lambda: scenes.skinned_morph_scene(400, 240, around=24, along=64, tex_size=32),
+             "atrium": lambda: scenes.atrium_scene(512, 288, detail=0.25, tex_scale=1 / 16)}[name]()
+    _check_host(scene, oracle_lut)
+
+
+def test_host_layer_shard_rows(oracle_lut):
+    _check_host(scenes.atrium_scene(384, 224, detail=0.125, tex_scale=1 / 32), oracle_lut, rows=(101, 197))
+
+
 def test_box(oracle_lut):
     _check(scenes.box_scene(256, 256), oracle_lut)
 
