@@ -27,13 +27,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def strip_rows(height: int, n: int, r: int):
-    """Contiguous strips of ceil(H/N) rows; the last one may be shorter."""
-    per = (height + n - 1) // n
-    y0 = min(r * per, height)
-    return y0, min(y0 + per, height), per
-
-
 def algorithmic_bytes(scene, stats, rows):
     """Compulsory HBM traffic per launch, SURVEY.md §8(d) (restated in DESIGN.md §"Measurement")."""
     import numpy as np
@@ -105,6 +98,7 @@ def main():
 
     from awsm_renderer_amd import scenes
     from awsm_renderer_amd.host import Renderer
+    from awsm_renderer_amd.sharding import gather_image, strip_rows
 
     W, H = args.width, args.height
     scene = scenes.atrium_scene(W, H, detail=args.detail, tex_scale=args.tex_scale)
@@ -130,7 +124,7 @@ def main():
         r.host.camera_update(scene.view, scene.proj, scene.camera_position)
         r.host.render(sync=False)
         if world > 1:
-            dist.all_gather_into_tensor(full, strip)
+            gather_image(strip, full, world)
 
     def barrier():
         if world > 1:
@@ -174,7 +168,7 @@ def main():
         from oracle import oracle_lib
         lut_rg = oracle_lib.brdf_lut(64, 64)
         mid = H // 2
-        half = max(8, H // 32)
+        half = max(8, H // 8)
         cpu = cpu_baseline(scene, lut_rg, (max(0, mid - half), min(H, mid + half)))
 
     if world > 1:

@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two processes (gloo), each renders its strip of the frame with the CPU oracle, the strips are
+all-gathered with awsm_renderer_amd.sharding exactly as bench.py does, and the assembled image must equal the
+single-process full frame bit for bit (a shard's rows are defined to be identical to the full frame's rows)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["AWSM_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from awsm_renderer_amd import scenes
+from awsm_renderer_amd.sharding import strip_rows, gather_image
+from oracle import oracle_lib
+from tests import helpers
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+scene = scenes.atrium_scene(160, 101, detail=0.125, tex_scale=1 / 64)
+lut = oracle_lib.brdf_lut(16, 16, threads=2)
+model = helpers.build_model(scene)
+y0, y1, per = strip_rows(scene.height, world, rank)
+fr = helpers.oracle_frame(model, lut, rows=(y0, y1), threads=2)
+# gloo has no 16-bit all-gather: ship each RGBA16F pixel as two int32 words (RCCL moves the f16 tensor directly)
+strip = torch.zeros((per, scene.width, 2), dtype=torch.int32)
+strip[: y1 - y0] = torch.from_numpy(np.ascontiguousarray(fr.rgba16f[y0:y1]).view(np.int32))
+full = torch.zeros((world * per, scene.width, 2), dtype=torch.int32)
+gather_image(strip, full, world)
+keys = torch.zeros((per, scene.width), dtype=torch.int64)
+keys[: y1 - y0] = torch.from_numpy(fr.keys[y0:y1].view(np.int64))
+full_keys = torch.zeros((world * per, scene.width), dtype=torch.int64)
+dist.all_gather_into_tensor(full_keys, keys)
+if rank == 0:
+    np.save(os.environ["AWSM_OUT"] + "_img.npy", full.numpy()[: scene.height])
+    np.save(os.environ["AWSM_OUT"] + "_keys.npy", full_keys.numpy()[: scene.height])
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strips_gather_to_the_full_frame(world, tmp_path):
+    from awsm_renderer_amd import scenes
+    from oracle import oracle_lib
+    from tests import helpers
+    out = str(tmp_path / "gather")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, AWSM_ROOT=ROOT, AWSM_OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    scene = scenes.atrium_scene(160, 101, detail=0.125, tex_scale=1 / 64)
+    lut = oracle_lib.brdf_lut(16, 16, threads=2)
+    ref = helpers.oracle_frame(helpers.build_model(scene), lut, threads=4)
+    img = np.ascontiguousarray(np.load(out + "_img.npy")).view(np.uint16)
+    keys = np.load(out + "_keys.npy").view(np.uint64)
+    assert np.array_equal(keys, ref.keys)
+    assert np.array_equal(img, ref.rgba16f)
+
+
+def test_strip_rows_cover_the_frame_exactly():
+    from awsm_renderer_amd.sharding import strip_rows
+    for h in (1, 31, 32, 33, 101, 1080, 2160):
+        for n in (1, 2, 3, 4, 8):
+            rows = [strip_rows(h, n, r) for r in range(n)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            for a, b in zip(rows, rows[1:]):
+                assert a[1] == b[0] or (a[1] == h and b[0] == h)
+            assert all(y1 - y0 <= per for y0, y1, per in rows)
