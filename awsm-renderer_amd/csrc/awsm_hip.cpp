@@ -23,6 +23,7 @@ void awsm_launch_bin_scan(const FrameDev* f, hipStream_t s);
 void awsm_launch_bin_fill(const FrameDev* f, hipStream_t s);
 void awsm_launch_raster(const FrameDev* f, hipStream_t s);
 void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
+void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
 void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s);
 void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n, hipStream_t s);
 }
@@ -68,6 +69,7 @@ struct AwsmHipCtx {
     bool geometry_done = false, opaque_done = false;
     AwsmOpaqueParams last_opaque{};
     uint32_t overflow_retries = 0;
+    bool has_opaque_for_stats() const { return !opaque_done || last_opaque.has_opaque != 0; }
 
     // pinned staging ring for buffer_write / small uploads
     uint8_t* stage = nullptr;
@@ -179,7 +181,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->bin_capacity = c->bin_capacity;
     f->draws = (const DrawDev*)c->draws_dev.ptr;
     f->clip = (float4*)c->clip.ptr; f->nrm = (float4*)c->nrm.ptr; f->tan = (float4*)c->tan.ptr;
-    f->tri_flags = (uint8_t*)c->tri_flags.ptr;
+    f->tri_info = (uint32_t*)c->tri_flags.ptr;
     f->tile_count = (uint32_t*)c->tile_count.ptr; f->tile_offset = (uint32_t*)c->tile_offset.ptr;
     f->tile_cursor = (uint32_t*)c->tile_cursor.ptr; f->bin_list = (uint32_t*)c->bin_list.ptr;
     f->counters = (uint32_t*)c->counters.ptr;
@@ -460,6 +462,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
         tris += d.tri_count;
         blocks += (3ull * d.tri_count + 255) / 256;
         if (tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one pass");
+        if (c->draws_host.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^24 non-empty draws in one pass");
     }
     c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
 
@@ -469,7 +472,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = dev_reserve(c, c->clip, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
     if ((rc = dev_reserve(c, c->nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
     if ((rc = dev_reserve(c, c->tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, c->tri_flags, std::max<size_t>(c->total_tris, 1)))) return rc;
+    if ((rc = dev_reserve(c, c->tri_flags, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
     const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
     const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
     if ((rc = dev_reserve(c, c->tile_count, n_tiles_full * 4))) return rc;
@@ -514,6 +517,12 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->device));
     for (int attempt = 0;; attempt++) {
+        if (out && c->geometry_done && c->has_opaque_for_stats()) {   // stats only: count covered pixels from the visibility buffer
+            FrameDev f;
+            fill_frame(c, &f);
+            HIPCHK(c, hipMemsetAsync((uint32_t*)c->counters.ptr + 3, 0, sizeof(uint32_t), c->stream));
+            awsm_launch_count_covered(&f, c->stream);
+        }
         HIPCHK(c, hipMemcpyAsync(c->counters_host, c->counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (!c->geometry_done || c->counters_host[2] == 0 || attempt >= 4) break;

@@ -54,7 +54,7 @@ struct FrameDev {
     float4* clip;                 // total_verts
     float4* nrm;                  // total_verts  (world normal xyz, 0)
     float4* tan;                  // total_verts  (world tangent xyz, handedness)
-    uint8_t* tri_flags;           // total_tris   (AWSM_DRAW_* of the owning draw)
+    uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..31)
     // binning
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1

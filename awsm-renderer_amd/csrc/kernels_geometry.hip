@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     f.clip[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
     f.nrm[gv] = make_float4(world_normal.x, world_normal.y, world_normal.z, 0.0f);
     f.tan[gv] = make_float4(tangent_ortho.x, tangent_ortho.y, tangent_ortho.z, tangent.w);
-    if (lv % 3u == 0u) f.tri_flags[d.first_tri + lv / 3u] = (uint8_t)d.flags;
+    if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | (d.flags << 24);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     bool ok = false;
     if (r < f.total_tris) {
         const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
-        const bool cull_back = (f.tri_flags[r] & AWSM_DRAW_CULL_BACK) != 0;
+        const bool cull_back = ((f.tri_info[r] >> 24) & AWSM_DRAW_CULL_BACK) != 0;
         ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, t);
     }
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;

@@ -23,12 +23,89 @@ AWSM_DI uint32_t xcd_remap_s(uint32_t b, uint32_t n) {
     return (b & 7u) * per + (b >> 3);
 }
 
+// ================================================================================================
+// STRICT section (arithmetic contract, -ffp-contract=off, IEEE div/sqrt): what fs_main wrote for this pixel
+// (fragment.wgsl:23-54), rounded to the G-buffer storage formats.  Bit-identical to oracle/c/oracle_shade.c.
+// ================================================================================================
+struct GBufferTexel {
+    f4 packed_nt;    // RGBA16F normal_tangent, already rounded to f16
+    float bx, by;    // RG16F barycentric, already rounded to f16
+    bool valid;
+};
+AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int cx, int cy) {
+    GBufferTexel g;
+    const float4 v0 = f.clip[(size_t)rank * 3], v1 = f.clip[(size_t)rank * 3 + 1], v2 = f.clip[(size_t)rank * 3 + 2];
+    TriSetup t;
+    g.valid = tri_setup(v0, v1, v2, false, f.width, f.height, 0u, f.height, t);
+    if (!g.valid) return g;
+    float e0, e1, e2;
+    tri_edges(t, cx, cy, e0, e1, e2);
+    const float esum = (e0 + e1) + e2;
+    const float b0 = e0 / esum, b1 = e1 / esum, b2 = e2 / esum;
+    const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
+    const float4 t0 = f.tan[(size_t)rank * 3], t1 = f.tan[(size_t)rank * 3 + 1], t2 = f.tan[(size_t)rank * 3 + 2];
+    const f3 Ni = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y, (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
+    const f4 Ti = {(b0 * t0.x + b1 * t1.x) + b2 * t2.x, (b0 * t0.y + b1 * t1.y) + b2 * t2.y,
+                   (b0 * t0.z + b1 * t1.z) + b2 * t2.z, (b0 * t0.w + b1 * t1.w) + b2 * t2.w};
+    const f4 p = pack_normal_tangent(normalize(Ni), normalize(mk3(Ti.x, Ti.y, Ti.z)), Ti.w);
+    g.packed_nt = {round_f16(p.x), round_f16(p.y), round_f16(p.z), round_f16(p.w)};
+    g.bx = round_f16(b0);
+    g.by = round_f16(b1);
+    return g;
+}
+
+// ================================================================================================
+// RELAXED section: everything downstream of the quantised G-buffer values only has to stay within 1e-4 of the
+// oracle (BASELINE.json north_star), so it may contract to FMA and use the hardware reciprocal / rsqrt / exp2 /
+// log2 / sin / cos units (each ~1 ulp).  Helpers are re-defined here under contract(fast); the strict ones in
+// device_math.hpp keep their own flags even when inlined.
+// ================================================================================================
+#pragma clang fp contract(fast)
+namespace fm {
+AWSM_DI float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+AWSM_DI float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+AWSM_DI float fdiv(float a, float b) { return a * rcp(b); }
+AWSM_DI float fdot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+AWSM_DI f3 fnormalize(f3 a) { return a * rsq(fdot(a, a)); }
+AWSM_DI f3 fsafe_normalize(f3 n) { const float l = fdot(n, n); return l > 0.0f ? n * rsq(l) : mk3(0.0f, 0.0f, 1.0f); }
+AWSM_DI float pow5(float x) { const float x2 = x * x; return x2 * x2 * x; }
+AWSM_DI float powp(float x, float y) { return x > 0.0f ? __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)) : (x == 0.0f ? (y == 0.0f ? 1.0f : 0.0f) : __builtin_nanf("")); }
+AWSM_DI f4 fmul(const m4& m, f4 v) {
+    return {m.c[0].x * v.x + m.c[1].x * v.y + m.c[2].x * v.z + m.c[3].x * v.w, m.c[0].y * v.x + m.c[1].y * v.y + m.c[2].y * v.z + m.c[3].y * v.w,
+            m.c[0].z * v.x + m.c[1].z * v.y + m.c[2].z * v.z + m.c[3].z * v.w, m.c[0].w * v.x + m.c[1].w * v.y + m.c[2].w * v.z + m.c[3].w * v.w};
+}
+AWSM_DI f3 fdecode_octahedral(f2 e) {         // math.wgsl:55-67
+    const float fx = e.x * 2.0f - 1.0f, fy = e.y * 2.0f - 1.0f;
+    f3 n = {fx, fy, (1.0f - fabsf(fx)) - fabsf(fy)};
+    const float t = clampf(-n.z, 0.0f, 1.0f);
+    n.x += (n.x >= 0.0f) ? -t : t;
+    n.y += (n.y >= 0.0f) ? -t : t;
+    return fnormalize(n);
+}
+AWSM_DI TBN funpack_normal_tangent(f4 rgba) {  // math.wgsl:104-116
+    TBN r;
+    r.N = fdecode_octahedral({rgba.x, rgba.y});
+    const float theta = rgba.z * kTau - kPi;
+    const float s = (rgba.w >= 0.5f) ? 1.0f : -1.0f;
+    f3 tt, tb;
+    if (r.N.z < -0.9999999f) { tt = {0.0f, -1.0f, 0.0f}; tb = {-1.0f, 0.0f, 0.0f}; }
+    else {
+        const float a = rcp(1.0f + r.N.z), bb = (-r.N.x * r.N.y) * a;
+        tt = {1.0f - (r.N.x * r.N.x) * a, bb, -r.N.x};
+        tb = {bb, 1.0f - (r.N.y * r.N.y) * a, -r.N.y};
+    }
+    const float c = __ocml_native_cos_f32(theta), sn = __ocml_native_sin_f32(theta);
+    r.T = fnormalize(tt * c + tb * sn);
+    r.B = fnormalize(cross(r.N, r.T)) * s;
+    return r;
+}
+}  // namespace fm
+
 // ---------------- textures.wgsl ----------------
 struct TexInfo {
     bool exists;
     uint32_t array_index, layer_index, uv_set_index, sampler_index, uv_transform_index;
 };
-AWSM_DI TexInfo tex_none() { return {false, 0u, 0u, 0u, 0u, 0u}; }
 AWSM_DI TexInfo tex_load(const uint32_t* __restrict__ m, uint32_t i) {      // textures.wgsl:75-114
     TexInfo t;
     const uint32_t array_and_layer = m[i + 1], uv_and_sampler = m[i + 2], extra = m[i + 3], transform_offset = m[i + 4];
@@ -39,21 +116,31 @@ AWSM_DI TexInfo tex_load(const uint32_t* __restrict__ m, uint32_t i) {      // t
     return t;
 }
 
+// exact integer wrap without an integer divide: power-of-two sizes use masks, other sizes a float quotient + fix-up
+AWSM_DI int mod_floor(int i, int n) {
+    if ((n & (n - 1)) == 0) return i & (n - 1);
+    int r = i - (int)floorf((float)i * fm::rcp((float)n)) * n;
+    if (r < 0) r += n;
+    if (r >= n) r -= n;
+    return r;
+}
 AWSM_DI int wrap_index(int i, int n, uint32_t mode) {
-    if (mode == 1u) { int m = i % n; return m < 0 ? m + n : m; }
-    if (mode == 2u) { int p = 2 * n; int m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; }
+    if (mode == 1u) return mod_floor(i, n);
+    if (mode == 2u) { const int m = mod_floor(i, 2 * n); return m < n ? m : 2 * n - 1 - m; }
     return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
 }
 AWSM_DI f4 texel_rgba8(const uint8_t* __restrict__ p) {
     const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
-    return {(float)(u & 255u) / 255.0f, (float)((u >> 8) & 255u) / 255.0f, (float)((u >> 16) & 255u) / 255.0f, (float)(u >> 24) / 255.0f};
+    const float k = 1.0f / 255.0f;
+    return {(float)(u & 255u) * k, (float)((u >> 8) & 255u) * k, (float)((u >> 16) & 255u) * k, (float)(u >> 24) * k};
 }
 AWSM_DI float safe_floor(float x, float& frac) {
-    float fl = floorf(x);
+    const float fl = floorf(x);
     if (!(fl >= -1073741824.0f && fl <= 1073741824.0f)) { frac = 0.0f; return 0.0f; }
     frac = x - fl;
     return fl;
 }
+AWSM_DI f4 lerp4(f4 a, f4 b, float t) { const float s = 1.0f - t; return {a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t}; }
 // textureSampleLevel(tex, sampler, uv, layer, 0): DESIGN.md §"Texture sampling"
 AWSM_DI f4 sample_array_level0(const TexArrayDev& arr, const AwsmSampler& smp, f2 uv, uint32_t layer) {
     const int W = (int)arr.width, H = (int)arr.height;
@@ -69,12 +156,10 @@ AWSM_DI f4 sample_array_level0(const TexArrayDev& arr, const AwsmSampler& smp, f
     const float y0f = safe_floor(uv.y * (float)H - 0.5f, fy);
     const int i0 = wrap_index((int)x0f, W, smp.address_mode_u), i1 = wrap_index((int)x0f + 1, W, smp.address_mode_u);
     const int j0 = wrap_index((int)y0f, H, smp.address_mode_v), j1 = wrap_index((int)y0f + 1, H, smp.address_mode_v);
-    const f4 c00 = texel_rgba8(base + ((size_t)j0 * W + i0) * 4u), c10 = texel_rgba8(base + ((size_t)j0 * W + i1) * 4u);
-    const f4 c01 = texel_rgba8(base + ((size_t)j1 * W + i0) * 4u), c11 = texel_rgba8(base + ((size_t)j1 * W + i1) * 4u);
-    const float gx = 1.0f - fx, gy = 1.0f - fy;
-    const f4 top = {c00.x * gx + c10.x * fx, c00.y * gx + c10.y * fx, c00.z * gx + c10.z * fx, c00.w * gx + c10.w * fx};
-    const f4 bot = {c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx};
-    return {top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy};
+    const uint8_t* r0 = base + (size_t)j0 * W * 4u;
+    const uint8_t* r1 = base + (size_t)j1 * W * 4u;
+    const f4 c00 = texel_rgba8(r0 + i0 * 4), c10 = texel_rgba8(r0 + i1 * 4), c01 = texel_rgba8(r1 + i0 * 4), c11 = texel_rgba8(r1 + i1 * 4);
+    return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
 }
 
 // ---------------- per-pixel attribute context ----------------
@@ -85,23 +170,13 @@ struct Attr {
     uint32_t uv_sets_index;
     f3 bary;
 };
-AWSM_DI f2 texture_uv(const Attr& a, const TexInfo& t) {                    // texture_uvs.wgsl:64-84
-    const uint32_t o = a.uv_sets_index + t.uv_set_index * 2u;
-    const float2 u0 = *reinterpret_cast<const float2*>(a.ad + a.v0 + o);   // strides are multiples of 8 B in practice;
-    const float2 u1 = *reinterpret_cast<const float2*>(a.ad + a.v1 + o);   // see aligned8 guard in the caller
-    const float2 u2 = *reinterpret_cast<const float2*>(a.ad + a.v2 + o);
-    return {(a.bary.x * u0.x + a.bary.y * u1.x) + a.bary.z * u2.x, (a.bary.x * u0.y + a.bary.y * u1.y) + a.bary.z * u2.y};
-}
-AWSM_DI f2 texture_uv_unaligned(const Attr& a, const TexInfo& t) {
+AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // texture_uvs.wgsl:64-84,144-187, textures.wgsl:131-150
     const uint32_t o = a.uv_sets_index + t.uv_set_index * 2u;
     const float x0 = a.ad[a.v0 + o], y0 = a.ad[a.v0 + o + 1], x1 = a.ad[a.v1 + o], y1 = a.ad[a.v1 + o + 1];
     const float x2 = a.ad[a.v2 + o], y2 = a.ad[a.v2 + o + 1];
-    return {(a.bary.x * x0 + a.bary.y * x1) + a.bary.z * x2, (a.bary.x * y0 + a.bary.y * y1) + a.bary.z * y2};
-}
-AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // texture_uvs.wgsl:144-187, textures.wgsl:131-150
-    const f2 uv = texture_uv_unaligned(a, t);
+    const f2 uv = {a.bary.x * x0 + a.bary.y * x1 + a.bary.z * x2, a.bary.x * y0 + a.bary.y * y1 + a.bary.z * y2};
     const float* tt = reinterpret_cast<const float*>(a.sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
-    const f2 uvt = {(tt[0] * uv.x + tt[1] * uv.y) + tt[4], (tt[2] * uv.x + tt[3] * uv.y) + tt[5]};
+    const f2 uvt = {tt[0] * uv.x + tt[1] * uv.y + tt[4], tt[2] * uv.x + tt[3] * uv.y + tt[5]};
     if (t.array_index >= a.sc->n_tex || t.sampler_index >= a.sc->n_samplers) return {0.0f, 0.0f, 0.0f, 0.0f};
     return sample_array_level0(a.sc->tex[t.array_index], a.sc->samplers[t.sampler_index], uvt, t.layer_index);
 }
@@ -109,7 +184,7 @@ AWSM_DI f4 vertex_color(const Attr& a, uint32_t set_index) {               // ve
     const uint32_t o = set_index * 4u;
     float r[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) r[j] = (a.bary.x * a.ad[a.v0 + o + j] + a.bary.y * a.ad[a.v1 + o + j]) + a.bary.z * a.ad[a.v2 + o + j];
+    for (int j = 0; j < 4; j++) r[j] = a.bary.x * a.ad[a.v0 + o + j] + a.bary.y * a.ad[a.v1 + o + j] + a.bary.z * a.ad[a.v2 + o + j];
     return {r[0], r[1], r[2], r[3]};
 }
 
@@ -128,96 +203,47 @@ struct PbrColor {
 AWSM_DI f3 normal_map(const Attr& a, const TexInfo& t, float scale, const TBN& tbn) {   // material_color_calc.wgsl:301-322
     if (!t.exists) return tbn.N;
     const f4 s = sample_tex(a, t);
-    const f3 tn = {(s.x * 2.0f - 1.0f) * scale, (s.y * 2.0f - 1.0f) * scale, s.z * 2.0f - 1.0f};
-    m3 m; m.c[0] = tbn.T; m.c[1] = tbn.B; m.c[2] = tbn.N;
-    return normalize(mul(m, tn));
+    const float tx = (s.x * 2.0f - 1.0f) * scale, ty = (s.y * 2.0f - 1.0f) * scale, tz = s.z * 2.0f - 1.0f;
+    return fm::fnormalize(tbn.T * tx + tbn.B * ty + tbn.N * tz);
 }
 
 // ---------------- brdf.wgsl ----------------
-AWSM_DI float effective_ior(float ior) { return ior < 1.0f ? 1.5f : ior; }
-AWSM_DI float ior_to_f0(float ior) { float v = effective_ior(ior); float r = (v - 1.0f) / (v + 1.0f); return r * r; }
+AWSM_DI float ior_to_f0(float ior) { const float v = ior < 1.0f ? 1.5f : ior; const float r = fm::fdiv(v - 1.0f, v + 1.0f); return r * r; }
 AWSM_DI f3 volume_attenuation(float distance, f3 color, float att_distance) {           // brdf.wgsl:55-74
     if (distance <= 0.0f) return splat3(1.0f);
     if (att_distance <= 0.0f || att_distance > 1e10f) return splat3(1.0f);
     if (color.x >= 0.999f && color.y >= 0.999f && color.z >= 0.999f) return splat3(1.0f);
-    const float e = distance / att_distance;
-    return {powf(color.x, e), powf(color.y, e), powf(color.z, e)};
+    const float e = fm::fdiv(distance, att_distance);
+    return {fm::powp(color.x, e), fm::powp(color.y, e), fm::powp(color.z, e)};
 }
 AWSM_DI bool should_apply_volume_attenuation(float thickness, float att_distance, f3 c) {
     return thickness > 0.0f && att_distance < 1e10f && (c.x < 1.0f || c.y < 1.0f || c.z < 1.0f);
 }
-AWSM_DI f3 safe_half_vector(f3 v, f3 l) {                                                // brdf.wgsl:94-101
-    const f3 sum = v + l;
-    const float len_sq = dot(sum, sum);
-    if (len_sq > 1e-8f) return sum * inverse_sqrt(len_sq);
-    return {0.0f, 0.0f, 0.0f};
-}
-AWSM_DI float pow5(float x) { return powf(x, 5.0f); }
 AWSM_DI f3 fresnel_schlick_f90(float cos_theta, f3 F0, float f90) {                      // brdf.wgsl:111-115
-    const float p = pow5(1.0f - saturate(cos_theta));
+    const float p = fm::pow5(1.0f - saturate(cos_theta));
     return {F0.x + (f90 - F0.x) * p, F0.y + (f90 - F0.y) * p, F0.z + (f90 - F0.z) * p};
 }
-AWSM_DI float fresnel_schlick_scalar(float cos_theta, float F0) {                        // brdf.wgsl:104-108 (.r of a splat)
-    const float p = pow5(1.0f - saturate(cos_theta));
-    return F0 + (1.0f - F0) * p;
-}
+AWSM_DI float fresnel_schlick_scalar(float cos_theta, float F0) { return F0 + (1.0f - F0) * fm::pow5(1.0f - saturate(cos_theta)); }
 AWSM_DI float distribution_ggx(float n_dot_h, float alpha) {                             // brdf.wgsl:118-124
     const float a = fmaxf(alpha, 0.001f);
     const float a2 = a * a;
     const float ndh = saturate(n_dot_h);
     const float d = (ndh * ndh) * (a2 - 1.0f) + 1.0f;
-    return a2 / ((kPi * d) * d + kEps);
+    return fm::fdiv(a2, (kPi * d) * d + kEps);
 }
 AWSM_DI float geometry_schlick_ggx(float n_dot_x, float alpha) {                         // brdf.wgsl:127-132
     const float a = fmaxf(alpha, 0.001f);
     const float k = ((a + 1.0f) * (a + 1.0f)) * 0.125f;
     const float ndx = saturate(n_dot_x);
-    return ndx / (ndx * (1.0f - k) + k);
-}
-AWSM_DI float geometry_smith(f3 n, f3 v, f3 l, float alpha) {
-    return geometry_schlick_ggx(saturate(dot(n, v)), alpha) * geometry_schlick_ggx(saturate(dot(n, l)), alpha);
+    return fm::fdiv(ndx, ndx * (1.0f - k) + k);
 }
 constexpr float kClearcoatF0 = 0.04f;
-AWSM_DI float clearcoat_brdf_direct(float clearcoat, float cc_roughness, f3 cc_normal, f3 v, f3 l) {   // brdf.wgsl:149-181
-    if (clearcoat <= 0.0f) return 0.0f;
-    const f3 cc_n = safe_normalize(cc_normal);
-    const f3 h = safe_half_vector(v, l);
-    if (dot(h, h) == 0.0f) return 0.0f;
-    const float cc_n_dot_l = fmaxf(dot(cc_n, l), 0.0f);
-    const float cc_n_dot_v = fmaxf(dot(cc_n, v), 1e-4f);
-    const float cc_n_dot_h = fmaxf(dot(cc_n, h), 0.0f);
-    const float cc_v_dot_h = fmaxf(dot(v, h), 0.0f);
-    const float cc_alpha = fmaxf(cc_roughness * cc_roughness, 0.001f);
-    const float Fc = fresnel_schlick_scalar(cc_v_dot_h, kClearcoatF0);
-    const float Dc = distribution_ggx(cc_n_dot_h, cc_alpha);
-    const float Gc = geometry_smith(cc_n, v, l, cc_alpha);
-    return (((clearcoat * Fc) * Dc) * Gc) / fmaxf((4.0f * cc_n_dot_l) * cc_n_dot_v, kEps);
-}
-AWSM_DI float clearcoat_fresnel(float clearcoat, float v_dot_h) {
-    if (clearcoat <= 0.0f) return 0.0f;
-    return clearcoat * fresnel_schlick_scalar(v_dot_h, kClearcoatF0);
-}
-AWSM_DI f3 sheen_brdf_direct(f3 sheen_color, float sheen_roughness, f3 n, f3 v, f3 l) {  // brdf.wgsl:198-240
-    if (sheen_color.x <= 0.0f && sheen_color.y <= 0.0f && sheen_color.z <= 0.0f) return {0.0f, 0.0f, 0.0f};
-    const f3 h = safe_half_vector(v, l);
-    if (dot(h, h) == 0.0f) return {0.0f, 0.0f, 0.0f};
-    const float n_dot_l = fmaxf(dot(n, l), 0.0f);
-    const float n_dot_v = fmaxf(dot(n, v), 1e-4f);
-    const float n_dot_h = fmaxf(dot(n, h), 0.0f);
-    const float roughness = fmaxf(sheen_roughness, 0.07f);
-    const float alpha = roughness * roughness;
-    const float inv_alpha = 1.0f / alpha;
-    const float sin2h = 1.0f - n_dot_h * n_dot_h;
-    const float D = ((2.0f + inv_alpha) * powf(sin2h, inv_alpha * 0.5f)) / (2.0f * kPi);
-    const float V = 1.0f / (4.0f * ((n_dot_l + n_dot_v) - n_dot_l * n_dot_v));
-    return (sheen_color * D) * V;
-}
+AWSM_DI float clearcoat_fresnel(float clearcoat, float v_dot_h) { return clearcoat <= 0.0f ? 0.0f : clearcoat * fresnel_schlick_scalar(v_dot_h, kClearcoatF0); }
 AWSM_DI float sheen_albedo_scaling(f3 sheen_color, float sheen_roughness, float n_dot_v) {   // brdf.wgsl:245-262
     const float sheen_max = fmaxf(fmaxf(sheen_color.x, sheen_color.y), sheen_color.z);
     if (sheen_max <= 0.0f) return 1.0f;
     const float alpha = sheen_roughness * sheen_roughness;
-    const float E = alpha * (0.18f + 0.06f * (1.0f - n_dot_v));
-    return 1.0f - sheen_max * E;
+    return 1.0f - sheen_max * (alpha * (0.18f + 0.06f * (1.0f - n_dot_v)));
 }
 // brdf.wgsl:293-302 — linear, clamp-to-edge, RG of the RGBA16F LUT
 AWSM_DI f2 sample_brdf_lut(const DevScene* sc, float n_dot_v, float roughness) {
@@ -238,86 +264,97 @@ AWSM_DI f2 sample_brdf_lut(const DevScene* sc, float n_dot_v, float roughness) {
     return {r_top * gy + r_bot * fy, g_top * gy + g_bot * fy};
 }
 
-// brdf.wgsl:308-381
-AWSM_DI f3 brdf_direct(const PbrColor& c, f3 normal, f3 light_dir, f3 radiance, f3 surface_to_camera) {
-    const f3 n = safe_normalize(normal);
-    const f3 v = safe_normalize(surface_to_camera);
-    const f3 l = safe_normalize(light_dir);
-    const f3 h = safe_half_vector(v, l);
-    const float metallic = clampf(c.mr.x, 0.0f, 1.0f);
-    const float roughness = fmaxf(clampf(c.mr.y, 0.0f, 1.0f), 0.04f);
-    const float alpha = roughness * roughness;
-    const float n_dot_l = fmaxf(dot(n, l), 0.0f);
-    const float n_dot_v = fmaxf(dot(n, v), 1e-4f);
-    const bool has_half = dot(h, h) > 0.0f;
-    const float n_dot_h = has_half ? fmaxf(dot(n, h), 0.0f) : 0.0f;
-    const float v_dot_h = has_half ? fmaxf(dot(v, h), 0.0f) : 0.0f;
-    const float f0b = ior_to_f0(c.ior);
-    const f3 dielectric_f0 = min3(splat3(f0b) * c.specular_color, splat3(1.0f)) * c.specular;
-    const f3 F0 = mix3(dielectric_f0, c.base, metallic);
-    const float f90 = mixf(c.specular, 1.0f, metallic);
-    const f3 F = has_half ? fresnel_schlick_f90(v_dot_h, F0, f90) : fresnel_schlick_f90(n_dot_v, F0, f90);
-    const float D = distribution_ggx(n_dot_h, alpha);
-    const float G = geometry_smith(n, v, l, alpha);
+// Per-pixel terms shared by the IBL lobe and every punctual light (brdf_direct recomputes them per light in the WGSL;
+// hoisting them is value-preserving up to rounding).
+struct Surface {
+    f3 n, v, F0;
+    float metallic, roughness, alpha, f90, n_dot_v_ibl /* saturate */, n_dot_v_dir /* max(.,1e-4) */, sheen_scaling_dir, g1_v;
+    f3 cc_n;
+};
+
+// brdf.wgsl:308-381 for one light
+AWSM_DI f3 brdf_direct(const PbrColor& c, const Surface& sf, f3 light_dir, f3 radiance) {
+    const f3 n = sf.n, v = sf.v;
+    const f3 l = fm::fsafe_normalize(light_dir);
+    const f3 sum = v + l;
+    const float len_sq = fm::fdot(sum, sum);
+    const bool has_half = len_sq > 1e-8f;
+    const f3 h = has_half ? sum * fm::rsq(len_sq) : mk3(0.0f, 0.0f, 0.0f);
+    const float n_dot_l = fmaxf(fm::fdot(n, l), 0.0f);
+    const float n_dot_v = sf.n_dot_v_dir;
+    const float n_dot_h = has_half ? fmaxf(fm::fdot(n, h), 0.0f) : 0.0f;
+    const float v_dot_h = has_half ? fmaxf(fm::fdot(v, h), 0.0f) : 0.0f;
+    const f3 F = fresnel_schlick_f90(has_half ? v_dot_h : n_dot_v, sf.F0, sf.f90);
     f3 specular = {0.0f, 0.0f, 0.0f};
-    if (has_half) specular = (F * (D * G)) / fmaxf((4.0f * n_dot_l) * n_dot_v, kEps);
+    if (has_half) {
+        const float D = distribution_ggx(n_dot_h, sf.alpha);
+        const float G = sf.g1_v * geometry_schlick_ggx(saturate(fm::fdot(n, l)), sf.alpha);
+        specular = F * fm::fdiv(D * G, fmaxf((4.0f * n_dot_l) * n_dot_v, kEps));
+    }
     const float F_max = fmaxf(fmaxf(F.x, F.y), F.z);
-    const float k_d = (1.0f - F_max) * (1.0f - metallic);
+    const float k_d = (1.0f - F_max) * (1.0f - sf.metallic);
     const f3 diffuse = (c.base * k_d) * (1.0f / kPi);
     f3 result = (((diffuse + specular) * radiance) * n_dot_l) * c.occlusion;
-    const f3 sheen = sheen_brdf_direct(c.sheen_color, c.sheen_roughness, n, v, l);
-    const float sheen_scaling = sheen_albedo_scaling(c.sheen_color, c.sheen_roughness, n_dot_v);
-    result = result * sheen_scaling + ((sheen * radiance) * n_dot_l) * c.occlusion;
-    const float clearcoat_spec = clearcoat_brdf_direct(c.clearcoat, c.clearcoat_roughness, c.clearcoat_normal, v, l);
-    const float cc_fresnel = clearcoat_fresnel(c.clearcoat, v_dot_h);
-    result = result * (1.0f - cc_fresnel) + (radiance * clearcoat_spec) * n_dot_l;
+    if (c.sheen_color.x > 0.0f || c.sheen_color.y > 0.0f || c.sheen_color.z > 0.0f) {   // brdf.wgsl:198-240
+        f3 sheen = {0.0f, 0.0f, 0.0f};
+        if (has_half) {
+            const float rough = fmaxf(c.sheen_roughness, 0.07f);
+            const float inv_alpha = fm::rcp(rough * rough);
+            const float sin2h = 1.0f - n_dot_h * n_dot_h;
+            const float D = ((2.0f + inv_alpha) * fm::powp(sin2h, inv_alpha * 0.5f)) * (1.0f / (2.0f * kPi));
+            const float V = fm::rcp(4.0f * ((n_dot_l + n_dot_v) - n_dot_l * n_dot_v));
+            sheen = (c.sheen_color * D) * V;
+        }
+        result = result * sf.sheen_scaling_dir + ((sheen * radiance) * n_dot_l) * c.occlusion;
+    }
+    if (c.clearcoat > 0.0f) {   // brdf.wgsl:149-190
+        float clearcoat_spec = 0.0f;
+        if (has_half) {
+            const float cc_n_dot_l = fmaxf(fm::fdot(sf.cc_n, l), 0.0f);
+            const float cc_n_dot_v = fmaxf(fm::fdot(sf.cc_n, v), 1e-4f);
+            const float cc_n_dot_h = fmaxf(fm::fdot(sf.cc_n, h), 0.0f);
+            const float cc_alpha = fmaxf(c.clearcoat_roughness * c.clearcoat_roughness, 0.001f);
+            const float Fc = fresnel_schlick_scalar(v_dot_h, kClearcoatF0);
+            const float Dc = distribution_ggx(cc_n_dot_h, cc_alpha);
+            const float Gc = geometry_schlick_ggx(saturate(fm::fdot(sf.cc_n, v)), cc_alpha) * geometry_schlick_ggx(saturate(fm::fdot(sf.cc_n, l)), cc_alpha);
+            clearcoat_spec = fm::fdiv(((c.clearcoat * Fc) * Dc) * Gc, fmaxf((4.0f * cc_n_dot_l) * cc_n_dot_v, kEps));
+        }
+        const float cc_fresnel = clearcoat_fresnel(c.clearcoat, v_dot_h);
+        result = result * (1.0f - cc_fresnel) + (radiance * clearcoat_spec) * n_dot_l;
+    }
     return result;
 }
 
 // brdf.wgsl:389-576 (brdf_ibl -> brdf_ibl_with_transmission); the three cubes are uniform colours
-AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, f3 normal, f3 surface_to_camera) {
+AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf) {
     const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
     const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
-    const f3 n = safe_normalize(normal);
-    const f3 v = safe_normalize(surface_to_camera);
-    const float metallic = clampf(c.mr.x, 0.0f, 1.0f);
-    const float roughness = fmaxf(clampf(c.mr.y, 0.0f, 1.0f), 0.04f);
-    const float n_dot_v = saturate(dot(n, v));
-    const float f0b = ior_to_f0(c.ior);
-    const f3 dielectric_f0 = min3(splat3(f0b) * c.specular_color, splat3(1.0f)) * c.specular;
-    const f3 F0 = mix3(dielectric_f0, c.base, metallic);
-    const float f90 = mixf(c.specular, 1.0f, metallic);
-    const f3 F_view = fresnel_schlick_f90(n_dot_v, F0, f90);
+    const float n_dot_v = sf.n_dot_v_ibl;
+    const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
     const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
-    const float effective_transmission = c.transmission * (1.0f - metallic);
-    f3 base_layer;
+    const float effective_transmission = c.transmission * (1.0f - sf.metallic);
+    f3 base_layer = (c.base * (1.0f / kPi)) * irradiance;
     if (effective_transmission > 0.0f) {
-        const f3 transmission_background = prefiltered;   // brdf.wgsl:531-561, uniform cube
-        const f3 diffuse_brdf = (c.base * (1.0f / kPi)) * irradiance;
         f3 attenuation = splat3(1.0f);
         if (should_apply_volume_attenuation(c.volume_thickness, c.volume_attenuation_distance, c.volume_attenuation_color))
             attenuation = volume_attenuation(c.volume_thickness, c.volume_attenuation_color, c.volume_attenuation_distance);
-        const f3 transmission_btdf = (transmission_background * c.base) * attenuation;
-        base_layer = mix3(diffuse_brdf, transmission_btdf, effective_transmission);
-    } else {
-        base_layer = (c.base * (1.0f / kPi)) * irradiance;
+        const f3 transmission_btdf = (prefiltered * c.base) * attenuation;   // brdf.wgsl:531-561, uniform cube
+        base_layer = mix3(base_layer, transmission_btdf, effective_transmission);
     }
-    const float k_d = (1.0f - F_view_max) * (1.0f - metallic);
+    const float k_d = (1.0f - F_view_max) * (1.0f - sf.metallic);
     const f3 base_contribution = (base_layer * k_d) * c.occlusion;
-    const f2 lut = sample_brdf_lut(sc, n_dot_v, roughness);
-    const f3 spec_term = F0 * lut.x + splat3(f90 * lut.y);
+    const f2 lut = sample_brdf_lut(sc, n_dot_v, sf.roughness);
+    const f3 spec_term = sf.F0 * lut.x + splat3(sf.f90 * lut.y);
     const f3 specular = (prefiltered * spec_term) * mixf(1.0f, c.occlusion, 0.5f);
-    const float sheen_scaling = sheen_albedo_scaling(c.sheen_color, c.sheen_roughness, n_dot_v);
-    f3 base_with_sheen = base_contribution * sheen_scaling;
+    f3 base_with_sheen = base_contribution * sheen_albedo_scaling(c.sheen_color, c.sheen_roughness, n_dot_v);
     if (c.sheen_color.x > 0.0f || c.sheen_color.y > 0.0f || c.sheen_color.z > 0.0f) {
         const float alpha = c.sheen_roughness * c.sheen_roughness;
-        const float fresnel_sheen = powf(1.0f - n_dot_v, 3.0f);
-        base_with_sheen = base_with_sheen + (((c.sheen_color * irradiance) * alpha) * fresnel_sheen) * c.occlusion;
+        const float om = 1.0f - n_dot_v;
+        base_with_sheen = base_with_sheen + (((c.sheen_color * irradiance) * alpha) * (om * om * om)) * c.occlusion;
     }
     f3 result = (base_with_sheen + specular) + c.emissive;
     if (c.clearcoat > 0.0f) {
-        const f3 cc_n = safe_normalize(c.clearcoat_normal);
-        const float cc_n_dot_v = saturate(dot(cc_n, v));
+        const float cc_n_dot_v = saturate(fm::fdot(sf.cc_n, sf.v));
         const float cc_roughness = fmaxf(c.clearcoat_roughness, 0.04f);
         const f2 cc_lut = sample_brdf_lut(sc, cc_n_dot_v, cc_roughness);
         const f3 cc_specular = prefiltered * (kClearcoatF0 * cc_lut.x + cc_lut.y);
@@ -329,7 +366,24 @@ AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, f3 normal, f3 surface
 
 // lights.wgsl:70-152
 AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_camera, f3 world_position, uint32_t n_lights) {
-    f3 color = brdf_ibl(sc, mc, mc.normal, surface_to_camera);
+    Surface sf;
+    sf.n = fm::fsafe_normalize(mc.normal);
+    sf.v = fm::fsafe_normalize(surface_to_camera);
+    sf.metallic = clampf(mc.mr.x, 0.0f, 1.0f);
+    sf.roughness = fmaxf(clampf(mc.mr.y, 0.0f, 1.0f), 0.04f);
+    sf.alpha = sf.roughness * sf.roughness;
+    const float ndv = fm::fdot(sf.n, sf.v);
+    sf.n_dot_v_ibl = saturate(ndv);
+    sf.n_dot_v_dir = fmaxf(ndv, 1e-4f);
+    const float f0b = ior_to_f0(mc.ior);
+    const f3 dielectric_f0 = min3(splat3(f0b) * mc.specular_color, splat3(1.0f)) * mc.specular;
+    sf.F0 = mix3(dielectric_f0, mc.base, sf.metallic);
+    sf.f90 = mixf(mc.specular, 1.0f, sf.metallic);
+    sf.sheen_scaling_dir = sheen_albedo_scaling(mc.sheen_color, mc.sheen_roughness, sf.n_dot_v_dir);
+    sf.g1_v = geometry_schlick_ggx(saturate(ndv), sf.alpha);
+    sf.cc_n = fm::fsafe_normalize(mc.clearcoat_normal);
+
+    f3 color = brdf_ibl(sc, mc, sf);
     const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
     for (uint32_t i = 0; i < n_lights; i++) {
         const float4 pos_range = lights[i * 4 + 0], dir_inner = lights[i * 4 + 1], color_intensity = lights[i * 4 + 2], kind_outer = lights[i * 4 + 3];
@@ -337,21 +391,25 @@ AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_
         const f3 lcolor = {color_intensity.x, color_intensity.y, color_intensity.z};
         f3 light_dir = {0.0f, 0.0f, 0.0f}, radiance = {0.0f, 0.0f, 0.0f};
         if (kind == 1u) {
-            light_dir = normalize(-mk3(dir_inner.x, dir_inner.y, dir_inner.z));
+            light_dir = fm::fnormalize(-mk3(dir_inner.x, dir_inner.y, dir_inner.z));
             radiance = lcolor * color_intensity.w;
         } else if (kind == 2u || kind == 3u) {
             const f3 stl = mk3(pos_range.x, pos_range.y, pos_range.z) - world_position;
-            const float dist = length(stl);
-            light_dir = stl / dist;
-            float att = inverse_square(pos_range.w, dist);
+            const float d2 = fm::fdot(stl, stl);
+            const float inv_d = fm::rsq(d2);
+            const float dist = d2 * inv_d;
+            light_dir = stl * inv_d;
+            float att;   // math.wgsl:12-19 inverse_square
+            if (pos_range.w == 0.0f) att = fm::rcp(fmaxf(dist * dist, 0.01f));
+            else { const float fo = 1.0f - fm::fdiv(dist * dist, pos_range.w * pos_range.w); att = fm::fdiv(saturate(fo * fo), dist * dist + 1.0f); }
             if (kind == 3u) {
-                const float cos_l = dot(light_dir, -normalize(mk3(dir_inner.x, dir_inner.y, dir_inner.z)));
-                const float sm = saturate((cos_l - kind_outer.y) / (dir_inner.w - kind_outer.y));
+                const float cos_l = fm::fdot(light_dir, -fm::fnormalize(mk3(dir_inner.x, dir_inner.y, dir_inner.z)));
+                const float sm = saturate(fm::fdiv(cos_l - kind_outer.y, dir_inner.w - kind_outer.y));
                 att = att * (sm * sm);
             }
             radiance = (lcolor * color_intensity.w) * att;
         }
-        color = color + brdf_direct(mc, mc.normal, light_dir, radiance, surface_to_camera);
+        color = color + brdf_direct(mc, sf, light_dir, radiance);
     }
     return color;
 }
@@ -378,46 +436,25 @@ __global__ __launch_bounds__(256) void k_shade(const DevScene* __restrict__ sc, 
 
     const unsigned long long key = f.vis[p];
     if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, sky); return; }   // compute.wgsl:149-153 / empty.wgsl
-    atomicAdd(&f.counters[3], 1u);   // wave-aggregated by the compiler
 
     const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     const float depth_sample = __uint_as_float((uint32_t)(key >> 32));
-    uint32_t lo = 0, hi = f.n_draws;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (f.draws[mid].first_tri <= rank) lo = mid; else hi = mid;
-    }
-    const uint32_t triangle_index = rank - f.draws[lo].first_tri;
-    const uint32_t geom_meta_off = f.draws[lo].geom_meta_off;
-    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + geom_meta_off + 36);
+    const DrawDev* dr = f.draws + (f.tri_info[rank] & 0x00FFFFFFu);
+    const uint32_t triangle_index = rank - dr->first_tri;
+    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr->geom_meta_off + 36);
     const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
-    if (mm[16] == 1u) { if (f.out_rgba32f) reinterpret_cast<float4*>(f.out_rgba32f)[p] = make_float4(0, 0, 0, 0);
-                        reinterpret_cast<ushort4*>(f.out_rgba16f)[p] = make_ushort4(0, 0, 0, 0); return; }   // is_hud: stays cleared
+    if (mm[16] == 1u) { store_pixel(f, p, {0.0f, 0.0f, 0.0f, 0.0f}); return; }   // is_hud (compute.wgsl:176-179): stays cleared
     const uint32_t material_offset = mm[6];
     const uint32_t attr_indices_off = mm[9] / 4u, attr_data_off = mm[10] / 4u, stride = mm[11] / 4u, uv_sets_index = mm[12];
 
-    // ---- fs_main for this pixel, rounded to the G-buffer storage formats ----
-    const float4 v0 = f.clip[(size_t)rank * 3], v1 = f.clip[(size_t)rank * 3 + 1], v2 = f.clip[(size_t)rank * 3 + 2];
-    TriSetup t;
-    if (!tri_setup(v0, v1, v2, false, f.width, f.height, 0u, f.height, t)) { store_pixel(f, p, sky); return; }
-    float e0, e1, e2;
-    tri_edges(t, cx, cy, e0, e1, e2);
-    const float esum = (e0 + e1) + e2;
-    const float b0 = e0 / esum, b1 = e1 / esum, b2 = e2 / esum;
-    const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
-    const float4 t0 = f.tan[(size_t)rank * 3], t1 = f.tan[(size_t)rank * 3 + 1], t2 = f.tan[(size_t)rank * 3 + 2];
-    const f3 Ni = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y, (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
-    const f4 Ti = {(b0 * t0.x + b1 * t1.x) + b2 * t2.x, (b0 * t0.y + b1 * t1.y) + b2 * t2.y,
-                   (b0 * t0.z + b1 * t1.z) + b2 * t2.z, (b0 * t0.w + b1 * t1.w) + b2 * t2.w};
-    f4 packed = pack_normal_tangent(normalize(Ni), normalize(mk3(Ti.x, Ti.y, Ti.z)), Ti.w);
-    packed = {round_f16(packed.x), round_f16(packed.y), round_f16(packed.z), round_f16(packed.w)};   // RGBA16F
-    const float bx = round_f16(b0), by = round_f16(b1);                                               // RG16F
+    const GBufferTexel g = reconstruct_gbuffer(f, rank, cx, cy);
+    if (!g.valid) { store_pixel(f, p, sky); return; }
 
     // ---- compute.wgsl:182-211 ----
     Attr a;
     a.sc = sc;
     a.ad = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_ATTR_DATA]);
-    a.bary = {bx, by, (1.0f - bx) - by};
+    a.bary = {g.bx, g.by, (1.0f - g.bx) - g.by};
     a.uv_sets_index = uv_sets_index;
     const uint32_t* attr_idx = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + attr_indices_off + triangle_index * 3u;
     a.v0 = attr_data_off + attr_idx[0] * stride;
@@ -430,20 +467,19 @@ __global__ __launch_bounds__(256) void k_shade(const DevScene* __restrict__ sc, 
     const m4 inv_view = load_m4(reinterpret_cast<const float*>(cam + 320));
     const float proj33 = *reinterpret_cast<const float*>(cam + 64 + 60);
     const float* cam_pos = reinterpret_cast<const float*>(cam + 384);
-    const f2 uv = {((float)cx + 0.5f) / (float)f.width, ((float)cy + 0.5f) / (float)f.height};
-    const f4 view_h = mul(inv_proj, {uv.x * 2.0f - 1.0f, 1.0f - uv.y * 2.0f, depth_sample, 1.0f});
-    const float vw = fmaxf(view_h.w, 1e-8f);
-    const f3 view_position = {view_h.x / vw, view_h.y / vw, view_h.z / vw};
-    const f4 wp = mul(inv_view, {view_position.x, view_position.y, view_position.z, 1.0f});
+    const f2 uv = {((float)cx + 0.5f) * fm::rcp((float)f.width), ((float)cy + 0.5f) * fm::rcp((float)f.height)};
+    const f4 view_h = fm::fmul(inv_proj, {uv.x * 2.0f - 1.0f, 1.0f - uv.y * 2.0f, depth_sample, 1.0f});
+    const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
+    const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
     const f3 world_position = {wp.x, wp.y, wp.z};
     f3 surface_to_camera;
     if (proj33 > 0.9f) {
-        surface_to_camera = normalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
+        surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
     } else {
         const f3 to_camera = mk3(cam_pos[0], cam_pos[1], cam_pos[2]) - world_position;
-        surface_to_camera = dot(to_camera, to_camera) > 0.0f ? safe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
+        surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
     }
-    const TBN tbn = unpack_normal_tangent(packed);
+    const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
     const uint32_t n_lights = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]);
 
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
@@ -551,6 +587,7 @@ __global__ __launch_bounds__(256) void k_shade(const DevScene* __restrict__ sc, 
     const f3 color = apply_lighting(sc, c, surface_to_camera, world_position, n_lights);
     store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
 }
+#pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------------------
 // BRDF LUT (crates/renderer-core/src/brdf_lut/shader.wgsl:1-78): one thread per texel, 1024 samples.
@@ -593,6 +630,16 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t* __restrict__ out_rg1
     out_rg16f[(size_t)j * width + i] = (uint32_t)f16_bits(a) | ((uint32_t)f16_bits(bsum) << 16);
 }
 
+// covered-pixel count for AwsmFrameStats: runs only when the caller asks for stats (frame_end), never in the frame itself.
+// (A per-wave atomicAdd on one counter inside k_shade serialised ~130k same-address atomics per 4K frame.)
+__global__ __launch_bounds__(256) void k_count_covered(const unsigned long long* __restrict__ vis, uint32_t width, uint32_t y0, uint32_t y1, uint32_t* counter) {
+    const size_t n = (size_t)width * (y1 - y0), base = (size_t)width * y0;
+    uint32_t local = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) local += vis[base + i] != ~0ull ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
+}
+
 // helper kernels for readback / upload conversions
 __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -605,6 +652,9 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = ((f->y1 - f->y0) + 15u) >> 4;
     const uint32_t nb = ((bx_n * by_n + 7u) / 8u) * 8u;
     if (nb) hipLaunchKernelGGL(awsm::k_shade, dim3(nb), dim3(256), 0, s, sc, *f);
+}
+extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
+    if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->counters + 3);
 }
 extern "C" void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_brdf_lut, dim3((w + 15u) / 16u, (h + 15u) / 16u), dim3(256), 0, s, out_rg16f, w, h);
