@@ -12,7 +12,7 @@ import numpy as np
 
 from . import PACKAGE_DIR
 
-LIB_PATH = os.path.join(PACKAGE_DIR, "libawsm_hip.so")
+LIB_PATH = os.environ.get("AWSM_HIP_LIB") or os.path.join(PACKAGE_DIR, "libawsm_hip.so")   # AWSM_HIP_LIB: A/B builds of the same ABI
 BUF_COUNT = 18
 AWSM_CFG_PARITY_TAP = 1
 

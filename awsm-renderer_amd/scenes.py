@@ -380,3 +380,84 @@ def atrium_scene(width=3840, height=2160, detail=1.0, tex_scale=1.0, seed=0xA35A
 
 def total_triangles(scene: SceneDesc) -> int:
     return int(sum(np.asarray(p.indices).reshape(-1, 3).shape[0] for n in scene.nodes for p in n.primitives))
+
+
+# ------------------------------------------------------------------------------------------------ material zoo (parity coverage)
+
+def material_zoo_scene(width=640, height=360, tex_size=64, seed=0xA35A0005) -> SceneDesc:
+    """A grid of bumpy spheres, one per shading feature of the opaque pass: every optional PBR block
+    (vertex colour, emissive strength, ior, specular, volume+transmission texture factor 0, clearcoat, sheen), unlit,
+    debug views, a second UV set, texture transforms, clamp / mirror / nearest samplers, non-power-of-two textures,
+    point + spot lights, double-sided and single-sided materials.  Not a BASELINE config; it exists so that the parity
+    tests reach every branch of compute.wgsl / material_color_calc.wgsl / brdf.wgsl."""
+    rng = np.random.default_rng(seed)
+    npot = max(12, (tex_size * 3) // 4 + 1)            # a non-power-of-two size -> second pool array, generic wrap path
+    textures = [
+        value_noise_rgba8(rng, tex_size, 8, base=(0.6, 0.5, 0.4), amp=(0.3, 0.3, 0.3)),      # 0 colour
+        value_noise_rgba8(rng, tex_size, 12, kind="normal"),                                 # 1 normal
+        value_noise_rgba8(rng, tex_size, 10, base=(0.5, 0.5, 0.5), amp=(0.4, 0.4, 0.4)),     # 2 generic data (all channels vary)
+        value_noise_rgba8(rng, npot, 6, base=(0.5, 0.6, 0.5), amp=(0.3, 0.3, 0.3)),          # 3 non-pow2 colour
+        value_noise_rgba8(rng, npot, 9, kind="normal"),                                      # 4 non-pow2 normal
+    ]
+    textures[2][..., 3] = rng.integers(60, 255, size=textures[2].shape[:2], dtype=np.uint8)  # alpha channel carries data too
+    samplers = [dict(REPEAT_LINEAR), dict(CLAMP_LINEAR), dict(MIRROR_NEAREST),
+                {"address_mode_u": 2, "address_mode_v": 0, "mag_filter": 1, "min_filter": 1, "mipmap_filter": 1, "max_anisotropy": 1}]
+    T = TextureRef
+    xf = {"offset": (0.13, -0.21), "origin": (0.5, 0.5), "rotation": 0.4, "scale": (1.7, 0.6)}
+    mats = [
+        MaterialDesc(base_color_tex=T(0), normal_tex=T(1), metallic_factor=0.0, roughness_factor=0.5),                                      # 0 plain
+        MaterialDesc(base_color_tex=T(0), metallic_roughness_tex=T(2), normal_tex=T(1), occlusion_tex=T(2), emissive_tex=T(0), emissive_factor=(0.5, 0.4, 0.3),
+                     occlusion_strength=0.7, normal_scale=1.4),                                                                             # 1 all five core textures
+        MaterialDesc(base_color_factor=(0.9, 0.8, 0.7, 1.0), vertex_color_set=0, metallic_factor=0.2, roughness_factor=0.6),                # 2 vertex colour
+        MaterialDesc(base_color_tex=T(3, sampler=1), normal_tex=T(4, sampler=3), metallic_factor=0.9, roughness_factor=0.3),                # 3 non-pow2, clamp, mirror/clamp mix
+        MaterialDesc(base_color_tex=T(0, sampler=2, transform=xf), emissive_tex=T(3, sampler=2), emissive_factor=(0.3, 0.3, 0.3), emissive_strength=2.5,
+                     roughness_factor=0.8, metallic_factor=0.0),                                                                             # 4 mirror+nearest, texture transform, emissive strength
+        MaterialDesc(base_color_tex=T(0, uv_index=1), normal_tex=T(1, uv_index=1, transform=xf), ior=1.9, roughness_factor=0.35, metallic_factor=0.0),  # 5 second UV set, ior
+        MaterialDesc(base_color_tex=T(0), specular={"tex": T(2), "factor": 0.8, "color_tex": T(0), "color_factor": (1.0, 0.7, 0.4)},
+                     metallic_factor=0.0, roughness_factor=0.4),                                                                             # 6 KHR_materials_specular
+        MaterialDesc(base_color_tex=T(0), clearcoat={"tex": T(2), "factor": 0.9, "roughness_tex": T(2), "roughness_factor": 0.5, "normal_tex": T(1), "normal_scale": 0.8},
+                     metallic_factor=0.3, roughness_factor=0.7),                                                                             # 7 clearcoat (all three textures)
+        MaterialDesc(base_color_factor=(0.5, 0.2, 0.6, 1.0), sheen={"roughness_tex": T(2), "roughness_factor": 0.6, "color_tex": T(0), "color_factor": (0.9, 0.8, 1.0)},
+                     metallic_factor=0.0, roughness_factor=0.9, double_sided=True),                                                          # 8 sheen, double sided
+        MaterialDesc(kind="unlit", base_color_tex=T(0), base_color_factor=(0.8, 0.9, 1.0, 1.0), emissive_tex=T(3, sampler=1), emissive_factor=(0.2, 0.1, 0.0)),  # 9 unlit
+        MaterialDesc(base_color_tex=T(0), normal_tex=T(1), debug_bitmask=4),                                                                 # 10 debug: normals
+        MaterialDesc(base_color_tex=T(0), metallic_roughness_tex=T(2), debug_bitmask=2),                                                     # 11 debug: metallic/roughness
+        MaterialDesc(base_color_tex=T(0), volume={"thickness_tex": T(2), "thickness_factor": 0.5, "attenuation_distance": 2.0, "attenuation_color": (0.8, 0.9, 0.7)},
+                     transmission={"tex": None, "factor": 0.0}, clearcoat={"factor": 0.6, "roughness_factor": 0.1}, sheen={"roughness_factor": 0.3, "color_factor": (0.2, 0.3, 0.1)},
+                     specular={"factor": 0.5}, ior=1.33, emissive_strength=1.5, emissive_factor=(0.05, 0.05, 0.1), metallic_factor=0.1, roughness_factor=0.5),  # 12 every block at once
+        MaterialDesc(base_color_tex=T(63), normal_tex=T(1, sampler=9), roughness_factor=0.5, metallic_factor=0.0),                          # 13 dangling texture / sampler ids -> SkipTexture
+    ]
+    nodes = [NodeDesc()]
+    cols = 7
+    for m in range(len(mats)):
+        gx, gy = m % cols, m // cols
+        kk = rng.uniform(2.0, 5.0, size=3)
+
+        def ball(U, V, kk=kk):
+            th, phi = U * 2 * math.pi, (0.03 + 0.94 * V) * math.pi
+            d = np.stack([np.sin(phi) * np.cos(th), np.cos(phi), -np.sin(phi) * np.sin(th)], axis=-1)
+            return d * (0.42 * (1.0 + 0.1 * np.sin(d @ kk * 3.0)))[..., None]
+        pos, nrm, tan, uvs, idx = grid_patch(ball, 20, 14, uv_scale=(2.0, 1.0))
+        uv1 = (uvs[:, ::-1] * np.array([1.5, 0.75], dtype=F) + np.array([0.25, -0.1], dtype=F)).astype(F)
+        col = np.concatenate([0.5 + 0.5 * nrm, np.ones((pos.shape[0], 1), dtype=F)], axis=1).astype(F)
+        prim = PrimitiveDesc(positions=pos, normals=nrm, tangents=tan, uvs=[uvs, uv1], colors=[col], indices=idx, material=m)
+        nodes.append(NodeDesc(translation=((gx - (cols - 1) / 2) * 1.05, (0.5 - gy) * 1.05, 0.0), rotation=quat_axis_angle((0.2, 1, 0.1), 0.3 * m),
+                              scale=(1.0, 1.0 + 0.1 * (m % 3), 1.0), parent=0, primitives=[prim]))
+    lights = list(DEFAULT_LIGHTS[:2]) + [
+        {"kind": "point", "color": (1.0, 0.7, 0.5), "intensity": 8.0, "position": (-2.0, 1.5, 2.0), "range": 12.0},
+        {"kind": "point", "color": (0.5, 0.7, 1.0), "intensity": 5.0, "position": (2.5, -1.0, 1.5), "range": 0.0},
+        {"kind": "spot", "color": (0.9, 1.0, 0.8), "intensity": 20.0, "position": (0.0, 0.0, 3.5), "direction": (0.0, 0.0, -1.0), "range": 20.0,
+         "inner_angle": 0.98, "outer_angle": 0.90},
+    ]
+    eye = (0.3, 0.2, 5.2)
+    return SceneDesc(nodes=nodes, materials=mats, textures=textures, samplers=samplers, lights=lights, width=width, height=height,
+                     view=look_at_rh(eye, (0, 0, 0)), proj=perspective_rh(math.radians(45), width / height, 0.1, 100.0), camera_position=eye,
+                     skybox_rgba=(0.02, 0.03, 0.05, 1.0), prefiltered_rgb=(0.9, 0.95, 1.0), irradiance_rgb=(0.8, 0.85, 0.9))
+
+
+def ortho_scene(width=320, height=240) -> SceneDesc:
+    """The helmet-class mesh under an orthographic camera (standard.wgsl:41-49, skybox.wgsl:13-29 ortho branches)."""
+    sc = helmet_scene(width, height, segments=32, rings=24, tex_size=32)
+    a = width / height
+    sc.proj = orthographic_rh(-1.6 * a, 1.6 * a, -1.6, 1.6, 0.1, 50.0)
+    return sc

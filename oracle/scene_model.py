@@ -275,8 +275,8 @@ class MaterialPacker:
 
     def _tex(self, ref: Optional[TextureRef]) -> bytes:
         """writer.rs:100-197: 5 words, or 20 zero bytes when absent."""
-        if ref is None or ref.texture not in self.pool.entries:
-            return bytes(20)
+        if ref is None or ref.texture not in self.pool.entries or ref.sampler >= len(self.samplers):
+            return bytes(20)   # map_texture(..) -> None -> Value::SkipTexture (writer.rs:100-112)
         ai, li = self.pool.entries[ref.texture]
         arr = self.pool.arrays[ai]
         smp = self.samplers[ref.sampler]
