@@ -61,7 +61,7 @@ struct AwsmHipCtx {
     size_t bound_out_bytes = 0;
 
     // geometry-pass resources
-    DevBuf clip, nrm, tan, tri_flags, draws_dev, tile_count, tile_offset, tile_cursor, bin_list, counters;
+    DevBuf clip, nrm, tan, tri_flags, draws_dev, tile_count, tile_offset, tile_cursor, tile_order, bin_list, counters;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
     uint32_t total_tris = 0, total_verts = 0, n_blocks = 0;
@@ -184,6 +184,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->tri_info = (uint32_t*)c->tri_flags.ptr;
     f->tile_count = (uint32_t*)c->tile_count.ptr; f->tile_offset = (uint32_t*)c->tile_offset.ptr;
     f->tile_cursor = (uint32_t*)c->tile_cursor.ptr; f->bin_list = (uint32_t*)c->bin_list.ptr;
+    f->tile_order = (uint32_t*)c->tile_order.ptr;
     f->counters = (uint32_t*)c->counters.ptr;
     f->vis = (unsigned long long*)c->vis.ptr;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? c->bound_out : c->out16.ptr);
@@ -292,7 +293,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
     fr(c->lut); fr(c->vis); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_flags);
-    fr(c->draws_dev); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->bin_list); fr(c->counters);
+    fr(c->draws_dev); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->counters);
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
@@ -478,6 +479,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = dev_reserve(c, c->tile_count, n_tiles_full * 4))) return rc;
     if ((rc = dev_reserve(c, c->tile_offset, (n_tiles_full + 1) * 4))) return rc;
     if ((rc = dev_reserve(c, c->tile_cursor, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, c->tile_order, n_tiles_full * 4))) return rc;
     if ((rc = ensure_bin_capacity(c, std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
     if (!c->draws_host.empty()) {
         const size_t bytes = c->draws_host.size() * sizeof(DrawDev);

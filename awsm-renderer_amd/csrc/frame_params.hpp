@@ -59,6 +59,7 @@ struct FrameDev {
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1
     uint32_t* tile_cursor;        // n_tiles
+    uint32_t* tile_order;         // n_tiles: tile ids, heaviest first (k_bin_scan)
     uint32_t* bin_list;           // bin_capacity
     uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels
     // targets

@@ -16,13 +16,6 @@
 
 namespace awsm {
 
-// Consecutive workgroup ids are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
-// work items so neighbouring tiles (which share triangles) hit the same L2.  Speed only.
-AWSM_DI uint32_t xcd_remap(uint32_t b, uint32_t n) {
-    uint32_t per = (n + 7u) >> 3;
-    return (b & 7u) * per + (b >> 3);
-}
-
 struct GeomMetaDev {
     uint32_t mesh_key_high, mesh_key_low;
     uint32_t morph_len, morph_weights_off, morph_values_off;
@@ -214,16 +207,30 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     }
 }
 
-// Exclusive scan of tile_count -> tile_offset (single workgroup; n_tiles is a few thousand).
+// Exclusive scan of tile_count -> tile_offset (single workgroup; n_tiles is a few thousand), plus tile_order: the tile
+// ids sorted by log2(count), heaviest first.  Workgroups start in blockIdx order, so k_raster_tile begins with the
+// fullest tiles and the light ones fill in behind them (longest-processing-time-first; the fullest tile of a frame holds
+// 20-40x the median number of triangles and would otherwise be the tail of the kernel).
 __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t bucket_n[33], bucket_at[33];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
+    if (tid < 33u) bucket_n[tid] = 0u;
+    __syncthreads();
     uint32_t sum = 0;
-    for (uint32_t i = b0; i < b1; i++) sum += f.tile_count[i];
+    for (uint32_t i = b0; i < b1; i++) {
+        const uint32_t c = f.tile_count[i];
+        sum += c;
+        atomicAdd(&bucket_n[32 - __clz(c)], 1u);          // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
+    }
     part[tid] = sum;
     __syncthreads();
+    if (tid == 0) {
+        uint32_t at = 0;
+        for (int k = 32; k >= 0; k--) { bucket_at[k] = at; at += bucket_n[k]; }
+    }
     for (uint32_t off = 1; off < 1024u; off <<= 1) {
         uint32_t v = (tid >= off) ? part[tid - off] : 0u;
         __syncthreads();
@@ -231,7 +238,11 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         __syncthreads();
     }
     uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's chunk
-    for (uint32_t i = b0; i < b1; i++) { f.tile_offset[i] = run; run += f.tile_count[i]; }
+    for (uint32_t i = b0; i < b1; i++) {
+        const uint32_t c = f.tile_count[i];
+        f.tile_offset[i] = run; run += c;
+        f.tile_order[atomicAdd(&bucket_at[32 - __clz(c)], 1u)] = i;
+    }
     if (tid == 1023u) {
         const uint32_t total = part[1023];
         f.tile_offset[n_tiles] = total;
@@ -242,12 +253,14 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
 
 // ------------------------------------------------------------------------------------------------
 // k_raster_tile: one 256-thread workgroup owns one 32x32 tile whose packed keys live in LDS (8 KB).
-//   - triangles whose bbox inside the tile is <= 16 pixels: the loading thread walks its own pixels;
-//   - everything else goes to an LDS work list that the four wavefronts drain, one triangle per
-//     wavefront at a time, 64 lanes = one 8x8 pixel block per step.
-// Both paths resolve depth + order with ds_min_u64 on the LDS tile.
+// Each thread sets up one binned triangle and classifies it by the pixel area of (bbox ∩ tile):
+//   - <= 4 pixels:  the thread samples them itself;
+//   - <= 256 pixels ("mid", the bulk of a 260k-triangle 4K frame: median bbox ~11x11): LDS work list drained by
+//     16-lane groups, one triangle per group at a time, 16 lanes = one 4x4 pixel block per step;
+//   - larger ("big"): LDS work list drained by whole wavefronts, 64 lanes = one 8x8 pixel block per step.
+// All paths resolve depth + submission order with ds_min_u64 on the LDS tile.
 // ------------------------------------------------------------------------------------------------
-struct BigTri {
+struct WorkTri {
     float a[3], b[3], c[3];
     float z[3];
     float det;
@@ -256,26 +269,32 @@ struct BigTri {
     uint32_t pad;
 };
 
+AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.z[i] = g.z[i]; }
+    t.det = g.det;
+}
+
 __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     __shared__ unsigned long long keys[kTile * kTile];
-    __shared__ BigTri big[256];
-    __shared__ uint32_t big_count;
+    __shared__ WorkTri work[256];      // mid triangles from the front, big triangles from the back
+    __shared__ uint32_t n_mid, n_big;
 
-    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
-    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-    if (tile >= n_tiles) return;
+    // Heaviest tiles first (tile_order, k_bin_scan).  Consecutive ids go to different XCDs (blockIdx & 7), which also
+    // spreads the dense band of the screen over all eight of them.
+    const uint32_t tile = f.tile_order[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const int tpx = (int)(tile % f.tiles_x) << kTileShift;
     const int tpy = (int)(tile / f.tiles_x + f.tile_row0) << kTileShift;
 
 #pragma unroll
     for (int i = 0; i < 4; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
-    const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, f.tile_offset[tile]));
     const uint32_t off = f.tile_offset[tile];
+    const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, off));
     const int lane = tid & 63, wave = tid >> 6;
 
     for (uint32_t base = 0; base < count; base += 256u) {
-        if (tid == 0) big_count = 0;
+        if (tid == 0) { n_mid = 0; n_big = 0; }
         __syncthreads();
         const uint32_t idx = base + tid;
         if (idx < count) {
@@ -288,15 +307,15 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                 const int y0 = max(t.miny, tpy), y1 = min(t.maxy, tpy + kTile - 1);
                 if (x0 <= x1 && y0 <= y1) {
                     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-                    if (area <= 16) {
+                    if (area <= 4) {
                         for (int py = y0; py <= y1; py++)
                             for (int px = x0; px <= x1; px++) {
                                 const unsigned long long k = tri_sample_key(t, px, py, r);
                                 if (k != ~0ull) atomicMin(&keys[(py - tpy) * kTile + (px - tpx)], k);
                             }
                     } else {
-                        const uint32_t slot = atomicAdd(&big_count, 1u);
-                        BigTri& g = big[slot];
+                        const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : 255u - atomicAdd(&n_big, 1u);
+                        WorkTri& g = work[slot];
 #pragma unroll
                         for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.z[i] = t.z[i]; }
                         g.det = t.det; g.rank = r;
@@ -306,13 +325,30 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
             }
         }
         __syncthreads();
-        const uint32_t nb = big_count;
-        for (uint32_t j = wave; j < nb; j += 4u) {
-            const BigTri& g = big[j];
+        const uint32_t nm = n_mid, nb = n_big;
+        {   // mid: 16 groups of 16 lanes, 4x4 pixel blocks
+            const uint32_t group = tid >> 4;
+            const int lx = (int)(tid & 3u), ly = (int)((tid >> 2) & 3u);
+            for (uint32_t j = group; j < nm; j += 16u) {
+                const WorkTri& g = work[j];
+                TriSetup t;
+                load_work_tri(g, t);
+                const uint32_t bb = g.bbox, r = g.rank;
+                const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+                for (int by = y0 & ~3; by <= y1; by += 4)
+                    for (int bx = x0 & ~3; bx <= x1; bx += 4) {
+                        const int px = bx + lx, py = by + ly;
+                        if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+                            const unsigned long long k = tri_sample_key(t, tpx + px, tpy + py, r);
+                            if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
+                        }
+                    }
+            }
+        }
+        for (uint32_t j = wave; j < nb; j += 4u) {   // big: one wavefront per triangle, 8x8 pixel blocks
+            const WorkTri& g = work[255u - j];
             TriSetup t;
-#pragma unroll
-            for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.z[i] = g.z[i]; }
-            t.det = g.det;
+            load_work_tri(g, t);
             const uint32_t bb = g.bbox, r = g.rank;
             const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
             const int lx = lane & 7, ly = lane >> 3;
@@ -356,6 +392,6 @@ extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
 }
 extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
-    const uint32_t nb = ((n_tiles + 7u) / 8u) * 8u;   // xcd_remap needs a multiple of 8
+    const uint32_t nb = n_tiles;
     if (nb) hipLaunchKernelGGL(awsm::k_raster_tile, dim3(nb), dim3(256), 0, s, *f);
 }

@@ -20,21 +20,15 @@ struct TriSetup {
 
 AWSM_DI bool finite4(float4 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w); }
 
-// Returns false if the triangle cannot produce a fragment (culled, degenerate, outside, empty bbox).
-AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t width, uint32_t height,
-                       uint32_t ry0, uint32_t ry1, TriSetup& t) {
-    if (!finite4(v0) || !finite4(v1) || !finite4(v2)) return false;
-    if (v0.x < -v0.w && v1.x < -v1.w && v2.x < -v2.w) return false;
-    if (v0.x > v0.w && v1.x > v1.w && v2.x > v2.w) return false;
-    if (v0.y < -v0.w && v1.y < -v1.w && v2.y < -v2.w) return false;
-    if (v0.y > v0.w && v1.y > v1.w && v2.y > v2.w) return false;
-    if (v0.z < 0.0f && v1.z < 0.0f && v2.z < 0.0f) return false;
-    if (v0.z > v0.w && v1.z > v1.w && v2.z > v2.w) return false;
-
+// Edge-function coefficients, orientation normalisation and det (the part of the setup that per-pixel sampling needs).
+// Returns false for a degenerate or culled triangle.  X*/Y* are the homogeneous screen coordinates, for the bbox.
+AWSM_DI bool tri_coefficients(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t width, uint32_t height, TriSetup& t,
+                              float& X0, float& Y0, float& X1, float& Y1, float& X2, float& Y2) {
     float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
-    float X0 = (v0.x + v0.w) * hw, Y0 = (v0.w - v0.y) * hh, w0 = v0.w;
-    float X1 = (v1.x + v1.w) * hw, Y1 = (v1.w - v1.y) * hh, w1 = v1.w;
-    float X2 = (v2.x + v2.w) * hw, Y2 = (v2.w - v2.y) * hh, w2 = v2.w;
+    const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
+    X0 = (v0.x + v0.w) * hw; Y0 = (v0.w - v0.y) * hh;
+    X1 = (v1.x + v1.w) * hw; Y1 = (v1.w - v1.y) * hh;
+    X2 = (v2.x + v2.w) * hw; Y2 = (v2.w - v2.y) * hh;
 
     float a0 = Y1 * w2 - Y2 * w1, b0 = X2 * w1 - X1 * w2, c0 = X1 * Y2 - X2 * Y1;
     float a1 = Y2 * w0 - Y0 * w2, b1 = X0 * w2 - X2 * w0, c1 = X2 * Y0 - X0 * Y2;
@@ -51,6 +45,23 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
     t.a[2] = a2; t.b[2] = b2; t.c[2] = c2;
     t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
     t.det = det;
+    return true;
+}
+
+// Returns false if the triangle cannot produce a fragment (culled, degenerate, outside, empty bbox).
+AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t width, uint32_t height,
+                       uint32_t ry0, uint32_t ry1, TriSetup& t) {
+    if (!finite4(v0) || !finite4(v1) || !finite4(v2)) return false;
+    if (v0.x < -v0.w && v1.x < -v1.w && v2.x < -v2.w) return false;
+    if (v0.x > v0.w && v1.x > v1.w && v2.x > v2.w) return false;
+    if (v0.y < -v0.w && v1.y < -v1.w && v2.y < -v2.w) return false;
+    if (v0.y > v0.w && v1.y > v1.w && v2.y > v2.w) return false;
+    if (v0.z < 0.0f && v1.z < 0.0f && v2.z < 0.0f) return false;
+    if (v0.z > v0.w && v1.z > v1.w && v2.z > v2.w) return false;
+
+    float X0, Y0, X1, Y1, X2, Y2;
+    if (!tri_coefficients(v0, v1, v2, cull_back, width, height, t, X0, Y0, X1, Y1, X2, Y2)) return false;
+    const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
 
     int minx = 0, maxx = (int)width - 1, miny = (int)ry0, maxy = (int)ry1 - 1;
     if (w0 > 0.0f && w1 > 0.0f && w2 > 0.0f) {

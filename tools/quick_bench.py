@@ -36,6 +36,8 @@ print({k: v / steps for k, v in acc.items()})
 t = time.time()
 for _ in range(steps):
     dev.geometry_pass(draws, n); dev.opaque_pass()
+t_enq = (time.time() - t) / steps
 st = dev.frame_end()
 dt = (time.time() - t) / steps
+print("host enqueue: %.3f ms/frame" % (t_enq * 1e3))
 print("pipelined: %.3f ms/frame  %.1f fps  %.1f Mpix/s" % (dt * 1e3, 1 / dt, W * H / dt / 1e6))
