@@ -18,6 +18,7 @@ using namespace awsm;
 
 extern "C" {
 void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
+void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s);
 void awsm_launch_bin_count(const FrameDev* f, hipStream_t s);
 void awsm_launch_bin_scan(const FrameDev* f, hipStream_t s);
 void awsm_launch_bin_fill(const FrameDev* f, hipStream_t s);
@@ -78,6 +79,9 @@ struct AwsmHipCtx {
 
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid[EV_COUNT] = {};
+    std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
+    void* draws_uploaded_ptr = nullptr;
+    bool draws_uploaded_valid = false;
 };
 
 namespace {
@@ -123,6 +127,8 @@ int dev_reserve(AwsmHipCtx* c, DevBuf& b, size_t bytes) {   // grow-only, conten
     return dev_realloc(c, b, want, false);
 }
 
+constexpr size_t kKernelUploadMax = 256u << 10;   // larger uploads go to the copy engine
+
 // returns a pinned pointer valid until the copy enqueued from it has executed
 int stage_alloc(AwsmHipCtx* c, size_t len, uint8_t** out) {
     len = (len + 255) & ~size_t(255);
@@ -148,7 +154,12 @@ int upload_small(AwsmHipCtx* c, void* dst, const void* src, size_t len) {
     int rc = stage_alloc(c, len, &st);
     if (rc) return rc;
     memcpy(st, src, len);
-    HIPCHK(c, hipMemcpyAsync(dst, st, len, hipMemcpyHostToDevice, c->stream));
+    if (len <= kKernelUploadMax && (len & 3u) == 0 && ((uintptr_t)dst & 3u) == 0 && ((uintptr_t)st & 3u) == 0) {
+        awsm_launch_upload_words(dst, st, (uint32_t)(len >> 2), c->stream);   // pinned memory is device-visible at the same address
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(dst, st, len, hipMemcpyHostToDevice, c->stream));
+    }
     return AWSM_OK;
 }
 
@@ -203,10 +214,10 @@ int enqueue_geometry(AwsmHipCtx* c) {
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     int rc = sync_scene(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
-    if (n_tiles) {
-        HIPCHK(c, hipMemsetAsync(c->tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->tile_cursor.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
+    const bool has_geometry = c->total_tris && n_tiles;
+    if (!has_geometry) {   // otherwise k_deform_transform clears counters + tile_count and k_bin_scan clears tile_cursor
+        HIPCHK(c, hipMemsetAsync(c->counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
+        if (n_tiles) HIPCHK(c, hipMemsetAsync(c->tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
     }
     if ((rc = record(c, EV_START))) return rc;
     if (c->total_tris && n_tiles) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
@@ -481,7 +492,13 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = dev_reserve(c, c->tile_cursor, n_tiles_full * 4))) return rc;
     if ((rc = dev_reserve(c, c->tile_order, n_tiles_full * 4))) return rc;
     if ((rc = ensure_bin_capacity(c, std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
-    if (!c->draws_host.empty()) {
+    // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
+    // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
+    const bool same_draws = c->draws_uploaded_valid && c->draws_uploaded_ptr == c->draws_dev.ptr &&
+                            c->draws_uploaded.size() == c->draws_host.size() &&
+                            (c->draws_host.empty() || memcmp(c->draws_uploaded.data(), c->draws_host.data(), c->draws_host.size() * sizeof(DrawDev)) == 0);
+    if (!c->draws_host.empty() && !same_draws) {
+        c->draws_uploaded = c->draws_host; c->draws_uploaded_ptr = c->draws_dev.ptr; c->draws_uploaded_valid = true;
         const size_t bytes = c->draws_host.size() * sizeof(DrawDev);
         if (bytes <= (1u << 20)) { if ((rc = upload_small(c, c->draws_dev.ptr, c->draws_host.data(), bytes))) return rc; }
         else { HIPCHK(c, hipMemcpyAsync(c->draws_dev.ptr, c->draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }

@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[256 * 14];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
+    {   // per-frame clears folded into the first kernel of the frame (saves three memset launches per frame)
+        const uint32_t n_tiles = f.tiles_x * f.tiles_y, gsz = gridDim.x * 256u, g0 = b * 256u + tid;
+        for (uint32_t i = g0; i < n_tiles; i += gsz) f.tile_count[i] = 0u;
+        if (g0 < 8u) f.counters[g0] = 0u;
+    }
     uint32_t lo = 0, hi = f.n_draws;
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
@@ -150,10 +155,17 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_bin<FILL>: one thread per triangle.  Pass 1 counts (triangle, tile) pairs per tile, pass 2 (after
-// the scan) writes the triangle ranks into each tile's list.  Triangles covering many tiles are walked
-// by the whole wavefront, 64 tiles per step.
+// k_bin<FILL>: one thread per triangle.  Pass 1 counts (triangle, tile) pairs per tile, pass 2 (after the scan) writes
+// the triangle ranks into each tile's list.
+//
+// The 256 consecutive triangles of a workgroup are neighbours on screen, so they fall into a small window of tiles.
+// The workgroup histograms them in LDS (window <= kBinWindow tiles) and touches global memory once per distinct tile:
+// one atomicAdd of the local count (pass 1), or one atomicAdd that reserves a run of the tile's list (pass 2), instead
+// of one same-address global atomic per (triangle, tile) pair.  Triangles covering more than 16 tiles are walked by the
+// whole wavefront, 64 tiles per step, with direct global atomics (there are few of them).
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kBinWindow = 2048;
+
 template <bool FILL>
 AWSM_DI void bin_emit(const FrameDev& f, int tx, int ty, uint32_t rank) {
     const uint32_t idx = (uint32_t)(ty - (int)f.tile_row0) * f.tiles_x + (uint32_t)tx;
@@ -168,7 +180,14 @@ AWSM_DI void bin_emit(const FrameDev& f, int tx, int ty, uint32_t rank) {
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    __shared__ int win[4];                       // tile window of the workgroup's small triangles: x0, y0, x1, y1
+    __shared__ uint32_t n_ok;
+    __shared__ uint32_t lcount[kBinWindow];
+    __shared__ uint32_t lbase[FILL ? kBinWindow : 1];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = blockIdx.x * 256u + tid;
+    if (tid == 0) { win[0] = 0x7fffffff; win[1] = 0x7fffffff; win[2] = -1; win[3] = -1; n_ok = 0; }
     TriSetup t;
     bool ok = false;
     if (r < f.total_tris) {
@@ -180,17 +199,60 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     if (ok) { tx0 = t.minx >> kTileShift; tx1 = t.maxx >> kTileShift; ty0 = t.miny >> kTileShift; ty1 = t.maxy >> kTileShift; }
     const int wdt = tx1 - tx0 + 1;
     const int ntiles = ok ? wdt * (ty1 - ty0 + 1) : 0;
-    if (!FILL && ok) atomicAdd(&f.counters[0], 1u);
-
     const bool big = ntiles > 16;
-    if (ok && !big) {
+    const bool small = ok && !big;
+    __syncthreads();
+    if (small) { atomicMin(&win[0], tx0); atomicMin(&win[1], ty0); atomicMax(&win[2], tx1); atomicMax(&win[3], ty1); }
+    if (!FILL) {
+        const unsigned long long okm = __ballot(ok);
+        if ((tid & 63u) == 0u && okm) atomicAdd(&n_ok, (uint32_t)__popcll(okm));
+    }
+    __syncthreads();
+    const int wx0 = win[0], wy0 = win[1], ww = win[2] - wx0 + 1, wh = win[3] - wy0 + 1;
+    const uint32_t nwin = (ww > 0 && wh > 0) ? (uint32_t)ww * (uint32_t)wh : 0u;
+    const bool use_lds = nwin <= kBinWindow;                          // workgroup-uniform
+    if (!FILL && tid == 0 && n_ok) atomicAdd(&f.counters[0], n_ok);
+    if (use_lds) for (uint32_t i = tid; i < nwin; i += 256u) lcount[i] = 0u;
+    __syncthreads();
+
+    // ---- small triangles, pass A: histogram (LDS) or direct emission (window too large) ----
+    if (small) {
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++)
-                if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift))
-                    bin_emit<FILL>(f, tx, ty, r);
+                if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift)) {
+                    if (use_lds) atomicAdd(&lcount[(ty - wy0) * ww + (tx - wx0)], 1u);
+                    else bin_emit<FILL>(f, tx, ty, r);
+                }
     }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = tid; i < nwin; i += 256u) {
+            const uint32_t c = lcount[i];
+            if (c) {
+                const uint32_t gidx = (uint32_t)(wy0 + (int)(i / (uint32_t)ww) - (int)f.tile_row0) * f.tiles_x + (uint32_t)(wx0 + (int)(i % (uint32_t)ww));
+                if (!FILL) atomicAdd(&f.tile_count[gidx], c);
+                else { lbase[i] = f.tile_offset[gidx] + atomicAdd(&f.tile_cursor[gidx], c); lcount[i] = 0u; }
+            }
+        }
+        if (FILL) {
+            __syncthreads();
+            // ---- pass B: write the ranks into the reserved runs (order inside a tile's list is irrelevant: the raster
+            // kernel resolves visibility with a min over packed keys) ----
+            if (small) {
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++)
+                        if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift)) {
+                            const uint32_t li = (uint32_t)((ty - wy0) * ww + (tx - wx0));
+                            const uint32_t pos = lbase[li] + atomicAdd(&lcount[li], 1u);
+                            if (pos < f.bin_capacity) f.bin_list[pos] = r;
+                        }
+            }
+        }
+    }
+
+    // ---- big triangles: the wavefront walks the tile rectangle together ----
     unsigned long long mask = __ballot(big);
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -241,6 +303,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = f.tile_count[i];
         f.tile_offset[i] = run; run += c;
+        f.tile_cursor[i] = 0u;
         f.tile_order[atomicAdd(&bucket_at[32 - __clz(c)], 1u)] = i;
     }
     if (tid == 1023u) {
@@ -373,7 +436,19 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     }
 }
 
+// Small host->device uploads (dirty ranges of the scene mirrors, the draw list) read the pinned staging ring directly
+// from a kernel: the copy stays in the compute queue, where an SDMA copy would stall the in-order stream on a
+// cross-engine signal for longer than the whole transform kernel runs.
+__global__ __launch_bounds__(256) void k_upload_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src_pinned, uint32_t n_words) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_words; i += gridDim.x * 256u) dst[i] = __builtin_nontemporal_load(src_pinned + i);
+}
+
 }  // namespace awsm
+
+extern "C" void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s) {
+    const uint32_t nb = (n_words + 255u) / 256u;
+    if (nb) hipLaunchKernelGGL(awsm::k_upload_words, dim3(nb < 64u ? nb : 64u), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src_pinned, n_words);
+}
 
 // ---- launch wrappers (called from awsm_hip.cpp) ----
 extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
