@@ -142,21 +142,25 @@ AWSM_DI float safe_floor(float x, float& frac) {
     return fl;
 }
 AWSM_DI f4 lerp4(f4 a, f4 b, float t) { const float s = 1.0f - t; return {a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t}; }
-// textureSampleLevel(tex, sampler, uv, layer, 0): DESIGN.md §"Texture sampling"
-AWSM_DI f4 sample_array_level0(const TexArrayDev& arr, const AwsmSampler& smp, f2 uv, uint32_t layer) {
-    const int W = (int)arr.width, H = (int)arr.height;
-    if (layer >= arr.layers) layer = arr.layers - 1u;
-    const uint8_t* base = arr.texels + (size_t)layer * (size_t)W * (size_t)H * 4u;
+// textureSampleLevel(tex, sampler, uv, layer, 0): DESIGN.md §"Texture sampling".  General form: any size, any address
+// mode, nearest or linear.  Out of line (one copy for all fourteen call sites); the hot path below handles the common
+// sampler inline and only falls back here when some lane of the wavefront needs it.
+__device__ __attribute__((noinline)) f4 sample_array_generic(const uint8_t* texels, uint32_t width, uint32_t height, uint32_t layers, uint32_t layer,
+                                                             uint32_t mode_u, uint32_t mode_v, uint32_t mag_filter, float u, float v) {
+    if (texels == nullptr || width == 0u || height == 0u || layers == 0u) return {0.0f, 0.0f, 0.0f, 0.0f};
+    const int W = (int)width, H = (int)height;
+    if (layer >= layers) layer = layers - 1u;
+    const uint8_t* base = texels + (size_t)layer * (size_t)W * (size_t)H * 4u;
     float fx, fy;
-    if (smp.mag_filter == 0u) {
-        const int i = wrap_index((int)safe_floor(uv.x * (float)W, fx), W, smp.address_mode_u);
-        const int j = wrap_index((int)safe_floor(uv.y * (float)H, fy), H, smp.address_mode_v);
+    if (mag_filter == 0u) {
+        const int i = wrap_index((int)safe_floor(u * (float)W, fx), W, mode_u);
+        const int j = wrap_index((int)safe_floor(v * (float)H, fy), H, mode_v);
         return texel_rgba8(base + ((size_t)j * W + i) * 4u);
     }
-    const float x0f = safe_floor(uv.x * (float)W - 0.5f, fx);
-    const float y0f = safe_floor(uv.y * (float)H - 0.5f, fy);
-    const int i0 = wrap_index((int)x0f, W, smp.address_mode_u), i1 = wrap_index((int)x0f + 1, W, smp.address_mode_u);
-    const int j0 = wrap_index((int)y0f, H, smp.address_mode_v), j1 = wrap_index((int)y0f + 1, H, smp.address_mode_v);
+    const float x0f = safe_floor(u * (float)W - 0.5f, fx);
+    const float y0f = safe_floor(v * (float)H - 0.5f, fy);
+    const int i0 = wrap_index((int)x0f, W, mode_u), i1 = wrap_index((int)x0f + 1, W, mode_u);
+    const int j0 = wrap_index((int)y0f, H, mode_v), j1 = wrap_index((int)y0f + 1, H, mode_v);
     const uint8_t* r0 = base + (size_t)j0 * W * 4u;
     const uint8_t* r1 = base + (size_t)j1 * W * 4u;
     const f4 c00 = texel_rgba8(r0 + i0 * 4), c10 = texel_rgba8(r0 + i1 * 4), c01 = texel_rgba8(r1 + i0 * 4), c11 = texel_rgba8(r1 + i1 * 4);
@@ -170,16 +174,57 @@ struct Attr {
     uint32_t v0, v1, v2;      // vertex_start of the three corners (floats)
     uint32_t uv_sets_index;
     f3 bary;
+    f2 uv0;                   // interpolated TEXCOORD_0, computed once per pixel when a core texture uses it
+    bool has_uv0;
 };
-AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // texture_uvs.wgsl:64-84,144-187, textures.wgsl:131-150
-    const uint32_t o = a.uv_sets_index + t.uv_set_index * 2u;
+AWSM_DI f2 attr_uv(const Attr& a, uint32_t set) {                          // texture_uvs.wgsl:64-84
+    const uint32_t o = a.uv_sets_index + set * 2u;
     const float x0 = a.ad[a.v0 + o], y0 = a.ad[a.v0 + o + 1], x1 = a.ad[a.v1 + o], y1 = a.ad[a.v1 + o + 1];
     const float x2 = a.ad[a.v2 + o], y2 = a.ad[a.v2 + o + 1];
-    const f2 uv = {a.bary.x * x0 + a.bary.y * x1 + a.bary.z * x2, a.bary.x * y0 + a.bary.y * y1 + a.bary.z * y2};
+    return {a.bary.x * x0 + a.bary.y * x1 + a.bary.z * x2, a.bary.x * y0 + a.bary.y * y1 + a.bary.z * y2};
+}
+AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // texture_uvs.wgsl:64-84,144-187, textures.wgsl:131-150
+    f2 uv = a.uv0;
+    if (!(a.has_uv0 && t.uv_set_index == 0u)) uv = attr_uv(a, t.uv_set_index);
     const float* tt = reinterpret_cast<const float*>(a.sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
-    const f2 uvt = {tt[0] * uv.x + tt[1] * uv.y + tt[4], tt[2] * uv.x + tt[3] * uv.y + tt[5]};
+    const float u = tt[0] * uv.x + tt[1] * uv.y + tt[4], v = tt[2] * uv.x + tt[3] * uv.y + tt[5];
     if (t.array_index >= a.sc->n_tex || t.sampler_index >= a.sc->n_samplers) return {0.0f, 0.0f, 0.0f, 0.0f};
-    return sample_array_level0(a.sc->tex[t.array_index], a.sc->samplers[t.sampler_index], uvt, t.layer_index);
+    const TexArrayDev& arr = a.sc->tex[t.array_index];
+    const AwsmSampler& smp = a.sc->samplers[t.sampler_index];
+    const uint32_t W = arr.width, H = arr.height, layers = arr.layers;
+    const uint8_t* texels = arr.texels;
+    // Hot path: linear filter, repeat/repeat, power-of-two extent (every texture of a typical glTF scene).  Taken when
+    // ALL lanes of the wavefront qualify (one scalar branch); wrap is a mask, no mode selects, no quotients.
+    const bool fast = smp.mag_filter != 0u && smp.address_mode_u == 1u && smp.address_mode_v == 1u && texels != nullptr && layers != 0u &&
+                      W != 0u && H != 0u && (W & (W - 1u)) == 0u && (H & (H - 1u)) == 0u;
+    if (__builtin_amdgcn_ballot_w64(!fast) != 0ull)
+        return sample_array_generic(texels, W, H, layers, t.layer_index, smp.address_mode_u, smp.address_mode_v, smp.mag_filter, u, v);
+    const uint32_t layer = min(t.layer_index, layers - 1u);
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(texels) + (size_t)layer * (size_t)W * (size_t)H;
+    float fx, fy;
+    const float x0f = safe_floor(u * (float)W - 0.5f, fx);
+    const float y0f = safe_floor(v * (float)H - 0.5f, fy);
+    const uint32_t xi = (uint32_t)(int)x0f, yi = (uint32_t)(int)y0f;
+    const uint32_t i0 = xi & (W - 1u), i1 = (xi + 1u) & (W - 1u);
+    const uint32_t r0 = (yi & (H - 1u)) * W, r1 = ((yi + 1u) & (H - 1u)) * W;
+    uint32_t t00, t10, t01, t11;
+    if (i1 == i0 + 1u) {   // the two taps of a row are neighbours in memory unless the footprint wraps: one 8-byte load per row
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        const u32x2 p0 = *reinterpret_cast<const u32x2*>(base + r0 + i0), p1 = *reinterpret_cast<const u32x2*>(base + r1 + i0);
+        t00 = p0.x; t10 = p0.y; t01 = p1.x; t11 = p1.y;
+    } else {
+        t00 = base[r0 + i0]; t10 = base[r0 + i1]; t01 = base[r1 + i0]; t11 = base[r1 + i1];
+    }
+    // bilinear on the raw 0..255 values, one scale by 1/255 at the end
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+    const float k = 1.0f / 255.0f;
+    f4 r;
+    r.x = ((float)(t00 & 255u) * w00 + (float)(t10 & 255u) * w10 + (float)(t01 & 255u) * w01 + (float)(t11 & 255u) * w11) * k;
+    r.y = ((float)((t00 >> 8) & 255u) * w00 + (float)((t10 >> 8) & 255u) * w10 + (float)((t01 >> 8) & 255u) * w01 + (float)((t11 >> 8) & 255u) * w11) * k;
+    r.z = ((float)((t00 >> 16) & 255u) * w00 + (float)((t10 >> 16) & 255u) * w10 + (float)((t01 >> 16) & 255u) * w01 + (float)((t11 >> 16) & 255u) * w11) * k;
+    r.w = ((float)(t00 >> 24) * w00 + (float)(t10 >> 24) * w10 + (float)(t01 >> 24) * w01 + (float)(t11 >> 24) * w11) * k;
+    return r;
 }
 AWSM_DI f4 vertex_color(const Attr& a, uint32_t set_index) {               // vertex_color_attrib.wgsl:1-21
     const uint32_t o = set_index * 4u;
@@ -271,46 +316,55 @@ struct Surface {
     f3 n, v, F0;
     float metallic, roughness, alpha, f90, n_dot_v_ibl /* saturate */, n_dot_v_dir /* max(.,1e-4) */, sheen_scaling_dir, g1_v;
     f3 cc_n;
+    // direct-light invariants
+    f3 df90;            // f90 - F0
+    f3 base_diffuse;    // base * (1 - metallic) / pi
+    float a2, a2m1;     // GGX alpha^2 (alpha clamped at 0.001) and alpha^2 - 1
+    float gk, one_m_gk; // Schlick-GGX k = (alpha + 1)^2 / 8
+    bool has_sheen, has_clearcoat;
 };
 
-// brdf.wgsl:308-381 for one light
+// brdf.wgsl:308-381 for one light.  `light_dir` need not be normalised (the WGSL normalises it again on entry).
 AWSM_DI f3 brdf_direct(const PbrColor& c, const Surface& sf, f3 light_dir, f3 radiance) {
     const f3 n = sf.n, v = sf.v;
     const f3 l = fm::fsafe_normalize(light_dir);
     const f3 sum = v + l;
     const float len_sq = fm::fdot(sum, sum);
     const bool has_half = len_sq > 1e-8f;
-    const f3 h = has_half ? sum * fm::rsq(len_sq) : mk3(0.0f, 0.0f, 0.0f);
-    const float n_dot_l = fmaxf(fm::fdot(n, l), 0.0f);
+    const float inv_len = has_half ? fm::rsq(len_sq) : 0.0f;          // h = sum * inv_len (never materialised for the base lobe)
+    const float ndl_raw = fm::fdot(n, l);
+    const float n_dot_l = fmaxf(ndl_raw, 0.0f);
     const float n_dot_v = sf.n_dot_v_dir;
-    const float n_dot_h = has_half ? fmaxf(fm::fdot(n, h), 0.0f) : 0.0f;
-    const float v_dot_h = has_half ? fmaxf(fm::fdot(v, h), 0.0f) : 0.0f;
-    const f3 F = fresnel_schlick_f90(has_half ? v_dot_h : n_dot_v, sf.F0, sf.f90);
-    f3 specular = {0.0f, 0.0f, 0.0f};
-    if (has_half) {
-        const float D = distribution_ggx(n_dot_h, sf.alpha);
-        const float G = sf.g1_v * geometry_schlick_ggx(saturate(fm::fdot(n, l)), sf.alpha);
-        specular = F * fm::fdiv(D * G, fmaxf((4.0f * n_dot_l) * n_dot_v, kEps));
-    }
-    const float F_max = fmaxf(fmaxf(F.x, F.y), F.z);
-    const float k_d = (1.0f - F_max) * (1.0f - sf.metallic);
-    const f3 diffuse = (c.base * k_d) * (1.0f / kPi);
-    f3 result = (((diffuse + specular) * radiance) * n_dot_l) * c.occlusion;
-    if (c.sheen_color.x > 0.0f || c.sheen_color.y > 0.0f || c.sheen_color.z > 0.0f) {   // brdf.wgsl:198-240
+    const float n_dot_h = fmaxf(fm::fdot(n, sum) * inv_len, 0.0f);
+    const float v_dot_h = fmaxf(fm::fdot(v, sum) * inv_len, 0.0f);
+    const float p5 = fm::pow5(1.0f - saturate(has_half ? v_dot_h : n_dot_v));   // brdf.wgsl:111-115
+    const f3 F = {sf.F0.x + sf.df90.x * p5, sf.F0.y + sf.df90.y * p5, sf.F0.z + sf.df90.z * p5};
+    const float ndh = saturate(n_dot_h);
+    const float dd = (ndh * ndh) * sf.a2m1 + 1.0f;                      // brdf.wgsl:118-124
+    const float D = sf.a2 * fm::rcp((kPi * dd) * dd + kEps);
+    const float ndl = saturate(ndl_raw);
+    const float g1_l = ndl * fm::rcp(ndl * sf.one_m_gk + sf.gk);        // brdf.wgsl:127-139
+    const float spec = has_half ? (D * (sf.g1_v * g1_l)) * fm::rcp(fmaxf((4.0f * n_dot_l) * n_dot_v, kEps)) : 0.0f;
+    const float k_d = 1.0f - fmaxf(fmaxf(F.x, F.y), F.z);
+    const float w = n_dot_l * c.occlusion;
+    f3 result = {((sf.base_diffuse.x * k_d + F.x * spec) * radiance.x) * w, ((sf.base_diffuse.y * k_d + F.y * spec) * radiance.y) * w,
+                 ((sf.base_diffuse.z * k_d + F.z * spec) * radiance.z) * w};
+    if (sf.has_sheen) {   // brdf.wgsl:198-240
         f3 sheen = {0.0f, 0.0f, 0.0f};
         if (has_half) {
             const float rough = fmaxf(c.sheen_roughness, 0.07f);
             const float inv_alpha = fm::rcp(rough * rough);
             const float sin2h = 1.0f - n_dot_h * n_dot_h;
-            const float D = ((2.0f + inv_alpha) * fm::powp(sin2h, inv_alpha * 0.5f)) * (1.0f / (2.0f * kPi));
+            const float Ds = ((2.0f + inv_alpha) * fm::powp(sin2h, inv_alpha * 0.5f)) * (1.0f / (2.0f * kPi));
             const float V = fm::rcp(4.0f * ((n_dot_l + n_dot_v) - n_dot_l * n_dot_v));
-            sheen = (c.sheen_color * D) * V;
+            sheen = (c.sheen_color * Ds) * V;
         }
         result = result * sf.sheen_scaling_dir + ((sheen * radiance) * n_dot_l) * c.occlusion;
     }
-    if (c.clearcoat > 0.0f) {   // brdf.wgsl:149-190
+    if (sf.has_clearcoat) {   // brdf.wgsl:149-190
         float clearcoat_spec = 0.0f;
         if (has_half) {
+            const f3 h = sum * inv_len;
             const float cc_n_dot_l = fmaxf(fm::fdot(sf.cc_n, l), 0.0f);
             const float cc_n_dot_v = fmaxf(fm::fdot(sf.cc_n, v), 1e-4f);
             const float cc_n_dot_h = fmaxf(fm::fdot(sf.cc_n, h), 0.0f);
@@ -383,6 +437,13 @@ AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_
     sf.sheen_scaling_dir = sheen_albedo_scaling(mc.sheen_color, mc.sheen_roughness, sf.n_dot_v_dir);
     sf.g1_v = geometry_schlick_ggx(saturate(ndv), sf.alpha);
     sf.cc_n = fm::fsafe_normalize(mc.clearcoat_normal);
+    sf.df90 = splat3(sf.f90) - sf.F0;
+    sf.base_diffuse = mc.base * ((1.0f - sf.metallic) * (1.0f / kPi));
+    const float ac = fmaxf(sf.alpha, 0.001f);
+    sf.a2 = ac * ac; sf.a2m1 = sf.a2 - 1.0f;
+    sf.gk = ((ac + 1.0f) * (ac + 1.0f)) * 0.125f; sf.one_m_gk = 1.0f - sf.gk;
+    sf.has_sheen = mc.sheen_color.x > 0.0f || mc.sheen_color.y > 0.0f || mc.sheen_color.z > 0.0f;
+    sf.has_clearcoat = mc.clearcoat > 0.0f;
 
     f3 color = brdf_ibl(sc, mc, sf);
     const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
@@ -392,7 +453,7 @@ AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_
         const f3 lcolor = {color_intensity.x, color_intensity.y, color_intensity.z};
         f3 light_dir = {0.0f, 0.0f, 0.0f}, radiance = {0.0f, 0.0f, 0.0f};
         if (kind == 1u) {
-            light_dir = fm::fnormalize(-mk3(dir_inner.x, dir_inner.y, dir_inner.z));
+            light_dir = -mk3(dir_inner.x, dir_inner.y, dir_inner.z);   // normalised on entry to brdf_direct
             radiance = lcolor * color_intensity.w;
         } else if (kind == 2u || kind == 3u) {
             const f3 stl = mk3(pos_range.x, pos_range.y, pos_range.z) - world_position;
@@ -424,7 +485,8 @@ AWSM_DI void store_pixel(const FrameDev& f, size_t p, f4 c) {
 // ------------------------------------------------------------------------------------------------
 // k_shade: 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers 16x4 here).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
+// 5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 starts to spill.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
     const uint32_t bx_n = (f.width + 15u) >> 4, by_n = ((f.y1 - f.y0) + 15u) >> 4;
     const uint32_t nblk = bx_n * by_n;
     // Workgroup ids are dealt round-robin over the 8 XCDs (blockIdx & 7), each with its own L2.  XCD x shades the block rows
@@ -466,6 +528,7 @@ __global__ __launch_bounds__(256) void k_shade(const DevScene* __restrict__ sc, 
     a.v0 = attr_data_off + attr_idx[0] * stride;
     a.v1 = attr_data_off + attr_idx[1] * stride;
     a.v2 = attr_data_off + attr_idx[2] * stride;
+    a.has_uv0 = false; a.uv0 = {0.0f, 0.0f};
 
     // ---- standard.wgsl:11-62 ----
     const uint8_t* cam = sc->buf[AWSM_BUF_CAMERA];
@@ -512,29 +575,29 @@ __global__ __launch_bounds__(256) void k_shade(const DevScene* __restrict__ sc, 
     const uint32_t idx_vertex_color = abs_index(b, M[fi + 0]), idx_emissive_strength = abs_index(b, M[fi + 1]);
     const uint32_t idx_ior = abs_index(b, M[fi + 2]), idx_specular = abs_index(b, M[fi + 3]), idx_transmission = abs_index(b, M[fi + 4]);
     const uint32_t idx_volume = abs_index(b, M[fi + 6]), idx_clearcoat = abs_index(b, M[fi + 7]), idx_sheen = abs_index(b, M[fi + 8]);
+    const TexInfo tx_base = tex_load(M, b + 2), tx_mr = tex_load(M, b + 11), tx_normal = tex_load(M, b + 18);
+    const TexInfo tx_occ = tex_load(M, b + 24), tx_em = tex_load(M, b + 30);
+    // TEXCOORD_0 is interpolated once for all the textures that use it (the WGSL re-derives it per texture)
+    if ((tx_base.exists && tx_base.uv_set_index == 0u) || (tx_mr.exists && tx_mr.uv_set_index == 0u) || (tx_normal.exists && tx_normal.uv_set_index == 0u) ||
+        (tx_occ.exists && tx_occ.uv_set_index == 0u) || (tx_em.exists && tx_em.uv_set_index == 0u)) {
+        a.uv0 = attr_uv(a, 0u);
+        a.has_uv0 = true;
+    }
     {
-        const TexInfo tx = tex_load(M, b + 2);
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
-        if (tx.exists) { const f4 s = sample_tex(a, tx); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+        if (tx_base.exists) { const f4 s = sample_tex(a, tx_base); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
         base.w = 1.0f;
         if (idx_vertex_color != 0u) { const f4 vc = vertex_color(a, M[idx_vertex_color]); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
         c.base = {base.x, base.y, base.z};
     }
+    c.mr = {mf(M, b + 16), mf(M, b + 17)};
+    if (tx_mr.exists) { const f4 s = sample_tex(a, tx_mr); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
+    c.normal = normal_map(a, tx_normal, mf(M, b + 23), tbn);
+    c.occlusion = 1.0f;
+    if (tx_occ.exists) { const f4 s = sample_tex(a, tx_occ); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
     {
-        const TexInfo tx = tex_load(M, b + 11);
-        c.mr = {mf(M, b + 16), mf(M, b + 17)};
-        if (tx.exists) { const f4 s = sample_tex(a, tx); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
-    }
-    c.normal = normal_map(a, tex_load(M, b + 18), mf(M, b + 23), tbn);
-    {
-        const TexInfo tx = tex_load(M, b + 24);
-        c.occlusion = 1.0f;
-        if (tx.exists) { const f4 s = sample_tex(a, tx); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
-    }
-    {
-        const TexInfo tx = tex_load(M, b + 30);
         f3 em = {mf(M, b + 35), mf(M, b + 36), mf(M, b + 37)};
-        if (tx.exists) { const f4 s = sample_tex(a, tx); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        if (tx_em.exists) { const f4 s = sample_tex(a, tx_em); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
         c.emissive = em * (idx_emissive_strength == 0u ? 1.0f : mf(M, idx_emissive_strength));
     }
     c.ior = idx_ior == 0u ? 1.5f : mf(M, idx_ior);

@@ -2,5 +2,5 @@
 # A/B harness: runs tools/quick_bench.py once per library given on the command line (AWSM_HIP_LIB override).
 for lib in "$@"; do
   echo "=== $lib"
-  AWSM_HIP_LIB=$lib timeout -k 10 200 python tools/quick_bench.py 3840 2160 20 2>&1 | tail -2
+  AWSM_HIP_LIB=$lib timeout -k 10 200 python tools/quick_bench.py 3840 2160 20 2>&1 | tail -3
 done
