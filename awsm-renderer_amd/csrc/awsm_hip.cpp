@@ -62,7 +62,7 @@ struct AwsmHipCtx {
     size_t bound_out_bytes = 0;
 
     // geometry-pass resources
-    DevBuf clip, nrm, tan, tri_flags, draws_dev, tile_count, tile_offset, tile_cursor, tile_order, bin_list, counters;
+    DevBuf clip, nrm, tan, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, counters;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
     uint32_t total_tris = 0, total_verts = 0, n_blocks = 0;
@@ -191,6 +191,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->total_tris = c->total_tris; f->total_verts = c->total_verts;
     f->bin_capacity = c->bin_capacity;
     f->draws = (const DrawDev*)c->draws_dev.ptr;
+    f->draw_shade = (DrawShadeDev*)c->draw_shade.ptr;
     f->clip = (float4*)c->clip.ptr; f->nrm = (float4*)c->nrm.ptr; f->tan = (float4*)c->tan.ptr;
     f->tri_info = (uint32_t*)c->tri_flags.ptr;
     f->tile_count = (uint32_t*)c->tile_count.ptr; f->tile_offset = (uint32_t*)c->tile_offset.ptr;
@@ -304,7 +305,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
     fr(c->lut); fr(c->vis); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_flags);
-    fr(c->draws_dev); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->counters);
+    fr(c->draws_dev); fr(c->draw_shade); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->counters);
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
@@ -481,6 +482,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     int rc;
     const size_t nd = std::max<size_t>(c->draws_host.size(), 1);
     if ((rc = dev_reserve(c, c->draws_dev, nd * sizeof(DrawDev)))) return rc;
+    if ((rc = dev_reserve(c, c->draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
     if ((rc = dev_reserve(c, c->clip, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
     if ((rc = dev_reserve(c, c->nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
     if ((rc = dev_reserve(c, c->tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;

@@ -22,6 +22,20 @@ struct DrawDev {
     uint32_t pad0, pad1;
 };
 
+// Per-draw constants of the opaque pass, resolved once per frame by k_resolve_draws from
+// geometry meta -> material mesh meta (material_mesh_meta.wgsl), so that k_shade reaches them with one dependent load
+// instead of three.
+struct DrawShadeDev {
+    uint32_t first_tri;
+    uint32_t material_word;       // material_offset / 4
+    uint32_t attr_indices_word;   // attribute index offset / 4
+    uint32_t attr_data_word;      // attribute data offset / 4
+    uint32_t stride_words;        // attribute stride / 4
+    uint32_t uv_sets_index;
+    uint32_t is_hud;
+    uint32_t pad;
+};
+
 struct TexArrayDev {
     const uint8_t* texels;
     uint32_t width, height, layers, pad;
@@ -50,6 +64,7 @@ struct FrameDev {
     uint32_t bin_capacity;        // entries in the (triangle,tile) list
     uint32_t has_opaque;
     const DrawDev* draws;
+    DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
     // transformed vertices (k_deform_transform outputs)
     float4* clip;                 // total_verts
     float4* nrm;                  // total_verts  (world normal xyz, 0)

@@ -483,6 +483,26 @@ AWSM_DI void store_pixel(const FrameDev& f, size_t p, f4 c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_resolve_draws: one thread per draw.  Follows geometry meta -> material mesh meta once per frame
+// (compute.wgsl:171-181 does it per pixel) and leaves the per-draw constants of the opaque pass in one 32-byte record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restrict__ sc, FrameDev f) {
+    const uint32_t d = blockIdx.x * 256u + threadIdx.x;
+    if (d >= f.n_draws) return;
+    const DrawDev dr = f.draws[d];
+    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
+    const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
+    DrawShadeDev o;
+    o.first_tri = dr.first_tri;
+    o.material_word = mm[6] / 4u;
+    o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
+    o.uv_sets_index = mm[12];
+    o.is_hud = mm[16];
+    o.pad = 0u;
+    f.draw_shade[d] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_shade: 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers 16x4 here).
 // ------------------------------------------------------------------------------------------------
 // 5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 starts to spill.
@@ -507,13 +527,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 
     const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     const float depth_sample = __uint_as_float((uint32_t)(key >> 32));
-    const DrawDev* dr = f.draws + (f.tri_info[rank] & 0x00FFFFFFu);
-    const uint32_t triangle_index = rank - dr->first_tri;
-    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr->geom_meta_off + 36);
-    const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
-    if (mm[16] == 1u) { store_pixel(f, p, {0.0f, 0.0f, 0.0f, 0.0f}); return; }   // is_hud (compute.wgsl:176-179): stays cleared
-    const uint32_t material_offset = mm[6];
-    const uint32_t attr_indices_off = mm[9] / 4u, attr_data_off = mm[10] / 4u, stride = mm[11] / 4u, uv_sets_index = mm[12];
+    const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
+    const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, is_hud
+    const uint32_t triangle_index = rank - ds0.x;
+    if (ds1.z == 1u) { store_pixel(f, p, {0.0f, 0.0f, 0.0f, 0.0f}); return; }   // is_hud (compute.wgsl:176-179): stays cleared
+    const uint32_t material_word = ds0.y;
+    const uint32_t attr_indices_off = ds0.z, attr_data_off = ds0.w, stride = ds1.x, uv_sets_index = ds1.y;
 
     const GBufferTexel g = reconstruct_gbuffer(f, rank, cx, cy);
     if (!g.valid) { store_pixel(f, p, sky); return; }
@@ -556,8 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 #endif
 
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
-    const uint32_t shader_id = M[material_offset / 4u];
-    const uint32_t b = material_offset / 4u + 1u;
+    const uint32_t shader_id = M[material_word];
+    const uint32_t b = material_word + 1u;
     if (shader_id == 2u) {   // unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580
         const TexInfo base_tex = tex_load(M, b + 2), em_tex = tex_load(M, b + 11);
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
@@ -728,6 +747,7 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = ((f->y1 - f->y0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
+    if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     if (nb) hipLaunchKernelGGL(awsm::k_shade, dim3(nb), dim3(256), 0, s, sc, *f);
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {

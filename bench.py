@@ -49,6 +49,21 @@ def algorithmic_bytes(scene, stats, rows):
     }
 
 
+def pmc_traffic(kernel, n_tris, W, H):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/latest_pmc.json, written by
+    tools/profile_collect.py from FETCH_SIZE / WRITE_SIZE collected in separate passes on this same workload).  None when
+    no profile of this exact workload is committed: counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        doc = json.load(open(path))
+        wl = doc["workload"]
+        if (wl["triangles"], wl["width"], wl["height"]) != (n_tris, W, H):
+            return None
+        return doc["kernels"]["awsm::" + kernel]["hbm_traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(scene, lut_rg, rows_sample):
     """Oracle (oracle/c/*.c, scalar f32, -O2) on a bounded strip of the same frame, all host cores (row bands)."""
     from oracle import oracle_lib
@@ -159,8 +174,9 @@ def main():
     alg = algorithmic_bytes(scene, {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}, y1 - y0)
     dom = max(kernel_ms, key=kernel_ms.get)
     achieved = alg[dom] / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
+    traffic = pmc_traffic(dom, n_tris, W, H) if world == 1 else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "launch_ms": kernel_ms[dom],
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "launch_ms": kernel_ms[dom],
                 "all_kernels_ms": kernel_ms, "all_kernels_algorithmic_bytes": alg}
 
     cpu = None

@@ -1,0 +1,39 @@
+"""Turn gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/.
+
+  profiles/<tag>_bench.json            the bench line
+  profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of the same command
+  profiles/<tag>_pmc.json              per-kernel mean counters per launch + derived HBM traffic
+"""
+import csv, glob, json, os, shutil, sys, collections
+tag = sys.argv[1]
+src = f"gpurun_out/{tag}"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
+stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
+ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(f"{src}/{d}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if name.startswith("awsm::"):
+                ctr[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
+for k, c in sorted(ctr.items()):
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    m["launches_sampled"] = max(len(v) for v in c.values())
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        # rocprofv3 reports both in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide
+        # (16 B/lane) streaming reads -> doubled there; other access widths are uncalibrated, so both readings are kept.
+        m["hbm_read_bytes_raw"] = m["FETCH_SIZE"] * 1024.0
+        m["hbm_read_bytes_wide_corrected"] = m["FETCH_SIZE"] * 2048.0
+        m["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024.0
+        m["hbm_traffic_bytes"] = m["hbm_read_bytes_wide_corrected"] + m["hbm_write_bytes"]
+    out[k] = m
+bench = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
+doc = {"tag": tag, "workload": bench["config"], "kernels": out}
+json.dump(doc, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+shutil.copy(f"profiles/{tag}_pmc.json", "profiles/latest_pmc.json")
+print(json.dumps({k: {n: v[n] for n in ("hbm_traffic_bytes", "FETCH_SIZE", "WRITE_SIZE") if n in v} for k, v in out.items()}, indent=1))
