@@ -57,6 +57,7 @@ struct AwsmHipCtx {
     // frame targets
     uint32_t width = 0, height = 0;
     uint32_t y0 = 0, y1 = 0;     // shard rows (0,0 = full)
+    uint32_t band_n = 1, band_r = 0, band_compact = 0;   // shard bands (awsm_hip_set_shard_bands)
     DevBuf vis, out16, out32;
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
@@ -185,8 +186,15 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     shard(c, &y0, &y1);
     f->width = c->width; f->height = c->height; f->y0 = y0; f->y1 = y1;
     f->tiles_x = (c->width + kTile - 1) / kTile;
+    f->band_n = 1; f->band_r = 0; f->out_compact = 0;
     f->tile_row0 = y0 >> kTileShift;
     f->tiles_y = (y1 > y0) ? ((y1 + kTile - 1) / kTile - f->tile_row0) : 0;
+    if (c->band_n > 1) {   // band mode: every band_n-th 32-row tile row, starting at band_r (row range is the full frame)
+        const uint32_t rows_full = (c->height + kTile - 1) / kTile;
+        f->band_n = c->band_n; f->band_r = c->band_r; f->out_compact = c->band_compact;
+        f->tile_row0 = c->band_r;
+        f->tiles_y = c->band_r < rows_full ? (rows_full - c->band_r + c->band_n - 1) / c->band_n : 0;
+    }
     f->n_draws = (uint32_t)c->draws_host.size();
     f->total_tris = c->total_tris; f->total_verts = c->total_verts;
     f->bin_capacity = c->bin_capacity;
@@ -239,6 +247,10 @@ int enqueue_opaque(AwsmHipCtx* c) {
     FrameDev f;
     fill_frame(c, &f);
     f.has_opaque = c->last_opaque.has_opaque;
+    if (c->bound_out) {
+        const size_t need = (f.out_compact ? (size_t)f.tiles_y * kTile : (size_t)c->height) * c->width * 8;
+        if (c->bound_out_bytes < need) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "opaque_pass: bound output holds %zu bytes, this shard layout writes %zu", c->bound_out_bytes, need);
+    }
     int rc = sync_scene(c);
     if (rc) return rc;
     if (f.y1 > f.y0) awsm_launch_shade(c->scene_dev, &f, c->stream);
@@ -364,13 +376,24 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     if (c->flags & AWSM_CFG_PARITY_TAP) { if ((rc = dev_realloc(c, c->out32, px * 16, true))) return rc; }
     c->width = width; c->height = height;
     c->y0 = c->y1 = 0;
+    c->band_n = 1; c->band_r = 0; c->band_compact = 0;
     c->geometry_done = c->opaque_done = false;
+    return AWSM_OK;
+}
+
+int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t compact_output) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_bands before resize");
+    if (n == 0 || r >= n) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_bands: need r < n (got n=%u r=%u)", n, r);
+    c->y0 = c->y1 = 0;                                   // bands and row ranges are alternatives
+    c->band_n = n; c->band_r = n > 1 ? r : 0; c->band_compact = (n > 1 && compact_output) ? 1u : 0u;
     return AWSM_OK;
 }
 
 int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_rows before resize");
+    c->band_n = 1; c->band_r = 0; c->band_compact = 0;   // bands and row ranges are alternatives
     if (y0 == 0 && y1 == 0) { c->y0 = c->y1 = 0; return AWSM_OK; }
     if (y0 >= y1 || y1 > c->height) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need y0 < y1 <= height (got %u,%u)", y0, y1);
     c->y0 = y0; c->y1 = y1;
@@ -576,8 +599,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
 
 int awsm_hip_bind_output(AwsmHipCtx* c, void* device_ptr, size_t bytes) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
-    if (device_ptr && bytes < (size_t)c->width * c->height * 8) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_output: %zu bytes < width*height*8", bytes);
-    c->bound_out = device_ptr; c->bound_out_bytes = bytes;
+    if (device_ptr && bytes == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_output: zero-sized image");
+    c->bound_out = device_ptr; c->bound_out_bytes = bytes;   // checked against the shard layout when the opaque pass is enqueued
     return AWSM_OK;
 }
 

@@ -57,7 +57,9 @@ struct FrameDev {
     uint32_t width, height;
     uint32_t y0, y1;              // shard rows [y0,y1)
     uint32_t tiles_x, tiles_y;    // tiles covering the shard: rows [y0>>5, ceil(y1/32))
-    uint32_t tile_row0;           // y0 >> 5
+    uint32_t tile_row0;           // first tile row (32 px) of the shard
+    uint32_t band_n, band_r;      // the shard owns the tile rows ty >= tile_row0 with ty % band_n == band_r (1, 0 = every row)
+    uint32_t out_compact;         // band mode: output row = local band * 32 + (y & 31) instead of y
     uint32_t n_draws;
     uint32_t total_tris;
     uint32_t total_verts;

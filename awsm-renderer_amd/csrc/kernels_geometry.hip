@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kBinWindow = 2048;
 
+// (tx, l): tile column and LOCAL tile row of the shard; absolute tile row = tile_row0 + l * band_n
 template <bool FILL>
-AWSM_DI void bin_emit(const FrameDev& f, int tx, int ty, uint32_t rank) {
-    const uint32_t idx = (uint32_t)(ty - (int)f.tile_row0) * f.tiles_x + (uint32_t)tx;
+AWSM_DI void bin_emit(const FrameDev& f, int tx, int l, uint32_t rank) {
+    const uint32_t idx = (uint32_t)l * f.tiles_x + (uint32_t)tx;
     if (!FILL) {
         atomicAdd(&f.tile_count[idx], 1u);
     } else {
@@ -195,8 +196,15 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
         const bool cull_back = ((f.tri_info[r] >> 24) & AWSM_DRAW_CULL_BACK) != 0;
         ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, t);
     }
+    // tile rectangle in (column, local row) space; a triangle that touches none of the shard's tile rows drops out here
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-    if (ok) { tx0 = t.minx >> kTileShift; tx1 = t.maxx >> kTileShift; ty0 = t.miny >> kTileShift; ty1 = t.maxy >> kTileShift; }
+    const int bn = (int)f.band_n, row0 = (int)f.tile_row0;
+    if (ok) {
+        tx0 = t.minx >> kTileShift; tx1 = t.maxx >> kTileShift;
+        const int a0 = (t.miny >> kTileShift) - row0, a1 = (t.maxy >> kTileShift) - row0;   // >= 0: tri_setup clamps to the shard rows
+        ty0 = (a0 + bn - 1) / bn; ty1 = a1 >= 0 ? a1 / bn : -1;            // ceil / floor; a0 > -bn
+        ok = ty0 <= ty1;
+    }
     const int wdt = tx1 - tx0 + 1;
     const int ntiles = ok ? wdt * (ty1 - ty0 + 1) : 0;
     const bool big = ntiles > 16;
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     if (small) {
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++)
-                if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift)) {
+                if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, (row0 + ty * bn) << kTileShift, (tx + 1) << kTileShift, (row0 + ty * bn + 1) << kTileShift)) {
                     if (use_lds) atomicAdd(&lcount[(ty - wy0) * ww + (tx - wx0)], 1u);
                     else bin_emit<FILL>(f, tx, ty, r);
                 }
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
         for (uint32_t i = tid; i < nwin; i += 256u) {
             const uint32_t c = lcount[i];
             if (c) {
-                const uint32_t gidx = (uint32_t)(wy0 + (int)(i / (uint32_t)ww) - (int)f.tile_row0) * f.tiles_x + (uint32_t)(wx0 + (int)(i % (uint32_t)ww));
+                const uint32_t gidx = (uint32_t)(wy0 + (int)(i / (uint32_t)ww)) * f.tiles_x + (uint32_t)(wx0 + (int)(i % (uint32_t)ww));
                 if (!FILL) atomicAdd(&f.tile_count[gidx], c);
                 else { lbase[i] = f.tile_offset[gidx] + atomicAdd(&f.tile_cursor[gidx], c); lcount[i] = 0u; }
             }
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
             if (small) {
                 for (int ty = ty0; ty <= ty1; ty++)
                     for (int tx = tx0; tx <= tx1; tx++)
-                        if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift)) {
+                        if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, (row0 + ty * bn) << kTileShift, (tx + 1) << kTileShift, (row0 + ty * bn + 1) << kTileShift)) {
                             const uint32_t li = (uint32_t)((ty - wy0) * ww + (tx - wx0));
                             const uint32_t pos = lbase[li] + atomicAdd(&lcount[li], 1u);
                             if (pos < f.bin_capacity) f.bin_list[pos] = r;
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
         const uint32_t sr = __shfl(r, src);
         for (int i = lane; i < sn; i += 64) {
             const int ty = sy0 + i / swd, tx = sx0 + i % swd;
-            if (tile_may_overlap(s, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift))
+            if (tile_may_overlap(s, tx << kTileShift, (row0 + ty * bn) << kTileShift, (tx + 1) << kTileShift, (row0 + ty * bn + 1) << kTileShift))
                 bin_emit<FILL>(f, tx, ty, sr);
         }
     }
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     const uint32_t tile = f.tile_order[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const int tpx = (int)(tile % f.tiles_x) << kTileShift;
-    const int tpy = (int)(tile / f.tiles_x + f.tile_row0) << kTileShift;
+    const int tpy = (int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift;
 
 #pragma unroll
     for (int i = 0; i < 4; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0

@@ -507,7 +507,9 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
 // ------------------------------------------------------------------------------------------------
 // 5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 starts to spill.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
-    const uint32_t bx_n = (f.width + 15u) >> 4, by_n = ((f.y1 - f.y0) + 15u) >> 4;
+    // block rows of 16 pixels: consecutive rows of the shard (row mode), or the two halves of each owned 32-row band (band mode)
+    const uint32_t bx_n = (f.width + 15u) >> 4;
+    const uint32_t by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.y1 - f.y0) + 15u) >> 4;
     const uint32_t nblk = bx_n * by_n;
     // Workgroup ids are dealt round-robin over the 8 XCDs (blockIdx & 7), each with its own L2.  XCD x shades the block rows
     // x, x+8, x+16, ...: coherent along a row (neighbouring blocks share triangles and texels in that L2) and balanced over
@@ -516,13 +518,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     const uint32_t rows_x = (by_n + 7u - xcd) >> 3;                 // block rows owned by this XCD
     const uint32_t blk = (k < rows_x * bx_n) ? ((k / bx_n) * 8u + xcd) * bx_n + (k % bx_n) : nblk;
     if (blk >= nblk) return;
+    const uint32_t brow = blk / bx_n;
     const int cx = (int)((blk % bx_n) << 4) + (int)(threadIdx.x & 15u);
-    const int cy = (int)f.y0 + (int)((blk / bx_n) << 4) + (int)(threadIdx.x >> 4);
+    const int cy = (f.band_n > 1u ? (int)(((f.tile_row0 + (brow >> 1) * f.band_n) << kTileShift) + ((brow & 1u) << 4)) : (int)f.y0 + (int)(brow << 4)) + (int)(threadIdx.x >> 4);
     if (cx >= (int)f.width || cy >= (int)f.y1) return;                   // compute.wgsl:111-113
-    const size_t p = (size_t)cy * f.width + (size_t)cx;
+    const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
+    const size_t p = f.out_compact ? (size_t)(((brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
     const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};   // skybox.wgsl:1-41, uniform cube
 
-    const unsigned long long key = f.vis[p];
+    const unsigned long long key = f.vis[pv];
     if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, sky); return; }   // compute.wgsl:149-153 / empty.wgsl
 
     const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
@@ -728,10 +732,15 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t* __restrict__ out_rg1
 
 // covered-pixel count for AwsmFrameStats: runs only when the caller asks for stats (frame_end), never in the frame itself.
 // (A per-wave atomicAdd on one counter inside k_shade serialised ~130k same-address atomics per 4K frame.)
-__global__ __launch_bounds__(256) void k_count_covered(const unsigned long long* __restrict__ vis, uint32_t width, uint32_t y0, uint32_t y1, uint32_t* counter) {
+__global__ __launch_bounds__(256) void k_count_covered(const unsigned long long* __restrict__ vis, uint32_t width, uint32_t y0, uint32_t y1,
+                                                       uint32_t band_n, uint32_t band_r, uint32_t* counter) {
     const size_t n = (size_t)width * (y1 - y0), base = (size_t)width * y0;
     uint32_t local = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) local += vis[base + i] != ~0ull ? 1u : 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t y = y0 + (uint32_t)(i / width);
+        if (band_n > 1u && ((y >> kTileShift) % band_n) != band_r) continue;      // rows of other shards hold stale keys
+        local += vis[base + i] != ~0ull ? 1u : 0u;
+    }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
 }
@@ -745,13 +754,13 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 }  // namespace awsm
 
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
-    const uint32_t bx_n = (f->width + 15u) >> 4, by_n = ((f->y1 - f->y0) + 15u) >> 4;
+    const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->y1 - f->y0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     if (nb) hipLaunchKernelGGL(awsm::k_shade, dim3(nb), dim3(256), 0, s, sc, *f);
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
-    if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->counters + 3);
+    if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->band_n, f->band_r, f->counters + 3);
 }
 extern "C" void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_brdf_lut, dim3((w + 15u) / 16u, (h + 15u) / 16u), dim3(256), 0, s, out_rg16f, w, h);

@@ -22,7 +22,7 @@ BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", 
 
 # every symbol include/awsm_hip.h declares (tests/test_abi_symbols.py checks the header against this list too)
 EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
-           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_texture_array_upload", "awsm_hip_sampler_set",
+           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_texture_array_upload", "awsm_hip_sampler_set",
            "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
@@ -93,6 +93,7 @@ def load_library():
     lib.awsm_hip_frame_flush.argtypes = [C.c_void_p]
     lib.awsm_hip_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.awsm_hip_set_shard_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.awsm_hip_set_shard_bands.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.awsm_hip_texture_array_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     lib.awsm_hip_sampler_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.awsm_hip_env_upload.argtypes = [C.c_void_p, C.c_void_p]
@@ -170,6 +171,9 @@ class HipDevice:
 
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_hip_set_shard_rows(self.ctx, y0, y1), "set_shard_rows")
+
+    def set_shard_bands(self, n: int, r: int, compact_output: bool = False):
+        self._chk(self.lib.awsm_hip_set_shard_bands(self.ctx, n, r, 1 if compact_output else 0), "set_shard_bands")
 
     def texture_array_upload(self, index: int, texels: np.ndarray):
         layers, h, w, _ = texels.shape

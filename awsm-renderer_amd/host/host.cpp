@@ -46,6 +46,7 @@ struct Backend {
     int (*buffer_write)(AwsmHipCtx*, AwsmBuf, size_t, const void*, size_t) = nullptr;
     int (*resize)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t) = nullptr;
     int (*set_shard_rows)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
+    int (*set_shard_bands)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t) = nullptr;
     int (*texture_array_upload)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, AwsmTexFormat, const void*) = nullptr;
     int (*sampler_set)(AwsmHipCtx*, uint32_t, const AwsmSampler*) = nullptr;
     int (*env_upload)(AwsmHipCtx*, const AwsmEnv*) = nullptr;
@@ -420,7 +421,7 @@ int awsm_host_create(const char* backend_path, int device, void* stream, uint32_
     bool ok = load_sym(h.get(), b.create, "awsm_hip_create") && load_sym(h.get(), b.destroy, "awsm_hip_destroy") &&
               load_sym(h.get(), b.last_error, "awsm_hip_last_error") && load_sym(h.get(), b.abi_version, "awsm_hip_abi_version") &&
               load_sym(h.get(), b.buffer_create, "awsm_hip_buffer_create") && load_sym(h.get(), b.buffer_write, "awsm_hip_buffer_write") &&
-              load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") &&
+              load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") && load_sym(h.get(), b.set_shard_bands, "awsm_hip_set_shard_bands") &&
               load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
               load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
               load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") &&
@@ -769,6 +770,7 @@ int awsm_host_resize(AwsmHost* h, uint32_t w, uint32_t ht) {
     return AWSM_OK;
 }
 int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1) { int rc = h->be.set_shard_rows(h->ctx, y0, y1); return rc ? dev_fail(h, rc, "set_shard_rows") : AWSM_OK; }
+int awsm_host_set_shard_bands(AwsmHost* h, uint32_t n, uint32_t r, uint32_t compact) { int rc = h->be.set_shard_bands(h->ctx, n, r, compact); return rc ? dev_fail(h, rc, "set_shard_bands") : AWSM_OK; }
 
 // ------------------------------------------------------------------------------------------------ frame
 int awsm_host_update_transforms(AwsmHost* h) {   // transforms.rs:29-39 + meshes.rs:872-939

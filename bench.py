@@ -6,8 +6,9 @@
 
 One "step" = one frame: camera write (the per-frame dirty upload of a static scene), geometry pass (deform/transform,
 bin, raster) and the single-dispatch opaque pass, driven through the C++ host layer and the C-ABI.  Scene data is
-resident in HBM before the timed region.  With N > 1 the frame is sharded into N horizontal strips (one process per
-GPU); every step ends with an RCCL all-gather of the RGBA16F strips so that every rank holds the full image.
+resident in HBM before the timed region.  With N > 1 the frame is sharded into 32-row bands dealt round-robin over the
+ranks (one process per GPU); every step ends with an RCCL all-gather of the RGBA16F bands so that every rank holds the
+full image (the gather of frame i runs while frame i+1 renders).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline      for the dominant kernel: algorithmic bytes per launch / hipEvent-measured launch time vs 8 TB/s
@@ -82,6 +83,10 @@ def cpu_baseline(scene, lut_rg, rows_sample):
                       f"transformed), {dt:.1f} s wall, scaled to whole frames"}
 
 
+def backend_is_rehearsal():
+    return os.environ.get("AWSM_BENCH_BACKEND", "nccl") != "nccl"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +98,7 @@ def main():
     ap.add_argument("--tex-scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=30)
+    ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,42 +112,89 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback for the product path")
+    if backend_is_rehearsal():
+        local_rank = 0                     # rehearsal: all ranks share GPU 0
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("AWSM_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # backend "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # backend "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from awsm_renderer_amd import scenes
     from awsm_renderer_amd.host import Renderer
-    from awsm_renderer_amd.sharding import gather_image, strip_rows
+    from awsm_renderer_amd.sharding import band_rows, bands_per_rank, bands_to_image
 
     W, H = args.width, args.height
     scene = scenes.atrium_scene(W, H, detail=args.detail, tex_scale=args.tex_scale)
     n_tris = scenes.total_triangles(scene)
-    stream = torch.cuda.current_stream()
+    # One explicit HIP stream for everything: the library launches its kernels on it, and torch (RCCL collectives, barrier
+    # tensors) orders against it as its current stream.  (torch's default stream has handle 0, which the C-ABI reads as
+    # "create a private stream" — that one would not be ordered with the collectives.)
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024)
-    y0, y1, per = strip_rows(H, world, rank)
-    full = torch.zeros((world * per, W, 4), dtype=torch.float16, device="cuda")   # padded to equal strips for the all-gather
+    from awsm_renderer_amd.hip_backend import HipDevice
+    dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
+    # N > 1: 32-row bands dealt round-robin over the ranks (rank r owns tile rows r, r+N, ...: every rank gets 1/N of the
+    # dense part of the screen), compact [L*32, W] output per rank, RCCL all-gather -> [N, L, 32, W], de-interleaved by
+    # bands_to_image.  Double-buffered: frame i is gathered (RCCL's stream) while frame i+1 renders.
+    L = bands_per_rank(H, world)
+    rows_out = L * 32 if world > 1 else H
+    n_buf = 2 if world > 1 else 1
+    gathered = [torch.zeros((world, L, 32, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)] if world > 1 else None
+    image = [torch.zeros((H, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)]       # what every rank ends up holding
+    mine = [torch.zeros((rows_out, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)] if world > 1 else None
+    pending = [None] * n_buf
+    frame_no = [0]
     if world > 1:
-        strip = torch.zeros((per, W, 4), dtype=torch.float16, device="cuda")
-        # the kernels address the image by absolute row: bind a base pointer such that row y0 lands on strip[0]
-        r.host.set_shard_rows(y0, y1)
-        base = strip.data_ptr() - y0 * W * 8
-        from awsm_renderer_amd.hip_backend import HipDevice
-        dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
-        dev.bind_output(base, H * W * 8)
+        r.host.set_shard_bands(world, rank, compact_output=True)
     else:
-        from awsm_renderer_amd.hip_backend import HipDevice
-        dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
-        dev.bind_output(full.data_ptr(), H * W * 8)
+        dev.bind_output(image[0].data_ptr(), H * W * 8)
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather(dst, src):
+        if backend == "nccl":
+            return dist.all_gather_into_tensor(dst, src, async_op=True)
+        # rehearsal backend (AWSM_BENCH_BACKEND=gloo, several ranks sharing one GPU): staged through the host, synchronous
+        torch.cuda.current_stream().synchronize()
+        host_src = src.view(torch.int32).cpu()
+        host_dst = torch.empty((world,) + tuple(host_src.shape), dtype=torch.int32)
+        dist.all_gather_into_tensor(host_dst.view(world * host_src.shape[0], *host_src.shape[1:]), host_src)
+        dst.copy_(host_dst.view(world * host_src.shape[0], *host_src.shape[1:]).view(torch.float16).view(dst.shape))
+        return _Done()
+
+    def finish(b):
+        """Order the gather of buffer b before the current stream and de-interleave it into image[b]."""
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+            image[b].copy_(bands_to_image(gathered[b], H, world))
 
     def step():
         r.host.camera_update(scene.view, scene.proj, scene.camera_position)
+        if world == 1:
+            r.host.render(sync=False)
+            return
+        b = frame_no[0] % n_buf
+        frame_no[0] += 1
+        finish(b)                      # frame i-2 used these buffers: complete it before they are overwritten
+        dev.bind_output(mine[b].data_ptr(), rows_out * W * 8)
         r.host.render(sync=False)
-        if world > 1:
-            gather_image(strip, full, world)
+        pending[b] = all_gather(gathered[b].view(world * rows_out, W, 4), mine[b])
+
+    def drain():
+        for b in range(n_buf):
+            finish(b)
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -156,11 +209,25 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
+
+    check = None
+    if args.check and world > 1:
+        last = (frame_no[0] - 1) % n_buf
+        got = image[last].clone()
+        ref = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+        r.host.set_shard_bands(1, 0)
+        dev.bind_output(ref.data_ptr(), H * W * 8)
+        r.host.render(sync=True)
+        check = "ok" if torch.equal(got.view(torch.int16), ref.view(torch.int16)) else "MISMATCH"
+        r.host.set_shard_bands(world, rank, compact_output=True)
+        dev.bind_output(mine[0].data_ptr(), rows_out * W * 8)
+        if check != "ok":
+            raise SystemExit(f"rank {rank}: gathered image differs from the unsharded frame")
 
     # ---- per-kernel launch durations: hipEvents recorded by the library on the kernels' own stream ----
     acc = {}
@@ -171,7 +238,8 @@ def main():
             acc[k] = acc.get(k, 0.0) + float(v)
     st = {k: v / max(1, args.profile_frames) for k, v in acc.items()}
     kernel_ms = {"k_deform_transform": st["ms_transform"], "k_bin": st["ms_bin"], "k_raster_tile": st["ms_raster"], "k_shade": st["ms_shade"]}
-    alg = algorithmic_bytes(scene, {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}, y1 - y0)
+    rows_mine = H if world == 1 else len(band_rows(H, world, rank))
+    alg = algorithmic_bytes(scene, {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}, rows_mine)
     dom = max(kernel_ms, key=kernel_ms.get)
     achieved = alg[dom] / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
     traffic = pmc_traffic(dom, n_tris, W, H) if world == 1 else None
@@ -198,11 +266,13 @@ def main():
             "config": {"workload": f"Sponza-class procedural atrium (configs[3]): {n_tris} triangles, {len(scene.materials)} materials, "
                                    f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, single-sample, MipmapMode::None",
                        "triangles": n_tris, "width": W, "height": H,
-                       "sharding": "none" if world == 1 else f"{world} horizontal strips of {per} rows + RCCL all-gather of the RGBA16F image",
+                       "sharding": "none" if world == 1 else f"32-row bands round-robin over {world} ranks ({L} bands each) + RCCL all-gather of the RGBA16F image "
+                                                             f"+ de-interleave; gather of frame i overlapped with the render of frame i+1 (double-buffered)",
                        "draws": len(r.host.draw_list())},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels")},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            **({"check": check} if check else {}),
         }
         print(json.dumps(out))
     dev.close()

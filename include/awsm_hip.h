@@ -161,6 +161,14 @@ int awsm_hip_resize(AwsmHipCtx* ctx, uint32_t width, uint32_t height, uint32_t m
  * straddle it are clipped per pixel, so a shard's rows are bit-identical to the same rows of the full frame. ---- */
 int awsm_hip_set_shard_rows(AwsmHipCtx* ctx, uint32_t y0, uint32_t y1);
 
+/* Interleaved sharding for load balance (no reference counterpart): this context rasterises and shades the
+ * 32-row tile rows ty with ty % n == r (n = 1 restores the full frame; replaces any set_shard_rows range).  Work per
+ * shard is then proportional to 1/n wherever the expensive part of the screen lies.  With compact_output != 0 the
+ * opaque image is written densely: output row = (ty / n) * 32 + (y & 31), ceil((ceil(H/32) - r) / n) * 32 rows — the
+ * layout an all-gather wants; otherwise rows keep their absolute position.  The visibility buffer is always
+ * addressed by absolute row.  Rows owned by a shard are bit-identical to the same rows of the unsharded frame. */
+int awsm_hip_set_shard_bands(AwsmHipCtx* ctx, uint32_t n, uint32_t r, uint32_t compact_output);
+
 /* ---- texture pool bind (crates/renderer/src/render_passes/material_opaque/bind_group.rs:331-360):
  * array `array_idx` is a texture_2d_array of `layers` w x h images; texels = layers*h*w*4 bytes, layer-major. ---- */
 int awsm_hip_texture_array_upload(AwsmHipCtx* ctx, uint32_t array_idx, uint32_t width, uint32_t height,
@@ -190,7 +198,9 @@ int awsm_hip_frame_flush(AwsmHipCtx* ctx);
 
 /* ---- output image: RGBA16F, row-major, width*height*8 bytes == the reference's `opaque` render
  * texture (crates/renderer/src/render_textures.rs:49-54).  bind_output lets the caller own the memory
- * (e.g. a torch tensor that RCCL all-gathers); NULL returns to the internal image. ---- */
+ * (e.g. a torch tensor that RCCL all-gathers); NULL returns to the internal image.  `bytes` must cover what the
+ * current shard layout writes: width*height*8, or bands*32*width*8 with awsm_hip_set_shard_bands(compact_output);
+ * checked when the opaque pass is enqueued. ---- */
 int awsm_hip_bind_output(AwsmHipCtx* ctx, void* device_ptr, size_t bytes);
 void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
 

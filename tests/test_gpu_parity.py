@@ -107,3 +107,58 @@ def test_empty_pipeline_is_skybox_only(oracle_lut):
     img = dev.read_opaque_f32()
     dev.close()
     assert np.all(img == np.array([0.25, 0.5, 0.75, 1.0], dtype=np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_band_sharding_rows_identical_to_full_frame(oracle_lut, n):
+    """awsm_hip_set_shard_bands: every shard's rows (visibility keys, f32 tap, RGBA16F) are bit-identical to the same rows
+    of the unsharded frame rendered by the same device; compact output lands where sharding.bands_to_image expects it."""
+    from awsm_renderer_amd import sharding
+    sc = scenes.atrium_scene(1000, 563, detail=0.25, tex_scale=0.125)      # 18 tile rows (the last one partial), odd width
+    model = helpers.build_model(sc)
+    dev, _ = helpers.hip_frame(model, oracle_lut)
+    full_keys, full_f32, full_f16 = dev.read_visibility(), dev.read_opaque_f32(), dev.read_opaque()
+    draws = model.collect_draws()
+    H, W = sc.height, sc.width
+    L = sharding.bands_per_rank(H, n)
+    gathered = np.zeros((n, L * 32, W, 4), dtype=np.uint16)
+    covered = 0
+    for r in range(n):
+        rows = np.array(sharding.band_rows(H, n, r), dtype=np.int64)
+        dev.set_shard_bands(n, r, compact_output=False)
+        dev.geometry_pass(draws); dev.opaque_pass(); st = dev.frame_end()
+        covered += st["covered_pixels"]
+        assert (dev.read_visibility()[rows] == full_keys[rows]).all()
+        assert (dev.read_opaque_f32()[rows].view(np.uint32) == full_f32[rows].view(np.uint32)).all()
+        dev.set_shard_bands(n, r, compact_output=True)
+        dev.geometry_pass(draws); dev.opaque_pass(); dev.frame_end()
+        comp = dev.read_opaque()
+        assert (comp[: len(rows)] == full_f16[rows]).all()
+        gathered[r, : len(rows)] = comp[: len(rows)]
+    assert covered == int((full_keys != helpers.NO_HIT).sum())
+    img = sharding.bands_to_image(gathered.reshape(n, L, 32, W, 4), H, n)
+    assert (img == full_f16).all()
+    dev.set_shard_bands(1, 0)
+    dev.geometry_pass(draws); dev.opaque_pass(); dev.frame_end()
+    assert (dev.read_visibility() == full_keys).all()
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path (band sharding, compact outputs, double-buffered gather, de-interleave) run as two processes
+    sharing this box's one GPU, with the collectives staged through gloo; --check compares the gathered image with an
+    unsharded render bit for bit.  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)"""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, AWSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--width", "640", "--height", "363", "--detail", "0.125",
+           "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["check"] == "ok" and out["n_gpus"] == 2 and out["value"] > 0

@@ -80,3 +80,66 @@ def test_strip_rows_cover_the_frame_exactly():
             for a, b in zip(rows, rows[1:]):
                 assert a[1] == b[0] or (a[1] == h and b[0] == h)
             assert all(y1 - y0 <= per for y0, y1, per in rows)
+
+
+BAND_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["AWSM_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from awsm_renderer_amd import scenes
+from awsm_renderer_amd.sharding import band_rows, bands_per_rank, bands_to_image
+from oracle import oracle_lib
+from tests import helpers
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+scene = scenes.atrium_scene(160, 101, detail=0.125, tex_scale=1 / 64)
+lut = oracle_lib.brdf_lut(16, 16, threads=2)
+model = helpers.build_model(scene)
+H, W = scene.height, scene.width
+# a shard's rows are defined to equal the full frame's rows, so the CPU stand-in for "render my bands" is: full frame, keep mine
+fr = helpers.oracle_frame(model, lut, threads=2)
+rows = band_rows(H, world, rank)
+L = bands_per_rank(H, world)
+compact = torch.zeros((L * 32, W, 2), dtype=torch.int32)          # what awsm_hip_set_shard_bands(..., compact_output=1) writes
+compact[: len(rows)] = torch.from_numpy(np.ascontiguousarray(fr.rgba16f[rows]).view(np.int32))
+gathered = torch.zeros((world * L * 32, W, 2), dtype=torch.int32)
+dist.all_gather_into_tensor(gathered, compact)
+img = bands_to_image(gathered.view(world, L, 32, W, 2), H, world)
+if rank == world - 1:
+    np.save(os.environ["AWSM_OUT"] + "_img.npy", img.contiguous().numpy())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bands_gather_to_the_full_frame(world, tmp_path):
+    from awsm_renderer_amd import scenes
+    from oracle import oracle_lib
+    from tests import helpers
+    out = str(tmp_path / "bands")
+    script = tmp_path / "band_worker.py"
+    script.write_text(BAND_WORKER)
+    env = dict(os.environ, AWSM_ROOT=ROOT, AWSM_OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    scene = scenes.atrium_scene(160, 101, detail=0.125, tex_scale=1 / 64)
+    ref = helpers.oracle_frame(helpers.build_model(scene), oracle_lib.brdf_lut(16, 16, threads=2), threads=4)
+    img = np.ascontiguousarray(np.load(out + "_img.npy")).view(np.uint16)
+    assert np.array_equal(img, ref.rgba16f)
+
+
+def test_band_rows_partition_the_frame():
+    from awsm_renderer_amd.sharding import band_rows, bands_per_rank, bands_to_image
+    for h in (1, 31, 32, 33, 101, 563, 1080, 2160):
+        for n in (1, 2, 3, 4, 8):
+            owned = [band_rows(h, n, r) for r in range(n)]
+            assert sorted(y for rows in owned for y in rows) == list(range(h))
+            L = bands_per_rank(h, n)
+            assert all(len(rows) <= L * 32 for rows in owned)
+            # layout check: put each row's index where the compact output would hold it and reassemble
+            g = np.full((n, L * 32, 1, 1), -1, dtype=np.int64)
+            for r, rows in enumerate(owned):
+                g[r, : len(rows), 0, 0] = rows
+            img = bands_to_image(g.reshape(n, L, 32, 1, 1), h, n)
+            assert img[:, 0, 0].tolist() == list(range(h))
