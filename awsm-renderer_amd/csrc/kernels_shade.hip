@@ -20,7 +20,7 @@ namespace awsm {
 
 // ================================================================================================
 // STRICT section (arithmetic contract, -ffp-contract=off, IEEE div/sqrt): what fs_main wrote for this pixel
-// (fragment.wgsl:23-54), rounded to the G-buffer storage formats.  Bit-identical to oracle/c/oracle_shade.c.
+// (fragment.wgsl:23-54), rounded to the G-buffer storage formats.  Bit-identical to the CPU oracle (tests only).
 // ================================================================================================
 struct GBufferTexel {
     f4 packed_nt;    // RGBA16F normal_tangent, already rounded to f16
