@@ -17,6 +17,7 @@
 using namespace awsm;
 
 extern "C" {
+void awsm_launch_bin_big(const FrameDev* f, int fill, hipStream_t s);
 void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
 void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s);
 void awsm_launch_bin_count(const FrameDev* f, hipStream_t s);
@@ -63,7 +64,7 @@ struct AwsmHipCtx {
     size_t bound_out_bytes = 0;
 
     // geometry-pass resources
-    DevBuf clip, nrm, tan, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, counters;
+    DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
     uint32_t total_tris = 0, total_verts = 0, n_blocks = 0;
@@ -202,9 +203,11 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->draw_shade = (DrawShadeDev*)c->draw_shade.ptr;
     f->clip = (float4*)c->clip.ptr; f->nrm = (float4*)c->nrm.ptr; f->tan = (float4*)c->tan.ptr;
     f->tri_info = (uint32_t*)c->tri_flags.ptr;
+    f->tri_rec = (TriRec*)c->tri_rec.ptr;
     f->tile_count = (uint32_t*)c->tile_count.ptr; f->tile_offset = (uint32_t*)c->tile_offset.ptr;
     f->tile_cursor = (uint32_t*)c->tile_cursor.ptr; f->bin_list = (uint32_t*)c->bin_list.ptr;
     f->tile_order = (uint32_t*)c->tile_order.ptr;
+    f->big_list = (uint32_t*)c->big_list.ptr;
     f->counters = (uint32_t*)c->counters.ptr;
     f->vis = (unsigned long long*)c->vis.ptr;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? c->bound_out : c->out16.ptr);
@@ -232,9 +235,9 @@ int enqueue_geometry(AwsmHipCtx* c) {
     if (c->total_tris && n_tiles) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
     if ((rc = record(c, EV_TRANSFORM))) return rc;
     if (n_tiles) {
-        if (c->total_tris) awsm_launch_bin_count(&f, c->stream);
+        if (c->total_tris) { awsm_launch_bin_count(&f, c->stream); awsm_launch_bin_big(&f, 0, c->stream); }
         awsm_launch_bin_scan(&f, c->stream);
-        if (c->total_tris) awsm_launch_bin_fill(&f, c->stream);
+        if (c->total_tris) { awsm_launch_bin_fill(&f, c->stream); awsm_launch_bin_big(&f, 1, c->stream); }
     }
     if ((rc = record(c, EV_BIN))) return rc;
     if (n_tiles) awsm_launch_raster(&f, c->stream);
@@ -316,8 +319,8 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->vis); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_flags);
-    fr(c->draws_dev); fr(c->draw_shade); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->counters);
+    fr(c->lut); fr(c->vis); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_rec); fr(c->tri_flags);
+    fr(c->draws_dev); fr(c->draw_shade); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->big_list); fr(c->counters);
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
@@ -510,6 +513,8 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = dev_reserve(c, c->nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
     if ((rc = dev_reserve(c, c->tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
     if ((rc = dev_reserve(c, c->tri_flags, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, c->big_list, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, c->tri_rec, std::max<size_t>(c->total_tris, 1) * kTriRecBytes))) return rc;
     const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
     const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
     if ((rc = dev_reserve(c, c->tile_count, n_tiles_full * 4))) return rc;

@@ -53,6 +53,9 @@ struct DevScene {
     uint32_t lut_w, lut_h;
 };
 
+struct TriRec;                                   // raster_setup.hpp (device side); 64 bytes
+constexpr size_t kTriRecBytes = 64;
+
 struct FrameDev {
     uint32_t width, height;
     uint32_t y0, y1;              // shard rows [y0,y1)
@@ -71,6 +74,7 @@ struct FrameDev {
     float4* clip;                 // total_verts
     float4* nrm;                  // total_verts  (world normal xyz, 0)
     float4* tan;                  // total_verts  (world tangent xyz, handedness)
+    TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)
     uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..31)
     // binning
     uint32_t* tile_count;         // n_tiles
@@ -78,7 +82,8 @@ struct FrameDev {
     uint32_t* tile_cursor;        // n_tiles
     uint32_t* tile_order;         // n_tiles: tile ids, heaviest first (k_bin_scan)
     uint32_t* bin_list;           // bin_capacity
-    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels
+    uint32_t* big_list;           // total_tris: ranks of the triangles covering > 16 tiles (count in counters[4])
+    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles
     // targets
     unsigned long long* vis;      // width*height packed keys
     uint16_t* out_rgba16f;        // width*height*4

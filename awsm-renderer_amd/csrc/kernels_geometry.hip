@@ -179,6 +179,50 @@ AWSM_DI void bin_emit(const FrameDev& f, int tx, int l, uint32_t rank) {
     }
 }
 
+// One triangle's share of the binning: its tile rectangle in (column, local tile row) space of the shard.
+struct BinTri {
+    TriSetup t;
+    int tx0, tx1, ty0, ty1, wdt, ntiles;
+    bool ok, big, small;
+};
+template <bool SETUP>
+AWSM_DI void bin_tri_load(const FrameDev& f, uint32_t r, BinTri& b) {
+    b.ok = false;
+    if (r < f.total_tris) {
+        if (SETUP) {   // the first phase of the counting pass does the setup once and leaves it for everyone downstream
+            const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
+            const bool cull_back = ((f.tri_info[r] >> 24) & AWSM_DRAW_CULL_BACK) != 0;
+            b.ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, b.t);
+            if (!b.ok) { b.t.minx = 0; b.t.maxx = 0; b.t.miny = 0; b.t.maxy = 0; }
+            tri_rec_store(f.tri_rec + r, b.t, b.ok);
+        } else {
+            b.ok = tri_rec_load(f.tri_rec + r, b.t);
+        }
+    }
+    // a triangle that touches none of the shard's tile rows drops out here
+    b.tx0 = 0; b.tx1 = -1; b.ty0 = 0; b.ty1 = -1;
+    const int bn = (int)f.band_n, row0 = (int)f.tile_row0;
+    if (b.ok) {
+        b.tx0 = b.t.minx >> kTileShift; b.tx1 = b.t.maxx >> kTileShift;
+        const int a0 = (b.t.miny >> kTileShift) - row0, a1 = (b.t.maxy >> kTileShift) - row0;   // row mode: >= 0 (tri_setup clamps to the shard rows)
+        b.ty0 = (a0 + bn - 1) / bn; b.ty1 = a1 >= 0 ? a1 / bn : -1;                               // ceil / floor; a0 > -bn
+        b.ok = b.ty0 <= b.ty1;
+    }
+    b.wdt = b.tx1 - b.tx0 + 1;
+    b.ntiles = b.ok ? b.wdt * (b.ty1 - b.ty0 + 1) : 0;
+    b.big = b.ntiles > 16;
+    b.small = b.ok && !b.big;
+}
+AWSM_DI bool bin_tile_hit(const FrameDev& f, const TriSetup& t, int ntiles, int tx, int l) {
+    const int ty = (int)f.tile_row0 + l * (int)f.band_n;
+    return ntiles == 1 || tile_may_overlap(t, tx << kTileShift, ty << kTileShift, (tx + 1) << kTileShift, (ty + 1) << kTileShift);
+}
+
+// kBinBatches x 256 consecutive triangles per workgroup: the more triangles share one LDS window, the fewer global
+// atomics reach the hot tiles (they serialise in L2).  Later phases re-read the 64-byte setup records (L2 hits) instead
+// of keeping kBinBatches setups in registers.
+constexpr uint32_t kBinBatches = 1;
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     __shared__ int win[4];                       // tile window of the workgroup's small triangles: x0, y0, x1, y1
@@ -187,33 +231,32 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     __shared__ uint32_t lbase[FILL ? kBinWindow : 1];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t r = blockIdx.x * 256u + tid;
+    const uint32_t r0 = blockIdx.x * (256u * kBinBatches) + tid;
+    const int lane = tid & 63;
     if (tid == 0) { win[0] = 0x7fffffff; win[1] = 0x7fffffff; win[2] = -1; win[3] = -1; n_ok = 0; }
-    TriSetup t;
-    bool ok = false;
-    if (r < f.total_tris) {
-        const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
-        const bool cull_back = ((f.tri_info[r] >> 24) & AWSM_DRAW_CULL_BACK) != 0;
-        ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, t);
-    }
-    // tile rectangle in (column, local row) space; a triangle that touches none of the shard's tile rows drops out here
-    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-    const int bn = (int)f.band_n, row0 = (int)f.tile_row0;
-    if (ok) {
-        tx0 = t.minx >> kTileShift; tx1 = t.maxx >> kTileShift;
-        const int a0 = (t.miny >> kTileShift) - row0, a1 = (t.maxy >> kTileShift) - row0;   // >= 0: tri_setup clamps to the shard rows
-        ty0 = (a0 + bn - 1) / bn; ty1 = a1 >= 0 ? a1 / bn : -1;            // ceil / floor; a0 > -bn
-        ok = ty0 <= ty1;
-    }
-    const int wdt = tx1 - tx0 + 1;
-    const int ntiles = ok ? wdt * (ty1 - ty0 + 1) : 0;
-    const bool big = ntiles > 16;
-    const bool small = ok && !big;
     __syncthreads();
-    if (small) { atomicMin(&win[0], tx0); atomicMin(&win[1], ty0); atomicMax(&win[2], tx1); atomicMax(&win[3], ty1); }
+
+    // ---- phase 0: setup (count pass) / load, window of the small triangles, big triangles walked by the wavefront ----
+    uint32_t my_ok = 0;
+    for (uint32_t j = 0; j < kBinBatches; j++) {
+        const uint32_t r = r0 + j * 256u;
+        BinTri b;
+        bin_tri_load<!FILL>(f, r, b);
+        my_ok += b.ok ? 1u : 0u;
+        if (b.small) { atomicMin(&win[0], b.tx0); atomicMin(&win[1], b.ty0); atomicMax(&win[2], b.tx1); atomicMax(&win[3], b.ty1); }
+        if (!FILL) {   // big triangles go to a global list that k_bin_big walks with one wavefront per triangle
+            const unsigned long long mask = __ballot(b.big);
+            if (mask) {
+                uint32_t base = 0;
+                if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&f.counters[4], (uint32_t)__popcll(mask));
+                base = __shfl(base, __ffsll((long long)mask) - 1);
+                if (b.big) f.big_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+            }
+        }
+    }
     if (!FILL) {
-        const unsigned long long okm = __ballot(ok);
-        if ((tid & 63u) == 0u && okm) atomicAdd(&n_ok, (uint32_t)__popcll(okm));
+        for (int off = 32; off > 0; off >>= 1) my_ok += __shfl_down(my_ok, off);
+        if (lane == 0 && my_ok) atomicAdd(&n_ok, my_ok);
     }
     __syncthreads();
     const int wx0 = win[0], wy0 = win[1], ww = win[2] - wx0 + 1, wh = win[3] - wy0 + 1;
@@ -223,56 +266,63 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     if (use_lds) for (uint32_t i = tid; i < nwin; i += 256u) lcount[i] = 0u;
     __syncthreads();
 
-    // ---- small triangles, pass A: histogram (LDS) or direct emission (window too large) ----
-    if (small) {
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++)
-                if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, (row0 + ty * bn) << kTileShift, (tx + 1) << kTileShift, (row0 + ty * bn + 1) << kTileShift)) {
-                    if (use_lds) atomicAdd(&lcount[(ty - wy0) * ww + (tx - wx0)], 1u);
-                    else bin_emit<FILL>(f, tx, ty, r);
-                }
+    // ---- phase A, small triangles: histogram in LDS (or direct emission when the window is too large) ----
+    for (uint32_t j = 0; j < kBinBatches; j++) {
+        const uint32_t r = r0 + j * 256u;
+        BinTri b;
+        bin_tri_load<false>(f, r, b);
+        if (b.small)
+            for (int l = b.ty0; l <= b.ty1; l++)
+                for (int tx = b.tx0; tx <= b.tx1; tx++)
+                    if (bin_tile_hit(f, b.t, b.ntiles, tx, l)) {
+                        if (use_lds) atomicAdd(&lcount[(l - wy0) * ww + (tx - wx0)], 1u);
+                        else bin_emit<FILL>(f, tx, l, r);
+                    }
     }
-    if (use_lds) {
-        __syncthreads();
-        for (uint32_t i = tid; i < nwin; i += 256u) {
-            const uint32_t c = lcount[i];
-            if (c) {
-                const uint32_t gidx = (uint32_t)(wy0 + (int)(i / (uint32_t)ww)) * f.tiles_x + (uint32_t)(wx0 + (int)(i % (uint32_t)ww));
-                if (!FILL) atomicAdd(&f.tile_count[gidx], c);
-                else { lbase[i] = f.tile_offset[gidx] + atomicAdd(&f.tile_cursor[gidx], c); lcount[i] = 0u; }
-            }
-        }
-        if (FILL) {
-            __syncthreads();
-            // ---- pass B: write the ranks into the reserved runs (order inside a tile's list is irrelevant: the raster
-            // kernel resolves visibility with a min over packed keys) ----
-            if (small) {
-                for (int ty = ty0; ty <= ty1; ty++)
-                    for (int tx = tx0; tx <= tx1; tx++)
-                        if (ntiles == 1 || tile_may_overlap(t, tx << kTileShift, (row0 + ty * bn) << kTileShift, (tx + 1) << kTileShift, (row0 + ty * bn + 1) << kTileShift)) {
-                            const uint32_t li = (uint32_t)((ty - wy0) * ww + (tx - wx0));
-                            const uint32_t pos = lbase[li] + atomicAdd(&lcount[li], 1u);
-                            if (pos < f.bin_capacity) f.bin_list[pos] = r;
-                        }
-            }
+    if (!use_lds) return;
+    __syncthreads();
+    for (uint32_t i = tid; i < nwin; i += 256u) {   // one global atomic per distinct tile of the workgroup
+        const uint32_t c = lcount[i];
+        if (c) {
+            const uint32_t gidx = (uint32_t)(wy0 + (int)(i / (uint32_t)ww)) * f.tiles_x + (uint32_t)(wx0 + (int)(i % (uint32_t)ww));
+            if (!FILL) atomicAdd(&f.tile_count[gidx], c);
+            else { lbase[i] = f.tile_offset[gidx] + atomicAdd(&f.tile_cursor[gidx], c); lcount[i] = 0u; }
         }
     }
+    if (!FILL) return;
+    __syncthreads();
+    // ---- phase B: write the ranks into the reserved runs (order inside a tile's list is irrelevant: the raster kernel
+    // resolves visibility with a min over packed keys) ----
+    for (uint32_t j = 0; j < kBinBatches; j++) {
+        const uint32_t r = r0 + j * 256u;
+        BinTri b;
+        bin_tri_load<false>(f, r, b);
+        if (b.small)
+            for (int l = b.ty0; l <= b.ty1; l++)
+                for (int tx = b.tx0; tx <= b.tx1; tx++)
+                    if (bin_tile_hit(f, b.t, b.ntiles, tx, l)) {
+                        const uint32_t li = (uint32_t)((l - wy0) * ww + (tx - wx0));
+                        const uint32_t pos = lbase[li] + atomicAdd(&lcount[li], 1u);
+                        if (pos < f.bin_capacity) f.bin_list[pos] = r;
+                    }
+    }
+}
 
-    // ---- big triangles: the wavefront walks the tile rectangle together ----
-    unsigned long long mask = __ballot(big);
-    const int lane = tid & 63;
-    while (mask) {
-        const int src = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        TriSetup s;
-#pragma unroll
-        for (int i = 0; i < 3; i++) { s.a[i] = __shfl(t.a[i], src); s.b[i] = __shfl(t.b[i], src); s.c[i] = __shfl(t.c[i], src); }
-        const int sx0 = __shfl(tx0, src), sy0 = __shfl(ty0, src), swd = __shfl(wdt, src), sn = __shfl(ntiles, src);
-        const uint32_t sr = __shfl(r, src);
-        for (int i = lane; i < sn; i += 64) {
-            const int ty = sy0 + i / swd, tx = sx0 + i % swd;
-            if (tile_may_overlap(s, tx << kTileShift, (row0 + ty * bn) << kTileShift, (tx + 1) << kTileShift, (row0 + ty * bn + 1) << kTileShift))
-                bin_emit<FILL>(f, tx, ty, sr);
+// k_bin_big<FILL>: the triangles that cover more than 16 tiles (near the camera: few, but each a long walk, and they come
+// in runs — whole workgroups of k_bin were nothing but such triangles and ran 3x longer than the rest of the grid).
+// One wavefront per triangle, 64 tiles per step, grid-stride over the list k_bin<count> built.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin_big(FrameDev f) {
+    const uint32_t n_big = f.counters[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    for (uint32_t i = wave; i < n_big; i += n_waves) {
+        const uint32_t r = f.big_list[i];
+        BinTri b;
+        bin_tri_load<false>(f, r, b);
+        for (int k = lane; k < b.ntiles; k += 64) {
+            const int l = b.ty0 + k / b.wdt, tx = b.tx0 + k % b.wdt;
+            if (bin_tile_hit(f, b.t, b.ntiles, tx, l)) bin_emit<FILL>(f, tx, l, r);
         }
     }
 }
@@ -282,37 +332,60 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
 // fullest tiles and the light ones fill in behind them (longest-processing-time-first; the fullest tile of a frame holds
 // 20-40x the median number of triangles and would otherwise be the tail of the kernel).
 __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t bucket_n[33], bucket_at[33];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t part[1024], part2[1024];
+    __shared__ uint32_t bucket_n[16][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
+    __shared__ uint32_t bucket_at[16][33];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
-    if (tid < 33u) bucket_n[tid] = 0u;
+    for (uint32_t i = tid; i < 16u * 33u; i += 1024u) (&bucket_n[0][0])[i] = 0u;
     __syncthreads();
+    // the first 8 counts of the chunk are loaded together and kept in registers for the second loop (one memory round trip
+    // instead of `per` dependent ones); longer chunks (frames beyond 8192 tiles) fall back to re-reading
+    uint32_t cnt[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++) cnt[j] = (b0 + j < b1) ? f.tile_count[b0 + j] : 0u;
     uint32_t sum = 0;
-    for (uint32_t i = b0; i < b1; i++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++)
+        if (b0 + j < b1) { sum += cnt[j]; atomicAdd(&bucket_n[wave][32 - __clz(cnt[j])], 1u); }   // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
+    for (uint32_t i = b0 + 8u; i < b1; i++) {
         const uint32_t c = f.tile_count[i];
         sum += c;
-        atomicAdd(&bucket_n[32 - __clz(c)], 1u);          // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
+        atomicAdd(&bucket_n[wave][32 - __clz(c)], 1u);
     }
     part[tid] = sum;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t at = 0;
-        for (int k = 32; k >= 0; k--) { bucket_at[k] = at; at += bucket_n[k]; }
-    }
+    // second scan, sharing the barriers of the first: start of every (bucket, wave) run in tile_order, buckets descending,
+    // waves ascending inside a bucket — entry e = (32 - bucket) * 16 + wave
+    const uint32_t e_bucket = 32u - (tid >> 4), e_wave = tid & 15u;
+    const uint32_t e_val = tid < 33u * 16u ? bucket_n[e_wave][e_bucket] : 0u;
+    part2[tid] = e_val;
+    __syncthreads();
     for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+        const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+        const uint32_t v2 = (tid >= off) ? part2[tid - off] : 0u;
         __syncthreads();
         part[tid] += v;
+        part2[tid] += v2;
         __syncthreads();
     }
+    if (tid < 33u * 16u) bucket_at[e_wave][e_bucket] = part2[tid] - e_val;
+    __syncthreads();
     uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's chunk
-    for (uint32_t i = b0; i < b1; i++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++)
+        if (b0 + j < b1) {
+            const uint32_t i = b0 + j, c = cnt[j];
+            f.tile_offset[i] = run; run += c;
+            f.tile_cursor[i] = 0u;
+            f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
+        }
+    for (uint32_t i = b0 + 8u; i < b1; i++) {
         const uint32_t c = f.tile_count[i];
         f.tile_offset[i] = run; run += c;
         f.tile_cursor[i] = 0u;
-        f.tile_order[atomicAdd(&bucket_at[32 - __clz(c)], 1u)] = i;
+        f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
     }
     if (tid == 1023u) {
         const uint32_t total = part[1023];
@@ -370,10 +443,8 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         const uint32_t idx = base + tid;
         if (idx < count) {
             const uint32_t r = f.bin_list[off + idx];
-            const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
             TriSetup t;
-            // culling already happened in k_bin; setup only normalises orientation here
-            if (tri_setup(v0, v1, v2, false, f.width, f.height, f.y0, f.y1, t)) {
+            if (tri_rec_load(f.tri_rec + r, t)) {       // setup done once per frame by k_bin<count>
                 const int x0 = max(t.minx, tpx), x1 = min(t.maxx, tpx + kTile - 1);
                 const int y0 = max(t.miny, tpy), y1 = min(t.maxy, tpy + kTile - 1);
                 if (x0 <= x1 && y0 <= y1) {
@@ -463,14 +534,19 @@ extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::Fram
     if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform, dim3(n_blocks), dim3(256), 0, s, sc, *f);
 }
 extern "C" void awsm_launch_bin_count(const awsm::FrameDev* f, hipStream_t s) {
-    const uint32_t nb = (f->total_tris + 255u) / 256u;
+    const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;
     if (nb) hipLaunchKernelGGL(awsm::k_bin<false>, dim3(nb), dim3(256), 0, s, *f);
+}
+extern "C" void awsm_launch_bin_big(const awsm::FrameDev* f, int fill, hipStream_t s) {
+    if (!f->total_tris) return;
+    if (fill) hipLaunchKernelGGL(awsm::k_bin_big<true>, dim3(512), dim3(256), 0, s, *f);
+    else hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_bin_scan, dim3(1), dim3(1024), 0, s, *f, f->tiles_x * f->tiles_y);
 }
 extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
-    const uint32_t nb = (f->total_tris + 255u) / 256u;
+    const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;
     if (nb) hipLaunchKernelGGL(awsm::k_bin<true>, dim3(nb), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {

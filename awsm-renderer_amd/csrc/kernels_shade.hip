@@ -29,13 +29,11 @@ struct GBufferTexel {
 };
 AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int cx, int cy) {
     GBufferTexel g;
-    const float4 v0 = f.clip[(size_t)rank * 3], v1 = f.clip[(size_t)rank * 3 + 1], v2 = f.clip[(size_t)rank * 3 + 2];
-    // A key in the visibility buffer means the raster kernel's tri_setup accepted this triangle, so only the edge
-    // coefficients are recomputed here (same code, same bits); the clip/bbox rejection tests cannot fail again.
+    // A key in the visibility buffer means the triangle's setup record is valid; its edge coefficients are the bits the
+    // raster kernel used.
     TriSetup t;
-    float X0, Y0, X1, Y1, X2, Y2;
-    g.valid = tri_coefficients(v0, v1, v2, false, f.width, f.height, t, X0, Y0, X1, Y1, X2, Y2);
-    if (!g.valid) return g;
+    tri_rec_load_edges(f.tri_rec + rank, t);
+    g.valid = true;
     float e0, e1, e2;
     tri_edges(t, cx, cy, e0, e1, e2);
     const float esum = (e0 + e1) + e2;

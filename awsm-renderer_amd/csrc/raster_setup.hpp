@@ -83,6 +83,48 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
     return true;
 }
 
+// Per-triangle setup record, written once per frame by the counting pass of the binner and read by the fill pass, the
+// raster kernel and the shade kernel (which would otherwise each redo the setup: ~250 VALU incl. six IEEE divisions).
+// Same bits everywhere by construction.  64 bytes, 16-byte aligned.
+struct alignas(16) TriRec {
+    float a[3], b[3], c[3];
+    float z[3];
+    float det;
+    uint32_t bbox_x;   // minx | maxx << 16   (inclusive, clamped to the target rect)
+    uint32_t bbox_y;   // miny | maxy << 16
+    uint32_t valid;    // 0: the triangle cannot produce a fragment in this shard
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok) {
+    float4* q = reinterpret_cast<float4*>(dst);
+    q[0] = make_float4(t.a[0], t.a[1], t.a[2], t.b[0]);
+    q[1] = make_float4(t.b[1], t.b[2], t.c[0], t.c[1]);
+    q[2] = make_float4(t.c[2], t.z[0], t.z[1], t.z[2]);
+    q[3] = make_float4(t.det, __uint_as_float((uint32_t)t.minx | ((uint32_t)t.maxx << 16)), __uint_as_float((uint32_t)t.miny | ((uint32_t)t.maxy << 16)),
+                       __uint_as_float(ok ? 1u : 0u));
+}
+AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) {
+    const float4* q = reinterpret_cast<const float4*>(src);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    t.a[0] = q0.x; t.a[1] = q0.y; t.a[2] = q0.z; t.b[0] = q0.w;
+    t.b[1] = q1.x; t.b[2] = q1.y; t.c[0] = q1.z; t.c[1] = q1.w;
+    t.c[2] = q2.x; t.z[0] = q2.y; t.z[1] = q2.z; t.z[2] = q2.w;
+    t.det = q3.x;
+    const uint32_t bx = __float_as_uint(q3.y), by = __float_as_uint(q3.z);
+    t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)(bx >> 16); t.miny = (int)(by & 0xFFFFu); t.maxy = (int)(by >> 16);
+    return __float_as_uint(q3.w) != 0u;
+}
+// the edge coefficients only (shade kernel)
+AWSM_DI void tri_rec_load_edges(const TriRec* __restrict__ src, TriSetup& t) {
+    const float4* q = reinterpret_cast<const float4*>(src);
+    const float4 q0 = q[0], q1 = q[1];
+    const float c2 = src->c[2];
+    t.a[0] = q0.x; t.a[1] = q0.y; t.a[2] = q0.z; t.b[0] = q0.w;
+    t.b[1] = q1.x; t.b[2] = q1.y; t.c[0] = q1.z; t.c[1] = q1.w;
+    t.c[2] = c2;
+}
+
 AWSM_DI bool edge_inside(float e, float a, float b) {
     return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));   // top-left rule
 }
