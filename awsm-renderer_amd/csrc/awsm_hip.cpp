@@ -18,6 +18,7 @@ using namespace awsm;
 
 extern "C" {
 void awsm_launch_bin_big(const FrameDev* f, int fill, hipStream_t s);
+void awsm_launch_pick(const DevScene* sc, const FrameDev* f, int x, int y, uint32_t* out, hipStream_t s);
 void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
 void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s);
 void awsm_launch_bin_count(const FrameDev* f, hipStream_t s);
@@ -301,8 +302,8 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE); c->own_stream = true; }
     for (int i = 0; i < EV_COUNT; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(AWSM_ERR_DEVICE);
     if (hipMalloc((void**)&c->scene_dev, sizeof(DevScene)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-    if (hipMalloc(&c->counters.ptr, 8 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-    c->counters.size = 8 * sizeof(uint32_t);
+    if (hipMalloc(&c->counters.ptr, 12 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words
+    c->counters.size = 12 * sizeof(uint32_t);
     if (hipHostMalloc((void**)&c->counters_host, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
     memset(&c->scene, 0, sizeof c->scene);
     // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
@@ -644,6 +645,25 @@ int awsm_hip_read_visibility_unpacked(AwsmHipCtx* c, uint32_t* tri_id, uint32_t*
         if (meta_off) meta_off[i] = meta[lo];
         if (depth) { uint32_t b = (uint32_t)(keys[i] >> 32); memcpy(&depth[i], &b, 4); }
     }
+    return AWSM_OK;
+}
+
+int awsm_hip_pick(AwsmHipCtx* c, int32_t x, int32_t y, AwsmPick* out) {
+    if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "pick before geometry_pass");
+    if (!c->bufs[AWSM_BUF_MATERIAL_META].ptr || !c->bufs[AWSM_BUF_GEOM_META].ptr) return fail(c, AWSM_ERR_NOT_READY, "pick: meta buffers missing");
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameDev f;
+    fill_frame(c, &f);
+    int rc = sync_scene(c);
+    if (rc) return rc;
+    uint32_t* dev_out = (uint32_t*)c->counters.ptr + 8;          // 4 words after the frame counters
+    awsm_launch_pick(c->scene_dev, &f, x, y, dev_out, c->stream);
+    HIPCHK(c, hipGetLastError());
+    uint32_t host_out[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(host_out, dev_out, sizeof host_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->valid = host_out[0]; out->mesh_key_high = host_out[1]; out->mesh_key_low = host_out[2]; out->triangle_index = host_out[3];
     return AWSM_OK;
 }
 

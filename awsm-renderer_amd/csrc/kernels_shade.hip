@@ -743,6 +743,20 @@ __global__ __launch_bounds__(256) void k_count_covered(const unsigned long long*
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
 }
 
+// picker_wgsl/compute.wgsl: one thread; out = {valid, mesh_key_high, mesh_key_low, triangle_index}
+__global__ void k_pick(const DevScene* __restrict__ sc, FrameDev f, int x, int y, uint32_t* __restrict__ out) {
+    out[0] = 0u; out[1] = 0u; out[2] = 0u; out[3] = 0xFFFFFFFFu;
+    if (x < 0 || y < 0 || x >= (int)f.width || y < (int)f.y0 || y >= (int)f.y1) return;
+    if (f.band_n > 1u && (((uint32_t)y >> kTileShift) % f.band_n) != f.band_r) return;
+    const unsigned long long key = f.vis[(size_t)y * f.width + (size_t)x];
+    if (key == ~0ull) return;
+    const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    const DrawDev dr = f.draws[f.tri_info[rank] & 0x00FFFFFFu];
+    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
+    const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
+    out[0] = 1u; out[1] = mm[0]; out[2] = mm[1]; out[3] = rank - dr.first_tri;
+}
+
 // helper kernels for readback / upload conversions
 __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -759,6 +773,9 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
     if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->band_n, f->band_r, f->counters + 3);
+}
+extern "C" void awsm_launch_pick(const awsm::DevScene* sc, const awsm::FrameDev* f, int x, int y, uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_pick, dim3(1), dim3(1), 0, s, sc, *f, x, y, out);
 }
 extern "C" void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_brdf_lut, dim3((w + 15u) / 16u, (h + 15u) / 16u), dim3(256), 0, s, out_rg16f, w, h);

@@ -22,7 +22,7 @@ BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", 
 
 # every symbol include/awsm_hip.h declares (tests/test_abi_symbols.py checks the header against this list too)
 EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
-           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_texture_array_upload", "awsm_hip_sampler_set",
+           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_pick", "awsm_hip_texture_array_upload", "awsm_hip_sampler_set",
            "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
@@ -94,6 +94,7 @@ def load_library():
     lib.awsm_hip_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.awsm_hip_set_shard_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.awsm_hip_set_shard_bands.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.awsm_hip_pick.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.awsm_hip_texture_array_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     lib.awsm_hip_sampler_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.awsm_hip_env_upload.argtypes = [C.c_void_p, C.c_void_p]
@@ -171,6 +172,12 @@ class HipDevice:
 
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_hip_set_shard_rows(self.ctx, y0, y1), "set_shard_rows")
+
+    def pick(self, x: int, y: int):
+        """picker.rs:55-121 -> (mesh_key u64, primitive-local triangle index) or None for background / outside the frame."""
+        out = (C.c_uint32 * 4)()
+        self._chk(self.lib.awsm_hip_pick(self.ctx, x, y, out), "pick")
+        return ((out[1] << 32) | out[2], out[3]) if out[0] else None
 
     def set_shard_bands(self, n: int, r: int, compact_output: bool = False):
         self._chk(self.lib.awsm_hip_set_shard_bands(self.ctx, n, r, 1 if compact_output else 0), "set_shard_bands")

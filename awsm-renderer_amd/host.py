@@ -83,7 +83,8 @@ def load_library():
         "awsm_host_set_ibl_mip_counts": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_camera_update": (C.c_int, [vp, F32P, F32P, F32P]), "awsm_host_env": (C.c_int, [vp, vp]),
         "awsm_host_brdf_lut_generate": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_resize": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
-        "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
+        "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
         "awsm_host_texture_array_info": (C.c_int, [vp, C.c_uint32, U32P, U32P, U32P, C.POINTER(vp)]),
@@ -281,6 +282,12 @@ class Host:
 
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_host_set_shard_rows(self.h, y0, y1), "set_shard_rows")
+
+    def pick(self, x: int, y: int):
+        """AwsmRenderer::pick: the MeshKey under pixel (x, y) of the last rendered frame, or None (PickResult::Miss)."""
+        hit, key = C.c_uint32(0), C.c_uint64(0)
+        self._chk(self.lib.awsm_host_pick(self.h, x, y, C.byref(hit), C.byref(key)), "pick")
+        return key.value if hit.value else None
 
     def set_shard_bands(self, n: int, r: int, compact_output: bool = False):
         self._chk(self.lib.awsm_host_set_shard_bands(self.h, n, r, 1 if compact_output else 0), "set_shard_bands")

@@ -212,6 +212,17 @@ int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
 int awsm_hip_read_visibility_unpacked(AwsmHipCtx* ctx, uint32_t* tri_id_out, uint32_t* meta_off_out, float* depth_out);
 int awsm_hip_read_opaque(AwsmHipCtx* ctx, uint16_t* rgba16f_out);
 int awsm_hip_read_opaque_f32(AwsmHipCtx* ctx, float* rgba32f_out);  /* needs AWSM_CFG_PARITY_TAP */
+/* ---- picking (crates/renderer/src/picker.rs:55-121 + picker/shader/picker_wgsl/compute.wgsl): the mesh under pixel
+ * (x, y) of the last geometry pass, read from the visibility buffer: key -> draw -> geometry meta -> material mesh meta
+ * -> mesh key words.  valid = 0 for background and for coordinates outside the frame (or outside this shard).
+ * triangle_index is the primitive-local triangle (the visibility texel's first component).  Synchronous. ---- */
+typedef struct AwsmPick {
+    uint32_t valid;
+    uint32_t mesh_key_high, mesh_key_low;   /* slotmap KeyData::as_ffi >> 32, & 0xFFFFFFFF */
+    uint32_t triangle_index;
+} AwsmPick;
+int awsm_hip_pick(AwsmHipCtx* ctx, int32_t x, int32_t y, AwsmPick* out);
+
 /* transformed vertices of the last geometry pass: per exploded vertex clip xyzw (16 B) and
  * {world N xyz, pad, world T xyzw} (32 B) == vert_main outputs (geometry_wgsl/vertex.wgsl:36-63). */
 int awsm_hip_read_transformed(AwsmHipCtx* ctx, float* clip_out, float* normal_tangent_out, uint32_t max_vertices);

@@ -122,6 +122,8 @@ int awsm_host_env(AwsmHost* h, const AwsmEnv* env);
 int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t height);
 int awsm_host_resize(AwsmHost* h, uint32_t width, uint32_t height);
 int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1);
+/* AwsmRenderer::pick (picker.rs:55-121): *hit = 1 and *mesh_key = the MeshKey (KeyData::as_ffi) under pixel (x, y) of the last frame, else *hit = 0 */
+int awsm_host_pick(AwsmHost* h, int32_t x, int32_t y, uint32_t* hit, uint64_t* mesh_key);
 int awsm_host_set_shard_bands(AwsmHost* h, uint32_t n, uint32_t r, uint32_t compact_output);   /* awsm_hip_set_shard_bands */
 
 /* ---- frame: update_all (update.rs:8-18) + AwsmRenderer::render (render.rs:53-383, hot path only) ---- */

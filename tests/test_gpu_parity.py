@@ -162,3 +162,45 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["check"] == "ok" and out["n_gpus"] == 2 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_picker_matches_visibility_buffer(oracle_lut):
+    """awsm_hip_pick / awsm_host_pick (picker.rs:55-121, picker_wgsl/compute.wgsl): the mesh key under a pixel is the one
+    the oracle's visibility buffer attributes to it; background, out-of-frame and other-shard pixels miss."""
+    from oracle.host_mirror import key_as_ffi
+    sc = scenes.atrium_scene(640, 360, detail=0.125, tex_scale=1 / 32)
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut)
+    draws = model.collect_draws()
+    first = np.concatenate([[0], np.cumsum([d["tri_count"] for d in draws])])
+    r, dev, _ = helpers.host_frame(sc, oracle_lut)
+    rng = np.random.default_rng(7)
+    pts = [(int(x), int(y)) for x, y in zip(rng.integers(0, sc.width, 40), rng.integers(0, sc.height, 40))] + [(0, 0), (sc.width - 1, sc.height - 1)]
+    hits = 0
+    for x, y in pts:
+        key = orc.keys[y, x]
+        got_dev, got_host = dev.pick(x, y), r.host.pick(x, y)
+        if key == helpers.NO_HIT:
+            assert got_dev is None and got_host is None
+            continue
+        rank = 0xFFFFFFFF - int(key & np.uint64(0xFFFFFFFF))
+        d = int(np.searchsorted(first, rank, side="right") - 1)
+        want_key = key_as_ffi(draws[d]["mesh_key"])
+        assert got_dev == (want_key, rank - int(first[d])), (x, y)
+        assert got_host == want_key and want_key in r.keys.mesh_keys
+        hits += 1
+    assert hits > 20
+    for x, y in [(-1, 5), (5, -1), (sc.width, 5), (5, sc.height), (2 ** 31 - 1, 0)]:
+        assert dev.pick(x, y) is None and r.host.pick(x, y) is None
+    # a pixel of another shard misses; one of this shard still hits
+    dev.set_shard_bands(2, 1)
+    dev.geometry_pass(HipDeviceDraws(model)); dev.opaque_pass(); dev.frame_end()
+    ys = [y for y in range(sc.height) if (y // 32) % 2 == 0 and orc.keys[y, 100] != helpers.NO_HIT]
+    yo = [y for y in range(sc.height) if (y // 32) % 2 == 1 and orc.keys[y, 100] != helpers.NO_HIT]
+    assert dev.pick(100, ys[0]) is None and dev.pick(100, yo[0]) is not None
+    r.close()
+
+
+def HipDeviceDraws(model):
+    return model.collect_draws()

@@ -15,7 +15,7 @@ from tests import helpers
 
 MOCK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock")
 MOCK = os.path.join(MOCK_DIR, "libmock_backend.so")
-OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard"}
+OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick"}
 
 
 @pytest.fixture(scope="module")
@@ -206,3 +206,15 @@ def test_missing_backend_fails_loudly(tmp_path):
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(bogus), str(src)])
     with pytest.raises(H.HostError):
         H.Host(backend_path=str(bogus))          # library loads but lacks the awsm_hip_* symbols
+
+
+def test_pick_and_band_sharding_pass_through(mock):
+    """awsm_host_pick / awsm_host_set_shard_bands reach the backend with their arguments; a miss is None (PickResult::Miss)."""
+    r = H.Renderer(scenes.box_scene(64, 64), backend_path=MOCK, lut_rgba16f=np.zeros((4, 4, 4), dtype=np.uint16))
+    r.render()
+    mock.mock_log_clear(r.host.device_ctx)
+    assert r.host.pick(12, 34) is None
+    r.host.set_shard_bands(4, 3, compact_output=True)
+    log = log_of(mock, r.host.device_ctx)
+    assert ("pick", 0, 12, 34) in log and ("shard_bands", 1, 4, 3) in log
+    r.close()
