@@ -108,9 +108,6 @@ AWSM_DI TexInfo tex_load(const uint32_t* __restrict__ m, uint32_t i) {      // t
     t.array_index = array_and_layer & 0xFFFu; t.layer_index = array_and_layer >> 12;
     t.uv_set_index = uv_and_sampler & 0xFFu; t.sampler_index = uv_and_sampler >> 8;
     t.exists = (extra & 1u) != 0u;
-#ifdef AWSM_EXP_NOTEX
-    t.exists = false;
-#endif
     t.uv_transform_index = transform_offset / 32u;
     return t;
 }
@@ -570,11 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
     }
     const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
-#ifdef AWSM_EXP_NOLIGHTS
-    const uint32_t n_lights = 0;
-#else
     const uint32_t n_lights = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]);
-#endif
 
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
     const uint32_t shader_id = M[material_word];
@@ -678,11 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         store_pixel(f, p, {dc.x, dc.y, dc.z, 1.0f});
         return;
     }
-#ifdef AWSM_EXP_NOSHADE
-    const f3 color = c.base + c.normal * c.mr.x + c.emissive * c.occlusion + surface_to_camera + world_position;
-#else
     const f3 color = apply_lighting(sc, c, surface_to_camera, world_position, n_lights);
-#endif
     store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
 }
 #pragma clang fp contract(off)
