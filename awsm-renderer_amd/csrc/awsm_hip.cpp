@@ -522,7 +522,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = dev_reserve(c, c->tile_offset, (n_tiles_full + 1) * 4))) return rc;
     if ((rc = dev_reserve(c, c->tile_cursor, n_tiles_full * 4))) return rc;
     if ((rc = dev_reserve(c, c->tile_order, n_tiles_full * 4))) return rc;
-    if ((rc = ensure_bin_capacity(c, std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
+    if ((rc = ensure_bin_capacity(c, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
     // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
     // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
     const bool same_draws = c->draws_uploaded_valid && c->draws_uploaded_ptr == c->draws_dev.ptr &&

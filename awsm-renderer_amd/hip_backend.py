@@ -15,6 +15,7 @@ from . import PACKAGE_DIR
 LIB_PATH = os.environ.get("AWSM_HIP_LIB") or os.path.join(PACKAGE_DIR, "libawsm_hip.so")   # AWSM_HIP_LIB: A/B builds of the same ABI
 BUF_COUNT = 18
 AWSM_CFG_PARITY_TAP = 1
+AWSM_CFG_SMALL_BIN_LIST = 2
 
 BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", "CAMERA", "SKIN_MATRICES", "SKIN_INDEX_WEIGHTS",
              "MORPH_WEIGHTS", "MORPH_VALUES", "GEOM_META", "MATERIAL_META", "VIS_GEOM_DATA", "VIS_GEOM_INDEX", "ATTR_DATA", "ATTR_INDEX",
@@ -114,9 +115,10 @@ def load_library():
 class HipDevice:
     """One AwsmHipCtx: one HIP device + stream."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False, small_bin_list: bool = False):
         self.lib = load_library()
-        cfg = AwsmConfig(C.sizeof(AwsmConfig), self.lib.awsm_hip_abi_version(), device, AWSM_CFG_PARITY_TAP if parity_tap else 0, stream)
+        flags = (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0)
+        cfg = AwsmConfig(C.sizeof(AwsmConfig), self.lib.awsm_hip_abi_version(), device, flags, stream)
         ctx = C.c_void_p()
         rc = self.lib.awsm_hip_create(C.byref(cfg), C.byref(ctx))
         if rc != 0:

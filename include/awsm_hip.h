@@ -77,6 +77,8 @@ typedef struct AwsmConfig {
     void*    stream;        /* hipStream_t to run on; NULL = the library creates its own */
 } AwsmConfig;
 #define AWSM_CFG_PARITY_TAP 1u   /* also keep the shaded RGBA in f32 (readable via awsm_hip_read_opaque_f32) */
+#define AWSM_CFG_SMALL_BIN_LIST 2u /* start with a 4096-entry (triangle, tile) list instead of sizing it from the triangle count:
+                                     exercises the overflow -> grow -> replay path of awsm_hip_frame_end (tests) */
 
 /* One geometry-pass draw == Mesh::push_geometry_pass_commands (crates/renderer/src/meshes/mesh.rs:70-126):
  * set_bind_group(2, meta, [geom_meta_off]); set_vertex_buffer(0, vis_data, vis_data_off);

@@ -204,3 +204,46 @@ def test_picker_matches_visibility_buffer(oracle_lut):
 
 def HipDeviceDraws(model):
     return model.collect_draws()
+
+
+@pytest.mark.gpu
+def test_bin_list_overflow_grows_and_replays(oracle_lut):
+    """A (triangle, tile) list that is too small (AWSM_CFG_SMALL_BIN_LIST: 4096 entries) overflows in the counting pass;
+    frame_end grows it to the measured need and replays the frame — the result is the same frame."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    sc = scenes.atrium_scene(640, 360, detail=0.25, tex_scale=1 / 32)
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut)
+    dev, stats = helpers.hip_frame(model, oracle_lut, dev=HipDevice(parity_tap=True, small_bin_list=True))
+    assert stats["bin_entries"] > 4096 and stats["bin_overflow_retries"] >= 1, stats
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and stats["covered_pixels"] == r["covered"], (r, stats)
+    # the list keeps its new size: the next frame needs no replay
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); st2 = dev.frame_end()
+    assert st2["bin_overflow_retries"] == stats["bin_overflow_retries"] and (dev.read_visibility() == orc.keys).all()
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_full_size_4k_frame_properties(oracle_lut):
+    """BASELINE configs[3] at its full size (3840x2160, 262,144 triangles): the oracle checks a 64-row strip (it needs
+    ~10 s per full frame on these cores); the rest of the frame is covered by size-independent properties — a re-render is
+    bit-identical, band shards reproduce the unsharded rows exactly, the covered-pixel count matches the visibility buffer."""
+    sc = scenes.atrium_scene(3840, 2160)
+    model = helpers.build_model(sc)
+    dev, stats = helpers.hip_frame(model, oracle_lut)
+    keys, img = dev.read_visibility(), dev.read_opaque()
+    assert stats["covered_pixels"] == int((keys != helpers.NO_HIT).sum()) > 8_000_000
+    rows = (1040, 1104)                                             # through the dense middle of the frame
+    orc = helpers.oracle_frame(model, oracle_lut, rows=rows, threads=16)
+    r = helpers.compare_frames(orc, dev, rows=rows, rgb_tol=RGB_TOL)
+    assert r["clip_mismatch"] == 0 and r["nt_mismatch"] == 0 and r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["f16_max_ulp"] <= 2, r
+    draws = model.collect_draws()
+    dev.geometry_pass(draws); dev.opaque_pass(); dev.frame_end()
+    assert (dev.read_visibility() == keys).all() and (dev.read_opaque() == img).all()           # deterministic
+    from awsm_renderer_amd import sharding
+    dev.set_shard_bands(4, 2)
+    dev.geometry_pass(draws); dev.opaque_pass(); dev.frame_end()
+    mine = np.array(sharding.band_rows(sc.height, 4, 2))
+    assert (dev.read_visibility()[mine] == keys[mine]).all() and (dev.read_opaque()[mine] == img[mine]).all()
+    dev.close()
