@@ -60,6 +60,8 @@ struct AwsmHipCtx {
     uint32_t width = 0, height = 0;
     uint32_t y0 = 0, y1 = 0;     // shard rows (0,0 = full)
     uint32_t band_n = 1, band_r = 0, band_compact = 0;   // shard bands (awsm_hip_set_shard_bands)
+    uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
+    DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
     DevBuf vis, out16, out32;
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
@@ -211,6 +213,9 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->big_list = (uint32_t*)c->big_list.ptr;
     f->counters = (uint32_t*)c->counters.ptr;
     f->vis = (unsigned long long*)c->vis.ptr;
+    f->msaa = c->msaa;
+    f->msaa_color0 = (float4*)c->msaa_color0.ptr;
+    f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? c->bound_out : c->out16.ptr);
     f->out_rgba32f = (float*)c->out32.ptr;
 }
@@ -320,7 +325,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->vis); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_rec); fr(c->tri_flags);
+    fr(c->lut); fr(c->vis); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_rec); fr(c->tri_flags);
     fr(c->draws_dev); fr(c->draw_shade); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->big_list); fr(c->counters);
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
@@ -370,12 +375,15 @@ int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf which, size_t dst_off, const vo
 
 int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msaa) {
     if (!c || width == 0 || height == 0 || width > 16384 || height > 16384) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "resize: bad size %ux%u", width, height);
-    if (msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "resize: MSAA x%u is not implemented (single-sample only; SURVEY §8f)", msaa);
+    if (msaa == 1) msaa = 0;
+    if (msaa != 0 && msaa != 4) return fail(c, AWSM_ERR_UNSUPPORTED, "resize: MSAA x%u (the reference supports None or 4, anti_alias.rs:28-38)", msaa);
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t px = (size_t)width * height;
+    const size_t px = (size_t)width * height, samples = msaa == 4 ? 4 : 1;
     int rc;
-    if ((rc = dev_realloc(c, c->vis, px * 8, false))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->vis.ptr, 0xFF, px * 8, c->stream));
+    if ((rc = dev_realloc(c, c->vis, px * samples * 8, false))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->vis.ptr, 0xFF, px * samples * 8, c->stream));
+    if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
+    c->msaa = msaa;
     if ((rc = dev_realloc(c, c->out16, px * 8, true))) return rc;
     if (c->flags & AWSM_CFG_PARITY_TAP) { if ((rc = dev_realloc(c, c->out32, px * 16, true))) return rc; }
     c->width = width; c->height = height;
@@ -389,6 +397,7 @@ int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t com
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_bands before resize");
     if (n == 0 || r >= n) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_bands: need r < n (got n=%u r=%u)", n, r);
+    if (n > 1 && c->msaa) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_bands: the MSAA edge detector reads neighbouring pixels across shard borders (needs a halo; SURVEY §8e)");
     c->y0 = c->y1 = 0;                                   // bands and row ranges are alternatives
     c->band_n = n; c->band_r = n > 1 ? r : 0; c->band_compact = (n > 1 && compact_output) ? 1u : 0u;
     return AWSM_OK;
@@ -400,6 +409,7 @@ int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) {
     c->band_n = 1; c->band_r = 0; c->band_compact = 0;   // bands and row ranges are alternatives
     if (y0 == 0 && y1 == 0) { c->y0 = c->y1 = 0; return AWSM_OK; }
     if (y0 >= y1 || y1 > c->height) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need y0 < y1 <= height (got %u,%u)", y0, y1);
+    if (c->msaa && !(y0 == 0 && y1 == c->height)) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_rows: the MSAA edge detector reads neighbouring pixels across shard borders (needs a halo; SURVEY §8e)");
     c->y0 = y0; c->y1 = y1;
     return AWSM_OK;
 }
@@ -617,14 +627,14 @@ int awsm_hip_read_visibility(AwsmHipCtx* c, uint64_t* keys_out) {
     if (!c->vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(keys_out, c->vis.ptr, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(keys_out, c->vis.ptr, (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1) * 8, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
 
 int awsm_hip_read_visibility_unpacked(AwsmHipCtx* c, uint32_t* tri_id, uint32_t* meta_off, float* depth) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
-    const size_t n = (size_t)c->width * c->height;
+    const size_t n = (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1);
     std::vector<uint64_t> keys(n);
     int rc = awsm_hip_read_visibility(c, keys.data());
     if (rc) return rc;

@@ -68,6 +68,7 @@ struct FrameDev {
     uint32_t total_verts;
     uint32_t bin_capacity;        // entries in the (triangle,tile) list
     uint32_t has_opaque;
+    uint32_t msaa;                // 0: one sample per pixel (pixel centre); 4: vis holds [pixel][4 samples]
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
     // transformed vertices (k_deform_transform outputs)
@@ -88,6 +89,8 @@ struct FrameDev {
     unsigned long long* vis;      // width*height packed keys
     uint16_t* out_rgba16f;        // width*height*4
     float* out_rgba32f;           // optional parity tap (may be null)
+    float4* msaa_color0;          // MSAA: width*height, f32 colour of sample 0 for the pixels in msaa_edges
+    uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
 };
 
 }  // namespace awsm

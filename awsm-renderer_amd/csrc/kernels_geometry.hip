@@ -419,8 +419,25 @@ AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
     t.det = g.det;
 }
 
+// One pixel of the tile against one triangle: S = 1 samples the pixel centre, S = 4 the four standard MSAA positions
+// (per-sample coverage and per-sample depth, as the multisampled visibility / depth targets of the reference receive them).
+template <int S>
+AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int px, int py, uint32_t r) {
+    if (S == 1) {
+        const unsigned long long k = tri_sample_key(t, tpx + px, tpy + py, r);
+        if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
+    } else {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const unsigned long long k = tri_sample_key_at(t, (float)(tpx + px) + msaa4_x(s), (float)(tpy + py) + msaa4_y(s), r);
+            if (k != ~0ull) atomicMin(&keys[(py * kTile + px) * S + s], k);
+        }
+    }
+}
+
+template <int S>
 __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
-    __shared__ unsigned long long keys[kTile * kTile];
+    __shared__ unsigned long long keys[kTile * kTile * S];   // 8 KB, or 32 KB with 4 samples per pixel: [pixel][sample]
     __shared__ WorkTri work[256];      // mid triangles from the front, big triangles from the back
     __shared__ uint32_t n_mid, n_big;
 
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     const int tpy = (int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift;
 
 #pragma unroll
-    for (int i = 0; i < 4; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
+    for (int i = 0; i < 4 * S; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
     const uint32_t off = f.tile_offset[tile];
     const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, off));
     const int lane = tid & 63, wave = tid >> 6;
@@ -451,10 +468,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
                     if (area <= 4) {
                         for (int py = y0; py <= y1; py++)
-                            for (int px = x0; px <= x1; px++) {
-                                const unsigned long long k = tri_sample_key(t, px, py, r);
-                                if (k != ~0ull) atomicMin(&keys[(py - tpy) * kTile + (px - tpx)], k);
-                            }
+                            for (int px = x0; px <= x1; px++) raster_pixel<S>(keys, t, tpx, tpy, px - tpx, py - tpy, r);
                     } else {
                         const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : 255u - atomicAdd(&n_big, 1u);
                         WorkTri& g = work[slot];
@@ -480,10 +494,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                 for (int by = y0 & ~3; by <= y1; by += 4)
                     for (int bx = x0 & ~3; bx <= x1; bx += 4) {
                         const int px = bx + lx, py = by + ly;
-                        if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
-                            const unsigned long long k = tri_sample_key(t, tpx + px, tpy + py, r);
-                            if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
-                        }
+                        if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
                     }
             }
         }
@@ -497,21 +508,20 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
             for (int by = y0 & ~7; by <= y1; by += 8)
                 for (int bx = x0 & ~7; bx <= x1; bx += 8) {
                     const int px = bx + lx, py = by + ly;
-                    if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
-                        const unsigned long long k = tri_sample_key(t, tpx + px, tpy + py, r);
-                        if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
-                    }
+                    if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
                 }
         }
         __syncthreads();
     }
     __syncthreads();
-    // tile -> HBM, once, row-major image: each wavefront writes two 32-pixel rows per step (256 B runs)
+    // tile -> HBM, once, row-major image with the samples of a pixel adjacent: each wavefront writes 256 B (S = 1: two
+    // 32-pixel rows) or 512 B runs per step
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int p = (int)tid + i * 256;
+    for (int i = 0; i < 4 * S; i++) {
+        const int e = (int)tid + i * 256;
+        const int p = e / S, s = e % S;
         const int px = tpx + (p & (kTile - 1)), py = tpy + (p >> kTileShift);
-        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) f.vis[(size_t)py * f.width + px] = keys[p];
+        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) f.vis[((size_t)py * f.width + px) * S + s] = keys[e];
     }
 }
 
@@ -552,5 +562,7 @@ extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
 extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     const uint32_t nb = n_tiles;
-    if (nb) hipLaunchKernelGGL(awsm::k_raster_tile, dim3(nb), dim3(256), 0, s, *f);
+    if (!nb) return;
+    if (f->msaa == 4u) hipLaunchKernelGGL(awsm::k_raster_tile<4>, dim3(nb), dim3(256), 0, s, *f);
+    else hipLaunchKernelGGL(awsm::k_raster_tile<1>, dim3(nb), dim3(256), 0, s, *f);
 }

@@ -25,15 +25,15 @@ namespace awsm {
 struct GBufferTexel {
     f4 packed_nt;    // RGBA16F normal_tangent, already rounded to f16
     float bx, by;    // RG16F barycentric, already rounded to f16
-    bool valid;
 };
+// The interpolants are evaluated at the PIXEL CENTRE (@interpolate(perspective, center)); with MSAA the centre may lie
+// outside the triangle and the values extrapolate — every sample the triangle covers in the pixel gets the same texel.
+// A key in the visibility buffer means the triangle's setup record is valid; its edge coefficients are the bits the
+// raster kernel used.
 AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int cx, int cy) {
     GBufferTexel g;
-    // A key in the visibility buffer means the triangle's setup record is valid; its edge coefficients are the bits the
-    // raster kernel used.
     TriSetup t;
     tri_rec_load_edges(f.tri_rec + rank, t);
-    g.valid = true;
     float e0, e1, e2;
     tri_edges(t, cx, cy, e0, e1, e2);
     const float esum = (e0 + e1) + e2;
@@ -48,6 +48,28 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
     g.bx = round_f16(b0);
     g.by = round_f16(b1);
     return g;
+}
+
+// ---- MSAA edge predicates (helpers/msaa.wgsl), STRICT: a decision that flips between implementations would swap a
+// pixel between one-sample and four-sample shading, so every value feeding a threshold follows the arithmetic contract ----
+constexpr float kEdgeNormalThreshold = 0.95f, kEdgeDepthThreshold = 0.02f, kEdgeMsaaDepthThreshold = 0.02f;
+AWSM_DI float view_space_depth(const m4& inv_proj, float depth, float px, float py, float W, float H) {   // msaa.wgsl:185-199
+    const f4 view_pos = mul(inv_proj, mk4((px / W) * 2.0f - 1.0f, 1.0f - (py / H) * 2.0f, depth, 1.0f));
+    return view_pos.z / view_pos.w;
+}
+AWSM_DI float key_depth(unsigned long long k) { return k == ~0ull ? 1.0f : __uint_as_float((uint32_t)(k >> 32)); }   // depth clear = 1.0
+AWSM_DI uint32_t key_rank(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull); }
+AWSM_DI bool edge_mask_depth_msaa(const m4& inv_proj, const unsigned long long k4[4], float pcx, float pcy, float W, float H) {   // msaa.wgsl:116-146
+    uint32_t count = 0; float dmin = 1e9f, dmax = -1e9f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (k4[s] == ~0ull) continue;
+        count++;
+        const float vd = view_space_depth(inv_proj, key_depth(k4[s]), pcx, pcy, W, H);
+        dmin = fminf(dmin, vd); dmax = fmaxf(dmax, vd);
+    }
+    if (count < 2u) return false;
+    return fabsf(dmax - dmin) > (kEdgeMsaaDepthThreshold * fabsf((dmax + dmin) * 0.5f));
 }
 
 // ================================================================================================
@@ -498,43 +520,23 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers 16x4 here).
+// shade_surface: the shading of one visibility sample — compute.wgsl:171-299 for the main sample,
+// material_shading.wgsl:69-168 (msaa_process_sample) for the samples of an edge pixel.  `g` is the G-buffer texel of
+// (triangle `rank`, pixel), `depth_sample` the depth the standard coordinates are built from (always sample 0's,
+// standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug view, 2 hud mesh (only reported when check_hud).
 // ------------------------------------------------------------------------------------------------
-// 5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 starts to spill.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
-    // block rows of 16 pixels: consecutive rows of the shard (row mode), or the two halves of each owned 32-row band (band mode)
-    const uint32_t bx_n = (f.width + 15u) >> 4;
-    const uint32_t by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.y1 - f.y0) + 15u) >> 4;
-    const uint32_t nblk = bx_n * by_n;
-    // Workgroup ids are dealt round-robin over the 8 XCDs (blockIdx & 7), each with its own L2.  XCD x shades the block rows
-    // x, x+8, x+16, ...: coherent along a row (neighbouring blocks share triangles and texels in that L2) and balanced over
-    // the screen (expensive regions — minified textures far away — are spread over all XCDs).
-    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;     // k-th block of this XCD
-    const uint32_t rows_x = (by_n + 7u - xcd) >> 3;                 // block rows owned by this XCD
-    const uint32_t blk = (k < rows_x * bx_n) ? ((k / bx_n) * 8u + xcd) * bx_n + (k % bx_n) : nblk;
-    if (blk >= nblk) return;
-    const uint32_t brow = blk / bx_n;
-    const int cx = (int)((blk % bx_n) << 4) + (int)(threadIdx.x & 15u);
-    const int cy = (f.band_n > 1u ? (int)(((f.tile_row0 + (brow >> 1) * f.band_n) << kTileShift) + ((brow & 1u) << 4)) : (int)f.y0 + (int)(brow << 4)) + (int)(threadIdx.x >> 4);
-    if (cx >= (int)f.width || cy >= (int)f.y1) return;                   // compute.wgsl:111-113
-    const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
-    const size_t p = f.out_compact ? (size_t)(((brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
-    const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};   // skybox.wgsl:1-41, uniform cube
-
-    const unsigned long long key = f.vis[pv];
-    if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, sky); return; }   // compute.wgsl:149-153 / empty.wgsl
-
-    const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
-    const float depth_sample = __uint_as_float((uint32_t)(key >> 32));
+struct SurfaceOut { f4 color; uint32_t kind; };
+AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev& f, uint32_t rank, int cx, int cy, float depth_sample,
+                                 const GBufferTexel& g, bool check_hud) {
+    SurfaceOut out;
+    out.color = {0.0f, 0.0f, 0.0f, 0.0f};
+    out.kind = 0u;
     const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
     const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, is_hud
     const uint32_t triangle_index = rank - ds0.x;
-    if (ds1.z == 1u) { store_pixel(f, p, {0.0f, 0.0f, 0.0f, 0.0f}); return; }   // is_hud (compute.wgsl:176-179): stays cleared
+    if (check_hud && ds1.z == 1u) { out.kind = 2u; return out; }   // is_hud (compute.wgsl:176-179); msaa_process_sample has no such test
     const uint32_t material_word = ds0.y;
     const uint32_t attr_indices_off = ds0.z, attr_data_off = ds0.w, stride = ds1.x, uv_sets_index = ds1.y;
-
-    const GBufferTexel g = reconstruct_gbuffer(f, rank, cx, cy);
-    if (!g.valid) { store_pixel(f, p, sky); return; }
 
     // ---- compute.wgsl:182-211 ----
     Attr a;
@@ -578,8 +580,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         f3 em = {mf(M, b + 16), mf(M, b + 17), mf(M, b + 18)};
         if (base_tex.exists) { const f4 s = sample_tex(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
         if (em_tex.exists) { const f4 s = sample_tex(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
-        store_pixel(f, p, {base.x + em.x, base.y + em.y, base.z + em.z, 1.0f});
-        return;
+        out.color = {base.x + em.x, base.y + em.y, base.z + em.z, 1.0f};
+        return out;
     }
 
     // ---- pbr_material.wgsl:110-216 + material_color_calc.wgsl:25-265 ----
@@ -668,11 +670,212 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         else if (debug_bitmask & 8u) dc = splat3(c.occlusion);
         else if (debug_bitmask & 16u) dc = c.emissive;
         else if (debug_bitmask & 32u) dc = c.specular_color * c.specular;
-        store_pixel(f, p, {dc.x, dc.y, dc.z, 1.0f});
-        return;
+        out.color = {dc.x, dc.y, dc.z, 1.0f};
+        out.kind = 1u;
+        return out;
     }
     const f3 color = apply_lighting(sc, c, surface_to_camera, world_position, n_lights);
-    store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
+    out.color = {color.x, color.y, color.z, 1.0f};
+    return out;
+}
+
+// Block of 16x16 pixels -> pixel of this thread.  Workgroup ids are dealt round-robin over the 8 XCDs (blockIdx & 7), each
+// with its own L2.  XCD x shades the block rows x, x+8, x+16, ...: coherent along a row (neighbouring blocks share
+// triangles and texels in that L2) and balanced over the screen (expensive regions — minified textures far away — are
+// spread over all XCDs).  Block rows are 16 consecutive rows of the shard (row mode) or the two halves of each owned
+// 32-row band (band mode).  Returns false for surplus workgroup ids.
+struct ShadeBlock { uint32_t blk, brow; int x0, y0; };
+AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
+    const uint32_t bx_n = (f.width + 15u) >> 4;
+    const uint32_t by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.y1 - f.y0) + 15u) >> 4;
+    const uint32_t nblk = bx_n * by_n;
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;     // k-th block of this XCD
+    const uint32_t rows_x = (by_n + 7u - xcd) >> 3;                 // block rows owned by this XCD
+    if (k >= rows_x * bx_n) return false;
+    b.blk = ((k / bx_n) * 8u + xcd) * bx_n + (k % bx_n);
+    if (b.blk >= nblk) return false;
+    b.brow = b.blk / bx_n;
+    b.x0 = (int)((b.blk % bx_n) << 4);
+    b.y0 = f.band_n > 1u ? (int)(((f.tile_row0 + (b.brow >> 1) * f.band_n) << kTileShift) + ((b.brow & 1u) << 4)) : (int)f.y0 + (int)(b.brow << 4);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: single-sampled opaque pass, 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers
+// 16x4 here).  5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 spills.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
+    ShadeBlock b;
+    if (!shade_block(f, b)) return;
+    const int cx = b.x0 + (int)(threadIdx.x & 15u), cy = b.y0 + (int)(threadIdx.x >> 4);
+    if (cx >= (int)f.width || cy >= (int)f.y1) return;                   // compute.wgsl:111-113
+    const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
+    const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
+    const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};   // skybox.wgsl:1-41, uniform cube
+
+    const unsigned long long key = f.vis[pv];
+    if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, sky); return; }   // compute.wgsl:149-153 / empty.wgsl
+    const uint32_t rank = key_rank(key);
+    const GBufferTexel g = reconstruct_gbuffer(f, rank, cx, cy);          // STRICT
+    const SurfaceOut o = shade_surface(sc, f, rank, cx, cy, key_depth(key), g, true);
+    store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);   // hud: stays cleared (compute.wgsl:176-179)
+}
+
+// ------------------------------------------------------------------------------------------------
+// MSAA x4 opaque pass = k_shade_msaa + k_shade_msaa_resolve (compute.wgsl:118-170,303-318, helpers/msaa.wgsl,
+// helpers/material_shading.wgsl:25-210).
+//
+// k_shade_msaa shades sample 0 of every pixel and runs the edge detector.  The detector compares the pixel's normal with
+// its four neighbours' (sample 0): each thread publishes its strict normal + depth in an 18x18 LDS tile, the first 68
+// threads fill the halo ring by reconstructing the neighbouring blocks' border pixels.  Edge pixels are not resolved in
+// place — a wavefront would run the whole shading four times for a handful of its lanes — but appended to the block's
+// list (LDS counter, no global atomics); k_shade_msaa_resolve then shades their remaining DISTINCT triangles densely.
+// All samples a triangle covers in a pixel carry the same G-buffer texel (centre-evaluated) and the standard
+// coordinates are shared (sample 0's depth), so equal triangle => equal colour and is shaded once.
+// Contract choice: a neighbour outside the frame contributes nothing to the edge test (WGSL leaves out-of-bounds
+// textureLoad to the implementation).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kEdgeRecBytes = 260;      // per block: u32 count + 256 one-byte pixel slots
+struct NeighbourCell { float nx, ny, nz; uint32_t depth_bits; uint32_t state; };   // state 0: outside the frame, 1: background, 2: covered
+
+AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& f, int px, int py) {
+    NeighbourCell c = {0.0f, 0.0f, 0.0f, 0u, 0u};
+    if (px >= 0 && py >= 0 && px < (int)f.width && py < (int)f.height) {
+        const unsigned long long k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
+        c.state = 1u;
+        if (k != ~0ull) {
+            const GBufferTexel g = reconstruct_gbuffer(f, key_rank(k), px, py);
+            const f3 n = decode_octahedral(mk2(g.packed_nt.x, g.packed_nt.y));     // strict unpack_normal_tangent(..).N
+            c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k >> 32); c.state = 2u;
+        }
+    }
+    cells[(ly + 1) * 18 + (lx + 1)] = c;
+}
+
+__global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__ sc, FrameDev f) {
+    __shared__ NeighbourCell cells[18 * 18];
+    __shared__ uint32_t n_edges;
+    ShadeBlock b;
+    if (!shade_block(f, b)) return;                                       // workgroup-uniform
+    const uint32_t tid = threadIdx.x;
+    const int lx = (int)(tid & 15u), ly = (int)(tid >> 4);
+    const int cx = b.x0 + lx, cy = b.y0 + ly;
+    const bool inside = cx < (int)f.width && cy < (int)f.height;
+    if (tid == 0) n_edges = 0u;
+
+    // ---- phase 1: G-buffer texel of sample 0 for every pixel of the block + the halo ring, normals into LDS ----
+    unsigned long long k4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    GBufferTexel g0;
+    g0.packed_nt = {0.0f, 0.0f, 0.0f, 0.0f}; g0.bx = 0.0f; g0.by = 0.0f;
+    {
+        NeighbourCell c = {0.0f, 0.0f, 0.0f, 0u, 0u};
+        if (inside) {
+            const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + ((size_t)cy * f.width + (size_t)cx) * 4);
+            const ulonglong2 ka = kp[0], kb = kp[1];
+            k4[0] = ka.x; k4[1] = ka.y; k4[2] = kb.x; k4[3] = kb.y;
+            c.state = 1u;
+            if (k4[0] != ~0ull) {
+                g0 = reconstruct_gbuffer(f, key_rank(k4[0]), cx, cy);     // STRICT
+                const f3 n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
+                c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k4[0] >> 32); c.state = 2u;
+            }
+        }
+        cells[(ly + 1) * 18 + (lx + 1)] = c;
+    }
+    if (tid < 68u) {   // halo ring: top row (18), bottom row (18), left column (16), right column (16)
+        int hx, hy;
+        if (tid < 18u) { hx = (int)tid - 1; hy = -1; }
+        else if (tid < 36u) { hx = (int)tid - 19; hy = 16; }
+        else if (tid < 52u) { hx = -1; hy = (int)tid - 36; }
+        else { hx = 16; hy = (int)tid - 52; }
+        publish_cell(cells, hx, hy, f, b.x0 + hx, b.y0 + hy);
+    }
+    __syncthreads();
+
+    // ---- phase 2: compute.wgsl main ----
+    const size_t p = (size_t)cy * f.width + (size_t)cx;
+    uint8_t* edge_rec = reinterpret_cast<uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
+    bool is_edge = false;
+    if (inside) {
+        const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+        const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
+        if (!f.has_opaque || !any_hit) {
+            store_pixel(f, p, sky);                                        // compute.wgsl:121-143
+        } else if (k4[0] == ~0ull) {
+            f.msaa_color0[p] = make_float4(sky.x, sky.y, sky.z, sky.w);   // compute.wgsl:155-170: sample 0 is background, others are not
+            is_edge = true;
+        } else {
+            const SurfaceOut o = shade_surface(sc, f, key_rank(k4[0]), cx, cy, key_depth(k4[0]), g0, true);
+            if (o.kind == 2u) store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f});   // hud
+            else if (o.kind == 1u) store_pixel(f, p, o.color);                 // debug view: written before the edge test
+            else {
+                // compute.wgsl:303-318 + msaa.wgsl:201-237 (STRICT)
+                const m4 inv_proj = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_CAMERA] + 256));
+                const float W = (float)f.width, H = (float)f.height, pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
+                is_edge = edge_mask_depth_msaa(inv_proj, k4, pcx, pcy, W, H);
+                if (!is_edge) {   // msaa.wgsl:42-112
+                    const NeighbourCell me = cells[(ly + 1) * 18 + (lx + 1)];
+                    const f3 center_normal = {me.nx, me.ny, me.nz};
+                    bool center_loaded = false; float view_depth_c = 0.0f, depth_threshold = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ox = i == 0 ? 1 : (i == 1 ? -1 : 0), oy = i == 2 ? 1 : (i == 3 ? -1 : 0);
+                        const NeighbourCell nb = cells[(ly + 1 + oy) * 18 + (lx + 1 + ox)];
+                        if (is_edge || nb.state == 0u) continue;
+                        if (nb.state == 1u) { is_edge = true; continue; }          // neighbour is background
+                        if (dot(center_normal, mk3(nb.nx, nb.ny, nb.nz)) < kEdgeNormalThreshold) { is_edge = true; continue; }
+                        if (!center_loaded) {
+                            view_depth_c = view_space_depth(inv_proj, key_depth(k4[0]), pcx, pcy, W, H);
+                            depth_threshold = kEdgeDepthThreshold * fabsf(view_depth_c);
+                            center_loaded = true;
+                        }
+                        const float nvd = view_space_depth(inv_proj, __uint_as_float(nb.depth_bits), pcx + (float)ox, pcy + (float)oy, W, H);
+                        if (fabsf(view_depth_c - nvd) > depth_threshold) is_edge = true;
+                    }
+                }
+                if (is_edge) f.msaa_color0[p] = make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
+                else store_pixel(f, p, o.color);
+            }
+        }
+    }
+    if (is_edge) edge_rec[4u + atomicAdd(&n_edges, 1u)] = (uint8_t)tid;
+    __syncthreads();
+    if (tid == 0) *reinterpret_cast<uint32_t*>(edge_rec) = n_edges;
+}
+
+// One thread per edge pixel of the block: the colours of samples 1..3 (material_shading.wgsl:170-210), shading each
+// distinct triangle once, then the average of the four.
+__global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
+    ShadeBlock b;
+    if (!shade_block(f, b)) return;
+    const uint8_t* edge_rec = reinterpret_cast<const uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
+    const uint32_t n = *reinterpret_cast<const uint32_t*>(edge_rec);
+    if (threadIdx.x >= n) return;
+    const uint32_t slot = edge_rec[4u + threadIdx.x];
+    const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
+    const size_t p = (size_t)cy * f.width + (size_t)cx;
+    const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + p * 4);
+    const ulonglong2 ka = kp[0], kb = kp[1];
+    const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
+    const float depth0 = key_depth(k4[0]);
+    const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+    const float4 c0v = f.msaa_color0[p];
+    f4 col[4];
+    col[0] = {c0v.x, c0v.y, c0v.z, c0v.w};
+    for (int s = 1; s < 4; s++) {                 // not unrolled: one copy of the shading code
+        f4 c = sky;
+        if (k4[s] != ~0ull) {
+            const uint32_t r = key_rank(k4[s]);
+            int same = -1;
+            for (int t = 0; t < s; t++) if (k4[t] != ~0ull && key_rank(k4[t]) == r) same = t;
+            if (same >= 0) c = col[same];
+            else c = shade_surface(sc, f, r, cx, cy, depth0, reconstruct_gbuffer(f, r, cx, cy), false).color;
+        }
+        col[s] = c;
+    }
+    const f4 sum = {((col[0].x + col[1].x) + col[2].x) + col[3].x, ((col[0].y + col[1].y) + col[2].y) + col[3].y,
+                    ((col[0].z + col[1].z) + col[2].z) + col[3].z, ((col[0].w + col[1].w) + col[2].w) + col[3].w};
+    store_pixel(f, p, {sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f});
 }
 #pragma clang fp contract(off)
 
@@ -720,13 +923,14 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t* __restrict__ out_rg1
 // covered-pixel count for AwsmFrameStats: runs only when the caller asks for stats (frame_end), never in the frame itself.
 // (A per-wave atomicAdd on one counter inside k_shade serialised ~130k same-address atomics per 4K frame.)
 __global__ __launch_bounds__(256) void k_count_covered(const unsigned long long* __restrict__ vis, uint32_t width, uint32_t y0, uint32_t y1,
-                                                       uint32_t band_n, uint32_t band_r, uint32_t* counter) {
+                                                       uint32_t band_n, uint32_t band_r, uint32_t msaa, uint32_t* counter) {
     const size_t n = (size_t)width * (y1 - y0), base = (size_t)width * y0;
     uint32_t local = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t y = y0 + (uint32_t)(i / width);
         if (band_n > 1u && ((y >> kTileShift) % band_n) != band_r) continue;      // rows of other shards hold stale keys
-        local += vis[base + i] != ~0ull ? 1u : 0u;
+        if (msaa == 4u) { const unsigned long long* k = vis + (base + i) * 4; local += (k[0] & k[1] & k[2] & k[3]) != ~0ull ? 1u : 0u; }   // any sample hit
+        else local += vis[base + i] != ~0ull ? 1u : 0u;
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
@@ -737,7 +941,7 @@ __global__ void k_pick(const DevScene* __restrict__ sc, FrameDev f, int x, int y
     out[0] = 0u; out[1] = 0u; out[2] = 0u; out[3] = 0xFFFFFFFFu;
     if (x < 0 || y < 0 || x >= (int)f.width || y < (int)f.y0 || y >= (int)f.y1) return;
     if (f.band_n > 1u && (((uint32_t)y >> kTileShift) % f.band_n) != f.band_r) return;
-    const unsigned long long key = f.vis[(size_t)y * f.width + (size_t)x];
+    const unsigned long long key = f.vis[((size_t)y * f.width + (size_t)x) * (f.msaa == 4u ? 4u : 1u)];   // MSAA: sample 0, as the picker's textureLoad(.., 0)
     if (key == ~0ull) return;
     const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     const DrawDev dr = f.draws[f.tri_info[rank] & 0x00FFFFFFu];
@@ -758,10 +962,16 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->y1 - f->y0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
-    if (nb) hipLaunchKernelGGL(awsm::k_shade, dim3(nb), dim3(256), 0, s, sc, *f);
+    if (!nb) return;
+    if (f->msaa == 4u) {
+        hipLaunchKernelGGL(awsm::k_shade_msaa, dim3(nb), dim3(256), 0, s, sc, *f);
+        hipLaunchKernelGGL(awsm::k_shade_msaa_resolve, dim3(nb), dim3(256), 0, s, sc, *f);
+    } else {
+        hipLaunchKernelGGL(awsm::k_shade, dim3(nb), dim3(256), 0, s, sc, *f);
+    }
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
-    if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->band_n, f->band_r, f->counters + 3);
+    if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->band_n, f->band_r, f->msaa, f->counters + 3);
 }
 extern "C" void awsm_launch_pick(const awsm::DevScene* sc, const awsm::FrameDev* f, int x, int y, uint32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_pick, dim3(1), dim3(1), 0, s, sc, *f, x, y, out);

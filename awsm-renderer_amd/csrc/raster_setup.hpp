@@ -129,17 +129,24 @@ AWSM_DI bool edge_inside(float e, float a, float b) {
     return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));   // top-left rule
 }
 
-AWSM_DI void tri_edges(const TriSetup& t, int px, int py, float& e0, float& e1, float& e2) {
-    float X = (float)px + 0.5f, Y = (float)py + 0.5f;
+AWSM_DI void tri_edges_at(const TriSetup& t, float X, float Y, float& e0, float& e1, float& e2) {
     e0 = (t.a[0] * X + t.b[0] * Y) + t.c[0];
     e1 = (t.a[1] * X + t.b[1] * Y) + t.c[1];
     e2 = (t.a[2] * X + t.b[2] * Y) + t.c[2];
 }
+AWSM_DI void tri_edges(const TriSetup& t, int px, int py, float& e0, float& e1, float& e2) {
+    tri_edges_at(t, (float)px + 0.5f, (float)py + 0.5f, e0, e1, e2);
+}
 
-// Coverage + depth at a pixel centre.  Returns the packed 64-bit key or ~0 if not covered.
-AWSM_DI unsigned long long tri_sample_key(const TriSetup& t, int px, int py, uint32_t rank) {
+// WebGPU's standard 4x sample pattern (GPUMultisampleState count = 4; the D3D standard pattern), pixel-relative.
+// Exactly representable, so px + offset is exact in f32 for any frame size.
+AWSM_DI float msaa4_x(int k) { return k == 0 ? 0.375f : (k == 1 ? 0.875f : (k == 2 ? 0.125f : 0.625f)); }
+AWSM_DI float msaa4_y(int k) { return k == 0 ? 0.125f : (k == 1 ? 0.375f : (k == 2 ? 0.625f : 0.875f)); }
+
+// Coverage + depth at sample position (X, Y) in pixel units.  Returns the packed 64-bit key or ~0 if not covered.
+AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, float X, float Y, uint32_t rank) {
     float e0, e1, e2;
-    tri_edges(t, px, py, e0, e1, e2);
+    tri_edges_at(t, X, Y, e0, e1, e2);
     if (!edge_inside(e0, t.a[0], t.b[0]) || !edge_inside(e1, t.a[1], t.b[1]) || !edge_inside(e2, t.a[2], t.b[2]))
         return ~0ull;
     float zn = ((e0 * t.z[0] + e1 * t.z[1]) + e2 * t.z[2]) / t.det;
@@ -148,10 +155,14 @@ AWSM_DI unsigned long long tri_sample_key(const TriSetup& t, int px, int py, uin
     // depth LessEqual + submission order: smaller depth wins, equal depth -> LATER primitive wins
     return ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
 }
+// Pixel centre (single-sampled targets).
+AWSM_DI unsigned long long tri_sample_key(const TriSetup& t, int px, int py, uint32_t rank) {
+    return tri_sample_key_at(t, (float)px + 0.5f, (float)py + 0.5f, rank);
+}
 
-// Conservative "tile can contain a covered pixel centre" test: evaluates every edge at the tile corner
-// that maximises it.  A half-pixel margin separates the corners from the outermost pixel centres, which
-// dwarfs the rounding error of the evaluation, so no covered pixel is ever rejected.
+// Conservative "tile can contain a covered sample" test: evaluates every edge at the tile corner that maximises it.
+// The corners are at least half a pixel (pixel centres) or an eighth of a pixel (MSAA sample positions) away from the
+// outermost samples, which dwarfs the rounding error of the evaluation, so no covered sample is ever rejected.
 AWSM_DI bool tile_may_overlap(const TriSetup& t, int tx0, int ty0, int tx1, int ty1 /* pixel bounds, exclusive max */) {
 #pragma unroll
     for (int i = 0; i < 3; i++) {

@@ -170,7 +170,7 @@ class HipDevice:
     # ---- targets / environment ----
     def resize(self, width: int, height: int, msaa: int = 0):
         self._chk(self.lib.awsm_hip_resize(self.ctx, width, height, msaa), "resize")
-        self.width, self.height = width, height
+        self.width, self.height, self.msaa = width, height, (4 if msaa == 4 else 0)
 
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_hip_set_shard_rows(self.ctx, y0, y1), "set_shard_rows")
@@ -249,15 +249,19 @@ class HipDevice:
         return self.lib.awsm_hip_output_device_ptr(self.ctx)
 
     # ---- readback ----
+    def _vis_shape(self):
+        return (self.height, self.width, 4) if getattr(self, "msaa", 0) == 4 else (self.height, self.width)
+
     def read_visibility(self) -> np.ndarray:
-        out = np.zeros((self.height, self.width), dtype=np.uint64)
+        """Packed keys [H, W] (with MSAA x4: [H, W, 4], sample-minor)."""
+        out = np.zeros(self._vis_shape(), dtype=np.uint64)
         self._chk(self.lib.awsm_hip_read_visibility(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_visibility")
         return out
 
     def read_visibility_unpacked(self):
-        tri = np.zeros((self.height, self.width), dtype=np.uint32)
-        meta = np.zeros((self.height, self.width), dtype=np.uint32)
-        depth = np.zeros((self.height, self.width), dtype=np.float32)
+        tri = np.zeros(self._vis_shape(), dtype=np.uint32)
+        meta = np.zeros(self._vis_shape(), dtype=np.uint32)
+        depth = np.zeros(self._vis_shape(), dtype=np.float32)
         self._chk(self.lib.awsm_hip_read_visibility_unpacked(self.ctx, tri.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p),
                                                              depth.ctypes.data_as(C.c_void_p)), "read_visibility_unpacked")
         return tri, meta, depth

@@ -155,7 +155,11 @@ int awsm_hip_buffer_create(AwsmHipCtx* ctx, AwsmBuf which, size_t bytes);
 int awsm_hip_buffer_write(AwsmHipCtx* ctx, AwsmBuf which, size_t dst_off, const void* src, size_t len);
 
 /* ---- render_textures.views() realloc on size/AA change (crates/renderer/src/render_textures.rs:103-147).
- * msaa: 0 = single sample; 4 -> AWSM_ERR_UNSUPPORTED this round. ---- */
+ * msaa: 0 (or 1) = single sample; 4 = the reference's default AntiAliasing (anti_alias.rs:28-38): the geometry pass keeps
+ * four visibility samples per pixel at WebGPU's standard 4x positions (per-sample coverage and depth; the interpolants
+ * are evaluated at the pixel centre, as @interpolate(perspective, center) does), and the opaque pass runs the edge
+ * detector + per-sample resolve of material_opaque_wgsl/helpers/{msaa,material_shading}.wgsl.  The output image stays
+ * single-sampled.  MSAA and sharding exclude each other for now (the edge detector reads neighbouring pixels). ---- */
 int awsm_hip_resize(AwsmHipCtx* ctx, uint32_t width, uint32_t height, uint32_t msaa);
 
 /* ---- multi-GPU screen sharding (new; no reference counterpart): this ctx rasterises and shades only
@@ -206,7 +210,8 @@ int awsm_hip_frame_flush(AwsmHipCtx* ctx);
 int awsm_hip_bind_output(AwsmHipCtx* ctx, void* device_ptr, size_t bytes);
 void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
 
-/* ---- readback for parity (new).  keys: width*height u64 = (depth_f32_bits << 32) | (0xFFFFFFFF - rank),
+/* ---- readback for parity (new).  keys: width*height u64 (x4 with MSAA: the samples of a pixel are adjacent) =
+ * (depth_f32_bits << 32) | (0xFFFFFFFF - rank),
  * rank = index of the triangle in draw order over the whole draw list; all ones = no hit.
  * unpack gives the reference's visibility_data texel: triangle_index (primitive-local) and
  * material_mesh_meta_offset, plus the Depth32Float value. ---- */

@@ -45,14 +45,17 @@ typedef struct OracleScene {
     float irradiance_rgb[4];
     const uint16_t* brdf_lut_rg16f;  /* lut_w*lut_h*2 halfs */
     uint32_t lut_width, lut_height;
+    uint32_t msaa;                   /* 0 (single sample) or 4: keys hold 4 samples per pixel, [pixel][sample] */
+    uint32_t pad_;
 } OracleScene;
 
 /* vert_main for every exploded vertex of every draw, in draw order.
  * clip_out: 4 floats / vertex; nt_out: 8 floats / vertex {N.xyz, 0, T.xyzw}. */
 int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out);
 
-/* Rasterise all draws (clip_in from oracle_transform) into keys[width*height]:
- * (depth_bits << 32) | (0xFFFFFFFF - rank); all ones = no hit. */
+/* Rasterise all draws (clip_in from oracle_transform) into keys[width*height] (keys[width*height*4] when msaa == 4,
+ * sample s of pixel p at [p*4 + s], standard 4x sample positions): (depth_bits << 32) | (0xFFFFFFFF - rank);
+ * all ones = no hit. */
 int oracle_raster(const OracleScene* s, const float* clip_in, uint64_t* keys_out, int threads);
 
 /* Opaque compute pass over keys; writes rgba32f (4 floats / pixel) and rgba16f (4 halfs / pixel).

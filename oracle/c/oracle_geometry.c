@@ -232,9 +232,16 @@ static inline int edge_inside(float e, float a, float b) {
     return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));   /* top-left rule */
 }
 
-/* returns 1 and the depth if pixel (px,py) is covered and inside the depth clip range */
+/* WebGPU's standard 4x sample pattern (GPUMultisampleState count 4; == D3D standard pattern), pixel-relative */
+const float oracle_msaa4_x[4] = {0.375f, 0.875f, 0.125f, 0.625f};
+const float oracle_msaa4_y[4] = {0.125f, 0.375f, 0.625f, 0.875f};
+
+/* returns 1 and the depth if the sample at (X, Y) (pixel units) is covered and inside the depth clip range */
+static inline int tri_sample_at(const TriSetup* t, float X, float Y, float* e_out, float* depth_out);
 static inline int tri_sample(const TriSetup* t, int px, int py, float* e_out, float* depth_out) {
-    float X = (float)px + 0.5f, Y = (float)py + 0.5f;
+    return tri_sample_at(t, (float)px + 0.5f, (float)py + 0.5f, e_out, depth_out);
+}
+static inline int tri_sample_at(const TriSetup* t, float X, float Y, float* e_out, float* depth_out) {
     float e0 = (t->a[0] * X + t->b[0] * Y) + t->c[0];
     float e1 = (t->a[1] * X + t->b[1] * Y) + t->c[1];
     float e2 = (t->a[2] * X + t->b[2] * Y) + t->c[2];
@@ -257,10 +264,11 @@ static void shard_rows(const OracleScene* s, uint32_t* y0, uint32_t* y1) {
 int oracle_raster(const OracleScene* s, const float* clip, uint64_t* keys, int threads) {
     uint32_t W = s->width, H = s->height, sy0, sy1;
     shard_rows(s, &sy0, &sy1);
-    float* depth = (float*)malloc((size_t)W * H * sizeof(float));
-    uint32_t* rank_buf = (uint32_t*)malloc((size_t)W * H * sizeof(uint32_t));
+    const uint32_t S = s->msaa == 4u ? 4u : 1u;                      /* samples per pixel */
+    float* depth = (float*)malloc((size_t)W * H * S * sizeof(float));
+    uint32_t* rank_buf = (uint32_t*)malloc((size_t)W * H * S * sizeof(uint32_t));
     if (!depth || !rank_buf) { free(depth); free(rank_buf); return -2; }
-    for (size_t i = 0; i < (size_t)W * H; i++) { depth[i] = 1.0f; rank_buf[i] = O_U32_MAX; }   /* render_pass.rs:107-114 */
+    for (size_t i = 0; i < (size_t)W * H * S; i++) { depth[i] = 1.0f; rank_buf[i] = O_U32_MAX; }   /* render_pass.rs:107-114 */
     if (threads < 1) threads = 1;
     uint32_t rows = sy1 - sy0;
     /* bands of rows; every band walks all triangles in submission order (depth test is order dependent) */
@@ -284,15 +292,22 @@ int oracle_raster(const OracleScene* s, const float* clip, uint64_t* keys, int t
                 for (int py = y_lo; py <= y_hi; py++) {
                     for (int px = ts.minx; px <= ts.maxx; px++) {
                         float e[3], zn;
-                        if (!tri_sample(&ts, px, py, e, &zn)) continue;
                         size_t p = (size_t)py * W + (size_t)px;
-                        if (zn <= depth[p]) { depth[p] = zn; rank_buf[p] = rank; }   /* CompareFunction::LessEqual */
+                        if (S == 1u) {
+                            if (!tri_sample(&ts, px, py, e, &zn)) continue;
+                            if (zn <= depth[p]) { depth[p] = zn; rank_buf[p] = rank; }   /* CompareFunction::LessEqual */
+                        } else {   /* per-sample coverage + per-sample depth (multisampled depth/visibility targets) */
+                            for (uint32_t k = 0; k < 4u; k++) {
+                                if (!tri_sample_at(&ts, (float)px + oracle_msaa4_x[k], (float)py + oracle_msaa4_y[k], e, &zn)) continue;
+                                if (zn <= depth[p * 4 + k]) { depth[p * 4 + k] = zn; rank_buf[p * 4 + k] = rank; }
+                            }
+                        }
                     }
                 }
             }
         }
     }
-    for (size_t i = 0; i < (size_t)W * H; i++) {
+    for (size_t i = 0; i < (size_t)W * H * S; i++) {
         if (rank_buf[i] == O_U32_MAX) keys[i] = ~0ull;
         else keys[i] = ((uint64_t)o_f32_bits(depth[i]) << 32) | (uint64_t)(O_U32_MAX - rank_buf[i]);
     }
@@ -312,7 +327,7 @@ static uint32_t find_draw(const OracleScene* s, uint32_t rank, uint32_t* first_r
 }
 
 int oracle_unpack_visibility(const OracleScene* s, const uint64_t* keys, uint32_t* tri_id, uint32_t* meta_off, float* depth) {
-    size_t n = (size_t)s->width * s->height;
+    size_t n = (size_t)s->width * s->height * (s->msaa == 4u ? 4u : 1u);
     for (size_t i = 0; i < n; i++) {
         if (keys[i] == ~0ull) {
             /* fragment.wgsl never ran: clear colour 0xFFFF per channel -> join32 = U32_MAX (render_pass.rs:22-30) */

@@ -661,28 +661,16 @@ static uint32_t find_draw(const OracleScene* s, uint32_t rank, uint32_t* first_r
     return s->n_draws;
 }
 
-/* compute.wgsl:100-322 for one pixel */
-static void shade_pixel(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
-                        int cx, int cy, float* rgba32f, uint16_t* rgba16f) {
-    uint32_t W = s->width, H = s->height;
-    size_t p = (size_t)cy * W + (size_t)cx;
-    ovec4 sky = ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
-    uint64_t key = keys[p];
-    if (!s->has_opaque || key == ~0ull) { store_pixel(rgba32f, rgba16f, p, sky); return; }   /* compute.wgsl:149-153; empty.wgsl */
-
-    uint32_t rank = O_U32_MAX - (uint32_t)(key & 0xFFFFFFFFull);
-    float depth_sample = o_bits_f32((uint32_t)(key >> 32));
-    uint32_t first;
-    uint32_t d = find_draw(s, rank, &first);
-    uint32_t triangle_index = rank - first;
-    uint32_t material_meta_offset = rd_u32(s->buf[AWSM_BUF_GEOM_META] + s->draws[d].geom_meta_off + 36);
-    MaterialMeta meta = load_material_meta(s, material_meta_offset);
-    if (meta.is_hud == 1u) return;   /* compute.wgsl:176-179: pixel stays as cleared */
-
-    /* ---- what fs_main wrote for this pixel (fragment.wgsl:23-54), rounded to the G-buffer formats ---- */
+/* What fs_main wrote for pixel (cx, cy) when triangle `rank` covered it (fragment.wgsl:23-54), rounded to the G-buffer
+ * formats: RG16F barycentric.xy and RGBA16F packed normal/tangent.  The varyings are interpolated at the PIXEL CENTRE
+ * (WGSL default @interpolate(perspective, center)); with MSAA the centre may lie outside the triangle and the values
+ * extrapolate — every sample the triangle covers in that pixel receives the same values. */
+typedef struct { float bx, by; ovec4 packed_nt; int valid; } GBufferTexel;
+static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const float* nt, uint32_t rank, int cx, int cy) {
+    GBufferTexel g; memset(&g, 0, sizeof g);
     const float* v0 = clip + (size_t)rank * 12;
     float e[3];
-    if (!oracle_tri_edges_at(v0, v0 + 4, v0 + 8, W, H, cx, cy, e)) { store_pixel(rgba32f, rgba16f, p, sky); return; }
+    if (!oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy, e)) return g;
     float esum = (e[0] + e[1]) + e[2];
     float b0 = e[0] / esum, b1 = e[1] / esum, b2 = e[2] / esum;
     const float* n0 = nt + (size_t)rank * 24;
@@ -694,11 +682,33 @@ static void shade_pixel(const OracleScene* s, const float* clip, const float* nt
     ovec3 Nn = ov3_normalize(Ni);
     ovec3 Tn = ov3_normalize(ov3(Ti.x, Ti.y, Ti.z));
     ovec4 packed = o_pack_normal_tangent(Nn, Tn, Ti.w);
-    packed = ov4(o_round_f16(packed.x), o_round_f16(packed.y), o_round_f16(packed.z), o_round_f16(packed.w));   /* RGBA16F */
-    float bx = o_round_f16(b0), by = o_round_f16(b1);                                                             /* RG16F */
+    g.packed_nt = ov4(o_round_f16(packed.x), o_round_f16(packed.y), o_round_f16(packed.z), o_round_f16(packed.w));   /* RGBA16F */
+    g.bx = o_round_f16(b0); g.by = o_round_f16(b1);                                                                   /* RG16F */
+    g.valid = 1;
+    return g;
+}
+
+/* The shading of one visibility sample: compute.wgsl:171-299 (main sample) == material_shading.wgsl:69-168
+ * (msaa_process_sample).  `depth_sample` is the depth the standard coordinates are built from (always sample 0's,
+ * standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug colour, 2 hud mesh (main path only), 3 no G-buffer texel. */
+typedef struct { ovec3 color; float alpha; int kind; ovec4 packed_nt; } SurfaceColor;
+static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const float* nt, uint32_t rank, int cx, int cy,
+                                  float depth_sample, int check_hud) {
+    SurfaceColor out; memset(&out, 0, sizeof out);
+    uint32_t W = s->width, H = s->height;
+    uint32_t first;
+    uint32_t d = find_draw(s, rank, &first);
+    uint32_t triangle_index = rank - first;
+    uint32_t material_meta_offset = rd_u32(s->buf[AWSM_BUF_GEOM_META] + s->draws[d].geom_meta_off + 36);
+    MaterialMeta meta = load_material_meta(s, material_meta_offset);
+    if (check_hud && meta.is_hud == 1u) { out.kind = 2; return out; }   /* compute.wgsl:176-179 */
+
+    GBufferTexel g = gbuffer_texel(s, clip, nt, rank, cx, cy);
+    if (!g.valid) { out.kind = 3; return out; }
+    out.packed_nt = g.packed_nt;
 
     /* ---- compute.wgsl:182-211 ---- */
-    ovec3 barycentric = ov3(bx, by, (1.0f - bx) - by);
+    ovec3 barycentric = ov3(g.bx, g.by, (1.0f - g.bx) - g.by);
     const uint32_t* materials = (const uint32_t*)s->buf[AWSM_BUF_MATERIALS];
     uint32_t material_offset = meta.material_offset;
     uint32_t shader_id = materials[material_offset / 4u];
@@ -734,10 +744,9 @@ static void shade_pixel(const OracleScene* s, const float* clip, const float* nt
         surface_to_camera = ov3_dot(to_camera, to_camera) > 0.0f ? o_safe_normalize(to_camera) : ov3(0.0f, 0.0f, 1.0f);
     }
 
-    o_tbn tbn = o_unpack_normal_tangent(packed);
+    o_tbn tbn = o_unpack_normal_tangent(g.packed_nt);
     uint32_t n_lights = rd_u32(s->buf[AWSM_BUF_LIGHTS_INFO]);   /* lights.wgsl:38-47 */
 
-    ovec3 color; float base_alpha;
     if (shader_id == 2u) {
         /* unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580 */
         uint32_t b = material_offset / 4u + 1u;
@@ -748,20 +757,143 @@ static void shade_pixel(const OracleScene* s, const float* clip, const float* nt
         if (base_tex.exists) { ovec4 t = sample_tex(&a, &base_tex); base = ov4(base.x * t.x, base.y * t.y, base.z * t.z, base.w * t.w); }
         if (em_tex.exists) { ovec4 t = sample_tex(&a, &em_tex); em = ov3(em.x * t.x, em.y * t.y, em.z * t.z); }
         base.w = 1.0f;
-        color = ov3(base.x + em.x, base.y + em.y, base.z + em.z);
-        base_alpha = base.w;
+        out.color = ov3(base.x + em.x, base.y + em.y, base.z + em.z);
+        out.alpha = base.w;
     } else {
         PbrMaterial mat = pbr_get_material(materials, material_offset);
         PbrColor mc = pbr_get_material_color(&a, materials, &mat, &tbn);
         if (mat.debug_bitmask != 0u) {
-            ovec3 dc = pbr_debug_material_color(mat.debug_bitmask, &mc);
-            store_pixel(rgba32f, rgba16f, p, ov4(dc.x, dc.y, dc.z, 1.0f));
-            return;
+            out.color = pbr_debug_material_color(mat.debug_bitmask, &mc);
+            out.alpha = 1.0f;              /* compute.wgsl:276-281 writes 1.0; material_shading.wgsl:153-156 returns base.a == 1 */
+            out.kind = 1;
+            return out;
         }
-        color = apply_lighting(s, &mc, surface_to_camera, world_position, n_lights);
-        base_alpha = mc.base.w;
+        out.color = apply_lighting(s, &mc, surface_to_camera, world_position, n_lights);
+        out.alpha = mc.base.w;
     }
-    store_pixel(rgba32f, rgba16f, p, ov4(color.x, color.y, color.z, base_alpha));
+    return out;
+}
+
+/* compute.wgsl:100-322 for one pixel, single-sampled */
+static void shade_pixel(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
+                        int cx, int cy, float* rgba32f, uint16_t* rgba16f) {
+    size_t p = (size_t)cy * s->width + (size_t)cx;
+    ovec4 sky = ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
+    uint64_t key = keys[p];
+    if (!s->has_opaque || key == ~0ull) { store_pixel(rgba32f, rgba16f, p, sky); return; }   /* compute.wgsl:149-153; empty.wgsl */
+    uint32_t rank = O_U32_MAX - (uint32_t)(key & 0xFFFFFFFFull);
+    float depth_sample = o_bits_f32((uint32_t)(key >> 32));
+    SurfaceColor c = shade_surface(s, clip, nt, rank, cx, cy, depth_sample, 1);
+    if (c.kind == 2) return;                                      /* hud: pixel stays as cleared */
+    if (c.kind == 3) { store_pixel(rgba32f, rgba16f, p, sky); return; }
+    store_pixel(rgba32f, rgba16f, p, ov4(c.color.x, c.color.y, c.color.z, c.alpha));
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * MSAA x4: compute.wgsl:118-170,303-318 + helpers/msaa.wgsl + helpers/material_shading.wgsl:25-210.
+ * keys hold 4 samples per pixel.  Every value of the edge predicates is evaluated in the contract's strict f32.
+ * Contract choice (WGSL leaves out-of-bounds textureLoad to the implementation): a neighbour outside the frame
+ * contributes nothing to edge_mask_neighbors.
+ * --------------------------------------------------------------------------------------------------------------- */
+#define EDGE_NORMAL_THRESHOLD 0.95f
+#define EDGE_DEPTH_THRESHOLD 0.02f
+#define EDGE_MSAA_DEPTH_THRESHOLD 0.02f
+
+/* msaa.wgsl:185-199 */
+static float view_space_depth(const omat4* inv_proj, float depth, float px, float py, float W, float H) {
+    ovec4 clip_pos = ov4((px / W) * 2.0f - 1.0f, 1.0f - (py / H) * 2.0f, depth, 1.0f);
+    ovec4 view_pos = omat4_mul_v4(inv_proj, clip_pos);
+    return view_pos.z / view_pos.w;
+}
+static inline uint32_t key_rank(uint64_t k) { return O_U32_MAX - (uint32_t)(k & 0xFFFFFFFFull); }
+static inline float key_depth(uint64_t k) { return k == ~0ull ? 1.0f : o_bits_f32((uint32_t)(k >> 32)); }   /* depth clear = 1.0 */
+
+/* msaa.wgsl:116-146 */
+static int edge_mask_depth_msaa(const omat4* inv_proj, const uint64_t* k4, float pcx, float pcy, float W, float H) {
+    uint32_t count = 0; float dmin = 1e9f, dmax = -1e9f;
+    for (int sidx = 0; sidx < 4; sidx++) {
+        if (k4[sidx] == ~0ull) continue;
+        count++;
+        float vd = view_space_depth(inv_proj, key_depth(k4[sidx]), pcx, pcy, W, H);
+        dmin = fminf(dmin, vd); dmax = fmaxf(dmax, vd);
+    }
+    if (count < 2u) return 0;
+    float depth_range = fabsf(dmax - dmin);
+    float avg_depth = fabsf((dmax + dmin) * 0.5f);
+    return depth_range > (EDGE_MSAA_DEPTH_THRESHOLD * avg_depth);
+}
+/* msaa.wgsl:42-112; center is covered (caller checked) */
+static int edge_mask_neighbors(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys, const omat4* inv_proj,
+                               int cx, int cy, ovec3 center_normal) {
+    const int W = (int)s->width, H = (int)s->height;
+    uint32_t y0 = s->y0, y1 = s->y1;
+    if (y1 == 0 || y1 > s->height) y1 = s->height;
+    static const int ox[4] = {1, -1, 0, 0}, oy[4] = {0, 0, 1, -1};
+    int center_loaded = 0; float view_depth_c = 0.0f, depth_threshold = 0.0f;
+    const float pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
+    for (int i = 0; i < 4; i++) {
+        const int nx = cx + ox[i], ny = cy + oy[i];
+        if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;            /* contract: out-of-frame neighbour ignored */
+        (void)y0; (void)y1;
+        const uint64_t nk = keys[((size_t)ny * W + nx) * 4];
+        if (nk == ~0ull) return 1;                                        /* neighbour is background: edge */
+        GBufferTexel ng = gbuffer_texel(s, clip, nt, key_rank(nk), nx, ny);
+        ovec3 neighbor_normal = o_decode_octahedral(ov2(ng.packed_nt.x, ng.packed_nt.y));
+        if (ov3_dot(center_normal, neighbor_normal) < EDGE_NORMAL_THRESHOLD) return 1;
+        if (!center_loaded) {
+            const float depth_c = key_depth(keys[((size_t)cy * W + cx) * 4]);
+            view_depth_c = view_space_depth(inv_proj, depth_c, pcx, pcy, (float)W, (float)H);
+            depth_threshold = EDGE_DEPTH_THRESHOLD * fabsf(view_depth_c);
+            center_loaded = 1;
+        }
+        const float nvd = view_space_depth(inv_proj, key_depth(nk), pcx + (float)ox[i], pcy + (float)oy[i], (float)W, (float)H);
+        if (fabsf(view_depth_c - nvd) > depth_threshold) return 1;
+    }
+    return 0;
+}
+
+/* material_shading.wgsl:170-210: all four samples, shared standard coordinates (sample 0's depth) */
+static void msaa_resolve(const OracleScene* s, const float* clip, const float* nt, const uint64_t* k4, int cx, int cy,
+                         float* rgba32f, uint16_t* rgba16f, size_t p) {
+    const float depth0 = key_depth(k4[0]);
+    ovec3 color_sum = ov3(0.0f, 0.0f, 0.0f); float alpha_sum = 0.0f; uint32_t valid = 0;
+    for (int sidx = 0; sidx < 4; sidx++) {
+        if (k4[sidx] == ~0ull) {   /* sample hit background: skybox colour */
+            color_sum = ov3_add(color_sum, ov3(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2])); alpha_sum += s->skybox_rgba[3]; valid++;
+            continue;
+        }
+        SurfaceColor c = shade_surface(s, clip, nt, key_rank(k4[sidx]), cx, cy, depth0, 0);   /* no hud test per sample */
+        if (c.kind == 3) { c.color = ov3(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2]); c.alpha = s->skybox_rgba[3]; }
+        color_sum = ov3_add(color_sum, c.color); alpha_sum += c.alpha; valid++;
+    }
+    const float n = (float)valid;
+    store_pixel(rgba32f, rgba16f, p, ov4(color_sum.x / n, color_sum.y / n, color_sum.z / n, alpha_sum / n));
+}
+
+static void shade_pixel_msaa(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
+                             int cx, int cy, float* rgba32f, uint16_t* rgba16f) {
+    const uint32_t W = s->width, H = s->height;
+    const size_t p = (size_t)cy * W + (size_t)cx;
+    const uint64_t* k4 = keys + p * 4;
+    ovec4 sky = ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
+    const int any_hit = k4[0] != ~0ull || k4[1] != ~0ull || k4[2] != ~0ull || k4[3] != ~0ull;
+    if (!s->has_opaque || !any_hit) { store_pixel(rgba32f, rgba16f, p, sky); return; }          /* compute.wgsl:121-143 */
+    if (k4[0] == ~0ull) { msaa_resolve(s, clip, nt, k4, cx, cy, rgba32f, rgba16f, p); return; }   /* compute.wgsl:155-170 */
+
+    const uint32_t rank0 = key_rank(k4[0]);
+    SurfaceColor c = shade_surface(s, clip, nt, rank0, cx, cy, key_depth(k4[0]), 1);
+    if (c.kind == 2) return;                                                                      /* hud */
+    if (c.kind == 3) { store_pixel(rgba32f, rgba16f, p, sky); return; }
+    if (c.kind == 1) { store_pixel(rgba32f, rgba16f, p, ov4(c.color.x, c.color.y, c.color.z, 1.0f)); return; }   /* debug view: before the edge test */
+
+    /* compute.wgsl:303-318 + msaa.wgsl:201-237 */
+    const uint8_t* cam = s->buf[AWSM_BUF_CAMERA];
+    omat4 inv_proj = omat4_load((const float*)(cam + 256));
+    ovec3 world_normal = o_decode_octahedral(ov2(c.packed_nt.x, c.packed_nt.y));                  /* tbn.N */
+    const int is_edge = edge_mask_depth_msaa(&inv_proj, k4, (float)cx + 0.5f, (float)cy + 0.5f, (float)W, (float)H) ||
+                        edge_mask_neighbors(s, clip, nt, keys, &inv_proj, cx, cy, world_normal);
+    if (is_edge) { msaa_resolve(s, clip, nt, k4, cx, cy, rgba32f, rgba16f, p); return; }
+    store_pixel(rgba32f, rgba16f, p, ov4(c.color.x, c.color.y, c.color.z, c.alpha));
 }
 
 int oracle_shade(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
@@ -775,6 +907,9 @@ int oracle_shade(const OracleScene* s, const float* clip, const float* nt, const
     if (rgba16f) memset(rgba16f, 0, (size_t)W * H * 8);
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
     for (int cy = (int)y0; cy < (int)y1; cy++)
-        for (int cx = 0; cx < (int)W; cx++) shade_pixel(s, clip, nt, keys, cx, cy, rgba32f, rgba16f);
+        for (int cx = 0; cx < (int)W; cx++) {
+            if (s->msaa == 4u) shade_pixel_msaa(s, clip, nt, keys, cx, cy, rgba32f, rgba16f);
+            else shade_pixel(s, clip, nt, keys, cx, cy, rgba32f, rgba16f);
+        }
     return 0;
 }

@@ -37,7 +37,8 @@ class OracleScene(C.Structure):
                 ("y0", C.c_uint32), ("y1", C.c_uint32), ("draws", C.POINTER(AwsmDraw)), ("n_draws", C.c_uint32), ("has_opaque", C.c_uint32),
                 ("n_tex_arrays", C.c_uint32), ("tex_arrays", OracleTexArray * MAX_TEX), ("n_samplers", C.c_uint32),
                 ("samplers", AwsmSampler * MAX_SAMPLERS), ("skybox_rgba", C.c_float * 4), ("prefiltered_rgb", C.c_float * 4),
-                ("irradiance_rgb", C.c_float * 4), ("brdf_lut_rg16f", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32)]
+                ("irradiance_rgb", C.c_float * 4), ("brdf_lut_rg16f", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
+                ("msaa", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:
@@ -86,7 +87,7 @@ class OracleFrame:
     """Holds the numpy arrays an OracleScene points at and runs the three oracle stages."""
 
     def __init__(self, mirrors: Dict[int, bytes], draws: List[dict], width: int, height: int, tex_arrays: List[dict], samplers: List[dict],
-                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True):
+                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True, msaa=0):
         self._keep = []
         s = OracleScene()
         for i in range(BUF_COUNT):
@@ -104,6 +105,9 @@ class OracleFrame:
         s.draws = C.cast(self.draw_arr, C.POINTER(AwsmDraw))
         s.n_draws = len(draws)
         s.has_opaque = 1 if has_opaque else 0
+        assert msaa in (0, 4)
+        s.msaa = msaa
+        self.msaa = msaa
         s.n_tex_arrays = len(tex_arrays)
         for i, t in enumerate(tex_arrays):
             arr = np.ascontiguousarray(t["texels"], dtype=np.uint8)
@@ -126,7 +130,7 @@ class OracleFrame:
         self.n_verts = int(lib().oracle_total_vertices(C.byref(s)))
         self.clip = np.zeros((max(1, self.n_verts), 4), dtype=np.float32)
         self.nt = np.zeros((max(1, self.n_verts), 8), dtype=np.float32)
-        self.keys = np.zeros((height, width), dtype=np.uint64)
+        self.keys = np.zeros((height, width, 4) if msaa == 4 else (height, width), dtype=np.uint64)   # msaa: [y][x][sample]
         self.rgba32f = np.zeros((height, width, 4), dtype=np.float32)
         self.rgba16f = np.zeros((height, width, 4), dtype=np.uint16)
 
@@ -148,15 +152,15 @@ class OracleFrame:
         return self.transform().raster(threads).shade(threads)
 
     def unpack_visibility(self):
-        tri = np.zeros((self.height, self.width), dtype=np.uint32)
-        meta = np.zeros((self.height, self.width), dtype=np.uint32)
-        depth = np.zeros((self.height, self.width), dtype=np.float32)
+        tri = np.zeros(self.keys.shape, dtype=np.uint32)
+        meta = np.zeros(self.keys.shape, dtype=np.uint32)
+        depth = np.zeros(self.keys.shape, dtype=np.float32)
         assert lib().oracle_unpack_visibility(C.byref(self.scene), self.keys.ctypes.data_as(C.c_void_p), tri.ctypes.data_as(C.c_void_p),
                                               meta.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p)) == 0
         return tri, meta, depth
 
 
-def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True) -> OracleFrame:
+def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0) -> OracleFrame:
     sc = model.scene
     return OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,
-                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque)
+                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque, msaa=msaa)

@@ -15,16 +15,16 @@ def build_model(scene):
     return m
 
 
-def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8):
-    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque).run(threads)
+def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0):
+    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa).run(threads)
 
 
-def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None):
+def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0):
     """Drive one frame through the C-ABI exactly as the host layer does: create+write every mirror, then the passes."""
     from awsm_renderer_amd.hip_backend import HipDevice
     sc = model.scene
     dev = dev or HipDevice(parity_tap=True)
-    dev.resize(sc.width, sc.height, 0)
+    dev.resize(sc.width, sc.height, msaa)
     dev.upload_mirrors(model.mirrors())
     for i, t in enumerate(model.texture_arrays()):
         dev.texture_array_upload(i, t["texels"])
@@ -70,7 +70,8 @@ def compare_frames(orc, dev, rows=None, rgb_tol=1e-4):
     out["nt_mismatch"] = int((nt.view(np.uint32) != orc.nt.view(np.uint32)).any(axis=1).sum()) if orc.n_verts else 0
     keys = dev.read_visibility()
     out["key_mismatch"] = int((keys[y0:y1] != orc.keys[y0:y1]).sum())
-    out["covered"] = int((orc.keys[y0:y1] != NO_HIT).sum())
+    hit = orc.keys[y0:y1] != NO_HIT
+    out["covered"] = int((hit.any(axis=2) if hit.ndim == 3 else hit).sum())     # pixels with any sample hit
     f32 = dev.read_opaque_f32()
     ref = orc.rgba32f[y0:y1].astype(np.float64)
     diff = np.abs(f32[y0:y1].astype(np.float64) - ref)

@@ -247,3 +247,49 @@ def test_full_size_4k_frame_properties(oracle_lut):
     mine = np.array(sharding.band_rows(sc.height, 4, 2))
     assert (dev.read_visibility()[mine] == keys[mine]).all() and (dev.read_opaque()[mine] == img[mine]).all()
     dev.close()
+
+
+# ------------------------------------------------------------------------------------------------ MSAA x4 (the reference's default AntiAliasing)
+def _check_msaa(scene, lut):
+    model = helpers.build_model(scene)
+    orc = helpers.oracle_frame(model, lut, msaa=4)
+    dev, stats = helpers.hip_frame(model, lut, msaa=4)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    dev.close()
+    assert r["clip_mismatch"] == 0 and r["nt_mismatch"] == 0 and r["key_mismatch"] == 0, r      # four samples per pixel, bit-exact
+    assert stats["covered_pixels"] == r["covered"] > 0, (stats, r)
+    assert r["rgb_over_tol"] == 0 and r["alpha_mismatch"] == 0 and r["f16_max_ulp"] <= 2, r
+    return orc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["box", "helmet", "skinned_morph", "atrium", "zoo"])
+def test_msaa4_geometry_and_edge_resolve(name, oracle_lut):
+    """resize(.., msaa=4): per-sample visibility keys bit-exact; edge detection (strict) + per-sample resolve within the
+    shading tolerance.  A flipped edge decision would show up as a large error on that pixel."""
+    sc = {"box": lambda: scenes.box_scene(160, 120), "helmet": lambda: scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=64),
+          "skinned_morph": lambda: scenes.skinned_morph_scene(320, 200, around=16, along=24, tex_size=16),
+          "atrium": lambda: scenes.atrium_scene(641, 363, detail=0.25, tex_scale=1 / 32),
+          "zoo": lambda: scenes.material_zoo_scene(400, 300)}[name]()
+    orc = _check_msaa(sc, oracle_lut)
+    if name == "atrium":   # the scene must actually exercise both outcomes of the edge test
+        ranks = orc.keys & np.uint64(0xFFFFFFFF)
+        assert 0.05 < float((ranks != ranks[..., :1]).any(axis=2).mean()) < 0.95
+
+
+@pytest.mark.gpu
+def test_msaa4_excludes_sharding_and_switches_back(oracle_lut):
+    from awsm_renderer_amd.hip_backend import HipDevice, AwsmHipError
+    sc = scenes.box_scene(96, 64)
+    model = helpers.build_model(sc)
+    dev, _ = helpers.hip_frame(model, oracle_lut, msaa=4)
+    for call in (lambda: dev.set_shard_bands(2, 0), lambda: dev.set_shard_rows(0, 32)):
+        with pytest.raises(AwsmHipError):
+            call()
+    dev.resize(sc.width, sc.height, 0)                       # back to single-sample on the same context
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); dev.frame_end()
+    orc = helpers.oracle_frame(model, oracle_lut)
+    assert (dev.read_visibility() == orc.keys).all()
+    with pytest.raises(AwsmHipError):
+        dev.resize(sc.width, sc.height, 2)
+    dev.close()
