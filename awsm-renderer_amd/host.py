@@ -84,7 +84,8 @@ def load_library():
         "awsm_host_camera_update": (C.c_int, [vp, F32P, F32P, F32P]), "awsm_host_env": (C.c_int, [vp, vp]),
         "awsm_host_brdf_lut_generate": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_resize": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
-        "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]), "awsm_host_update_transforms": (C.c_int, [vp]),
+        "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+        "awsm_host_set_anti_aliasing": (C.c_int, [vp, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
         "awsm_host_texture_array_info": (C.c_int, [vp, C.c_uint32, U32P, U32P, U32P, C.POINTER(vp)]),
@@ -283,6 +284,10 @@ class Host:
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_host_set_shard_rows(self.h, y0, y1), "set_shard_rows")
 
+    def set_anti_aliasing(self, msaa_sample_count: int = 0):
+        """AwsmRenderer::set_anti_aliasing: 0 (None) or 4 (the reference's default)."""
+        self._chk(self.lib.awsm_host_set_anti_aliasing(self.h, msaa_sample_count), "set_anti_aliasing")
+
     def pick(self, x: int, y: int):
         """AwsmRenderer::pick: the MeshKey under pixel (x, y) of the last rendered frame, or None (PickResult::Miss)."""
         hit, key = C.c_uint32(0), C.c_uint64(0)
@@ -440,9 +445,10 @@ class Renderer:
     """Convenience wrapper: Host + populated scene, frame loop = update_all -> render (crates/renderer/src/update.rs, render.rs)."""
 
     def __init__(self, scene: SceneDesc, backend_path: Optional[str] = None, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False,
-                 lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024):
+                 lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024, msaa: int = 0):
         self.scene = scene
         self.host = Host(backend_path, device, stream, parity_tap)
+        self.host.set_anti_aliasing(msaa)       # AwsmRendererBuilder::with_anti_aliasing (None here unless asked: BASELINE configs are single-sampled)
         self.host.resize(scene.width, scene.height)
         self.keys = populate(self.host, scene)
         if lut_rgba16f is not None:

@@ -173,6 +173,7 @@ struct AwsmHost {
     Mat4 cam_view = mat4_identity(), cam_proj = mat4_identity();
     uint32_t frame_count = 0;
     uint32_t width = 0, height = 0;
+    uint32_t msaa_sample_count = 0;   // AntiAliasing::msaa_sample_count: 0 = None, 4 = Some(4)
 
     bool created[AWSM_BUF_COUNT] = {};
     uint64_t upload_bytes = 0;
@@ -765,10 +766,18 @@ int awsm_host_camera_update(AwsmHost* h, const float view[16], const float proje
 int awsm_host_env(AwsmHost* h, const AwsmEnv* env) { int rc = h->be.env_upload(h->ctx, env); return rc ? dev_fail(h, rc, "env_upload") : AWSM_OK; }
 int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t ht) { int rc = h->be.brdf_lut_generate(h->ctx, w, ht); return rc ? dev_fail(h, rc, "brdf_lut_generate") : AWSM_OK; }
 int awsm_host_resize(AwsmHost* h, uint32_t w, uint32_t ht) {
-    int rc = h->be.resize(h->ctx, w, ht, 0);
+    int rc = h->be.resize(h->ctx, w, ht, h->msaa_sample_count);
     if (rc) return dev_fail(h, rc, "resize");
     h->width = w; h->height = ht;
     return AWSM_OK;
+}
+// AwsmRenderer::set_anti_aliasing (anti_alias.rs:42-45): msaa_sample_count None (0) or Some(4); other counts are
+// AwsmError::UnsupportedMsaaCount (anti_alias.rs:19-25).  The render targets are recreated (TextureViewRecreate).
+int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count) {
+    if (!h) return AWSM_ERR_INVALID_ARGUMENT;
+    if (msaa_sample_count != 0 && msaa_sample_count != 4) { h->last_error = "UnsupportedMsaaCount"; return AWSM_ERR_UNSUPPORTED; }
+    h->msaa_sample_count = msaa_sample_count;
+    return h->width ? awsm_host_resize(h, h->width, h->height) : AWSM_OK;
 }
 int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1) { int rc = h->be.set_shard_rows(h->ctx, y0, y1); return rc ? dev_fail(h, rc, "set_shard_rows") : AWSM_OK; }
 // picker.rs:55-121: PickResult::Hit(MeshKey) / Miss for the pixel under the cursor, from the last rendered frame

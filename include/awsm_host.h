@@ -121,6 +121,8 @@ int awsm_host_camera_update(AwsmHost* h, const float view[16], const float proje
 int awsm_host_env(AwsmHost* h, const AwsmEnv* env);
 int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t height);
 int awsm_host_resize(AwsmHost* h, uint32_t width, uint32_t height);
+/* AwsmRenderer::set_anti_aliasing (anti_alias.rs:42-45): msaa_sample_count 0 (None) or 4; recreates the render targets */
+int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count);
 int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1);
 /* AwsmRenderer::pick (picker.rs:55-121): *hit = 1 and *mesh_key = the MeshKey (KeyData::as_ffi) under pixel (x, y) of the last frame, else *hit = 0 */
 int awsm_host_pick(AwsmHost* h, int32_t x, int32_t y, uint32_t* hit, uint64_t* mesh_key);

@@ -293,3 +293,24 @@ def test_msaa4_excludes_sharding_and_switches_back(oracle_lut):
     with pytest.raises(AwsmHipError):
         dev.resize(sc.width, sc.height, 2)
     dev.close()
+
+
+@pytest.mark.gpu
+def test_msaa4_through_host_layer(oracle_lut):
+    """AwsmRenderer::set_anti_aliasing(Some(4)) through the C++ host: same bar; switching back to None re-renders single-sampled."""
+    sc = scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=64)
+    model = helpers.build_model(sc)
+    orc4 = helpers.oracle_frame(model, oracle_lut, msaa=4)
+    r, dev, stats = helpers.host_frame(sc, oracle_lut, msaa=4)
+    res = helpers.compare_frames(orc4, dev, rgb_tol=RGB_TOL)
+    assert res["key_mismatch"] == 0 and res["rgb_over_tol"] == 0 and res["f16_max_ulp"] <= 2 and stats["covered_pixels"] == res["covered"], (res, stats)
+    assert r.host.pick(160, 90) == dev.pick(160, 90)[0]
+    r.host.set_anti_aliasing(0)
+    dev.msaa = 0
+    r.render(sync=True)
+    orc1 = helpers.oracle_frame(model, oracle_lut)
+    res1 = helpers.compare_frames(orc1, dev, rgb_tol=RGB_TOL)
+    assert res1["key_mismatch"] == 0 and res1["rgb_over_tol"] == 0, res1
+    with pytest.raises(Exception):
+        r.host.set_anti_aliasing(2)
+    r.close()
