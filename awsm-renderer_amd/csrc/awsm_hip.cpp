@@ -188,11 +188,14 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     memset(f, 0, sizeof *f);
     uint32_t y0, y1;
     shard(c, &y0, &y1);
-    f->width = c->width; f->height = c->height; f->y0 = y0; f->y1 = y1;
+    f->width = c->width; f->height = c->height; f->y0 = y0; f->y1 = y1; f->sy0 = y0; f->sy1 = y1;
+    if (c->msaa && (y0 > 0 || y1 < c->height)) {   // MSAA edge detector reads the rows next to the shard: rasterise one halo row each side
+        f->y0 = y0 > 0 ? y0 - 1 : 0; f->y1 = std::min(c->height, y1 + 1);
+    }
     f->tiles_x = (c->width + kTile - 1) / kTile;
     f->band_n = 1; f->band_r = 0; f->out_compact = 0;
-    f->tile_row0 = y0 >> kTileShift;
-    f->tiles_y = (y1 > y0) ? ((y1 + kTile - 1) / kTile - f->tile_row0) : 0;
+    f->tile_row0 = f->y0 >> kTileShift;
+    f->tiles_y = (f->y1 > f->y0) ? ((f->y1 + kTile - 1) / kTile - f->tile_row0) : 0;
     if (c->band_n > 1) {   // band mode: every band_n-th 32-row tile row, starting at band_r (row range is the full frame)
         const uint32_t rows_full = (c->height + kTile - 1) / kTile;
         f->band_n = c->band_n; f->band_r = c->band_r; f->out_compact = c->band_compact;
@@ -262,7 +265,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
     }
     int rc = sync_scene(c);
     if (rc) return rc;
-    if (f.y1 > f.y0) awsm_launch_shade(c->scene_dev, &f, c->stream);
+    if (f.sy1 > f.sy0) awsm_launch_shade(c->scene_dev, &f, c->stream);
     if ((rc = record(c, EV_SHADE))) return rc;
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
@@ -397,7 +400,7 @@ int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t com
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_bands before resize");
     if (n == 0 || r >= n) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_bands: need r < n (got n=%u r=%u)", n, r);
-    if (n > 1 && c->msaa) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_bands: the MSAA edge detector reads neighbouring pixels across shard borders (needs a halo; SURVEY §8e)");
+    if (n > 1 && c->msaa) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_bands: with MSAA use set_shard_rows (row strips carry the one-row halo the edge detector needs; bands would need one per band)");
     c->y0 = c->y1 = 0;                                   // bands and row ranges are alternatives
     c->band_n = n; c->band_r = n > 1 ? r : 0; c->band_compact = (n > 1 && compact_output) ? 1u : 0u;
     return AWSM_OK;
@@ -409,7 +412,7 @@ int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) {
     c->band_n = 1; c->band_r = 0; c->band_compact = 0;   // bands and row ranges are alternatives
     if (y0 == 0 && y1 == 0) { c->y0 = c->y1 = 0; return AWSM_OK; }
     if (y0 >= y1 || y1 > c->height) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need y0 < y1 <= height (got %u,%u)", y0, y1);
-    if (c->msaa && !(y0 == 0 && y1 == c->height)) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_rows: the MSAA edge detector reads neighbouring pixels across shard borders (needs a halo; SURVEY §8e)");
+
     c->y0 = y0; c->y1 = y1;
     return AWSM_OK;
 }

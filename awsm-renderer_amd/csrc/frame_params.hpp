@@ -58,7 +58,8 @@ constexpr size_t kTriRecBytes = 64;
 
 struct FrameDev {
     uint32_t width, height;
-    uint32_t y0, y1;              // shard rows [y0,y1)
+    uint32_t y0, y1;              // rows the geometry pass rasterises: the shard's rows [sy0, sy1), plus one halo row on each side with MSAA
+    uint32_t sy0, sy1;            // rows the opaque pass shades / owns
     uint32_t tiles_x, tiles_y;    // tiles covering the shard: rows [y0>>5, ceil(y1/32))
     uint32_t tile_row0;           // first tile row (32 px) of the shard
     uint32_t band_n, band_r;      // the shard owns the tile rows ty >= tile_row0 with ty % band_n == band_r (1, 0 = every row)

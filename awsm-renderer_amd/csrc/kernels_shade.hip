@@ -687,7 +687,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
 struct ShadeBlock { uint32_t blk, brow; int x0, y0; };
 AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
     const uint32_t bx_n = (f.width + 15u) >> 4;
-    const uint32_t by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.y1 - f.y0) + 15u) >> 4;
+    const uint32_t by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.sy1 - f.sy0) + 15u) >> 4;
     const uint32_t nblk = bx_n * by_n;
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;     // k-th block of this XCD
     const uint32_t rows_x = (by_n + 7u - xcd) >> 3;                 // block rows owned by this XCD
@@ -696,7 +696,7 @@ AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
     if (b.blk >= nblk) return false;
     b.brow = b.blk / bx_n;
     b.x0 = (int)((b.blk % bx_n) << 4);
-    b.y0 = f.band_n > 1u ? (int)(((f.tile_row0 + (b.brow >> 1) * f.band_n) << kTileShift) + ((b.brow & 1u) << 4)) : (int)f.y0 + (int)(b.brow << 4);
+    b.y0 = f.band_n > 1u ? (int)(((f.tile_row0 + (b.brow >> 1) * f.band_n) << kTileShift) + ((b.brow & 1u) << 4)) : (int)f.sy0 + (int)(b.brow << 4);
     return true;
 }
 
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     ShadeBlock b;
     if (!shade_block(f, b)) return;
     const int cx = b.x0 + (int)(threadIdx.x & 15u), cy = b.y0 + (int)(threadIdx.x >> 4);
-    if (cx >= (int)f.width || cy >= (int)f.y1) return;                   // compute.wgsl:111-113
+    if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
     const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
     const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
     const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};   // skybox.wgsl:1-41, uniform cube
@@ -740,7 +740,7 @@ struct NeighbourCell { float nx, ny, nz; uint32_t depth_bits; uint32_t state; };
 
 AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& f, int px, int py) {
     NeighbourCell c = {0.0f, 0.0f, 0.0f, 0u, 0u};
-    if (px >= 0 && py >= 0 && px < (int)f.width && py < (int)f.height) {
+    if (px >= 0 && px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) {   // rasterised rows: the shard's + one halo row each side
         const unsigned long long k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
         c.state = 1u;
         if (k != ~0ull) {
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     const uint32_t tid = threadIdx.x;
     const int lx = (int)(tid & 15u), ly = (int)(tid >> 4);
     const int cx = b.x0 + lx, cy = b.y0 + ly;
-    const bool inside = cx < (int)f.width && cy < (int)f.height;
+    const bool inside = cx < (int)f.width && cy < (int)f.sy1;            // rows below sy0 never occur (blocks start at sy0)
     if (tid == 0) n_edges = 0u;
 
     // ---- phase 1: G-buffer texel of sample 0 for every pixel of the block + the halo ring, normals into LDS ----
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     g0.packed_nt = {0.0f, 0.0f, 0.0f, 0.0f}; g0.bx = 0.0f; g0.by = 0.0f;
     {
         NeighbourCell c = {0.0f, 0.0f, 0.0f, 0u, 0u};
-        if (inside) {
+        if (cx < (int)f.width && cy < (int)f.y1) {    // also the halo row below the shard when it falls inside this block
             const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + ((size_t)cy * f.width + (size_t)cx) * 4);
             const ulonglong2 ka = kp[0], kb = kp[1];
             k4[0] = ka.x; k4[1] = ka.y; k4[2] = kb.x; k4[3] = kb.y;
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256) void k_count_covered(const unsigned long long*
 // picker_wgsl/compute.wgsl: one thread; out = {valid, mesh_key_high, mesh_key_low, triangle_index}
 __global__ void k_pick(const DevScene* __restrict__ sc, FrameDev f, int x, int y, uint32_t* __restrict__ out) {
     out[0] = 0u; out[1] = 0u; out[2] = 0u; out[3] = 0xFFFFFFFFu;
-    if (x < 0 || y < 0 || x >= (int)f.width || y < (int)f.y0 || y >= (int)f.y1) return;
+    if (x < 0 || y < 0 || x >= (int)f.width || y < (int)f.sy0 || y >= (int)f.sy1) return;
     if (f.band_n > 1u && (((uint32_t)y >> kTileShift) % f.band_n) != f.band_r) return;
     const unsigned long long key = f.vis[((size_t)y * f.width + (size_t)x) * (f.msaa == 4u ? 4u : 1u)];   // MSAA: sample 0, as the picker's textureLoad(.., 0)
     if (key == ~0ull) return;
@@ -959,7 +959,7 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 }  // namespace awsm
 
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
-    const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->y1 - f->y0) + 15u) >> 4;
+    const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     if (!nb) return;
@@ -971,7 +971,7 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
     }
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
-    if (f->y1 > f->y0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->y0, f->y1, f->band_n, f->band_r, f->msaa, f->counters + 3);
+    if (f->sy1 > f->sy0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->sy0, f->sy1, f->band_n, f->band_r, f->msaa, f->counters + 3);
 }
 extern "C" void awsm_launch_pick(const awsm::DevScene* sc, const awsm::FrameDev* f, int x, int y, uint32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_pick, dim3(1), dim3(1), 0, s, sc, *f, x, y, out);

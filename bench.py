@@ -138,22 +138,26 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa)
-    if args.msaa and world > 1:
-        raise SystemExit("--msaa 4 with --gpus > 1: MSAA and sharding exclude each other for now (edge detector needs a halo)")
     from awsm_renderer_amd.hip_backend import HipDevice
     dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
     # N > 1: 32-row bands dealt round-robin over the ranks (rank r owns tile rows r, r+N, ...: every rank gets 1/N of the
     # dense part of the screen), compact [L*32, W] output per rank, RCCL all-gather -> [N, L, 32, W], de-interleaved by
     # bands_to_image.  Double-buffered: frame i is gathered (RCCL's stream) while frame i+1 renders.
+    # With --msaa 4 the shards are contiguous row strips instead (they carry the one-row halo the MSAA edge detector needs).
+    strips = bool(args.msaa) and world > 1
     L = bands_per_rank(H, world)
-    rows_out = L * 32 if world > 1 else H
+    per = (H + world - 1) // world                      # rows per strip
+    y0s, y1s = min(rank * per, H), min(rank * per + per, H)
+    rows_out = (per if strips else L * 32) if world > 1 else H
     n_buf = 2 if world > 1 else 1
-    gathered = [torch.zeros((world, L, 32, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)] if world > 1 else None
+    gathered = [torch.zeros((world, rows_out, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)] if world > 1 else None
     image = [torch.zeros((H, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)]       # what every rank ends up holding
     mine = [torch.zeros((rows_out, W, 4), dtype=torch.float16, device="cuda") for _ in range(n_buf)] if world > 1 else None
     pending = [None] * n_buf
     frame_no = [0]
-    if world > 1:
+    if strips:
+        r.host.set_shard_rows(y0s, y1s)
+    elif world > 1:
         r.host.set_shard_bands(world, rank, compact_output=True)
     else:
         dev.bind_output(image[0].data_ptr(), H * W * 8)
@@ -178,7 +182,10 @@ def main():
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-            image[b].copy_(bands_to_image(gathered[b], H, world))
+            if strips:
+                image[b].copy_(gathered[b].view(world * rows_out, W, 4)[:H])
+            else:
+                image[b].copy_(bands_to_image(gathered[b].view(world, L, 32, W, 4), H, world))
 
     def step():
         r.host.camera_update(scene.view, scene.proj, scene.camera_position)
@@ -188,7 +195,10 @@ def main():
         b = frame_no[0] % n_buf
         frame_no[0] += 1
         finish(b)                      # frame i-2 used these buffers: complete it before they are overwritten
-        dev.bind_output(mine[b].data_ptr(), rows_out * W * 8)
+        if strips:   # the kernels address the image by absolute row: a base pointer such that row y0s lands on mine[b][0]
+            dev.bind_output(mine[b].data_ptr() - y0s * W * 8, H * W * 8)
+        else:
+            dev.bind_output(mine[b].data_ptr(), rows_out * W * 8)
         r.host.render(sync=False)
         pending[b] = all_gather(gathered[b].view(world * rows_out, W, 4), mine[b])
 
@@ -223,12 +233,19 @@ def main():
         last = (frame_no[0] - 1) % n_buf
         got = image[last].clone()
         ref = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
-        r.host.set_shard_bands(1, 0)
+        if strips:
+            r.host.set_shard_rows(0, 0)
+        else:
+            r.host.set_shard_bands(1, 0)
         dev.bind_output(ref.data_ptr(), H * W * 8)
         r.host.render(sync=True)
         check = "ok" if torch.equal(got.view(torch.int16), ref.view(torch.int16)) else "MISMATCH"
-        r.host.set_shard_bands(world, rank, compact_output=True)
-        dev.bind_output(mine[0].data_ptr(), rows_out * W * 8)
+        if strips:
+            r.host.set_shard_rows(y0s, y1s)
+            dev.bind_output(mine[0].data_ptr() - y0s * W * 8, H * W * 8)
+        else:
+            r.host.set_shard_bands(world, rank, compact_output=True)
+            dev.bind_output(mine[0].data_ptr(), rows_out * W * 8)
         if check != "ok":
             raise SystemExit(f"rank {rank}: gathered image differs from the unsharded frame")
 
@@ -241,7 +258,7 @@ def main():
             acc[k] = acc.get(k, 0.0) + float(v)
     st = {k: v / max(1, args.profile_frames) for k, v in acc.items()}
     kernel_ms = {"k_deform_transform": st["ms_transform"], "k_bin": st["ms_bin"], "k_raster_tile": st["ms_raster"], "k_shade": st["ms_shade"]}
-    rows_mine = H if world == 1 else len(band_rows(H, world, rank))
+    rows_mine = H if world == 1 else (y1s - y0s if strips else len(band_rows(H, world, rank)))
     alg = algorithmic_bytes(scene, {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}, rows_mine)
     dom = max(kernel_ms, key=kernel_ms.get)
     achieved = alg[dom] / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
@@ -260,6 +277,13 @@ def main():
 
     if world > 1:
         dist.barrier()
+    if world == 1:
+        sharding_desc = "none"
+    elif strips:
+        sharding_desc = f"{world} row strips of {per} rows (+1-row halo for the MSAA edge detector) + RCCL all-gather of the RGBA16F image, overlapped with the next frame"
+    else:
+        sharding_desc = (f"32-row bands round-robin over {world} ranks ({L} bands each) + RCCL all-gather of the RGBA16F image + de-interleave; "
+                         f"gather of frame i overlapped with the render of frame i+1 (double-buffered)")
     if rank == 0:
         out = {
             "metric": "frames/sec + shaded Mpix/s, 4K Sponza glTF, 1/2/4/8 MI355X",
@@ -269,8 +293,7 @@ def main():
             "config": {"workload": f"Sponza-class procedural atrium (configs[3]): {n_tris} triangles, {len(scene.materials)} materials, "
                                    f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + ", MipmapMode::None",
                        "triangles": n_tris, "width": W, "height": H,
-                       "sharding": "none" if world == 1 else f"32-row bands round-robin over {world} ranks ({L} bands each) + RCCL all-gather of the RGBA16F image "
-                                                             f"+ de-interleave; gather of frame i overlapped with the render of frame i+1 (double-buffered)",
+                       "sharding": sharding_desc,
                        "draws": len(r.host.draw_list())},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels")},
             "roofline": roofline,

@@ -159,7 +159,8 @@ int awsm_hip_buffer_write(AwsmHipCtx* ctx, AwsmBuf which, size_t dst_off, const 
  * four visibility samples per pixel at WebGPU's standard 4x positions (per-sample coverage and depth; the interpolants
  * are evaluated at the pixel centre, as @interpolate(perspective, center) does), and the opaque pass runs the edge
  * detector + per-sample resolve of material_opaque_wgsl/helpers/{msaa,material_shading}.wgsl.  The output image stays
- * single-sampled.  MSAA and sharding exclude each other for now (the edge detector reads neighbouring pixels). ---- */
+ * single-sampled.  Sharding with MSAA: row strips (awsm_hip_set_shard_rows; one halo row each side is rasterised for the
+ * edge detector); bands are refused. ---- */
 int awsm_hip_resize(AwsmHipCtx* ctx, uint32_t width, uint32_t height, uint32_t msaa);
 
 /* ---- multi-GPU screen sharding (new; no reference counterpart): this ctx rasterises and shades only

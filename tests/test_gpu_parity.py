@@ -146,7 +146,8 @@ def test_band_sharding_rows_identical_to_full_frame(oracle_lut, n):
 
 
 @pytest.mark.gpu
-def test_bench_two_rank_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("msaa", [0, 4])
+def test_bench_two_rank_rehearsal_on_one_gpu(msaa):
     """bench.py's N > 1 path (band sharding, compact outputs, double-buffered gather, de-interleave) run as two processes
     sharing this box's one GPU, with the collectives staged through gloo; --check compares the gathered image with an
     unsharded render bit for bit.  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)"""
@@ -156,7 +157,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     env = dict(os.environ, AWSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--width", "640", "--height", "363", "--detail", "0.125",
-           "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1"]
+           "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1", "--msaa", str(msaa)]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -278,14 +279,13 @@ def test_msaa4_geometry_and_edge_resolve(name, oracle_lut):
 
 
 @pytest.mark.gpu
-def test_msaa4_excludes_sharding_and_switches_back(oracle_lut):
+def test_msaa4_excludes_band_sharding_and_switches_back(oracle_lut):
     from awsm_renderer_amd.hip_backend import HipDevice, AwsmHipError
     sc = scenes.box_scene(96, 64)
     model = helpers.build_model(sc)
     dev, _ = helpers.hip_frame(model, oracle_lut, msaa=4)
-    for call in (lambda: dev.set_shard_bands(2, 0), lambda: dev.set_shard_rows(0, 32)):
-        with pytest.raises(AwsmHipError):
-            call()
+    with pytest.raises(AwsmHipError):
+        dev.set_shard_bands(2, 0)                          # bands + MSAA: not supported (each band would need its own halo rows)
     dev.resize(sc.width, sc.height, 0)                       # back to single-sample on the same context
     dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); dev.frame_end()
     orc = helpers.oracle_frame(model, oracle_lut)
@@ -314,3 +314,22 @@ def test_msaa4_through_host_layer(oracle_lut):
     with pytest.raises(Exception):
         r.host.set_anti_aliasing(2)
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [(0, 121), (121, 250), (250, 363), (96, 97)])
+def test_msaa4_row_strips_carry_the_edge_detector_halo(oracle_lut, rows):
+    """MSAA + set_shard_rows: the geometry pass rasterises one extra row on each side of the strip so that the edge detector
+    sees the same neighbours as in the unsharded frame; the strip's rows of the image are bit-identical to the full frame's."""
+    sc = scenes.atrium_scene(641, 363, detail=0.25, tex_scale=1 / 32)
+    model = helpers.build_model(sc)
+    dev, _ = helpers.hip_frame(model, oracle_lut, msaa=4)
+    full_img, full_f32, full_keys = dev.read_opaque(), dev.read_opaque_f32(), dev.read_visibility()
+    dev.set_shard_rows(*rows)
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); st = dev.frame_end()
+    y0, y1 = rows
+    assert (dev.read_visibility()[y0:y1] == full_keys[y0:y1]).all()
+    assert (dev.read_opaque_f32()[y0:y1].view(np.uint32) == full_f32[y0:y1].view(np.uint32)).all()
+    assert (dev.read_opaque()[y0:y1] == full_img[y0:y1]).all()
+    assert st["covered_pixels"] == int((full_keys[y0:y1] != helpers.NO_HIT).any(axis=2).sum())
+    dev.close()
