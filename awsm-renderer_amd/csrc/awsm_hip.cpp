@@ -18,6 +18,8 @@ using namespace awsm;
 
 extern "C" {
 void awsm_launch_bin_big(const FrameDev* f, int fill, hipStream_t s);
+void awsm_launch_gen_mip_level(uint8_t* chain, uint32_t src_off, uint32_t dst_off, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, uint32_t layers,
+                               const uint32_t* kinds, hipStream_t s);
 void awsm_launch_pick(const DevScene* sc, const FrameDev* f, int x, int y, uint32_t* out, hipStream_t s);
 void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
 void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s);
@@ -61,6 +63,7 @@ struct AwsmHipCtx {
     uint32_t y0 = 0, y1 = 0;     // shard rows (0,0 = full)
     uint32_t band_n = 1, band_r = 0, band_compact = 0;   // shard bands (awsm_hip_set_shard_bands)
     uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
+    DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
     DevBuf vis, out16, out32;
     void* bound_out = nullptr;
@@ -259,6 +262,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
     FrameDev f;
     fill_frame(c, &f);
     f.has_opaque = c->last_opaque.has_opaque;
+    f.mipmap = c->last_opaque.mipmap;
     if (c->bound_out) {
         const size_t need = (f.out_compact ? (size_t)f.tiles_y * kTile : (size_t)c->height) * c->width * 8;
         if (c->bound_out_bytes < need) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "opaque_pass: bound output holds %zu bytes, this shard layout writes %zu", c->bound_out_bytes, need);
@@ -269,6 +273,12 @@ int enqueue_opaque(AwsmHipCtx* c) {
     if ((rc = record(c, EV_SHADE))) return rc;
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
+}
+
+uint32_t mip_levels_full(uint32_t w, uint32_t h) {   // calculate_mipmap_levels (renderer-core/src/texture/mipmap.rs:60-62)
+    uint32_t m = std::max(w, h), n = 0;
+    while (m > 1u) { m >>= 1; n++; }
+    return n + 1u;
 }
 
 int ensure_bin_capacity(AwsmHipCtx* c, uint32_t entries) {
@@ -328,7 +338,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->vis); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_rec); fr(c->tri_flags);
+    fr(c->lut); fr(c->vis); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_rec); fr(c->tri_flags);
     fr(c->draws_dev); fr(c->draw_shade); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->big_list); fr(c->counters);
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
@@ -422,17 +432,53 @@ int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t array_idx, uint32_t wi
     if (!c || array_idx >= (uint32_t)kMaxTexArrays || !texels || width == 0 || height == 0 || layers == 0)
         return fail(c, AWSM_ERR_INVALID_ARGUMENT, "texture_array_upload: bad argument");
     if (fmt != AWSM_TEX_RGBA8_UNORM) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: only RGBA8_UNORM");
-    if (mips > 1) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: mip chains need MipmapMode::Gradient (SURVEY §8f)");
+    const uint32_t full = mip_levels_full(width, height);
+    if (mips == 0) mips = 1;
+    if (mips > full || mips > (uint32_t)kMaxMipLevels) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "texture_array_upload: %u mip levels, a %ux%u texture has at most %u", mips, width, height, full);
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t bytes = (size_t)width * height * layers * 4;
-    int rc = dev_realloc(c, c->tex[array_idx], bytes, false);
+    TexArrayDev t{};
+    size_t texels_total = 0;
+    for (uint32_t l = 0; l < mips; l++) { t.level_off[l] = (uint32_t)texels_total; texels_total += (size_t)layers * std::max(1u, width >> l) * std::max(1u, height >> l); }
+    if (texels_total > 0xFFFFFFFFull) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: array larger than 2^32 texels");
+    const size_t bytes0 = (size_t)width * height * layers * 4;
+    int rc = dev_realloc(c, c->tex[array_idx], texels_total * 4 + 16, false);   // +16: the shade kernel's paired row loads may read one texel past the end
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->tex[array_idx].ptr, texels, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tex[array_idx].ptr, texels, bytes0, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    TexArrayDev& t = c->scene.tex[array_idx];
-    t.texels = (const uint8_t*)c->tex[array_idx].ptr; t.width = width; t.height = height; t.layers = layers;
+    t.texels = (const uint8_t*)c->tex[array_idx].ptr; t.width = width; t.height = height; t.layers = layers; t.mips = mips;
+    c->scene.tex[array_idx] = t;
     c->scene.n_tex = std::max(c->scene.n_tex, array_idx + 1);
     c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_texture_array_generate_mips(AwsmHipCtx* c, uint32_t array_idx, const uint32_t* kind_per_layer) {
+    if (!c || array_idx >= (uint32_t)kMaxTexArrays) return AWSM_ERR_INVALID_ARGUMENT;
+    const TexArrayDev& t = c->scene.tex[array_idx];
+    if (!t.texels) return fail(c, AWSM_ERR_NOT_READY, "generate_mips: array %u was never uploaded", array_idx);
+    if (t.mips < 2) return AWSM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint32_t> kinds(t.layers, 0u);
+    if (kind_per_layer) kinds.assign(kind_per_layer, kind_per_layer + t.layers);
+    int rc = dev_reserve(c, c->mip_kinds, kinds.size() * 4);
+    if (rc) return rc;
+    if ((rc = upload_small(c, c->mip_kinds.ptr, kinds.data(), kinds.size() * 4))) return rc;
+    for (uint32_t l = 1; l < t.mips; l++)
+        awsm_launch_gen_mip_level((uint8_t*)c->tex[array_idx].ptr, t.level_off[l - 1], t.level_off[l], std::max(1u, t.width >> (l - 1)), std::max(1u, t.height >> (l - 1)),
+                                  std::max(1u, t.width >> l), std::max(1u, t.height >> l), t.layers, (const uint32_t*)c->mip_kinds.ptr, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // mip_kinds may be reused by the next call
+    return AWSM_OK;
+}
+
+int awsm_hip_texture_array_read_level(AwsmHipCtx* c, uint32_t array_idx, uint32_t level, void* out) {
+    if (!c || !out || array_idx >= (uint32_t)kMaxTexArrays) return AWSM_ERR_INVALID_ARGUMENT;
+    const TexArrayDev& t = c->scene.tex[array_idx];
+    if (!t.texels || level >= t.mips) return fail(c, AWSM_ERR_OUT_OF_RANGE, "texture_array_read_level: array %u has %u levels", array_idx, t.mips);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)t.layers * std::max(1u, t.width >> level) * std::max(1u, t.height >> level) * 4;
+    HIPCHK(c, hipMemcpy(out, t.texels + (size_t)t.level_off[level] * 4, n, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
 
@@ -554,7 +600,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
 
 int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
     if (!c || !p) return AWSM_ERR_INVALID_ARGUMENT;
-    if (p->mipmap != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "opaque_pass: MipmapMode::Gradient is not implemented (SURVEY §8f)");
+    if (p->mipmap > 1) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "opaque_pass: mipmap must be 0 (MipmapMode::None) or 1 (MipmapMode::Gradient)");
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass before resize");
     if (p->has_opaque) {
         if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass before geometry_pass");

@@ -36,9 +36,12 @@ struct DrawShadeDev {
     uint32_t pad;
 };
 
+constexpr int kMaxMipLevels = 16;
 struct TexArrayDev {
-    const uint8_t* texels;
-    uint32_t width, height, layers, pad;
+    const uint8_t* texels;            // [level][layer][h_l][w_l] RGBA8, (w >> l).max(1); levels >= 1 valid after generate_mips
+    uint32_t width, height, layers;
+    uint32_t mips;                    // levels reserved (>= 1)
+    uint32_t level_off[kMaxMipLevels];   // first texel of each level
 };
 
 struct DevScene {
@@ -69,6 +72,7 @@ struct FrameDev {
     uint32_t total_verts;
     uint32_t bin_capacity;        // entries in the (triangle,tile) list
     uint32_t has_opaque;
+    uint32_t mipmap;              // 0: MipmapMode::None (level 0 only), 1: MipmapMode::Gradient
     uint32_t msaa;                // 0: one sample per pixel (pixel centre); 4: vis holds [pixel][4 samples]
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)

@@ -532,8 +532,56 @@ __global__ __launch_bounds__(256) void k_upload_words(uint32_t* __restrict__ dst
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_words; i += gridDim.x * 256u) dst[i] = __builtin_nontemporal_load(src_pinned + i);
 }
 
+// generate_mipmaps, one level (renderer-core/src/texture/mipmap.rs:140-250), STRICT f32 so that the RGBA8 results are
+// bit-identical everywhere: 2x2 texel loads clamped to 2 x the destination extent (and to the real source extent), filter
+// by MipmapTextureKind, store as unorm8 = floor(clamp(v,0,1)*255 + 0.5).  One thread per destination texel and layer.
+AWSM_DI uint32_t to_unorm8(float v) {
+    if (!(v > 0.0f)) return 0u;          // also NaN
+    if (v > 1.0f) v = 1.0f;
+    return (uint32_t)floorf(v * 255.0f + 0.5f);
+}
+__global__ __launch_bounds__(256) void k_gen_mip_level(uint32_t* __restrict__ chain, uint32_t src_off, uint32_t dst_off, uint32_t sw, uint32_t sh,
+                                                       uint32_t dw, uint32_t dh, uint32_t layers, const uint32_t* __restrict__ kinds) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= dw * dh * layers) return;
+    const uint32_t x = i % dw, y = (i / dw) % dh, layer = i / (dw * dh);
+    const uint32_t kind = kinds[layer];
+    const uint32_t* src = chain + src_off + (size_t)layer * sw * sh;
+    float r[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t sx = min(min(x * 2u + (uint32_t)(k & 1), dw * 2u - 1u), sw - 1u);
+        uint32_t sy = min(min(y * 2u + (uint32_t)(k >> 1), dh * 2u - 1u), sh - 1u);
+        const uint32_t t = src[(size_t)sy * sw + sx];
+        r[k][0] = (float)(t & 255u) / 255.0f; r[k][1] = (float)((t >> 8) & 255u) / 255.0f;
+        r[k][2] = (float)((t >> 16) & 255u) / 255.0f; r[k][3] = (float)(t >> 24) / 255.0f;
+    }
+    float o0, o1, o2, o3;
+    if (kind == 2u) {            // filter_metallic_roughness
+        float m = 0.0f, r2 = 0.0f, b = 0.0f, al = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m += r[k][0]; r2 += r[k][1] * r[k][1]; b += r[k][2]; al += r[k][3]; }
+        o0 = m * 0.25f; o1 = sqrtf(r2 * 0.25f); o2 = b * 0.25f; o3 = al * 0.25f;
+    } else {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s0 += r[k][0]; s1 += r[k][1]; s2 += r[k][2]; s3 += r[k][3]; }
+        o0 = s0 * 0.25f; o1 = s1 * 0.25f; o2 = s2 * 0.25f; o3 = s3 * 0.25f;          // filter_simple
+        if (kind == 1u) {        // filter_normal: renormalise
+            const f3 n = normalize(mk3(o0 * 2.0f - 1.0f, o1 * 2.0f - 1.0f, o2 * 2.0f - 1.0f));
+            o0 = n.x * 0.5f + 0.5f; o1 = n.y * 0.5f + 0.5f; o2 = n.z * 0.5f + 0.5f;
+        }
+    }
+    chain[dst_off + ((size_t)layer * dh + y) * dw + x] = to_unorm8(o0) | (to_unorm8(o1) << 8) | (to_unorm8(o2) << 16) | (to_unorm8(o3) << 24);
+}
+
 }  // namespace awsm
 
+extern "C" void awsm_launch_gen_mip_level(uint8_t* chain, uint32_t src_off, uint32_t dst_off, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, uint32_t layers,
+                                          const uint32_t* kinds, hipStream_t s) {
+    const uint32_t n = dw * dh * layers;
+    if (n) hipLaunchKernelGGL(awsm::k_gen_mip_level, dim3((n + 255u) / 256u), dim3(256), 0, s, (uint32_t*)chain, src_off, dst_off, sw, sh, dw, dh, layers, kinds);
+}
 extern "C" void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s) {
     const uint32_t nb = (n_words + 255u) / 256u;
     if (nb) hipLaunchKernelGGL(awsm::k_upload_words, dim3(nb < 64u ? nb : 64u), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src_pinned, n_words);

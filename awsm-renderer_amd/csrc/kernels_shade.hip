@@ -25,13 +25,16 @@ namespace awsm {
 struct GBufferTexel {
     f4 packed_nt;    // RGBA16F normal_tangent, already rounded to f16
     float bx, by;    // RG16F barycentric, already rounded to f16
+    f4 bary_derivs;  // RGBA16F barycentric_derivatives (db0/dx, db0/dy, db1/dx, db1/dy), rounded to f16; MipmapMode::Gradient only
 };
 // The interpolants are evaluated at the PIXEL CENTRE (@interpolate(perspective, center)); with MSAA the centre may lie
 // outside the triangle and the values extrapolate — every sample the triangle covers in the pixel gets the same texel.
 // A key in the visibility buffer means the triangle's setup record is valid; its edge coefficients are the bits the
 // raster kernel used.
+template <bool DERIVS>
 AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int cx, int cy) {
     GBufferTexel g;
+    g.bary_derivs = {0.0f, 0.0f, 0.0f, 0.0f};
     TriSetup t;
     tri_rec_load_edges(f.tri_rec + rank, t);
     float e0, e1, e2;
@@ -47,6 +50,19 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
     g.packed_nt = {round_f16(p.x), round_f16(p.y), round_f16(p.z), round_f16(p.w)};
     g.bx = round_f16(b0);
     g.by = round_f16(b1);
+    if (DERIVS) {
+        // fragment.wgsl:46-51 dpdx/dpdy of the barycentrics.  Contract ("fine" derivatives of a 2x2 quad): the difference
+        // between the two pixels of the quad row / column this pixel sits in, both evaluated for THIS triangle (helper
+        // invocations extrapolate), right minus left and bottom minus top; then RGBA16F.
+        float h0, h1, h2, w0, w1, w2;
+        tri_edges(t, cx ^ 1, cy, h0, h1, h2);
+        tri_edges(t, cx, cy ^ 1, w0, w1, w2);
+        const float sh = (h0 + h1) + h2, sv = (w0 + w1) + w2;
+        const float hb0 = h0 / sh, hb1 = h1 / sh, vb0 = w0 / sv, vb1 = w1 / sv;
+        const float ddx0 = (cx & 1) ? b0 - hb0 : hb0 - b0, ddx1 = (cx & 1) ? b1 - hb1 : hb1 - b1;
+        const float ddy0 = (cy & 1) ? b0 - vb0 : vb0 - b0, ddy1 = (cy & 1) ? b1 - vb1 : vb1 - b1;
+        g.bary_derivs = {round_f16(ddx0), round_f16(ddy0), round_f16(ddx1), round_f16(ddy1)};
+    }
     return g;
 }
 
@@ -159,17 +175,14 @@ AWSM_DI float safe_floor(float x, float& frac) {
     return fl;
 }
 AWSM_DI f4 lerp4(f4 a, f4 b, float t) { const float s = 1.0f - t; return {a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t}; }
-// textureSampleLevel(tex, sampler, uv, layer, 0): DESIGN.md §"Texture sampling".  General form: any size, any address
-// mode, nearest or linear.  Out of line (one copy for all fourteen call sites); the hot path below handles the common
-// sampler inline and only falls back here when some lane of the wavefront needs it.
-__device__ __attribute__((noinline)) f4 sample_array_generic(const uint8_t* texels, uint32_t width, uint32_t height, uint32_t layers, uint32_t layer,
-                                                             uint32_t mode_u, uint32_t mode_v, uint32_t mag_filter, float u, float v) {
-    if (texels == nullptr || width == 0u || height == 0u || layers == 0u) return {0.0f, 0.0f, 0.0f, 0.0f};
+// textureSampleLevel(tex, sampler, uv, layer, level) on one level of one layer: DESIGN.md §"Texture sampling".  General
+// form: any size, any address mode, nearest or linear.  Out of line (one copy for all call sites); the hot path below
+// handles the common sampler inline and only falls back here when some lane of the wavefront needs it.
+__device__ __attribute__((noinline)) f4 sample_level_generic(const uint8_t* base, uint32_t width, uint32_t height, uint32_t mode_u, uint32_t mode_v,
+                                                             uint32_t linear, float u, float v) {
     const int W = (int)width, H = (int)height;
-    if (layer >= layers) layer = layers - 1u;
-    const uint8_t* base = texels + (size_t)layer * (size_t)W * (size_t)H * 4u;
     float fx, fy;
-    if (mag_filter == 0u) {
+    if (linear == 0u) {
         const int i = wrap_index((int)safe_floor(u * (float)W, fx), W, mode_u);
         const int j = wrap_index((int)safe_floor(v * (float)H, fy), H, mode_v);
         return texel_rgba8(base + ((size_t)j * W + i) * 4u);
@@ -183,41 +196,9 @@ __device__ __attribute__((noinline)) f4 sample_array_generic(const uint8_t* texe
     const f4 c00 = texel_rgba8(r0 + i0 * 4), c10 = texel_rgba8(r0 + i1 * 4), c01 = texel_rgba8(r1 + i0 * 4), c11 = texel_rgba8(r1 + i1 * 4);
     return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
 }
-
-// ---------------- per-pixel attribute context ----------------
-struct Attr {
-    const DevScene* sc;
-    const float* ad;          // attribute_data (f32 view)
-    uint32_t v0, v1, v2;      // vertex_start of the three corners (floats)
-    uint32_t uv_sets_index;
-    f3 bary;
-    f2 uv0;                   // interpolated TEXCOORD_0, computed once per pixel when a core texture uses it
-    bool has_uv0;
-};
-AWSM_DI f2 attr_uv(const Attr& a, uint32_t set) {                          // texture_uvs.wgsl:64-84
-    const uint32_t o = a.uv_sets_index + set * 2u;
-    const float x0 = a.ad[a.v0 + o], y0 = a.ad[a.v0 + o + 1], x1 = a.ad[a.v1 + o], y1 = a.ad[a.v1 + o + 1];
-    const float x2 = a.ad[a.v2 + o], y2 = a.ad[a.v2 + o + 1];
-    return {a.bary.x * x0 + a.bary.y * x1 + a.bary.z * x2, a.bary.x * y0 + a.bary.y * y1 + a.bary.z * y2};
-}
-AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // texture_uvs.wgsl:64-84,144-187, textures.wgsl:131-150
-    f2 uv = a.uv0;
-    if (!(a.has_uv0 && t.uv_set_index == 0u)) uv = attr_uv(a, t.uv_set_index);
-    const float* tt = reinterpret_cast<const float*>(a.sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
-    const float u = tt[0] * uv.x + tt[1] * uv.y + tt[4], v = tt[2] * uv.x + tt[3] * uv.y + tt[5];
-    if (t.array_index >= a.sc->n_tex || t.sampler_index >= a.sc->n_samplers) return {0.0f, 0.0f, 0.0f, 0.0f};
-    const TexArrayDev& arr = a.sc->tex[t.array_index];
-    const AwsmSampler& smp = a.sc->samplers[t.sampler_index];
-    const uint32_t W = arr.width, H = arr.height, layers = arr.layers;
-    const uint8_t* texels = arr.texels;
-    // Hot path: linear filter, repeat/repeat, power-of-two extent (every texture of a typical glTF scene).  Taken when
-    // ALL lanes of the wavefront qualify (one scalar branch); wrap is a mask, no mode selects, no quotients.
-    const bool fast = smp.mag_filter != 0u && smp.address_mode_u == 1u && smp.address_mode_v == 1u && texels != nullptr && layers != 0u &&
-                      W != 0u && H != 0u && (W & (W - 1u)) == 0u && (H & (H - 1u)) == 0u;
-    if (__builtin_amdgcn_ballot_w64(!fast) != 0ull)
-        return sample_array_generic(texels, W, H, layers, t.layer_index, smp.address_mode_u, smp.address_mode_v, smp.mag_filter, u, v);
-    const uint32_t layer = min(t.layer_index, layers - 1u);
-    const uint32_t* base = reinterpret_cast<const uint32_t*>(texels) + (size_t)layer * (size_t)W * (size_t)H;
+// The common sampler (linear, repeat/repeat, power-of-two extent) inline: wrap is a mask, no mode selects, no quotients,
+// the two taps of a row in one 8-byte load.
+AWSM_DI f4 sample_level_fast(const uint32_t* base, uint32_t W, uint32_t H, float u, float v) {
     float fx, fy;
     const float x0f = safe_floor(u * (float)W - 0.5f, fx);
     const float y0f = safe_floor(v * (float)H - 0.5f, fy);
@@ -225,7 +206,7 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // t
     const uint32_t i0 = xi & (W - 1u), i1 = (xi + 1u) & (W - 1u);
     const uint32_t r0 = (yi & (H - 1u)) * W, r1 = ((yi + 1u) & (H - 1u)) * W;
     uint32_t t00, t10, t01, t11;
-    if (i1 == i0 + 1u) {   // the two taps of a row are neighbours in memory unless the footprint wraps: one 8-byte load per row
+    if (i1 == i0 + 1u) {   // neighbours in memory unless the footprint wraps
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
         const u32x2 p0 = *reinterpret_cast<const u32x2*>(base + r0 + i0), p1 = *reinterpret_cast<const u32x2*>(base + r1 + i0);
         t00 = p0.x; t10 = p0.y; t01 = p1.x; t11 = p1.y;
@@ -242,6 +223,91 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {                    // t
     r.z = ((float)((t00 >> 16) & 255u) * w00 + (float)((t10 >> 16) & 255u) * w10 + (float)((t01 >> 16) & 255u) * w01 + (float)((t11 >> 16) & 255u) * w11) * k;
     r.w = ((float)(t00 >> 24) * w00 + (float)(t10 >> 24) * w10 + (float)(t01 >> 24) * w01 + (float)(t11 >> 24) * w11) * k;
     return r;
+}
+
+// ---------------- per-pixel attribute context ----------------
+struct Attr {
+    const DevScene* sc;
+    const float* ad;          // attribute_data (f32 view)
+    uint32_t v0, v1, v2;      // vertex_start of the three corners (floats)
+    uint32_t uv_sets_index;
+    f3 bary;
+    f2 uv0;                   // interpolated TEXCOORD_0, computed once per pixel when a core texture uses it
+    bool has_uv0;
+    f4 bary_derivs;           // MipmapMode::Gradient: the RGBA16F barycentric_derivatives texel (db0/dx, db0/dy, db1/dx, db1/dy)
+    f2 duv0_dx, duv0_dy;      // ... and d(TEXCOORD_0)/d(screen), alongside uv0
+};
+// texture_uvs.wgsl:64-84 (+ helpers/mipmap.wgsl:113-205 get_uv_derivatives when GRAD: chain rule over the vertex UVs)
+template <bool GRAD>
+AWSM_DI f2 attr_uv(const Attr& a, uint32_t set, f2& ddx, f2& ddy) {
+    const uint32_t o = a.uv_sets_index + set * 2u;
+    const float x0 = a.ad[a.v0 + o], y0 = a.ad[a.v0 + o + 1], x1 = a.ad[a.v1 + o], y1 = a.ad[a.v1 + o + 1];
+    const float x2 = a.ad[a.v2 + o], y2 = a.ad[a.v2 + o + 1];
+    if (GRAD) {
+        const float dAlphaDx = a.bary_derivs.x, dAlphaDy = a.bary_derivs.y, dBetaDx = a.bary_derivs.z, dBetaDy = a.bary_derivs.w;
+        const float dGammaDx = -dAlphaDx - dBetaDx, dGammaDy = -dAlphaDy - dBetaDy;
+        ddx = {x0 * dAlphaDx + x1 * dBetaDx + x2 * dGammaDx, y0 * dAlphaDx + y1 * dBetaDx + y2 * dGammaDx};
+        ddy = {x0 * dAlphaDy + x1 * dBetaDy + x2 * dGammaDy, y0 * dAlphaDy + y1 * dBetaDy + y2 * dGammaDy};
+        const bool tiny = (fabsf(dAlphaDx) + fabsf(dAlphaDy) + fabsf(dBetaDx) + fabsf(dBetaDy)) < 1e-20f;
+        const bool ok = (ddx.x == ddx.x) && (ddx.y == ddx.y) && (ddy.x == ddy.x) && (ddy.y == ddy.y);   // NaN guard
+        if (tiny || !ok) { ddx = {0.0f, 0.0f}; ddy = {0.0f, 0.0f}; }
+    }
+    return {a.bary.x * x0 + a.bary.y * x1 + a.bary.z * x2, a.bary.x * y0 + a.bary.y * y1 + a.bary.z * y2};
+}
+// texture_uvs.wgsl:64-187 + textures.wgsl:131-150.  GRAD = MipmapMode::Gradient: textureSampleGrad by the contract the
+// reference documents as "mimics the hardware mip selection" (helpers/mipmap.wgsl:419-439): rho = max(|ddx*size|, |ddy*size|),
+// lod = log2(max(rho, 1e-6)) clamped to the chain; magnification -> mag filter on level 0; otherwise min filter on
+// floor(lod) and floor(lod)+1 blended by the fraction (mipmap filter linear) or round(lod) (nearest).  Isotropic.
+template <bool GRAD>
+AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
+    f2 uv = a.uv0, ddx = a.duv0_dx, ddy = a.duv0_dy;
+    if (!(a.has_uv0 && t.uv_set_index == 0u)) uv = attr_uv<GRAD>(a, t.uv_set_index, ddx, ddy);
+    const float* tt = reinterpret_cast<const float*>(a.sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
+    const float u = tt[0] * uv.x + tt[1] * uv.y + tt[4], v = tt[2] * uv.x + tt[3] * uv.y + tt[5];
+    if (t.array_index >= a.sc->n_tex || t.sampler_index >= a.sc->n_samplers) return {0.0f, 0.0f, 0.0f, 0.0f};
+    const TexArrayDev& arr = a.sc->tex[t.array_index];
+    const AwsmSampler& smp = a.sc->samplers[t.sampler_index];
+    const uint32_t W = arr.width, H = arr.height, layers = arr.layers;
+    const uint8_t* texels = arr.texels;
+    if (texels == nullptr || W == 0u || H == 0u || layers == 0u) return {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t layer = min(t.layer_index, layers - 1u);
+    const bool common = smp.address_mode_u == 1u && smp.address_mode_v == 1u && (W & (W - 1u)) == 0u && (H & (H - 1u)) == 0u;
+    if (!GRAD) {
+        // Hot path taken when ALL lanes of the wavefront qualify (one scalar branch)
+        const bool fast = common && smp.mag_filter != 0u;
+        if (__builtin_amdgcn_ballot_w64(!fast) != 0ull)
+            return sample_level_generic(texels + (size_t)layer * W * H * 4u, W, H, smp.address_mode_u, smp.address_mode_v, smp.mag_filter, u, v);
+        return sample_level_fast(reinterpret_cast<const uint32_t*>(texels) + (size_t)layer * W * H, W, H, u, v);
+    }
+    // ---- level selection ----
+    const float dxu = tt[0] * ddx.x + tt[1] * ddx.y, dxv = tt[2] * ddx.x + tt[3] * ddx.y;     // texture_uvs.wgsl:27-35
+    const float dyu = tt[0] * ddy.x + tt[1] * ddy.y, dyv = tt[2] * ddy.x + tt[3] * ddy.y;
+    const float ax = dxu * (float)W, ay = dxv * (float)H, bx = dyu * (float)W, by = dyv * (float)H;
+    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    const uint32_t levels = max(arr.mips, 1u);
+    float lod = 0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1e-12f));      // log2(max(rho, 1e-6))
+    uint32_t lo = 0u, hi = 0u, linear = smp.mag_filter;
+    float f = 0.0f;
+    if (lod > 0.0f && levels > 1u) {
+        lod = fminf(lod, (float)(levels - 1u));
+        linear = smp.min_filter;
+        if (smp.mipmap_filter == 0u) { lo = hi = (uint32_t)floorf(lod + 0.5f); }
+        else { const float fl = floorf(lod); lo = (uint32_t)fl; hi = min(lo + 1u, levels - 1u); f = (hi != lo) ? lod - fl : 0.0f; }
+    }
+    const bool fast = common && linear != 0u;
+    const bool all_fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int n = f > 0.0f ? 2 : 1;
+    for (int k = 0; k < n; k++) {            // not unrolled: one copy of the samplers per call site
+        const uint32_t level = k ? hi : lo;
+        const float w = k ? f : 1.0f - f;
+        const uint32_t Wl = max(W >> level, 1u), Hl = max(H >> level, 1u);
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(texels) + arr.level_off[level] + (size_t)layer * Wl * Hl;
+        const f4 c = all_fast ? sample_level_fast(base, Wl, Hl, u, v)
+                              : sample_level_generic(reinterpret_cast<const uint8_t*>(base), Wl, Hl, smp.address_mode_u, smp.address_mode_v, linear, u, v);
+        acc = {acc.x + c.x * w, acc.y + c.y * w, acc.z + c.z * w, acc.w + c.w * w};
+    }
+    return acc;
 }
 AWSM_DI f4 vertex_color(const Attr& a, uint32_t set_index) {               // vertex_color_attrib.wgsl:1-21
     const uint32_t o = set_index * 4u;
@@ -263,9 +329,10 @@ struct PbrColor {
     f3 sheen_color; float sheen_roughness;
 };
 
+template <bool GRAD>
 AWSM_DI f3 normal_map(const Attr& a, const TexInfo& t, float scale, const TBN& tbn) {   // material_color_calc.wgsl:301-322
     if (!t.exists) return tbn.N;
-    const f4 s = sample_tex(a, t);
+    const f4 s = sample_tex<GRAD>(a, t);
     const float tx = (s.x * 2.0f - 1.0f) * scale, ty = (s.y * 2.0f - 1.0f) * scale, tz = s.z * 2.0f - 1.0f;
     return fm::fnormalize(tbn.T * tx + tbn.B * ty + tbn.N * tz);
 }
@@ -526,6 +593,7 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
 // standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug view, 2 hud mesh (only reported when check_hud).
 // ------------------------------------------------------------------------------------------------
 struct SurfaceOut { f4 color; uint32_t kind; };
+template <bool GRAD>
 AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev& f, uint32_t rank, int cx, int cy, float depth_sample,
                                  const GBufferTexel& g, bool check_hud) {
     SurfaceOut out;
@@ -549,6 +617,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     a.v1 = attr_data_off + attr_idx[1] * stride;
     a.v2 = attr_data_off + attr_idx[2] * stride;
     a.has_uv0 = false; a.uv0 = {0.0f, 0.0f};
+    a.bary_derivs = g.bary_derivs; a.duv0_dx = {0.0f, 0.0f}; a.duv0_dy = {0.0f, 0.0f};
 
     // ---- standard.wgsl:11-62 ----
     const uint8_t* cam = sc->buf[AWSM_BUF_CAMERA];
@@ -578,8 +647,8 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
         const TexInfo base_tex = tex_load(M, b + 2), em_tex = tex_load(M, b + 11);
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
         f3 em = {mf(M, b + 16), mf(M, b + 17), mf(M, b + 18)};
-        if (base_tex.exists) { const f4 s = sample_tex(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
-        if (em_tex.exists) { const f4 s = sample_tex(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        if (base_tex.exists) { const f4 s = sample_tex<GRAD>(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+        if (em_tex.exists) { const f4 s = sample_tex<GRAD>(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
         out.color = {base.x + em.x, base.y + em.y, base.z + em.z, 1.0f};
         return out;
     }
@@ -596,24 +665,24 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     // TEXCOORD_0 is interpolated once for all the textures that use it (the WGSL re-derives it per texture)
     if ((tx_base.exists && tx_base.uv_set_index == 0u) || (tx_mr.exists && tx_mr.uv_set_index == 0u) || (tx_normal.exists && tx_normal.uv_set_index == 0u) ||
         (tx_occ.exists && tx_occ.uv_set_index == 0u) || (tx_em.exists && tx_em.uv_set_index == 0u)) {
-        a.uv0 = attr_uv(a, 0u);
+        a.uv0 = attr_uv<GRAD>(a, 0u, a.duv0_dx, a.duv0_dy);
         a.has_uv0 = true;
     }
     {
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
-        if (tx_base.exists) { const f4 s = sample_tex(a, tx_base); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+        if (tx_base.exists) { const f4 s = sample_tex<GRAD>(a, tx_base); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
         base.w = 1.0f;
         if (idx_vertex_color != 0u) { const f4 vc = vertex_color(a, M[idx_vertex_color]); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
         c.base = {base.x, base.y, base.z};
     }
     c.mr = {mf(M, b + 16), mf(M, b + 17)};
-    if (tx_mr.exists) { const f4 s = sample_tex(a, tx_mr); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
-    c.normal = normal_map(a, tx_normal, mf(M, b + 23), tbn);
+    if (tx_mr.exists) { const f4 s = sample_tex<GRAD>(a, tx_mr); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
+    c.normal = normal_map<GRAD>(a, tx_normal, mf(M, b + 23), tbn);
     c.occlusion = 1.0f;
-    if (tx_occ.exists) { const f4 s = sample_tex(a, tx_occ); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
+    if (tx_occ.exists) { const f4 s = sample_tex<GRAD>(a, tx_occ); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
     {
         f3 em = {mf(M, b + 35), mf(M, b + 36), mf(M, b + 37)};
-        if (tx_em.exists) { const f4 s = sample_tex(a, tx_em); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        if (tx_em.exists) { const f4 s = sample_tex<GRAD>(a, tx_em); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
         c.emissive = em * (idx_emissive_strength == 0u ? 1.0f : mf(M, idx_emissive_strength));
     }
     c.ior = idx_ior == 0u ? 1.5f : mf(M, idx_ior);
@@ -622,23 +691,23 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
         const uint32_t i = idx_specular;
         const TexInfo tx = tex_load(M, i), ctx = tex_load(M, i + 6);
         c.specular = mf(M, i + 5);
-        if (tx.exists) c.specular = c.specular * sample_tex(a, tx).w;
+        if (tx.exists) c.specular = c.specular * sample_tex<GRAD>(a, tx).w;
         c.specular_color = {mf(M, i + 11), mf(M, i + 12), mf(M, i + 13)};
-        if (ctx.exists) { const f4 s = sample_tex(a, ctx); c.specular_color = {c.specular_color.x * s.x, c.specular_color.y * s.y, c.specular_color.z * s.z}; }
+        if (ctx.exists) { const f4 s = sample_tex<GRAD>(a, ctx); c.specular_color = {c.specular_color.x * s.x, c.specular_color.y * s.y, c.specular_color.z * s.z}; }
     }
     c.transmission = 0.0f;
     if (idx_transmission != 0u) {
         const uint32_t i = idx_transmission;
         const TexInfo tx = tex_load(M, i);
         const float factor = mf(M, i + 5);
-        if (!(!tx.exists && factor == 0.0f)) { c.transmission = factor; if (tx.exists) c.transmission = c.transmission * sample_tex(a, tx).x; }
+        if (!(!tx.exists && factor == 0.0f)) { c.transmission = factor; if (tx.exists) c.transmission = c.transmission * sample_tex<GRAD>(a, tx).x; }
     }
     c.volume_thickness = 0.0f; c.volume_attenuation_distance = 0.0f; c.volume_attenuation_color = {1.0f, 1.0f, 1.0f};
     if (idx_volume != 0u) {
         const uint32_t i = idx_volume;
         const TexInfo tx = tex_load(M, i);
         const float factor = mf(M, i + 5);
-        if (!(!tx.exists && factor == 0.0f)) { c.volume_thickness = factor; if (tx.exists) c.volume_thickness = c.volume_thickness * sample_tex(a, tx).y; }
+        if (!(!tx.exists && factor == 0.0f)) { c.volume_thickness = factor; if (tx.exists) c.volume_thickness = c.volume_thickness * sample_tex<GRAD>(a, tx).y; }
         c.volume_attenuation_distance = mf(M, i + 6);
         c.volume_attenuation_color = {mf(M, i + 7), mf(M, i + 8), mf(M, i + 9)};
     }
@@ -647,19 +716,19 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
         const uint32_t i = idx_clearcoat;
         const TexInfo tx = tex_load(M, i), rtx = tex_load(M, i + 6);
         const float factor = mf(M, i + 5);
-        if (!(!tx.exists && factor == 0.0f)) { c.clearcoat = factor; if (tx.exists) c.clearcoat = c.clearcoat * sample_tex(a, tx).x; }
+        if (!(!tx.exists && factor == 0.0f)) { c.clearcoat = factor; if (tx.exists) c.clearcoat = c.clearcoat * sample_tex<GRAD>(a, tx).x; }
         c.clearcoat_roughness = mf(M, i + 11);
-        if (rtx.exists) c.clearcoat_roughness = c.clearcoat_roughness * sample_tex(a, rtx).y;
-        c.clearcoat_normal = normal_map(a, tex_load(M, i + 12), mf(M, i + 17), tbn);
+        if (rtx.exists) c.clearcoat_roughness = c.clearcoat_roughness * sample_tex<GRAD>(a, rtx).y;
+        c.clearcoat_normal = normal_map<GRAD>(a, tex_load(M, i + 12), mf(M, i + 17), tbn);
     }
     c.sheen_color = {0.0f, 0.0f, 0.0f}; c.sheen_roughness = 0.0f;
     if (idx_sheen != 0u) {
         const uint32_t i = idx_sheen;
         const TexInfo rtx = tex_load(M, i), ctx = tex_load(M, i + 6);
         c.sheen_roughness = mf(M, i + 5);
-        if (rtx.exists) c.sheen_roughness = c.sheen_roughness * sample_tex(a, rtx).w;
+        if (rtx.exists) c.sheen_roughness = c.sheen_roughness * sample_tex<GRAD>(a, rtx).w;
         c.sheen_color = {mf(M, i + 11), mf(M, i + 12), mf(M, i + 13)};
-        if (ctx.exists) { const f4 s = sample_tex(a, ctx); c.sheen_color = {c.sheen_color.x * s.x, c.sheen_color.y * s.y, c.sheen_color.z * s.z}; }
+        if (ctx.exists) { const f4 s = sample_tex<GRAD>(a, ctx); c.sheen_color = {c.sheen_color.x * s.x, c.sheen_color.y * s.y, c.sheen_color.z * s.z}; }
     }
 
     if (debug_bitmask != 0u) {   // pbr_material_color.wgsl:34-60
@@ -704,6 +773,7 @@ AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
 // k_shade: single-sampled opaque pass, 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers
 // 16x4 here).  5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 spills.
 // ------------------------------------------------------------------------------------------------
+template <bool GRAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
     ShadeBlock b;
     if (!shade_block(f, b)) return;
@@ -716,8 +786,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     const unsigned long long key = f.vis[pv];
     if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, sky); return; }   // compute.wgsl:149-153 / empty.wgsl
     const uint32_t rank = key_rank(key);
-    const GBufferTexel g = reconstruct_gbuffer(f, rank, cx, cy);          // STRICT
-    const SurfaceOut o = shade_surface(sc, f, rank, cx, cy, key_depth(key), g, true);
+    const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
+    const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
     store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);   // hud: stays cleared (compute.wgsl:176-179)
 }
 
@@ -744,7 +814,7 @@ AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& 
         const unsigned long long k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
         c.state = 1u;
         if (k != ~0ull) {
-            const GBufferTexel g = reconstruct_gbuffer(f, key_rank(k), px, py);
+            const GBufferTexel g = reconstruct_gbuffer<false>(f, key_rank(k), px, py);
             const f3 n = decode_octahedral(mk2(g.packed_nt.x, g.packed_nt.y));     // strict unpack_normal_tangent(..).N
             c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k >> 32); c.state = 2u;
         }
@@ -752,6 +822,7 @@ AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& 
     cells[(ly + 1) * 18 + (lx + 1)] = c;
 }
 
+template <bool GRAD>
 __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ NeighbourCell cells[18 * 18];
     __shared__ uint32_t n_edges;
@@ -766,7 +837,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     // ---- phase 1: G-buffer texel of sample 0 for every pixel of the block + the halo ring, normals into LDS ----
     unsigned long long k4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
     GBufferTexel g0;
-    g0.packed_nt = {0.0f, 0.0f, 0.0f, 0.0f}; g0.bx = 0.0f; g0.by = 0.0f;
+    g0.packed_nt = {0.0f, 0.0f, 0.0f, 0.0f}; g0.bx = 0.0f; g0.by = 0.0f; g0.bary_derivs = {0.0f, 0.0f, 0.0f, 0.0f};
     {
         NeighbourCell c = {0.0f, 0.0f, 0.0f, 0u, 0u};
         if (cx < (int)f.width && cy < (int)f.y1) {    // also the halo row below the shard when it falls inside this block
@@ -775,7 +846,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
             k4[0] = ka.x; k4[1] = ka.y; k4[2] = kb.x; k4[3] = kb.y;
             c.state = 1u;
             if (k4[0] != ~0ull) {
-                g0 = reconstruct_gbuffer(f, key_rank(k4[0]), cx, cy);     // STRICT
+                g0 = reconstruct_gbuffer<GRAD>(f, key_rank(k4[0]), cx, cy);   // STRICT
                 const f3 n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
                 c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k4[0] >> 32); c.state = 2u;
             }
@@ -805,7 +876,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
             f.msaa_color0[p] = make_float4(sky.x, sky.y, sky.z, sky.w);   // compute.wgsl:155-170: sample 0 is background, others are not
             is_edge = true;
         } else {
-            const SurfaceOut o = shade_surface(sc, f, key_rank(k4[0]), cx, cy, key_depth(k4[0]), g0, true);
+            const SurfaceOut o = shade_surface<GRAD>(sc, f, key_rank(k4[0]), cx, cy, key_depth(k4[0]), g0, true);
             if (o.kind == 2u) store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f});   // hud
             else if (o.kind == 1u) store_pixel(f, p, o.color);                 // debug view: written before the edge test
             else {
@@ -845,6 +916,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 
 // One thread per edge pixel of the block: the colours of samples 1..3 (material_shading.wgsl:170-210), shading each
 // distinct triangle once, then the average of the four.
+template <bool GRAD>
 __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
     ShadeBlock b;
     if (!shade_block(f, b)) return;
@@ -869,7 +941,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __re
             int same = -1;
             for (int t = 0; t < s; t++) if (k4[t] != ~0ull && key_rank(k4[t]) == r) same = t;
             if (same >= 0) c = col[same];
-            else c = shade_surface(sc, f, r, cx, cy, depth0, reconstruct_gbuffer(f, r, cx, cy), false).color;
+            else c = shade_surface<GRAD>(sc, f, r, cx, cy, depth0, reconstruct_gbuffer<GRAD>(f, r, cx, cy), false).color;
         }
         col[s] = c;
     }
@@ -963,11 +1035,13 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     if (!nb) return;
+    const bool grad = f->mipmap != 0u;      // MipmapMode::Gradient vs None: separate instantiations, as the reference keeps separate pipelines
     if (f->msaa == 4u) {
-        hipLaunchKernelGGL(awsm::k_shade_msaa, dim3(nb), dim3(256), 0, s, sc, *f);
-        hipLaunchKernelGGL(awsm::k_shade_msaa_resolve, dim3(nb), dim3(256), 0, s, sc, *f);
+        if (grad) { hipLaunchKernelGGL(awsm::k_shade_msaa<true>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
+        else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
     } else {
-        hipLaunchKernelGGL(awsm::k_shade, dim3(nb), dim3(256), 0, s, sc, *f);
+        if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
     }
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {

@@ -23,7 +23,7 @@ BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", 
 
 # every symbol include/awsm_hip.h declares (tests/test_abi_symbols.py checks the header against this list too)
 EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
-           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_pick", "awsm_hip_texture_array_upload", "awsm_hip_sampler_set",
+           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_pick", "awsm_hip_texture_array_upload", "awsm_hip_texture_array_generate_mips", "awsm_hip_texture_array_read_level", "awsm_hip_sampler_set",
            "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
@@ -96,6 +96,8 @@ def load_library():
     lib.awsm_hip_set_shard_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.awsm_hip_set_shard_bands.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.awsm_hip_pick.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.awsm_hip_texture_array_generate_mips.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.awsm_hip_texture_array_read_level.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.awsm_hip_texture_array_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     lib.awsm_hip_sampler_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.awsm_hip_env_upload.argtypes = [C.c_void_p, C.c_void_p]
@@ -184,10 +186,24 @@ class HipDevice:
     def set_shard_bands(self, n: int, r: int, compact_output: bool = False):
         self._chk(self.lib.awsm_hip_set_shard_bands(self.ctx, n, r, 1 if compact_output else 0), "set_shard_bands")
 
-    def texture_array_upload(self, index: int, texels: np.ndarray):
+    def texture_array_upload(self, index: int, texels: np.ndarray, mips: int = 1):
+        """Level 0 of a pool array; `mips` levels are reserved (see texture_array_generate_mips)."""
         layers, h, w, _ = texels.shape
         t = np.ascontiguousarray(texels, dtype=np.uint8)
-        self._chk(self.lib.awsm_hip_texture_array_upload(self.ctx, index, w, h, layers, 1, 0, t.ctypes.data_as(C.c_void_p)), "texture_array_upload")
+        self._chk(self.lib.awsm_hip_texture_array_upload(self.ctx, index, w, h, layers, mips, 0, t.ctypes.data_as(C.c_void_p)), "texture_array_upload")
+        self._tex_shapes = getattr(self, "_tex_shapes", {})
+        self._tex_shapes[index] = (layers, h, w)
+
+    def texture_array_generate_mips(self, index: int, kinds=None):
+        layers = self._tex_shapes[index][0]
+        k = None if kinds is None else (C.c_uint32 * layers)(*[int(x) for x in kinds])
+        self._chk(self.lib.awsm_hip_texture_array_generate_mips(self.ctx, index, k), "texture_array_generate_mips")
+
+    def texture_array_read_level(self, index: int, level: int) -> np.ndarray:
+        layers, h, w = self._tex_shapes[index]
+        out = np.zeros((layers, max(1, h >> level), max(1, w >> level), 4), dtype=np.uint8)
+        self._chk(self.lib.awsm_hip_texture_array_read_level(self.ctx, index, level, out.ctypes.data_as(C.c_void_p)), "texture_array_read_level")
+        return out
 
     def sampler_set(self, index: int, s: dict):
         smp = AwsmSampler(s.get("address_mode_u", 1), s.get("address_mode_v", 1), s.get("mag_filter", 1), s.get("min_filter", 1),

@@ -279,7 +279,7 @@ void write_tex(AwsmHost* h, std::vector<uint8_t>& d, const AwsmHostTexRef& r) {
     push_u32(d, (arr.h << 16) | (arr.w & 0xFFFFu));
     push_u32(d, (li << 12) | (ai & 0xFFFu));
     push_u32(d, (r.sampler << 8) | (r.uv_index & 0xFFu));
-    const uint32_t flags = 1u;   // exists; mip bit stays clear (MipmapMode::None)
+    const uint32_t flags = 1u | 2u;   // bit 0 exists; bit 1 has mipmaps: pool arrays are always created with mipmap = true (texture_pool.rs:166-176, writer.rs:163-171)
     push_u32(d, flags | ((smp.address_mode_u & 0xFFu) << 8) | ((smp.address_mode_v & 0xFFu) << 16));
     long long toff = r.transform ? h->tex_transforms_buf.offset(r.transform) : -1;
     push_u32(d, (uint32_t)(toff >= 0 ? (size_t)toff : h->tex_transform_identity_offset));

@@ -100,3 +100,40 @@ class SceneDesc:
     lut_size: int = 64
 
 
+
+
+# MipmapTextureKind (renderer-core/src/texture/mipmap.rs:28-47) by texture role, as gltf/populate/material.rs assigns them
+MIP_KIND_ALBEDO, MIP_KIND_NORMAL, MIP_KIND_METALLIC_ROUGHNESS, MIP_KIND_OCCLUSION, MIP_KIND_EMISSIVE = 0, 1, 2, 3, 4
+MIP_KIND_SPECULAR, MIP_KIND_SPECULAR_COLOR, MIP_KIND_TRANSMISSION, MIP_KIND_VOLUME_THICKNESS = 5, 6, 7, 8
+
+
+def texture_mip_kinds(scene: "SceneDesc") -> List[int]:
+    """Mip-generation filter per texture of the scene: the role under which the image first enters the pool
+    (materials in order; roles in the order pbr_material_mapper visits them, populate/material.rs:94-640)."""
+    kinds: List[Optional[int]] = [None] * len(scene.textures)
+
+    def use(ref, kind):
+        if ref is not None and 0 <= ref.texture < len(kinds) and kinds[ref.texture] is None:
+            kinds[ref.texture] = kind
+
+    for m in scene.materials:
+        use(m.base_color_tex, MIP_KIND_ALBEDO)
+        use(m.metallic_roughness_tex, MIP_KIND_METALLIC_ROUGHNESS)
+        use(m.normal_tex, MIP_KIND_NORMAL)
+        use(m.occlusion_tex, MIP_KIND_OCCLUSION)
+        use(m.emissive_tex, MIP_KIND_EMISSIVE)
+        if m.specular:
+            use(m.specular.get("tex"), MIP_KIND_SPECULAR)
+            use(m.specular.get("color_tex"), MIP_KIND_SPECULAR)
+        if m.transmission:
+            use(m.transmission.get("tex"), MIP_KIND_TRANSMISSION)
+        if m.volume:
+            use(m.volume.get("thickness_tex"), MIP_KIND_VOLUME_THICKNESS)
+        if m.clearcoat:
+            use(m.clearcoat.get("tex"), MIP_KIND_ALBEDO)
+            use(m.clearcoat.get("roughness_tex"), MIP_KIND_METALLIC_ROUGHNESS)
+            use(m.clearcoat.get("normal_tex"), MIP_KIND_NORMAL)
+        if m.sheen:
+            use(m.sheen.get("color_tex"), MIP_KIND_SPECULAR)
+            use(m.sheen.get("roughness_tex"), MIP_KIND_METALLIC_ROUGHNESS)
+    return [MIP_KIND_ALBEDO if k is None else k for k in kinds]

@@ -177,9 +177,19 @@ int awsm_hip_set_shard_rows(AwsmHipCtx* ctx, uint32_t y0, uint32_t y1);
 int awsm_hip_set_shard_bands(AwsmHipCtx* ctx, uint32_t n, uint32_t r, uint32_t compact_output);
 
 /* ---- texture pool bind (crates/renderer/src/render_passes/material_opaque/bind_group.rs:331-360):
- * array `array_idx` is a texture_2d_array of `layers` w x h images; texels = layers*h*w*4 bytes, layer-major. ---- */
+ * array `array_idx` is a texture_2d_array of `layers` w x h images; texels = layers*h*w*4 bytes, layer-major: mip
+ * level 0 (what copyExternalImageToTexture writes, renderer-core/src/texture/texture_pool.rs:252-300).  `mips` = number
+ * of levels the array holds (1, or up to floor(log2(max(w,h))) + 1): the space is reserved here and levels >= 1 are
+ * produced by awsm_hip_texture_array_generate_mips. ---- */
 int awsm_hip_texture_array_upload(AwsmHipCtx* ctx, uint32_t array_idx, uint32_t width, uint32_t height,
                                   uint32_t layers, uint32_t mips, AwsmTexFormat fmt, const void* texels);
+/* generate_mipmaps (renderer-core/src/texture/mipmap.rs:95-330): every level from the previous one, 2x2 texels, filter
+ * chosen per layer by MipmapTextureKind (0 albedo, 1 normal: renormalised, 2 metallic-roughness: roughness averaged as
+ * r^2, 3 occlusion, 4 emissive, 5.. = box filter); kind_per_layer = `layers` values or NULL (all albedo).  Results are
+ * stored as RGBA8 (floor(clamp(v,0,1)*255 + 0.5)). */
+int awsm_hip_texture_array_generate_mips(AwsmHipCtx* ctx, uint32_t array_idx, const uint32_t* kind_per_layer);
+/* texels of one mip level back to the host (tests): layers*h_l*w_l*4 bytes */
+int awsm_hip_texture_array_read_level(AwsmHipCtx* ctx, uint32_t array_idx, uint32_t level, void* texels_out);
 int awsm_hip_sampler_set(AwsmHipCtx* ctx, uint32_t sampler_idx, const AwsmSampler* sampler);
 int awsm_hip_env_upload(AwsmHipCtx* ctx, const AwsmEnv* env);
 

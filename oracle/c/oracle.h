@@ -24,8 +24,9 @@ extern "C" {
 #define ORACLE_MAX_SAMPLERS 32
 
 typedef struct OracleTexArray {
-    const uint8_t* texels;   /* layers*h*w*4 RGBA8 */
+    const uint8_t* texels;   /* RGBA8; mips == 1: [layer][h][w]; mips > 1: the whole chain, [level][layer][h_l][w_l] */
     uint32_t width, height, layers;
+    uint32_t mips;           /* 0/1 = level 0 only */
 } OracleTexArray;
 
 typedef struct OracleScene {
@@ -46,7 +47,7 @@ typedef struct OracleScene {
     const uint16_t* brdf_lut_rg16f;  /* lut_w*lut_h*2 halfs */
     uint32_t lut_width, lut_height;
     uint32_t msaa;                   /* 0 (single sample) or 4: keys hold 4 samples per pixel, [pixel][sample] */
-    uint32_t pad_;
+    uint32_t mipmap;                 /* 0 = MipmapMode::None, 1 = MipmapMode::Gradient */
 } OracleScene;
 
 /* vert_main for every exploded vertex of every draw, in draw order.
@@ -66,6 +67,13 @@ int oracle_shade(const OracleScene* s, const float* clip_in, const float* nt_in,
 /* key -> reference visibility texel (primitive-local triangle id, material-mesh-meta byte offset) + depth */
 int oracle_unpack_visibility(const OracleScene* s, const uint64_t* keys, uint32_t* tri_id_out,
                              uint32_t* meta_off_out, float* depth_out);
+
+/* Mip chain of a texture pool array (renderer-core/src/texture/mipmap.rs:95-250): chain holds level 0 on entry
+ * ([layer][h][w] RGBA8) and every level on return ([level][layer][h_l][w_l], (w >> l).max(1)); kinds[layer] is the
+ * MipmapTextureKind (0 albedo, 1 normal, 2 metallic-roughness, others = box filter).  Returns the chain size in bytes. */
+size_t oracle_mip_chain_bytes(uint32_t width, uint32_t height, uint32_t layers, uint32_t levels);
+uint32_t oracle_mip_levels(uint32_t width, uint32_t height);
+int oracle_generate_mips(uint32_t width, uint32_t height, uint32_t layers, const uint32_t* kinds, uint32_t levels, uint8_t* chain);
 
 /* BRDF LUT: rg16f_out[h*w*2].  Row j, column i == fragment (i+0.5, j+0.5) of the reference's
  * full-screen triangle (renderer-core/src/brdf_lut/shader.wgsl). */

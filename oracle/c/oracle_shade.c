@@ -68,12 +68,77 @@ static inline float safe_floor(float x, float* frac) {
     *frac = x - f;
     return f;
 }
-/* textureSampleLevel(tex, sampler, uv, layer, 0) — sampling contract, DESIGN.md §"Texture sampling" */
-static ovec4 sample_array_level0(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer) {
-    int W = (int)arr->width, H = (int)arr->height;
+/* mip chain geometry (renderer-core/src/texture/mipmap.rs:60-75) */
+static inline uint32_t mip_dim(uint32_t base, uint32_t level) { uint32_t v = base >> level; return v ? v : 1u; }
+static size_t mip_level_offset_texels(uint32_t w, uint32_t h, uint32_t layers, uint32_t level) {
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; l++) off += (size_t)layers * mip_dim(w, l) * mip_dim(h, l);
+    return off;
+}
+uint32_t oracle_mip_levels(uint32_t width, uint32_t height) {
+    uint32_t m = width > height ? width : height, n = 0;
+    while (m > 1u) { m >>= 1; n++; }
+    return n + 1u;                                             /* floor(log2(max)) + 1 */
+}
+size_t oracle_mip_chain_bytes(uint32_t width, uint32_t height, uint32_t layers, uint32_t levels) {
+    return mip_level_offset_texels(width, height, layers, levels) * 4u;
+}
+static inline uint8_t to_unorm8(float v) {                     /* textureStore to rgba8unorm; contract: floor(clamp(v,0,1)*255 + 0.5), NaN -> 0 */
+    if (!(v > 0.0f)) return 0;
+    if (v > 1.0f) v = 1.0f;
+    return (uint8_t)floorf(v * 255.0f + 0.5f);
+}
+/* mipmap.rs:140-250: every level from the previous one, 2x2 texel loads with clamping, filter by texture kind.
+ * Contract addition: source coordinates are also clamped to the real extent of the source level (the shader clamps
+ * to 2 x the destination extent, which exceeds a 1-texel-wide source). */
+int oracle_generate_mips(uint32_t width, uint32_t height, uint32_t layers, const uint32_t* kinds, uint32_t levels, uint8_t* chain) {
+    for (uint32_t l = 1; l < levels; l++) {
+        const uint32_t sw = mip_dim(width, l - 1), sh = mip_dim(height, l - 1), dw = mip_dim(width, l), dh = mip_dim(height, l);
+        const uint8_t* src = chain + mip_level_offset_texels(width, height, layers, l - 1) * 4u;
+        uint8_t* dst = chain + mip_level_offset_texels(width, height, layers, l) * 4u;
+        for (uint32_t layer = 0; layer < layers; layer++) {
+            const uint32_t kind = kinds ? kinds[layer] : 0u;
+            for (uint32_t y = 0; y < dh; y++)
+                for (uint32_t x = 0; x < dw; x++) {
+                    ovec4 smp[4];
+                    for (int k = 0; k < 4; k++) {
+                        int sx = (int)(x * 2u) + (k & 1), sy = (int)(y * 2u) + (k >> 1);
+                        const int mx = (int)(dw * 2u) - 1, my = (int)(dh * 2u) - 1;
+                        sx = sx < 0 ? 0 : (sx > mx ? mx : sx); sy = sy < 0 ? 0 : (sy > my ? my : sy);
+                        if (sx > (int)sw - 1) sx = (int)sw - 1;
+                        if (sy > (int)sh - 1) sy = (int)sh - 1;
+                        const uint8_t* t = src + (((size_t)layer * sh + (size_t)sy) * sw + (size_t)sx) * 4u;
+                        smp[k] = ov4((float)t[0] / 255.0f, (float)t[1] / 255.0f, (float)t[2] / 255.0f, (float)t[3] / 255.0f);
+                    }
+                    ovec4 r;
+                    if (kind == 2u) {            /* filter_metallic_roughness */
+                        float m = 0.0f, r2 = 0.0f, b = 0.0f, al = 0.0f;
+                        for (int k = 0; k < 4; k++) { m += smp[k].x; r2 += smp[k].y * smp[k].y; b += smp[k].z; al += smp[k].w; }
+                        r = ov4(m * 0.25f, sqrtf(r2 * 0.25f), b * 0.25f, al * 0.25f);
+                    } else {
+                        ovec4 sum = ov4(0.0f, 0.0f, 0.0f, 0.0f);
+                        for (int k = 0; k < 4; k++) sum = ov4(sum.x + smp[k].x, sum.y + smp[k].y, sum.z + smp[k].z, sum.w + smp[k].w);
+                        r = ov4(sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f);   /* filter_simple */
+                        if (kind == 1u) {        /* filter_normal: renormalise */
+                            ovec3 n = ov3_normalize(ov3(r.x * 2.0f - 1.0f, r.y * 2.0f - 1.0f, r.z * 2.0f - 1.0f));
+                            r = ov4(n.x * 0.5f + 0.5f, n.y * 0.5f + 0.5f, n.z * 0.5f + 0.5f, r.w);
+                        }
+                    }
+                    uint8_t* o = dst + (((size_t)layer * dh + y) * dw + x) * 4u;
+                    o[0] = to_unorm8(r.x); o[1] = to_unorm8(r.y); o[2] = to_unorm8(r.z); o[3] = to_unorm8(r.w);
+                }
+        }
+    }
+    return 0;
+}
+
+/* textureSampleLevel(tex, sampler, uv, layer, level) with an integer level — sampling contract, DESIGN.md §"Texture
+ * sampling".  `linear` selects bilinear vs nearest (mag filter at level 0 / magnification, min filter otherwise). */
+static ovec4 sample_array_level(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer, uint32_t level, int linear) {
+    int W = (int)mip_dim(arr->width, level), H = (int)mip_dim(arr->height, level);
     if (layer >= arr->layers) layer = arr->layers - 1u;
-    const uint8_t* base = arr->texels + (size_t)layer * (size_t)W * (size_t)H * 4u;
-    if (smp->mag_filter == 0u) {
+    const uint8_t* base = arr->texels + (mip_level_offset_texels(arr->width, arr->height, arr->layers, level) + (size_t)layer * (size_t)W * (size_t)H) * 4u;
+    if (!linear) {
         float fx, fy;
         int i = wrap_index((int)safe_floor(uv.x * (float)W, &fx), W, smp->address_mode_u);
         int j = wrap_index((int)safe_floor(uv.y * (float)H, &fy), H, smp->address_mode_v);
@@ -91,6 +156,34 @@ static ovec4 sample_array_level0(const OracleTexArray* arr, const AwsmSampler* s
     ovec4 bot = ov4(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
     return ov4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
 }
+static ovec4 sample_array_level0(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer) {
+    return sample_array_level(arr, smp, uv, layer, 0u, smp->mag_filter != 0u);
+}
+/* textureSampleGrad(tex, sampler, uv, layer, ddx, ddy).  WebGPU leaves LOD selection and anisotropy to the hardware;
+ * the contract is the isotropic rule the reference itself documents as "mimics the hardware mip selection"
+ * (helpers/mipmap.wgsl:419-439): rho = max(|ddx * size|, |ddy * size|), lod = log2(max(rho, 1e-6)), clamped to the
+ * chain, magnification (lod <= 0) uses the mag filter on level 0, otherwise the min filter on floor(lod) and
+ * floor(lod) + 1 blended by the fraction (mipmap filter linear) or on round(lod) (nearest).  No anisotropic probes. */
+static ovec4 sample_array_grad(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer, ovec2 ddx, ovec2 ddy) {
+    const uint32_t levels = arr->mips > 1u ? arr->mips : 1u;
+    const float W = (float)arr->width, H = (float)arr->height;
+    const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
+    const float rho_x = sqrtf(ax * ax + ay * ay), rho_y = sqrtf(bx * bx + by * by);
+    const float rho = fmaxf(rho_x, rho_y);
+    float lod = log2f(fmaxf(rho, 1e-6f));
+    if (!(lod > 0.0f) || levels == 1u) return sample_array_level(arr, smp, uv, layer, 0u, smp->mag_filter != 0u);
+    const float max_lod = (float)(levels - 1u);
+    if (lod > max_lod) lod = max_lod;
+    const int lin = smp->min_filter != 0u;
+    if (smp->mipmap_filter == 0u) return sample_array_level(arr, smp, uv, layer, (uint32_t)floorf(lod + 0.5f), lin);
+    const float fl = floorf(lod), f = lod - fl;
+    const uint32_t lo = (uint32_t)fl, hi = lo + 1u < levels ? lo + 1u : levels - 1u;
+    ovec4 a = sample_array_level(arr, smp, uv, layer, lo, lin);
+    if (!(f > 0.0f) || hi == lo) return a;
+    ovec4 b = sample_array_level(arr, smp, uv, layer, hi, lin);
+    const float g = 1.0f - f;
+    return ov4(a.x * g + b.x * f, a.y * g + b.y * f, a.z * g + b.z * f, a.w * g + b.w * f);
+}
 
 /* texture_uvs.wgsl:144-187 + textures.wgsl:131-150 */
 static ovec4 texture_pool_sample_no_mips(const OracleScene* s, const TexInfo* info, ovec2 uv) {
@@ -99,6 +192,16 @@ static ovec4 texture_pool_sample_no_mips(const OracleScene* s, const TexInfo* in
     if (info->array_index >= s->n_tex_arrays) return ov4(0, 0, 0, 0);
     if (info->sampler_index >= s->n_samplers) return ov4(0, 0, 0, 0);
     return sample_array_level0(&s->tex_arrays[info->array_index], &s->samplers[info->sampler_index], uvt, info->layer_index);
+}
+/* texture_uvs.wgsl:7-43,88-141 (MipmapMode::Gradient): the transform's 2x2 part also maps the derivatives */
+static ovec4 texture_pool_sample_grad(const OracleScene* s, const TexInfo* info, ovec2 uv, ovec2 ddx, ovec2 ddy) {
+    const float* t = (const float*)(s->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)info->uv_transform_index * 32u);
+    ovec2 uvt = ov2((t[0] * uv.x + t[1] * uv.y) + t[4], (t[2] * uv.x + t[3] * uv.y) + t[5]);
+    ovec2 dx = ov2(t[0] * ddx.x + t[1] * ddx.y, t[2] * ddx.x + t[3] * ddx.y);
+    ovec2 dy = ov2(t[0] * ddy.x + t[1] * ddy.y, t[2] * ddy.x + t[3] * ddy.y);
+    if (info->array_index >= s->n_tex_arrays) return ov4(0, 0, 0, 0);
+    if (info->sampler_index >= s->n_samplers) return ov4(0, 0, 0, 0);
+    return sample_array_grad(&s->tex_arrays[info->array_index], &s->samplers[info->sampler_index], uvt, info->layer_index, dx, dy);
 }
 
 /* ---------------- per-pixel attribute context ---------------- */
@@ -109,6 +212,8 @@ typedef struct {
     uint32_t stride;                 /* in floats */
     uint32_t uv_sets_index;
     ovec3 bary;
+    int grad;                        /* MipmapMode::Gradient */
+    ovec4 bary_derivs;               /* RGBA16F barycentric_derivatives texel: (db0/dx, db0/dy, db1/dx, db1/dy) */
 } AttrCtx;
 
 /* texture_uvs.wgsl:64-84 */
@@ -134,8 +239,31 @@ static ovec4 vertex_color(const AttrCtx* a, uint32_t set_index) {
     for (int j = 0; j < 4; j++) r[j] = (a->bary.x * c[0][j] + a->bary.y * c[1][j]) + a->bary.z * c[2][j];
     return ov4(r[0], r[1], r[2], r[3]);
 }
+/* helpers/mipmap.wgsl:113-205 get_uv_derivatives: chain rule d(uv)/d(screen) = sum_i uv_i * d(b_i)/d(screen) */
+static void get_uv_derivatives(const AttrCtx* a, const TexInfo* info, ovec2* ddx, ovec2* ddy) {
+    const float* ad = (const float*)a->s->buf[AWSM_BUF_ATTR_DATA];
+    ovec2 uv[3];
+    for (int k = 0; k < 3; k++) {
+        uint32_t idx = a->attribute_data_offset + a->tri[k] * a->stride + a->uv_sets_index + info->uv_set_index * 2u;
+        uv[k] = ov2(ad[idx], ad[idx + 1]);
+    }
+    const float dAlphaDx = a->bary_derivs.x, dAlphaDy = a->bary_derivs.y, dBetaDx = a->bary_derivs.z, dBetaDy = a->bary_derivs.w;
+    *ddx = ov2(0.0f, 0.0f); *ddy = ov2(0.0f, 0.0f);
+    const float m = ((fabsf(dAlphaDx) + fabsf(dAlphaDy)) + fabsf(dBetaDx)) + fabsf(dBetaDy);
+    if (m < 1e-20f) return;
+    const float dGammaDx = -dAlphaDx - dBetaDx, dGammaDy = -dAlphaDy - dBetaDy;
+    const float dudx = (uv[0].x * dAlphaDx + uv[1].x * dBetaDx) + uv[2].x * dGammaDx;
+    const float dvdx = (uv[0].y * dAlphaDx + uv[1].y * dBetaDx) + uv[2].y * dGammaDx;
+    const float dudy = (uv[0].x * dAlphaDy + uv[1].x * dBetaDy) + uv[2].x * dGammaDy;
+    const float dvdy = (uv[0].y * dAlphaDy + uv[1].y * dBetaDy) + uv[2].y * dGammaDy;
+    if (!((dudx == dudx) && (dudy == dudy) && (dvdx == dvdx) && (dvdy == dvdy))) return;   /* NaN guard */
+    *ddx = ov2(dudx, dvdx); *ddy = ov2(dudy, dvdy);
+}
 static ovec4 sample_tex(const AttrCtx* a, const TexInfo* info) {
-    return texture_pool_sample_no_mips(a->s, info, texture_uv(a, info));
+    if (!a->grad) return texture_pool_sample_no_mips(a->s, info, texture_uv(a, info));
+    ovec2 ddx, ddy;
+    get_uv_derivatives(a, info, &ddx, &ddy);
+    return texture_pool_sample_grad(a->s, info, texture_uv(a, info), ddx, ddy);
 }
 
 /* ---------------- pbr_material.wgsl ---------------- */
@@ -665,7 +793,7 @@ static uint32_t find_draw(const OracleScene* s, uint32_t rank, uint32_t* first_r
  * formats: RG16F barycentric.xy and RGBA16F packed normal/tangent.  The varyings are interpolated at the PIXEL CENTRE
  * (WGSL default @interpolate(perspective, center)); with MSAA the centre may lie outside the triangle and the values
  * extrapolate — every sample the triangle covers in that pixel receives the same values. */
-typedef struct { float bx, by; ovec4 packed_nt; int valid; } GBufferTexel;
+typedef struct { float bx, by; ovec4 packed_nt; ovec4 bary_derivs; int valid; } GBufferTexel;
 static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const float* nt, uint32_t rank, int cx, int cy) {
     GBufferTexel g; memset(&g, 0, sizeof g);
     const float* v0 = clip + (size_t)rank * 12;
@@ -684,6 +812,19 @@ static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const
     ovec4 packed = o_pack_normal_tangent(Nn, Tn, Ti.w);
     g.packed_nt = ov4(o_round_f16(packed.x), o_round_f16(packed.y), o_round_f16(packed.z), o_round_f16(packed.w));   /* RGBA16F */
     g.bx = o_round_f16(b0); g.by = o_round_f16(b1);                                                                   /* RG16F */
+    if (s->mipmap) {
+        /* fragment.wgsl:46-51 dpdx/dpdy of the barycentrics.  Contract ("fine" derivatives of a 2x2 quad): the difference
+         * between the two pixels of the quad row / column this pixel sits in, both evaluated for THIS triangle (helper
+         * invocations extrapolate), right minus left and bottom minus top; then RGBA16F. */
+        float eh[3], ev[3];
+        oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx ^ 1, cy, eh);
+        oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy ^ 1, ev);
+        const float sh = (eh[0] + eh[1]) + eh[2], sv = (ev[0] + ev[1]) + ev[2];
+        const float h0 = eh[0] / sh, h1 = eh[1] / sh, w0 = ev[0] / sv, w1 = ev[1] / sv;
+        const float ddx0 = (cx & 1) ? b0 - h0 : h0 - b0, ddx1 = (cx & 1) ? b1 - h1 : h1 - b1;
+        const float ddy0 = (cy & 1) ? b0 - w0 : w0 - b0, ddy1 = (cy & 1) ? b1 - w1 : w1 - b1;
+        g.bary_derivs = ov4(o_round_f16(ddx0), o_round_f16(ddy0), o_round_f16(ddx1), o_round_f16(ddy1));
+    }
     g.valid = 1;
     return g;
 }
@@ -718,6 +859,8 @@ static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const
     a.attribute_data_offset = meta.attr_data_offset / 4u;
     a.uv_sets_index = meta.uv_sets_index;
     a.bary = barycentric;
+    a.grad = s->mipmap != 0u;
+    a.bary_derivs = g.bary_derivs;
     const uint32_t* attr_idx = (const uint32_t*)s->buf[AWSM_BUF_ATTR_INDEX];
     uint32_t base_tri = meta.attr_indices_offset / 4u + triangle_index * 3u;
     a.tri[0] = attr_idx[base_tri]; a.tri[1] = attr_idx[base_tri + 1]; a.tri[2] = attr_idx[base_tri + 2];

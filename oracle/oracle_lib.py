@@ -29,7 +29,7 @@ class AwsmSampler(C.Structure):
 
 
 class OracleTexArray(C.Structure):
-    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("layers", C.c_uint32)]
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("layers", C.c_uint32), ("mips", C.c_uint32)]
 
 
 class OracleScene(C.Structure):
@@ -38,7 +38,7 @@ class OracleScene(C.Structure):
                 ("n_tex_arrays", C.c_uint32), ("tex_arrays", OracleTexArray * MAX_TEX), ("n_samplers", C.c_uint32),
                 ("samplers", AwsmSampler * MAX_SAMPLERS), ("skybox_rgba", C.c_float * 4), ("prefiltered_rgb", C.c_float * 4),
                 ("irradiance_rgb", C.c_float * 4), ("brdf_lut_rg16f", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
-                ("msaa", C.c_uint32), ("pad_", C.c_uint32)]
+                ("msaa", C.c_uint32), ("mipmap", C.c_uint32)]
 
 
 def build(force: bool = False) -> str:
@@ -58,6 +58,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_total_vertices.restype = C.c_uint32
+        _lib.oracle_mip_levels.restype = C.c_uint32
         _lib.oracle_det_atan2f.restype = C.c_float
         _lib.oracle_det_atan2f.argtypes = [C.c_float, C.c_float]
         _lib.oracle_f32_to_f16.restype = C.c_uint16
@@ -74,6 +75,30 @@ def brdf_lut(width: int, height: int, threads: int = 8) -> np.ndarray:
     return out
 
 
+def mip_levels(width: int, height: int) -> int:
+    return int(lib().oracle_mip_levels(C.c_uint32(width), C.c_uint32(height)))
+
+
+def mip_chain(texels: np.ndarray, kinds=None):
+    """[layers, h, w, 4] level 0 -> (flat uint8 chain [level][layer][h_l][w_l][4], levels): the oracle's generate_mipmaps."""
+    layers, h, w, _ = texels.shape
+    L = lib()
+    L.oracle_mip_chain_bytes.restype = C.c_size_t
+    levels = mip_levels(w, h)
+    n = int(L.oracle_mip_chain_bytes(C.c_uint32(w), C.c_uint32(h), C.c_uint32(layers), C.c_uint32(levels)))
+    chain = np.zeros(n + 16, dtype=np.uint8)
+    chain[: layers * h * w * 4] = np.ascontiguousarray(texels, dtype=np.uint8).reshape(-1)
+    k = (C.c_uint32 * layers)(*([0] * layers if kinds is None else [int(x) for x in kinds]))
+    assert L.oracle_generate_mips(C.c_uint32(w), C.c_uint32(h), C.c_uint32(layers), k, C.c_uint32(levels), chain.ctypes.data_as(C.c_void_p)) == 0
+    return chain, levels
+
+
+def mip_level_view(chain: np.ndarray, width: int, height: int, layers: int, level: int) -> np.ndarray:
+    off = sum(layers * max(1, width >> l) * max(1, height >> l) for l in range(level)) * 4
+    wl, hl = max(1, width >> level), max(1, height >> level)
+    return chain[off: off + layers * hl * wl * 4].reshape(layers, hl, wl, 4)
+
+
 def lut_rg_to_rgba16f(rg: np.ndarray) -> np.ndarray:
     """RG16F -> the reference's RGBA16F texel (b = 0, a = 1.0)."""
     h, w, _ = rg.shape
@@ -87,7 +112,7 @@ class OracleFrame:
     """Holds the numpy arrays an OracleScene points at and runs the three oracle stages."""
 
     def __init__(self, mirrors: Dict[int, bytes], draws: List[dict], width: int, height: int, tex_arrays: List[dict], samplers: List[dict],
-                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True, msaa=0):
+                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True, msaa=0, mipmap=False):
         self._keep = []
         s = OracleScene()
         for i in range(BUF_COUNT):
@@ -109,10 +134,18 @@ class OracleFrame:
         s.msaa = msaa
         self.msaa = msaa
         s.n_tex_arrays = len(tex_arrays)
+        s.mipmap = 1 if mipmap else 0
+        self.mip_chains = []
         for i, t in enumerate(tex_arrays):
+            if mipmap:     # TexturePoolArray: mipmap = true, full chain generated per layer kind (texture_pool.rs:187-320)
+                chain, levels = mip_chain(t["texels"], t.get("kinds"))
+                self._keep.append(chain)
+                self.mip_chains.append((chain, levels))
+                s.tex_arrays[i] = OracleTexArray(chain.ctypes.data, t["width"], t["height"], t["layers"], levels)
+                continue
             arr = np.ascontiguousarray(t["texels"], dtype=np.uint8)
             self._keep.append(arr)
-            s.tex_arrays[i] = OracleTexArray(arr.ctypes.data, t["width"], t["height"], t["layers"])
+            s.tex_arrays[i] = OracleTexArray(arr.ctypes.data, t["width"], t["height"], t["layers"], 1)
         s.n_samplers = len(samplers)
         for i, sm in enumerate(samplers):
             s.samplers[i] = AwsmSampler(sm.get("address_mode_u", 1), sm.get("address_mode_v", 1), sm.get("mag_filter", 1), sm.get("min_filter", 1),
@@ -160,7 +193,7 @@ class OracleFrame:
         return tri, meta, depth
 
 
-def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0) -> OracleFrame:
+def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0, mipmap=False) -> OracleFrame:
     sc = model.scene
     return OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,
-                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque, msaa=msaa)
+                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap)

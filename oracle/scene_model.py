@@ -40,7 +40,7 @@ from .host_mirror import (Aabb, DynamicStorageBuffer, DynamicUniformBuffer, Frus
  BUF_VIS_GEOM_INDEX, BUF_ATTR_DATA, BUF_ATTR_INDEX, BUF_TEXTURE_TRANSFORMS, BUF_INSTANCES) = range(18)
 BUF_COUNT = 18
 
-from awsm_renderer_amd.scene_desc import (MaterialDesc, NodeDesc, PrimitiveDesc, SceneDesc, SkinDesc, TextureRef)  # noqa: E402,F401
+from awsm_renderer_amd.scene_desc import (MaterialDesc, NodeDesc, PrimitiveDesc, SceneDesc, SkinDesc, TextureRef, texture_mip_kinds)  # noqa: E402,F401
 
 # ------------------------------------------------------------------------------------------------ packers (gltf/buffers)
 
@@ -254,14 +254,15 @@ class TexturePool:
         self.arrays: List[dict] = []          # {width,height,layers:[np.ndarray]}
         self.entries: Dict[int, Tuple[int, int]] = {}   # texture index -> (array_index, layer_index)
 
-    def insert(self, tex_index: int, image: np.ndarray):
+    def insert(self, tex_index: int, image: np.ndarray, mip_kind: int = 0):
         h, w = image.shape[:2]
         for ai, a in enumerate(self.arrays):
             if a["width"] == w and a["height"] == h:
                 a["layers"].append(image)
+                a["kinds"].append(mip_kind)
                 self.entries[tex_index] = (ai, len(a["layers"]) - 1)
                 return
-        self.arrays.append({"width": w, "height": h, "layers": [image]})
+        self.arrays.append({"width": w, "height": h, "layers": [image], "kinds": [mip_kind]})
         self.entries[tex_index] = (len(self.arrays) - 1, 0)
 
 
@@ -283,7 +284,7 @@ class MaterialPacker:
         size = (arr["height"] << 16) | (arr["width"] & 0xFFFF)
         array_and_layer = (li << 12) | (ai & 0xFFF)
         uv_and_sampler = (ref.sampler << 8) | (ref.uv_index & 0xFF)
-        flags = 1  # exists; bit1 (mipmaps) off: MipmapMode::None configs
+        flags = 1 | 2  # bit0 exists; bit1 has mipmaps: TexturePoolArray::new sets mipmap = true for every array (texture_pool.rs:166-176, writer.rs:163-171)
         extra = flags | ((encode_address_mode(smp.get("address_mode_u", 1)) & 0xFF) << 8) | ((encode_address_mode(smp.get("address_mode_v", 1)) & 0xFF) << 16)
         toff = self.tt.offset_for(ref.transform)
         return struct.pack("<5I", size, array_and_layer, uv_and_sampler, extra, toff)
@@ -392,8 +393,9 @@ class HostModel:
         self.transforms = Transforms()
         self.tex_transforms = TextureTransforms()
         self.pool = TexturePool()
+        kinds = texture_mip_kinds(scene)
         for i, t in enumerate(scene.textures):
-            self.pool.insert(i, t)
+            self.pool.insert(i, t, kinds[i])
         self.mat_packer = MaterialPacker(self.pool, scene.samplers, self.tex_transforms)
         self.materials_keys = SlotMap()
         self.materials = DynamicStorageBuffer(8192)
@@ -616,6 +618,6 @@ class HostModel:
     def texture_arrays(self) -> List[dict]:
         out = []
         for a in self.pool.arrays:
-            out.append({"width": a["width"], "height": a["height"], "layers": len(a["layers"]),
+            out.append({"width": a["width"], "height": a["height"], "layers": len(a["layers"]), "kinds": list(a["kinds"]),
                         "texels": np.ascontiguousarray(np.stack(a["layers"]).astype(np.uint8))})
         return out

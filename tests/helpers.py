@@ -15,11 +15,11 @@ def build_model(scene):
     return m
 
 
-def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0):
-    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa).run(threads)
+def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0, mipmap=False):
+    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap).run(threads)
 
 
-def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0):
+def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False):
     """Drive one frame through the C-ABI exactly as the host layer does: create+write every mirror, then the passes."""
     from awsm_renderer_amd.hip_backend import HipDevice
     sc = model.scene
@@ -27,7 +27,11 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0):
     dev.resize(sc.width, sc.height, msaa)
     dev.upload_mirrors(model.mirrors())
     for i, t in enumerate(model.texture_arrays()):
-        dev.texture_array_upload(i, t["texels"])
+        if mipmap:
+            dev.texture_array_upload(i, t["texels"], mips=oracle_lib.mip_levels(t["width"], t["height"]))
+            dev.texture_array_generate_mips(i, t["kinds"])
+        else:
+            dev.texture_array_upload(i, t["texels"])
     for i, s in enumerate(sc.samplers):
         dev.sampler_set(i, s)
     dev.env_upload(sc.skybox_rgba, sc.prefiltered_rgb, sc.irradiance_rgb, oracle_lib.lut_rg_to_rgba16f(lut))
@@ -35,7 +39,7 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0):
         dev.set_shard_rows(*rows)
     draws = model.collect_draws()
     dev.geometry_pass(draws)
-    dev.opaque_pass(has_opaque=has_opaque)
+    dev.opaque_pass(has_opaque=has_opaque, mipmap=1 if mipmap else 0)
     stats = dev.frame_end()
     return dev, stats
 

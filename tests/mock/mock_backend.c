@@ -35,6 +35,8 @@ int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf w, size_t off, const void* src,
 }
 int awsm_hip_resize(AwsmHipCtx* c, uint32_t w, uint32_t h, uint32_t msaa) { if (msaa) return AWSM_ERR_UNSUPPORTED; c->width = w; c->height = h; logc(c, 3, 0, w, h); return 0; }
 int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) { logc(c, 11, 0, y0, y1); return 0; }
+int awsm_hip_texture_array_generate_mips(AwsmHipCtx* c, uint32_t idx, const uint32_t* kinds) { logc(c, 14, (int)idx, kinds ? kinds[0] : 0, 0); return 0; }
+int awsm_hip_texture_array_read_level(AwsmHipCtx* c, uint32_t idx, uint32_t level, void* out) { (void)c; (void)idx; (void)level; (void)out; return AWSM_ERR_UNSUPPORTED; }
 int awsm_hip_pick(AwsmHipCtx* c, int32_t x, int32_t y, AwsmPick* out) { logc(c, 13, 0, (uint32_t)x, (uint32_t)y); out->valid = 0; out->mesh_key_high = 0; out->mesh_key_low = 0; out->triangle_index = 0xFFFFFFFFu; return 0; }
 int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t compact) { logc(c, 12, (int)compact, n, r); return 0; }
 int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t idx, uint32_t w, uint32_t h, uint32_t layers, uint32_t mips, AwsmTexFormat fmt, const void* t) {
