@@ -774,7 +774,7 @@ AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
 // 16x4 here).  5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 spills.
 // ------------------------------------------------------------------------------------------------
 template <bool GRAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
     ShadeBlock b;
     if (!shade_block(f, b)) return;
     const int cx = b.x0 + (int)(threadIdx.x & 15u), cy = b.y0 + (int)(threadIdx.x >> 4);

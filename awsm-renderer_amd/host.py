@@ -13,7 +13,7 @@ import numpy as np
 
 from . import PACKAGE_DIR, hip_backend
 from .hip_backend import AwsmDraw, AwsmEnv, AwsmFrameStats, AwsmSampler
-from .scene_desc import MaterialDesc, SceneDesc, TextureRef
+from .scene_desc import MaterialDesc, SceneDesc, TextureRef, texture_mip_kinds
 
 LIB_PATH = os.path.join(PACKAGE_DIR, "libawsm_host.so")
 F32P = C.POINTER(C.c_float)
@@ -85,7 +85,8 @@ def load_library():
         "awsm_host_brdf_lut_generate": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_resize": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
         "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
-        "awsm_host_set_anti_aliasing": (C.c_int, [vp, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
+        "awsm_host_set_anti_aliasing": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+        "awsm_host_texture_insert_kind": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
         "awsm_host_texture_array_info": (C.c_int, [vp, C.c_uint32, U32P, U32P, U32P, C.POINTER(vp)]),
@@ -160,9 +161,9 @@ class Host:
         return out.reshape(4, 4)
 
     # ---- textures / samplers ----
-    def texture_insert(self, image: np.ndarray) -> int:
+    def texture_insert(self, image: np.ndarray, mip_kind: int = 0) -> int:
         img = np.ascontiguousarray(image, dtype=np.uint8)
-        r = self.lib.awsm_host_texture_insert(self.h, img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0])
+        r = self.lib.awsm_host_texture_insert_kind(self.h, img.ctypes.data_as(C.c_void_p), img.shape[1], img.shape[0], mip_kind)
         if r < 0:
             self._chk(r, "texture_insert")
         return r
@@ -284,9 +285,9 @@ class Host:
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_host_set_shard_rows(self.h, y0, y1), "set_shard_rows")
 
-    def set_anti_aliasing(self, msaa_sample_count: int = 0):
-        """AwsmRenderer::set_anti_aliasing: 0 (None) or 4 (the reference's default)."""
-        self._chk(self.lib.awsm_host_set_anti_aliasing(self.h, msaa_sample_count), "set_anti_aliasing")
+    def set_anti_aliasing(self, msaa_sample_count: int = 0, mipmap: bool = False):
+        """AwsmRenderer::set_anti_aliasing: msaa 0 (None) or 4, gradient mipmaps on/off (the reference's default: 4, True)."""
+        self._chk(self.lib.awsm_host_set_anti_aliasing(self.h, msaa_sample_count, 1 if mipmap else 0), "set_anti_aliasing")
 
     def pick(self, x: int, y: int):
         """AwsmRenderer::pick: the MeshKey under pixel (x, y) of the last rendered frame, or None (PickResult::Miss)."""
@@ -396,8 +397,9 @@ class Populated:
 
 def populate(host: Host, scene: SceneDesc) -> Populated:
     out = Populated()
-    for tex in scene.textures:
-        host.texture_insert(tex)
+    kinds = texture_mip_kinds(scene)
+    for tex, kind in zip(scene.textures, kinds):
+        host.texture_insert(tex, kind)
     for s in scene.samplers:
         host.sampler_insert(s)
     host.set_ibl_mip_counts(scene.prefiltered_mip_count, scene.irradiance_mip_count)
@@ -445,10 +447,10 @@ class Renderer:
     """Convenience wrapper: Host + populated scene, frame loop = update_all -> render (crates/renderer/src/update.rs, render.rs)."""
 
     def __init__(self, scene: SceneDesc, backend_path: Optional[str] = None, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False,
-                 lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024, msaa: int = 0):
+                 lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024, msaa: int = 0, mipmap: bool = False):
         self.scene = scene
         self.host = Host(backend_path, device, stream, parity_tap)
-        self.host.set_anti_aliasing(msaa)       # AwsmRendererBuilder::with_anti_aliasing (None here unless asked: BASELINE configs are single-sampled)
+        self.host.set_anti_aliasing(msaa, mipmap)   # AwsmRendererBuilder::with_anti_aliasing (off unless asked: BASELINE configs are single-sampled, MipmapMode::None)
         self.host.resize(scene.width, scene.height)
         self.keys = populate(self.host, scene)
         if lut_rgba16f is not None:

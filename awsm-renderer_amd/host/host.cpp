@@ -49,6 +49,7 @@ struct Backend {
     int (*set_shard_bands)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t) = nullptr;
     int (*pick)(AwsmHipCtx*, int32_t, int32_t, AwsmPick*) = nullptr;
     int (*texture_array_upload)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, AwsmTexFormat, const void*) = nullptr;
+    int (*texture_array_generate_mips)(AwsmHipCtx*, uint32_t, const uint32_t*) = nullptr;
     int (*sampler_set)(AwsmHipCtx*, uint32_t, const AwsmSampler*) = nullptr;
     int (*env_upload)(AwsmHipCtx*, const AwsmEnv*) = nullptr;
     int (*brdf_lut_generate)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
@@ -129,7 +130,7 @@ struct AwsmHost {
     DynamicUniformBuffer normals_buf{32, 36};
 
     // ---- textures.rs ----
-    struct PoolArray { uint32_t w, h; std::vector<uint8_t> texels; uint32_t layers = 0; bool dirty = true; };
+    struct PoolArray { uint32_t w, h; std::vector<uint8_t> texels; uint32_t layers = 0; bool dirty = true; std::vector<uint32_t> kinds; };   // kinds: MipmapTextureKind per layer
     std::vector<PoolArray> pool;
     std::vector<std::pair<uint32_t, uint32_t>> tex_entries;   // texture id -> (array, layer)
     std::vector<AwsmSampler> samplers;
@@ -174,6 +175,7 @@ struct AwsmHost {
     uint32_t frame_count = 0;
     uint32_t width = 0, height = 0;
     uint32_t msaa_sample_count = 0;   // AntiAliasing::msaa_sample_count: 0 = None, 4 = Some(4)
+    bool mipmap = false;              // AntiAliasing::mipmap: MipmapMode::Gradient vs None in the opaque pass
 
     bool created[AWSM_BUF_COUNT] = {};
     uint64_t upload_bytes = 0;
@@ -424,7 +426,7 @@ int awsm_host_create(const char* backend_path, int device, void* stream, uint32_
               load_sym(h.get(), b.last_error, "awsm_hip_last_error") && load_sym(h.get(), b.abi_version, "awsm_hip_abi_version") &&
               load_sym(h.get(), b.buffer_create, "awsm_hip_buffer_create") && load_sym(h.get(), b.buffer_write, "awsm_hip_buffer_write") &&
               load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") && load_sym(h.get(), b.set_shard_bands, "awsm_hip_set_shard_bands") && load_sym(h.get(), b.pick, "awsm_hip_pick") &&
-              load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
+              load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.texture_array_generate_mips, "awsm_hip_texture_array_generate_mips") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
               load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
               load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") &&
               load_sym(h.get(), b.frame_end, "awsm_hip_frame_end");
@@ -517,16 +519,21 @@ int awsm_host_transform_world(AwsmHost* h, AwsmKey key, float out[16]) {
 }
 
 // ------------------------------------------------------------------------------------------------ textures
-int awsm_host_texture_insert(AwsmHost* h, const uint8_t* rgba8, uint32_t w, uint32_t ht) {
+int awsm_host_texture_insert(AwsmHost* h, const uint8_t* rgba8, uint32_t w, uint32_t ht) { return awsm_host_texture_insert_kind(h, rgba8, w, ht, 0u); }
+
+// TexturePool::add_image with TextureColorInfo{mipmap_kind} (gltf/populate/material.rs:128-260): the kind selects the
+// filter the array's mip generation applies to this layer.
+int awsm_host_texture_insert_kind(AwsmHost* h, const uint8_t* rgba8, uint32_t w, uint32_t ht, uint32_t mipmap_kind) {
     if (!rgba8 || !w || !ht || w > 0xFFFF || ht > 0xFFFF) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "texture_insert: bad image");
     uint32_t ai = 0;
     for (; ai < h->pool.size(); ai++) if (h->pool[ai].w == w && h->pool[ai].h == ht) break;
     if (ai == h->pool.size()) {
         if (h->pool.size() >= 64) return fail(h, AWSM_ERR_UNSUPPORTED, "more than 64 pool arrays");
-        h->pool.push_back({w, ht, {}, 0, true});
+        h->pool.push_back({w, ht, {}, 0, true, {}});
     }
     AwsmHost::PoolArray& a = h->pool[ai];
     a.texels.insert(a.texels.end(), rgba8, rgba8 + (size_t)w * ht * 4);
+    a.kinds.push_back(mipmap_kind);
     a.dirty = true;
     h->tex_entries.push_back({ai, a.layers});
     a.layers++;
@@ -771,11 +778,13 @@ int awsm_host_resize(AwsmHost* h, uint32_t w, uint32_t ht) {
     h->width = w; h->height = ht;
     return AWSM_OK;
 }
-// AwsmRenderer::set_anti_aliasing (anti_alias.rs:42-45): msaa_sample_count None (0) or Some(4); other counts are
+// AwsmRenderer::set_anti_aliasing (anti_alias.rs:42-45): {msaa_sample_count None (0) or Some(4), mipmap}; other counts are
 // AwsmError::UnsupportedMsaaCount (anti_alias.rs:19-25).  The render targets are recreated (TextureViewRecreate).
-int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count) {
+int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count, uint32_t mipmap) {
     if (!h) return AWSM_ERR_INVALID_ARGUMENT;
     if (msaa_sample_count != 0 && msaa_sample_count != 4) { h->last_error = "UnsupportedMsaaCount"; return AWSM_ERR_UNSUPPORTED; }
+    h->mipmap = mipmap != 0;
+    if (h->msaa_sample_count == msaa_sample_count) return AWSM_OK;
     h->msaa_sample_count = msaa_sample_count;
     return h->width ? awsm_host_resize(h, h->width, h->height) : AWSM_OK;
 }
@@ -879,14 +888,18 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
     for (uint32_t i = 0; i < h->pool.size(); i++) {   // finalize_gpu_textures: (re)upload arrays that gained layers
         AwsmHost::PoolArray& a = h->pool[i];
         if (!a.dirty) continue;
-        if ((rc = h->be.texture_array_upload(h->ctx, i, a.w, a.h, a.layers, 1, AWSM_TEX_RGBA8_UNORM, a.texels.data()))) return dev_fail(h, rc, "texture_array_upload");
+        // TexturePoolArray::new: mipmap = true for every array -> full chain (texture_pool.rs:166-176,187-192,317-319)
+        uint32_t levels = 1;
+        for (uint32_t m = std::max(a.w, a.h); m > 1u; m >>= 1) levels++;
+        if ((rc = h->be.texture_array_upload(h->ctx, i, a.w, a.h, a.layers, levels, AWSM_TEX_RGBA8_UNORM, a.texels.data()))) return dev_fail(h, rc, "texture_array_upload");
+        if ((rc = h->be.texture_array_generate_mips(h->ctx, i, a.kinds.data()))) return dev_fail(h, rc, "texture_array_generate_mips");
         a.dirty = false;
     }
     // ---- collect_renderables -> geometry pass -> opaque pass (render.rs:144-221) ----
     collect_draws(h, h->last_draws);
     if ((rc = h->be.geometry_pass(h->ctx, h->last_draws.data(), (uint32_t)h->last_draws.size()))) return dev_fail(h, rc, "geometry_pass");
     AwsmOpaqueParams op{};
-    op.mipmap = 0; op.has_opaque = h->last_draws.empty() ? 0u : 1u;   // material_opaque/render_pass.rs:64-71
+    op.mipmap = h->mipmap ? 1u : 0u; op.has_opaque = h->last_draws.empty() ? 0u : 1u;   // material_opaque/render_pass.rs:64-71
     if ((rc = h->be.opaque_pass(h->ctx, &op))) return dev_fail(h, rc, "opaque_pass");
     if (sync) { if ((rc = h->be.frame_end(h->ctx, stats))) return dev_fail(h, rc, "frame_end"); }   // gpu.submit_commands (render.rs:370)
     return AWSM_OK;

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--tex-scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=30)
+    ap.add_argument("--mipmap", action="store_true", help="MipmapMode::Gradient (the reference's default; not the BASELINE config)")
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4), help="MSAA x4 geometry + edge resolve (the reference's default AntiAliasing; not the BASELINE config)")
     ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
     args = ap.parse_args()
@@ -137,7 +138,7 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa)
+    r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa, mipmap=args.mipmap)
     from awsm_renderer_amd.hip_backend import HipDevice
     dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
     # N > 1: 32-row bands dealt round-robin over the ranks (rank r owns tile rows r, r+N, ...: every rank gets 1/N of the
@@ -291,7 +292,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "shaded_mpix_per_s": W * H * fps / 1e6,
             "config": {"workload": f"Sponza-class procedural atrium (configs[3]): {n_tris} triangles, {len(scene.materials)} materials, "
-                                   f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + ", MipmapMode::None",
+                                   f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + (", MipmapMode::Gradient" if args.mipmap else ", MipmapMode::None"),
                        "triangles": n_tris, "width": W, "height": H,
                        "sharding": sharding_desc,
                        "draws": len(r.host.draw_list())},

@@ -43,7 +43,9 @@ AwsmKey awsm_host_transform_parent(AwsmHost* h, AwsmKey child);          /* 0 if
 int awsm_host_transform_world(AwsmHost* h, AwsmKey key, float out_mat4[16]);
 
 /* ---- Textures (textures.rs; renderer-core texture_pool): decoded RGBA8 images, one array per (w,h) ---- */
-int awsm_host_texture_insert(AwsmHost* h, const uint8_t* rgba8, uint32_t width, uint32_t height);   /* returns texture id >= 0 */
+int awsm_host_texture_insert(AwsmHost* h, const uint8_t* rgba8, uint32_t width, uint32_t height);   /* returns texture id >= 0; mip kind albedo */
+/* with the MipmapTextureKind the image's role implies (0 albedo, 1 normal, 2 metallic-roughness, 3 occlusion, 4 emissive, 5.. box) */
+int awsm_host_texture_insert_kind(AwsmHost* h, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t mipmap_kind);
 int awsm_host_sampler_insert(AwsmHost* h, const AwsmSampler* sampler);                                /* returns sampler id >= 0 */
 AwsmKey awsm_host_texture_transform_insert(AwsmHost* h, const float offset[2], const float origin[2], float rotation, const float scale[2]);
 
@@ -121,8 +123,9 @@ int awsm_host_camera_update(AwsmHost* h, const float view[16], const float proje
 int awsm_host_env(AwsmHost* h, const AwsmEnv* env);
 int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t height);
 int awsm_host_resize(AwsmHost* h, uint32_t width, uint32_t height);
-/* AwsmRenderer::set_anti_aliasing (anti_alias.rs:42-45): msaa_sample_count 0 (None) or 4; recreates the render targets */
-int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count);
+/* AwsmRenderer::set_anti_aliasing (anti_alias.rs:9-45): msaa_sample_count 0 (None) or 4 (recreates the render targets);
+ * mipmap != 0 selects MipmapMode::Gradient in the opaque pass.  The reference's default is {Some(4), mipmap: true}. */
+int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count, uint32_t mipmap);
 int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1);
 /* AwsmRenderer::pick (picker.rs:55-121): *hit = 1 and *mesh_key = the MeshKey (KeyData::as_ffi) under pixel (x, y) of the last frame, else *hit = 0 */
 int awsm_host_pick(AwsmHost* h, int32_t x, int32_t y, uint32_t* hit, uint64_t* mesh_key);

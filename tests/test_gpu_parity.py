@@ -305,7 +305,7 @@ def test_msaa4_through_host_layer(oracle_lut):
     res = helpers.compare_frames(orc4, dev, rgb_tol=RGB_TOL)
     assert res["key_mismatch"] == 0 and res["rgb_over_tol"] == 0 and res["f16_max_ulp"] <= 2 and stats["covered_pixels"] == res["covered"], (res, stats)
     assert r.host.pick(160, 90) == dev.pick(160, 90)[0]
-    r.host.set_anti_aliasing(0)
+    r.host.set_anti_aliasing(0, False)
     dev.msaa = 0
     r.render(sync=True)
     orc1 = helpers.oracle_frame(model, oracle_lut)
@@ -378,3 +378,16 @@ def test_gradient_mipmaps(name, msaa, oracle_lut):
         base = helpers.oracle_frame(model, oracle_lut)
         assert float(np.abs(base.rgba32f - orc.rgba32f).max()) > 0.02
     dev.close()
+
+
+@pytest.mark.gpu
+def test_reference_default_anti_aliasing_through_host_layer(oracle_lut):
+    """AntiAliasing::default() = {msaa_sample_count: Some(4), mipmap: true} (anti_alias.rs:28-38) through the C++ host: the
+    host generates every array's mip chain with the per-role kinds and selects the MSAA + gradient pipeline."""
+    sc = scenes.atrium_scene(480, 270, detail=0.25, tex_scale=1 / 16)
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut, msaa=4, mipmap=True)
+    r, dev, stats = helpers.host_frame(sc, oracle_lut, msaa=4, mipmap=True)
+    res = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert res["key_mismatch"] == 0 and res["rgb_over_tol"] == 0 and res["f16_max_ulp"] <= 2 and stats["covered_pixels"] == res["covered"], (res, stats)
+    r.close()

@@ -15,7 +15,7 @@ from tests import helpers
 
 MOCK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock")
 MOCK = os.path.join(MOCK_DIR, "libmock_backend.so")
-OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick"}
+OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips"}
 
 
 @pytest.fixture(scope="module")
