@@ -40,7 +40,17 @@ struct DevBuf {
     size_t size = 0;
 };
 
-enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE, EV_COUNT };
+enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE, EV_COUNT };
+
+// Everything the geometry pass produces for one frame and the opaque pass consumes.
+struct FrameBufs {
+    DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
+    DevBuf camera;                         // snapshot of the camera UBO taken by the geometry pass (overlap mode)
+    uint32_t bin_capacity = 0;
+    std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
+    void* draws_uploaded_ptr = nullptr;
+    bool draws_uploaded_valid = false;
+};
 
 }  // namespace
 
@@ -65,16 +75,22 @@ struct AwsmHipCtx {
     uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
     DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
-    DevBuf vis, out16, out32;
+    DevBuf out16, out32;
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
 
     // geometry-pass resources
-    DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters;
+    // Frame overlap (AWSM_CFG_OVERLAP_FRAMES): the opaque pass of frame i runs on shade_stream while the caller's stream
+    // already runs the geometry pass of frame i+1 into the other slot.
+    bool overlap = false;
+    hipStream_t shade_stream = nullptr;
+    hipEvent_t ev_geom_done[2] = {}, ev_shade_done[2] = {};
+    bool shade_pending[2] = {false, false};
+    FrameBufs fb[2];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
+    int slot = 0;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
     uint32_t total_tris = 0, total_verts = 0, n_blocks = 0;
-    uint32_t bin_capacity = 0;
     bool geometry_done = false, opaque_done = false;
     AwsmOpaqueParams last_opaque{};
     uint32_t overflow_retries = 0;
@@ -87,12 +103,12 @@ struct AwsmHipCtx {
 
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid[EV_COUNT] = {};
-    std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
-    void* draws_uploaded_ptr = nullptr;
-    bool draws_uploaded_valid = false;
 };
 
 namespace {
+
+inline FrameBufs& FB(AwsmHipCtx* c) { return c->fb[c->slot]; }
+inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade_stream : c->stream; }
 
 int fail(AwsmHipCtx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -119,6 +135,7 @@ int dev_realloc(AwsmHipCtx* c, DevBuf& b, size_t bytes, bool zero) {
     }
     if (b.ptr) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->shade_stream) HIPCHK(c, hipStreamSynchronize(c->shade_stream));
         HIPCHK(c, hipFree(b.ptr));
         b.ptr = nullptr; b.size = 0;
     }
@@ -177,8 +194,25 @@ void shard(const AwsmHipCtx* c, uint32_t* y0, uint32_t* y1) {
     if (*y0 > *y1) *y0 = *y1;
 }
 
+// Overlap mode: anything that writes scene state the opaque pass reads (every buffer but the camera, whose snapshot the
+// geometry pass takes; textures; samplers; environment; the DevScene table) is ordered after the opaque passes still in
+// flight on the shade stream.  A frame therefore always shades the scene as it was when it was submitted.
+int scene_write_barrier(AwsmHipCtx* c) {
+    if (!c->overlap) return AWSM_OK;
+    for (int s = 0; s < 2; s++)
+        if (c->shade_pending[s]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[s], 0)); c->shade_pending[s] = false; }
+    return AWSM_OK;
+}
+int sync_all(AwsmHipCtx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->shade_stream) HIPCHK(c, hipStreamSynchronize(c->shade_stream));
+    c->shade_pending[0] = c->shade_pending[1] = false;
+    return AWSM_OK;
+}
+
 int sync_scene(AwsmHipCtx* c) {
     if (!c->scene_dirty) return AWSM_OK;
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     for (int i = 0; i < AWSM_BUF_COUNT; i++) c->scene.buf[i] = (const uint8_t*)c->bufs[i].ptr;
     c->scene.lut_rg16f = (const uint16_t*)c->lut.ptr;
     int rc = upload_small(c, c->scene_dev, &c->scene, sizeof(DevScene));
@@ -207,18 +241,19 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     }
     f->n_draws = (uint32_t)c->draws_host.size();
     f->total_tris = c->total_tris; f->total_verts = c->total_verts;
-    f->bin_capacity = c->bin_capacity;
-    f->draws = (const DrawDev*)c->draws_dev.ptr;
-    f->draw_shade = (DrawShadeDev*)c->draw_shade.ptr;
-    f->clip = (float4*)c->clip.ptr; f->nrm = (float4*)c->nrm.ptr; f->tan = (float4*)c->tan.ptr;
-    f->tri_info = (uint32_t*)c->tri_flags.ptr;
-    f->tri_rec = (TriRec*)c->tri_rec.ptr;
-    f->tile_count = (uint32_t*)c->tile_count.ptr; f->tile_offset = (uint32_t*)c->tile_offset.ptr;
-    f->tile_cursor = (uint32_t*)c->tile_cursor.ptr; f->bin_list = (uint32_t*)c->bin_list.ptr;
-    f->tile_order = (uint32_t*)c->tile_order.ptr;
-    f->big_list = (uint32_t*)c->big_list.ptr;
-    f->counters = (uint32_t*)c->counters.ptr;
-    f->vis = (unsigned long long*)c->vis.ptr;
+    f->bin_capacity = FB(c).bin_capacity;
+    f->draws = (const DrawDev*)FB(c).draws_dev.ptr;
+    f->draw_shade = (DrawShadeDev*)FB(c).draw_shade.ptr;
+    f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
+    f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
+    f->tri_rec = (TriRec*)FB(c).tri_rec.ptr;
+    f->tile_count = (uint32_t*)FB(c).tile_count.ptr; f->tile_offset = (uint32_t*)FB(c).tile_offset.ptr;
+    f->tile_cursor = (uint32_t*)FB(c).tile_cursor.ptr; f->bin_list = (uint32_t*)FB(c).bin_list.ptr;
+    f->tile_order = (uint32_t*)FB(c).tile_order.ptr;
+    f->big_list = (uint32_t*)FB(c).big_list.ptr;
+    f->counters = (uint32_t*)FB(c).counters.ptr;
+    f->vis = (unsigned long long*)FB(c).vis.ptr;
+    f->camera = (const uint8_t*)(c->overlap ? FB(c).camera.ptr : c->bufs[AWSM_BUF_CAMERA].ptr);
     f->msaa = c->msaa;
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
@@ -226,8 +261,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->out_rgba32f = (float*)c->out32.ptr;
 }
 
-int record(AwsmHipCtx* c, int which) {
-    HIPCHK(c, hipEventRecord(c->ev[which], c->stream));
+int record(AwsmHipCtx* c, int which, hipStream_t s = nullptr) {
+    HIPCHK(c, hipEventRecord(c->ev[which], s ? s : c->stream));
     c->ev_valid[which] = true;
     return AWSM_OK;
 }
@@ -238,10 +273,16 @@ int enqueue_geometry(AwsmHipCtx* c) {
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     int rc = sync_scene(c);
     if (rc) return rc;
+    if (c->overlap) {
+        // this slot's buffers were last read by the opaque pass two frames ago
+        if (c->shade_pending[c->slot]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0)); c->shade_pending[c->slot] = false; }
+        // the camera the frame is shaded with = the camera it was submitted with
+        if (c->bufs[AWSM_BUF_CAMERA].ptr) HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size), hipMemcpyDeviceToDevice, c->stream));
+    }
     const bool has_geometry = c->total_tris && n_tiles;
     if (!has_geometry) {   // otherwise k_deform_transform clears counters + tile_count and k_bin_scan clears tile_cursor
-        HIPCHK(c, hipMemsetAsync(c->counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
-        if (n_tiles) HIPCHK(c, hipMemsetAsync(c->tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(FB(c).counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
+        if (n_tiles) HIPCHK(c, hipMemsetAsync(FB(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
     }
     if ((rc = record(c, EV_START))) return rc;
     if (c->total_tris && n_tiles) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
@@ -269,8 +310,15 @@ int enqueue_opaque(AwsmHipCtx* c) {
     }
     int rc = sync_scene(c);
     if (rc) return rc;
-    if (f.sy1 > f.sy0) awsm_launch_shade(c->scene_dev, &f, c->stream);
-    if ((rc = record(c, EV_SHADE))) return rc;
+    hipStream_t ss = shade_stream_of(c);
+    if (c->overlap) {   // the shade stream picks up where the caller's stream is now (geometry pass + uploads of this frame)
+        HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
+    }
+    if ((rc = record(c, EV_SHADE_BEGIN, ss))) return rc;
+    if (f.sy1 > f.sy0) awsm_launch_shade(c->scene_dev, &f, ss);
+    if ((rc = record(c, EV_SHADE, ss))) return rc;
+    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; }
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -282,11 +330,11 @@ uint32_t mip_levels_full(uint32_t w, uint32_t h) {   // calculate_mipmap_levels 
 }
 
 int ensure_bin_capacity(AwsmHipCtx* c, uint32_t entries) {
-    if (entries <= c->bin_capacity && c->bin_list.ptr) return AWSM_OK;
-    uint32_t cap = std::max(entries, c->bin_capacity + c->bin_capacity / 2);
-    int rc = dev_realloc(c, c->bin_list, (size_t)cap * 4, false);
+    if (entries <= FB(c).bin_capacity && FB(c).bin_list.ptr) return AWSM_OK;
+    uint32_t cap = std::max(entries, FB(c).bin_capacity + FB(c).bin_capacity / 2);
+    int rc = dev_realloc(c, FB(c).bin_list, (size_t)cap * 4, false);
     if (rc) return rc;
-    c->bin_capacity = cap;
+    FB(c).bin_capacity = cap;
     return AWSM_OK;
 }
 
@@ -320,8 +368,19 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE); c->own_stream = true; }
     for (int i = 0; i < EV_COUNT; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(AWSM_ERR_DEVICE);
     if (hipMalloc((void**)&c->scene_dev, sizeof(DevScene)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-    if (hipMalloc(&c->counters.ptr, 12 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words
-    c->counters.size = 12 * sizeof(uint32_t);
+    c->overlap = (cfg->flags & AWSM_CFG_OVERLAP_FRAMES) != 0;
+    for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
+        if (hipMalloc(&c->fb[s].counters.ptr, 12 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words
+        c->fb[s].counters.size = 12 * sizeof(uint32_t);
+    }
+    if (c->overlap) {
+        if (hipStreamCreateWithFlags(&c->shade_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        for (int s = 0; s < 2; s++) {
+            if (hipEventCreateWithFlags(&c->ev_geom_done[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+            if (hipMalloc(&c->fb[s].camera.ptr, 512) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+            c->fb[s].camera.size = 512;
+        }
+    }
     if (hipHostMalloc((void**)&c->counters_host, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
     memset(&c->scene, 0, sizeof c->scene);
     // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
@@ -335,11 +394,17 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->shade_stream) (void)hipStreamSynchronize(c->shade_stream);
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->vis); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->clip); fr(c->nrm); fr(c->tan); fr(c->tri_rec); fr(c->tri_flags);
-    fr(c->draws_dev); fr(c->draw_shade); fr(c->tile_count); fr(c->tile_offset); fr(c->tile_cursor); fr(c->tile_order); fr(c->bin_list); fr(c->big_list); fr(c->counters);
+    fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32);
+    for (FrameBufs& b : c->fb) {
+        fr(b.vis); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
+        fr(b.tile_cursor); fr(b.tile_order); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
+    }
+    if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
+    for (int i = 0; i < 2; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); }
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
@@ -362,6 +427,7 @@ int awsm_hip_device_info(AwsmHipCtx* c, char* name_out, size_t name_cap, uint32_
 int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     if (!c || (int)which < 0 || which >= AWSM_BUF_COUNT) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "buffer_create: bad buffer id %d", (int)which);
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     // +16 bytes of slack so 16-byte vector loads of the last record never leave the allocation
     int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
     if (rc) return rc;
@@ -378,6 +444,7 @@ int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf which, size_t dst_off, const vo
     if (dst_off > b.size || len > b.size - dst_off) return fail(c, AWSM_ERR_OUT_OF_RANGE, "buffer_write: [%zu,+%zu) outside buffer %d of %zu bytes", dst_off, len, (int)which, b.size);
     if (len == 0) return AWSM_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    if (which != AWSM_BUF_CAMERA) { int rcb = scene_write_barrier(c); if (rcb) return rcb; }   // the opaque pass reads a per-frame camera snapshot
     uint8_t* dst = (uint8_t*)b.ptr + dst_off;
     if (len <= (1u << 20)) return upload_small(c, dst, src, len);
     // large (resize-time) uploads: the runtime stages pageable memory itself; wait so `src` is not retained
@@ -393,8 +460,11 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     HIPCHK(c, hipSetDevice(c->device));
     const size_t px = (size_t)width * height, samples = msaa == 4 ? 4 : 1;
     int rc;
-    if ((rc = dev_realloc(c, c->vis, px * samples * 8, false))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->vis.ptr, 0xFF, px * samples * 8, c->stream));
+    if ((rc = sync_all(c))) return rc;
+    for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
+        if ((rc = dev_realloc(c, c->fb[s].vis, px * samples * 8, false))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->fb[s].vis.ptr, 0xFF, px * samples * 8, c->stream));
+    }
     if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
     c->msaa = msaa;
     if ((rc = dev_realloc(c, c->out16, px * 8, true))) return rc;
@@ -410,6 +480,7 @@ int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t com
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_bands before resize");
     if (n == 0 || r >= n) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_bands: need r < n (got n=%u r=%u)", n, r);
+    { int rcs = sync_all(c); if (rcs) return rcs; }
     if (n > 1 && c->msaa) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_bands: with MSAA use set_shard_rows (row strips carry the one-row halo the edge detector needs; bands would need one per band)");
     c->y0 = c->y1 = 0;                                   // bands and row ranges are alternatives
     c->band_n = n; c->band_r = n > 1 ? r : 0; c->band_compact = (n > 1 && compact_output) ? 1u : 0u;
@@ -419,6 +490,7 @@ int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t com
 int awsm_hip_set_shard_rows(AwsmHipCtx* c, uint32_t y0, uint32_t y1) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_rows before resize");
+    { int rcs = sync_all(c); if (rcs) return rcs; }
     c->band_n = 1; c->band_r = 0; c->band_compact = 0;   // bands and row ranges are alternatives
     if (y0 == 0 && y1 == 0) { c->y0 = c->y1 = 0; return AWSM_OK; }
     if (y0 >= y1 || y1 > c->height) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_rows: need y0 < y1 <= height (got %u,%u)", y0, y1);
@@ -436,6 +508,7 @@ int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t array_idx, uint32_t wi
     if (mips == 0) mips = 1;
     if (mips > full || mips > (uint32_t)kMaxMipLevels) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "texture_array_upload: %u mip levels, a %ux%u texture has at most %u", mips, width, height, full);
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     TexArrayDev t{};
     size_t texels_total = 0;
     for (uint32_t l = 0; l < mips; l++) { t.level_off[l] = (uint32_t)texels_total; texels_total += (size_t)layers * std::max(1u, width >> l) * std::max(1u, height >> l); }
@@ -458,6 +531,7 @@ int awsm_hip_texture_array_generate_mips(AwsmHipCtx* c, uint32_t array_idx, cons
     if (!t.texels) return fail(c, AWSM_ERR_NOT_READY, "generate_mips: array %u was never uploaded", array_idx);
     if (t.mips < 2) return AWSM_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     std::vector<uint32_t> kinds(t.layers, 0u);
     if (kind_per_layer) kinds.assign(kind_per_layer, kind_per_layer + t.layers);
     int rc = dev_reserve(c, c->mip_kinds, kinds.size() * 4);
@@ -494,6 +568,7 @@ int awsm_hip_sampler_set(AwsmHipCtx* c, uint32_t idx, const AwsmSampler* s) {
 int awsm_hip_env_upload(AwsmHipCtx* c, const AwsmEnv* env) {
     if (!c || !env) return AWSM_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     memcpy(c->scene.skybox_rgba, env->skybox_rgba, 16);
     memcpy(c->scene.prefiltered_rgb, env->prefiltered_rgb, 16);
     memcpy(c->scene.irradiance_rgb, env->irradiance_rgb, 16);
@@ -517,6 +592,7 @@ int awsm_hip_env_upload(AwsmHipCtx* c, const AwsmEnv* env) {
 int awsm_hip_brdf_lut_generate(AwsmHipCtx* c, uint32_t width, uint32_t height) {
     if (!c || width == 0 || height == 0 || width > 8192 || height > 8192) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "brdf_lut_generate: bad size");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     int rc = dev_realloc(c, c->lut, (size_t)width * height * 4, false);
     if (rc) return rc;
     awsm_launch_brdf_lut((uint32_t*)c->lut.ptr, width, height, c->stream);
@@ -542,6 +618,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if (n) for (AwsmBuf b : need) if (!c->bufs[b].ptr) return fail(c, AWSM_ERR_NOT_READY, "geometry_pass: buffer %d missing", (int)b);
     HIPCHK(c, hipSetDevice(c->device));
 
+    if (c->overlap) c->slot ^= 1;            // the previous frame's opaque pass may still be reading the other slot
     c->draws_host.clear(); c->draws_api.assign(draws, draws + n);
     uint64_t tris = 0, blocks = 0;
     bool any_morph_skin_checked = false; (void)any_morph_skin_checked;
@@ -567,31 +644,31 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
 
     int rc;
     const size_t nd = std::max<size_t>(c->draws_host.size(), 1);
-    if ((rc = dev_reserve(c, c->draws_dev, nd * sizeof(DrawDev)))) return rc;
-    if ((rc = dev_reserve(c, c->draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
-    if ((rc = dev_reserve(c, c->clip, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, c->nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, c->tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, c->tri_flags, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
-    if ((rc = dev_reserve(c, c->big_list, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
-    if ((rc = dev_reserve(c, c->tri_rec, std::max<size_t>(c->total_tris, 1) * kTriRecBytes))) return rc;
+    if ((rc = dev_reserve(c, FB(c).draws_dev, nd * sizeof(DrawDev)))) return rc;
+    if ((rc = dev_reserve(c, FB(c).draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
+    if ((rc = dev_reserve(c, FB(c).clip, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
+    if ((rc = dev_reserve(c, FB(c).nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tri_flags, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, FB(c).big_list, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tri_rec, std::max<size_t>(c->total_tris, 1) * kTriRecBytes))) return rc;
     const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
     const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
-    if ((rc = dev_reserve(c, c->tile_count, n_tiles_full * 4))) return rc;
-    if ((rc = dev_reserve(c, c->tile_offset, (n_tiles_full + 1) * 4))) return rc;
-    if ((rc = dev_reserve(c, c->tile_cursor, n_tiles_full * 4))) return rc;
-    if ((rc = dev_reserve(c, c->tile_order, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tile_count, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tile_offset, (n_tiles_full + 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tile_cursor, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, FB(c).tile_order, n_tiles_full * 4))) return rc;
     if ((rc = ensure_bin_capacity(c, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
     // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
     // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
-    const bool same_draws = c->draws_uploaded_valid && c->draws_uploaded_ptr == c->draws_dev.ptr &&
-                            c->draws_uploaded.size() == c->draws_host.size() &&
-                            (c->draws_host.empty() || memcmp(c->draws_uploaded.data(), c->draws_host.data(), c->draws_host.size() * sizeof(DrawDev)) == 0);
+    const bool same_draws = FB(c).draws_uploaded_valid && FB(c).draws_uploaded_ptr == FB(c).draws_dev.ptr &&
+                            FB(c).draws_uploaded.size() == c->draws_host.size() &&
+                            (c->draws_host.empty() || memcmp(FB(c).draws_uploaded.data(), c->draws_host.data(), c->draws_host.size() * sizeof(DrawDev)) == 0);
     if (!c->draws_host.empty() && !same_draws) {
-        c->draws_uploaded = c->draws_host; c->draws_uploaded_ptr = c->draws_dev.ptr; c->draws_uploaded_valid = true;
+        FB(c).draws_uploaded = c->draws_host; FB(c).draws_uploaded_ptr = FB(c).draws_dev.ptr; FB(c).draws_uploaded_valid = true;
         const size_t bytes = c->draws_host.size() * sizeof(DrawDev);
-        if (bytes <= (1u << 20)) { if ((rc = upload_small(c, c->draws_dev.ptr, c->draws_host.data(), bytes))) return rc; }
-        else { HIPCHK(c, hipMemcpyAsync(c->draws_dev.ptr, c->draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+        if (bytes <= (1u << 20)) { if ((rc = upload_small(c, FB(c).draws_dev.ptr, c->draws_host.data(), bytes))) return rc; }
+        else { HIPCHK(c, hipMemcpyAsync(FB(c).draws_dev.ptr, c->draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     }
     if ((rc = enqueue_geometry(c))) return rc;
     c->geometry_done = true; c->opaque_done = false;
@@ -619,7 +696,9 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
 
 int awsm_hip_frame_flush(AwsmHipCtx* c) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
-    return AWSM_OK;   // everything is already enqueued on the stream; nothing is batched host-side
+    // Nothing is batched host-side.  In overlap mode the opaque passes run on an internal stream: order them before whatever the
+    // caller enqueues next on its own stream (a collective over the image, a copy, ...).
+    return scene_write_barrier(c);
 }
 
 int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
@@ -629,11 +708,12 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         if (out && c->geometry_done && c->has_opaque_for_stats()) {   // stats only: count covered pixels from the visibility buffer
             FrameDev f;
             fill_frame(c, &f);
-            HIPCHK(c, hipMemsetAsync((uint32_t*)c->counters.ptr + 3, 0, sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 3, 0, sizeof(uint32_t), c->stream));
             awsm_launch_count_covered(&f, c->stream);
         }
-        HIPCHK(c, hipMemcpyAsync(c->counters_host, c->counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->shade_stream) { HIPCHK(c, hipStreamSynchronize(c->shade_stream)); c->shade_pending[0] = c->shade_pending[1] = false; }
         if (!c->geometry_done || c->counters_host[2] == 0 || attempt >= 4) break;
         // (triangle, tile) list overflowed: grow to the measured need and replay the frame
         int rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024);
@@ -651,8 +731,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             out->ms_bin = ms(EV_TRANSFORM, EV_BIN);
             out->ms_raster = ms(EV_BIN, EV_RASTER);
         }
-        if (c->opaque_done) out->ms_shade = ms(c->geometry_done ? EV_RASTER : EV_SHADE, EV_SHADE);
-        out->ms_total = ms(c->geometry_done ? EV_START : EV_SHADE, c->opaque_done ? EV_SHADE : EV_RASTER);
+        if (c->opaque_done) out->ms_shade = ms(EV_SHADE_BEGIN, EV_SHADE);
+        out->ms_total = (c->geometry_done ? ms(EV_START, EV_RASTER) : 0.0f) + out->ms_shade;   // the two passes may run on different streams
         out->triangles_in = c->total_tris;
         out->triangles_binned = c->counters_host[0];
         out->bin_entries = c->counters_host[1];
@@ -673,16 +753,16 @@ void* awsm_hip_output_device_ptr(AwsmHipCtx* c) { return c ? (c->bound_out ? c->
 
 int awsm_hip_read_visibility(AwsmHipCtx* c, uint64_t* keys_out) {
     if (!c || !keys_out) return AWSM_ERR_INVALID_ARGUMENT;
-    if (!c->vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
+    if (!FB(c).vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(keys_out, c->vis.ptr, (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1) * 8, hipMemcpyDeviceToHost));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    HIPCHK(c, hipMemcpy(keys_out, FB(c).vis.ptr, (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1) * 8, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
 
 int awsm_hip_read_visibility_unpacked(AwsmHipCtx* c, uint32_t* tri_id, uint32_t* meta_off, float* depth) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
-    if (!c->vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
+    if (!FB(c).vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_visibility before resize");
     const size_t n = (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1);
     std::vector<uint64_t> keys(n);
     int rc = awsm_hip_read_visibility(c, keys.data());
@@ -716,7 +796,7 @@ int awsm_hip_pick(AwsmHipCtx* c, int32_t x, int32_t y, AwsmPick* out) {
     fill_frame(c, &f);
     int rc = sync_scene(c);
     if (rc) return rc;
-    uint32_t* dev_out = (uint32_t*)c->counters.ptr + 8;          // 4 words after the frame counters
+    uint32_t* dev_out = (uint32_t*)FB(c).counters.ptr + 8;          // 4 words after the frame counters
     awsm_launch_pick(c->scene_dev, &f, x, y, dev_out, c->stream);
     HIPCHK(c, hipGetLastError());
     uint32_t host_out[4] = {0, 0, 0, 0};
@@ -731,7 +811,7 @@ int awsm_hip_read_opaque(AwsmHipCtx* c, uint16_t* out) {
     void* src = awsm_hip_output_device_ptr(c);
     if (!src) return fail(c, AWSM_ERR_NOT_READY, "read_opaque before resize");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
     HIPCHK(c, hipMemcpy(out, src, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
@@ -740,7 +820,7 @@ int awsm_hip_read_opaque_f32(AwsmHipCtx* c, float* out) {
     if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->out32.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_opaque_f32 needs AWSM_CFG_PARITY_TAP and a resize");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
     HIPCHK(c, hipMemcpy(out, c->out32.ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
@@ -750,13 +830,13 @@ int awsm_hip_read_transformed(AwsmHipCtx* c, float* clip_out, float* nt_out, uin
     if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "read_transformed before geometry_pass");
     const uint32_t n = std::min(max_vertices, c->total_verts);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
     if (n == 0) return AWSM_OK;
-    if (clip_out) HIPCHK(c, hipMemcpy(clip_out, c->clip.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (clip_out) HIPCHK(c, hipMemcpy(clip_out, FB(c).clip.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
     if (nt_out) {
         std::vector<float> nn((size_t)n * 4), tt((size_t)n * 4);
-        HIPCHK(c, hipMemcpy(nn.data(), c->nrm.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(tt.data(), c->tan.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(nn.data(), FB(c).nrm.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tt.data(), FB(c).tan.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) { memcpy(nt_out + i * 8, &nn[i * 4], 16); memcpy(nt_out + i * 8 + 4, &tt[i * 4], 16); }
     }
     return AWSM_OK;

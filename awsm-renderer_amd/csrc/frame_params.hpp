@@ -74,6 +74,7 @@ struct FrameDev {
     uint32_t has_opaque;
     uint32_t mipmap;              // 0: MipmapMode::None (level 0 only), 1: MipmapMode::Gradient
     uint32_t msaa;                // 0: one sample per pixel (pixel centre); 4: vis holds [pixel][4 samples]
+    const uint8_t* camera;        // the camera UBO this frame is shaded with (a per-frame snapshot in overlap mode)
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
     // transformed vertices (k_deform_transform outputs)

@@ -620,7 +620,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     a.bary_derivs = g.bary_derivs; a.duv0_dx = {0.0f, 0.0f}; a.duv0_dy = {0.0f, 0.0f};
 
     // ---- standard.wgsl:11-62 ----
-    const uint8_t* cam = sc->buf[AWSM_BUF_CAMERA];
+    const uint8_t* cam = f.camera;
     const m4 inv_proj = load_m4(reinterpret_cast<const float*>(cam + 256));
     const m4 inv_view = load_m4(reinterpret_cast<const float*>(cam + 320));
     const float proj33 = *reinterpret_cast<const float*>(cam + 64 + 60);
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
             else if (o.kind == 1u) store_pixel(f, p, o.color);                 // debug view: written before the edge test
             else {
                 // compute.wgsl:303-318 + msaa.wgsl:201-237 (STRICT)
-                const m4 inv_proj = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_CAMERA] + 256));
+                const m4 inv_proj = load_m4(reinterpret_cast<const float*>(f.camera + 256));
                 const float W = (float)f.width, H = (float)f.height, pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
                 is_edge = edge_mask_depth_msaa(inv_proj, k4, pcx, pcy, W, H);
                 if (!is_edge) {   // msaa.wgsl:42-112

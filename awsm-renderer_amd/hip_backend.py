@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("AWSM_HIP_LIB") or os.path.join(PACKAGE_DIR, "libawsm_
 BUF_COUNT = 18
 AWSM_CFG_PARITY_TAP = 1
 AWSM_CFG_SMALL_BIN_LIST = 2
+AWSM_CFG_OVERLAP_FRAMES = 4
 
 BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", "CAMERA", "SKIN_MATRICES", "SKIN_INDEX_WEIGHTS",
              "MORPH_WEIGHTS", "MORPH_VALUES", "GEOM_META", "MATERIAL_META", "VIS_GEOM_DATA", "VIS_GEOM_INDEX", "ATTR_DATA", "ATTR_INDEX",
@@ -117,9 +118,9 @@ def load_library():
 class HipDevice:
     """One AwsmHipCtx: one HIP device + stream."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False, small_bin_list: bool = False):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False, small_bin_list: bool = False, overlap_frames: bool = False):
         self.lib = load_library()
-        flags = (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0)
+        flags = (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0) | (AWSM_CFG_OVERLAP_FRAMES if overlap_frames else 0)
         cfg = AwsmConfig(C.sizeof(AwsmConfig), self.lib.awsm_hip_abi_version(), device, flags, stream)
         ctx = C.c_void_p()
         rc = self.lib.awsm_hip_create(C.byref(cfg), C.byref(ctx))
@@ -257,6 +258,10 @@ class HipDevice:
         st = AwsmFrameStats()
         self._chk(self.lib.awsm_hip_frame_end(self.ctx, C.byref(st)), "frame_end")
         return st.as_dict()
+
+    def frame_flush(self):
+        """Order everything enqueued so far (incl. overlapped opaque passes) before later work on the caller's stream."""
+        self._chk(self.lib.awsm_hip_frame_flush(self.ctx), "frame_flush")
 
     def bind_output(self, device_ptr: Optional[int], nbytes: int = 0):
         self._chk(self.lib.awsm_hip_bind_output(self.ctx, device_ptr, nbytes), "bind_output")

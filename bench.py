@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--tex-scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=30)
+    ap.add_argument("--no-overlap", action="store_true", help="do not overlap the opaque pass of frame i with the geometry pass of frame i+1")
     ap.add_argument("--mipmap", action="store_true", help="MipmapMode::Gradient (the reference's default; not the BASELINE config)")
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4), help="MSAA x4 geometry + edge resolve (the reference's default AntiAliasing; not the BASELINE config)")
     ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
@@ -138,7 +139,7 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa, mipmap=args.mipmap)
+    r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa, mipmap=args.mipmap, overlap_frames=not args.no_overlap)
     from awsm_renderer_amd.hip_backend import HipDevice
     dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
     # N > 1: 32-row bands dealt round-robin over the ranks (rank r owns tile rows r, r+N, ...: every rank gets 1/N of the
@@ -201,6 +202,7 @@ def main():
         else:
             dev.bind_output(mine[b].data_ptr(), rows_out * W * 8)
         r.host.render(sync=False)
+        dev.frame_flush()              # the opaque pass ran on the library's shade stream: order it before the collective
         pending[b] = all_gather(gathered[b].view(world * rows_out, W, 4), mine[b])
 
     def drain():
@@ -295,7 +297,8 @@ def main():
                                    f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + (", MipmapMode::Gradient" if args.mipmap else ", MipmapMode::None"),
                        "triangles": n_tris, "width": W, "height": H,
                        "sharding": sharding_desc,
-                       "draws": len(r.host.draw_list())},
+                       "draws": len(r.host.draw_list()),
+                       "frame_overlap": not args.no_overlap},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels")},
             "roofline": roofline,
             "cpu_baseline": cpu,

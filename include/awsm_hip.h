@@ -77,6 +77,11 @@ typedef struct AwsmConfig {
     void*    stream;        /* hipStream_t to run on; NULL = the library creates its own */
 } AwsmConfig;
 #define AWSM_CFG_PARITY_TAP 1u   /* also keep the shaded RGBA in f32 (readable via awsm_hip_read_opaque_f32) */
+#define AWSM_CFG_OVERLAP_FRAMES 4u /* pipelining across frames: the opaque pass runs on an internal stream and overlaps the NEXT frame's
+                                     geometry pass (per-frame device state is double-buffered; a frame is shaded with the camera it was
+                                     submitted with; any other scene write waits for the opaque passes in flight).  Work the caller
+                                     enqueues on its own stream after a frame must be preceded by awsm_hip_frame_flush(); awsm_hip_frame_end
+                                     and the read-back calls wait for everything. */
 #define AWSM_CFG_SMALL_BIN_LIST 2u /* start with a 4096-entry (triangle, tile) list instead of sizing it from the triangle count:
                                      exercises the overflow -> grow -> replay path of awsm_hip_frame_end (tests) */
 
