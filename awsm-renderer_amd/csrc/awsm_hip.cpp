@@ -624,21 +624,30 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     bool any_morph_skin_checked = false; (void)any_morph_skin_checked;
     for (uint32_t i = 0; i < n; i++) {
         const AwsmDraw& d = draws[i];
-        if (d.inst_count != 0 || d.inst_off != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "draw %u: instancing is not implemented (SURVEY §8f)", i);
+        if (d.inst_count != 0) {   // instanced draw: inst_count mat4s at inst_off of the instance-transform buffer (instances.rs)
+            const DevBuf& ib = c->bufs[AWSM_BUF_INSTANCES];
+            if (!ib.ptr) return fail(c, AWSM_ERR_NOT_READY, "draw %u: instanced, but the instance-transform buffer was never created", i);
+            if ((d.inst_off & 15u) || (uint64_t)d.inst_off + 64ull * d.inst_count > ib.size)
+                return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: %u instances at %u exceed the instance-transform buffer", i, d.inst_count, d.inst_off);
+        }
         if (d.vis_data_off & 15u) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "draw %u: vis_data_off %u not 16-byte aligned", i, d.vis_data_off);
         if ((uint64_t)d.vis_data_off + 168ull * d.tri_count > c->bufs[AWSM_BUF_VIS_GEOM_DATA].size)
             return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: %u triangles at %u exceed the visibility-geometry buffer", i, d.tri_count, d.vis_data_off);
         if ((uint64_t)d.geom_meta_off + 40 > c->bufs[AWSM_BUF_GEOM_META].size || (d.geom_meta_off & 3u))
             return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: geometry meta offset %u out of range", i, d.geom_meta_off);
         if (d.tri_count == 0) continue;   // draw_indexed(0) draws nothing; keeps first_block strictly increasing
-        DrawDev dd{};
-        dd.geom_meta_off = d.geom_meta_off; dd.vis_data_off = d.vis_data_off; dd.tri_count = d.tri_count; dd.flags = d.flags;
-        dd.first_tri = (uint32_t)tris; dd.first_block = (uint32_t)blocks;
-        c->draws_host.push_back(dd);
-        tris += d.tri_count;
-        blocks += (3ull * d.tri_count + 255) / 256;
-        if (tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one pass");
-        if (c->draws_host.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^24 non-empty draws in one pass");
+        const uint32_t copies = d.inst_count ? d.inst_count : 1u;   // draw_indexed_with_instance_count(n, 0) draws nothing either, but the host never issues it
+        for (uint32_t k = 0; k < copies; k++) {
+            DrawDev dd{};
+            dd.geom_meta_off = d.geom_meta_off; dd.vis_data_off = d.vis_data_off; dd.tri_count = d.tri_count; dd.flags = d.flags & 0x7Fu;
+            if (d.inst_count) { dd.flags |= kDrawInstanced; dd.inst_off = d.inst_off + 64u * k; }
+            dd.first_tri = (uint32_t)tris; dd.first_block = (uint32_t)blocks;
+            c->draws_host.push_back(dd);
+            tris += d.tri_count;
+            blocks += (3ull * d.tri_count + 255) / 256;
+            if (tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one pass");
+            if (c->draws_host.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^24 non-empty draws (instances included) in one pass");
+        }
     }
     c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
 

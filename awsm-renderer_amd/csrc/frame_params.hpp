@@ -11,7 +11,10 @@ constexpr int kTileShift = 5;
 constexpr int kMaxTexArrays = 64;
 constexpr int kMaxSamplers = 32;
 
-// One draw as the kernels see it (AwsmDraw + prefix sums computed on the host in draw order).
+constexpr uint32_t kDrawInstanced = 0x80u;   // DrawDev.flags (internal; the API's AWSM_DRAW_* flags use the low bits)
+
+// One draw as the kernels see it — an instanced API draw becomes one DrawDev per instance, in instance order, which is the
+// order the hardware rasterises draw_indexed(.., instance_count) in (meshes/mesh.rs:115-121) — (AwsmDraw + prefix sums computed on the host in draw order).
 struct DrawDev {
     uint32_t geom_meta_off;
     uint32_t vis_data_off;
@@ -19,7 +22,8 @@ struct DrawDev {
     uint32_t flags;
     uint32_t first_tri;     // global triangle rank of this draw's triangle 0
     uint32_t first_block;   // first k_deform_transform block of this draw
-    uint32_t pad0, pad1;
+    uint32_t inst_off;      // byte offset of this instance's mat4 in the instance-transform buffer (kDrawInstanced set)
+    uint32_t pad1;
 };
 
 // Per-draw constants of the opaque pass, resolved once per frame by k_resolve_draws from

@@ -121,7 +121,14 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
         tangent = {t.x, t.y, t.z, tangent.w};
     }
 
-    const m4 model = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TRANSFORMS] + (size_t)(gm.transform_off / 64u) * 64u));
+    m4 model = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TRANSFORMS] + (size_t)(gm.transform_off / 64u) * 64u));
+    if (d.flags & kDrawInstanced) {   // apply_vertex.wgsl:47-59: model_transform = model * instance_transform (column by column)
+        const m4 inst = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_INSTANCES] + d.inst_off));
+        m4 mi;
+#pragma unroll
+        for (int j = 0; j < 4; j++) mi.c[j] = mul(model, inst.c[j]);
+        model = mi;
+    }
     const m4 view_proj = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_CAMERA] + 128));
     const f4 world_pos = mul(model, {pos.x, pos.y, pos.z, 1.0f});
     const f4 clip = mul(view_proj, world_pos);

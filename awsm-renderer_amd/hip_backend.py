@@ -241,7 +241,7 @@ class HipDevice:
     def make_draws(draws: Sequence[dict]):
         arr = (AwsmDraw * max(1, len(draws)))()
         for i, d in enumerate(draws):
-            arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], 0, 0)
+            arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], d.get("inst_off", 0), d.get("inst_count", 0))
         return arr
 
     def geometry_pass(self, draws, n: Optional[int] = None):

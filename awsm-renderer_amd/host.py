@@ -86,6 +86,7 @@ def load_library():
         "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
         "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
         "awsm_host_set_anti_aliasing": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+        "awsm_host_mesh_set_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]), "awsm_host_mesh_append_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]),
         "awsm_host_texture_insert_kind": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
@@ -286,6 +287,22 @@ class Host:
     def set_shard_rows(self, y0: int, y1: int):
         self._chk(self.lib.awsm_host_set_shard_rows(self.h, y0, y1), "set_shard_rows")
 
+    @staticmethod
+    def _trs10(instances) -> np.ndarray:
+        return np.ascontiguousarray([list(t) + list(r) + list(sc) for (t, r, sc) in instances], dtype=np.float32).reshape(-1, 10)
+
+    def mesh_set_instances(self, mesh_key: int, instances):
+        """Meshes::enable_mesh_instancing / set_mesh_instances: [(translation, rotation xyzw, scale), ...]."""
+        a, ap = _f(self._trs10(instances))
+        self._chk(self.lib.awsm_host_mesh_set_instances(self.h, mesh_key, ap, len(a)), "mesh_set_instances")
+
+    def mesh_append_instances(self, mesh_key: int, instances) -> int:
+        a, ap = _f(self._trs10(instances))
+        r = self.lib.awsm_host_mesh_append_instances(self.h, mesh_key, ap, len(a))
+        if r < 0:
+            self._chk(r, "mesh_append_instances")
+        return r
+
     def set_anti_aliasing(self, msaa_sample_count: int = 0, mipmap: bool = False):
         """AwsmRenderer::set_anti_aliasing: msaa 0 (None) or 4, gradient mipmaps on/off (the reference's default: 4, True)."""
         self._chk(self.lib.awsm_host_set_anti_aliasing(self.h, msaa_sample_count, 1 if mipmap else 0), "set_anti_aliasing")
@@ -319,7 +336,13 @@ class Host:
         self._chk(self.lib.awsm_host_draw_list(self.h, None, 0, C.byref(n)), "draw_list")
         arr = (AwsmDraw * max(1, n.value))()
         self._chk(self.lib.awsm_host_draw_list(self.h, arr, n.value, C.byref(n)), "draw_list")
-        return [{"geom_meta_off": d.geom_meta_off, "vis_data_off": d.vis_data_off, "tri_count": d.tri_count, "flags": d.flags} for d in arr[:n.value]]
+        out = []
+        for d in arr[:n.value]:
+            e = {"geom_meta_off": d.geom_meta_off, "vis_data_off": d.vis_data_off, "tri_count": d.tri_count, "flags": d.flags}
+            if d.inst_count:
+                e["inst_off"], e["inst_count"] = d.inst_off, d.inst_count
+            out.append(e)
+        return out
 
     def upload_bytes_last_frame(self) -> int:
         return self.lib.awsm_host_upload_bytes_last_frame(self.h)
@@ -434,6 +457,8 @@ def populate(host: Host, scene: SceneDesc) -> Populated:
                 if p.material not in out.material_keys:
                     out.material_keys[p.material] = host.material_insert(material_struct(scene.materials[p.material], host, tt_keys))
                 out.mesh_keys.append(host.mesh_insert(p, tk, out.material_keys[p.material], skin_key))
+                if p.instances is not None:
+                    host.mesh_set_instances(out.mesh_keys[-1], p.instances)
         for c in children.get(i, []):
             add_meshes(c)
 

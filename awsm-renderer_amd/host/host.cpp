@@ -104,7 +104,7 @@ void push_u32(std::vector<uint8_t>& d, uint32_t v) { uint8_t b[4]; memcpy(b, &v,
 
 struct MeshRec {
     SlotKey transform_key = 0, material_key = 0, resource_key = 0, skin_key = 0, morph_key = 0;
-    bool double_sided = false, hidden = false, hud = false, has_world_aabb = true;
+    bool double_sided = false, hidden = false, hud = false, has_world_aabb = true, instanced = false;
     Aabb local_aabb{}, world_aabb{};
     uint32_t tri_count = 0;
     size_t vis_off = 0;
@@ -157,6 +157,12 @@ struct AwsmHost {
     std::unordered_map<SlotKey, std::vector<SlotKey>> transform_to_meshes;
     DynamicStorageBuffer vis_data{kIndicesInitial * 56}, vis_index{kIndicesInitial}, attr_data{kIndicesInitial * 16}, attr_index{kIndicesInitial};
     bool vis_data_dirty = true, vis_index_dirty = true, attr_data_dirty = true, attr_index_dirty = true;
+
+    // ---- instances.rs: per-instance mat4s, keyed by the instanced mesh's transform key ----
+    DynamicStorageBuffer instances{64 * 32};
+    std::unordered_map<SlotKey, uint32_t> instance_count;
+    std::unordered_map<SlotKey, std::vector<Transform>> instance_list;
+    bool instances_dirty = true;
     DynamicUniformBuffer geom_meta{512, 40, 256}, material_meta{512, 68, 256};
     bool geom_meta_dirty = true, material_meta_dirty = true;
     SlotMap<std::vector<SlotKey>> skins;   // skeleton joint transforms
@@ -379,7 +385,8 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out) {   // renderable.rs
         if (m.hidden) continue;
         if (fr && m.has_world_aabb && !fr->intersects(m.world_aabb)) continue;
         if (m.hud) continue;   // HUD meshes go to their own pass (out of scope)
-        Item it{keys[i], &m, m.double_sided ? 0 : 1, 0.0f, m.has_world_aabb};   // pipeline key order: no_cull < back_cull (G/pipeline.rs:179-265)
+        // pipeline key creation order (G/pipeline.rs:179-265): no_instancing {no_cull, back_cull, front_cull}, instancing {no_cull, back_cull, front_cull}
+        Item it{keys[i], &m, (m.instanced ? 3 : 0) + (m.double_sided ? 0 : 1), 0.0f, m.has_world_aabb};
         if (m.has_world_aabb) {
             const float a = mat4_transform_point3(view_proj, m.world_aabb.min).z, b = mat4_transform_point3(view_proj, m.world_aabb.max).z;
             it.closest = std::fmin(a, b);
@@ -400,6 +407,11 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out) {   // renderable.rs
         d.vis_data_off = (uint32_t)it.rec->vis_off;
         d.tri_count = it.rec->tri_count;
         d.flags = it.rec->double_sided ? 0u : AWSM_DRAW_CULL_BACK;
+        if (it.rec->instanced) {   // meshes/mesh.rs:91-121: instance buffer bound at the transform key's offset, draw_indexed_with_instance_count
+            d.inst_off = (uint32_t)h->instances.offset(it.rec->transform_key);
+            d.inst_count = h->instance_count[it.rec->transform_key];
+            if (d.inst_count == 0) continue;
+        }
         out.push_back(d);
     }
 }
@@ -724,6 +736,46 @@ int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh) {
     return AWSM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ instancing (meshes.rs:176-290, instances.rs)
+static std::vector<uint8_t> instance_bytes(const Transform* list, size_t n) {   // Instances::transforms_to_bytes: to_matrix().to_cols_array() each
+    std::vector<uint8_t> out(n * 64);
+    for (size_t i = 0; i < n; i++) { const Mat4 m = to_matrix(list[i]); memcpy(out.data() + i * 64, &m, 64); }
+    return out;
+}
+static Transform trs_at(const float* trs10, size_t i) {
+    const float* p = trs10 + i * 10;
+    return Transform{{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}, {p[7], p[8], p[9]}};
+}
+// Meshes::enable_mesh_instancing (first call) / set_mesh_instances (later calls): `n` transforms as 10 floats each
+// (translation xyz, rotation xyzw, scale xyz)
+int awsm_host_mesh_set_instances(AwsmHost* h, AwsmKey mesh, const float* trs10, uint32_t n) {
+    MeshRec* rec = h->meshes.get(mesh);
+    if (!rec || (!trs10 && n)) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[mesh] not found / null transforms");
+    rec->instanced = true;
+    std::vector<Transform> list(n);
+    for (uint32_t i = 0; i < n; i++) list[i] = trs_at(trs10, i);
+    const std::vector<uint8_t> bytes = instance_bytes(list.data(), n);
+    h->instances.update(rec->transform_key, bytes.data(), bytes.size());     // Instances::transform_insert
+    h->instance_count[rec->transform_key] = n;
+    h->instance_list[rec->transform_key] = std::move(list);
+    h->instances_dirty = true;
+    return AWSM_OK;
+}
+// Meshes::append_mesh_instances -> Instances::transform_extend: appended in place while the block has room, else re-inserted whole
+int awsm_host_mesh_append_instances(AwsmHost* h, AwsmKey mesh, const float* trs10, uint32_t n) {
+    MeshRec* rec = h->meshes.get(mesh);
+    if (!rec || !rec->instanced) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[mesh] not found or not instanced");
+    if (n == 0) return (int)h->instance_count[rec->transform_key];
+    std::vector<Transform>& list = h->instance_list[rec->transform_key];
+    const size_t start = list.size();
+    for (uint32_t i = 0; i < n; i++) list.push_back(trs_at(trs10, i));
+    const std::vector<uint8_t> bytes = instance_bytes(list.data(), list.size());
+    h->instances.update(rec->transform_key, bytes.data(), bytes.size());     // same bytes either way; update() keeps the block when it fits
+    h->instance_count[rec->transform_key] = (uint32_t)list.size();
+    h->instances_dirty = true;
+    return (int)start;
+}
+
 // ------------------------------------------------------------------------------------------------ lights / camera / env
 AwsmKey awsm_host_light_insert(AwsmHost* h, const AwsmHostLight* l) {
     if (!l || l->kind < 1 || l->kind > 3) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "light_insert: bad kind"); return 0; }
@@ -879,6 +931,7 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
     h->vis_index.take_dirty_ranges(); h->vis_index.take_gpu_needs_resize(); h->vis_index_dirty = false;
     if ((rc = flush_buffer(h, h->attr_data, AWSM_BUF_ATTR_DATA, h->attr_data_dirty))) return rc;
     if ((rc = flush_buffer(h, h->attr_index, AWSM_BUF_ATTR_INDEX, h->attr_index_dirty))) return rc;
+    if ((rc = flush_buffer(h, h->instances, AWSM_BUF_INSTANCES, h->instances_dirty))) return rc;   // instances.rs write_gpu
     if (h->camera_dirty) {   // camera.rs:232-251
         if (!h->camera_created) { if ((rc = h->be.buffer_create(h->ctx, AWSM_BUF_CAMERA, 512))) return dev_fail(h, rc, "buffer_create(camera)"); h->camera_created = true; }
         if ((rc = h->be.buffer_write(h->ctx, AWSM_BUF_CAMERA, 0, h->camera_raw, 512))) return dev_fail(h, rc, "buffer_write(camera)");
@@ -923,6 +976,7 @@ int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* l
         case AWSM_BUF_ATTR_DATA: v = &h->attr_data.raw(); break;
         case AWSM_BUF_ATTR_INDEX: v = &h->attr_index.raw(); break;
         case AWSM_BUF_TEXTURE_TRANSFORMS: v = &h->tex_transforms_buf.raw(); break;
+        case AWSM_BUF_INSTANCES: v = &h->instances.raw(); break;
         case AWSM_BUF_CAMERA: *data = h->camera_raw; *len = 512; return AWSM_OK;
         default: return fail(h, AWSM_ERR_INVALID_ARGUMENT, "mirror: buffer %d has no persistent mirror", (int)which);
     }

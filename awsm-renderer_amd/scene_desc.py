@@ -58,6 +58,7 @@ class PrimitiveDesc:
     colors: List[np.ndarray] = field(default_factory=list)   # each (V,4) f32
     joints: List[np.ndarray] = field(default_factory=list)   # per set (V,4) u32
     weights: List[np.ndarray] = field(default_factory=list)  # per set (V,4) f32
+    instances: Optional[List[tuple]] = None                 # GPU instancing: [(translation xyz, rotation xyzw, scale xyz), ...] (meshes.rs:176-218)
     morph_targets: List[dict] = field(default_factory=list)  # {positions?, normals?, tangents?} each (V,3) f32
     morph_weights: Optional[np.ndarray] = None               # (targets,) f32  (glTF mesh.weights)
     animated_morph_weights: Optional[np.ndarray] = None      # written through the animation path ([1..n+1))

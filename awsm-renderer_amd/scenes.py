@@ -461,3 +461,43 @@ def ortho_scene(width=320, height=240) -> SceneDesc:
     a = width / height
     sc.proj = orthographic_rh(-1.6 * a, 1.6 * a, -1.6, 1.6, 0.1, 50.0)
     return sc
+
+
+# ------------------------------------------------------------------------------------------------ instancing
+
+def instanced_scene(width=640, height=360, seed=0xA35A0006) -> SceneDesc:
+    """A textured floor plus two instanced meshes (a bumpy sphere x 24 on a ring, double-sided; a box x 9 in a grid, back-face
+    culled, non-uniformly scaled and rotated) and one ordinary mesh between them in submission order.  Not a BASELINE
+    config; it exercises GPU instancing: per-instance mat4s (instances.rs), model * instance in apply_vertex
+    (apply_vertex.wgsl:47-59), one draw per mesh with an instance count (meshes/mesh.rs:91-121)."""
+    rng = np.random.default_rng(seed)
+    textures = [value_noise_rgba8(rng, 128, 8, base=(0.6, 0.5, 0.4), amp=(0.3, 0.3, 0.3)), value_noise_rgba8(rng, 128, 16, kind="normal")]
+    mats = [MaterialDesc(base_color_tex=TextureRef(0), normal_tex=TextureRef(1), metallic_factor=0.1, roughness_factor=0.6),
+            MaterialDesc(base_color_factor=(0.9, 0.3, 0.2, 1.0), metallic_factor=0.8, roughness_factor=0.35, double_sided=True),
+            MaterialDesc(base_color_factor=(0.2, 0.5, 0.9, 1.0), base_color_tex=TextureRef(0), metallic_factor=0.0, roughness_factor=0.8)]
+
+    def plane(U, V):
+        return np.stack([(U - 0.5) * 16.0, np.zeros_like(U), (0.5 - V) * 16.0], axis=-1)
+
+    def ball(U, V):
+        th, phi = U * 2 * math.pi, (0.02 + 0.96 * V) * math.pi
+        d = np.stack([np.sin(phi) * np.cos(th), np.cos(phi), -np.sin(phi) * np.sin(th)], axis=-1)
+        return d * (0.35 * (1.0 + 0.15 * np.sin(6 * th) * np.sin(4 * phi)))[..., None]
+
+    def quat_y(a):
+        return (0.0, math.sin(a / 2), 0.0, math.cos(a / 2))
+
+    ring = [((4.5 * math.cos(2 * math.pi * i / 24), 0.8 + 0.3 * math.sin(i), 4.5 * math.sin(2 * math.pi * i / 24)), quat_y(0.3 * i), (1.0 + 0.3 * (i % 3),) * 3)
+            for i in range(24)]
+    grid = [((-2.0 + 2.0 * (i % 3), 0.5, -2.0 + 2.0 * (i // 3)), quat_y(0.4 * i), (0.6, 0.4 + 0.2 * (i % 4), 0.9)) for i in range(9)]
+    box = box_scene().nodes[1].primitives[0]
+    box_prim = PrimitiveDesc(positions=box.positions, normals=box.normals, indices=box.indices, material=2, uvs=[np.zeros((len(box.positions), 2), dtype=np.float32) + 0.37],
+                             instances=grid)
+    nodes = [NodeDesc(),
+             NodeDesc(parent=0, primitives=[_prim(grid_patch(plane, 16, 16, uv_scale=(4, 4)), 0)]),
+             NodeDesc(parent=0, translation=(0.0, 0.2, 0.0), primitives=[_prim(grid_patch(ball, 24, 16, uv_scale=(2, 1)), 1, instances=ring)]),
+             NodeDesc(parent=0, translation=(0.0, 1.6, 0.0), primitives=[_prim(grid_patch(ball, 24, 16, uv_scale=(2, 1)), 0)]),
+             NodeDesc(parent=0, rotation=quat_y(0.5), primitives=[box_prim])]
+    eye = (7.5, 5.0, 8.5)
+    return SceneDesc(nodes=nodes, materials=mats, textures=textures, samplers=[dict(REPEAT_LINEAR)], lights=list(DEFAULT_LIGHTS), width=width, height=height,
+                     view=look_at_rh(eye, (0.0, 0.6, 0.0)), proj=perspective_rh(math.radians(50), width / height, 0.1, 100.0), camera_position=eye)

@@ -127,6 +127,11 @@ int awsm_host_resize(AwsmHost* h, uint32_t width, uint32_t height);
  * mipmap != 0 selects MipmapMode::Gradient in the opaque pass.  The reference's default is {Some(4), mipmap: true}. */
 int awsm_host_set_anti_aliasing(AwsmHost* h, uint32_t msaa_sample_count, uint32_t mipmap);
 int awsm_host_set_shard_rows(AwsmHost* h, uint32_t y0, uint32_t y1);
+/* GPU instancing (meshes.rs:176-290, instances.rs): n transforms of 10 floats each (translation xyz, rotation xyzw, scale xyz);
+ * the first call enables instancing for the mesh (enable_mesh_instancing), later calls replace the list (set_mesh_instances);
+ * append returns the index of the first appended instance (append_mesh_instances). */
+int awsm_host_mesh_set_instances(AwsmHost* h, AwsmKey mesh, const float* trs10, uint32_t n);
+int awsm_host_mesh_append_instances(AwsmHost* h, AwsmKey mesh, const float* trs10, uint32_t n);
 /* AwsmRenderer::pick (picker.rs:55-121): *hit = 1 and *mesh_key = the MeshKey (KeyData::as_ffi) under pixel (x, y) of the last frame, else *hit = 0 */
 int awsm_host_pick(AwsmHost* h, int32_t x, int32_t y, uint32_t* hit, uint64_t* mesh_key);
 int awsm_host_set_shard_bands(AwsmHost* h, uint32_t n, uint32_t r, uint32_t compact_output);   /* awsm_hip_set_shard_bands */

@@ -45,7 +45,7 @@ static GeomMeta load_geom_meta(const OracleScene* s, uint32_t off) {
 
 uint32_t oracle_total_vertices(const OracleScene* s) {
     uint64_t t = 0;
-    for (uint32_t d = 0; d < s->n_draws; d++) t += 3ull * s->draws[d].tri_count;
+    for (uint32_t d = 0; d < s->n_draws; d++) t += 3ull * s->draws[d].tri_count * (s->draws[d].inst_count ? s->draws[d].inst_count : 1u);   /* every instance has its own transformed vertices */
     return (uint32_t)t;
 }
 
@@ -78,7 +78,7 @@ static omat4 skin_matrix(const OracleScene* s, const GeomMeta* gm, uint32_t vert
 }
 
 /* apply_vertex.wgsl:24-118 for one exploded vertex (56-byte record, pipeline.rs:28-73) */
-static void apply_vertex(const OracleScene* s, const GeomMeta* gm, const omat4* view_proj, const uint8_t* vtx,
+static void apply_vertex(const OracleScene* s, const GeomMeta* gm, const omat4* view_proj, const uint8_t* vtx, const float* instance_mat4,
                          float* clip_out, float* nt_out) {
     ovec3 pos = ov3(rd_f32(vtx + 0), rd_f32(vtx + 4), rd_f32(vtx + 8));
     ovec3 normal = ov3(rd_f32(vtx + 24), rd_f32(vtx + 28), rd_f32(vtx + 32));
@@ -111,6 +111,11 @@ static void apply_vertex(const OracleScene* s, const GeomMeta* gm, const omat4* 
     }
 
     omat4 model = omat4_load((const float*)(s->buf[AWSM_BUF_TRANSFORMS] + (size_t)(gm->transform_off / 64u) * 64u));
+    if (instance_mat4) {   /* apply_vertex.wgsl:47-59: model_transform = model * instance_transform (column by column) */
+        omat4 inst = omat4_load(instance_mat4), mi;
+        for (int j = 0; j < 4; j++) mi.c[j] = omat4_mul_v4(&model, inst.c[j]);
+        model = mi;
+    }
     ovec4 world_pos = omat4_mul_v4(&model, ov4(pos.x, pos.y, pos.z, 1.0f));
     ovec4 clip = omat4_mul_v4(view_proj, world_pos);
 
@@ -150,8 +155,11 @@ int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out) {
         const AwsmDraw* dr = &s->draws[d];
         GeomMeta gm = load_geom_meta(s, dr->geom_meta_off);
         const uint8_t* base = s->buf[AWSM_BUF_VIS_GEOM_DATA] + dr->vis_data_off;
-        for (uint32_t i = 0; i < 3u * dr->tri_count; i++, v++) {
-            apply_vertex(s, &gm, &view_proj, base + (size_t)i * 56u, clip_out + v * 4, nt_out + v * 8);
+        const uint32_t copies = dr->inst_count ? dr->inst_count : 1u;       /* draw_indexed(.., instance_count): instance after instance */
+        for (uint32_t k = 0; k < copies; k++) {
+            const float* inst = dr->inst_count ? (const float*)(s->buf[AWSM_BUF_INSTANCES] + dr->inst_off + 64u * k) : NULL;
+            for (uint32_t i = 0; i < 3u * dr->tri_count; i++, v++)
+                apply_vertex(s, &gm, &view_proj, base + (size_t)i * 56u, inst, clip_out + v * 4, nt_out + v * 8);
         }
     }
     return 0;
@@ -281,7 +289,8 @@ int oracle_raster(const OracleScene* s, const float* clip, uint64_t* keys, int t
         for (uint32_t d = 0; d < s->n_draws; d++) {
             const AwsmDraw* dr = &s->draws[d];
             int cull_back = (dr->flags & AWSM_DRAW_CULL_BACK) != 0;
-            for (uint32_t t = 0; t < dr->tri_count; t++, rank++) {
+            const uint32_t copies = dr->inst_count ? dr->inst_count : 1u;
+            for (uint32_t t = 0; t < dr->tri_count * copies; t++, rank++) {
                 const float* v = clip + (size_t)rank * 12;
                 TriSetup ts;
                 /* setup uses the SHARD rect so that a shard's result equals the full frame's rows */
@@ -317,10 +326,11 @@ int oracle_raster(const OracleScene* s, const float* clip, uint64_t* keys, int t
 
 /* rank -> draw via the prefix of triangle counts */
 static uint32_t find_draw(const OracleScene* s, uint32_t rank, uint32_t* first_rank) {
-    uint32_t acc = 0;
+    uint32_t acc = 0;   /* first_rank = rank of triangle 0 of the INSTANCE the rank falls in, so rank - first_rank is primitive-local */
     for (uint32_t d = 0; d < s->n_draws; d++) {
-        if (rank < acc + s->draws[d].tri_count) { *first_rank = acc; return d; }
-        acc += s->draws[d].tri_count;
+        const uint32_t tc = s->draws[d].tri_count, copies = s->draws[d].inst_count ? s->draws[d].inst_count : 1u;
+        if (tc && rank < acc + tc * copies) { *first_rank = acc + ((rank - acc) / tc) * tc; return d; }
+        acc += tc * copies;
     }
     *first_rank = acc;
     return s->n_draws;

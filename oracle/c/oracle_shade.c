@@ -780,10 +780,11 @@ static void store_pixel(float* rgba32f, uint16_t* rgba16f, size_t p, ovec4 c) {
 }
 
 static uint32_t find_draw(const OracleScene* s, uint32_t rank, uint32_t* first_rank) {
-    uint32_t acc = 0;
+    uint32_t acc = 0;   /* first_rank = rank of triangle 0 of the INSTANCE the rank falls in, so rank - first_rank is primitive-local */
     for (uint32_t d = 0; d < s->n_draws; d++) {
-        if (rank < acc + s->draws[d].tri_count) { *first_rank = acc; return d; }
-        acc += s->draws[d].tri_count;
+        const uint32_t tc = s->draws[d].tri_count, copies = s->draws[d].inst_count ? s->draws[d].inst_count : 1u;
+        if (tc && rank < acc + tc * copies) { *first_rank = acc + ((rank - acc) / tc) * tc; return d; }
+        acc += tc * copies;
     }
     *first_rank = acc;
     return s->n_draws;

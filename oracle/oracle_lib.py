@@ -126,7 +126,7 @@ class OracleFrame:
         s.width, s.height, s.y0, s.y1 = width, height, rows[0], rows[1]
         self.draw_arr = (AwsmDraw * max(1, len(draws)))()
         for i, d in enumerate(draws):
-            self.draw_arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], 0, 0)
+            self.draw_arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], d.get("inst_off", 0), d.get("inst_count", 0))
         s.draws = C.cast(self.draw_arr, C.POINTER(AwsmDraw))
         s.n_draws = len(draws)
         s.has_opaque = 1 if has_opaque else 0

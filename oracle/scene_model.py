@@ -400,6 +400,9 @@ class HostModel:
         self.materials_keys = SlotMap()
         self.materials = DynamicStorageBuffer(8192)
         self.material_keys_by_index: Dict[int, tuple] = {}
+        # instances.rs:30-47: per-instance mat4s keyed by the instanced mesh's transform key
+        self.instances = DynamicStorageBuffer(64 * 32)
+        self.instance_count: Dict[tuple, int] = {}
         # meshes.rs:353-364
         self.vis_data = DynamicStorageBuffer(INDICES_INITIAL_SIZE * 56)
         self.vis_index = DynamicStorageBuffer(INDICES_INITIAL_SIZE)
@@ -512,6 +515,12 @@ class HostModel:
         mesh_key = self.meshes.insert(rec)
         self.transform_to_meshes.setdefault(transform_key, []).append(mesh_key)
         rec.vis_off, rec.skin_key, rec.morph_key = vis_off, skin_key, morph_key
+        rec.instanced = False
+        if getattr(p, "instances", None) is not None:      # Meshes::enable_mesh_instancing -> Instances::transform_insert (meshes.rs:176-218, instances.rs:49-57)
+            rec.instanced = True
+            raw = b"".join(hm.mat4_from_srt(np.asarray(sc_, dtype=F), np.asarray(r_, dtype=F), np.asarray(t_, dtype=F)).astype(F).tobytes() for (t_, r_, sc_) in p.instances)
+            self.instances.update(transform_key, raw)
+            self.instance_count[transform_key] = len(p.instances)
 
         # meta.rs:89-146: material meta first, then geometry meta
         hi, lo = key_as_ffi(mesh_key) >> 32, key_as_ffi(mesh_key) & 0xFFFFFFFF
@@ -569,8 +578,8 @@ class HostModel:
                 continue
             opaque.append((mk, rec))
 
-        def pipeline_rank(rec):   # G/pipeline.rs:179-265 creation order: no_cull < back_cull
-            return 0 if rec.double_sided else 1
+        def pipeline_rank(rec):   # G/pipeline.rs:179-265 creation order: no_instancing {no_cull, back_cull, front_cull}, instancing {...}
+            return (3 if getattr(rec, "instanced", False) else 0) + (0 if rec.double_sided else 1)
 
         def closest(rec):
             a = hm.mat4_transform_point3(view_proj, rec.world_aabb.min)[2]
@@ -591,8 +600,14 @@ class HostModel:
         opaque.sort(key=functools.cmp_to_key(cmp))   # Python's sort is stable, like slice::sort_by
         draws = []
         for mk, rec in opaque:
-            draws.append({"geom_meta_off": self.geom_meta.offset(mk), "vis_data_off": rec.vis_off, "tri_count": rec.tri_count,
-                          "flags": 0 if rec.double_sided else 1, "mesh_key": mk})
+            d = {"geom_meta_off": self.geom_meta.offset(mk), "vis_data_off": rec.vis_off, "tri_count": rec.tri_count,
+                 "flags": 0 if rec.double_sided else 1, "mesh_key": mk}
+            if getattr(rec, "instanced", False):     # meshes/mesh.rs:91-121
+                d["inst_off"] = self.instances.offset(rec.transform_key)
+                d["inst_count"] = self.instance_count[rec.transform_key]
+                if d["inst_count"] == 0:
+                    continue
+            draws.append(d)
         return draws
 
     # ---- mirrors as the device must see them ----
@@ -613,6 +628,7 @@ class HostModel:
             BUF_MATERIAL_META: bytes(self.material_meta.raw), BUF_VIS_GEOM_DATA: bytes(self.vis_data.raw),
             BUF_VIS_GEOM_INDEX: bytes(self.vis_index.raw), BUF_ATTR_DATA: bytes(self.attr_data.raw), BUF_ATTR_INDEX: bytes(self.attr_index.raw),
             BUF_TEXTURE_TRANSFORMS: bytes(self.tex_transforms.buffer.raw),
+            BUF_INSTANCES: bytes(self.instances.raw),
         }
 
     def texture_arrays(self) -> List[dict]:

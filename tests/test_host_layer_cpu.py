@@ -53,6 +53,7 @@ SCENES = {
     "helmet": lambda: scenes.helmet_scene(64, 64, segments=16, rings=12, tex_size=16),
     "skinned_morph": lambda: scenes.skinned_morph_scene(64, 64, around=8, along=12, tex_size=16),
     "atrium": lambda: scenes.atrium_scene(96, 64, detail=0.125, tex_scale=1 / 64),
+    "instanced": lambda: scenes.instanced_scene(96, 64),
 }
 
 
