@@ -162,7 +162,7 @@ struct AwsmHost {
     DynamicStorageBuffer instances{64 * 32};
     std::unordered_map<SlotKey, uint32_t> instance_count;
     std::unordered_map<SlotKey, std::vector<Transform>> instance_list;
-    bool instances_dirty = true;
+    bool instances_dirty = false;   // Instances::transform_gpu_dirty: set by the first transform_insert
     DynamicUniformBuffer geom_meta{512, 40, 256}, material_meta{512, 68, 256};
     bool geom_meta_dirty = true, material_meta_dirty = true;
     SlotMap<std::vector<SlotKey>> skins;   // skeleton joint transforms
@@ -918,6 +918,7 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
         h->upload_bytes += 16;
         h->lights_info_dirty = false;
     }
+    if ((rc = flush_buffer(h, h->instances, AWSM_BUF_INSTANCES, h->instances_dirty))) return rc;   // instances.write_gpu: after lights, before skins (render.rs:73-80)
     if ((rc = flush_buffer(h, h->skin_matrices, AWSM_BUF_SKIN_MATRICES, h->skin_matrices_dirty))) return rc;
     if ((rc = flush_buffer(h, h->skin_index_weights, AWSM_BUF_SKIN_INDEX_WEIGHTS, h->skin_iw_dirty))) return rc;
     if ((rc = flush_buffer(h, h->morph_weights, AWSM_BUF_MORPH_WEIGHTS, h->morph_weights_dirty))) return rc;
@@ -931,7 +932,6 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
     h->vis_index.take_dirty_ranges(); h->vis_index.take_gpu_needs_resize(); h->vis_index_dirty = false;
     if ((rc = flush_buffer(h, h->attr_data, AWSM_BUF_ATTR_DATA, h->attr_data_dirty))) return rc;
     if ((rc = flush_buffer(h, h->attr_index, AWSM_BUF_ATTR_INDEX, h->attr_index_dirty))) return rc;
-    if ((rc = flush_buffer(h, h->instances, AWSM_BUF_INSTANCES, h->instances_dirty))) return rc;   // instances.rs write_gpu
     if (h->camera_dirty) {   // camera.rs:232-251
         if (!h->camera_created) { if ((rc = h->be.buffer_create(h->ctx, AWSM_BUF_CAMERA, 512))) return dev_fail(h, rc, "buffer_create(camera)"); h->camera_created = true; }
         if ((rc = h->be.buffer_write(h->ctx, AWSM_BUF_CAMERA, 0, h->camera_raw, 512))) return dev_fail(h, rc, "buffer_write(camera)");
