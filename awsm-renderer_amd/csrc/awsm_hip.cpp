@@ -621,7 +621,6 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if (c->overlap) c->slot ^= 1;            // the previous frame's opaque pass may still be reading the other slot
     c->draws_host.clear(); c->draws_api.assign(draws, draws + n);
     uint64_t tris = 0, blocks = 0;
-    bool any_morph_skin_checked = false; (void)any_morph_skin_checked;
     for (uint32_t i = 0; i < n; i++) {
         const AwsmDraw& d = draws[i];
         if (d.inst_count != 0) {   // instanced draw: inst_count mat4s at inst_off of the instance-transform buffer (instances.rs)
