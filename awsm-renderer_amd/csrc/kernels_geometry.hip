@@ -414,7 +414,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
 struct WorkTri {
     float a[3], b[3], c[3];
     float z[3];
-    float det;
+    float inv_det;
     uint32_t rank;
     uint32_t bbox;   // x0 | x1<<8 | y0<<16 | y1<<24, tile-local, inclusive
     uint32_t pad;
@@ -423,7 +423,7 @@ struct WorkTri {
 AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 #pragma unroll
     for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.z[i] = g.z[i]; }
-    t.det = g.det;
+    t.inv_det = g.inv_det;
 }
 
 // One pixel of the tile against one triangle: S = 1 samples the pixel centre, S = 4 the four standard MSAA positions
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                         WorkTri& g = work[slot];
 #pragma unroll
                         for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.z[i] = t.z[i]; }
-                        g.det = t.det; g.rank = r;
+                        g.inv_det = t.inv_det; g.rank = r;
                         g.bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
                     }
                 }

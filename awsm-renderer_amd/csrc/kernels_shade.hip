@@ -39,8 +39,8 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
     tri_rec_load_edges(f.tri_rec + rank, t);
     float e0, e1, e2;
     tri_edges(t, cx, cy, e0, e1, e2);
-    const float esum = (e0 + e1) + e2;
-    const float b0 = e0 / esum, b1 = e1 / esum, b2 = e2 / esum;
+    const float inv_esum = 1.0f / ((e0 + e1) + e2);                       // one IEEE reciprocal, three products
+    const float b0 = e0 * inv_esum, b1 = e1 * inv_esum, b2 = e2 * inv_esum;
     const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
     const float4 t0 = f.tan[(size_t)rank * 3], t1 = f.tan[(size_t)rank * 3 + 1], t2 = f.tan[(size_t)rank * 3 + 2];
     const f3 Ni = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y, (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
@@ -57,8 +57,8 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
         float h0, h1, h2, w0, w1, w2;
         tri_edges(t, cx ^ 1, cy, h0, h1, h2);
         tri_edges(t, cx, cy ^ 1, w0, w1, w2);
-        const float sh = (h0 + h1) + h2, sv = (w0 + w1) + w2;
-        const float hb0 = h0 / sh, hb1 = h1 / sh, vb0 = w0 / sv, vb1 = w1 / sv;
+        const float ish = 1.0f / ((h0 + h1) + h2), isv = 1.0f / ((w0 + w1) + w2);
+        const float hb0 = h0 * ish, hb1 = h1 * ish, vb0 = w0 * isv, vb1 = w1 * isv;
         const float ddx0 = (cx & 1) ? b0 - hb0 : hb0 - b0, ddx1 = (cx & 1) ? b1 - hb1 : hb1 - b1;
         const float ddy0 = (cy & 1) ? b0 - vb0 : vb0 - b0, ddy1 = (cy & 1) ? b1 - vb1 : vb1 - b1;
         g.bary_derivs = {round_f16(ddx0), round_f16(ddy0), round_f16(ddx1), round_f16(ddy1)};

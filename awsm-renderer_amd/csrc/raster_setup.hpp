@@ -4,7 +4,8 @@
 //   crates/renderer/src/render_passes/geometry/pipeline.rs:337-344
 //   (TriangleList, FrontFace::Ccw, CullMode::{None,Back}, depth write, CompareFunction::LessEqual).
 // The raster contract (DESIGN.md §"Raster contract"): homogeneous edge functions in f32, evaluated at
-// pixel centres, top-left rule, per-pixel 0 <= z_ndc <= 1 clip, z_ndc = (e0*z0 + e1*z1 + e2*z2) / det.
+// pixel centres, top-left rule, per-pixel 0 <= z_ndc <= 1 clip, z_ndc = (e0*z0 + e1*z1 + e2*z2) * (1/det) with the
+// reciprocal taken once per triangle (IEEE division) — one multiply per sample instead of an 11-instruction division.
 // Used by the binning, raster and shade kernels so that all three see bit-identical edge values.
 #pragma once
 #include "device_math.hpp"
@@ -15,6 +16,7 @@ struct TriSetup {
     float a[3], b[3], c[3];   // e_i(X,Y) = (a*X + b*Y) + c ; inside >= 0 ; e_i is the weight of vertex i
     float z[3];
     float det;                // > 0 after orientation normalisation
+    float inv_det;            // 1 / det (IEEE), the factor of the per-sample depth
     int minx, maxx, miny, maxy;   // inclusive, conservative, clamped to the target rect
 };
 
@@ -45,6 +47,7 @@ AWSM_DI bool tri_coefficients(float4 v0, float4 v1, float4 v2, bool cull_back, u
     t.a[2] = a2; t.b[2] = b2; t.c[2] = c2;
     t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
     t.det = det;
+    t.inv_det = 1.0f / det;
     return true;
 }
 
@@ -89,7 +92,7 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
 struct alignas(16) TriRec {
     float a[3], b[3], c[3];
     float z[3];
-    float det;
+    float inv_det;
     uint32_t bbox_x;   // minx | maxx << 16   (inclusive, clamped to the target rect)
     uint32_t bbox_y;   // miny | maxy << 16
     uint32_t valid;    // 0: the triangle cannot produce a fragment in this shard
@@ -101,7 +104,7 @@ AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok)
     q[0] = make_float4(t.a[0], t.a[1], t.a[2], t.b[0]);
     q[1] = make_float4(t.b[1], t.b[2], t.c[0], t.c[1]);
     q[2] = make_float4(t.c[2], t.z[0], t.z[1], t.z[2]);
-    q[3] = make_float4(t.det, __uint_as_float((uint32_t)t.minx | ((uint32_t)t.maxx << 16)), __uint_as_float((uint32_t)t.miny | ((uint32_t)t.maxy << 16)),
+    q[3] = make_float4(t.inv_det, __uint_as_float((uint32_t)t.minx | ((uint32_t)t.maxx << 16)), __uint_as_float((uint32_t)t.miny | ((uint32_t)t.maxy << 16)),
                        __uint_as_float(ok ? 1u : 0u));
 }
 AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) {
@@ -110,7 +113,7 @@ AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) {
     t.a[0] = q0.x; t.a[1] = q0.y; t.a[2] = q0.z; t.b[0] = q0.w;
     t.b[1] = q1.x; t.b[2] = q1.y; t.c[0] = q1.z; t.c[1] = q1.w;
     t.c[2] = q2.x; t.z[0] = q2.y; t.z[1] = q2.z; t.z[2] = q2.w;
-    t.det = q3.x;
+    t.inv_det = q3.x;
     const uint32_t bx = __float_as_uint(q3.y), by = __float_as_uint(q3.z);
     t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)(bx >> 16); t.miny = (int)(by & 0xFFFFu); t.maxy = (int)(by >> 16);
     return __float_as_uint(q3.w) != 0u;
@@ -149,7 +152,7 @@ AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, float X, float Y
     tri_edges_at(t, X, Y, e0, e1, e2);
     if (!edge_inside(e0, t.a[0], t.b[0]) || !edge_inside(e1, t.a[1], t.b[1]) || !edge_inside(e2, t.a[2], t.b[2]))
         return ~0ull;
-    float zn = ((e0 * t.z[0] + e1 * t.z[1]) + e2 * t.z[2]) / t.det;
+    float zn = ((e0 * t.z[0] + e1 * t.z[1]) + e2 * t.z[2]) * t.inv_det;
     if (!(zn >= 0.0f && zn <= 1.0f)) return ~0ull;
     if (zn == 0.0f) zn = 0.0f;   // -0 -> +0 so the bits order as an unsigned integer
     // depth LessEqual + submission order: smaller depth wins, equal depth -> LATER primitive wins

@@ -172,6 +172,7 @@ typedef struct {
     float a[3], b[3], c[3];   /* edge i: e_i(X,Y) = (a*X + b*Y) + c, inside >= 0, weight of vertex i */
     float z[3];
     float det;                /* > 0 after orientation normalisation */
+    float inv_det;            /* 1 / det, taken once per triangle: depth = numerator * inv_det */
     int minx, maxx, miny, maxy;  /* inclusive, conservative, clamped to the target rect */
     int valid;
 } TriSetup;
@@ -212,7 +213,7 @@ static void tri_setup(const float* v0, const float* v1, const float* v2, int cul
     t->a[1] = a1; t->b[1] = b1; t->c[1] = c1;
     t->a[2] = a2; t->b[2] = b2; t->c[2] = c2;
     t->z[0] = v0[2]; t->z[1] = v1[2]; t->z[2] = v2[2];
-    t->det = det;
+    t->det = det; t->inv_det = 1.0f / det;
 
     int minx = 0, maxx = (int)width - 1, miny = (int)ry0, maxy = (int)ry1 - 1;
     if (w0 > 0.0f && w1 > 0.0f && w2 > 0.0f) {
@@ -255,7 +256,7 @@ static inline int tri_sample_at(const TriSetup* t, float X, float Y, float* e_ou
     float e2 = (t->a[2] * X + t->b[2] * Y) + t->c[2];
     if (!edge_inside(e0, t->a[0], t->b[0]) || !edge_inside(e1, t->a[1], t->b[1]) || !edge_inside(e2, t->a[2], t->b[2]))
         return 0;
-    float zn = ((e0 * t->z[0] + e1 * t->z[1]) + e2 * t->z[2]) / t->det;
+    float zn = ((e0 * t->z[0] + e1 * t->z[1]) + e2 * t->z[2]) * t->inv_det;
     if (!(zn >= 0.0f && zn <= 1.0f)) return 0;
     if (zn == 0.0f) zn = 0.0f;   /* canonicalise -0 so the bit pattern orders as an unsigned integer */
     e_out[0] = e0; e_out[1] = e1; e_out[2] = e2;

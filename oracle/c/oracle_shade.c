@@ -800,8 +800,8 @@ static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const
     const float* v0 = clip + (size_t)rank * 12;
     float e[3];
     if (!oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy, e)) return g;
-    float esum = (e[0] + e[1]) + e[2];
-    float b0 = e[0] / esum, b1 = e[1] / esum, b2 = e[2] / esum;
+    float inv_esum = 1.0f / ((e[0] + e[1]) + e[2]);                      /* one reciprocal, three products */
+    float b0 = e[0] * inv_esum, b1 = e[1] * inv_esum, b2 = e[2] * inv_esum;
     const float* n0 = nt + (size_t)rank * 24;
     /* perspective-correct varyings: (b0*A0 + b1*A1) + b2*A2 */
     ovec3 Ni = ov3((b0 * n0[0] + b1 * n0[8]) + b2 * n0[16], (b0 * n0[1] + b1 * n0[9]) + b2 * n0[17],
@@ -820,8 +820,8 @@ static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const
         float eh[3], ev[3];
         oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx ^ 1, cy, eh);
         oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy ^ 1, ev);
-        const float sh = (eh[0] + eh[1]) + eh[2], sv = (ev[0] + ev[1]) + ev[2];
-        const float h0 = eh[0] / sh, h1 = eh[1] / sh, w0 = ev[0] / sv, w1 = ev[1] / sv;
+        const float ish = 1.0f / ((eh[0] + eh[1]) + eh[2]), isv = 1.0f / ((ev[0] + ev[1]) + ev[2]);
+        const float h0 = eh[0] * ish, h1 = eh[1] * ish, w0 = ev[0] * isv, w1 = ev[1] * isv;
         const float ddx0 = (cx & 1) ? b0 - h0 : h0 - b0, ddx1 = (cx & 1) ? b1 - h1 : h1 - b1;
         const float ddy0 = (cy & 1) ? b0 - w0 : w0 - b0, ddy1 = (cy & 1) ? b1 - w1 : w1 - b1;
         g.bary_derivs = ov4(o_round_f16(ddx0), o_round_f16(ddy0), o_round_f16(ddx1), o_round_f16(ddy1));
