@@ -37,7 +37,7 @@ AWSM_DI f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 AWSM_DI float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 AWSM_DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 AWSM_DI float length(f3 a) { return sqrtf(dot(a, a)); }
-AWSM_DI f3 normalize(f3 a) { return a / length(a); }
+AWSM_DI f3 normalize(f3 a) { const float inv = 1.0f / length(a); return {a.x * inv, a.y * inv, a.z * inv}; }   // contract: one IEEE reciprocal, three products
 AWSM_DI float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 AWSM_DI f3 mix3(f3 a, f3 b, float t) { float s = 1.0f - t; return {a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t}; }
 AWSM_DI f3 min3(f3 a, f3 b) { return {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
@@ -117,8 +117,8 @@ AWSM_DI float inverse_square(float range, float dist) {   // math.wgsl:12-19
     return saturate(falloff * falloff) / denom;
 }
 AWSM_DI f2 encode_octahedral(f3 n_in) {      // math.wgsl:44-53
-    float d = (fabsf(n_in.x) + fabsf(n_in.y)) + fabsf(n_in.z);
-    f3 n = {n_in.x / d, n_in.y / d, n_in.z / d};
+    const float inv = 1.0f / ((fabsf(n_in.x) + fabsf(n_in.y)) + fabsf(n_in.z));
+    f3 n = {n_in.x * inv, n_in.y * inv, n_in.z * inv};
     if (n.z < 0.0f) {
         float wx = (1.0f - fabsf(n.y)) * signf(n.x);
         float wy = (1.0f - fabsf(n.x)) * signf(n.y);

@@ -54,7 +54,8 @@ static inline ovec3 ov3_cross(ovec3 a, ovec3 b) {
     return ov3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 static inline float ov3_length(ovec3 a) { return sqrtf(ov3_dot(a, a)); }
-static inline ovec3 ov3_normalize(ovec3 a) { return ov3_div(a, ov3_length(a)); }
+/* contract: normalize(v) = v * (1 / sqrt(dot(v,v))) — one IEEE reciprocal, three products (WGSL leaves normalize's precision open) */
+static inline ovec3 ov3_normalize(ovec3 a) { float inv = 1.0f / ov3_length(a); return ov3(a.x * inv, a.y * inv, a.z * inv); }
 static inline ovec3 ov3_mix(ovec3 a, ovec3 b, float t) {
     float s = 1.0f - t;
     return ov3(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t);
@@ -181,8 +182,8 @@ static inline uint32_t o_join32(uint32_t lo, uint32_t hi) { return (hi << 16) | 
 
 /* math.wgsl:44-53 */
 static inline ovec2 o_encode_octahedral(ovec3 n_in) {
-    float d = (fabsf(n_in.x) + fabsf(n_in.y)) + fabsf(n_in.z);
-    ovec3 n = ov3(n_in.x / d, n_in.y / d, n_in.z / d);
+    float inv = 1.0f / ((fabsf(n_in.x) + fabsf(n_in.y)) + fabsf(n_in.z));
+    ovec3 n = ov3(n_in.x * inv, n_in.y * inv, n_in.z * inv);
     if (n.z < 0.0f) {
         float wx = (1.0f - fabsf(n.y)) * o_sign(n.x);
         float wy = (1.0f - fabsf(n.x)) * o_sign(n.y);
