@@ -168,11 +168,21 @@ int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out) {
 /* ------------------------------------------------------------------------------------------------
  * Raster contract (shared with awsm-renderer_amd/csrc/raster_setup.hpp — same operations, same order)
  * ---------------------------------------------------------------------------------------------- */
+/* Two kinds of setup (DESIGN.md "Raster contract"):
+ *  kind 0, every triangle in front of the camera (w > 0 at all three vertices, inside a +-32768-pixel guard band): the
+ *    vertices are projected and SNAPPED to a 1/256-pixel grid, and everything that decides coverage — facing, edge
+ *    functions, the top-left rule — is exact integer arithmetic (|values| < 2^49), as in a hardware rasteriser.  Exactness
+ *    is what makes shared edges watertight and keeps small distant triangles from being lost to rounding.
+ *  kind 1, triangles that touch w <= 0 (they cross the near plane; close to the camera, hence large on screen and well
+ *    conditioned): homogeneous clip-less edge functions in f32, no geometric clipping. */
 typedef struct {
-    float a[3], b[3], c[3];   /* edge i: e_i(X,Y) = (a*X + b*Y) + c, inside >= 0, weight of vertex i */
-    float z[3];
-    float det;                /* > 0 after orientation normalisation */
-    float inv_det;            /* 1 / det, taken once per triangle: depth = numerator * inv_det */
+    int kind;
+    int64_t a[3], b[3], c[3];  /* kind 0: E_i(P) = a*Px + b*Py + c in 1/256-pixel units, sign-normalised (>= 0 inside), weight of vertex i */
+    float zq[3];               /* kind 0: (z_i / w_i) / |2*area| */
+    float iw[3];               /* kind 0: 1 / w_i (perspective correction of the attribute interpolation) */
+    float ha[3], hb[3], hc[3]; /* kind 1: e_i(X,Y) = (a*X + b*Y) + c in pixels */
+    float hz[3];               /* kind 1: clip z */
+    float inv_det;             /* kind 1 */
     int minx, maxx, miny, maxy;  /* inclusive, conservative, clamped to the target rect */
     int valid;
 } TriSetup;
@@ -180,6 +190,8 @@ typedef struct {
 static inline int finite4(const float* v) {
     return isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]);
 }
+#define SUBPIX 256            /* 8 fractional bits */
+#define GUARD_BAND 8388608.0f /* |coordinate| * 256 <= 2^23  (+-32768 pixels) */
 
 static void tri_setup(const float* v0, const float* v1, const float* v2, int cull_back,
                       uint32_t width, uint32_t height, uint32_t ry0, uint32_t ry1, TriSetup* t) {
@@ -193,73 +205,105 @@ static void tri_setup(const float* v0, const float* v1, const float* v2, int cul
     if (v0[2] < 0.0f && v1[2] < 0.0f && v2[2] < 0.0f) return;
     if (v0[2] > v0[3] && v1[2] > v1[3] && v2[2] > v2[3]) return;
 
-    float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
-    float X0 = (v0[0] + v0[3]) * hw, Y0 = (v0[3] - v0[1]) * hh, w0 = v0[3];
-    float X1 = (v1[0] + v1[3]) * hw, Y1 = (v1[3] - v1[1]) * hh, w1 = v1[3];
-    float X2 = (v2[0] + v2[3]) * hw, Y2 = (v2[3] - v2[1]) * hh, w2 = v2[3];
-
-    float a0 = Y1 * w2 - Y2 * w1, b0 = X2 * w1 - X1 * w2, c0 = X1 * Y2 - X2 * Y1;
-    float a1 = Y2 * w0 - Y0 * w2, b1 = X0 * w2 - X2 * w0, c1 = X2 * Y0 - X0 * Y2;
-    float a2 = Y0 * w1 - Y1 * w0, b2 = X1 * w0 - X0 * w1, c2 = X0 * Y1 - X1 * Y0;
-    float det = (X0 * a0 + Y0 * b0) + w0 * c0;
-    if (!(det != 0.0f) || !isfinite(det)) return;   /* zero area or NaN */
-    /* y-down framebuffer: det < 0 <=> counter-clockwise on screen <=> front facing (FrontFace::Ccw) */
-    if (cull_back && det > 0.0f) return;
-    if (det < 0.0f) {
-        a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
-        det = -det;
-    }
-    t->a[0] = a0; t->b[0] = b0; t->c[0] = c0;
-    t->a[1] = a1; t->b[1] = b1; t->c[1] = c1;
-    t->a[2] = a2; t->b[2] = b2; t->c[2] = c2;
-    t->z[0] = v0[2]; t->z[1] = v1[2]; t->z[2] = v2[2];
-    t->det = det; t->inv_det = 1.0f / det;
-
+    const float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
+    const float* v[3] = {v0, v1, v2};
     int minx = 0, maxx = (int)width - 1, miny = (int)ry0, maxy = (int)ry1 - 1;
-    if (w0 > 0.0f && w1 > 0.0f && w2 > 0.0f) {
-        float sx0 = X0 / w0, sx1 = X1 / w1, sx2 = X2 / w2;
-        float sy0 = Y0 / w0, sy1 = Y1 / w1, sy2 = Y2 / w2;
-        float fminx = fminf(fminf(sx0, sx1), sx2), fmaxx = fmaxf(fmaxf(sx0, sx1), sx2);
-        float fminy = fminf(fminf(sy0, sy1), sy2), fmaxy = fmaxf(fmaxf(sy0, sy1), sy2);
-        fminx = fminf(fmaxf(fminx, -16777216.0f), 16777216.0f);
-        fmaxx = fminf(fmaxf(fmaxx, -16777216.0f), 16777216.0f);
-        fminy = fminf(fmaxf(fminy, -16777216.0f), 16777216.0f);
-        fmaxy = fminf(fmaxf(fmaxy, -16777216.0f), 16777216.0f);
-        int bx0 = (int)floorf(fminx) - 1, bx1 = (int)floorf(fmaxx) + 1;
-        int by0 = (int)floorf(fminy) - 1, by1 = (int)floorf(fmaxy) + 1;
-        if (bx0 > minx) minx = bx0;
-        if (bx1 < maxx) maxx = bx1;
-        if (by0 > miny) miny = by0;
-        if (by1 < maxy) maxy = by1;
+
+    int snapped = v0[3] > 0.0f && v1[3] > 0.0f && v2[3] > 0.0f;
+    int64_t x[3] = {0, 0, 0}, y[3] = {0, 0, 0};
+    float iw[3] = {0, 0, 0};
+    if (snapped) {
+        for (int i = 0; i < 3; i++) {
+            iw[i] = 1.0f / v[i][3];
+            const float fx = ((v[i][0] * iw[i] + 1.0f) * hw) * (float)SUBPIX;     /* screen x, y-down screen y, in 1/256 pixel */
+            const float fy = ((1.0f - v[i][1] * iw[i]) * hh) * (float)SUBPIX;
+            if (!(fabsf(fx) <= GUARD_BAND && fabsf(fy) <= GUARD_BAND)) { snapped = 0; break; }
+            x[i] = (int64_t)rintf(fx); y[i] = (int64_t)rintf(fy);                     /* round to nearest even */
+        }
+    }
+    if (snapped) {
+        t->kind = 0;
+        /* 2*area; y-down screen: negative <=> counter-clockwise in NDC <=> front facing (FrontFace::Ccw) */
+        const int64_t A2 = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+        if (A2 == 0) return;
+        if (cull_back && A2 > 0) return;
+        const int64_t sgn = A2 < 0 ? -1 : 1;
+        for (int i = 0; i < 3; i++) {
+            const int j = (i + 1) % 3, k = (i + 2) % 3;          /* weight of vertex i = edge j -> k */
+            t->a[i] = sgn * (y[j] - y[k]);
+            t->b[i] = sgn * (x[k] - x[j]);
+            t->c[i] = sgn * (x[j] * y[k] - x[k] * y[j]);
+        }
+        const float inv_area = 1.0f / (float)(sgn * A2);
+        for (int i = 0; i < 3; i++) { t->zq[i] = (v[i][2] * iw[i]) * inv_area; t->iw[i] = iw[i]; }
+        /* pixels that can hold a sample strictly inside [min, max] of the snapped vertices */
+        int64_t mnx = x[0] < x[1] ? x[0] : x[1], mxx = x[0] > x[1] ? x[0] : x[1], mny = y[0] < y[1] ? y[0] : y[1], mxy = y[0] > y[1] ? y[0] : y[1];
+        if (x[2] < mnx) mnx = x[2]; if (x[2] > mxx) mxx = x[2]; if (y[2] < mny) mny = y[2]; if (y[2] > mxy) mxy = y[2];
+        const int64_t bx0 = mnx >> 8, bx1 = (mxx - 1) >> 8, by0 = mny >> 8, by1 = (mxy - 1) >> 8;      /* arithmetic shifts: floor */
+        if (bx0 > minx) minx = (int)bx0;
+        if (bx1 < maxx) maxx = (int)bx1;
+        if (by0 > miny) miny = (int)by0;
+        if (by1 < maxy) maxy = (int)by1;
+    } else {
+        t->kind = 1;
+        float X0 = (v0[0] + v0[3]) * hw, Y0 = (v0[3] - v0[1]) * hh, w0 = v0[3];
+        float X1 = (v1[0] + v1[3]) * hw, Y1 = (v1[3] - v1[1]) * hh, w1 = v1[3];
+        float X2 = (v2[0] + v2[3]) * hw, Y2 = (v2[3] - v2[1]) * hh, w2 = v2[3];
+        float a0 = Y1 * w2 - Y2 * w1, b0 = X2 * w1 - X1 * w2, c0 = X1 * Y2 - X2 * Y1;
+        float a1 = Y2 * w0 - Y0 * w2, b1 = X0 * w2 - X2 * w0, c1 = X2 * Y0 - X0 * Y2;
+        float a2 = Y0 * w1 - Y1 * w0, b2 = X1 * w0 - X0 * w1, c2 = X0 * Y1 - X1 * Y0;
+        float det = (X0 * a0 + Y0 * b0) + w0 * c0;
+        if (!(det != 0.0f) || !isfinite(det)) return;   /* zero area or NaN */
+        if (cull_back && det > 0.0f) return;            /* det < 0 <=> front facing */
+        if (det < 0.0f) {
+            a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
+            det = -det;
+        }
+        t->ha[0] = a0; t->hb[0] = b0; t->hc[0] = c0;
+        t->ha[1] = a1; t->hb[1] = b1; t->hc[1] = c1;
+        t->ha[2] = a2; t->hb[2] = b2; t->hc[2] = c2;
+        t->hz[0] = v0[2]; t->hz[1] = v1[2]; t->hz[2] = v2[2];
+        t->inv_det = 1.0f / det;
     }
     if (minx > maxx || miny > maxy) return;
     t->minx = minx; t->maxx = maxx; t->miny = miny; t->maxy = maxy;
     t->valid = 1;
 }
 
-static inline int edge_inside(float e, float a, float b) {
-    return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));   /* top-left rule */
-}
+/* WebGPU's standard 4x sample pattern (GPUMultisampleState count 4; == D3D standard pattern) in 1/256 pixel:
+ * (0.375, 0.125) (0.875, 0.375) (0.125, 0.625) (0.625, 0.875); the pixel centre is (128, 128) */
+const int oracle_msaa4_x[4] = {96, 224, 32, 160};
+const int oracle_msaa4_y[4] = {32, 96, 160, 224};
 
-/* WebGPU's standard 4x sample pattern (GPUMultisampleState count 4; == D3D standard pattern), pixel-relative */
-const float oracle_msaa4_x[4] = {0.375f, 0.875f, 0.125f, 0.625f};
-const float oracle_msaa4_y[4] = {0.125f, 0.375f, 0.625f, 0.875f};
-
-/* returns 1 and the depth if the sample at (X, Y) (pixel units) is covered and inside the depth clip range */
-static inline int tri_sample_at(const TriSetup* t, float X, float Y, float* e_out, float* depth_out);
-static inline int tri_sample(const TriSetup* t, int px, int py, float* e_out, float* depth_out) {
-    return tri_sample_at(t, (float)px + 0.5f, (float)py + 0.5f, e_out, depth_out);
+/* Edge values at the sample (px, py) + (ox, oy)/256, as floats: exact-then-rounded for kind 0, f32-evaluated for kind 1.
+ * Returns 1 if the sample is inside (top-left rule). */
+static inline int tri_edges_sample(const TriSetup* t, int px, int py, int ox, int oy, float* e) {
+    if (t->kind == 0) {
+        const int64_t Px = (int64_t)px * SUBPIX + ox, Py = (int64_t)py * SUBPIX + oy;
+        int inside = 1;
+        for (int i = 0; i < 3; i++) {
+            const int64_t E = t->a[i] * Px + t->b[i] * Py + t->c[i];
+            if (!(E > 0 || (E == 0 && (t->a[i] > 0 || (t->a[i] == 0 && t->b[i] > 0))))) inside = 0;   /* top-left rule */
+            e[i] = (float)E;
+        }
+        return inside;
+    }
+    const float X = (float)px + (float)ox / 256.0f, Y = (float)py + (float)oy / 256.0f;     /* exact */
+    int inside = 1;
+    for (int i = 0; i < 3; i++) {
+        e[i] = (t->ha[i] * X + t->hb[i] * Y) + t->hc[i];
+        if (!(e[i] > 0.0f || (e[i] == 0.0f && (t->ha[i] > 0.0f || (t->ha[i] == 0.0f && t->hb[i] > 0.0f))))) inside = 0;
+    }
+    return inside;
 }
-static inline int tri_sample_at(const TriSetup* t, float X, float Y, float* e_out, float* depth_out) {
-    float e0 = (t->a[0] * X + t->b[0] * Y) + t->c[0];
-    float e1 = (t->a[1] * X + t->b[1] * Y) + t->c[1];
-    float e2 = (t->a[2] * X + t->b[2] * Y) + t->c[2];
-    if (!edge_inside(e0, t->a[0], t->b[0]) || !edge_inside(e1, t->a[1], t->b[1]) || !edge_inside(e2, t->a[2], t->b[2]))
-        return 0;
-    float zn = ((e0 * t->z[0] + e1 * t->z[1]) + e2 * t->z[2]) * t->inv_det;
+/* returns 1 and the depth if the sample is covered and inside the depth clip range */
+static inline int tri_sample(const TriSetup* t, int px, int py, int ox, int oy, float* depth_out) {
+    float e[3];
+    if (!tri_edges_sample(t, px, py, ox, oy, e)) return 0;
+    float zn = t->kind == 0 ? (e[0] * t->zq[0] + e[1] * t->zq[1]) + e[2] * t->zq[2]
+                            : ((e[0] * t->hz[0] + e[1] * t->hz[1]) + e[2] * t->hz[2]) * t->inv_det;
     if (!(zn >= 0.0f && zn <= 1.0f)) return 0;
     if (zn == 0.0f) zn = 0.0f;   /* canonicalise -0 so the bit pattern orders as an unsigned integer */
-    e_out[0] = e0; e_out[1] = e1; e_out[2] = e2;
     *depth_out = zn;
     return 1;
 }
@@ -301,14 +345,14 @@ int oracle_raster(const OracleScene* s, const float* clip, uint64_t* keys, int t
                 int y_hi = ts.maxy > (int)by1 - 1 ? (int)by1 - 1 : ts.maxy;
                 for (int py = y_lo; py <= y_hi; py++) {
                     for (int px = ts.minx; px <= ts.maxx; px++) {
-                        float e[3], zn;
+                        float zn;
                         size_t p = (size_t)py * W + (size_t)px;
                         if (S == 1u) {
-                            if (!tri_sample(&ts, px, py, e, &zn)) continue;
+                            if (!tri_sample(&ts, px, py, 128, 128, &zn)) continue;
                             if (zn <= depth[p]) { depth[p] = zn; rank_buf[p] = rank; }   /* CompareFunction::LessEqual */
                         } else {   /* per-sample coverage + per-sample depth (multisampled depth/visibility targets) */
                             for (uint32_t k = 0; k < 4u; k++) {
-                                if (!tri_sample_at(&ts, (float)px + oracle_msaa4_x[k], (float)py + oracle_msaa4_y[k], e, &zn)) continue;
+                                if (!tri_sample(&ts, px, py, oracle_msaa4_x[k], oracle_msaa4_y[k], &zn)) continue;
                                 if (zn <= depth[p * 4 + k]) { depth[p * 4 + k] = zn; rank_buf[p * 4 + k] = rank; }
                             }
                         }
@@ -361,15 +405,18 @@ int oracle_unpack_visibility(const OracleScene* s, const uint64_t* keys, uint32_
 }
 
 /* ---- shared with oracle_shade.c: recompute the winner's edge values at a pixel ---- */
-int oracle_tri_edges_at(const float* v0, const float* v1, const float* v2, uint32_t width, uint32_t height,
-                        int px, int py, float* e_out) {
+/* Perspective-correct barycentrics of the centre of pixel (px, py) in the plane of the triangle (the pixel need not be
+ * covered: MSAA extrapolates, and the derivative contract evaluates the quad neighbours).  One reciprocal, three products. */
+int oracle_tri_bary_at(const float* v0, const float* v1, const float* v2, uint32_t width, uint32_t height,
+                       int px, int py, float* b_out) {
     TriSetup ts;
     tri_setup(v0, v1, v2, 0, width, height, 0, height, &ts);
     if (!ts.valid) return 0;
-    float X = (float)px + 0.5f, Y = (float)py + 0.5f;
-    e_out[0] = (ts.a[0] * X + ts.b[0] * Y) + ts.c[0];
-    e_out[1] = (ts.a[1] * X + ts.b[1] * Y) + ts.c[1];
-    e_out[2] = (ts.a[2] * X + ts.b[2] * Y) + ts.c[2];
+    float e[3];
+    (void)tri_edges_sample(&ts, px, py, 128, 128, e);
+    if (ts.kind == 0) { e[0] *= ts.iw[0]; e[1] *= ts.iw[1]; e[2] *= ts.iw[2]; }   /* screen-space weights -> perspective-correct */
+    const float inv = 1.0f / ((e[0] + e[1]) + e[2]);
+    b_out[0] = e[0] * inv; b_out[1] = e[1] * inv; b_out[2] = e[2] * inv;
     return 1;
 }
 

@@ -24,8 +24,8 @@
 #include "oracle_math.h"
 #include <stdlib.h>
 
-int oracle_tri_edges_at(const float* v0, const float* v1, const float* v2, uint32_t width, uint32_t height,
-                        int px, int py, float* e_out);
+int oracle_tri_bary_at(const float* v0, const float* v1, const float* v2, uint32_t width, uint32_t height,
+                       int px, int py, float* b_out);
 
 static inline uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
@@ -798,10 +798,9 @@ typedef struct { float bx, by; ovec4 packed_nt; ovec4 bary_derivs; int valid; } 
 static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const float* nt, uint32_t rank, int cx, int cy) {
     GBufferTexel g; memset(&g, 0, sizeof g);
     const float* v0 = clip + (size_t)rank * 12;
-    float e[3];
-    if (!oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy, e)) return g;
-    float inv_esum = 1.0f / ((e[0] + e[1]) + e[2]);                      /* one reciprocal, three products */
-    float b0 = e[0] * inv_esum, b1 = e[1] * inv_esum, b2 = e[2] * inv_esum;
+    float bb[3];
+    if (!oracle_tri_bary_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy, bb)) return g;
+    float b0 = bb[0], b1 = bb[1], b2 = bb[2];
     const float* n0 = nt + (size_t)rank * 24;
     /* perspective-correct varyings: (b0*A0 + b1*A1) + b2*A2 */
     ovec3 Ni = ov3((b0 * n0[0] + b1 * n0[8]) + b2 * n0[16], (b0 * n0[1] + b1 * n0[9]) + b2 * n0[17],
@@ -817,11 +816,10 @@ static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const
         /* fragment.wgsl:46-51 dpdx/dpdy of the barycentrics.  Contract ("fine" derivatives of a 2x2 quad): the difference
          * between the two pixels of the quad row / column this pixel sits in, both evaluated for THIS triangle (helper
          * invocations extrapolate), right minus left and bottom minus top; then RGBA16F. */
-        float eh[3], ev[3];
-        oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx ^ 1, cy, eh);
-        oracle_tri_edges_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy ^ 1, ev);
-        const float ish = 1.0f / ((eh[0] + eh[1]) + eh[2]), isv = 1.0f / ((ev[0] + ev[1]) + ev[2]);
-        const float h0 = eh[0] * ish, h1 = eh[1] * ish, w0 = ev[0] * isv, w1 = ev[1] * isv;
+        float bh[3], bv[3];
+        oracle_tri_bary_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx ^ 1, cy, bh);
+        oracle_tri_bary_at(v0, v0 + 4, v0 + 8, s->width, s->height, cx, cy ^ 1, bv);
+        const float h0 = bh[0], h1 = bh[1], w0 = bv[0], w1 = bv[1];
         const float ddx0 = (cx & 1) ? b0 - h0 : h0 - b0, ddx1 = (cx & 1) ? b1 - h1 : h1 - b1;
         const float ddy0 = (cy & 1) ? b0 - w0 : w0 - b0, ddy1 = (cy & 1) ? b1 - w1 : w1 - b1;
         g.bary_derivs = ov4(o_round_f16(ddx0), o_round_f16(ddy0), o_round_f16(ddx1), o_round_f16(ddy1));
