@@ -172,4 +172,10 @@ AWSM_DI TBN unpack_normal_tangent(f4 rgba) {  // math.wgsl:104-116
     return r;
 }
 
+// Texture coordinates follow the arithmetic contract up to the texel address even though the rest of the shading is
+// relaxed: with a nearest filter a coordinate that lands exactly on a texel boundary (common once vertices are snapped to
+// the sub-pixel grid and UVs are simple fractions) must pick the same texel as the oracle.
+AWSM_DI float interp3_strict(float b0, float b1, float b2, float x0, float x1, float x2) { return (b0 * x0 + b1 * x1) + b2 * x2; }
+AWSM_DI float affine2_strict(float a, float b, float c, float x, float y) { return (a * x + b * y) + c; }
+
 }  // namespace awsm

@@ -60,8 +60,8 @@ struct DevScene {
     uint32_t lut_w, lut_h;
 };
 
-struct TriRec;                                   // raster_setup.hpp (device side); 64 bytes
-constexpr size_t kTriRecBytes = 64;
+struct TriRec;                                   // raster_setup.hpp (device side); 80 bytes
+constexpr size_t kTriRecBytes = 80;
 
 struct FrameDev {
     uint32_t width, height;

@@ -412,31 +412,32 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
 // All paths resolve depth + submission order with ds_min_u64 on the LDS tile.
 // ------------------------------------------------------------------------------------------------
 struct WorkTri {
-    float a[3], b[3], c[3];
-    float z[3];
-    float inv_det;
+    double c[3];
+    float a[3], b[3];
+    float zq[3];
     uint32_t rank;
     uint32_t bbox;   // x0 | x1<<8 | y0<<16 | y1<<24, tile-local, inclusive
     uint32_t pad;
 };
+static_assert(sizeof(WorkTri) == 72, "WorkTri");
 
 AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.z[i] = g.z[i]; }
-    t.inv_det = g.inv_det;
+    for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.zq[i] = g.zq[i]; }
 }
 
 // One pixel of the tile against one triangle: S = 1 samples the pixel centre, S = 4 the four standard MSAA positions
 // (per-sample coverage and per-sample depth, as the multisampled visibility / depth targets of the reference receive them).
 template <int S>
 AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int px, int py, uint32_t r) {
+    const int sx = (tpx + px) << 8, sy = (tpy + py) << 8;
     if (S == 1) {
-        const unsigned long long k = tri_sample_key(t, tpx + px, tpy + py, r);
+        const unsigned long long k = tri_sample_key_at(t, sample_coord(sx + 128), sample_coord(sy + 128), r);
         if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
     } else {
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const unsigned long long k = tri_sample_key_at(t, (float)(tpx + px) + msaa4_x(s), (float)(tpy + py) + msaa4_y(s), r);
+            const unsigned long long k = tri_sample_key_at(t, sample_coord(sx + msaa4_x(s)), sample_coord(sy + msaa4_y(s)), r);
             if (k != ~0ull) atomicMin(&keys[(py * kTile + px) * S + s], k);
         }
     }
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                         const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : 255u - atomicAdd(&n_big, 1u);
                         WorkTri& g = work[slot];
 #pragma unroll
-                        for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.z[i] = t.z[i]; }
-                        g.inv_det = t.inv_det; g.rank = r;
+                        for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
+                        g.rank = r;
                         g.bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
                     }
                 }

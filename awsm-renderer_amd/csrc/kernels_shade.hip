@@ -36,10 +36,12 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
     GBufferTexel g;
     g.bary_derivs = {0.0f, 0.0f, 0.0f, 0.0f};
     TriSetup t;
-    tri_rec_load_edges(f.tri_rec + rank, t);
-    float e0, e1, e2;
-    tri_edges(t, cx, cy, e0, e1, e2);
-    const float inv_esum = 1.0f / ((e0 + e1) + e2);                       // one IEEE reciprocal, three products
+    tri_rec_load(f.tri_rec + rank, t);
+    const double Xc = sample_coord((cx << 8) + 128), Yc = sample_coord((cy << 8) + 128);
+    const EdgeVals ev = tri_edges_d(t, Xc, Yc);
+    // screen-space edge weights -> perspective-correct barycentrics: one IEEE reciprocal, six products
+    const float e0 = (float)ev.E[0] * t.iw[0], e1 = (float)ev.E[1] * t.iw[1], e2 = (float)ev.E[2] * t.iw[2];
+    const float inv_esum = 1.0f / ((e0 + e1) + e2);
     const float b0 = e0 * inv_esum, b1 = e1 * inv_esum, b2 = e2 * inv_esum;
     const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
     const float4 t0 = f.tan[(size_t)rank * 3], t1 = f.tan[(size_t)rank * 3 + 1], t2 = f.tan[(size_t)rank * 3 + 2];
@@ -54,9 +56,9 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
         // fragment.wgsl:46-51 dpdx/dpdy of the barycentrics.  Contract ("fine" derivatives of a 2x2 quad): the difference
         // between the two pixels of the quad row / column this pixel sits in, both evaluated for THIS triangle (helper
         // invocations extrapolate), right minus left and bottom minus top; then RGBA16F.
-        float h0, h1, h2, w0, w1, w2;
-        tri_edges(t, cx ^ 1, cy, h0, h1, h2);
-        tri_edges(t, cx, cy ^ 1, w0, w1, w2);
+        const EdgeVals eh = tri_edges_d(t, sample_coord(((cx ^ 1) << 8) + 128), Yc), evv = tri_edges_d(t, Xc, sample_coord(((cy ^ 1) << 8) + 128));
+        const float h0 = (float)eh.E[0] * t.iw[0], h1 = (float)eh.E[1] * t.iw[1], h2 = (float)eh.E[2] * t.iw[2];
+        const float w0 = (float)evv.E[0] * t.iw[0], w1 = (float)evv.E[1] * t.iw[1], w2 = (float)evv.E[2] * t.iw[2];
         const float ish = 1.0f / ((h0 + h1) + h2), isv = 1.0f / ((w0 + w1) + w2);
         const float hb0 = h0 * ish, hb1 = h1 * ish, vb0 = w0 * isv, vb1 = w1 * isv;
         const float ddx0 = (cx & 1) ? b0 - hb0 : hb0 - b0, ddx1 = (cx & 1) ? b1 - hb1 : hb1 - b1;
@@ -252,7 +254,7 @@ AWSM_DI f2 attr_uv(const Attr& a, uint32_t set, f2& ddx, f2& ddy) {
         const bool ok = (ddx.x == ddx.x) && (ddx.y == ddx.y) && (ddy.x == ddy.x) && (ddy.y == ddy.y);   // NaN guard
         if (tiny || !ok) { ddx = {0.0f, 0.0f}; ddy = {0.0f, 0.0f}; }
     }
-    return {a.bary.x * x0 + a.bary.y * x1 + a.bary.z * x2, a.bary.x * y0 + a.bary.y * y1 + a.bary.z * y2};
+    return {interp3_strict(a.bary.x, a.bary.y, a.bary.z, x0, x1, x2), interp3_strict(a.bary.x, a.bary.y, a.bary.z, y0, y1, y2)};
 }
 // texture_uvs.wgsl:64-187 + textures.wgsl:131-150.  GRAD = MipmapMode::Gradient: textureSampleGrad by the contract the
 // reference documents as "mimics the hardware mip selection" (helpers/mipmap.wgsl:419-439): rho = max(|ddx*size|, |ddy*size|),
@@ -263,7 +265,7 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
     f2 uv = a.uv0, ddx = a.duv0_dx, ddy = a.duv0_dy;
     if (!(a.has_uv0 && t.uv_set_index == 0u)) uv = attr_uv<GRAD>(a, t.uv_set_index, ddx, ddy);
     const float* tt = reinterpret_cast<const float*>(a.sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
-    const float u = tt[0] * uv.x + tt[1] * uv.y + tt[4], v = tt[2] * uv.x + tt[3] * uv.y + tt[5];
+    const float u = affine2_strict(tt[0], tt[1], tt[4], uv.x, uv.y), v = affine2_strict(tt[2], tt[3], tt[5], uv.x, uv.y);
     if (t.array_index >= a.sc->n_tex || t.sampler_index >= a.sc->n_samplers) return {0.0f, 0.0f, 0.0f, 0.0f};
     const TexArrayDev& arr = a.sc->tex[t.array_index];
     const AwsmSampler& smp = a.sc->samplers[t.sampler_index];

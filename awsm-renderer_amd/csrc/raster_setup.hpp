@@ -3,9 +3,14 @@
 // Replaces WebGPU's fixed-function rasteriser as configured by
 //   crates/renderer/src/render_passes/geometry/pipeline.rs:337-344
 //   (TriangleList, FrontFace::Ccw, CullMode::{None,Back}, depth write, CompareFunction::LessEqual).
-// The raster contract (DESIGN.md §"Raster contract"): homogeneous edge functions in f32, evaluated at
-// pixel centres, top-left rule, per-pixel 0 <= z_ndc <= 1 clip, z_ndc = (e0*z0 + e1*z1 + e2*z2) * (1/det) with the
-// reciprocal taken once per triangle (IEEE division) — one multiply per sample instead of an 11-instruction division.
+// The raster contract (DESIGN.md §"Raster contract"), two kinds of triangle setup:
+//   kind 0 — w > 0 at all three vertices and inside a +-32768-pixel guard band: vertices projected and SNAPPED to a 1/256-pixel
+//     grid; facing, edge functions and the top-left rule are exact (integers < 2^49, carried in f64 where every operation on
+//     them is exact), as in a hardware rasteriser: shared edges are watertight and small distant triangles keep their depth;
+//   kind 1 — triangles touching w <= 0 (crossing the near plane): homogeneous clip-less edge functions, f32 coefficients.
+// Both kinds evaluate a sample with the same instructions: E_i = fma(a_i, X, fma(b_i, Y, c_i)) in f64 with X, Y in pixels
+// (exact for kind 0), e_i = (float)E_i, depth = (e0*zq0 + e1*zq1) + e2*zq2 in f32, 0 <= depth <= 1 clip per sample;
+// perspective-correct barycentrics for the opaque pass: u_i = e_i * iw_i, b_i = u_i * (1 / ((u0 + u1) + u2)).
 // Used by the binning, raster and shade kernels so that all three see bit-identical edge values.
 #pragma once
 #include "device_math.hpp"
@@ -13,43 +18,17 @@
 namespace awsm {
 
 struct TriSetup {
-    float a[3], b[3], c[3];   // e_i(X,Y) = (a*X + b*Y) + c ; inside >= 0 ; e_i is the weight of vertex i
-    float z[3];
-    float det;                // > 0 after orientation normalisation
-    float inv_det;            // 1 / det (IEEE), the factor of the per-sample depth
+    float a[3], b[3];         // E_i(X,Y) = a*X + b*Y + c, X/Y in pixels ; inside >= 0 ; E_i is the (screen-space) weight of vertex i
+    double c[3];
+    float zq[3];              // kind 0: (z_i / w_i) / |2 area| ; kind 1: z_i / det
+    float iw[3];              // kind 0: 1 / w_i ; kind 1: 1
     int minx, maxx, miny, maxy;   // inclusive, conservative, clamped to the target rect
 };
 
 AWSM_DI bool finite4(float4 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w); }
 
-// Edge-function coefficients, orientation normalisation and det (the part of the setup that per-pixel sampling needs).
-// Returns false for a degenerate or culled triangle.  X*/Y* are the homogeneous screen coordinates, for the bbox.
-AWSM_DI bool tri_coefficients(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t width, uint32_t height, TriSetup& t,
-                              float& X0, float& Y0, float& X1, float& Y1, float& X2, float& Y2) {
-    float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
-    const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
-    X0 = (v0.x + v0.w) * hw; Y0 = (v0.w - v0.y) * hh;
-    X1 = (v1.x + v1.w) * hw; Y1 = (v1.w - v1.y) * hh;
-    X2 = (v2.x + v2.w) * hw; Y2 = (v2.w - v2.y) * hh;
-
-    float a0 = Y1 * w2 - Y2 * w1, b0 = X2 * w1 - X1 * w2, c0 = X1 * Y2 - X2 * Y1;
-    float a1 = Y2 * w0 - Y0 * w2, b1 = X0 * w2 - X2 * w0, c1 = X2 * Y0 - X0 * Y2;
-    float a2 = Y0 * w1 - Y1 * w0, b2 = X1 * w0 - X0 * w1, c2 = X0 * Y1 - X1 * Y0;
-    float det = (X0 * a0 + Y0 * b0) + w0 * c0;
-    if (!(det != 0.0f) || !isfinite(det)) return false;
-    if (cull_back && det > 0.0f) return false;      // y-down framebuffer: det < 0 <=> CCW on screen <=> front
-    if (det < 0.0f) {
-        a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
-        det = -det;
-    }
-    t.a[0] = a0; t.b[0] = b0; t.c[0] = c0;
-    t.a[1] = a1; t.b[1] = b1; t.c[1] = c1;
-    t.a[2] = a2; t.b[2] = b2; t.c[2] = c2;
-    t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
-    t.det = det;
-    t.inv_det = 1.0f / det;
-    return true;
-}
+constexpr float kSubPix = 256.0f;            // 8 fractional bits
+constexpr float kGuardBand = 8388608.0f;     // |coordinate| * 256 <= 2^23
 
 // Returns false if the triangle cannot produce a fragment (culled, degenerate, outside, empty bbox).
 AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t width, uint32_t height,
@@ -62,24 +41,67 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
     if (v0.z < 0.0f && v1.z < 0.0f && v2.z < 0.0f) return false;
     if (v0.z > v0.w && v1.z > v1.w && v2.z > v2.w) return false;
 
-    float X0, Y0, X1, Y1, X2, Y2;
-    if (!tri_coefficients(v0, v1, v2, cull_back, width, height, t, X0, Y0, X1, Y1, X2, Y2)) return false;
-    const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
-
+    const float hw = 0.5f * (float)width, hh = 0.5f * (float)height;
     int minx = 0, maxx = (int)width - 1, miny = (int)ry0, maxy = (int)ry1 - 1;
-    if (w0 > 0.0f && w1 > 0.0f && w2 > 0.0f) {
-        float sx0 = X0 / w0, sx1 = X1 / w1, sx2 = X2 / w2;
-        float sy0 = Y0 / w0, sy1 = Y1 / w1, sy2 = Y2 / w2;
-        float fminx = fminf(fminf(sx0, sx1), sx2), fmaxx = fmaxf(fmaxf(sx0, sx1), sx2);
-        float fminy = fminf(fminf(sy0, sy1), sy2), fmaxy = fmaxf(fmaxf(sy0, sy1), sy2);
-        fminx = fminf(fmaxf(fminx, -16777216.0f), 16777216.0f);
-        fmaxx = fminf(fmaxf(fmaxx, -16777216.0f), 16777216.0f);
-        fminy = fminf(fmaxf(fminy, -16777216.0f), 16777216.0f);
-        fmaxy = fminf(fmaxf(fmaxy, -16777216.0f), 16777216.0f);
-        int bx0 = (int)floorf(fminx) - 1, bx1 = (int)floorf(fmaxx) + 1;
-        int by0 = (int)floorf(fminy) - 1, by1 = (int)floorf(fmaxy) + 1;
-        minx = max(minx, bx0); maxx = min(maxx, bx1);
-        miny = max(miny, by0); maxy = min(maxy, by1);
+
+    bool snapped = v0.w > 0.0f && v1.w > 0.0f && v2.w > 0.0f;
+    int x[3] = {0, 0, 0}, y[3] = {0, 0, 0};
+    float iw[3] = {1.0f, 1.0f, 1.0f};
+    const float4 v[3] = {v0, v1, v2};
+    if (snapped) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            iw[i] = 1.0f / v[i].w;
+            const float fx = ((v[i].x * iw[i] + 1.0f) * hw) * kSubPix;      // screen x, y-down screen y, in 1/256 pixel
+            const float fy = ((1.0f - v[i].y * iw[i]) * hh) * kSubPix;
+            if (!(fabsf(fx) <= kGuardBand && fabsf(fy) <= kGuardBand)) snapped = false;
+            x[i] = (int)rintf(fx); y[i] = (int)rintf(fy);                     // round to nearest even; garbage if !snapped, unused
+        }
+    }
+    if (snapped) {
+        // 2*area; y-down screen: negative <=> counter-clockwise in NDC <=> front facing (FrontFace::Ccw)
+        const long long A2 = (long long)(x[1] - x[0]) * (long long)(y[2] - y[0]) - (long long)(x[2] - x[0]) * (long long)(y[1] - y[0]);
+        if (A2 == 0) return false;
+        if (cull_back && A2 > 0) return false;
+        const bool flip = A2 < 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int j = (i + 1) % 3, k = (i + 2) % 3;                       // weight of vertex i = edge j -> k
+            const int ai = y[j] - y[k], bi = x[k] - x[j];                     // |.| <= 2^24: exact in f32, and so is * 256
+            const long long ci = (long long)x[j] * (long long)y[k] - (long long)x[k] * (long long)y[j];   // |.| < 2^48: exact in f64
+            t.a[i] = (float)(flip ? -ai : ai) * kSubPix;                      // pixel units: a*256 * (Px/256)
+            t.b[i] = (float)(flip ? -bi : bi) * kSubPix;
+            t.c[i] = (double)(flip ? -ci : ci);
+        }
+        const float inv_area = 1.0f / (float)(double)(flip ? -A2 : A2);      // i64 -> f64 exact, one rounding to f32
+#pragma unroll
+        for (int i = 0; i < 3; i++) { t.zq[i] = (v[i].z * iw[i]) * inv_area; t.iw[i] = iw[i]; }
+        // pixels that can hold a sample inside [min, max] of the snapped vertices
+        const int mnx = min(min(x[0], x[1]), x[2]), mxx = max(max(x[0], x[1]), x[2]);
+        const int mny = min(min(y[0], y[1]), y[2]), mxy = max(max(y[0], y[1]), y[2]);
+        minx = max(minx, mnx >> 8); maxx = min(maxx, (mxx - 1) >> 8);        // arithmetic shifts: floor
+        miny = max(miny, mny >> 8); maxy = min(maxy, (mxy - 1) >> 8);
+    } else {
+        const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
+        const float X0 = (v0.x + v0.w) * hw, Y0 = (v0.w - v0.y) * hh;
+        const float X1 = (v1.x + v1.w) * hw, Y1 = (v1.w - v1.y) * hh;
+        const float X2 = (v2.x + v2.w) * hw, Y2 = (v2.w - v2.y) * hh;
+        float a0 = Y1 * w2 - Y2 * w1, b0 = X2 * w1 - X1 * w2, c0 = X1 * Y2 - X2 * Y1;
+        float a1 = Y2 * w0 - Y0 * w2, b1 = X0 * w2 - X2 * w0, c1 = X2 * Y0 - X0 * Y2;
+        float a2 = Y0 * w1 - Y1 * w0, b2 = X1 * w0 - X0 * w1, c2 = X0 * Y1 - X1 * Y0;
+        float det = (X0 * a0 + Y0 * b0) + w0 * c0;
+        if (!(det != 0.0f) || !isfinite(det)) return false;
+        if (cull_back && det > 0.0f) return false;      // y-down framebuffer: det < 0 <=> CCW on screen <=> front
+        if (det < 0.0f) {
+            a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
+            det = -det;
+        }
+        t.a[0] = a0; t.b[0] = b0; t.c[0] = (double)c0;
+        t.a[1] = a1; t.b[1] = b1; t.c[1] = (double)c1;
+        t.a[2] = a2; t.b[2] = b2; t.c[2] = (double)c2;
+        const float inv_det = 1.0f / det;
+        t.zq[0] = v0.z * inv_det; t.zq[1] = v1.z * inv_det; t.zq[2] = v2.z * inv_det;
+        t.iw[0] = 1.0f; t.iw[1] = 1.0f; t.iw[2] = 1.0f;
     }
     if (minx > maxx || miny > maxy) return false;
     t.minx = minx; t.maxx = maxx; t.miny = miny; t.maxy = maxy;
@@ -87,80 +109,73 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
 }
 
 // Per-triangle setup record, written once per frame by the counting pass of the binner and read by the fill pass, the
-// raster kernel and the shade kernel (which would otherwise each redo the setup: ~250 VALU incl. six IEEE divisions).
-// Same bits everywhere by construction.  64 bytes, 16-byte aligned.
+// raster kernel and the shade kernel (which would otherwise each redo the setup: ~250 VALU incl. IEEE divisions).
+// Same bits everywhere by construction.  80 bytes, 16-byte aligned.  An empty bbox (minx > maxx) marks a triangle that
+// cannot produce a fragment in this shard.
 struct alignas(16) TriRec {
-    float a[3], b[3], c[3];
-    float z[3];
-    float inv_det;
+    float a[3], b[3];
+    float zq[3];
+    float iw[3];
+    double c[3];
     uint32_t bbox_x;   // minx | maxx << 16   (inclusive, clamped to the target rect)
     uint32_t bbox_y;   // miny | maxy << 16
-    uint32_t valid;    // 0: the triangle cannot produce a fragment in this shard
 };
-static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
 AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok) {
     float4* q = reinterpret_cast<float4*>(dst);
+    const uint32_t bx = ok ? ((uint32_t)t.minx | ((uint32_t)t.maxx << 16)) : 1u;   // minx 1 > maxx 0
+    const uint32_t by = ok ? ((uint32_t)t.miny | ((uint32_t)t.maxy << 16)) : 1u;
     q[0] = make_float4(t.a[0], t.a[1], t.a[2], t.b[0]);
-    q[1] = make_float4(t.b[1], t.b[2], t.c[0], t.c[1]);
-    q[2] = make_float4(t.c[2], t.z[0], t.z[1], t.z[2]);
-    q[3] = make_float4(t.inv_det, __uint_as_float((uint32_t)t.minx | ((uint32_t)t.maxx << 16)), __uint_as_float((uint32_t)t.miny | ((uint32_t)t.maxy << 16)),
-                       __uint_as_float(ok ? 1u : 0u));
+    q[1] = make_float4(t.b[1], t.b[2], t.zq[0], t.zq[1]);
+    q[2] = make_float4(t.zq[2], t.iw[0], t.iw[1], t.iw[2]);
+    double2* d = reinterpret_cast<double2*>(dst);
+    d[3] = make_double2(t.c[0], t.c[1]);
+    d[4] = make_double2(t.c[2], __hiloint2double((int)by, (int)bx));
 }
 AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) {
     const float4* q = reinterpret_cast<const float4*>(src);
-    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const double2* d = reinterpret_cast<const double2*>(src);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const double2 d3 = d[3], d4 = d[4];
     t.a[0] = q0.x; t.a[1] = q0.y; t.a[2] = q0.z; t.b[0] = q0.w;
-    t.b[1] = q1.x; t.b[2] = q1.y; t.c[0] = q1.z; t.c[1] = q1.w;
-    t.c[2] = q2.x; t.z[0] = q2.y; t.z[1] = q2.z; t.z[2] = q2.w;
-    t.inv_det = q3.x;
-    const uint32_t bx = __float_as_uint(q3.y), by = __float_as_uint(q3.z);
+    t.b[1] = q1.x; t.b[2] = q1.y; t.zq[0] = q1.z; t.zq[1] = q1.w;
+    t.zq[2] = q2.x; t.iw[0] = q2.y; t.iw[1] = q2.z; t.iw[2] = q2.w;
+    t.c[0] = d3.x; t.c[1] = d3.y; t.c[2] = d4.x;
+    const uint32_t bx = (uint32_t)__double2loint(d4.y), by = (uint32_t)__double2hiint(d4.y);
     t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)(bx >> 16); t.miny = (int)(by & 0xFFFFu); t.maxy = (int)(by >> 16);
-    return __float_as_uint(q3.w) != 0u;
-}
-// the edge coefficients only (shade kernel)
-AWSM_DI void tri_rec_load_edges(const TriRec* __restrict__ src, TriSetup& t) {
-    const float4* q = reinterpret_cast<const float4*>(src);
-    const float4 q0 = q[0], q1 = q[1];
-    const float c2 = src->c[2];
-    t.a[0] = q0.x; t.a[1] = q0.y; t.a[2] = q0.z; t.b[0] = q0.w;
-    t.b[1] = q1.x; t.b[2] = q1.y; t.c[0] = q1.z; t.c[1] = q1.w;
-    t.c[2] = c2;
+    return t.minx <= t.maxx;
 }
 
-AWSM_DI bool edge_inside(float e, float a, float b) {
-    return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));   // top-left rule
+// Edge values at a sample given in 1/256-pixel units (pixel centre = px*256 + 128).
+struct EdgeVals { double E[3]; };
+AWSM_DI double sample_coord(int p_sub) { return (double)p_sub * 0.00390625; }    // exact
+AWSM_DI EdgeVals tri_edges_d(const TriSetup& t, double X, double Y) {
+    EdgeVals r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.E[i] = fma((double)t.a[i], X, fma((double)t.b[i], Y, t.c[i]));
+    return r;
+}
+AWSM_DI bool edge_inside(double e, float a, float b) {
+    return e > 0.0 || (e == 0.0 && (a > 0.0f || (a == 0.0f && b > 0.0f)));   // top-left rule
 }
 
-AWSM_DI void tri_edges_at(const TriSetup& t, float X, float Y, float& e0, float& e1, float& e2) {
-    e0 = (t.a[0] * X + t.b[0] * Y) + t.c[0];
-    e1 = (t.a[1] * X + t.b[1] * Y) + t.c[1];
-    e2 = (t.a[2] * X + t.b[2] * Y) + t.c[2];
-}
-AWSM_DI void tri_edges(const TriSetup& t, int px, int py, float& e0, float& e1, float& e2) {
-    tri_edges_at(t, (float)px + 0.5f, (float)py + 0.5f, e0, e1, e2);
-}
+// WebGPU's standard 4x sample pattern (GPUMultisampleState count = 4; the D3D standard pattern) in 1/256 pixel:
+// (0.375, 0.125) (0.875, 0.375) (0.125, 0.625) (0.625, 0.875).
+AWSM_DI int msaa4_x(int k) { return k == 0 ? 96 : (k == 1 ? 224 : (k == 2 ? 32 : 160)); }
+AWSM_DI int msaa4_y(int k) { return k == 0 ? 32 : (k == 1 ? 96 : (k == 2 ? 160 : 224)); }
 
-// WebGPU's standard 4x sample pattern (GPUMultisampleState count = 4; the D3D standard pattern), pixel-relative.
-// Exactly representable, so px + offset is exact in f32 for any frame size.
-AWSM_DI float msaa4_x(int k) { return k == 0 ? 0.375f : (k == 1 ? 0.875f : (k == 2 ? 0.125f : 0.625f)); }
-AWSM_DI float msaa4_y(int k) { return k == 0 ? 0.125f : (k == 1 ? 0.375f : (k == 2 ? 0.625f : 0.875f)); }
-
-// Coverage + depth at sample position (X, Y) in pixel units.  Returns the packed 64-bit key or ~0 if not covered.
-AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, float X, float Y, uint32_t rank) {
-    float e0, e1, e2;
-    tri_edges_at(t, X, Y, e0, e1, e2);
-    if (!edge_inside(e0, t.a[0], t.b[0]) || !edge_inside(e1, t.a[1], t.b[1]) || !edge_inside(e2, t.a[2], t.b[2]))
+// Coverage + depth at the sample (X, Y) (pixels, f64).  Returns the packed 64-bit key or ~0 if not covered.
+AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, double X, double Y, uint32_t rank) {
+    const EdgeVals ev = tri_edges_d(t, X, Y);
+    if (!edge_inside(ev.E[0], t.a[0], t.b[0]) || !edge_inside(ev.E[1], t.a[1], t.b[1]) || !edge_inside(ev.E[2], t.a[2], t.b[2]))
         return ~0ull;
-    float zn = ((e0 * t.z[0] + e1 * t.z[1]) + e2 * t.z[2]) * t.inv_det;
+    const float e0 = (float)ev.E[0], e1 = (float)ev.E[1], e2 = (float)ev.E[2];
+    float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];
     if (!(zn >= 0.0f && zn <= 1.0f)) return ~0ull;
     if (zn == 0.0f) zn = 0.0f;   // -0 -> +0 so the bits order as an unsigned integer
     // depth LessEqual + submission order: smaller depth wins, equal depth -> LATER primitive wins
     return ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
-}
-// Pixel centre (single-sampled targets).
-AWSM_DI unsigned long long tri_sample_key(const TriSetup& t, int px, int py, uint32_t rank) {
-    return tri_sample_key_at(t, (float)px + 0.5f, (float)py + 0.5f, rank);
 }
 
 // Conservative "tile can contain a covered sample" test: evaluates every edge at the tile corner that maximises it.
@@ -169,11 +184,11 @@ AWSM_DI unsigned long long tri_sample_key(const TriSetup& t, int px, int py, uin
 AWSM_DI bool tile_may_overlap(const TriSetup& t, int tx0, int ty0, int tx1, int ty1 /* pixel bounds, exclusive max */) {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        float X = t.a[i] > 0.0f ? (float)tx1 : (float)tx0;
-        float Y = t.b[i] > 0.0f ? (float)ty1 : (float)ty0;
-        float ax = t.a[i] * X, by = t.b[i] * Y;
-        float e = (ax + by) + t.c[i];
-        float slack = 4e-7f * ((fabsf(ax) + fabsf(by)) + fabsf(t.c[i]));   // > 3 ulp of the largest term
+        const double X = t.a[i] > 0.0f ? (double)tx1 : (double)tx0;
+        const double Y = t.b[i] > 0.0f ? (double)ty1 : (double)ty0;
+        const double ax = (double)t.a[i] * X, by = (double)t.b[i] * Y;
+        const double e = (ax + by) + t.c[i];
+        const double slack = 1e-15 * ((fabs(ax) + fabs(by)) + fabs(t.c[i]));   // > 3 ulp of the largest term (kind 1; kind 0 is exact)
         if (e < -slack) return false;
     }
     return true;

@@ -174,15 +174,14 @@ int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out) {
  *    functions, the top-left rule — is exact integer arithmetic (|values| < 2^49), as in a hardware rasteriser.  Exactness
  *    is what makes shared edges watertight and keeps small distant triangles from being lost to rounding.
  *  kind 1, triangles that touch w <= 0 (they cross the near plane; close to the camera, hence large on screen and well
- *    conditioned): homogeneous clip-less edge functions in f32, no geometric clipping. */
+ *    conditioned): homogeneous clip-less edge functions, no geometric clipping; coefficients in f32, evaluated per sample
+ *    with two fused multiply-adds in f64 (the same instruction sequence the exact kind uses on the device). */
 typedef struct {
     int kind;
     int64_t a[3], b[3], c[3];  /* kind 0: E_i(P) = a*Px + b*Py + c in 1/256-pixel units, sign-normalised (>= 0 inside), weight of vertex i */
-    float zq[3];               /* kind 0: (z_i / w_i) / |2*area| */
-    float iw[3];               /* kind 0: 1 / w_i (perspective correction of the attribute interpolation) */
-    float ha[3], hb[3], hc[3]; /* kind 1: e_i(X,Y) = (a*X + b*Y) + c in pixels */
-    float hz[3];               /* kind 1: clip z */
-    float inv_det;             /* kind 1 */
+    float ha[3], hb[3], hc[3]; /* kind 1: e_i(X,Y) = fma(a, X, fma(b, Y, c)) in f64, X/Y in pixels */
+    float zq[3];               /* kind 0: (z_i / w_i) / |2*area| ; kind 1: z_i / det */
+    float iw[3];               /* kind 0: 1 / w_i (perspective correction of the attribute interpolation) ; kind 1: 1 (e_i already is) */
     int minx, maxx, miny, maxy;  /* inclusive, conservative, clamped to the target rect */
     int valid;
 } TriSetup;
@@ -238,7 +237,10 @@ static void tri_setup(const float* v0, const float* v1, const float* v2, int cul
         for (int i = 0; i < 3; i++) { t->zq[i] = (v[i][2] * iw[i]) * inv_area; t->iw[i] = iw[i]; }
         /* pixels that can hold a sample strictly inside [min, max] of the snapped vertices */
         int64_t mnx = x[0] < x[1] ? x[0] : x[1], mxx = x[0] > x[1] ? x[0] : x[1], mny = y[0] < y[1] ? y[0] : y[1], mxy = y[0] > y[1] ? y[0] : y[1];
-        if (x[2] < mnx) mnx = x[2]; if (x[2] > mxx) mxx = x[2]; if (y[2] < mny) mny = y[2]; if (y[2] > mxy) mxy = y[2];
+        if (x[2] < mnx) mnx = x[2];
+        if (x[2] > mxx) mxx = x[2];
+        if (y[2] < mny) mny = y[2];
+        if (y[2] > mxy) mxy = y[2];
         const int64_t bx0 = mnx >> 8, bx1 = (mxx - 1) >> 8, by0 = mny >> 8, by1 = (mxy - 1) >> 8;      /* arithmetic shifts: floor */
         if (bx0 > minx) minx = (int)bx0;
         if (bx1 < maxx) maxx = (int)bx1;
@@ -262,8 +264,9 @@ static void tri_setup(const float* v0, const float* v1, const float* v2, int cul
         t->ha[0] = a0; t->hb[0] = b0; t->hc[0] = c0;
         t->ha[1] = a1; t->hb[1] = b1; t->hc[1] = c1;
         t->ha[2] = a2; t->hb[2] = b2; t->hc[2] = c2;
-        t->hz[0] = v0[2]; t->hz[1] = v1[2]; t->hz[2] = v2[2];
-        t->inv_det = 1.0f / det;
+        const float inv_det = 1.0f / det;
+        t->zq[0] = v0[2] * inv_det; t->zq[1] = v1[2] * inv_det; t->zq[2] = v2[2] * inv_det;
+        t->iw[0] = 1.0f; t->iw[1] = 1.0f; t->iw[2] = 1.0f;
     }
     if (minx > maxx || miny > maxy) return;
     t->minx = minx; t->maxx = maxx; t->miny = miny; t->maxy = maxy;
@@ -288,11 +291,12 @@ static inline int tri_edges_sample(const TriSetup* t, int px, int py, int ox, in
         }
         return inside;
     }
-    const float X = (float)px + (float)ox / 256.0f, Y = (float)py + (float)oy / 256.0f;     /* exact */
+    const double X = (double)(px * SUBPIX + ox) * (1.0 / SUBPIX), Y = (double)(py * SUBPIX + oy) * (1.0 / SUBPIX);     /* exact */
     int inside = 1;
     for (int i = 0; i < 3; i++) {
-        e[i] = (t->ha[i] * X + t->hb[i] * Y) + t->hc[i];
-        if (!(e[i] > 0.0f || (e[i] == 0.0f && (t->ha[i] > 0.0f || (t->ha[i] == 0.0f && t->hb[i] > 0.0f))))) inside = 0;
+        const double E = fma((double)t->ha[i], X, fma((double)t->hb[i], Y, (double)t->hc[i]));
+        if (!(E > 0.0 || (E == 0.0 && (t->ha[i] > 0.0f || (t->ha[i] == 0.0f && t->hb[i] > 0.0f))))) inside = 0;
+        e[i] = (float)E;
     }
     return inside;
 }
@@ -300,8 +304,7 @@ static inline int tri_edges_sample(const TriSetup* t, int px, int py, int ox, in
 static inline int tri_sample(const TriSetup* t, int px, int py, int ox, int oy, float* depth_out) {
     float e[3];
     if (!tri_edges_sample(t, px, py, ox, oy, e)) return 0;
-    float zn = t->kind == 0 ? (e[0] * t->zq[0] + e[1] * t->zq[1]) + e[2] * t->zq[2]
-                            : ((e[0] * t->hz[0] + e[1] * t->hz[1]) + e[2] * t->hz[2]) * t->inv_det;
+    float zn = (e[0] * t->zq[0] + e[1] * t->zq[1]) + e[2] * t->zq[2];
     if (!(zn >= 0.0f && zn <= 1.0f)) return 0;
     if (zn == 0.0f) zn = 0.0f;   /* canonicalise -0 so the bit pattern orders as an unsigned integer */
     *depth_out = zn;
@@ -414,7 +417,7 @@ int oracle_tri_bary_at(const float* v0, const float* v1, const float* v2, uint32
     if (!ts.valid) return 0;
     float e[3];
     (void)tri_edges_sample(&ts, px, py, 128, 128, e);
-    if (ts.kind == 0) { e[0] *= ts.iw[0]; e[1] *= ts.iw[1]; e[2] *= ts.iw[2]; }   /* screen-space weights -> perspective-correct */
+    e[0] *= ts.iw[0]; e[1] *= ts.iw[1]; e[2] *= ts.iw[2];   /* screen-space weights -> perspective-correct (kind 1: * 1) */
     const float inv = 1.0f / ((e[0] + e[1]) + e[2]);
     b_out[0] = e[0] * inv; b_out[1] = e[1] * inv; b_out[2] = e[2] * inv;
     return 1;
