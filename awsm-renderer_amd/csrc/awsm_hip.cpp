@@ -22,6 +22,8 @@ void awsm_launch_gen_mip_level(uint8_t* chain, uint32_t src_off, uint32_t dst_of
                                const uint32_t* kinds, hipStream_t s);
 void awsm_launch_pick(const DevScene* sc, const FrameDev* f, int x, int y, uint32_t* out, hipStream_t s);
 void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
+void awsm_launch_transform_forward(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
+void awsm_launch_forward(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s);
 void awsm_launch_bin_count(const FrameDev* f, hipStream_t s);
 void awsm_launch_bin_scan(const FrameDev* f, hipStream_t s);
@@ -40,10 +42,11 @@ struct DevBuf {
     size_t size = 0;
 };
 
-enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE, EV_COUNT };
+enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE, EV_FWD_BEGIN, EV_FWD, EV_COUNT };
 
 // Everything the geometry pass produces for one frame and the opaque pass consumes.
 struct FrameBufs {
+    DevBuf wpos;                           // transparent pass only
     DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
     DevBuf camera;                         // snapshot of the camera UBO taken by the geometry pass (overlap mode)
     uint32_t bin_capacity = 0;
@@ -87,6 +90,13 @@ struct AwsmHipCtx {
     hipEvent_t ev_geom_done[2] = {}, ev_shade_done[2] = {};
     bool shade_pending[2] = {false, false};
     FrameBufs fb[2];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
+    FrameBufs tr[2];             // the same for the transparent pass's own draws (vertices, setup records, bins); no visibility buffer
+    std::vector<DrawDev> tr_draws_host;
+    uint32_t tr_total_tris = 0, tr_n_blocks = 0;
+    bool transparent_done = false;
+    DevBuf comp16, comp32;       // composite image (after the transparent pass) + parity tap
+    void* bound_comp = nullptr;
+    size_t bound_comp_bytes = 0;
     int slot = 0;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
@@ -99,7 +109,7 @@ struct AwsmHipCtx {
     // pinned staging ring for buffer_write / small uploads
     uint8_t* stage = nullptr;
     size_t stage_cap = 0, stage_head = 0;
-    uint32_t* counters_host = nullptr;   // pinned, 8 u32
+    uint32_t* counters_host = nullptr;   // pinned, 16 u32: [0..8) geometry pass, [8..16) transparent pass
 
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid[EV_COUNT] = {};
@@ -323,20 +333,146 @@ int enqueue_opaque(AwsmHipCtx* c) {
     return AWSM_OK;
 }
 
+inline FrameBufs& TR(AwsmHipCtx* c) { return c->tr[c->slot]; }
+
+// The transparent pass's frame: its own draws / vertices / setup records / bins; the geometry pass's visibility keys for the depth
+// test; the opaque image as blit source and transmission background; the composite image as target.
+void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
+    fill_frame(c, f);
+    FrameBufs& t = TR(c);
+    f->n_draws = (uint32_t)c->tr_draws_host.size();
+    f->total_tris = c->tr_total_tris; f->total_verts = 3u * c->tr_total_tris;
+    f->bin_capacity = t.bin_capacity;
+    f->draws = (const DrawDev*)t.draws_dev.ptr;
+    f->draw_shade = (DrawShadeDev*)t.draw_shade.ptr;
+    f->clip = (float4*)t.clip.ptr; f->nrm = (float4*)t.nrm.ptr; f->tan = (float4*)t.tan.ptr; f->wpos = (float4*)t.wpos.ptr;
+    f->tri_info = (uint32_t*)t.tri_flags.ptr;
+    f->tri_rec = (TriRec*)t.tri_rec.ptr;
+    f->tile_count = (uint32_t*)t.tile_count.ptr; f->tile_offset = (uint32_t*)t.tile_offset.ptr;
+    f->tile_cursor = (uint32_t*)t.tile_cursor.ptr; f->bin_list = (uint32_t*)t.bin_list.ptr;
+    f->tile_order = (uint32_t*)t.tile_order.ptr;
+    f->big_list = (uint32_t*)t.big_list.ptr;
+    f->counters = (uint32_t*)t.counters.ptr;
+    f->opaque_rgba16f = f->out_rgba16f;
+    f->out_rgba16f = (uint16_t*)(c->bound_comp ? c->bound_comp : c->comp16.ptr);
+    f->out_rgba32f = (float*)c->comp32.ptr;
+    f->has_opaque = c->last_opaque.has_opaque;
+    f->mipmap = c->last_opaque.mipmap;
+}
+
+int enqueue_transparent(AwsmHipCtx* c) {
+    FrameDev f;
+    fill_frame_forward(c, &f);
+    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
+    int rc = sync_scene(c);
+    if (rc) return rc;
+    hipStream_t ss = shade_stream_of(c);          // in order after the opaque pass
+    if ((rc = record(c, EV_FWD_BEGIN, ss))) return rc;
+    const bool has_geometry = f.total_tris && n_tiles;
+    if (!has_geometry) {
+        HIPCHK(c, hipMemsetAsync(TR(c).counters.ptr, 0, 8 * sizeof(uint32_t), ss));
+        if (n_tiles) HIPCHK(c, hipMemsetAsync(TR(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), ss));
+    } else {
+        awsm_launch_transform_forward(c->scene_dev, &f, c->tr_n_blocks, ss);
+    }
+    if (n_tiles) {
+        if (f.total_tris) { awsm_launch_bin_count(&f, ss); awsm_launch_bin_big(&f, 0, ss); }
+        awsm_launch_bin_scan(&f, ss);
+        if (f.total_tris) { awsm_launch_bin_fill(&f, ss); awsm_launch_bin_big(&f, 1, ss); }
+        awsm_launch_forward(c->scene_dev, &f, ss);
+    }
+    if ((rc = record(c, EV_FWD, ss))) return rc;
+    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; }
+    HIPCHK(c, hipGetLastError());
+    return AWSM_OK;
+}
+
+int ensure_bin_capacity_of(AwsmHipCtx* c, FrameBufs& b, uint32_t entries) {
+    if (entries <= b.bin_capacity && b.bin_list.ptr) return AWSM_OK;
+    uint32_t cap = std::max(entries, b.bin_capacity + b.bin_capacity / 2);
+    int rc = dev_realloc(c, b.bin_list, (size_t)cap * 4, false);
+    if (rc) return rc;
+    b.bin_capacity = cap;
+    return AWSM_OK;
+}
+
+// API draws -> one DrawDev per (draw, instance) with the running triangle / block prefix sums; `data` = the vertex buffer the
+// draws index, `bytes_per_tri` the extent check per triangle (0 = the vertices are indexed: not checkable here).
+int build_draw_list(AwsmHipCtx* c, const char* pass, const AwsmDraw* draws, uint32_t n, AwsmBuf data, uint32_t bytes_per_tri,
+                    std::vector<DrawDev>& out, uint64_t* tris_out, uint64_t* blocks_out) {
+    out.clear();
+    uint64_t tris = 0, blocks = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const AwsmDraw& d = draws[i];
+        if (d.inst_count != 0) {   // instanced draw: inst_count mat4s at inst_off of the instance-transform buffer (instances.rs)
+            const DevBuf& ib = c->bufs[AWSM_BUF_INSTANCES];
+            if (!ib.ptr) return fail(c, AWSM_ERR_NOT_READY, "%s: draw %u: instanced, but the instance-transform buffer was never created", pass, i);
+            if ((d.inst_off & 15u) || (uint64_t)d.inst_off + 64ull * d.inst_count > ib.size)
+                return fail(c, AWSM_ERR_OUT_OF_RANGE, "%s: draw %u: %u instances at %u exceed the instance-transform buffer", pass, i, d.inst_count, d.inst_off);
+        }
+        if (d.vis_data_off & (bytes_per_tri ? 15u : 3u)) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "%s: draw %u: vertex data offset %u misaligned", pass, i, d.vis_data_off);
+        if ((uint64_t)d.vis_data_off + (uint64_t)bytes_per_tri * d.tri_count > c->bufs[data].size || (!bytes_per_tri && d.tri_count && (uint64_t)d.vis_data_off + 40 > c->bufs[data].size))
+            return fail(c, AWSM_ERR_OUT_OF_RANGE, "%s: draw %u: %u triangles at %u exceed the vertex buffer", pass, i, d.tri_count, d.vis_data_off);
+        if ((uint64_t)d.geom_meta_off + 40 > c->bufs[AWSM_BUF_GEOM_META].size || (d.geom_meta_off & 3u))
+            return fail(c, AWSM_ERR_OUT_OF_RANGE, "%s: draw %u: geometry meta offset %u out of range", pass, i, d.geom_meta_off);
+        if (d.tri_count == 0) continue;   // draw_indexed(0) draws nothing; keeps first_block strictly increasing
+        const uint32_t copies = d.inst_count ? d.inst_count : 1u;
+        for (uint32_t k = 0; k < copies; k++) {
+            DrawDev dd{};
+            dd.geom_meta_off = d.geom_meta_off; dd.vis_data_off = d.vis_data_off; dd.tri_count = d.tri_count; dd.flags = d.flags & 0x7Fu;
+            if (d.inst_count) { dd.flags |= kDrawInstanced; dd.inst_off = d.inst_off + 64u * k; }
+            dd.first_tri = (uint32_t)tris; dd.first_block = (uint32_t)blocks;
+            out.push_back(dd);
+            tris += d.tri_count;
+            blocks += (3ull * d.tri_count + 255) / 256;
+            if (tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "%s: more than 2^32/3 triangles in one pass", pass);
+            if (out.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "%s: more than 2^24 non-empty draws (instances included) in one pass", pass);
+        }
+    }
+    *tris_out = tris; *blocks_out = blocks;
+    return AWSM_OK;
+}
+
+// per-pass device state sized for `draws_host` / total_tris; uploads the draw list when it changed
+int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
+    int rc;
+    const size_t nd = std::max<size_t>(draws_host.size(), 1), nv = std::max<size_t>(3ull * total_tris, 1), nt = std::max<size_t>(total_tris, 1);
+    if ((rc = dev_reserve(c, b.draws_dev, nd * sizeof(DrawDev)))) return rc;
+    if ((rc = dev_reserve(c, b.draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
+    if ((rc = dev_reserve(c, b.clip, nv * 16))) return rc;
+    if ((rc = dev_reserve(c, b.nrm, nv * 16))) return rc;
+    if ((rc = dev_reserve(c, b.tan, nv * 16))) return rc;
+    if (forward && (rc = dev_reserve(c, b.wpos, nv * 16))) return rc;
+    if ((rc = dev_reserve(c, b.tri_flags, nt * 4))) return rc;
+    if ((rc = dev_reserve(c, b.big_list, nt * 4))) return rc;
+    if ((rc = dev_reserve(c, b.tri_rec, nt * kTriRecBytes))) return rc;
+    const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
+    const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
+    if ((rc = dev_reserve(c, b.tile_count, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, b.tile_offset, (n_tiles_full + 1) * 4))) return rc;
+    if ((rc = dev_reserve(c, b.tile_cursor, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, b.tile_order, n_tiles_full * 4))) return rc;
+    if ((rc = ensure_bin_capacity_of(c, b, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * total_tris + 65536u, 1u << 18)))) return rc;
+    // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
+    // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
+    const bool same_draws = b.draws_uploaded_valid && b.draws_uploaded_ptr == b.draws_dev.ptr && b.draws_uploaded.size() == draws_host.size() &&
+                            (draws_host.empty() || memcmp(b.draws_uploaded.data(), draws_host.data(), draws_host.size() * sizeof(DrawDev)) == 0);
+    if (!draws_host.empty() && !same_draws) {
+        b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true;
+        const size_t bytes = draws_host.size() * sizeof(DrawDev);
+        if (bytes <= (1u << 20)) { if ((rc = upload_small(c, b.draws_dev.ptr, draws_host.data(), bytes))) return rc; }
+        else { HIPCHK(c, hipMemcpyAsync(b.draws_dev.ptr, draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    }
+    return AWSM_OK;
+}
+
 uint32_t mip_levels_full(uint32_t w, uint32_t h) {   // calculate_mipmap_levels (renderer-core/src/texture/mipmap.rs:60-62)
     uint32_t m = std::max(w, h), n = 0;
     while (m > 1u) { m >>= 1; n++; }
     return n + 1u;
 }
 
-int ensure_bin_capacity(AwsmHipCtx* c, uint32_t entries) {
-    if (entries <= FB(c).bin_capacity && FB(c).bin_list.ptr) return AWSM_OK;
-    uint32_t cap = std::max(entries, FB(c).bin_capacity + FB(c).bin_capacity / 2);
-    int rc = dev_realloc(c, FB(c).bin_list, (size_t)cap * 4, false);
-    if (rc) return rc;
-    FB(c).bin_capacity = cap;
-    return AWSM_OK;
-}
+int ensure_bin_capacity(AwsmHipCtx* c, uint32_t entries) { return ensure_bin_capacity_of(c, FB(c), entries); }
 
 }  // namespace
 
@@ -372,7 +508,10 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
         if (hipMalloc(&c->fb[s].counters.ptr, 12 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words
         c->fb[s].counters.size = 12 * sizeof(uint32_t);
+        if (hipMalloc(&c->tr[s].counters.ptr, 8 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        c->tr[s].counters.size = 8 * sizeof(uint32_t);
     }
+
     if (c->overlap) {
         if (hipStreamCreateWithFlags(&c->shade_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
         for (int s = 0; s < 2; s++) {
@@ -381,7 +520,8 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             c->fb[s].camera.size = 512;
         }
     }
-    if (hipHostMalloc((void**)&c->counters_host, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    if (hipHostMalloc((void**)&c->counters_host, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    memset(c->counters_host, 0, 16 * sizeof(uint32_t));
     memset(&c->scene, 0, sizeof c->scene);
     // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
     c->scene.skybox_rgba[3] = 1.0f;
@@ -398,9 +538,10 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32);
-    for (FrameBufs& b : c->fb) {
-        fr(b.vis); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
+    fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32);
+    for (int k = 0; k < 4; k++) {
+        FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
+        fr(b.vis); fr(b.wpos); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
@@ -472,7 +613,7 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     c->width = width; c->height = height;
     c->y0 = c->y1 = 0;
     c->band_n = 1; c->band_r = 0; c->band_compact = 0;
-    c->geometry_done = c->opaque_done = false;
+    c->geometry_done = c->opaque_done = c->transparent_done = false;
     return AWSM_OK;
 }
 
@@ -619,67 +760,14 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     HIPCHK(c, hipSetDevice(c->device));
 
     if (c->overlap) c->slot ^= 1;            // the previous frame's opaque pass may still be reading the other slot
-    c->draws_host.clear(); c->draws_api.assign(draws, draws + n);
+    c->draws_api.assign(draws, draws + n);
     uint64_t tris = 0, blocks = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const AwsmDraw& d = draws[i];
-        if (d.inst_count != 0) {   // instanced draw: inst_count mat4s at inst_off of the instance-transform buffer (instances.rs)
-            const DevBuf& ib = c->bufs[AWSM_BUF_INSTANCES];
-            if (!ib.ptr) return fail(c, AWSM_ERR_NOT_READY, "draw %u: instanced, but the instance-transform buffer was never created", i);
-            if ((d.inst_off & 15u) || (uint64_t)d.inst_off + 64ull * d.inst_count > ib.size)
-                return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: %u instances at %u exceed the instance-transform buffer", i, d.inst_count, d.inst_off);
-        }
-        if (d.vis_data_off & 15u) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "draw %u: vis_data_off %u not 16-byte aligned", i, d.vis_data_off);
-        if ((uint64_t)d.vis_data_off + 168ull * d.tri_count > c->bufs[AWSM_BUF_VIS_GEOM_DATA].size)
-            return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: %u triangles at %u exceed the visibility-geometry buffer", i, d.tri_count, d.vis_data_off);
-        if ((uint64_t)d.geom_meta_off + 40 > c->bufs[AWSM_BUF_GEOM_META].size || (d.geom_meta_off & 3u))
-            return fail(c, AWSM_ERR_OUT_OF_RANGE, "draw %u: geometry meta offset %u out of range", i, d.geom_meta_off);
-        if (d.tri_count == 0) continue;   // draw_indexed(0) draws nothing; keeps first_block strictly increasing
-        const uint32_t copies = d.inst_count ? d.inst_count : 1u;   // draw_indexed_with_instance_count(n, 0) draws nothing either, but the host never issues it
-        for (uint32_t k = 0; k < copies; k++) {
-            DrawDev dd{};
-            dd.geom_meta_off = d.geom_meta_off; dd.vis_data_off = d.vis_data_off; dd.tri_count = d.tri_count; dd.flags = d.flags & 0x7Fu;
-            if (d.inst_count) { dd.flags |= kDrawInstanced; dd.inst_off = d.inst_off + 64u * k; }
-            dd.first_tri = (uint32_t)tris; dd.first_block = (uint32_t)blocks;
-            c->draws_host.push_back(dd);
-            tris += d.tri_count;
-            blocks += (3ull * d.tri_count + 255) / 256;
-            if (tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^32/3 triangles in one pass");
-            if (c->draws_host.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "more than 2^24 non-empty draws (instances included) in one pass");
-        }
-    }
+    int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, c->draws_host, &tris, &blocks);
+    if (rc) return rc;
     c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
-
-    int rc;
-    const size_t nd = std::max<size_t>(c->draws_host.size(), 1);
-    if ((rc = dev_reserve(c, FB(c).draws_dev, nd * sizeof(DrawDev)))) return rc;
-    if ((rc = dev_reserve(c, FB(c).draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
-    if ((rc = dev_reserve(c, FB(c).clip, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, FB(c).nrm, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, FB(c).tan, std::max<size_t>(c->total_verts, 1) * 16))) return rc;
-    if ((rc = dev_reserve(c, FB(c).tri_flags, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
-    if ((rc = dev_reserve(c, FB(c).big_list, std::max<size_t>(c->total_tris, 1) * 4))) return rc;
-    if ((rc = dev_reserve(c, FB(c).tri_rec, std::max<size_t>(c->total_tris, 1) * kTriRecBytes))) return rc;
-    const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
-    const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
-    if ((rc = dev_reserve(c, FB(c).tile_count, n_tiles_full * 4))) return rc;
-    if ((rc = dev_reserve(c, FB(c).tile_offset, (n_tiles_full + 1) * 4))) return rc;
-    if ((rc = dev_reserve(c, FB(c).tile_cursor, n_tiles_full * 4))) return rc;
-    if ((rc = dev_reserve(c, FB(c).tile_order, n_tiles_full * 4))) return rc;
-    if ((rc = ensure_bin_capacity(c, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * c->total_tris + 65536u, 1u << 18)))) return rc;
-    // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
-    // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
-    const bool same_draws = FB(c).draws_uploaded_valid && FB(c).draws_uploaded_ptr == FB(c).draws_dev.ptr &&
-                            FB(c).draws_uploaded.size() == c->draws_host.size() &&
-                            (c->draws_host.empty() || memcmp(FB(c).draws_uploaded.data(), c->draws_host.data(), c->draws_host.size() * sizeof(DrawDev)) == 0);
-    if (!c->draws_host.empty() && !same_draws) {
-        FB(c).draws_uploaded = c->draws_host; FB(c).draws_uploaded_ptr = FB(c).draws_dev.ptr; FB(c).draws_uploaded_valid = true;
-        const size_t bytes = c->draws_host.size() * sizeof(DrawDev);
-        if (bytes <= (1u << 20)) { if ((rc = upload_small(c, FB(c).draws_dev.ptr, c->draws_host.data(), bytes))) return rc; }
-        else { HIPCHK(c, hipMemcpyAsync(FB(c).draws_dev.ptr, c->draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-    }
+    if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
     if ((rc = enqueue_geometry(c))) return rc;
-    c->geometry_done = true; c->opaque_done = false;
+    c->geometry_done = true; c->opaque_done = false; c->transparent_done = false;
     return AWSM_OK;
 }
 
@@ -698,7 +786,37 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
     c->last_opaque = *p;
     int rc = enqueue_opaque(c);
     if (rc) return rc;
-    c->opaque_done = true;
+    c->opaque_done = true; c->transparent_done = false;
+    return AWSM_OK;
+}
+
+int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
+    if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->geometry_done || !c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass needs the geometry and opaque passes of the same frame first");
+    if (c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height)))
+        return fail(c, AWSM_ERR_UNSUPPORTED, "transparent_pass on a sharded context (screen-space transmission reads the whole opaque image)");
+    static const AwsmBuf need[] = {AWSM_BUF_TRANSFORMS, AWSM_BUF_CAMERA, AWSM_BUF_GEOM_META, AWSM_BUF_MATERIAL_META, AWSM_BUF_MATERIALS, AWSM_BUF_ATTR_INDEX,
+                                   AWSM_BUF_ATTR_DATA, AWSM_BUF_TEXTURE_TRANSFORMS, AWSM_BUF_LIGHTS_INFO, AWSM_BUF_LIGHTS, AWSM_BUF_TRANSPARENCY_GEOM_DATA};
+    if (n) {
+        for (AwsmBuf b : need) if (!c->bufs[b].ptr) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass: buffer %d missing", (int)b);
+        if (!c->lut.ptr) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass: no BRDF LUT (env_upload or brdf_lut_generate)");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t tris = 0, blocks = 0;
+    int rc = build_draw_list(c, "transparent_pass", draws, n, AWSM_BUF_TRANSPARENCY_GEOM_DATA, 0u, c->tr_draws_host, &tris, &blocks);
+    if (rc) return rc;
+    c->tr_total_tris = (uint32_t)tris; c->tr_n_blocks = (uint32_t)blocks;
+    const size_t px = (size_t)c->width * c->height;
+    if (!c->bound_comp && (rc = dev_reserve(c, c->comp16, px * 8))) return rc;
+    if (c->bound_comp && c->bound_comp_bytes < px * 8) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "transparent_pass: bound composite holds %zu bytes, the frame needs %zu", c->bound_comp_bytes, px * 8);
+    if ((c->flags & AWSM_CFG_PARITY_TAP) && (rc = dev_reserve(c, c->comp32, px * 16))) return rc;
+    if ((rc = reserve_pass_buffers(c, TR(c), c->tr_draws_host, c->tr_total_tris, true))) return rc;
+    if (c->overlap) {   // the draw-list upload went to the caller's stream; the pass runs on the shade stream
+        HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->shade_stream, c->ev_geom_done[c->slot], 0));
+    }
+    if ((rc = enqueue_transparent(c))) return rc;
+    c->transparent_done = true;
     return AWSM_OK;
 }
 
@@ -722,15 +840,22 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->shade_stream) { HIPCHK(c, hipStreamSynchronize(c->shade_stream)); c->shade_pending[0] = c->shade_pending[1] = false; }
-        if (!c->geometry_done || c->counters_host[2] == 0 || attempt >= 4) break;
-        // (triangle, tile) list overflowed: grow to the measured need and replay the frame
-        int rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024);
-        if (rc) return rc;
+        memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
+        if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
+        if ((!geom_over && !fwd_over) || attempt >= 4) break;
+        // a (triangle, tile) list overflowed: grow to the measured need and replay from the pass that lost entries
+        int rc;
         c->overflow_retries++;
-        if ((rc = enqueue_geometry(c))) return rc;
-        if (c->opaque_done && (rc = enqueue_opaque(c))) return rc;
+        if (geom_over) {
+            if ((rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024))) return rc;
+            if ((rc = enqueue_geometry(c))) return rc;
+            if (c->opaque_done && (rc = enqueue_opaque(c))) return rc;
+        }
+        if (fwd_over && (rc = ensure_bin_capacity_of(c, TR(c), c->counters_host[9] + c->counters_host[9] / 4 + 1024))) return rc;
+        if (c->transparent_done && (rc = enqueue_transparent(c))) return rc;
     }
-    if (c->geometry_done && c->counters_host[2] != 0) return fail(c, AWSM_ERR_DEVICE, "bin list overflow persisted after retries");
+    if ((c->geometry_done && c->counters_host[2] != 0) || (c->transparent_done && c->counters_host[10] != 0)) return fail(c, AWSM_ERR_DEVICE, "bin list overflow persisted after retries");
     if (out) {
         memset(out, 0, sizeof *out);
         auto ms = [&](int a, int b) { float t = 0.0f; if (c->ev_valid[a] && c->ev_valid[b] && hipEventElapsedTime(&t, c->ev[a], c->ev[b]) == hipSuccess) return t; return 0.0f; };
@@ -740,7 +865,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             out->ms_raster = ms(EV_BIN, EV_RASTER);
         }
         if (c->opaque_done) out->ms_shade = ms(EV_SHADE_BEGIN, EV_SHADE);
-        out->ms_total = (c->geometry_done ? ms(EV_START, EV_RASTER) : 0.0f) + out->ms_shade;   // the two passes may run on different streams
+        if (c->transparent_done) { out->ms_forward = ms(EV_FWD_BEGIN, EV_FWD); out->forward_triangles = c->tr_total_tris; }
+        out->ms_total = (c->geometry_done ? ms(EV_START, EV_RASTER) : 0.0f) + out->ms_shade + out->ms_forward;   // the two passes may run on different streams
         out->triangles_in = c->total_tris;
         out->triangles_binned = c->counters_host[0];
         out->bin_entries = c->counters_host[1];
@@ -830,6 +956,49 @@ int awsm_hip_read_opaque_f32(AwsmHipCtx* c, float* out) {
     HIPCHK(c, hipSetDevice(c->device));
     { int rcs = sync_all(c); if (rcs) return rcs; }
     HIPCHK(c, hipMemcpy(out, c->out32.ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_bind_composite(AwsmHipCtx* c, void* device_ptr, size_t bytes) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (device_ptr && bytes == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_composite: zero-sized image");
+    c->bound_comp = device_ptr; c->bound_comp_bytes = bytes;
+    return AWSM_OK;
+}
+
+int awsm_hip_read_composite(AwsmHipCtx* c, uint16_t* out) {
+    if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->transparent_done) return fail(c, AWSM_ERR_NOT_READY, "read_composite before transparent_pass");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    HIPCHK(c, hipMemcpy(out, c->bound_comp ? c->bound_comp : c->comp16.ptr, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_read_composite_f32(AwsmHipCtx* c, float* out) {
+    if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->transparent_done || !c->comp32.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_composite_f32 needs AWSM_CFG_PARITY_TAP and a transparent_pass");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    HIPCHK(c, hipMemcpy(out, c->comp32.ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_read_transformed_forward(AwsmHipCtx* c, float* clip_out, float* nt_out, float* wpos_out, uint32_t max_vertices) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->transparent_done) return fail(c, AWSM_ERR_NOT_READY, "read_transformed_forward before transparent_pass");
+    const uint32_t n = std::min(max_vertices, 3u * c->tr_total_tris);
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    if (n == 0) return AWSM_OK;
+    if (clip_out) HIPCHK(c, hipMemcpy(clip_out, TR(c).clip.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (wpos_out) HIPCHK(c, hipMemcpy(wpos_out, TR(c).wpos.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (nt_out) {
+        std::vector<float> nn((size_t)n * 4), tt((size_t)n * 4);
+        HIPCHK(c, hipMemcpy(nn.data(), TR(c).nrm.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tt.data(), TR(c).tan.ptr, (size_t)n * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) { memcpy(nt_out + i * 8, &nn[i * 4], 16); memcpy(nt_out + i * 8 + 4, &tt[i * 4], 16); }
+    }
     return AWSM_OK;
 }
 

@@ -178,4 +178,9 @@ AWSM_DI TBN unpack_normal_tangent(f4 rgba) {  // math.wgsl:104-116
 AWSM_DI float interp3_strict(float b0, float b1, float b2, float x0, float x1, float x2) { return (b0 * x0 + b1 * x1) + b2 * x2; }
 AWSM_DI float affine2_strict(float a, float b, float c, float x, float y) { return (a * x + b * y) + c; }
 
+// Blend of the transparent pass into its RGBA16F target (material_transparent/pipeline.rs:96-110: One / OneMinusSrcAlpha,
+// colour and alpha): the stored f16 value is read back, the blend is f32 without contraction, the store rounds to f16.
+AWSM_DI float blend_over_f16(float src, float dst, float one_minus_a) { return round_f16(src + dst * one_minus_a); }
+AWSM_DI float resolve4_f16(float s0, float s1, float s2, float s3) { return round_f16((((s0 + s1) + s2) + s3) * 0.25f); }
+
 }  // namespace awsm

@@ -37,7 +37,7 @@ struct DrawShadeDev {
     uint32_t stride_words;        // attribute stride / 4
     uint32_t uv_sets_index;
     uint32_t is_hud;
-    uint32_t pad;
+    uint32_t color_sets;          // COLOR_n sets in the mesh's vertex attributes (transparent pass)
 };
 
 constexpr int kMaxMipLevels = 16;
@@ -85,6 +85,7 @@ struct FrameDev {
     float4* clip;                 // total_verts
     float4* nrm;                  // total_verts  (world normal xyz, 0)
     float4* tan;                  // total_verts  (world tangent xyz, handedness)
+    float4* wpos;                 // total_verts  (world position xyz, 1): transparent pass only, else null
     TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)
     uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..31)
     // binning
@@ -101,6 +102,7 @@ struct FrameDev {
     float* out_rgba32f;           // optional parity tap (may be null)
     float4* msaa_color0;          // MSAA: width*height, f32 colour of sample 0 for the pixels in msaa_edges
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
+    const uint16_t* opaque_rgba16f;   // transparent pass: the opaque pass's image (blit source and transmission background); out_rgba16f/32f = composite
 };
 
 }  // namespace awsm

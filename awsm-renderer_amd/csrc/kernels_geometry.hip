@@ -27,8 +27,12 @@ struct GeomMetaDev {
 // k_deform_transform: one thread per exploded vertex, 256 vertices per workgroup.  The 56-byte vertex
 // records of a workgroup are one contiguous 14 KB run: staged through LDS with 16-byte coalesced loads.
 // ------------------------------------------------------------------------------------------------
+// FWD = the transparent pass's vert_main (material_transparent_wgsl/vertex.wgsl:40-72): an indexed draw of the mesh's 40-byte
+// vertices (AWSM_BUF_TRANSPARENCY_GEOM_DATA at draw.vis_data_off) through the custom-attribute index buffer
+// (meshes/mesh.rs:129-200); one thread per triangle corner, which also leaves the world position for the fragment stage.
+template <bool FWD>
 __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[256 * 14];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[FWD ? 4 : 256 * 14];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     {   // per-frame clears folded into the first kernel of the frame (saves three memset launches per frame)
@@ -46,28 +50,38 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     const uint32_t local0 = (b - d.first_block) * 256u;
     const uint32_t count = min(256u, nverts - local0);
 
-    const uint8_t* src = sc->buf[AWSM_BUF_VIS_GEOM_DATA] + (size_t)d.vis_data_off + (size_t)local0 * 56u;
-    const uint32_t bytes = count * 56u;
-    const uint32_t n16 = bytes >> 4;
-    const uint4* src16 = reinterpret_cast<const uint4*>(src);
-    uint4* lds16 = reinterpret_cast<uint4*>(lds_vtx);
-    for (uint32_t i = tid; i < n16; i += 256u) lds16[i] = src16[i];
-    const uint32_t tail0 = n16 << 2;          // remaining dwords (0 or 2)
-    if (tid < (bytes >> 2) - tail0) lds_vtx[tail0 + tid] = reinterpret_cast<const uint32_t*>(src)[tail0 + tid];
-    __syncthreads();
-    if (tid >= count) return;
-
     const uint32_t* gmp = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + d.geom_meta_off);
     GeomMetaDev gm;
     gm.morph_len = gmp[2]; gm.morph_weights_off = gmp[3]; gm.morph_values_off = gmp[4];
     gm.skin_sets = gmp[5]; gm.skin_matrices_off = gmp[6]; gm.skin_index_weights_off = gmp[7];
     gm.transform_off = gmp[8];
 
-    const uint32_t* v = lds_vtx + tid * 14u;
-    f3 pos = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])};
-    f3 normal = {__uint_as_float(v[6]), __uint_as_float(v[7]), __uint_as_float(v[8])};
-    f4 tangent = {__uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]), __uint_as_float(v[12])};
-    const uint32_t vertex_index = v[13];    // original_vertex_index
+    f3 pos, normal; f4 tangent; uint32_t vertex_index;
+    if (!FWD) {
+        const uint8_t* src = sc->buf[AWSM_BUF_VIS_GEOM_DATA] + (size_t)d.vis_data_off + (size_t)local0 * 56u;
+        const uint32_t bytes = count * 56u;
+        const uint32_t n16 = bytes >> 4;
+        const uint4* src16 = reinterpret_cast<const uint4*>(src);
+        uint4* lds16 = reinterpret_cast<uint4*>(lds_vtx);
+        for (uint32_t i = tid; i < n16; i += 256u) lds16[i] = src16[i];
+        const uint32_t tail0 = n16 << 2;          // remaining dwords (0 or 2)
+        if (tid < (bytes >> 2) - tail0) lds_vtx[tail0 + tid] = reinterpret_cast<const uint32_t*>(src)[tail0 + tid];
+        __syncthreads();
+        if (tid >= count) return;
+        const uint32_t* v = lds_vtx + tid * 14u;
+        pos = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])};
+        normal = {__uint_as_float(v[6]), __uint_as_float(v[7]), __uint_as_float(v[8])};
+        tangent = {__uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]), __uint_as_float(v[12])};
+        vertex_index = v[13];    // original_vertex_index
+    } else {
+        if (tid >= count) return;
+        const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(gmp[9] / 256u) * 256u);
+        vertex_index = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX])[mm[9] / 4u + local0 + tid];   // @builtin(vertex_index) of an indexed draw
+        const float* v = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TRANSPARENCY_GEOM_DATA] + (size_t)d.vis_data_off + (size_t)vertex_index * 40u);
+        pos = {v[0], v[1], v[2]};
+        normal = {v[3], v[4], v[5]};
+        tangent = {v[6], v[7], v[8], v[9]};
+    }
 
     if (gm.morph_len != 0u) {               // morph.wgsl: weights at [off/4 + 1 + i]
         const float* mw = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_MORPH_WEIGHTS]);
@@ -158,6 +172,7 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     f.clip[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
     f.nrm[gv] = make_float4(world_normal.x, world_normal.y, world_normal.z, 0.0f);
     f.tan[gv] = make_float4(tangent_ortho.x, tangent_ortho.y, tangent_ortho.z, tangent.w);
+    if (FWD) f.wpos[gv] = make_float4(world_pos.x, world_pos.y, world_pos.z, 1.0f);
     if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | (d.flags << 24);
 }
 
@@ -597,7 +612,10 @@ extern "C" void awsm_launch_upload_words(void* dst, const void* src_pinned, uint
 
 // ---- launch wrappers (called from awsm_hip.cpp) ----
 extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
-    if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform, dim3(n_blocks), dim3(256), 0, s, sc, *f);
+    if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform<false>, dim3(n_blocks), dim3(256), 0, s, sc, *f);
+}
+extern "C" void awsm_launch_transform_forward(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
+    if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform<true>, dim3(n_blocks), dim3(256), 0, s, sc, *f);
 }
 extern "C" void awsm_launch_bin_count(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;

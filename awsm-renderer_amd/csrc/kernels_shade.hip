@@ -467,7 +467,7 @@ AWSM_DI f3 brdf_direct(const PbrColor& c, const Surface& sf, f3 light_dir, f3 ra
 }
 
 // brdf.wgsl:389-576 (brdf_ibl -> brdf_ibl_with_transmission); the three cubes are uniform colours
-AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf) {
+AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf, f3 transmission_background) {
     const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
     const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
     const float n_dot_v = sf.n_dot_v_ibl;
@@ -479,7 +479,7 @@ AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf) {
         f3 attenuation = splat3(1.0f);
         if (should_apply_volume_attenuation(c.volume_thickness, c.volume_attenuation_distance, c.volume_attenuation_color))
             attenuation = volume_attenuation(c.volume_thickness, c.volume_attenuation_color, c.volume_attenuation_distance);
-        const f3 transmission_btdf = (prefiltered * c.base) * attenuation;   // brdf.wgsl:531-561, uniform cube
+        const f3 transmission_btdf = (transmission_background * c.base) * attenuation;   // brdf.wgsl:531-561 (opaque pass: the uniform cube)
         base_layer = mix3(base_layer, transmission_btdf, effective_transmission);
     }
     const float k_d = (1.0f - F_view_max) * (1.0f - sf.metallic);
@@ -506,7 +506,7 @@ AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf) {
 }
 
 // lights.wgsl:70-152
-AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_camera, f3 world_position, uint32_t n_lights) {
+AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_camera, f3 world_position, uint32_t n_lights, f3 transmission_background) {
     Surface sf;
     sf.n = fm::fsafe_normalize(mc.normal);
     sf.v = fm::fsafe_normalize(surface_to_camera);
@@ -531,7 +531,7 @@ AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_
     sf.has_sheen = mc.sheen_color.x > 0.0f || mc.sheen_color.y > 0.0f || mc.sheen_color.z > 0.0f;
     sf.has_clearcoat = mc.clearcoat > 0.0f;
 
-    f3 color = brdf_ibl(sc, mc, sf);
+    f3 color = brdf_ibl(sc, mc, sf, transmission_background);
     const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
     for (uint32_t i = 0; i < n_lights; i++) {
         const float4 pos_range = lights[i * 4 + 0], dir_inner = lights[i * 4 + 1], color_intensity = lights[i * 4 + 2], kind_outer = lights[i * 4 + 3];
@@ -584,64 +584,76 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
     o.uv_sets_index = mm[12];
     o.is_hud = mm[16];
-    o.pad = 0u;
+    o.color_sets = mm[14];
     f.draw_shade[d] = o;
 }
 
-// ------------------------------------------------------------------------------------------------
-// shade_surface: the shading of one visibility sample — compute.wgsl:171-299 for the main sample,
-// material_shading.wgsl:69-168 (msaa_process_sample) for the samples of an edge pixel.  `g` is the G-buffer texel of
-// (triangle `rank`, pixel), `depth_sample` the depth the standard coordinates are built from (always sample 0's,
-// standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug view, 2 hud mesh (only reported when check_hud).
-// ------------------------------------------------------------------------------------------------
-struct SurfaceOut { f4 color; uint32_t kind; };
-template <bool GRAD>
-AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev& f, uint32_t rank, int cx, int cy, float depth_sample,
-                                 const GBufferTexel& g, bool check_hud) {
+// fragment.wgsl:27-186 (transparent pass): the opaque image behind a transmissive surface, refracted through the volume
+// (KHR_materials_volume) and blurred by roughness with up to three rings of eight taps (transmission_blur_rings = 3,
+// material_transparent/shader/template.rs:170).  Outside the screen: the (uniform) prefiltered environment.
+AWSM_DI f3 opaque_texel(const FrameDev& f, int x, int y) {
+    x = min(max(x, 0), (int)f.width - 1); y = min(max(y, 0), (int)f.height - 1);
+    const uint2 h = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[(size_t)y * f.width + (size_t)x];
+    return {f16_bits_to_f32((unsigned short)(h.x & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.x >> 16)), f16_bits_to_f32((unsigned short)(h.y & 0xFFFFu))};
+}
+__device__ __attribute__((noinline)) f3 sample_transmission_background(const DevScene* sc, const FrameDev& f, float frag_x, float frag_y, f3 world_position, f3 normal,
+                                                                        f3 view_dir, float ior, float roughness, float thickness) {
+    const float Wf = (float)f.width, Hf = (float)f.height;
+    f2 screen_uv = {frag_x / Wf, frag_y / Hf};
+    const float ior_val = ior < 1.0f ? 1.5f : ior;
+    if (thickness > 0.0f && ior_val != 1.0f) {
+        // brdf.wgsl:30-47 refract_direction
+        const float eta = 1.0f / ior_val;
+        const float cos_i = -fm::fdot(normal, view_dir);
+        const float k = 1.0f - eta * eta * (1.0f - cos_i * cos_i);
+        f3 refracted = {0.0f, 0.0f, 0.0f};
+        if (!(k < 0.0f)) refracted = view_dir * eta + normal * (eta * cos_i - sqrtf(k));
+        if (fm::fdot(refracted, refracted) > 1e-6f) {
+            const f3 exit = world_position + normalize(refracted) * thickness;
+            const m4 view_proj = load_m4(reinterpret_cast<const float*>(f.camera + 128));
+            const f4 clip_pos = mul(view_proj, {exit.x, exit.y, exit.z, 1.0f});
+            screen_uv = {(clip_pos.x / clip_pos.w + 1.0f) * 0.5f, (1.0f - clip_pos.y / clip_pos.w) * 0.5f};
+        }
+    }
+    if (!(screen_uv.x >= 0.0f && screen_uv.x <= 1.0f && screen_uv.y >= 0.0f && screen_uv.y <= 1.0f))
+        return {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
+    const float sx = screen_uv.x * Wf, sy = screen_uv.y * Hf;
+    const int tx = (int)sx, ty = (int)sy;
+    const float blur_roughness = roughness * clampf(ior * 2.0f - 2.0f, 0.0f, 1.0f);
+    if (blur_roughness > 0.05f) {
+        const float target_mip = __builtin_amdgcn_logf(Wf) * blur_roughness;
+        const float blur_radius = __builtin_amdgcn_exp2f(clampf(target_mip, 0.0f, 8.0f));
+        const float sigma = blur_radius * 0.5f, sigma_sq_2 = 2.0f * sigma * sigma;
+        f3 sum = opaque_texel(f, tx, ty);
+        float wsum = 1.0f;
+        for (int k = 0; k < 3; k++) {
+            const float r = blur_radius * (k == 0 ? 0.33f : (k == 1 ? 0.67f : 1.0f));
+            const float w = __expf(-(r * r) / sigma_sq_2);
+            for (int i = 0; i < 8; i++) {
+                const float ox = (i == 0 ? 1.0f : i == 1 ? 0.707f : i == 2 ? 0.0f : i == 3 ? -0.707f : i == 4 ? -1.0f : i == 5 ? -0.707f : i == 6 ? 0.0f : 0.707f);
+                const float oy = (i == 0 ? 0.0f : i == 1 ? 0.707f : i == 2 ? 1.0f : i == 3 ? 0.707f : i == 4 ? 0.0f : i == 5 ? -0.707f : i == 6 ? -1.0f : -0.707f);
+                const float fx = sx + ox * r, fy = sy + oy * r;
+                const int cx = (int)fx, cy = (int)fy;           // vec2<i32>(): truncation toward zero
+                if (cx >= 0 && cx <= (int)f.width - 1 && cy >= 0 && cy <= (int)f.height - 1) { sum = sum + opaque_texel(f, cx, cy) * w; wsum += w; }
+            }
+        }
+        return sum * fm::rcp(wsum);
+    }
+    return opaque_texel(f, tx, ty);
+}
+
+// The material half of the shading, shared by the opaque pass (FWD = false: compute.wgsl:212-299, material_color_calc.wgsl of
+// material_opaque) and the transparent pass (FWD = true: fragment.wgsl:217-281, material_color_calc.wgsl of
+// material_transparent): same textures, factors and lighting; they differ in the alpha rules, the vertex-colour rule and
+// where the transmission background comes from.  out.color.w = alpha.
+struct SurfaceOut { f4 color; uint32_t kind; bool discard; };
+template <bool GRAD, bool FWD>
+AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TBN& tbn, f3 world_position,
+                                  f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y) {
     SurfaceOut out;
     out.color = {0.0f, 0.0f, 0.0f, 0.0f};
-    out.kind = 0u;
-    const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
-    const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, is_hud
-    const uint32_t triangle_index = rank - ds0.x;
-    if (check_hud && ds1.z == 1u) { out.kind = 2u; return out; }   // is_hud (compute.wgsl:176-179); msaa_process_sample has no such test
-    const uint32_t material_word = ds0.y;
-    const uint32_t attr_indices_off = ds0.z, attr_data_off = ds0.w, stride = ds1.x, uv_sets_index = ds1.y;
-
-    // ---- compute.wgsl:182-211 ----
-    Attr a;
-    a.sc = sc;
-    a.ad = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_ATTR_DATA]);
-    a.bary = {g.bx, g.by, (1.0f - g.bx) - g.by};
-    a.uv_sets_index = uv_sets_index;
-    const uint32_t* attr_idx = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + attr_indices_off + triangle_index * 3u;
-    a.v0 = attr_data_off + attr_idx[0] * stride;
-    a.v1 = attr_data_off + attr_idx[1] * stride;
-    a.v2 = attr_data_off + attr_idx[2] * stride;
-    a.has_uv0 = false; a.uv0 = {0.0f, 0.0f};
-    a.bary_derivs = g.bary_derivs; a.duv0_dx = {0.0f, 0.0f}; a.duv0_dy = {0.0f, 0.0f};
-
-    // ---- standard.wgsl:11-62 ----
-    const uint8_t* cam = f.camera;
-    const m4 inv_proj = load_m4(reinterpret_cast<const float*>(cam + 256));
-    const m4 inv_view = load_m4(reinterpret_cast<const float*>(cam + 320));
-    const float proj33 = *reinterpret_cast<const float*>(cam + 64 + 60);
-    const float* cam_pos = reinterpret_cast<const float*>(cam + 384);
-    const f2 uv = {((float)cx + 0.5f) * fm::rcp((float)f.width), ((float)cy + 0.5f) * fm::rcp((float)f.height)};
-    const f4 view_h = fm::fmul(inv_proj, {uv.x * 2.0f - 1.0f, 1.0f - uv.y * 2.0f, depth_sample, 1.0f});
-    const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
-    const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
-    const f3 world_position = {wp.x, wp.y, wp.z};
-    f3 surface_to_camera;
-    if (proj33 > 0.9f) {
-        surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
-    } else {
-        const f3 to_camera = mk3(cam_pos[0], cam_pos[1], cam_pos[2]) - world_position;
-        surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
-    }
-    const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
+    out.kind = 0u; out.discard = false;
     const uint32_t n_lights = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]);
-
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
     const uint32_t shader_id = M[material_word];
     const uint32_t b = material_word + 1u;
@@ -651,12 +663,18 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
         f3 em = {mf(M, b + 16), mf(M, b + 17), mf(M, b + 18)};
         if (base_tex.exists) { const f4 s = sample_tex<GRAD>(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
         if (em_tex.exists) { const f4 s = sample_tex<GRAD>(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
-        out.color = {base.x + em.x, base.y + em.y, base.z + em.z, 1.0f};
+        float alpha = 1.0f;
+        if (FWD) {            // transparent material_color_calc.wgsl:344-372: alpha kept; ALPHA_MODE_MASK discards or forces 1
+            if (M[b + 0] == 1u) { if (base.w < mf(M, b + 1)) { out.discard = true; return out; } base.w = 1.0f; }
+            alpha = base.w;
+        }
+        out.color = {base.x + em.x, base.y + em.y, base.z + em.z, alpha};
         return out;
     }
 
     // ---- pbr_material.wgsl:110-216 + material_color_calc.wgsl:25-265 ----
     PbrColor c;
+    float base_alpha = 1.0f;
     const uint32_t debug_bitmask = M[b + 38];
     const uint32_t fi = b + 39u;
     const uint32_t idx_vertex_color = abs_index(b, M[fi + 0]), idx_emissive_strength = abs_index(b, M[fi + 1]);
@@ -673,8 +691,19 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     {
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
         if (tx_base.exists) { const f4 s = sample_tex<GRAD>(a, tx_base); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
-        base.w = 1.0f;
-        if (idx_vertex_color != 0u) { const f4 vc = vertex_color(a, M[idx_vertex_color]); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
+        if (!FWD) {
+            base.w = 1.0f;
+            if (idx_vertex_color != 0u) { const f4 vc = vertex_color(a, M[idx_vertex_color]); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
+        } else {
+            // transparent material_color_calc.wgsl:38-52: a mesh with colour sets always multiplies (set 0 unless the material names
+            // one; a set the mesh lacks reads as 1); alpha is kept; ALPHA_MODE_MASK discards below the cutoff, else alpha = 1
+            if (color_sets != 0u) {
+                const uint32_t set_index = idx_vertex_color != 0u ? M[idx_vertex_color] : 0u;
+                if (set_index < color_sets) { const f4 vc = vertex_color(a, set_index); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
+            }
+            if (M[b + 0] == 1u) { if (base.w < mf(M, b + 1)) { out.discard = true; return out; } base.w = 1.0f; }
+            base_alpha = base.w;
+        }
         c.base = {base.x, base.y, base.z};
     }
     c.mr = {mf(M, b + 16), mf(M, b + 17)};
@@ -741,13 +770,274 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
         else if (debug_bitmask & 8u) dc = splat3(c.occlusion);
         else if (debug_bitmask & 16u) dc = c.emissive;
         else if (debug_bitmask & 32u) dc = c.specular_color * c.specular;
-        out.color = {dc.x, dc.y, dc.z, 1.0f};
+        out.color = {dc.x, dc.y, dc.z, base_alpha};
         out.kind = 1u;
         return out;
     }
-    const f3 color = apply_lighting(sc, c, surface_to_camera, world_position, n_lights);
-    out.color = {color.x, color.y, color.z, 1.0f};
+    f3 background = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};   // opaque pass: IBL only (brdf.wgsl:531-561)
+    if (FWD) {     // fragment.wgsl:245-270: screen-space transmission from the opaque image
+        const float metallic = clampf(c.mr.x, 0.0f, 1.0f);
+        if (c.transmission * (1.0f - metallic) > 0.0f)
+            background = sample_transmission_background(sc, f, frag_x, frag_y, world_position, c.normal, -surface_to_camera, c.ior,
+                                                        fmaxf(clampf(c.mr.y, 0.0f, 1.0f), 0.04f), c.volume_thickness);
+    }
+    const f3 color = apply_lighting(sc, c, surface_to_camera, world_position, n_lights, background);
+    out.color = {color.x, color.y, color.z, base_alpha};
     return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shade_surface: the shading of one visibility sample — compute.wgsl:171-299 for the main sample,
+// material_shading.wgsl:69-168 (msaa_process_sample) for the samples of an edge pixel.  `g` is the G-buffer texel of
+// (triangle `rank`, pixel), `depth_sample` the depth the standard coordinates are built from (always sample 0's,
+// standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug view, 2 hud mesh (only reported when check_hud).
+// ------------------------------------------------------------------------------------------------
+template <bool GRAD>
+AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev& f, uint32_t rank, int cx, int cy, float depth_sample,
+                                 const GBufferTexel& g, bool check_hud) {
+    SurfaceOut out;
+    out.color = {0.0f, 0.0f, 0.0f, 0.0f};
+    out.kind = 0u; out.discard = false;
+    const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
+    const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, is_hud
+    const uint32_t triangle_index = rank - ds0.x;
+    if (check_hud && ds1.z == 1u) { out.kind = 2u; return out; }   // is_hud (compute.wgsl:176-179); msaa_process_sample has no such test
+    const uint32_t material_word = ds0.y;
+    const uint32_t attr_indices_off = ds0.z, attr_data_off = ds0.w, stride = ds1.x, uv_sets_index = ds1.y;
+
+    // ---- compute.wgsl:182-211 ----
+    Attr a;
+    a.sc = sc;
+    a.ad = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_ATTR_DATA]);
+    a.bary = {g.bx, g.by, (1.0f - g.bx) - g.by};
+    a.uv_sets_index = uv_sets_index;
+    const uint32_t* attr_idx = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + attr_indices_off + triangle_index * 3u;
+    a.v0 = attr_data_off + attr_idx[0] * stride;
+    a.v1 = attr_data_off + attr_idx[1] * stride;
+    a.v2 = attr_data_off + attr_idx[2] * stride;
+    a.has_uv0 = false; a.uv0 = {0.0f, 0.0f};
+    a.bary_derivs = g.bary_derivs; a.duv0_dx = {0.0f, 0.0f}; a.duv0_dy = {0.0f, 0.0f};
+
+    // ---- standard.wgsl:11-62 ----
+    const uint8_t* cam = f.camera;
+    const m4 inv_proj = load_m4(reinterpret_cast<const float*>(cam + 256));
+    const m4 inv_view = load_m4(reinterpret_cast<const float*>(cam + 320));
+    const float proj33 = *reinterpret_cast<const float*>(cam + 64 + 60);
+    const float* cam_pos = reinterpret_cast<const float*>(cam + 384);
+    const f2 uv = {((float)cx + 0.5f) * fm::rcp((float)f.width), ((float)cy + 0.5f) * fm::rcp((float)f.height)};
+    const f4 view_h = fm::fmul(inv_proj, {uv.x * 2.0f - 1.0f, 1.0f - uv.y * 2.0f, depth_sample, 1.0f});
+    const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
+    const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
+    const f3 world_position = {wp.x, wp.y, wp.z};
+    f3 surface_to_camera;
+    if (proj33 > 0.9f) {
+        surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
+    } else {
+        const f3 to_camera = mk3(cam_pos[0], cam_pos[1], cam_pos[2]) - world_position;
+        surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
+    }
+    const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
+
+    return shade_material<GRAD, false>(sc, f, a, material_word, tbn, world_position, surface_to_camera, 0u, 0.0f, 0.0f);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_forward_tile: the world transparent pass (render.rs:224-297; material_transparent/{pipeline,render_pass}.rs;
+// material_transparent_wgsl/fragment.wgsl) for one 32x32 tile.
+//
+// Blending is order dependent: fragments must reach a pixel in submission order (the host sorts the meshes back to front,
+// renderable.rs:90,131-135).  One workgroup owns the tile and every thread owns one 2x2 quad of it, so a pixel's
+// read-modify-write chain lives in one thread — no atomics, no locks — and the whole workgroup walks the tile's triangle
+// list in rank order.  The binner appends ranks to a tile's list in no particular order; they are sorted here for free:
+// ranks are unique, so setting bit (rank - base) of an LDS bitmap and scanning the bitmap IS the sorted list (windows of
+// kFwdWindow ranks).  Per-sample depth and colour of the tile stay in LDS for the whole pass (the multisampled colour
+// target of the reference never exists in HBM): initialised from the geometry pass's depth and the opaque image
+// (the opaque -> transparent blit), blended in place, resolved and written once.
+//
+// Contract (DESIGN.md "Transparent pass"): coverage/facing/depth as the geometry pass; varyings
+// and implicit derivatives from the pixel centre's barycentrics; RGBA16F target rounding at every blend.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kFwdWindow = 16384;       // ranks per bitmap window (2 KB of LDS)
+
+template <bool GRAD>
+AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py) {
+    // ---- STRICT: barycentrics (and their quad differences) exactly as the oracle derives them from the setup record ----
+    const double Xc = sample_coord((px << 8) + 128), Yc = sample_coord((py << 8) + 128);
+    const EdgeVals ev = tri_edges_d(t, Xc, Yc);
+    const float e0 = (float)ev.E[0] * t.iw[0], e1 = (float)ev.E[1] * t.iw[1], e2 = (float)ev.E[2] * t.iw[2];
+    const float inv_esum = 1.0f / ((e0 + e1) + e2);
+    const float b0 = e0 * inv_esum, b1 = e1 * inv_esum, b2 = e2 * inv_esum;
+    f4 derivs = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (GRAD) {
+        const EdgeVals eh = tri_edges_d(t, sample_coord(((px ^ 1) << 8) + 128), Yc), evv = tri_edges_d(t, Xc, sample_coord(((py ^ 1) << 8) + 128));
+        const float h0 = (float)eh.E[0] * t.iw[0], h1 = (float)eh.E[1] * t.iw[1], h2 = (float)eh.E[2] * t.iw[2];
+        const float w0 = (float)evv.E[0] * t.iw[0], w1 = (float)evv.E[1] * t.iw[1], w2 = (float)evv.E[2] * t.iw[2];
+        const float ish = 1.0f / ((h0 + h1) + h2), isv = 1.0f / ((w0 + w1) + w2);
+        const float hb0 = h0 * ish, hb1 = h1 * ish, vb0 = w0 * isv, vb1 = w1 * isv;
+        derivs = {(px & 1) ? b0 - hb0 : hb0 - b0, (py & 1) ? b0 - vb0 : vb0 - b0, (px & 1) ? b1 - hb1 : hb1 - b1, (py & 1) ? b1 - vb1 : vb1 - b1};
+    }
+    // ---- RELAXED from here ----
+    const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
+    const uint4 ds0 = dsp[0], ds1 = dsp[1];
+    const uint32_t triangle_index = rank - ds0.x;
+    Attr a;
+    a.sc = sc;
+    a.ad = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_ATTR_DATA]);
+    a.bary = {b0, b1, b2};
+    a.uv_sets_index = ds1.y;
+    const uint32_t* attr_idx = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + ds0.z + triangle_index * 3u;
+    a.v0 = ds0.w + attr_idx[0] * ds1.x;
+    a.v1 = ds0.w + attr_idx[1] * ds1.x;
+    a.v2 = ds0.w + attr_idx[2] * ds1.x;
+    a.has_uv0 = false; a.uv0 = {0.0f, 0.0f};
+    a.bary_derivs = derivs; a.duv0_dx = {0.0f, 0.0f}; a.duv0_dy = {0.0f, 0.0f};
+
+    const size_t v = (size_t)rank * 3;
+    const float4 n0 = f.nrm[v], n1 = f.nrm[v + 1], n2 = f.nrm[v + 2];
+    const float4 t0 = f.tan[v], t1 = f.tan[v + 1], t2 = f.tan[v + 2];
+    const float4 w0 = f.wpos[v], w1 = f.wpos[v + 1], w2 = f.wpos[v + 2];
+    const f3 world_position = {b0 * w0.x + b1 * w1.x + b2 * w2.x, b0 * w0.y + b1 * w1.y + b2 * w2.y, b0 * w0.z + b1 * w1.z + b2 * w2.z};
+    f3 world_normal = {b0 * n0.x + b1 * n1.x + b2 * n2.x, b0 * n0.y + b1 * n1.y + b2 * n2.y, b0 * n0.z + b1 * n1.z + b2 * n2.z};
+    const f3 tangent_xyz = {b0 * t0.x + b1 * t1.x + b2 * t2.x, b0 * t0.y + b1 * t1.y + b2 * t2.y, b0 * t0.z + b1 * t1.z + b2 * t2.z};
+    float handedness = b0 * t0.w + b1 * t1.w + b2 * t2.w;
+    if (!t.front) { world_normal = -world_normal; handedness = -handedness; }     // fragment.wgsl:195-203
+
+    const uint8_t* cam = f.camera;
+    const m4 inv_view = load_m4(reinterpret_cast<const float*>(cam + 320));
+    const float proj33 = *reinterpret_cast<const float*>(cam + 64 + 60);
+    const float* cam_pos = reinterpret_cast<const float*>(cam + 384);
+    const f3 surface_to_camera = fabsf(proj33 - 1.0f) < 0.001f ? fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z))     // fragment.wgsl:205-215
+                                                               : fm::fnormalize(mk3(cam_pos[0], cam_pos[1], cam_pos[2]) - world_position);
+    // transparent material_color_calc.wgsl:5-19,125-153: N, T, B from the interpolated varyings
+    TBN tbn;
+    tbn.N = fm::fnormalize(world_normal);
+    {
+        const f3 tt = tangent_xyz - tbn.N * fm::fdot(tangent_xyz, tbn.N);
+        const float len_sq = fm::fdot(tt, tt);
+        if (len_sq > 1e-8f) tbn.T = tt * fm::rsq(len_sq);
+        else tbn.T = fm::fnormalize(cross(fabsf(tbn.N.z) > 0.999f ? mk3(0.0f, 1.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f), tbn.N));
+    }
+    tbn.B = cross(tbn.N, tbn.T) * handedness;
+    return shade_material<GRAD, true>(sc, f, a, ds0.y, tbn, world_position, surface_to_camera, ds1.w, (float)px + 0.5f, (float)py + 0.5f);
+}
+
+template <int S, bool GRAD>
+__global__ __launch_bounds__(256) void k_forward_tile(const DevScene* __restrict__ sc, FrameDev f) {
+    __shared__ float sdepth[kTile * kTile * S];
+    __shared__ uint2 scolor[kTile * kTile * S];          // RGBA16F, as the target stores it
+    __shared__ uint32_t bitmap[kFwdWindow / 32];
+    __shared__ uint32_t rmin, rmax;
+
+    const uint32_t tile = f.tile_order[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const int tpx = (int)(tile % f.tiles_x) << kTileShift;
+    const int tpy = (int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift;
+    const int qx = (int)(tid & 15u) * 2, qy = (int)(tid >> 4) * 2;        // this thread's 2x2 quad, tile-local
+
+    // opaque -> transparent blit (every sample gets the opaque colour) + depth LoadOp::Load
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int lx = qx + (q & 1), ly = qy + (q >> 1), px = tpx + lx, py = tpy + ly;
+        const int li = (ly * kTile + lx) * S;
+        if (px < (int)f.width && py < (int)f.height) {
+            const size_t p = (size_t)py * f.width + (size_t)px;
+            const uint2 c = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];
+#pragma unroll
+            for (int s = 0; s < S; s++) { sdepth[li + s] = key_depth(f.vis[p * S + s]); scolor[li + s] = c; }
+        }
+    }
+    if (tid == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; }
+    __syncthreads();
+    const uint32_t off = f.tile_offset[tile];
+    const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, off));
+    {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint32_t i = tid; i < count; i += 256u) { const uint32_t r = f.bin_list[off + i]; lo = min(lo, r); hi = max(hi, r); }
+        if (lo <= hi) { atomicMin(&rmin, lo); atomicMax(&rmax, hi); }
+    }
+    __syncthreads();
+    const uint32_t r_lo = rmin, r_hi = rmax;
+    if (count) for (uint32_t wbase = r_lo - (r_lo % kFwdWindow); wbase <= r_hi; wbase += kFwdWindow) {
+        for (uint32_t i = tid; i < kFwdWindow / 32; i += 256u) bitmap[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < count; i += 256u) {
+            const uint32_t r = f.bin_list[off + i] - wbase;      // unsigned: ranks below the window wrap to huge values
+            if (r < kFwdWindow) atomicOr(&bitmap[r >> 5], 1u << (r & 31u));
+        }
+        __syncthreads();
+        for (uint32_t w = 0; w < kFwdWindow / 32; w++) {
+            uint32_t bits = bitmap[w];                           // same word in every lane: the loop is uniform
+            while (bits) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                const uint32_t rank = wbase + w * 32u + bit;
+                TriSetup t;
+                if (!tri_rec_load(f.tri_rec + rank, t)) continue;
+#pragma unroll 1
+                for (int q = 0; q < 4; q++) {
+                    const int lx = qx + (q & 1), ly = qy + (q >> 1), px = tpx + lx, py = tpy + ly;
+                    const int li = (ly * kTile + lx) * S;
+                    uint32_t mask = 0u;
+                    float z[S];
+                    if (px >= t.minx && px <= t.maxx && py >= t.miny && py <= t.maxy) {     // bbox is clamped to the frame
+#pragma unroll
+                        for (int s = 0; s < S; s++) {
+                            const int ox = S == 1 ? 128 : msaa4_x(s), oy = S == 1 ? 128 : msaa4_y(s);
+                            const unsigned long long k = tri_sample_key_at(t, sample_coord((px << 8) + ox), sample_coord((py << 8) + oy), rank);
+                            z[s] = __uint_as_float((uint32_t)(k >> 32));
+                            if (k != ~0ull && z[s] <= sdepth[li + s]) mask |= 1u << s;       // CompareFunction::LessEqual
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(mask != 0u) == 0ull) continue;          // nothing in this wavefront: skip the shading code
+                    if (mask) {
+                        const SurfaceOut o = forward_fragment<GRAD>(sc, f, t, rank, px, py);
+                        if (!o.discard) {                                                    // discard: neither colour nor depth
+                            const float a = o.color.w, om = 1.0f - a;
+                            const float sr = o.color.x * a, sg = o.color.y * a, sb = o.color.z * a;   // fragment.wgsl:283-285 premultiplied
+#pragma unroll
+                            for (int s = 0; s < S; s++) {
+                                if (!(mask & (1u << s))) continue;
+                                sdepth[li + s] = z[s];
+                                const uint2 d = scolor[li + s];
+                                const float r = blend_over_f16(sr, f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)), om);
+                                const float g = blend_over_f16(sg, f16_bits_to_f32((unsigned short)(d.x >> 16)), om);
+                                const float b = blend_over_f16(sb, f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)), om);
+                                const float al = blend_over_f16(a, f16_bits_to_f32((unsigned short)(d.y >> 16)), om);
+                                scolor[li + s] = make_uint2((uint32_t)f16_bits(r) | ((uint32_t)f16_bits(g) << 16), (uint32_t)f16_bits(b) | ((uint32_t)f16_bits(al) << 16));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // resolve + store (the reference resolves the multisampled `transparent` target into `composite`)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int lx = qx + (q & 1), ly = qy + (q >> 1), px = tpx + lx, py = tpy + ly;
+        const int li = (ly * kTile + lx) * S;
+        if (px < (int)f.width && py < (int)f.height) {
+            float c[4];
+            if (S == 1) {
+                const uint2 d = scolor[li];
+                c[0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); c[1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
+                c[2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); c[3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
+            } else {
+                float v[4][4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const uint2 d = scolor[li + (S == 1 ? 0 : s)];
+                    v[s][0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); v[s][1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
+                    v[s][2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); v[s][3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) c[k] = resolve4_f16(v[0][k], v[1][k], v[2][k], v[3][k]);
+            }
+            store_pixel(f, (size_t)py * f.width + (size_t)px, {c[0], c[1], c[2], c[3]});
+        }
+    }
 }
 
 // Block of 16x16 pixels -> pixel of this thread.  Workgroup ids are dealt round-robin over the 8 XCDs (blockIdx & 7), each
@@ -1044,6 +1334,21 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
     } else {
         if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
         else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
+    }
+}
+// f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;
+// out_rgba16f / out_rgba32f = the composite image).  Every tile of the frame is launched: a tile without transparent triangles is a copy.
+extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
+    const uint32_t n_tiles = f->tiles_x * f->tiles_y;
+    if (!n_tiles) return;
+    if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
+    const bool grad = f->mipmap != 0u;
+    if (f->msaa == 4u) {
+        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<4, true>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_forward_tile<4, false>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
+    } else {
+        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<1, true>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_forward_tile<1, false>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
     }
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {

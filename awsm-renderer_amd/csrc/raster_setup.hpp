@@ -23,6 +23,7 @@ struct TriSetup {
     float zq[3];              // kind 0: (z_i / w_i) / |2 area| ; kind 1: z_i / det
     float iw[3];              // kind 0: 1 / w_i ; kind 1: 1
     int minx, maxx, miny, maxy;   // inclusive, conservative, clamped to the target rect
+    bool front;                   // @builtin(front_facing): counter-clockwise in NDC (FrontFace::Ccw)
 };
 
 AWSM_DI bool finite4(float4 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w); }
@@ -64,6 +65,7 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
         if (A2 == 0) return false;
         if (cull_back && A2 > 0) return false;
         const bool flip = A2 < 0;
+        t.front = flip;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const int j = (i + 1) % 3, k = (i + 2) % 3;                       // weight of vertex i = edge j -> k
@@ -92,6 +94,7 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
         float det = (X0 * a0 + Y0 * b0) + w0 * c0;
         if (!(det != 0.0f) || !isfinite(det)) return false;
         if (cull_back && det > 0.0f) return false;      // y-down framebuffer: det < 0 <=> CCW on screen <=> front
+        t.front = det < 0.0f;
         if (det < 0.0f) {
             a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
             det = -det;
@@ -118,14 +121,14 @@ struct alignas(16) TriRec {
     float iw[3];
     double c[3];
     uint32_t bbox_x;   // minx | maxx << 16   (inclusive, clamped to the target rect)
-    uint32_t bbox_y;   // miny | maxy << 16
+    uint32_t bbox_y;   // miny | maxy << 16 | front_facing << 31   (frame height <= 32768)
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
 AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok) {
     float4* q = reinterpret_cast<float4*>(dst);
     const uint32_t bx = ok ? ((uint32_t)t.minx | ((uint32_t)t.maxx << 16)) : 1u;   // minx 1 > maxx 0
-    const uint32_t by = ok ? ((uint32_t)t.miny | ((uint32_t)t.maxy << 16)) : 1u;
+    const uint32_t by = ok ? ((uint32_t)t.miny | ((uint32_t)t.maxy << 16) | (t.front ? 0x80000000u : 0u)) : 1u;
     q[0] = make_float4(t.a[0], t.a[1], t.a[2], t.b[0]);
     q[1] = make_float4(t.b[1], t.b[2], t.zq[0], t.zq[1]);
     q[2] = make_float4(t.zq[2], t.iw[0], t.iw[1], t.iw[2]);
@@ -143,7 +146,8 @@ AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) {
     t.zq[2] = q2.x; t.iw[0] = q2.y; t.iw[1] = q2.z; t.iw[2] = q2.w;
     t.c[0] = d3.x; t.c[1] = d3.y; t.c[2] = d4.x;
     const uint32_t bx = (uint32_t)__double2loint(d4.y), by = (uint32_t)__double2hiint(d4.y);
-    t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)(bx >> 16); t.miny = (int)(by & 0xFFFFu); t.maxy = (int)(by >> 16);
+    t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)(bx >> 16); t.miny = (int)(by & 0xFFFFu); t.maxy = (int)((by >> 16) & 0x7FFFu);
+    t.front = (by >> 31) != 0u;
     return t.minx <= t.maxx;
 }
 

@@ -13,14 +13,14 @@ import numpy as np
 from . import PACKAGE_DIR
 
 LIB_PATH = os.environ.get("AWSM_HIP_LIB") or os.path.join(PACKAGE_DIR, "libawsm_hip.so")   # AWSM_HIP_LIB: A/B builds of the same ABI
-BUF_COUNT = 18
+BUF_COUNT = 19
 AWSM_CFG_PARITY_TAP = 1
 AWSM_CFG_SMALL_BIN_LIST = 2
 AWSM_CFG_OVERLAP_FRAMES = 4
 
 BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", "CAMERA", "SKIN_MATRICES", "SKIN_INDEX_WEIGHTS",
              "MORPH_WEIGHTS", "MORPH_VALUES", "GEOM_META", "MATERIAL_META", "VIS_GEOM_DATA", "VIS_GEOM_INDEX", "ATTR_DATA", "ATTR_INDEX",
-             "TEXTURE_TRANSFORMS", "INSTANCES"]
+             "TEXTURE_TRANSFORMS", "INSTANCES", "TRANSPARENCY_GEOM_DATA"]
 
 # every symbol include/awsm_hip.h declares (tests/test_abi_symbols.py checks the header against this list too)
 EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
@@ -28,7 +28,8 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
-           "awsm_hip_device_info"]
+           "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
+           "awsm_hip_read_transformed_forward"]
 
 
 class AwsmConfig(C.Structure):
@@ -57,7 +58,7 @@ class AwsmEnv(C.Structure):
 class AwsmFrameStats(C.Structure):
     _fields_ = [("ms_transform", C.c_float), ("ms_bin", C.c_float), ("ms_raster", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
                 ("triangles_in", C.c_uint32), ("triangles_binned", C.c_uint32), ("bin_entries", C.c_uint32), ("covered_pixels", C.c_uint32),
-                ("bin_overflow_retries", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("bin_overflow_retries", C.c_uint32), ("ms_forward", C.c_float), ("forward_triangles", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -111,6 +112,11 @@ def load_library():
     lib.awsm_hip_read_transformed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.awsm_hip_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.awsm_hip_destroy.argtypes = [C.c_void_p]
+    lib.awsm_hip_transparent_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.awsm_hip_read_composite.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_read_composite_f32.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_bind_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.awsm_hip_read_transformed_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     _lib = lib
     return lib
 
@@ -254,6 +260,13 @@ class HipDevice:
         p = AwsmOpaqueParams(mipmap, 1 if has_opaque else 0)
         self._chk(self.lib.awsm_hip_opaque_pass(self.ctx, C.byref(p)), "opaque_pass")
 
+    def transparent_pass(self, draws, n: Optional[int] = None):
+        """World transparent pass over the back-to-front draw list (after opaque_pass); the result is the composite image."""
+        if not isinstance(draws, C.Array):
+            n = len(draws)
+            draws = self.make_draws(draws)
+        self._chk(self.lib.awsm_hip_transparent_pass(self.ctx, draws, n if n is not None else len(draws)), "transparent_pass")
+
     def frame_end(self) -> dict:
         st = AwsmFrameStats()
         self._chk(self.lib.awsm_hip_frame_end(self.ctx, C.byref(st)), "frame_end")
@@ -296,6 +309,27 @@ class HipDevice:
         out = np.zeros((self.height, self.width, 4), dtype=np.float32)
         self._chk(self.lib.awsm_hip_read_opaque_f32(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_opaque_f32")
         return out
+
+    def read_composite(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint16)
+        self._chk(self.lib.awsm_hip_read_composite(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_composite")
+        return out
+
+    def read_composite_f32(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._chk(self.lib.awsm_hip_read_composite_f32(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_composite_f32")
+        return out
+
+    def bind_composite(self, device_ptr: Optional[int], nbytes: int = 0):
+        self._chk(self.lib.awsm_hip_bind_composite(self.ctx, device_ptr, nbytes), "bind_composite")
+
+    def read_transformed_forward(self, n_vertices: int):
+        clip = np.zeros((max(1, n_vertices), 4), dtype=np.float32)
+        nt = np.zeros((max(1, n_vertices), 8), dtype=np.float32)
+        wpos = np.zeros((max(1, n_vertices), 4), dtype=np.float32)
+        self._chk(self.lib.awsm_hip_read_transformed_forward(self.ctx, clip.ctypes.data_as(C.c_void_p), nt.ctypes.data_as(C.c_void_p),
+                                                             wpos.ctypes.data_as(C.c_void_p), n_vertices), "read_transformed_forward")
+        return clip, nt, wpos
 
     def read_transformed(self, n_vertices: int):
         clip = np.zeros((max(1, n_vertices), 4), dtype=np.float32)

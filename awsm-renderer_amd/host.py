@@ -37,7 +37,8 @@ class HostMaterial(C.Structure):
                 ("volume_attenuation_color", C.c_float * 3), ("volume_thickness_tex", TexRef),
                 ("has_clearcoat", C.c_uint32), ("clearcoat_factor", C.c_float), ("clearcoat_roughness_factor", C.c_float), ("clearcoat_normal_scale", C.c_float),
                 ("clearcoat_tex", TexRef), ("clearcoat_roughness_tex", TexRef), ("clearcoat_normal_tex", TexRef),
-                ("has_sheen", C.c_uint32), ("sheen_roughness_factor", C.c_float), ("sheen_color_factor", C.c_float * 3), ("sheen_roughness_tex", TexRef), ("sheen_color_tex", TexRef)]
+                ("has_sheen", C.c_uint32), ("sheen_roughness_factor", C.c_float), ("sheen_color_factor", C.c_float * 3), ("sheen_roughness_tex", TexRef), ("sheen_color_tex", TexRef),
+                ("alpha_mode", C.c_uint32), ("alpha_cutoff", C.c_float)]
 
 
 class MorphTarget(C.Structure):
@@ -89,7 +90,7 @@ def load_library():
         "awsm_host_mesh_set_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]), "awsm_host_mesh_append_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]),
         "awsm_host_texture_insert_kind": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
-        "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
+        "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_transparent_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
         "awsm_host_texture_array_info": (C.c_int, [vp, C.c_uint32, U32P, U32P, U32P, C.POINTER(vp)]),
         "awsm_host_upload_bytes_last_frame": (u64, [vp]),
     }
@@ -331,11 +332,16 @@ class Host:
         self._chk(self.lib.awsm_host_mirror(self.h, which, C.byref(p), C.byref(n)), "mirror")
         return C.string_at(p, n.value)
 
-    def draw_list(self) -> List[dict]:
+    def transparent_draw_list(self) -> List[dict]:
+        """The world transparent pass's list: back to front; vis_data_off = offset into the transparency geometry buffer."""
+        return self.draw_list(fn="awsm_host_transparent_draw_list")
+
+    def draw_list(self, fn: str = "awsm_host_draw_list") -> List[dict]:
         n = C.c_uint32()
-        self._chk(self.lib.awsm_host_draw_list(self.h, None, 0, C.byref(n)), "draw_list")
+        f = getattr(self.lib, fn)
+        self._chk(f(self.h, None, 0, C.byref(n)), "draw_list")
         arr = (AwsmDraw * max(1, n.value))()
-        self._chk(self.lib.awsm_host_draw_list(self.h, arr, n.value, C.byref(n)), "draw_list")
+        self._chk(f(self.h, arr, n.value, C.byref(n)), "draw_list")
         out = []
         for d in arr[:n.value]:
             e = {"geom_meta_off": d.geom_meta_off, "vis_data_off": d.vis_data_off, "tri_count": d.tri_count, "flags": d.flags}
@@ -370,6 +376,8 @@ def material_struct(m: MaterialDesc, host: Host, tt_keys: Dict[tuple, int]) -> H
     hm.metallic_factor, hm.roughness_factor, hm.normal_scale, hm.occlusion_strength = m.metallic_factor, m.roughness_factor, m.normal_scale, m.occlusion_strength
     hm.emissive_factor = (C.c_float * 3)(*m.emissive_factor)
     hm.debug_bitmask = m.debug_bitmask
+    hm.alpha_mode = {"opaque": 0, "mask": 1, "blend": 2}[m.alpha_mode]
+    hm.alpha_cutoff = m.alpha_cutoff
     hm.base_color_tex, hm.metallic_roughness_tex, hm.normal_tex = tr(m.base_color_tex), tr(m.metallic_roughness_tex), tr(m.normal_tex)
     hm.occlusion_tex, hm.emissive_tex = tr(m.occlusion_tex), tr(m.emissive_tex)
     none = TexRef(-1, 0, 0, 0, 0)

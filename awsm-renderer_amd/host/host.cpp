@@ -55,6 +55,7 @@ struct Backend {
     int (*brdf_lut_generate)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
     int (*geometry_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
     int (*opaque_pass)(AwsmHipCtx*, const AwsmOpaqueParams*) = nullptr;
+    int (*transparent_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
     int (*frame_end)(AwsmHipCtx*, AwsmFrameStats*) = nullptr;
 };
 
@@ -105,9 +106,10 @@ void push_u32(std::vector<uint8_t>& d, uint32_t v) { uint8_t b[4]; memcpy(b, &v,
 struct MeshRec {
     SlotKey transform_key = 0, material_key = 0, resource_key = 0, skin_key = 0, morph_key = 0;
     bool double_sided = false, hidden = false, hud = false, has_world_aabb = true, instanced = false;
+    bool transparent = false;   // transparency geometry instead of visibility geometry (gltf/buffers/mesh.rs:33-57)
     Aabb local_aabb{}, world_aabb{};
     uint32_t tri_count = 0;
-    size_t vis_off = 0;
+    size_t vis_off = 0, tr_off = 0;
 };
 
 }  // namespace
@@ -157,6 +159,8 @@ struct AwsmHost {
     std::unordered_map<SlotKey, std::vector<SlotKey>> transform_to_meshes;
     DynamicStorageBuffer vis_data{kIndicesInitial * 56}, vis_index{kIndicesInitial}, attr_data{kIndicesInitial * 16}, attr_index{kIndicesInitial};
     bool vis_data_dirty = true, vis_index_dirty = true, attr_data_dirty = true, attr_index_dirty = true;
+    DynamicStorageBuffer tr_data{kIndicesInitial * 40};   // meshes.rs:358-359,403-415: 40 B / original vertex of the transparent meshes
+    bool tr_data_dirty = true;
 
     // ---- instances.rs: per-instance mat4s, keyed by the instanced mesh's transform key ----
     DynamicStorageBuffer instances{64 * 32};
@@ -185,7 +189,8 @@ struct AwsmHost {
 
     bool created[AWSM_BUF_COUNT] = {};
     uint64_t upload_bytes = 0;
-    std::vector<AwsmDraw> last_draws;
+    std::vector<AwsmDraw> last_draws, last_transparent_draws;
+    bool has_transparent_meshes = false;
 };
 
 namespace {
@@ -297,7 +302,7 @@ std::vector<uint8_t> material_bytes(AwsmHost* h, const AwsmHostMaterial& m) {
     std::vector<uint8_t> d;
     d.reserve(256);
     if (m.shader == 2u) {   // unlit.rs:72-105
-        push_u32(d, 2u); push_u32(d, 0u); push_f32(d, 0.0f);
+        push_u32(d, 2u); push_u32(d, m.alpha_mode); push_f32(d, m.alpha_mode == 1u ? m.alpha_cutoff : 0.0f);   // unlit.rs:72-105
         write_tex(h, d, m.base_color_tex);
         for (int i = 0; i < 4; i++) push_f32(d, m.base_color_factor[i]);
         write_tex(h, d, m.emissive_tex);
@@ -305,7 +310,7 @@ std::vector<uint8_t> material_bytes(AwsmHost* h, const AwsmHostMaterial& m) {
         return d;
     }
     // pbr.rs:258-589
-    push_u32(d, 1u); push_u32(d, 0u); push_f32(d, 0.0f);   // shader id, alpha_mode Opaque, alpha_cutoff
+    push_u32(d, 1u); push_u32(d, m.alpha_mode); push_f32(d, m.alpha_mode == 1u ? m.alpha_cutoff : 0.0f);   // shader id, alpha_mode, alpha_cutoff (pbr.rs:268-269)
     write_tex(h, d, m.base_color_tex);
     for (int i = 0; i < 4; i++) push_f32(d, m.base_color_factor[i]);
     write_tex(h, d, m.metallic_roughness_tex);
@@ -371,8 +376,14 @@ void texture_transform_bytes(const float offset[2], const float origin[2], float
 // f32::total_cmp key
 int32_t total_key(float x) { int32_t b; memcpy(&b, &x, 4); return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1); }
 
-void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out) {   // renderable.rs:38-150
-    out.clear();
+bool is_transparency_pass(const AwsmHostMaterial& m) {   // pbr.rs:213-224, unlit.rs:36-38
+    if (m.alpha_mode == 1u || m.alpha_mode == 2u) return true;
+    return m.shader != 2u && m.has_transmission && (m.transmission_factor > 0.0f || m.transmission_tex.texture >= 0);
+}
+
+void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out_opaque, std::vector<AwsmDraw>* transparent_out = nullptr) {   // renderable.rs:38-150
+    out_opaque.clear();
+    if (transparent_out) transparent_out->clear();
     struct Item { SlotKey key; const MeshRec* rec; int pipeline; float closest; bool has_aabb; };
     std::vector<Item> items;
     const Mat4 view_proj = mat4_mul(h->cam_proj, h->cam_view);
@@ -393,6 +404,12 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out) {   // renderable.rs
         }
         items.push_back(it);
     }
+    std::vector<Item> tr_items;   // renderable.rs:78-84: hud, else transparent by material, else opaque
+    {
+        std::vector<Item> op;
+        for (const Item& it : items) (it.rec->transparent ? tr_items : op).push_back(it);
+        items.swap(op);
+    }
     if (h->have_camera) {
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
             if (a.pipeline != b.pipeline) return a.pipeline < b.pipeline;
@@ -400,11 +417,20 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out) {   // renderable.rs
             if (a.has_aabb != b.has_aabb) return a.has_aabb;                                     // (Some, None) => Less
             return false;
         });
+        std::stable_sort(tr_items.begin(), tr_items.end(), [](const Item& a, const Item& b) {   // same pipeline grouping, then back to front (renderable.rs:90,131-135)
+            if (a.pipeline != b.pipeline) return a.pipeline < b.pipeline;
+            if (a.has_aabb && b.has_aabb) return total_key(b.closest) < total_key(a.closest);
+            if (a.has_aabb != b.has_aabb) return a.has_aabb;
+            return false;
+        });
     }
-    for (const Item& it : items) {
+    for (int pass = 0; pass < 2; pass++)
+    for (const Item& it : (pass == 0 ? items : tr_items)) {
+        if (pass == 1 && !transparent_out) break;
+        std::vector<AwsmDraw>& out = pass == 0 ? *(&out_opaque) : *transparent_out;
         AwsmDraw d{};
         d.geom_meta_off = (uint32_t)h->geom_meta.offset(it.key);
-        d.vis_data_off = (uint32_t)it.rec->vis_off;
+        d.vis_data_off = (uint32_t)(pass == 0 ? it.rec->vis_off : it.rec->tr_off);
         d.tri_count = it.rec->tri_count;
         d.flags = it.rec->double_sided ? 0u : AWSM_DRAW_CULL_BACK;
         if (it.rec->instanced) {   // meshes/mesh.rs:91-121: instance buffer bound at the transform key's offset, draw_indexed_with_instance_count
@@ -440,7 +466,7 @@ int awsm_host_create(const char* backend_path, int device, void* stream, uint32_
               load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") && load_sym(h.get(), b.set_shard_bands, "awsm_hip_set_shard_bands") && load_sym(h.get(), b.pick, "awsm_hip_pick") &&
               load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.texture_array_generate_mips, "awsm_hip_texture_array_generate_mips") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
               load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
-              load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") &&
+              load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") && load_sym(h.get(), b.transparent_pass, "awsm_hip_transparent_pass") &&
               load_sym(h.get(), b.frame_end, "awsm_hip_frame_end");
     if (!ok) { fprintf(stderr, "awsm_host: %s\n", h->last_error.c_str()); dlclose(b.dl); return AWSM_ERR_NOT_READY; }
     if (b.abi_version() != AWSM_HIP_ABI_VERSION) { dlclose(b.dl); return AWSM_ERR_INVALID_ARGUMENT; }
@@ -657,11 +683,13 @@ AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey t
         h->morph_weights_dirty = h->morph_values_dirty = true;
     }
 
+    // ---- gltf/buffers/mesh.rs:33-57: visibility geometry XOR transparency geometry, by the material ----
+    const bool transparent = is_transparency_pass(*mat);
     // ---- gltf/buffers/mesh/visibility.rs:35-165: vertex explosion, 56 B / corner ----
-    std::vector<uint8_t> vis((size_t)T * 3 * 56);
+    std::vector<uint8_t> vis(transparent ? 0 : (size_t)T * 3 * 56);
     static const float kBary[3][2] = {{1.0f, 0.0f}, {0.0f, 1.0f}, {0.0f, 0.0f}};
     const float default_tangent[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-    for (uint32_t t = 0; t < T; t++) {
+    for (uint32_t t = 0; t < T && !transparent; t++) {
         uint32_t vi[3] = {p->indices[t * 3], p->indices[t * 3 + 1], p->indices[t * 3 + 2]};
         int bi[3] = {0, 1, 2};
         if (p->front_face_cw) { std::swap(vi[1], vi[2]); std::swap(bi[1], bi[2]); }
@@ -685,17 +713,31 @@ AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey t
     }
     // ---- meshes.rs:486-560 insert_resource: vis index, vis data, attr index, attr data ----
     SlotKey rk = h->resources.insert(0);
-    std::vector<uint32_t> ident((size_t)T * 3);
-    for (size_t i = 0; i < ident.size(); i++) ident[i] = (uint32_t)i;
-    h->vis_index.update(rk, reinterpret_cast<const uint8_t*>(ident.data()), ident.size() * 4);
-    const size_t vis_off = h->vis_data.update(rk, vis.data(), vis.size());
+    size_t vis_off = 0, tr_off = 0;
+    if (!transparent) {
+        std::vector<uint32_t> ident((size_t)T * 3);
+        for (size_t i = 0; i < ident.size(); i++) ident[i] = (uint32_t)i;
+        h->vis_index.update(rk, reinterpret_cast<const uint8_t*>(ident.data()), ident.size() * 4);
+        vis_off = h->vis_data.update(rk, vis.data(), vis.size());
+    } else {   // gltf/buffers/mesh/transparency.rs:31-175: 40 B per ORIGINAL vertex, drawn through the custom-attribute indices
+        std::vector<uint8_t> tv((size_t)V * 40);
+        for (uint32_t v = 0; v < V; v++) {
+            uint8_t* dst = tv.data() + (size_t)v * 40;
+            memcpy(dst, p->positions + (size_t)v * 3, 12);
+            memcpy(dst + 12, p->normals + (size_t)v * 3, 12);
+            memcpy(dst + 24, p->tangents ? p->tangents + (size_t)v * 4 : default_tangent, 16);
+        }
+        tr_off = h->tr_data.update(rk, tv.data(), tv.size());
+        h->tr_data_dirty = true;
+    }
     const size_t attr_index_off = h->attr_index.update(rk, reinterpret_cast<const uint8_t*>(p->indices), (size_t)T * 12);
     const size_t attr_data_off = h->attr_data.update(rk, reinterpret_cast<const uint8_t*>(attr.data()), attr.size() * 4);
     h->vis_index_dirty = h->vis_data_dirty = h->attr_index_dirty = h->attr_data_dirty = true;
 
     MeshRec rec;
     rec.transform_key = transform; rec.material_key = material; rec.resource_key = rk; rec.skin_key = skin; rec.morph_key = morph_key;
-    rec.double_sided = mat->double_sided != 0; rec.hidden = hidden != 0; rec.tri_count = T; rec.vis_off = vis_off;
+    rec.double_sided = mat->double_sided != 0; rec.hidden = hidden != 0; rec.tri_count = T; rec.vis_off = vis_off; rec.transparent = transparent; rec.tr_off = tr_off;
+    if (transparent) h->has_transparent_meshes = true;
     Vec3 mn = {p->positions[0], p->positions[1], p->positions[2]}, mx = mn;   // accessor min/max (populate/mesh.rs try_position_aabb)
     for (uint32_t v = 1; v < V; v++) {
         const Vec3 q = {p->positions[(size_t)v * 3], p->positions[(size_t)v * 3 + 1], p->positions[(size_t)v * 3 + 2]};
@@ -724,7 +766,8 @@ int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh) {
     MeshRec* rec = h->meshes.get(mesh);
     if (!rec) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[mesh] not found");
     const SlotKey rk = rec->resource_key, tk = rec->transform_key, mk = rec->morph_key;
-    h->vis_index.remove(rk); h->vis_data.remove(rk); h->attr_index.remove(rk); h->attr_data.remove(rk);
+    h->vis_index.remove(rk); h->vis_data.remove(rk); h->tr_data.remove(rk); h->attr_index.remove(rk); h->attr_data.remove(rk);
+    if (rec->transparent) h->tr_data_dirty = true;
     h->resources.remove(rk);
     if (mk) { h->morph_weights.remove(mk); h->morph_values.remove(mk); h->morphs.remove(mk); h->morph_weights_dirty = h->morph_values_dirty = true; }
     auto& v = h->transform_to_meshes[tk];
@@ -930,6 +973,7 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
     // VisGeomIndex (identity indices) stays a host mirror only: a software rasteriser has no index fetch.  The
     // mirror still tracks the reference's allocation; nothing is uploaded (SURVEY Appendix A "redundant").
     h->vis_index.take_dirty_ranges(); h->vis_index.take_gpu_needs_resize(); h->vis_index_dirty = false;
+    if ((rc = flush_buffer(h, h->tr_data, AWSM_BUF_TRANSPARENCY_GEOM_DATA, h->tr_data_dirty))) return rc;   // meshes.rs:1268: between the visibility and the attribute buffers
     if ((rc = flush_buffer(h, h->attr_data, AWSM_BUF_ATTR_DATA, h->attr_data_dirty))) return rc;
     if ((rc = flush_buffer(h, h->attr_index, AWSM_BUF_ATTR_INDEX, h->attr_index_dirty))) return rc;
     if (h->camera_dirty) {   // camera.rs:232-251
@@ -949,11 +993,14 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
         a.dirty = false;
     }
     // ---- collect_renderables -> geometry pass -> opaque pass (render.rs:144-221) ----
-    collect_draws(h, h->last_draws);
+    collect_draws(h, h->last_draws, &h->last_transparent_draws);
     if ((rc = h->be.geometry_pass(h->ctx, h->last_draws.data(), (uint32_t)h->last_draws.size()))) return dev_fail(h, rc, "geometry_pass");
     AwsmOpaqueParams op{};
     op.mipmap = h->mipmap ? 1u : 0u; op.has_opaque = h->last_draws.empty() ? 0u : 1u;   // material_opaque/render_pass.rs:64-71
     if ((rc = h->be.opaque_pass(h->ctx, &op))) return dev_fail(h, rc, "opaque_pass");
+    // ---- opaque -> transparent blit + world transparent pass (render.rs:224-297).  A scene without transparent meshes skips it:
+    // the composite image then IS the opaque image (the reference would copy it). ----
+    if (h->has_transparent_meshes) { if ((rc = h->be.transparent_pass(h->ctx, h->last_transparent_draws.data(), (uint32_t)h->last_transparent_draws.size()))) return dev_fail(h, rc, "transparent_pass"); }
     if (sync) { if ((rc = h->be.frame_end(h->ctx, stats))) return dev_fail(h, rc, "frame_end"); }   // gpu.submit_commands (render.rs:370)
     return AWSM_OK;
 }
@@ -977,10 +1024,19 @@ int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* l
         case AWSM_BUF_ATTR_INDEX: v = &h->attr_index.raw(); break;
         case AWSM_BUF_TEXTURE_TRANSFORMS: v = &h->tex_transforms_buf.raw(); break;
         case AWSM_BUF_INSTANCES: v = &h->instances.raw(); break;
+        case AWSM_BUF_TRANSPARENCY_GEOM_DATA: v = &h->tr_data.raw(); break;
         case AWSM_BUF_CAMERA: *data = h->camera_raw; *len = 512; return AWSM_OK;
         default: return fail(h, AWSM_ERR_INVALID_ARGUMENT, "mirror: buffer %d has no persistent mirror", (int)which);
     }
     *data = v->data(); *len = v->size();
+    return AWSM_OK;
+}
+
+int awsm_host_transparent_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n) {
+    std::vector<AwsmDraw> d, t;
+    collect_draws(h, d, &t);
+    *n = (uint32_t)t.size();
+    if (out) memcpy(out, t.data(), std::min<size_t>(cap, t.size()) * sizeof(AwsmDraw));
     return AWSM_OK;
 }
 

@@ -36,15 +36,25 @@ class MaterialDesc:
     occlusion_tex: Optional[TextureRef] = None
     emissive_tex: Optional[TextureRef] = None
     double_sided: bool = False
+    alpha_mode: str = "opaque"       # "opaque" | "mask" | "blend"  (MaterialAlphaMode, materials.rs:255-273)
+    alpha_cutoff: float = 0.5        # Mask only
     debug_bitmask: int = 0
     vertex_color_set: Optional[int] = None
     emissive_strength: Optional[float] = None
     ior: Optional[float] = None
     specular: Optional[dict] = None       # {tex, factor, color_tex, color_factor}
-    transmission: Optional[dict] = None   # never reaches the opaque pass when factor > 0 (routed to transparency)
+    transmission: Optional[dict] = None   # {tex, factor}; factor > 0 or a texture routes the mesh to the transparent pass
     volume: Optional[dict] = None         # {thickness_tex, thickness_factor, attenuation_distance, attenuation_color}
     clearcoat: Optional[dict] = None      # {tex, factor, roughness_tex, roughness_factor, normal_tex, normal_scale}
     sheen: Optional[dict] = None          # {roughness_tex, roughness_factor, color_tex, color_factor}
+
+    def is_transparency_pass(self) -> bool:
+        """materials/pbr.rs:213-224, materials/unlit.rs:36-38"""
+        if self.alpha_mode in ("blend", "mask"):
+            return True
+        if self.kind != "unlit" and self.transmission is not None:
+            return float(self.transmission.get("factor", 0.0)) > 0.0 or self.transmission.get("tex") is not None
+        return False
 
 
 @dataclass

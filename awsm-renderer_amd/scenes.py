@@ -501,3 +501,98 @@ def instanced_scene(width=640, height=360, seed=0xA35A0006) -> SceneDesc:
     eye = (7.5, 5.0, 8.5)
     return SceneDesc(nodes=nodes, materials=mats, textures=textures, samplers=[dict(REPEAT_LINEAR)], lights=list(DEFAULT_LIGHTS), width=width, height=height,
                      view=look_at_rh(eye, (0.0, 0.6, 0.0)), proj=perspective_rh(math.radians(50), width / height, 0.1, 100.0), camera_position=eye)
+
+
+# ------------------------------------------------------------------------------------------------ transparent pass
+
+def transparent_scene(width=640, height=360, tex_size=64, seed=0xA35A0007) -> SceneDesc:
+    """An opaque backdrop (textured wall + floor + three spheres) seen through a row of transparent objects, one per branch of
+    the forward pass (material_transparent_wgsl/fragment.wgsl + helpers): alpha blend with a textured alpha, a double-sided
+    blended shell whose back faces show through its front faces, ALPHA_MODE_MASK with a cutoff, vertex-colour alpha, unlit
+    blend, KHR_materials_transmission (smooth: one refracted tap of the opaque image; rough: the 25-tap blur; thin: no
+    refraction), volume attenuation, a blended mesh that also carries morph targets, a blended instanced mesh, and two
+    overlapping blended quads to pin the back-to-front order.  Not a BASELINE config."""
+    rng = np.random.default_rng(seed)
+    textures = [
+        value_noise_rgba8(rng, tex_size, 8, base=(0.6, 0.5, 0.4), amp=(0.3, 0.3, 0.3)),      # 0 colour, opaque alpha
+        value_noise_rgba8(rng, tex_size, 12, kind="normal"),                                 # 1 normal
+        value_noise_rgba8(rng, tex_size, 6, base=(0.5, 0.6, 0.7), amp=(0.3, 0.3, 0.3)),      # 2 colour with varying alpha
+        value_noise_rgba8(rng, tex_size, 10, base=(0.5, 0.5, 0.5), amp=(0.4, 0.4, 0.4)),     # 3 data (transmission / thickness)
+    ]
+    a = value_noise_rgba8(rng, tex_size, 5, base=(0.5, 0.5, 0.5), amp=(0.5, 0.5, 0.5))[..., 0]
+    textures[2][..., 3] = a
+    T = TextureRef
+    mats = [
+        MaterialDesc(base_color_tex=T(0), normal_tex=T(1), metallic_factor=0.0, roughness_factor=0.6),                                        # 0 opaque backdrop
+        MaterialDesc(base_color_factor=(0.9, 0.3, 0.2, 1.0), metallic_factor=0.6, roughness_factor=0.35),                                    # 1 opaque sphere
+        MaterialDesc(base_color_tex=T(2), base_color_factor=(1.0, 1.0, 1.0, 0.8), normal_tex=T(1), alpha_mode="blend", metallic_factor=0.0, roughness_factor=0.4),   # 2 blend, textured alpha
+        MaterialDesc(base_color_factor=(0.2, 0.6, 0.9, 0.45), alpha_mode="blend", double_sided=True, metallic_factor=0.1, roughness_factor=0.3),                 # 3 blend, double sided
+        MaterialDesc(base_color_tex=T(2), alpha_mode="mask", alpha_cutoff=0.5, double_sided=True, metallic_factor=0.0, roughness_factor=0.7),                    # 4 mask
+        MaterialDesc(base_color_factor=(1.0, 1.0, 1.0, 0.9), vertex_color_set=0, alpha_mode="blend", metallic_factor=0.0, roughness_factor=0.8),                 # 5 vertex colour (alpha in the colour)
+        MaterialDesc(kind="unlit", base_color_tex=T(2), base_color_factor=(0.9, 1.0, 0.8, 0.7), emissive_factor=(0.1, 0.0, 0.1), alpha_mode="blend"),            # 6 unlit blend
+        MaterialDesc(base_color_factor=(0.95, 0.98, 1.0, 1.0), transmission={"factor": 0.95}, volume={"thickness_factor": 0.35, "attenuation_distance": 1.5, "attenuation_color": (0.7, 0.9, 0.8)},
+                     ior=1.5, metallic_factor=0.0, roughness_factor=0.02),                                                                    # 7 smooth glass: refraction, one tap
+        MaterialDesc(base_color_factor=(1.0, 0.9, 0.8, 1.0), transmission={"factor": 0.8, "tex": T(3)}, volume={"thickness_factor": 0.25, "thickness_tex": T(3)},
+                     ior=1.7, metallic_factor=0.0, roughness_factor=0.45, normal_tex=T(1)),                                                   # 8 rough glass: 25-tap blur, textured factors
+        MaterialDesc(base_color_factor=(0.8, 1.0, 0.9, 1.0), transmission={"factor": 0.6}, metallic_factor=0.0, roughness_factor=0.2,
+                     clearcoat={"factor": 0.5, "roughness_factor": 0.1}),                                                                     # 9 thin-walled transmission (no volume): unrefracted tap
+        MaterialDesc(base_color_factor=(0.9, 0.8, 0.2, 0.6), alpha_mode="blend", metallic_factor=0.0, roughness_factor=0.5),                 # 10 blend + morph targets
+        MaterialDesc(base_color_factor=(0.7, 0.2, 0.8, 0.5), alpha_mode="blend", metallic_factor=0.0, roughness_factor=0.5, double_sided=True),   # 11 blend, instanced
+        MaterialDesc(base_color_factor=(1.0, 0.1, 0.1, 0.5), alpha_mode="blend", double_sided=True, roughness_factor=0.9, metallic_factor=0.0),  # 12 overlapping quad A
+        MaterialDesc(base_color_factor=(0.1, 1.0, 0.1, 0.5), alpha_mode="blend", double_sided=True, roughness_factor=0.9, metallic_factor=0.0),  # 13 overlapping quad B
+    ]
+
+    def wall(U, V):
+        return np.stack([(U - 0.5) * 14.0, (V - 0.5) * 8.0, np.full_like(U, -3.0) + 0.3 * np.sin(U * 9.0) * np.sin(V * 7.0)], axis=-1)
+
+    def floor(U, V):
+        return np.stack([(U - 0.5) * 14.0, np.full_like(U, -1.6), (0.5 - V) * 10.0 - 1.0], axis=-1)
+
+    def ball_fn(radius, bump, k):
+        def ball(U, V):
+            th, phi = U * 2 * math.pi, (0.03 + 0.94 * V) * math.pi
+            d = np.stack([np.sin(phi) * np.cos(th), np.cos(phi), -np.sin(phi) * np.sin(th)], axis=-1)
+            return d * (radius * (1.0 + bump * np.sin(d @ k * 3.0)))[..., None]
+        return ball
+
+    def quad_fn(w, h):
+        def quad(U, V):
+            return np.stack([(U - 0.5) * w, (V - 0.5) * h, np.zeros_like(U)], axis=-1)
+        return quad
+
+    def prim(fn, nu, nv, material, with_color=False, **kw):
+        pos, nrm, tan, uvs, idx = grid_patch(fn, nu, nv, uv_scale=(2.0, 1.0))
+        colors = []
+        if with_color:
+            colors = [np.concatenate([0.5 + 0.5 * nrm, (0.35 + 0.6 * uvs[:, 1:2] / 1.0).clip(0, 1)], axis=1).astype(F)]
+        return PrimitiveDesc(positions=pos, normals=nrm, tangents=tan, uvs=[uvs], colors=colors, indices=idx, material=material, **kw)
+
+    nodes = [NodeDesc(),
+             NodeDesc(parent=0, primitives=[prim(wall, 24, 16, 0)]),
+             NodeDesc(parent=0, primitives=[prim(floor, 16, 16, 0)])]
+    for i, x in enumerate((-3.0, 0.2, 3.2)):
+        nodes.append(NodeDesc(parent=0, translation=(x, -0.4 + 0.5 * i, -1.6), primitives=[prim(ball_fn(0.7, 0.1, np.array([2.0, 3.0, 4.0])), 20, 14, 1 if i != 1 else 0)]))
+    # front row of transparent objects
+    xs = np.linspace(-4.2, 4.2, 9)
+    row = [2, 3, 4, 5, 6, 7, 8, 9]
+    for j, m in enumerate(row):
+        kk = rng.uniform(2.0, 5.0, size=3)
+        p = prim(ball_fn(0.42, 0.08, kk), 20, 14, m, with_color=(m == 5))
+        nodes.append(NodeDesc(parent=0, translation=(float(xs[j]), 0.55 if j % 2 else -0.45, 1.0 + 0.15 * j), rotation=quat_axis_angle((0.2, 1, 0.1), 0.4 * j), primitives=[p]))
+    # morph-target blended sphere
+    base = prim(ball_fn(0.4, 0.05, np.array([3.0, 2.0, 5.0])), 18, 12, 10)
+    tgt = {"positions": (base.normals * 0.15 * np.sin(base.positions[:, 1:2] * 9.0)).astype(F), "normals": (0.2 * np.cos(base.positions * 5.0)).astype(F)}
+    base.morph_targets = [tgt]
+    base.morph_weights = np.array([0.8], dtype=F)
+    nodes.append(NodeDesc(parent=0, translation=(float(xs[8]), -0.4, 1.4), primitives=[base]))
+    # instanced blended shards
+    inst = [((-3.5 + 1.4 * i, 1.7 + 0.1 * (i % 2), 0.4 + 0.2 * i), quat_axis_angle((0.3, 1.0, 0.2), 0.7 * i), (0.5, 0.35 + 0.1 * (i % 3), 0.5)) for i in range(6)]
+    nodes.append(NodeDesc(parent=0, primitives=[prim(ball_fn(0.5, 0.2, np.array([4.0, 1.0, 2.0])), 10, 8, 11, instances=inst)]))
+    # two interpenetrating blended quads: submission order = back to front by the closest AABB corner, whatever the per-pixel order is
+    nodes.append(NodeDesc(parent=0, translation=(-0.6, -0.9, 2.2), rotation=quat_axis_angle((0, 1, 0), 0.5), primitives=[prim(quad_fn(1.6, 0.9), 4, 3, 12)]))
+    nodes.append(NodeDesc(parent=0, translation=(-0.3, -0.8, 2.3), rotation=quat_axis_angle((0, 1, 0), -0.6), primitives=[prim(quad_fn(1.6, 0.9), 4, 3, 13)]))
+    lights = list(DEFAULT_LIGHTS[:2]) + [{"kind": "point", "color": (1.0, 0.9, 0.7), "intensity": 12.0, "position": (0.0, 2.5, 3.0), "range": 20.0}]
+    eye = (0.4, 0.3, 6.0)
+    return SceneDesc(nodes=nodes, materials=mats, textures=textures, samplers=[dict(REPEAT_LINEAR), dict(CLAMP_LINEAR)], lights=lights, width=width, height=height,
+                     view=look_at_rh(eye, (0, 0, 0)), proj=perspective_rh(math.radians(50), width / height, 0.1, 100.0), camera_position=eye,
+                     skybox_rgba=(0.02, 0.03, 0.05, 1.0), prefiltered_rgb=(0.9, 0.95, 1.0), irradiance_rgb=(0.8, 0.85, 0.9))

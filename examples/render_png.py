@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Render one of the synthetic scenes through the host layer + HIP kernels and save it as a PNG (needs an MI355X).
 
-    python examples/render_png.py {box,helmet,skinned,atrium,zoo,instanced} out.png [--width W --height H --msaa 4 --mipmap]
+    python examples/render_png.py {box,helmet,skinned,atrium,zoo,instanced,transparent} out.png [--width W --height H --msaa 4 --mipmap]
 
 The output image of the opaque pass is linear HDR RGBA16F; the PNG is Reinhard tone-mapped and gamma-encoded for viewing.
 """
@@ -19,7 +19,7 @@ from awsm_renderer_amd.host import Renderer               # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("scene", choices=["box", "helmet", "skinned", "atrium", "zoo", "instanced"])
+    ap.add_argument("scene", choices=["box", "helmet", "skinned", "atrium", "zoo", "instanced", "transparent"])
     ap.add_argument("out")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -29,17 +29,18 @@ def main():
     W, H = a.width, a.height
     sc = {"box": lambda: scenes.box_scene(W, H), "helmet": lambda: scenes.helmet_scene(W, H), "skinned": lambda: scenes.skinned_morph_scene(W, H),
           "atrium": lambda: scenes.atrium_scene(W, H, tex_scale=0.5), "zoo": lambda: scenes.material_zoo_scene(W, H),
-          "instanced": lambda: scenes.instanced_scene(W, H)}[a.scene]()
+          "instanced": lambda: scenes.instanced_scene(W, H), "transparent": lambda: scenes.transparent_scene(W, H, tex_size=256)}[a.scene]()
     r = Renderer(sc, msaa=a.msaa, mipmap=a.mipmap)
     stats = r.render(sync=True)
     dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
-    img = dev.read_opaque().view(np.float16).astype(np.float32)[..., :3]
+    final = dev.read_composite() if stats["forward_triangles"] else dev.read_opaque()      # the image after the transparent pass, when the scene has one
+    img = final.view(np.float16).astype(np.float32)[..., :3]
     r.close()
     ldr = np.clip(img / (1.0 + img), 0.0, 1.0) ** (1.0 / 2.2)
     from PIL import Image
     Image.fromarray((ldr * 255.0 + 0.5).astype(np.uint8)).save(a.out)
     print(f"{a.out}: {W}x{H}, {stats['triangles_in']} triangles, {stats['covered_pixels']} covered pixels, "
-          f"geometry {stats['ms_transform'] + stats['ms_bin'] + stats['ms_raster']:.3f} ms, opaque {stats['ms_shade']:.3f} ms")
+          f"geometry {stats['ms_transform'] + stats['ms_bin'] + stats['ms_raster']:.3f} ms, opaque {stats['ms_shade']:.3f} ms, transparent {stats['ms_forward']:.3f} ms")
 
 
 if __name__ == "__main__":

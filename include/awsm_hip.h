@@ -64,8 +64,10 @@ typedef enum AwsmBuf {
     AWSM_BUF_ATTR_DATA = 14,        /* interleaved f32 custom attributes   crates/renderer/src/gltf/buffers/attributes.rs:113-160 */
     AWSM_BUF_ATTR_INDEX = 15,       /* 3 x u32 / triangle                  crates/renderer/src/meshes.rs:434-446 */
     AWSM_BUF_TEXTURE_TRANSFORMS = 16,/* 32 B records                       crates/renderer/src/textures.rs:247-284 */
-    AWSM_BUF_INSTANCES = 17,        /* mat4 / instance (accepted, unread: instancing is SURVEY §8f "next") */
-    AWSM_BUF_COUNT = 18
+    AWSM_BUF_INSTANCES = 17,        /* mat4 / instance                       crates/renderer/src/instances.rs:30-57 */
+    AWSM_BUF_TRANSPARENCY_GEOM_DATA = 18, /* 40 B / original vertex {pos, normal, tangent}, drawn through AWSM_BUF_ATTR_INDEX
+                                       crates/renderer/src/gltf/buffers/mesh/transparency.rs:31-175, meshes.rs:1116-1125 */
+    AWSM_BUF_COUNT = 19
 } AwsmBuf;
 
 /* Replaces AwsmRendererBuilder::build() (crates/renderer/src/lib.rs:213-259) for the two passes. */
@@ -91,11 +93,12 @@ typedef struct AwsmConfig {
  * Order of the array == the reference's sorted renderable order (crates/renderer/src/renderable.rs:38-150). */
 typedef struct AwsmDraw {
     uint32_t geom_meta_off;   /* byte offset of the 256-B GeometryMeshMeta slot */
-    uint32_t vis_data_off;    /* byte offset of the first exploded vertex in AWSM_BUF_VIS_GEOM_DATA */
+    uint32_t vis_data_off;    /* byte offset of the first exploded vertex in AWSM_BUF_VIS_GEOM_DATA (geometry pass), or of the mesh's
+                                 first 40-byte vertex in AWSM_BUF_TRANSPARENCY_GEOM_DATA (transparent pass) */
     uint32_t tri_count;
     uint32_t flags;           /* AWSM_DRAW_* */
-    uint32_t inst_off;        /* instancing: reserved, must be 0 */
-    uint32_t inst_count;      /* instancing: reserved, must be 0 */
+    uint32_t inst_off;        /* instanced mesh: byte offset of its first mat4 in AWSM_BUF_INSTANCES (meshes/mesh.rs:91-121) */
+    uint32_t inst_count;      /* instanced mesh: instance count; 0 = not instanced */
 } AwsmDraw;
 #define AWSM_DRAW_CULL_BACK 1u   /* CullMode::Back (single-sided); 0 = CullMode::None */
 
@@ -140,7 +143,9 @@ typedef struct AwsmFrameStats {
     uint32_t bin_entries;       /* (triangle, tile) pairs */
     uint32_t covered_pixels;    /* pixels with a hit (inside the shard rect) */
     uint32_t bin_overflow_retries;
-    uint32_t reserved[3];
+    float ms_forward;           /* transparent pass: transform + binning + k_forward_tile */
+    uint32_t forward_triangles; /* sum of tri_count (x instances) over the transparent draws */
+    uint32_t reserved[1];
 } AwsmFrameStats;
 
 /* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */
@@ -211,6 +216,18 @@ int awsm_hip_geometry_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_dr
  * (crates/renderer/src/render.rs:209,219-221): one dispatch over the screen. ---- */
 int awsm_hip_opaque_pass(AwsmHipCtx* ctx, const AwsmOpaqueParams* params);
 
+/* ---- opaque -> transparent blit + MaterialTransparentRenderPass::render(.., is_hud = false) (+ the MSAA resolve into `composite`)
+ * (crates/renderer/src/render.rs:224-297, render_passes/material_transparent/{render_pass,pipeline}.rs,
+ * material_transparent_wgsl/{vertex,fragment}.wgsl).  `draws` = the transparent renderables in the reference's order (grouped by
+ * pipeline, then back to front: renderable.rs:90,131-135); each mesh's 40-byte vertices (AWSM_BUF_TRANSPARENCY_GEOM_DATA at
+ * vis_data_off) are drawn through its custom-attribute indices.  Forward shading per fragment with the premultiplied "over" blend
+ * (One / OneMinusSrcAlpha), depth test LessEqual against the geometry pass's depth, depth write, screen-space transmission from
+ * the opaque image.  Call after awsm_hip_opaque_pass of the same frame (it uses that call's mipmap mode and the context's MSAA
+ * mode).  The result is the `composite` image (awsm_hip_read_composite / awsm_hip_bind_composite); the opaque image is
+ * unchanged.  n_draws = 0 is valid (composite = opaque).  Not available on a sharded context (transmission reads the whole
+ * opaque image): AWSM_ERR_UNSUPPORTED. ---- */
+int awsm_hip_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
+
 /* ---- gpu.submit_commands(encoder.finish()) (crates/renderer/src/render.rs:370): waits for the frame,
  * fills per-kernel times.  `out` may be NULL. ---- */
 int awsm_hip_frame_end(AwsmHipCtx* ctx, AwsmFrameStats* out);
@@ -234,6 +251,14 @@ void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
 int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
 int awsm_hip_read_visibility_unpacked(AwsmHipCtx* ctx, uint32_t* tri_id_out, uint32_t* meta_off_out, float* depth_out);
 int awsm_hip_read_opaque(AwsmHipCtx* ctx, uint16_t* rgba16f_out);
+/* the image after the transparent pass == the reference's `composite` render texture (render_textures.rs:49-54; what the
+ * display pass tone-maps): RGBA16F, width*height*8 bytes.  bind_composite lets the caller own the memory (NULL = internal). */
+int awsm_hip_read_composite(AwsmHipCtx* ctx, uint16_t* rgba16f_out);
+int awsm_hip_read_composite_f32(AwsmHipCtx* ctx, float* rgba32f_out);  /* needs AWSM_CFG_PARITY_TAP: the same f16 values, widened */
+int awsm_hip_bind_composite(AwsmHipCtx* ctx, void* device_ptr, size_t bytes);
+/* transformed vertices of the last transparent pass, one per triangle corner in draw order: clip xyzw (16 B),
+ * {world N xyz, pad, world T xyzw} (32 B), world position xyz1 (16 B) == vert_main outputs (material_transparent_wgsl/vertex.wgsl) */
+int awsm_hip_read_transformed_forward(AwsmHipCtx* ctx, float* clip_out, float* normal_tangent_out, float* world_pos_out, uint32_t max_vertices);
 int awsm_hip_read_opaque_f32(AwsmHipCtx* ctx, float* rgba32f_out);  /* needs AWSM_CFG_PARITY_TAP */
 /* ---- picking (crates/renderer/src/picker.rs:55-121 + picker/shader/picker_wgsl/compute.wgsl): the mesh under pixel
  * (x, y) of the last geometry pass, read from the visibility buffer: key -> draw -> geometry meta -> material mesh meta

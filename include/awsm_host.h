@@ -76,6 +76,10 @@ typedef struct AwsmHostMaterial {
     uint32_t has_clearcoat; float clearcoat_factor, clearcoat_roughness_factor, clearcoat_normal_scale;
     AwsmHostTexRef clearcoat_tex, clearcoat_roughness_tex, clearcoat_normal_tex;
     uint32_t has_sheen; float sheen_roughness_factor; float sheen_color_factor[3]; AwsmHostTexRef sheen_roughness_tex, sheen_color_tex;
+    /* MaterialAlphaMode (materials.rs:255-273): 0 Opaque, 1 Mask { cutoff }, 2 Blend.  Mask, Blend and any transmission route the
+     * meshes that use the material to the transparent pass (pbr.rs:213-224, unlit.rs:36-38; decided when the mesh is inserted,
+     * as the glTF loader does: gltf/buffers/mesh.rs:33-57). */
+    uint32_t alpha_mode; float alpha_cutoff;
 } AwsmHostMaterial;
 
 AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m);
@@ -143,6 +147,8 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats);
 
 /* ---- introspection (tests, parity, INTEGRATION) ---- */
 int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* len);
+/* the world transparent pass's list (back to front), as awsm_host_draw_list gives the geometry pass's */
+int awsm_host_transparent_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);
 int awsm_host_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);   /* the list render() would submit */
 uint32_t awsm_host_texture_array_count(AwsmHost* h);
 int awsm_host_texture_array_info(AwsmHost* h, uint32_t array_idx, uint32_t* width, uint32_t* height, uint32_t* layers, const uint8_t** texels);

@@ -64,6 +64,14 @@ int oracle_raster(const OracleScene* s, const float* clip_in, uint64_t* keys_out
 int oracle_shade(const OracleScene* s, const float* clip_in, const float* nt_in, const uint64_t* keys,
                  float* rgba32f_out, uint16_t* rgba16f_out, int threads);
 
+/* World transparent pass (render.rs:224-297; material_transparent/): `draws` is the back-to-front list, draw.vis_data_off = byte
+ * offset of the mesh's 40-byte vertices in AWSM_BUF_TRANSPARENCY_GEOM_DATA.  oracle_forward_transform: vert_main per triangle
+ * corner (clip 4, nt 8, wpos 4 floats / vertex).  oracle_forward: blit + forward pass + resolve -> the `composite` image. */
+uint32_t oracle_forward_total_vertices(const AwsmDraw* draws, uint32_t n_draws);
+int oracle_forward_transform(const OracleScene* s, const AwsmDraw* draws, uint32_t n_draws, float* clip_out, float* nt_out, float* wpos_out);
+int oracle_forward(const OracleScene* s, const AwsmDraw* draws, uint32_t n_draws, const float* clip, const float* nt, const float* wpos,
+                   const uint64_t* keys, const uint16_t* opaque16f, float* composite32f_out, uint16_t* composite16f_out, uint8_t* touched_out, int threads);
+
 /* key -> reference visibility texel (primitive-local triangle id, material-mesh-meta byte offset) + depth */
 int oracle_unpack_visibility(const OracleScene* s, const uint64_t* keys, uint32_t* tri_id_out,
                              uint32_t* meta_off_out, float* depth_out);

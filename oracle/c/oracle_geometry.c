@@ -21,6 +21,7 @@
  */
 #include "oracle.h"
 #include "oracle_math.h"
+#include "oracle_raster.h"
 #include <stdlib.h>
 
 typedef struct {
@@ -77,13 +78,11 @@ static omat4 skin_matrix(const OracleScene* s, const GeomMeta* gm, uint32_t vert
     return skin;
 }
 
-/* apply_vertex.wgsl:24-118 for one exploded vertex (56-byte record, pipeline.rs:28-73) */
-static void apply_vertex(const OracleScene* s, const GeomMeta* gm, const omat4* view_proj, const uint8_t* vtx, const float* instance_mat4,
-                         float* clip_out, float* nt_out) {
-    ovec3 pos = ov3(rd_f32(vtx + 0), rd_f32(vtx + 4), rd_f32(vtx + 8));
-    ovec3 normal = ov3(rd_f32(vtx + 24), rd_f32(vtx + 28), rd_f32(vtx + 32));
-    ovec4 tangent = ov4(rd_f32(vtx + 36), rd_f32(vtx + 40), rd_f32(vtx + 44), rd_f32(vtx + 48));
-    uint32_t vertex_index = rd_u32(vtx + 52);   /* original_vertex_index */
+/* apply_vertex.wgsl:24-118 for one vertex: position, normal, tangent and the vertex index that addresses the morph and skin
+ * data (the exploded 56-byte record of the geometry pass carries original_vertex_index, pipeline.rs:28-73; the indexed
+ * 40-byte vertices of the transparent pass use @builtin(vertex_index)).  wpos_out (may be NULL): world position xyz. */
+static void apply_vertex(const OracleScene* s, const GeomMeta* gm, const omat4* view_proj, ovec3 pos, ovec3 normal, ovec4 tangent,
+                         uint32_t vertex_index, const float* instance_mat4, float* clip_out, float* nt_out, float* wpos_out) {
 
     if (gm->morph_len != 0u) {                  /* morph.wgsl: weights read at [off/4 + 1 + i] (morph.wgsl:19) */
         const float* mw = (const float*)s->buf[AWSM_BUF_MORPH_WEIGHTS];
@@ -145,6 +144,7 @@ static void apply_vertex(const OracleScene* s, const GeomMeta* gm, const omat4* 
     clip_out[0] = clip.x; clip_out[1] = clip.y; clip_out[2] = clip.z; clip_out[3] = clip.w;
     nt_out[0] = world_normal.x; nt_out[1] = world_normal.y; nt_out[2] = world_normal.z; nt_out[3] = 0.0f;
     nt_out[4] = tangent_ortho.x; nt_out[5] = tangent_ortho.y; nt_out[6] = tangent_ortho.z; nt_out[7] = tangent.w;
+    if (wpos_out) { wpos_out[0] = world_pos.x; wpos_out[1] = world_pos.y; wpos_out[2] = world_pos.z; wpos_out[3] = 1.0f; }
 }
 
 int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out) {
@@ -158,8 +158,44 @@ int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out) {
         const uint32_t copies = dr->inst_count ? dr->inst_count : 1u;       /* draw_indexed(.., instance_count): instance after instance */
         for (uint32_t k = 0; k < copies; k++) {
             const float* inst = dr->inst_count ? (const float*)(s->buf[AWSM_BUF_INSTANCES] + dr->inst_off + 64u * k) : NULL;
-            for (uint32_t i = 0; i < 3u * dr->tri_count; i++, v++)
-                apply_vertex(s, &gm, &view_proj, base + (size_t)i * 56u, inst, clip_out + v * 4, nt_out + v * 8);
+            for (uint32_t i = 0; i < 3u * dr->tri_count; i++, v++) {
+                const uint8_t* vtx = base + (size_t)i * 56u;
+                apply_vertex(s, &gm, &view_proj, ov3(rd_f32(vtx + 0), rd_f32(vtx + 4), rd_f32(vtx + 8)), ov3(rd_f32(vtx + 24), rd_f32(vtx + 28), rd_f32(vtx + 32)),
+                             ov4(rd_f32(vtx + 36), rd_f32(vtx + 40), rd_f32(vtx + 44), rd_f32(vtx + 48)), rd_u32(vtx + 52), inst,
+                             clip_out + v * 4, nt_out + v * 8, NULL);
+            }
+        }
+    }
+    return 0;
+}
+
+/* Transparent pass vert_main (material_transparent_wgsl/vertex.wgsl:40-72): indexed draw of the mesh's 40-byte vertices
+ * (AWSM_BUF_TRANSPARENCY_GEOM_DATA at draw.vis_data_off) through the custom-attribute index buffer
+ * (meshes/mesh.rs:129-200).  Output is one vertex per triangle corner, in triangle order, like oracle_transform. */
+uint32_t oracle_forward_total_vertices(const AwsmDraw* draws, uint32_t n_draws) {
+    uint32_t n = 0;
+    for (uint32_t d = 0; d < n_draws; d++) n += 3u * draws[d].tri_count * (draws[d].inst_count ? draws[d].inst_count : 1u);
+    return n;
+}
+int oracle_forward_transform(const OracleScene* s, const AwsmDraw* draws, uint32_t n_draws, float* clip_out, float* nt_out, float* wpos_out) {
+    omat4 view_proj = omat4_load((const float*)(s->buf[AWSM_BUF_CAMERA] + 128));
+    size_t v = 0;
+    for (uint32_t d = 0; d < n_draws; d++) {
+        const AwsmDraw* dr = &draws[d];
+        GeomMeta gm = load_geom_meta(s, dr->geom_meta_off);
+        const uint8_t* mm = s->buf[AWSM_BUF_MATERIAL_META] + (size_t)(gm.material_meta_off / 256u) * 256u;
+        const uint32_t* index = (const uint32_t*)(s->buf[AWSM_BUF_ATTR_INDEX] + rd_u32(mm + 36));   /* custom_attribute_indices_offset */
+        const uint8_t* base = s->buf[AWSM_BUF_TRANSPARENCY_GEOM_DATA] + dr->vis_data_off;
+        const uint32_t copies = dr->inst_count ? dr->inst_count : 1u;
+        for (uint32_t k = 0; k < copies; k++) {
+            const float* inst = dr->inst_count ? (const float*)(s->buf[AWSM_BUF_INSTANCES] + dr->inst_off + 64u * k) : NULL;
+            for (uint32_t i = 0; i < 3u * dr->tri_count; i++, v++) {
+                const uint32_t vi = index[i];
+                const uint8_t* vtx = base + (size_t)vi * 40u;
+                apply_vertex(s, &gm, &view_proj, ov3(rd_f32(vtx + 0), rd_f32(vtx + 4), rd_f32(vtx + 8)), ov3(rd_f32(vtx + 12), rd_f32(vtx + 16), rd_f32(vtx + 20)),
+                             ov4(rd_f32(vtx + 24), rd_f32(vtx + 28), rd_f32(vtx + 32), rd_f32(vtx + 36)), vi, inst,
+                             clip_out + v * 4, nt_out + v * 8, wpos_out + v * 4);
+            }
         }
     }
     return 0;
@@ -176,15 +212,7 @@ int oracle_transform(const OracleScene* s, float* clip_out, float* nt_out) {
  *  kind 1, triangles that touch w <= 0 (they cross the near plane; close to the camera, hence large on screen and well
  *    conditioned): homogeneous clip-less edge functions, no geometric clipping; coefficients in f32, evaluated per sample
  *    with two fused multiply-adds in f64 (the same instruction sequence the exact kind uses on the device). */
-typedef struct {
-    int kind;
-    int64_t a[3], b[3], c[3];  /* kind 0: E_i(P) = a*Px + b*Py + c in 1/256-pixel units, sign-normalised (>= 0 inside), weight of vertex i */
-    float ha[3], hb[3], hc[3]; /* kind 1: e_i(X,Y) = fma(a, X, fma(b, Y, c)) in f64, X/Y in pixels */
-    float zq[3];               /* kind 0: (z_i / w_i) / |2*area| ; kind 1: z_i / det */
-    float iw[3];               /* kind 0: 1 / w_i (perspective correction of the attribute interpolation) ; kind 1: 1 (e_i already is) */
-    int minx, maxx, miny, maxy;  /* inclusive, conservative, clamped to the target rect */
-    int valid;
-} TriSetup;
+/* TriSetup: oracle_raster.h */
 
 static inline int finite4(const float* v) {
     return isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]);
@@ -227,6 +255,7 @@ static void tri_setup(const float* v0, const float* v1, const float* v2, int cul
         if (A2 == 0) return;
         if (cull_back && A2 > 0) return;
         const int64_t sgn = A2 < 0 ? -1 : 1;
+        t->front = A2 < 0;
         for (int i = 0; i < 3; i++) {
             const int j = (i + 1) % 3, k = (i + 2) % 3;          /* weight of vertex i = edge j -> k */
             t->a[i] = sgn * (y[j] - y[k]);
@@ -257,6 +286,7 @@ static void tri_setup(const float* v0, const float* v1, const float* v2, int cul
         float det = (X0 * a0 + Y0 * b0) + w0 * c0;
         if (!(det != 0.0f) || !isfinite(det)) return;   /* zero area or NaN */
         if (cull_back && det > 0.0f) return;            /* det < 0 <=> front facing */
+        t->front = det < 0.0f;
         if (det < 0.0f) {
             a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
             det = -det;
@@ -309,6 +339,19 @@ static inline int tri_sample(const TriSetup* t, int px, int py, int ox, int oy, 
     if (zn == 0.0f) zn = 0.0f;   /* canonicalise -0 so the bit pattern orders as an unsigned integer */
     *depth_out = zn;
     return 1;
+}
+
+/* the setup and the per-sample test, for the forward pass in oracle_shade.c */
+void oracle_tri_setup(const float* v0, const float* v1, const float* v2, int cull_back, uint32_t width, uint32_t height,
+                      uint32_t ry0, uint32_t ry1, TriSetup* t) { tri_setup(v0, v1, v2, cull_back, width, height, ry0, ry1, t); }
+int oracle_tri_sample(const TriSetup* t, int px, int py, int ox, int oy, float* depth_out) { return tri_sample(t, px, py, ox, oy, depth_out); }
+/* perspective-correct barycentrics of a pixel centre from an existing setup (what oracle_tri_bary_at computes) */
+void oracle_tri_bary(const TriSetup* t, int px, int py, float* b_out) {
+    float e[3];
+    (void)tri_edges_sample(t, px, py, 128, 128, e);
+    e[0] *= t->iw[0]; e[1] *= t->iw[1]; e[2] *= t->iw[2];
+    const float inv = 1.0f / ((e[0] + e[1]) + e[2]);
+    b_out[0] = e[0] * inv; b_out[1] = e[1] * inv; b_out[2] = e[2] * inv;
 }
 
 static void shard_rows(const OracleScene* s, uint32_t* y0, uint32_t* y1) {

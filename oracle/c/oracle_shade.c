@@ -22,6 +22,7 @@
  */
 #include "oracle.h"
 #include "oracle_math.h"
+#include "oracle_raster.h"
 #include <stdlib.h>
 
 int oracle_tri_bary_at(const float* v0, const float* v1, const float* v2, uint32_t width, uint32_t height,
@@ -214,6 +215,9 @@ typedef struct {
     ovec3 bary;
     int grad;                        /* MipmapMode::Gradient */
     ovec4 bary_derivs;               /* RGBA16F barycentric_derivatives texel: (db0/dx, db0/dy, db1/dx, db1/dy) */
+    int forward;                     /* transparent pass: material_transparent_wgsl/helpers/material_color_calc.wgsl instead of the opaque one */
+    uint32_t color_set_count;        /* forward only: COLOR_n sets in the mesh's vertex attributes */
+    int discard;                     /* forward only, out: ALPHA_MODE_MASK rejected the fragment */
 } AttrCtx;
 
 /* texture_uvs.wgsl:64-84 */
@@ -370,7 +374,7 @@ static ovec3 normal_map(const AttrCtx* a, const TexInfo* tex, float scale, const
 }
 
 /* material_color_calc.wgsl:25-265 pbr_get_material_color_no_mips */
-static PbrColor pbr_get_material_color(const AttrCtx* a, const uint32_t* m, const PbrMaterial* mat, const o_tbn* tbn) {
+static PbrColor pbr_get_material_color(AttrCtx* a, const uint32_t* m, const PbrMaterial* mat, const o_tbn* tbn) {
     float emissive_strength = mat->idx_emissive_strength == 0u ? 1.0f : mat_f32(m, mat->idx_emissive_strength);
     float ior = mat->idx_ior == 0u ? 1.5f : mat_f32(m, mat->idx_ior);
     PbrSpecular specular = load_specular(m, mat->idx_specular);
@@ -386,11 +390,27 @@ static PbrColor pbr_get_material_color(const AttrCtx* a, const uint32_t* m, cons
         ovec4 t = sample_tex(a, &mat->base_color_tex);
         base = ov4(base.x * t.x, base.y * t.y, base.z * t.z, base.w * t.w);
     }
-    base.w = 1.0f;
-    if (mat->idx_vertex_color != 0u) {            /* :56-66 */
-        uint32_t set_index = m[mat->idx_vertex_color];
-        ovec4 vc = vertex_color(a, set_index);
-        base = ov4(base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w);
+    if (!a->forward) {
+        base.w = 1.0f;
+        if (mat->idx_vertex_color != 0u) {            /* :56-66 */
+            uint32_t set_index = m[mat->idx_vertex_color];
+            ovec4 vc = vertex_color(a, set_index);
+            base = ov4(base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w);
+        }
+    } else {
+        /* transparent material_color_calc.wgsl:38-52: every mesh with colour sets multiplies (set 0 when the material names none;
+         * a set the mesh lacks reads as 1, vertex_color_attrib.wgsl:7-21); alpha is kept; ALPHA_MODE_MASK discards or forces 1 */
+        if (a->color_set_count != 0u) {
+            uint32_t set_index = mat->idx_vertex_color != 0u ? m[mat->idx_vertex_color] : 0u;
+            if (set_index < a->color_set_count) {
+                ovec4 vc = vertex_color(a, set_index);
+                base = ov4(base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w);
+            }
+        }
+        if (mat->alpha_mode == 1u) {
+            if (base.w < mat->alpha_cutoff) a->discard = 1;
+            else base.w = 1.0f;
+        }
     }
     c.base = base;
 
@@ -756,6 +776,18 @@ static ovec3 apply_lighting(const OracleScene* s, const PbrColor* mc, ovec3 surf
     return color;
 }
 
+/* lights.wgsl:155-188 */
+static ovec3 apply_lighting_with_transmission(const OracleScene* s, const PbrColor* mc, ovec3 surface_to_camera, ovec3 world_position,
+                                              uint32_t n_lights, ovec3 transmission_background) {
+    ovec3 color = brdf_ibl_with_transmission(s, mc, mc->normal, surface_to_camera, transmission_background);
+    const float* lights = (const float*)s->buf[AWSM_BUF_LIGHTS];
+    for (uint32_t i = 0; i < n_lights; i++) {
+        LightBrdf lb = light_to_brdf(lights + (size_t)i * 16, mc->normal, world_position);
+        color = ov3_add(color, brdf_direct(mc, &lb, surface_to_camera));
+    }
+    return color;
+}
+
 /* ---------------- material_mesh_meta.wgsl:6-28 (17 live words in a 256-B slot) ---------------- */
 typedef struct {
     uint32_t material_offset, transform_offset, normal_matrix_offset, attr_indices_offset, attr_data_offset,
@@ -860,6 +892,7 @@ static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const
     a.bary = barycentric;
     a.grad = s->mipmap != 0u;
     a.bary_derivs = g.bary_derivs;
+    a.forward = 0; a.color_set_count = 0; a.discard = 0;
     const uint32_t* attr_idx = (const uint32_t*)s->buf[AWSM_BUF_ATTR_INDEX];
     uint32_t base_tri = meta.attr_indices_offset / 4u + triangle_index * 3u;
     a.tri[0] = attr_idx[base_tri]; a.tri[1] = attr_idx[base_tri + 1]; a.tri[2] = attr_idx[base_tri + 2];
@@ -1036,6 +1069,264 @@ static void shade_pixel_msaa(const OracleScene* s, const float* clip, const floa
                         edge_mask_neighbors(s, clip, nt, keys, &inv_proj, cx, cy, world_normal);
     if (is_edge) { msaa_resolve(s, clip, nt, k4, cx, cy, rgba32f, rgba16f, p); return; }
     store_pixel(rgba32f, rgba16f, p, ov4(c.color.x, c.color.y, c.color.z, c.alpha));
+}
+
+/* ===============================================================================================================
+ * World transparent pass: render.rs:224-297 (opaque -> transparent blit, then the forward pass over the back-to-front
+ * list), material_transparent/pipeline.rs:96-110,182-190 (premultiplied "over" blend One / OneMinusSrcAlpha on colour and
+ * alpha; depth test LessEqual against the geometry pass's depth, depth write on; cull per mesh),
+ * material_transparent_wgsl/{vertex,fragment}.wgsl.
+ *
+ * Contract (the reference leaves these to the GPU):
+ *  - coverage, facing and depth: the raster contract of the geometry pass, same setup, per sample with MSAA;
+ *  - varyings: perspective-correct barycentrics of the PIXEL CENTRE (b_i as the opaque pass reconstructs them, unrounded),
+ *    every varying = (b0*v0 + b1*v1) + b2*v2;
+ *  - textureSample's implicit derivatives (MipmapMode::Gradient): "fine" differences of the barycentrics inside the 2x2
+ *    quad, evaluated for this triangle, then the opaque pass's chain rule and LOD (isotropic);
+ *  - the colour target is RGBA16F: the blend reads the stored f16 value, computes src + dst*(1 - a) in f32 and rounds to
+ *    f16 (nearest even); with MSAA x4 every covered sample that passes the depth test gets the fragment's colour and the
+ *    pass ends with the resolve, (((s0 + s1) + s2) + s3) * 0.25 rounded to f16;
+ *  - textureLoad(opaque_tex) outside the image (screen_uv == 1.0 exactly) clamps to the edge texel.
+ * =============================================================================================================== */
+#define FWD_BLUR_RINGS 3          /* material_transparent/shader/template.rs:170 */
+static ovec3 opaque_texel(const uint16_t* opaque, uint32_t W, uint32_t H, int x, int y) {
+    if (x < 0) x = 0;
+    if (y < 0) y = 0;
+    if (x > (int)W - 1) x = (int)W - 1;
+    if (y > (int)H - 1) y = (int)H - 1;
+    const uint16_t* p = opaque + ((size_t)y * W + (size_t)x) * 4;
+    return ov3(o_f16_to_f32(p[0]), o_f16_to_f32(p[1]), o_f16_to_f32(p[2]));
+}
+/* fragment.wgsl:27-186 */
+static ovec3 sample_transmission_background(const OracleScene* s, const uint16_t* opaque, float frag_x, float frag_y, ovec3 world_position,
+                                            ovec3 normal, ovec3 view_dir, float ior, float roughness, float thickness, const omat4* view_proj) {
+    const float Wf = (float)s->width, Hf = (float)s->height;
+    ovec2 screen_uv = ov2(frag_x / Wf, frag_y / Hf);
+    const float ior_val = effective_ior(ior);
+    if (thickness > 0.0f && ior_val != 1.0f) {
+        ovec3 refracted = refract_direction(view_dir, normal, 1.0f / ior_val);
+        if (ov3_dot(refracted, refracted) > 1e-6f) {
+            ovec3 exit = ov3_add(world_position, ov3_scale(ov3_normalize(refracted), thickness));
+            ovec4 clip_pos = omat4_mul_v4(view_proj, ov4(exit.x, exit.y, exit.z, 1.0f));
+            ovec2 ndc = ov2(clip_pos.x / clip_pos.w, clip_pos.y / clip_pos.w);
+            screen_uv = ov2((ndc.x + 1.0f) * 0.5f, (1.0f - ndc.y) * 0.5f);
+        }
+    }
+    if (screen_uv.x < 0.0f || screen_uv.x > 1.0f || screen_uv.y < 0.0f || screen_uv.y > 1.0f || screen_uv.x != screen_uv.x || screen_uv.y != screen_uv.y)
+        return sample_prefiltered(s);      /* IBL fallback: the cube is a uniform colour, direction and mip do not matter */
+    const float sx = screen_uv.x * Wf, sy = screen_uv.y * Hf;
+    const int tx = (int)sx, ty = (int)sy;
+    const float blur_roughness = roughness * o_clamp(ior * 2.0f - 2.0f, 0.0f, 1.0f);
+    if (FWD_BLUR_RINGS > 0 && blur_roughness > 0.05f) {
+        const float target_mip = log2f(Wf) * blur_roughness;
+        const float blur_radius = exp2f(o_clamp(target_mip, 0.0f, 8.0f));
+        static const float ring[8][2] = {{1.0f, 0.0f}, {0.707f, 0.707f}, {0.0f, 1.0f}, {-0.707f, 0.707f}, {-1.0f, 0.0f}, {-0.707f, -0.707f}, {0.0f, -1.0f}, {0.707f, -0.707f}};
+        const float sigma = blur_radius * 0.5f, sigma_sq_2 = 2.0f * sigma * sigma;
+        ovec3 sum = opaque_texel(opaque, s->width, s->height, tx, ty);
+        float wsum = 1.0f;
+        static const float rf[3] = {0.33f, 0.67f, 1.0f};
+        for (int k = 0; k < FWD_BLUR_RINGS; k++) {
+            const float r = blur_radius * rf[k];
+            const float w = expf(-(r * r) / sigma_sq_2);
+            for (int i = 0; i < 8; i++) {
+                const float fx = sx + ring[i][0] * r, fy = sy + ring[i][1] * r;
+                if (!(fabsf(fx) < 1e9f && fabsf(fy) < 1e9f)) continue;
+                const int cx = (int)fx, cy = (int)fy;           /* vec2<i32>(): truncation toward zero */
+                if (cx >= 0 && cx <= (int)s->width - 1 && cy >= 0 && cy <= (int)s->height - 1) {
+                    sum = ov3_add(sum, ov3_scale(opaque_texel(opaque, s->width, s->height, cx, cy), w));
+                    wsum += w;
+                }
+            }
+        }
+        return ov3_scale(sum, 1.0f / wsum);
+    }
+    return opaque_texel(opaque, s->width, s->height, tx, ty);
+}
+
+/* material_color_calc.wgsl:5-19 (transparent) */
+static ovec3 orthonormal_tangent_from_vertex(ovec3 normal, ovec3 tangent_xyz) {
+    ovec3 t = ov3_sub(tangent_xyz, ov3_scale(normal, ov3_dot(tangent_xyz, normal)));
+    float len_sq = ov3_dot(t, t);
+    if (len_sq > 1e-8f) return ov3_scale(t, o_inverse_sqrt(len_sq));
+    ovec3 axis = fabsf(normal.z) > 0.999f ? ov3(0.0f, 1.0f, 0.0f) : ov3(0.0f, 0.0f, 1.0f);
+    return ov3_normalize(ov3_cross(axis, normal));
+}
+
+typedef struct { const AwsmDraw* draws; uint32_t n_draws; const float* clip; const float* nt; const float* wpos; const uint16_t* opaque; } FwdPass;
+static uint32_t fwd_find_draw(const FwdPass* fp, uint32_t rank, uint32_t* first_rank) {
+    uint32_t acc = 0;
+    for (uint32_t d = 0; d < fp->n_draws; d++) {
+        const uint32_t tc = fp->draws[d].tri_count, copies = fp->draws[d].inst_count ? fp->draws[d].inst_count : 1u;
+        if (tc && rank < acc + tc * copies) { *first_rank = acc + ((rank - acc) / tc) * tc; return d; }
+        acc += tc * copies;
+    }
+    *first_rank = acc;
+    return fp->n_draws;
+}
+
+/* fs_main (fragment.wgsl:188-288) for triangle `rank` at the centre of pixel (px, py).  Returns 0 when the fragment is discarded,
+ * else the premultiplied colour in out[4]. */
+static int forward_fragment(const OracleScene* s, const FwdPass* fp, const TriSetup* ts, uint32_t rank, int px, int py, float* out) {
+    uint32_t first;
+    const uint32_t d = fwd_find_draw(fp, rank, &first);
+    const uint32_t triangle_index = rank - first;
+    const uint32_t material_meta_offset = rd_u32(s->buf[AWSM_BUF_GEOM_META] + fp->draws[d].geom_meta_off + 36);
+    const MaterialMeta meta = load_material_meta(s, material_meta_offset);
+    float b[3];
+    oracle_tri_bary(ts, px, py, b);
+    AttrCtx a;
+    a.s = s;
+    a.stride = meta.attr_stride / 4u;
+    a.attribute_data_offset = meta.attr_data_offset / 4u;
+    a.uv_sets_index = meta.uv_sets_index;
+    a.bary = ov3(b[0], b[1], b[2]);
+    a.grad = s->mipmap != 0u;
+    a.bary_derivs = ov4(0, 0, 0, 0);
+    a.forward = 1; a.color_set_count = meta.color_set_count; a.discard = 0;
+    if (a.grad) {
+        float bh[3], bv[3];
+        oracle_tri_bary(ts, px ^ 1, py, bh);
+        oracle_tri_bary(ts, px, py ^ 1, bv);
+        a.bary_derivs = ov4((px & 1) ? b[0] - bh[0] : bh[0] - b[0], (py & 1) ? b[0] - bv[0] : bv[0] - b[0],
+                            (px & 1) ? b[1] - bh[1] : bh[1] - b[1], (py & 1) ? b[1] - bv[1] : bv[1] - b[1]);
+    }
+    const uint32_t* attr_idx = (const uint32_t*)s->buf[AWSM_BUF_ATTR_INDEX];
+    const uint32_t base_tri = meta.attr_indices_offset / 4u + triangle_index * 3u;
+    a.tri[0] = attr_idx[base_tri]; a.tri[1] = attr_idx[base_tri + 1]; a.tri[2] = attr_idx[base_tri + 2];
+
+    /* varyings */
+    const float* n0 = fp->nt + (size_t)rank * 24; const float* n1 = n0 + 8; const float* n2 = n0 + 16;
+    const float* w0 = fp->wpos + (size_t)rank * 12; const float* w1 = w0 + 4; const float* w2 = w0 + 8;
+#define VARY(p0, p1, p2, k) ((b[0] * (p0)[k] + b[1] * (p1)[k]) + b[2] * (p2)[k])
+    ovec3 world_position = ov3(VARY(w0, w1, w2, 0), VARY(w0, w1, w2, 1), VARY(w0, w1, w2, 2));
+    ovec3 world_normal = ov3(VARY(n0, n1, n2, 0), VARY(n0, n1, n2, 1), VARY(n0, n1, n2, 2));
+    ovec4 world_tangent = ov4(VARY(n0, n1, n2, 4), VARY(n0, n1, n2, 5), VARY(n0, n1, n2, 6), VARY(n0, n1, n2, 7));
+#undef VARY
+    if (!ts->front) { world_normal = ov3_neg(world_normal); world_tangent.w = -world_tangent.w; }   /* fragment.wgsl:195-203 */
+
+    const uint8_t* cam = s->buf[AWSM_BUF_CAMERA];
+    omat4 proj = omat4_load((const float*)(cam + 64));
+    omat4 view_proj = omat4_load((const float*)(cam + 128));
+    omat4 inv_view = omat4_load((const float*)(cam + 320));
+    const float* cam_pos = (const float*)(cam + 384);
+    const int is_ortho = fabsf(proj.c[3].w - 1.0f) < 0.001f;            /* fragment.wgsl:205-215 */
+    ovec3 surface_to_camera = is_ortho ? ov3_normalize(ov3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z))
+                                       : ov3_normalize(ov3_sub(ov3(cam_pos[0], cam_pos[1], cam_pos[2]), world_position));
+
+    /* material_color_calc.wgsl:125-153 (pbr_normal) / :283-311 (clearcoat): N, T, B from the interpolated varyings */
+    o_tbn tbn;
+    tbn.N = ov3_normalize(world_normal);
+    tbn.T = orthonormal_tangent_from_vertex(tbn.N, ov3(world_tangent.x, world_tangent.y, world_tangent.z));
+    tbn.B = ov3_scale(ov3_cross(tbn.N, tbn.T), world_tangent.w);
+
+    const uint32_t* materials = (const uint32_t*)s->buf[AWSM_BUF_MATERIALS];
+    const uint32_t material_offset = meta.material_offset;
+    const uint32_t shader_id = materials[material_offset / 4u];
+    const uint32_t n_lights = rd_u32(s->buf[AWSM_BUF_LIGHTS_INFO]);
+    ovec3 color; float base_alpha;
+    if (shader_id == 2u) {     /* unlit: material_color_calc.wgsl:344-372 + unlit.wgsl compute_unlit_output */
+        uint32_t bb = material_offset / 4u + 1u;
+        const uint32_t alpha_mode = materials[bb + 0]; const float alpha_cutoff = mat_f32(materials, bb + 1);
+        TexInfo base_tex = tex_info_load(materials, bb + 2);
+        ovec4 base = ov4(mat_f32(materials, bb + 7), mat_f32(materials, bb + 8), mat_f32(materials, bb + 9), mat_f32(materials, bb + 10));
+        TexInfo em_tex = tex_info_load(materials, bb + 11);
+        ovec3 em = ov3(mat_f32(materials, bb + 16), mat_f32(materials, bb + 17), mat_f32(materials, bb + 18));
+        if (base_tex.exists) { ovec4 t = sample_tex(&a, &base_tex); base = ov4(base.x * t.x, base.y * t.y, base.z * t.z, base.w * t.w); }
+        if (alpha_mode == 1u) { if (base.w < alpha_cutoff) return 0; base.w = 1.0f; }
+        if (em_tex.exists) { ovec4 t = sample_tex(&a, &em_tex); em = ov3(em.x * t.x, em.y * t.y, em.z * t.z); }
+        color = ov3(base.x + em.x, base.y + em.y, base.z + em.z);
+        base_alpha = base.w;
+    } else {
+        PbrMaterial mat = pbr_get_material(materials, material_offset);
+        PbrColor mc = pbr_get_material_color(&a, materials, &mat, &tbn);
+        if (a.discard) return 0;
+        const float metallic = o_clamp(mc.metallic_roughness.x, 0.0f, 1.0f);
+        const float effective_transmission = mc.transmission * (1.0f - metallic);
+        if (mat.debug_bitmask != 0u) {
+            color = pbr_debug_material_color(mat.debug_bitmask, &mc);
+        } else if (effective_transmission > 0.0f) {
+            const float roughness = fmaxf(o_clamp(mc.metallic_roughness.y, 0.0f, 1.0f), 0.04f);
+            ovec3 bg = sample_transmission_background(s, fp->opaque, (float)px + 0.5f, (float)py + 0.5f, world_position, mc.normal, ov3_neg(surface_to_camera),
+                                                      mc.ior, roughness, mc.volume_thickness, &view_proj);
+            color = apply_lighting_with_transmission(s, &mc, surface_to_camera, world_position, n_lights, bg);
+        } else {
+            color = apply_lighting(s, &mc, surface_to_camera, world_position, n_lights);
+        }
+        base_alpha = mc.base.w;
+    }
+    out[0] = color.x * base_alpha; out[1] = color.y * base_alpha; out[2] = color.z * base_alpha; out[3] = base_alpha;   /* fragment.wgsl:283-285 */
+    return 1;
+}
+
+/* keys: the geometry pass's visibility/depth (S samples per pixel); opaque16f: the opaque pass's image.  composite outputs:
+ * the resolved image after the transparent pass (the reference's `composite` target), f32 copy of the f16 values + the halfs;
+ * touched_out (may be NULL): 1 for every pixel at least one fragment was blended into. */
+int oracle_forward(const OracleScene* s, const AwsmDraw* draws, uint32_t n_draws, const float* clip, const float* nt, const float* wpos,
+                   const uint64_t* keys, const uint16_t* opaque16f, float* composite32f_out, uint16_t* composite16f_out, uint8_t* touched_out, int threads) {
+    const uint32_t W = s->width, H = s->height;
+    if (touched_out) memset(touched_out, 0, (size_t)W * H);
+    const uint32_t S = s->msaa == 4u ? 4u : 1u;
+    FwdPass fp; fp.draws = draws; fp.n_draws = n_draws; fp.clip = clip; fp.nt = nt; fp.wpos = wpos; fp.opaque = opaque16f;
+    float* depth = (float*)malloc((size_t)W * H * S * sizeof(float));
+    float* color = (float*)malloc((size_t)W * H * S * 4 * sizeof(float));
+    if (!depth || !color) { free(depth); free(color); return -2; }
+    for (size_t p = 0; p < (size_t)W * H; p++)
+        for (uint32_t k = 0; k < S; k++) {
+            depth[p * S + k] = key_depth(keys[p * S + k]);                 /* depth LoadOp::Load (render.rs:474-478) */
+            for (int c = 0; c < 4; c++) color[(p * S + k) * 4 + c] = o_f16_to_f32(opaque16f[p * 4 + c]);   /* opaque -> transparent blit, every sample */
+        }
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (int band = 0; band < threads * 4; band++) {
+        const uint32_t by0 = (uint32_t)(((uint64_t)H * (uint64_t)band) / (uint64_t)(threads * 4));
+        const uint32_t by1 = (uint32_t)(((uint64_t)H * (uint64_t)(band + 1)) / (uint64_t)(threads * 4));
+        if (by0 >= by1) continue;
+        uint32_t rank = 0;
+        for (uint32_t d = 0; d < n_draws; d++) {
+            const AwsmDraw* dr = &draws[d];
+            const int cull_back = (dr->flags & AWSM_DRAW_CULL_BACK) != 0;
+            const uint32_t copies = dr->inst_count ? dr->inst_count : 1u;
+            for (uint32_t t = 0; t < dr->tri_count * copies; t++, rank++) {
+                const float* v = clip + (size_t)rank * 12;
+                TriSetup ts;
+                oracle_tri_setup(v, v + 4, v + 8, cull_back, W, H, 0, H, &ts);
+                if (!ts.valid) continue;
+                const int y_lo = ts.miny < (int)by0 ? (int)by0 : ts.miny;
+                const int y_hi = ts.maxy > (int)by1 - 1 ? (int)by1 - 1 : ts.maxy;
+                for (int py = y_lo; py <= y_hi; py++)
+                    for (int px = ts.minx; px <= ts.maxx; px++) {
+                        const size_t p = (size_t)py * W + (size_t)px;
+                        float z[4]; uint32_t mask = 0;
+                        for (uint32_t k = 0; k < S; k++) {
+                            const int ox = S == 1u ? 128 : oracle_msaa4_x[k], oy = S == 1u ? 128 : oracle_msaa4_y[k];
+                            if (oracle_tri_sample(&ts, px, py, ox, oy, &z[k]) && z[k] <= depth[p * S + k]) mask |= 1u << k;   /* LessEqual */
+                        }
+                        if (!mask) continue;
+                        float src[4];
+                        if (!forward_fragment(s, &fp, &ts, rank, px, py, src)) continue;      /* discard: neither colour nor depth */
+                        const float om = 1.0f - src[3];
+                        if (touched_out) touched_out[p] = 1;
+                        for (uint32_t k = 0; k < S; k++) {
+                            if (!(mask & (1u << k))) continue;
+                            depth[p * S + k] = z[k];
+                            float* dst = color + (p * S + k) * 4;
+                            for (int c = 0; c < 4; c++) dst[c] = o_round_f16(src[c] + dst[c] * om);
+                        }
+                    }
+            }
+        }
+    }
+    for (size_t p = 0; p < (size_t)W * H; p++) {
+        float r[4];
+        for (int c = 0; c < 4; c++) {
+            if (S == 1u) r[c] = color[p * 4 + c];
+            else r[c] = o_round_f16((((color[(p * 4 + 0) * 4 + c] + color[(p * 4 + 1) * 4 + c]) + color[(p * 4 + 2) * 4 + c]) + color[(p * 4 + 3) * 4 + c]) * 0.25f);
+        }
+        if (composite32f_out) for (int c = 0; c < 4; c++) composite32f_out[p * 4 + c] = r[c];
+        if (composite16f_out) for (int c = 0; c < 4; c++) composite16f_out[p * 4 + c] = o_f32_to_f16(r[c]);
+    }
+    free(depth); free(color);
+    return 0;
 }
 
 int oracle_shade(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,

@@ -13,7 +13,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "liboracle.so")
-BUF_COUNT = 18
+BUF_COUNT = 19
 MAX_TEX = 64
 MAX_SAMPLERS = 32
 
@@ -183,6 +183,29 @@ class OracleFrame:
 
     def run(self, threads=8):
         return self.transform().raster(threads).shade(threads)
+
+    def forward(self, draws: List[dict], threads=8):
+        """World transparent pass over `draws` (HostModel.collect_transparent_draws()), after run(): fills fwd_clip / fwd_nt / fwd_wpos
+        and the composite image (composite32f holds the f16 values, composite16f their bits)."""
+        L = lib()
+        arr = (AwsmDraw * max(1, len(draws)))()
+        for i, d in enumerate(draws):
+            arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], d.get("inst_off", 0), d.get("inst_count", 0))
+        n = len(draws)
+        L.oracle_forward_total_vertices.restype = C.c_uint32
+        nv = int(L.oracle_forward_total_vertices(arr, C.c_uint32(n)))
+        self.fwd_n_verts = nv
+        self.fwd_clip = np.zeros((max(1, nv), 4), dtype=np.float32)
+        self.fwd_nt = np.zeros((max(1, nv), 8), dtype=np.float32)
+        self.fwd_wpos = np.zeros((max(1, nv), 4), dtype=np.float32)
+        self.composite32f = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self.composite16f = np.zeros((self.height, self.width, 4), dtype=np.uint16)
+        self.fwd_touched = np.zeros((self.height, self.width), dtype=np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        assert L.oracle_forward_transform(C.byref(self.scene), arr, C.c_uint32(n), p(self.fwd_clip), p(self.fwd_nt), p(self.fwd_wpos)) == 0
+        assert L.oracle_forward(C.byref(self.scene), arr, C.c_uint32(n), p(self.fwd_clip), p(self.fwd_nt), p(self.fwd_wpos), p(self.keys), p(self.rgba16f),
+                                p(self.composite32f), p(self.composite16f), p(self.fwd_touched), C.c_int(threads)) == 0
+        return self
 
     def unpack_visibility(self):
         tri = np.zeros(self.keys.shape, dtype=np.uint32)

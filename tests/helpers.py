@@ -19,7 +19,7 @@ def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0, mi
     return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap).run(threads)
 
 
-def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False):
+def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False, transparent=False):
     """Drive one frame through the C-ABI exactly as the host layer does: create+write every mirror, then the passes."""
     from awsm_renderer_amd.hip_backend import HipDevice
     sc = model.scene
@@ -40,6 +40,8 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap
     draws = model.collect_draws()
     dev.geometry_pass(draws)
     dev.opaque_pass(has_opaque=has_opaque, mipmap=1 if mipmap else 0)
+    if transparent:
+        dev.transparent_pass(model.collect_transparent_draws())
     stats = dev.frame_end()
     return dev, stats
 
@@ -55,6 +57,29 @@ def host_frame(scene, lut, rows=(0, 0), msaa=0, mipmap=False):
     dev = HipDevice.from_ctx(r.host.device_ctx, scene.width, scene.height)
     dev.msaa = msaa
     return r, dev, stats
+
+
+def compare_composite(orc, dev):
+    """The image after the transparent pass.  Both sides store f16 at every blend, so the comparison is in f16 steps."""
+    out = {}
+    nv = orc.fwd_n_verts
+    clip, nt, wpos = dev.read_transformed_forward(nv)
+    out["clip_mismatch"] = int((clip.view(np.uint32) != orc.fwd_clip.view(np.uint32)).any(axis=1).sum()) if nv else 0
+    out["nt_mismatch"] = int((nt.view(np.uint32) != orc.fwd_nt.view(np.uint32)).any(axis=1).sum()) if nv else 0
+    out["wpos_mismatch"] = int((wpos.view(np.uint32) != orc.fwd_wpos.view(np.uint32)).any(axis=1).sum()) if nv else 0
+    h16 = dev.read_composite()
+    ulp = f16_ulp_distance(h16, orc.composite16f)
+    touched = orc.fwd_touched != 0
+    out["touched_pixels"] = int(touched.sum())
+    out["untouched_changed"] = int((h16 != dev.read_opaque())[~touched].any(axis=-1).sum()) if (~touched).any() else 0   # a copy of the device's own opaque image
+    out["max_ulp"] = int(ulp.max())
+    out["pixels_over_2ulp"] = int((ulp > 2).any(axis=-1).sum())
+    ref = orc.composite32f.astype(np.float64)
+    f32 = dev.read_composite_f32().astype(np.float64)
+    bound = 2e-3 * np.maximum(1.0, np.abs(ref))      # 2 f16 steps of a value near 1 (f16 has 11 significant bits)
+    out["pixels_over_bound"] = int((np.abs(f32 - ref) > bound).any(axis=-1).sum())
+    out["alpha_mismatch"] = int((h16[..., 3] != orc.composite16f[..., 3]).sum())
+    return out
 
 
 def f16_ulp_distance(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:

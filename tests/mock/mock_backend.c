@@ -8,7 +8,7 @@
 #include <string.h>
 #include "../../include/awsm_hip.h"
 
-typedef struct MockCall { int op; int which; uint64_t a, b; } MockCall;   /* op: 1 create, 2 write, 3 resize, 4 texture, 5 sampler, 6 env, 7 geometry, 8 opaque, 9 frame_end, 10 lut, 11 shard */
+typedef struct MockCall { int op; int which; uint64_t a, b; } MockCall;   /* op: 1 create, 2 write, 3 resize, 4 texture, 5 sampler, 6 env, 7 geometry, 8 opaque, 9 frame_end, 10 lut, 11 shard, 15 transparent */
 struct AwsmHipCtx {
     uint8_t* buf[AWSM_BUF_COUNT]; size_t size[AWSM_BUF_COUNT];
     MockCall* log; size_t n_log, cap_log;
@@ -50,6 +50,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) {
     logc(c, 7, 0, n, 0); return 0;
 }
 int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) { c->has_opaque = p->has_opaque; logc(c, 8, 0, p->has_opaque, p->mipmap); return 0; }
+int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) { (void)d; logc(c, 15, 0, n, 0); return 0; }
 int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* s) { if (s) memset(s, 0, sizeof *s); logc(c, 9, 0, 0, 0); return 0; }
 /* ---- inspection ---- */
 size_t mock_log_count(AwsmHipCtx* c) { return c->n_log; }

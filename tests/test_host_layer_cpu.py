@@ -15,7 +15,7 @@ from tests import helpers
 
 MOCK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock")
 MOCK = os.path.join(MOCK_DIR, "libmock_backend.so")
-OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips"}
+OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips", 15: "transparent"}
 
 
 @pytest.fixture(scope="module")
@@ -88,10 +88,33 @@ def test_write_gpu_order_and_frame_sequence(mock):
     creates = [w for op, w, _, _ in log if op == "create"]
     assert creates == [sm.BUF_TRANSFORMS, sm.BUF_NORMAL_MATS, sm.BUF_MATERIALS, sm.BUF_LIGHTS, sm.BUF_LIGHTS_INFO, sm.BUF_SKIN_MATRICES,
                        sm.BUF_SKIN_INDEX_WEIGHTS, sm.BUF_MORPH_WEIGHTS, sm.BUF_MORPH_VALUES, sm.BUF_GEOM_META, sm.BUF_MATERIAL_META,
-                       sm.BUF_TEXTURE_TRANSFORMS, sm.BUF_VIS_GEOM_DATA, sm.BUF_ATTR_DATA, sm.BUF_ATTR_INDEX, sm.BUF_CAMERA]
-    tail = [op for op, _, _, _ in log if op in ("geometry", "opaque", "frame_end")]
-    assert tail == ["geometry", "opaque", "frame_end"]
+                       sm.BUF_TEXTURE_TRANSFORMS, sm.BUF_VIS_GEOM_DATA, sm.BUF_TRANSPARENCY_GEOM_DATA, sm.BUF_ATTR_DATA, sm.BUF_ATTR_INDEX, sm.BUF_CAMERA]   # meshes.rs:1240-1300
+    tail = [op for op, _, _, _ in log if op in ("geometry", "opaque", "transparent", "frame_end")]
+    assert tail == ["geometry", "opaque", "frame_end"]          # no transparent mesh in the scene: the composite is the opaque image
     assert [op for op, _, _, _ in log].index("geometry") > max(i for i, (op, _, _, _) in enumerate(log) if op in ("create", "write", "texture"))
+    r.close()
+
+
+def test_transparent_meshes_get_transparency_geometry_and_their_own_pass(mock):
+    """gltf/buffers/mesh.rs:33-57 (visibility XOR transparency geometry by material), renderable.rs:78-90,131-135 (own list, back to
+    front), render.rs:224-297 (the pass after the opaque pass)."""
+    scene = scenes.transparent_scene(96, 64, tex_size=16)
+    model = helpers.build_model(scene)
+    r = H.Renderer(scene, backend_path=MOCK, lut_rgba16f=np.zeros((4, 4, 4), dtype=np.uint16))
+    ctx = r.host.device_ctx
+    mock.mock_log_clear(ctx)
+    r.render()
+    for which in (sm.BUF_MATERIALS, sm.BUF_VIS_GEOM_DATA, sm.BUF_TRANSPARENCY_GEOM_DATA, sm.BUF_ATTR_INDEX, sm.BUF_ATTR_DATA, sm.BUF_MATERIAL_META, sm.BUF_GEOM_META,
+                  sm.BUF_MORPH_VALUES, sm.BUF_INSTANCES):
+        assert r.host.mirror(which) == bytes(model.mirrors()[which]), f"mirror {which} differs"
+        assert device_bytes(mock, ctx, which) == bytes(model.mirrors()[which])
+    strip = lambda ds: [{k: v for k, v in d.items() if k != "mesh_key"} for d in ds]   # noqa: E731
+    assert r.host.draw_list() == strip(model.collect_draws())
+    want_tr = strip(model.collect_transparent_draws())
+    assert len(want_tr) >= 10 and r.host.transparent_draw_list() == want_tr
+    log = log_of(mock, ctx)
+    assert [op for op, _, _, _ in log if op in ("geometry", "opaque", "transparent", "frame_end")] == ["geometry", "opaque", "transparent", "frame_end"]
+    assert [a for op, _, a, _ in log if op == "transparent"] == [len(want_tr)]
     r.close()
 
 
