@@ -583,7 +583,8 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     o.material_word = mm[6] / 4u;
     o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
     o.uv_sets_index = mm[12];
-    o.is_hud = mm[16];
+    // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments, so their depth write waits for the shading)
+    o.is_hud = (mm[16] & 1u) | (reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS])[mm[6] / 4u + 1u] == 1u ? 2u : 0u);
     o.color_sets = mm[14];
     f.draw_shade[d] = o;
 }
@@ -801,7 +802,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
     const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, is_hud
     const uint32_t triangle_index = rank - ds0.x;
-    if (check_hud && ds1.z == 1u) { out.kind = 2u; return out; }   // is_hud (compute.wgsl:176-179); msaa_process_sample has no such test
+    if (check_hud && (ds1.z & 1u)) { out.kind = 2u; return out; }   // is_hud (compute.wgsl:176-179); msaa_process_sample has no such test
     const uint32_t material_word = ds0.y;
     const uint32_t attr_indices_off = ds0.z, attr_data_off = ds0.w, stride = ds1.x, uv_sets_index = ds1.y;
 
@@ -847,11 +848,12 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
 // material_transparent_wgsl/fragment.wgsl) for one 32x32 tile.
 //
 // Blending is order dependent: fragments must reach a pixel in submission order (the host sorts the meshes back to front,
-// renderable.rs:90,131-135).  One workgroup owns the tile and every thread owns one 2x2 quad of it, so a pixel's
-// read-modify-write chain lives in one thread — no atomics, no locks — and the whole workgroup walks the tile's triangle
-// list in rank order.  The binner appends ranks to a tile's list in no particular order; they are sorted here for free:
+// renderable.rs:90,131-135).  One wavefront owns an 8x8 block of the tile and every lane one pixel of it, so a pixel's
+// read-modify-write chain lives in one lane's registers — no atomics, no locks — and the wavefront walks the triangles of
+// the tile's list that touch its block in rank order (coverage and depth first; the shading is queued per lane and run a
+// wavefront at a time).  The binner appends ranks to a tile's list in no particular order; they are sorted here for free:
 // ranks are unique, so setting bit (rank - base) of an LDS bitmap and scanning the bitmap IS the sorted list (windows of
-// kFwdWindow ranks).  Per-sample depth and colour of the tile stay in LDS for the whole pass (the multisampled colour
+// kFwdWindow ranks).  Per-sample depth and colour stay in registers for the whole pass (the multisampled colour
 // target of the reference never exists in HBM): initialised from the geometry pass's depth and the opaque image
 // (the opaque -> transparent blit), blended in place, resolved and written once.
 //
@@ -922,121 +924,180 @@ AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const Frame
     return shade_material<GRAD, true>(sc, f, a, ds0.y, tbn, world_position, surface_to_camera, ds1.w, (float)px + 0.5f, (float)py + 0.5f);
 }
 
+// A fragment that passed coverage and the depth test, waiting to be shaded: triangle, which samples, their depths.
+// flags = deferred_depth | sample_mask << 4.
+template <int S> struct FwdFrag { uint32_t rank, flags; float z[S]; };
+constexpr uint32_t kFwdFifo = 8;            // queue entries per thread
+constexpr int kFwdBlock = 8;                // one wavefront owns an 8x8 pixel block of the binning tile, one pixel per lane
+
+template <int S> struct FwdPixel { float depth[S]; uint2 color[S]; };    // the lane's pixel: per-sample depth and RGBA16F colour, in registers
+
+// Shade and blend the wavefront's pending fragments: round j takes entry j of every lane that has one.  Lanes work on
+// different triangles, each in its own submission order — the order per pixel is what blending needs.
 template <int S, bool GRAD>
-__global__ __launch_bounds__(256) void k_forward_tile(const DevScene* __restrict__ sc, FrameDev f) {
-    __shared__ float sdepth[kTile * kTile * S];
-    __shared__ uint2 scolor[kTile * kTile * S];          // RGBA16F, as the target stores it
+AWSM_DI void forward_flush(const DevScene* __restrict__ sc, const FrameDev& f, const FwdFrag<S>* fifo, uint32_t& n_pending, FwdPixel<S>& pix, int px, int py) {
+    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < n_pending) != 0ull; j++) {
+        if (j >= n_pending) continue;
+        const FwdFrag<S> e = fifo[j * 64u];
+        const uint32_t mask = e.flags >> 4;
+        TriSetup t;
+        tri_rec_load(f.tri_rec + e.rank, t);
+        const SurfaceOut o = forward_fragment<GRAD>(sc, f, t, e.rank, px, py);
+        if (o.discard) continue;                                                         // neither colour nor depth
+        const float a = o.color.w, om = 1.0f - a;
+        const float sr = o.color.x * a, sg = o.color.y * a, sb = o.color.z * a;          // fragment.wgsl:283-285 premultiplied
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (!(mask & (1u << s))) continue;
+            if (e.flags & 1u) pix.depth[s] = e.z[s];
+            const uint2 d = pix.color[s];
+            const float r = blend_over_f16(sr, f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)), om);
+            const float g = blend_over_f16(sg, f16_bits_to_f32((unsigned short)(d.x >> 16)), om);
+            const float b = blend_over_f16(sb, f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)), om);
+            const float al = blend_over_f16(a, f16_bits_to_f32((unsigned short)(d.y >> 16)), om);
+            pix.color[s] = make_uint2((uint32_t)f16_bits(r) | ((uint32_t)f16_bits(g) << 16), (uint32_t)f16_bits(b) | ((uint32_t)f16_bits(al) << 16));
+        }
+    }
+    n_pending = 0u;
+}
+
+// does triangle `rank` (its setup record's bbox) touch the block [bx0, bx0+8) x [by0, by0+8) ?
+AWSM_DI bool forward_block_hit(const FrameDev& f, uint32_t rank, int bx0, int by0) {
+    const uint32_t bx = f.tri_rec[rank].bbox_x, by = f.tri_rec[rank].bbox_y;
+    const int x0 = (int)(bx & 0xFFFFu), x1 = (int)(bx >> 16), y0 = (int)(by & 0xFFFFu), y1 = (int)((by >> 16) & 0x7FFFu);
+    return x0 <= x1 && x1 >= bx0 && x0 < bx0 + kFwdBlock && y1 >= by0 && y0 < by0 + kFwdBlock;
+}
+
+template <int S, bool GRAD>
+__global__ __launch_bounds__(64) void k_forward_tile(const DevScene* __restrict__ sc, FrameDev f) {
+    constexpr uint32_t D = kFwdFifo;
+    __shared__ FwdFrag<S> fifo_all[D * 64];              // [entry][lane]
     __shared__ uint32_t bitmap[kFwdWindow / 32];
     __shared__ uint32_t rmin, rmax;
 
-    const uint32_t tile = f.tile_order[blockIdx.x];
-    const uint32_t tid = threadIdx.x;
-    const int tpx = (int)(tile % f.tiles_x) << kTileShift;
-    const int tpy = (int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift;
-    const int qx = (int)(tid & 15u) * 2, qy = (int)(tid >> 4) * 2;        // this thread's 2x2 quad, tile-local
+    const uint32_t tile = f.tile_order[blockIdx.x >> 4];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x & 15u;
+    const int bx0 = ((int)(tile % f.tiles_x) << kTileShift) + (int)(blk & 3u) * kFwdBlock;                       // origin of this wavefront's block
+    const int by0 = ((int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift) + (int)(blk >> 2) * kFwdBlock;
+    const int px = bx0 + (int)(tid & 7u), py = by0 + (int)(tid >> 3);
+    const bool in_frame = px < (int)f.width && py < (int)f.height;
+    if (__builtin_amdgcn_ballot_w64(in_frame) == 0ull) return;
+    const FwdFrag<S>* fifo = fifo_all + tid;
+    uint32_t n_pending = 0u;
 
     // opaque -> transparent blit (every sample gets the opaque colour) + depth LoadOp::Load
+    FwdPixel<S> pix;
+    {
+        const size_t p = in_frame ? (size_t)py * f.width + (size_t)px : 0;
+        const uint2 c = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int lx = qx + (q & 1), ly = qy + (q >> 1), px = tpx + lx, py = tpy + ly;
-        const int li = (ly * kTile + lx) * S;
-        if (px < (int)f.width && py < (int)f.height) {
-            const size_t p = (size_t)py * f.width + (size_t)px;
-            const uint2 c = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];
-#pragma unroll
-            for (int s = 0; s < S; s++) { sdepth[li + s] = key_depth(f.vis[p * S + s]); scolor[li + s] = c; }
-        }
+        for (int s = 0; s < S; s++) { pix.depth[s] = in_frame ? key_depth(f.vis[p * S + s]) : -1.0f; pix.color[s] = c; }   // out-of-frame lanes fail every depth test
     }
-    if (tid == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; }
-    __syncthreads();
     const uint32_t off = f.tile_offset[tile];
     const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, off));
-    {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        for (uint32_t i = tid; i < count; i += 256u) { const uint32_t r = f.bin_list[off + i]; lo = min(lo, r); hi = max(hi, r); }
-        if (lo <= hi) { atomicMin(&rmin, lo); atomicMax(&rmax, hi); }
-    }
-    __syncthreads();
-    const uint32_t r_lo = rmin, r_hi = rmax;
-    if (count) for (uint32_t wbase = r_lo - (r_lo % kFwdWindow); wbase <= r_hi; wbase += kFwdWindow) {
-        for (uint32_t i = tid; i < kFwdWindow / 32; i += 256u) bitmap[i] = 0u;
+    if (count) {
+        if (tid == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; }
         __syncthreads();
-        for (uint32_t i = tid; i < count; i += 256u) {
-            const uint32_t r = f.bin_list[off + i] - wbase;      // unsigned: ranks below the window wrap to huge values
-            if (r < kFwdWindow) atomicOr(&bitmap[r >> 5], 1u << (r & 31u));
+        {   // rank range of the tile's triangles that touch this block
+            uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+            for (uint32_t i = tid; i < count; i += 64u) {
+                const uint32_t r = f.bin_list[off + i];
+                if (forward_block_hit(f, r, bx0, by0)) { lo = min(lo, r); hi = max(hi, r); }
+            }
+            if (lo <= hi) { atomicMin(&rmin, lo); atomicMax(&rmax, hi); }
         }
         __syncthreads();
-        for (uint32_t w = 0; w < kFwdWindow / 32; w++) {
-            uint32_t bits = bitmap[w];                           // same word in every lane: the loop is uniform
-            while (bits) {
-                const uint32_t bit = (uint32_t)__builtin_ctz(bits);
-                bits &= bits - 1u;
-                const uint32_t rank = wbase + w * 32u + bit;
-                TriSetup t;
-                if (!tri_rec_load(f.tri_rec + rank, t)) continue;
-#pragma unroll 1
-                for (int q = 0; q < 4; q++) {
-                    const int lx = qx + (q & 1), ly = qy + (q >> 1), px = tpx + lx, py = tpy + ly;
-                    const int li = (ly * kTile + lx) * S;
+        const uint32_t r_lo = rmin, r_hi = rmax;
+        if (r_lo <= r_hi) for (uint32_t wbase = r_lo - (r_lo % kFwdWindow); wbase <= r_hi; wbase += kFwdWindow) {
+            const uint32_t n_words = min(kFwdWindow, r_hi - wbase + 1u + 31u) / 32u;       // words that can hold a bit
+            for (uint32_t i = tid; i < n_words; i += 64u) bitmap[i] = 0u;
+            __syncthreads();
+            for (uint32_t i = tid; i < count; i += 64u) {
+                const uint32_t r = f.bin_list[off + i], rr = r - wbase;      // unsigned: ranks below the window wrap to huge values
+                if (rr < kFwdWindow && forward_block_hit(f, r, bx0, by0)) atomicOr(&bitmap[rr >> 5], 1u << (rr & 31u));
+            }
+            __syncthreads();
+            // Coverage + depth run ahead of the shading: a fragment that passes is queued (its depth is written at once unless the
+            // material can discard), and the wavefront shades its queues when one is full — lanes on different triangles —
+            // instead of running the material code once per triangle for the few lanes that triangle covers.  The walk over
+            // the bitmap is a scalar iterator (64 words per step, one per lane; the non-empty ones are visited in order through
+            // the ballot mask) so that the material code has ONE call site: fill the queues, flush, repeat.
+            uint32_t wc = 0u, my_word = 0u, word_index = 0u, bits = 0u, carry = 0u;
+            unsigned long long nz = 0ull;
+            bool have_carry = false, exhausted = false;
+            for (;;) {
+                for (;;) {      // fill: next triangle until a queue cannot take its fragment, a discardable fragment was queued, or the window ends
+                    uint32_t rank;
+                    if (have_carry) { rank = carry; have_carry = false; }
+                    else {
+                        while (bits == 0u && !exhausted) {
+                            if (nz == 0ull) {
+                                if (wc >= n_words) { exhausted = true; break; }
+                                my_word = wc + tid < n_words ? bitmap[wc + tid] : 0u;
+                                nz = __builtin_amdgcn_ballot_w64(my_word != 0u);
+                                wc += 64u;
+                                continue;
+                            }
+                            const uint32_t wl = (uint32_t)__builtin_ctzll(nz);
+                            nz &= nz - 1ull;
+                            bits = (uint32_t)__builtin_amdgcn_readlane((int)my_word, (int)wl);
+                            word_index = wc - 64u + wl;
+                        }
+                        if (exhausted) break;
+                        const uint32_t bit = (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        rank = wbase + word_index * 32u + bit;
+                    }
+                    TriSetup t;
+                    if (!tri_rec_load(f.tri_rec + rank, t)) continue;
+                    const bool may_discard = (f.draw_shade[f.tri_info[rank] & 0x00FFFFFFu].is_hud & 2u) != 0u;     // ALPHA_MODE_MASK
                     uint32_t mask = 0u;
                     float z[S];
-                    if (px >= t.minx && px <= t.maxx && py >= t.miny && py <= t.maxy) {     // bbox is clamped to the frame
 #pragma unroll
-                        for (int s = 0; s < S; s++) {
-                            const int ox = S == 1 ? 128 : msaa4_x(s), oy = S == 1 ? 128 : msaa4_y(s);
-                            const unsigned long long k = tri_sample_key_at(t, sample_coord((px << 8) + ox), sample_coord((py << 8) + oy), rank);
-                            z[s] = __uint_as_float((uint32_t)(k >> 32));
-                            if (k != ~0ull && z[s] <= sdepth[li + s]) mask |= 1u << s;       // CompareFunction::LessEqual
-                        }
+                    for (int s = 0; s < S; s++) {
+                        const int ox = S == 1 ? 128 : msaa4_x(s), oy = S == 1 ? 128 : msaa4_y(s);
+                        const unsigned long long k = tri_sample_key_at(t, sample_coord((px << 8) + ox), sample_coord((py << 8) + oy), rank);
+                        z[s] = __uint_as_float((uint32_t)(k >> 32));
+                        if (k != ~0ull && z[s] <= pix.depth[s]) mask |= 1u << s;       // CompareFunction::LessEqual
                     }
-                    if (__builtin_amdgcn_ballot_w64(mask != 0u) == 0ull) continue;          // nothing in this wavefront: skip the shading code
+                    // queue full in a lane that has a fragment to add: shade what is pending first, then take this triangle again
+                    if (__builtin_amdgcn_ballot_w64(mask != 0u && n_pending == D) != 0ull) { carry = rank; have_carry = true; break; }
                     if (mask) {
-                        const SurfaceOut o = forward_fragment<GRAD>(sc, f, t, rank, px, py);
-                        if (!o.discard) {                                                    // discard: neither colour nor depth
-                            const float a = o.color.w, om = 1.0f - a;
-                            const float sr = o.color.x * a, sg = o.color.y * a, sb = o.color.z * a;   // fragment.wgsl:283-285 premultiplied
+                        FwdFrag<S> e;
+                        e.rank = rank; e.flags = (may_discard ? 1u : 0u) | (mask << 4);
 #pragma unroll
-                            for (int s = 0; s < S; s++) {
-                                if (!(mask & (1u << s))) continue;
-                                sdepth[li + s] = z[s];
-                                const uint2 d = scolor[li + s];
-                                const float r = blend_over_f16(sr, f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)), om);
-                                const float g = blend_over_f16(sg, f16_bits_to_f32((unsigned short)(d.x >> 16)), om);
-                                const float b = blend_over_f16(sb, f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)), om);
-                                const float al = blend_over_f16(a, f16_bits_to_f32((unsigned short)(d.y >> 16)), om);
-                                scolor[li + s] = make_uint2((uint32_t)f16_bits(r) | ((uint32_t)f16_bits(g) << 16), (uint32_t)f16_bits(b) | ((uint32_t)f16_bits(al) << 16));
-                            }
-                        }
+                        for (int s = 0; s < S; s++) { e.z[s] = z[s]; if (!may_discard && (mask & (1u << s))) pix.depth[s] = z[s]; }
+                        fifo_all[n_pending * 64u + tid] = e;
+                        n_pending++;
                     }
+                    // a discardable fragment must resolve its depth before the next triangle is tested
+                    if (may_discard && __builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) break;
                 }
+                forward_flush<S, GRAD>(sc, f, fifo, n_pending, pix, px, py);
+                if (exhausted && !have_carry) break;
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     // resolve + store (the reference resolves the multisampled `transparent` target into `composite`)
+    if (in_frame) {
+        float c[4];
+        if (S == 1) {
+            const uint2 d = pix.color[0];
+            c[0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); c[1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
+            c[2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); c[3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
+        } else {
+            float v[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int lx = qx + (q & 1), ly = qy + (q >> 1), px = tpx + lx, py = tpy + ly;
-        const int li = (ly * kTile + lx) * S;
-        if (px < (int)f.width && py < (int)f.height) {
-            float c[4];
-            if (S == 1) {
-                const uint2 d = scolor[li];
-                c[0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); c[1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
-                c[2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); c[3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
-            } else {
-                float v[4][4];
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const uint2 d = scolor[li + (S == 1 ? 0 : s)];
-                    v[s][0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); v[s][1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
-                    v[s][2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); v[s][3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) c[k] = resolve4_f16(v[0][k], v[1][k], v[2][k], v[3][k]);
+            for (int s = 0; s < 4; s++) {
+                const uint2 d = pix.color[S == 1 ? 0 : s];
+                v[s][0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); v[s][1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
+                v[s][2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); v[s][3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
             }
-            store_pixel(f, (size_t)py * f.width + (size_t)px, {c[0], c[1], c[2], c[3]});
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] = resolve4_f16(v[0][k], v[1][k], v[2][k], v[3][k]);
         }
+        store_pixel(f, (size_t)py * f.width + (size_t)px, {c[0], c[1], c[2], c[3]});
     }
 }
 
@@ -1344,11 +1405,11 @@ extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameD
     if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     const bool grad = f->mipmap != 0u;
     if (f->msaa == 4u) {
-        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<4, true>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
-        else hipLaunchKernelGGL((awsm::k_forward_tile<4, false>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
+        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<4, true>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_forward_tile<4, false>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
     } else {
-        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<1, true>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
-        else hipLaunchKernelGGL((awsm::k_forward_tile<1, false>), dim3(n_tiles), dim3(256), 0, s, sc, *f);
+        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<1, true>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_forward_tile<1, false>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
     }
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {

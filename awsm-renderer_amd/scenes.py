@@ -505,7 +505,7 @@ def instanced_scene(width=640, height=360, seed=0xA35A0006) -> SceneDesc:
 
 # ------------------------------------------------------------------------------------------------ transparent pass
 
-def transparent_scene(width=640, height=360, tex_size=64, seed=0xA35A0007) -> SceneDesc:
+def transparent_scene(width=640, height=360, tex_size=64, seed=0xA35A0007, detail=1.0) -> SceneDesc:
     """An opaque backdrop (textured wall + floor + three spheres) seen through a row of transparent objects, one per branch of
     the forward pass (material_transparent_wgsl/fragment.wgsl + helpers): alpha blend with a textured alpha, a double-sided
     blended shell whose back faces show through its front faces, ALPHA_MODE_MASK with a cutoff, vertex-colour alpha, unlit
@@ -561,6 +561,7 @@ def transparent_scene(width=640, height=360, tex_size=64, seed=0xA35A0007) -> Sc
         return quad
 
     def prim(fn, nu, nv, material, with_color=False, **kw):
+        nu, nv = max(2, int(round(nu * detail))), max(2, int(round(nv * detail)))     # detail: tessellation factor (benchmarks)
         pos, nrm, tan, uvs, idx = grid_patch(fn, nu, nv, uv_scale=(2.0, 1.0))
         colors = []
         if with_color:
