@@ -90,6 +90,7 @@ def load_library():
         "awsm_host_mesh_set_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]), "awsm_host_mesh_append_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]),
         "awsm_host_texture_insert_kind": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
+        "awsm_host_load_gltf": (C.c_int, [vp, C.c_char_p, C.c_int, vp, C.c_char_p, C.c_size_t]),
         "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_transparent_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
         "awsm_host_texture_array_info": (C.c_int, [vp, C.c_uint32, U32P, U32P, U32P, C.POINTER(vp)]),
         "awsm_host_upload_bytes_last_frame": (u64, [vp]),
@@ -332,6 +333,16 @@ class Host:
         self._chk(self.lib.awsm_host_mirror(self.h, which, C.byref(p), C.byref(n)), "mirror")
         return C.string_at(p, n.value)
 
+    def load_gltf(self, path: str, scene_index: int = -1) -> dict:
+        """Populate this host from a .gltf / .glb file (awsm_host_load_gltf); returns the counts of what was inserted."""
+        info = (C.c_uint32 * 12)()
+        err = C.create_string_buffer(512)
+        rc = self.lib.awsm_host_load_gltf(self.h, os.fsencode(path), scene_index, info, err, 512)
+        if rc != 0:
+            raise HostError(f"load_gltf({path}) failed ({rc}): {err.value.decode(errors='replace')}")
+        names = ("nodes", "meshes", "materials", "images", "samplers", "skins", "lights", "triangles", "generated_tangents")
+        return {k: int(info[i]) for i, k in enumerate(names)}
+
     def transparent_draw_list(self) -> List[dict]:
         """The world transparent pass's list: back to front; vis_data_off = offset into the transparency geometry buffer."""
         return self.draw_list(fn="awsm_host_transparent_draw_list")
@@ -481,12 +492,20 @@ class Renderer:
     """Convenience wrapper: Host + populated scene, frame loop = update_all -> render (crates/renderer/src/update.rs, render.rs)."""
 
     def __init__(self, scene: SceneDesc, backend_path: Optional[str] = None, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False,
-                 lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024, msaa: int = 0, mipmap: bool = False, overlap_frames: bool = False):
+                 lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024, msaa: int = 0, mipmap: bool = False, overlap_frames: bool = False,
+                 gltf: Optional[str] = None):
+        """gltf: path of a .gltf / .glb file to populate from (AwsmRenderer::populate_gltf); `scene` then only supplies the frame size,
+        the camera and the environment."""
         self.scene = scene
         self.host = Host(backend_path, device, stream, parity_tap, overlap_frames)
         self.host.set_anti_aliasing(msaa, mipmap)   # AwsmRendererBuilder::with_anti_aliasing (off unless asked: BASELINE configs are single-sampled, MipmapMode::None)
         self.host.resize(scene.width, scene.height)
-        self.keys = populate(self.host, scene)
+        if gltf is not None:
+            self.host.set_ibl_mip_counts(scene.prefiltered_mip_count, scene.irradiance_mip_count)
+            self.gltf_info = self.host.load_gltf(gltf)
+            self.keys = None
+        else:
+            self.keys = populate(self.host, scene)
         if lut_rgba16f is not None:
             self.host.env(scene.skybox_rgba, scene.prefiltered_rgb, scene.irradiance_rgb, lut_rgba16f)
         else:

@@ -25,12 +25,18 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4))
     ap.add_argument("--mipmap", action="store_true")
+    ap.add_argument("--via-glb", action="store_true", help="write the scene to a .glb next to the output and render from the file (native glTF reader)")
     a = ap.parse_args()
     W, H = a.width, a.height
     sc = {"box": lambda: scenes.box_scene(W, H), "helmet": lambda: scenes.helmet_scene(W, H), "skinned": lambda: scenes.skinned_morph_scene(W, H),
           "atrium": lambda: scenes.atrium_scene(W, H, tex_scale=0.5), "zoo": lambda: scenes.material_zoo_scene(W, H),
           "instanced": lambda: scenes.instanced_scene(W, H), "transparent": lambda: scenes.transparent_scene(W, H, tex_size=256)}[a.scene]()
-    r = Renderer(sc, msaa=a.msaa, mipmap=a.mipmap)
+    gltf = None
+    if a.via_glb:
+        from awsm_renderer_amd import gltf_export
+        gltf = os.path.splitext(a.out)[0] + ".glb"
+        gltf_export.write_glb(sc, gltf)
+    r = Renderer(sc, msaa=a.msaa, mipmap=a.mipmap, gltf=gltf)
     stats = r.render(sync=True)
     dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
     final = dev.read_composite() if stats["forward_triangles"] else dev.read_opaque()      # the image after the transparent pass, when the scene has one

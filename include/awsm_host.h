@@ -147,6 +147,17 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats);
 
 /* ---- introspection (tests, parity, INTEGRATION) ---- */
 int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* len);
+/* ---- glTF ingest (crates/renderer/src/gltf/{loader,buffers,populate}.rs): reads a .gltf (external / data-URI buffers and images)
+ * or a .glb, decodes the images (PNG), converts every accessor, generates missing normals / tangents, and populates this host
+ * through the key API above in the reference's order (transforms, skins, meshes; populate.rs:185-205).  scene_index < 0 = the
+ * document's default scene.  The camera is not taken from the file.  On failure returns a negative AwsmStatus and, if err_out is
+ * given, the reason (AWSM_ERR_UNSUPPORTED for JPEG / KTX2 images, sparse accessors, point / line primitives, unknown required
+ * extensions); objects inserted before the failure stay inserted. ---- */
+typedef struct AwsmGltfInfo {
+    uint32_t nodes, meshes, materials, images, samplers, skins, lights, triangles, generated_tangents, reserved[3];
+} AwsmGltfInfo;
+int awsm_host_load_gltf(AwsmHost* h, const char* path, int scene_index, AwsmGltfInfo* info_out, char* err_out, size_t err_cap);
+
 /* the world transparent pass's list (back to front), as awsm_host_draw_list gives the geometry pass's */
 int awsm_host_transparent_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);
 int awsm_host_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);   /* the list render() would submit */

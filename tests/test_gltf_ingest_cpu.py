@@ -1,0 +1,202 @@
+"""glTF ingest: scenes written as .glb / .gltf by awsm_renderer_amd.gltf_export and read back by the native reader
+(awsm_host_load_gltf) must populate the host exactly as the same SceneDesc does through the key API — same mirrors, same draw
+lists — plus the reader's own conversions (normalised integer attributes, u8/u16 indices, strips and fans, matrix nodes,
+generated normals and tangents, data URIs, external files)."""
+import base64
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from awsm_renderer_amd import gltf_export, scenes
+from awsm_renderer_amd import host as H
+from awsm_renderer_amd.scene_desc import MaterialDesc, NodeDesc, PrimitiveDesc, SceneDesc, TextureRef
+from oracle import scene_model as sm
+from tests import helpers
+
+MOCK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock", "libmock_backend.so")
+
+MIRRORS = (sm.BUF_TRANSFORMS, sm.BUF_NORMAL_MATS, sm.BUF_MATERIALS, sm.BUF_SKIN_MATRICES, sm.BUF_SKIN_INDEX_WEIGHTS, sm.BUF_MORPH_WEIGHTS, sm.BUF_MORPH_VALUES,
+           sm.BUF_GEOM_META, sm.BUF_MATERIAL_META, sm.BUF_VIS_GEOM_DATA, sm.BUF_VIS_GEOM_INDEX, sm.BUF_ATTR_DATA, sm.BUF_ATTR_INDEX, sm.BUF_TEXTURE_TRANSFORMS,
+           sm.BUF_INSTANCES, sm.BUF_TRANSPARENCY_GEOM_DATA)
+
+
+def _host_from_file(path, scene):
+    h = H.Host(MOCK)
+    h.resize(scene.width, scene.height)
+    h.set_ibl_mip_counts(scene.prefiltered_mip_count, scene.irradiance_mip_count)
+    info = h.load_gltf(path)
+    h.update_transforms()
+    h.camera_update(scene.view, scene.proj, scene.camera_position)
+    return h, info
+
+
+def _host_from_desc(scene):
+    h = H.Host(MOCK)
+    h.resize(scene.width, scene.height)
+    H.populate(h, scene)
+    h.update_transforms()
+    h.camera_update(scene.view, scene.proj, scene.camera_position)
+    return h
+
+
+def _same(a, b):
+    for which in MIRRORS:
+        assert a.mirror(which) == b.mirror(which), f"mirror {which} differs"
+    assert a.draw_list() == b.draw_list()
+    assert a.transparent_draw_list() == b.transparent_draw_list()
+    assert a.texture_arrays() == b.texture_arrays() if hasattr(a, "texture_arrays") else True
+
+
+SCENES = {
+    "box": lambda: scenes.box_scene(64, 64),
+    "helmet": lambda: scenes.helmet_scene(96, 64, segments=12, rings=8, tex_size=16),
+    "skinned_morph": lambda: scenes.skinned_morph_scene(64, 64, around=8, along=12, tex_size=16),
+    "zoo": lambda: scenes.material_zoo_scene(96, 64, tex_size=16),
+    "transparent": lambda: scenes.transparent_scene(96, 64, tex_size=16),
+    "instanced": lambda: scenes.instanced_scene(96, 64),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+@pytest.mark.parametrize("container", ["glb", "gltf", "gltf_data_uri"])
+def test_round_trip_equals_direct_population(name, container, tmp_path):
+    if container != "glb" and name not in ("helmet", "skinned_morph"):
+        pytest.skip("one container variant per scene is enough beyond glb")
+    scene = SCENES[name]()
+    path = str(tmp_path / (name + (".glb" if container == "glb" else ".gltf")))
+    if container == "glb":
+        gltf_export.write_glb(scene, path)
+    else:
+        gltf_export.write_gltf(scene, path, data_uri=(container == "gltf_data_uri"))
+    a, info = _host_from_file(path, scene)
+    b = _host_from_desc(scene)
+    _same(a, b)
+    n_tris = sum(int(np.asarray(p.indices).reshape(-1, 3).shape[0]) for n in scene.nodes for p in n.primitives)
+    assert info["triangles"] == n_tris and info["images"] == len(scene.textures) and info["lights"] == len(scene.lights)
+    assert info["meshes"] == sum(len(n.primitives) for n in scene.nodes)
+    # the same frame goes to the device: creates / writes / passes in the same order with the same bytes
+    a.render(); b.render()
+    a.close(); b.close()
+
+
+def _write_raw_glb(path, doc, blob):
+    js = json.dumps(doc).encode()
+    js += b" " * ((4 - len(js) % 4) % 4)
+    blob = blob + b"\0" * ((4 - len(blob) % 4) % 4)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, 28 + len(js) + len(blob)))
+        f.write(struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob)
+
+
+def _quad_doc(extra_prim=None, indices=None, mode=4):
+    """A unit quad with interleaved (strided) f32 positions + normalised u16 UVs + normalised u8 colours and u8 indices."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float32)
+    uv = np.array([[0, 0], [65535, 0], [65535, 65535], [0, 65535]], dtype=np.uint16)
+    col = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]], dtype=np.uint8)
+    inter = b"".join(pos[i].tobytes() + uv[i].tobytes() + col[i].tobytes() + b"\0" for i in range(4))     # stride 20
+    idx = np.array(indices if indices is not None else [0, 1, 2, 0, 2, 3], dtype=np.uint8).tobytes()
+    blob = inter + idx
+    views = [{"buffer": 0, "byteOffset": 0, "byteLength": len(inter), "byteStride": 20}, {"buffer": 0, "byteOffset": len(inter), "byteLength": len(idx)}]
+    acc = [{"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": 4, "type": "VEC3", "min": [0, 0, 0], "max": [1, 1, 0]},
+           {"bufferView": 0, "byteOffset": 12, "componentType": 5123, "normalized": True, "count": 4, "type": "VEC2"},
+           {"bufferView": 0, "byteOffset": 16, "componentType": 5121, "normalized": True, "count": 4, "type": "VEC3"},
+           {"bufferView": 1, "componentType": 5121, "count": len(idx), "type": "SCALAR"}]
+    prim = {"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "COLOR_0": 2}, "indices": 3, "mode": mode}
+    if extra_prim:
+        prim.update(extra_prim)
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+           "nodes": [{"matrix": [0, 2, 0, 0, -2, 0, 0, 0, 0, 0, 2, 0, 1, 2, 3, 1], "mesh": 0}],       # scale 2, 90 degrees about z, translation (1, 2, 3)
+           "meshes": [{"primitives": [prim]}], "bufferViews": views, "accessors": acc, "buffers": [{"byteLength": len(blob)}]}
+    return doc, blob
+
+
+def test_reader_conversions(tmp_path):
+    """Strided + normalised integer attributes, u8 indices, a matrix node, default material, generated normals."""
+    doc, blob = _quad_doc()
+    path = str(tmp_path / "quad.glb")
+    _write_raw_glb(path, doc, blob)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    info = h.load_gltf(path)
+    assert info["triangles"] == 2 and info["meshes"] == 1 and info["materials"] == 1
+    h.update_transforms()
+    attr = np.frombuffer(h.mirror(sm.BUF_ATTR_DATA)[:4 * 6 * 4], dtype=np.float32).reshape(4, 6)       # COLOR_0 rgba, TEXCOORD_0
+    assert np.array_equal(attr[:, :4], np.array([[1, 0, 0, 1], [0, 1, 0, 1], [0, 0, 1, 1], [1, 1, 1, 1]], dtype=np.float32))
+    assert np.array_equal(attr[:, 4:], np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32))
+    assert np.array_equal(np.frombuffer(h.mirror(sm.BUF_ATTR_INDEX)[:24], dtype=np.uint32), [0, 1, 2, 0, 2, 3])
+    vis = np.frombuffer(h.mirror(sm.BUF_VIS_GEOM_DATA)[:6 * 56], dtype=np.float32).reshape(6, 14)
+    assert np.allclose(vis[:, 6:9], [0, 0, 1])                                   # normals computed from the faces (buffers/normals.rs)
+    slots = np.frombuffer(h.mirror(sm.BUF_TRANSFORMS), dtype=np.float32).reshape(-1, 4, 4)             # one of the slots holds the node's world matrix
+    want = np.array([[0, 2, 0, 0], [-2, 0, 0, 0], [0, 0, 2, 0], [1, 2, 3, 1]], dtype=np.float32)         # matrix -> TRS -> matrix (transforms.rs)
+    assert any(np.allclose(m, want, atol=1e-6) for m in slots)
+    h.close()
+
+
+@pytest.mark.parametrize("mode,indices,want", [(5, [0, 1, 3, 2], [0, 1, 3, 1, 2, 3]), (6, [0, 1, 2, 3], [0, 1, 2, 0, 2, 3])])
+def test_strips_and_fans_become_lists(mode, indices, want, tmp_path):
+    doc, blob = _quad_doc(indices=indices, mode=mode)
+    path = str(tmp_path / "q.glb")
+    _write_raw_glb(path, doc, blob)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    h.load_gltf(path)
+    assert np.array_equal(np.frombuffer(h.mirror(sm.BUF_ATTR_INDEX)[:24], dtype=np.uint32), want)      # buffers/index.rs:146-201
+    h.close()
+
+
+def test_tangents_are_generated_for_normal_mapped_primitives(tmp_path):
+    """ensure_tangents: a primitive without TANGENT whose material has a normal map gets per-vertex tangents — unit length,
+    orthogonal to the normal, pointing along +u, handedness +1 for a right-handed UV layout."""
+    sc = scenes.helmet_scene(64, 64, segments=16, rings=12, tex_size=16)
+    prim = [p for n in sc.nodes for p in n.primitives][0]
+    given = np.asarray(prim.tangents, dtype=np.float32).copy()
+    prim.tangents = None
+    path = str(tmp_path / "nt.glb")
+    gltf_export.write_glb(sc, path)
+    h = H.Host(MOCK)
+    h.resize(64, 64)
+    info = h.load_gltf(path)
+    assert info["generated_tangents"] == 1
+    T = int(np.asarray(prim.indices).reshape(-1, 3).shape[0])
+    vis = np.frombuffer(h.mirror(sm.BUF_VIS_GEOM_DATA)[:T * 3 * 56], dtype=np.float32).reshape(T * 3, 14)
+    n, t, w = vis[:, 6:9], vis[:, 9:12], vis[:, 12]
+    orig = vis[:, 13].view(np.uint32)
+    assert np.allclose(np.linalg.norm(t, axis=1), 1.0, atol=1e-5)
+    assert np.abs((n * t).sum(axis=1)).max() < 1e-4
+    assert set(np.unique(w)) <= {-1.0, 1.0}
+    cos = (t * given[orig, :3]).sum(axis=1)                                       # against the analytic tangents of the parametric surface
+    assert np.median(cos) > 0.95 and (w == given[orig, 3]).mean() > 0.95
+    h.close()
+
+
+def test_unsupported_inputs_fail_loudly(tmp_path):
+    doc, blob = _quad_doc()
+    jpeg = bytes([0xFF, 0xD8, 0xFF, 0xE0]) + bytes(32)
+    doc["images"] = [{"uri": "data:image/jpeg;base64," + base64.b64encode(jpeg).decode()}]
+    doc["textures"] = [{"source": 0}]
+    doc["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    path = str(tmp_path / "j.glb")
+    _write_raw_glb(path, doc, blob)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    with pytest.raises(H.HostError, match="JPEG"):
+        h.load_gltf(path)
+    doc, blob = _quad_doc(mode=1)
+    _write_raw_glb(path, doc, blob)
+    with pytest.raises(H.HostError, match="mode 1"):
+        h.load_gltf(path)
+    doc, blob = _quad_doc()
+    doc["extensionsRequired"] = ["KHR_draco_mesh_compression"]
+    _write_raw_glb(path, doc, blob)
+    with pytest.raises(H.HostError, match="KHR_draco_mesh_compression"):
+        h.load_gltf(path)
+    with pytest.raises(H.HostError, match="cannot read"):
+        h.load_gltf(str(tmp_path / "missing.glb"))
+    with open(path, "wb") as f:
+        f.write(b"{ not json")
+    with pytest.raises(H.HostError, match="JSON"):
+        h.load_gltf(path)
+    h.close()

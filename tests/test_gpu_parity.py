@@ -542,3 +542,27 @@ def test_transparent_pass_edge_cases(oracle_lut):
     with pytest.raises(AwsmHipError):
         dev.transparent_pass(model.collect_transparent_draws())
     dev.close()
+
+
+# ------------------------------------------------------------------------------------------------ glTF ingest
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["helmet", "skinned_morph", "transparent"])
+def test_frames_rendered_from_a_glb_file(name, oracle_lut, tmp_path):
+    """File -> native glTF reader -> host layer -> HIP kernels, against the oracle's frame of the scene the file was written from."""
+    from awsm_renderer_amd import gltf_export
+    sc = {"helmet": lambda: scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=64),
+          "skinned_morph": lambda: scenes.skinned_morph_scene(320, 200, around=16, along=24, tex_size=16),
+          "transparent": lambda: scenes.transparent_scene(320, 180, tex_size=32)}[name]()
+    path = str(tmp_path / (name + ".glb"))
+    gltf_export.write_glb(sc, path)
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut)
+    r, dev, stats = helpers.host_frame(sc, oracle_lut, gltf=path)
+    res = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert res["clip_mismatch"] == 0 and res["nt_mismatch"] == 0 and res["key_mismatch"] == 0 and res["rgb_over_tol"] == 0 and res["covered"] > 0, res
+    if name == "transparent":
+        orc.forward(model.collect_transparent_draws())
+        c = helpers.compare_composite(orc, dev)
+        assert c["clip_mismatch"] == 0 and c["untouched_changed"] == 0 and c["pixels_over_2ulp"] <= c["touched_pixels"] // 200, c
+    r.close()
