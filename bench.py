@@ -60,7 +60,11 @@ def pmc_traffic(kernel, n_tris, W, H):
         wl = doc["workload"]
         if (wl["triangles"], wl["width"], wl["height"]) != (n_tris, W, H):
             return None
-        return doc["kernels"]["awsm::" + kernel]["hbm_traffic_bytes"]
+        ks = doc["kernels"]
+        for name in ("awsm::" + kernel, "awsm::" + kernel + "<false>", "awsm::" + kernel + "<1>"):      # the profiled workload is single-sample, MipmapMode::None
+            if name in ks:
+                return ks[name]["hbm_traffic_bytes"]
+        return None
     except (OSError, KeyError, ValueError):
         return None
 
