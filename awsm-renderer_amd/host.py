@@ -91,6 +91,7 @@ def load_library():
         "awsm_host_texture_insert_kind": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_update_transforms": (C.c_int, [vp]),
         "awsm_host_render": (C.c_int, [vp, C.c_int, vp]), "awsm_host_mirror": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "awsm_host_load_gltf": (C.c_int, [vp, C.c_char_p, C.c_int, vp, C.c_char_p, C.c_size_t]),
+        "awsm_host_decode_image": (C.c_int, [C.c_char_p, C.c_size_t, vp, C.c_size_t, U32P, U32P, C.c_char_p, C.c_size_t]),
         "awsm_host_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_transparent_draw_list": (C.c_int, [vp, vp, C.c_uint32, U32P]), "awsm_host_texture_array_count": (C.c_uint32, [vp]),
         "awsm_host_texture_array_info": (C.c_int, [vp, C.c_uint32, U32P, U32P, U32P, C.POINTER(vp)]),
         "awsm_host_upload_bytes_last_frame": (u64, [vp]),
@@ -425,6 +426,21 @@ def material_struct(m: MaterialDesc, host: Host, tt_keys: Dict[tuple, int]) -> H
         hm.sheen_color_factor = (C.c_float * 3)(*s.get("color_factor", (0, 0, 0)))
         hm.sheen_roughness_tex, hm.sheen_color_tex = tr(s.get("roughness_tex")), tr(s.get("color_tex"))
     return hm
+
+
+def decode_image(data: bytes) -> np.ndarray:
+    """PNG / baseline JPEG bytes -> (h, w, 4) u8 through the host library's own decoders (awsm_host_decode_image)."""
+    lib = load_library()
+    w, h = C.c_uint32(), C.c_uint32()
+    err = C.create_string_buffer(256)
+    rc = lib.awsm_host_decode_image(data, len(data), None, 0, C.byref(w), C.byref(h), err, 256)
+    if rc != 0:
+        raise HostError(f"decode_image failed ({rc}): {err.value.decode(errors='replace')}")
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    rc = lib.awsm_host_decode_image(data, len(data), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(w), C.byref(h), err, 256)
+    if rc != 0:
+        raise HostError(f"decode_image failed ({rc}): {err.value.decode(errors='replace')}")
+    return out
 
 
 class Populated:

@@ -15,7 +15,8 @@
 // (mikktspace's vertex weighting), accumulated per vertex, projected off the normal and normalised with the reference's
 // fallbacks and sign vote — mikktspace's splitting of a vertex between smoothing groups is what is not reproduced.
 //
-// Images: PNG (png.hpp, zlib inflate).  JPEG and KTX2 return AWSM_ERR_UNSUPPORTED with the image index in the message.
+// Images: PNG (png.hpp, zlib inflate) and baseline JPEG (jpeg.hpp).  Progressive JPEG, KTX2 and anything else return
+// AWSM_ERR_UNSUPPORTED with the image index in the message.
 // Not read: cameras (the caller owns the camera), animations, sparse accessors, KHR_mesh_quantization beyond the normalised
 // integer attribute types glTF core already allows, EXT_mesh_gpu_instancing.
 #include <algorithm>
@@ -30,6 +31,7 @@
 
 #include "../../include/awsm_host.h"
 #include "json.hpp"
+#include "jpeg.hpp"
 #include "png.hpp"
 
 using awsm_json::Value;
@@ -249,12 +251,9 @@ bool load_images(Loader& L) {
         if (!image_bytes(L, images[i], bytes)) return false;
         uint32_t w = 0, ht = 0;
         std::string perr;
-        if (!awsm_png::is_png(bytes.data(), bytes.size())) {
-            const bool jpeg = bytes.size() > 2 && bytes[0] == 0xFF && bytes[1] == 0xD8;
-            L.fail("image %zu: %s is not supported (PNG only)", i, jpeg ? "JPEG" : "this image format");
-            return false;
-        }
-        if (!awsm_png::decode(bytes.data(), bytes.size(), rgba, w, ht, perr)) return L.fail("image %zu: %s", i, perr.c_str());
+        if (awsm_png::is_png(bytes.data(), bytes.size())) { if (!awsm_png::decode(bytes.data(), bytes.size(), rgba, w, ht, perr)) return L.fail("image %zu: %s", i, perr.c_str()); }
+        else if (awsm_jpeg::is_jpeg(bytes.data(), bytes.size())) { if (!awsm_jpeg::decode(bytes.data(), bytes.size(), rgba, w, ht, perr)) return L.fail("image %zu: %s", i, perr.c_str()); }
+        else return L.fail("image %zu: this image format is not supported (PNG and baseline JPEG only)", i);
         const int id = awsm_host_texture_insert_kind(L.h, rgba.data(), w, ht, (uint32_t)(kinds[i] < 0 ? 0 : kinds[i]));
         if (id < 0) return L.fail("image %zu: %s", i, awsm_host_last_error(L.h));
         L.image_tex[i] = id;
@@ -769,6 +768,19 @@ bool load(Loader& L, const char* path, int scene_index) {
 bool err_or(Loader& L, const char* msg) { if (L.err.empty()) L.fail("%s", msg); return false; }
 
 }  // namespace
+
+extern "C" int awsm_host_decode_image(const uint8_t* data, size_t len, uint8_t* rgba_out, size_t cap, uint32_t* width, uint32_t* height, char* err_out, size_t err_cap) {
+    if (!data || !width || !height) return AWSM_ERR_INVALID_ARGUMENT;
+    std::vector<uint8_t> rgba;
+    std::string err;
+    bool ok = false;
+    if (awsm_png::is_png(data, len)) ok = awsm_png::decode(data, len, rgba, *width, *height, err);
+    else if (awsm_jpeg::is_jpeg(data, len)) ok = awsm_jpeg::decode(data, len, rgba, *width, *height, err);
+    else err = "this image format is not supported (PNG and baseline JPEG only)";
+    if (!ok) { if (err_out && err_cap) snprintf(err_out, err_cap, "%s", err.c_str()); return err.find("not supported") != std::string::npos ? AWSM_ERR_UNSUPPORTED : AWSM_ERR_INVALID_ARGUMENT; }
+    if (rgba_out) { if (cap < rgba.size()) return AWSM_ERR_OUT_OF_RANGE; memcpy(rgba_out, rgba.data(), rgba.size()); }
+    return AWSM_OK;
+}
 
 extern "C" int awsm_host_load_gltf(AwsmHost* h, const char* path, int scene_index, AwsmGltfInfo* info_out, char* err_out, size_t err_cap) {
     if (!h || !path) return AWSM_ERR_INVALID_ARGUMENT;

@@ -151,12 +151,15 @@ int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* l
  * or a .glb, decodes the images (PNG), converts every accessor, generates missing normals / tangents, and populates this host
  * through the key API above in the reference's order (transforms, skins, meshes; populate.rs:185-205).  scene_index < 0 = the
  * document's default scene.  The camera is not taken from the file.  On failure returns a negative AwsmStatus and, if err_out is
- * given, the reason (AWSM_ERR_UNSUPPORTED for JPEG / KTX2 images, sparse accessors, point / line primitives, unknown required
+ * given, the reason (AWSM_ERR_UNSUPPORTED for progressive JPEG / KTX2 images, sparse accessors, point / line primitives, unknown required
  * extensions); objects inserted before the failure stay inserted. ---- */
 typedef struct AwsmGltfInfo {
     uint32_t nodes, meshes, materials, images, samplers, skins, lights, triangles, generated_tangents, reserved[3];
 } AwsmGltfInfo;
 int awsm_host_load_gltf(AwsmHost* h, const char* path, int scene_index, AwsmGltfInfo* info_out, char* err_out, size_t err_cap);
+/* the image decoders the reader uses (PNG: all colour types / bit depths, non-interlaced; JPEG: baseline / extended sequential Huffman,
+ * 8-bit, grayscale or YCbCr) on their own: rgba_out = NULL queries the size; needs width * height * 4 bytes. */
+int awsm_host_decode_image(const uint8_t* data, size_t len, uint8_t* rgba_out, size_t cap, uint32_t* width, uint32_t* height, char* err_out, size_t err_cap);
 
 /* the world transparent pass's list (back to front), as awsm_host_draw_list gives the geometry pass's */
 int awsm_host_transparent_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);

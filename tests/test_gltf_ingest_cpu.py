@@ -200,3 +200,74 @@ def test_unsupported_inputs_fail_loudly(tmp_path):
     with pytest.raises(H.HostError, match="JSON"):
         h.load_gltf(path)
     h.close()
+
+
+# ------------------------------------------------------------------------------------------------ image decoders
+
+def _test_image(w, h, seed=3, smooth=True):
+    rng = np.random.default_rng(seed)
+    if smooth:
+        y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.stack([127 + 100 * np.sin(x / 9.0) * np.cos(y / 13.0), 127 + 90 * np.cos(x / 17.0 + y / 11.0), 127 + 110 * np.sin((x + y) / 23.0), np.full_like(x, 255)], axis=-1)
+        return img.clip(0, 255).astype(np.uint8)
+    return rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("mode,size", [("RGBA", (37, 23)), ("RGB", (64, 40)), ("L", (19, 31)), ("LA", (16, 16)), ("P", (33, 17)), ("I;16", (20, 12)), ("1", (29, 9))])
+def test_png_decoder_matches_pil(mode, size):
+    import io
+    from PIL import Image
+    w, h = size
+    src = Image.fromarray(_test_image(w, h, smooth=False), "RGBA")
+    if mode == "I;16":
+        im = Image.fromarray((np.arange(w * h, dtype=np.uint32).reshape(h, w) * 257 % 65536).astype(np.uint16))
+    elif mode == "P":
+        im = src.convert("RGB").quantize(colors=16)
+    elif mode == "1":
+        im = src.convert("L").point(lambda v: 255 if v > 127 else 0).convert("1")
+    else:
+        im = src.convert(mode)
+    buf = io.BytesIO()
+    im.save(buf, format="PNG")
+    got = H.decode_image(buf.getvalue())
+    if mode == "I;16":
+        want = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)               # 16 -> 8 bits: the high byte
+        assert np.array_equal(got[..., 0], want) and np.array_equal(got[..., 1], want) and (got[..., 3] == 255).all()
+    else:
+        assert np.array_equal(got, np.asarray(im.convert("RGBA")))
+
+
+@pytest.mark.parametrize("subsampling,quality,size,gray", [(0, 92, (64, 48), False), (2, 85, (80, 56), False), (1, 90, (37, 29), False), (0, 80, (40, 40), True)])
+def test_baseline_jpeg_decoder_is_close_to_libjpeg(subsampling, quality, size, gray):
+    """Lossy format, decoders differ in IDCT rounding and chroma upsampling (replication here, triangle filter in libjpeg): close, not equal."""
+    import io
+    from PIL import Image
+    w, h = size
+    src = Image.fromarray(_test_image(w, h)[..., :3], "RGB")
+    if gray:
+        src = src.convert("L")
+    buf = io.BytesIO()
+    kw = {} if gray else {"subsampling": subsampling}
+    src.save(buf, format="JPEG", quality=quality, **kw)
+    got = H.decode_image(buf.getvalue()).astype(np.int32)
+    want = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA")).astype(np.int32)
+    assert got.shape == want.shape and (got[..., 3] == 255).all()
+    d = np.abs(got[..., :3] - want[..., :3])
+    assert d.mean() < (1.0 if subsampling == 0 else 3.0) and np.percentile(d, 99) <= (3 if subsampling == 0 else 16), (d.mean(), d.max())
+
+
+def test_jpeg_restart_intervals_and_refusals():
+    import io
+    from PIL import Image
+    src = Image.fromarray(_test_image(72, 40)[..., :3], "RGB")
+    a, b = io.BytesIO(), io.BytesIO()
+    src.save(a, format="JPEG", quality=90, subsampling=0)
+    src.save(b, format="JPEG", quality=90, subsampling=0, restart_marker_blocks=3)
+    assert b"\xff\xdd" in b.getvalue()
+    assert np.array_equal(H.decode_image(a.getvalue()), H.decode_image(b.getvalue()))
+    p = io.BytesIO()
+    src.save(p, format="JPEG", quality=90, progressive=True)
+    with pytest.raises(H.HostError, match="progressive"):
+        H.decode_image(p.getvalue())
+    with pytest.raises(H.HostError, match="not supported"):
+        H.decode_image(b"GIF89a" + bytes(32))
