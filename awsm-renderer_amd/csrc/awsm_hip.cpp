@@ -95,6 +95,7 @@ struct AwsmHipCtx {
     uint32_t tr_total_tris = 0, tr_n_blocks = 0;
     bool transparent_done = false;
     DevBuf comp16, comp32;       // composite image (after the transparent pass) + parity tap
+    DevBuf lights_pre;           // per-light constants (k_resolve_draws), sized with the lights buffer
     void* bound_comp = nullptr;
     size_t bound_comp_bytes = 0;
     int slot = 0;
@@ -269,6 +270,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? c->bound_out : c->out16.ptr);
     f->out_rgba32f = (float*)c->out32.ptr;
+    f->lights_pre = (float4*)c->lights_pre.ptr;
+    f->lights_cap = (uint32_t)(c->lights_pre.size / 32);
 }
 
 int record(AwsmHipCtx* c, int which, hipStream_t s = nullptr) {
@@ -538,7 +541,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32);
+    fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
         fr(b.vis); fr(b.wpos); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -573,6 +576,7 @@ int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
     if (rc) return rc;
     if (bytes) c->bufs[which].size = bytes;
+    if (which == AWSM_BUF_LIGHTS && (rc = dev_realloc(c, c->lights_pre, std::max<size_t>(bytes / 64, 1) * 32, true))) return rc;   // 2 x float4 per 64-byte light
     c->scene_dirty = true;
     return AWSM_OK;
 }

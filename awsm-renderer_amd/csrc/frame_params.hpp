@@ -36,7 +36,7 @@ struct DrawShadeDev {
     uint32_t attr_data_word;      // attribute data offset / 4
     uint32_t stride_words;        // attribute stride / 4
     uint32_t uv_sets_index;
-    uint32_t is_hud;
+    uint32_t flags;               // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments)
     uint32_t color_sets;          // COLOR_n sets in the mesh's vertex attributes (transparent pass)
 };
 
@@ -81,6 +81,8 @@ struct FrameDev {
     const uint8_t* camera;        // the camera UBO this frame is shaded with (a per-frame snapshot in overlap mode)
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
+    float4* lights_pre;           // 2 x float4 per light (k_resolve_draws): {unit direction to the light (directional) or unit spot axis, kind}, {colour * intensity, 0}
+    uint32_t lights_cap;          // records lights_pre can hold
     // transformed vertices (k_deform_transform outputs)
     float4* clip;                 // total_verts
     float4* nrm;                  // total_verts  (world normal xyz, 0)

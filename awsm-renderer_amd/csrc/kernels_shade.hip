@@ -410,10 +410,9 @@ struct Surface {
     bool has_sheen, has_clearcoat;
 };
 
-// brdf.wgsl:308-381 for one light.  `light_dir` need not be normalised (the WGSL normalises it again on entry).
-AWSM_DI f3 brdf_direct(const PbrColor& c, const Surface& sf, f3 light_dir, f3 radiance) {
+// brdf.wgsl:308-381 for one light.  `l` is the unit vector towards the light (the WGSL normalises it again on entry; callers here pass unit vectors).
+AWSM_DI f3 brdf_direct(const PbrColor& c, const Surface& sf, f3 l, f3 radiance) {
     const f3 n = sf.n, v = sf.v;
-    const f3 l = fm::fsafe_normalize(light_dir);
     const f3 sum = v + l;
     const float len_sq = fm::fdot(sum, sum);
     const bool has_half = len_sq > 1e-8f;
@@ -506,7 +505,7 @@ AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf, f3
 }
 
 // lights.wgsl:70-152
-AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_camera, f3 world_position, uint32_t n_lights, f3 transmission_background) {
+AWSM_DI f3 apply_lighting(const DevScene* sc, const float4* __restrict__ lights_pre, const PbrColor& mc, f3 surface_to_camera, f3 world_position, uint32_t n_lights, f3 transmission_background) {
     Surface sf;
     sf.n = fm::fsafe_normalize(mc.normal);
     sf.v = fm::fsafe_normalize(surface_to_camera);
@@ -534,29 +533,28 @@ AWSM_DI f3 apply_lighting(const DevScene* sc, const PbrColor& mc, f3 surface_to_
     f3 color = brdf_ibl(sc, mc, sf, transmission_background);
     const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
     for (uint32_t i = 0; i < n_lights; i++) {
-        const float4 pos_range = lights[i * 4 + 0], dir_inner = lights[i * 4 + 1], color_intensity = lights[i * 4 + 2], kind_outer = lights[i * 4 + 3];
-        const uint32_t kind = (uint32_t)kind_outer.x;
-        const f3 lcolor = {color_intensity.x, color_intensity.y, color_intensity.z};
-        f3 light_dir = {0.0f, 0.0f, 0.0f}, radiance = {0.0f, 0.0f, 0.0f};
-        if (kind == 1u) {
-            light_dir = -mk3(dir_inner.x, dir_inner.y, dir_inner.z);   // normalised on entry to brdf_direct
-            radiance = lcolor * color_intensity.w;
-        } else if (kind == 2u || kind == 3u) {
+        const float4 pre0 = lights_pre[i * 2], pre1 = lights_pre[i * 2 + 1];      // k_resolve_draws: unit direction / spot axis + kind, colour * intensity
+        const uint32_t kind = (uint32_t)pre0.w;
+        f3 light_dir = {pre0.x, pre0.y, pre0.z}, radiance = {pre1.x, pre1.y, pre1.z};
+        if (kind == 2u || kind == 3u) {
+            const float4 pos_range = lights[i * 4 + 0];
             const f3 stl = mk3(pos_range.x, pos_range.y, pos_range.z) - world_position;
             const float d2 = fm::fdot(stl, stl);
-            const float inv_d = fm::rsq(d2);
+            const float inv_d = d2 > 0.0f ? fm::rsq(d2) : 0.0f;
             const float dist = d2 * inv_d;
-            light_dir = stl * inv_d;
             float att;   // math.wgsl:12-19 inverse_square
             if (pos_range.w == 0.0f) att = fm::rcp(fmaxf(dist * dist, 0.01f));
             else { const float fo = 1.0f - fm::fdiv(dist * dist, pos_range.w * pos_range.w); att = fm::fdiv(saturate(fo * fo), dist * dist + 1.0f); }
+            const f3 to_light = stl * inv_d;
             if (kind == 3u) {
-                const float cos_l = fm::fdot(light_dir, -fm::fnormalize(mk3(dir_inner.x, dir_inner.y, dir_inner.z)));
+                const float4 dir_inner = lights[i * 4 + 1], kind_outer = lights[i * 4 + 3];
+                const float cos_l = fm::fdot(to_light, -light_dir);                 // light_dir holds the unit spot axis here
                 const float sm = saturate(fm::fdiv(cos_l - kind_outer.y, dir_inner.w - kind_outer.y));
                 att = att * (sm * sm);
             }
-            radiance = (lcolor * color_intensity.w) * att;
-        }
+            light_dir = to_light;
+            radiance = radiance * att;
+        } else if (kind != 1u) { light_dir = {0.0f, 0.0f, 0.0f}; radiance = {0.0f, 0.0f, 0.0f}; }
         color = color + brdf_direct(mc, sf, light_dir, radiance);
     }
     return color;
@@ -574,6 +572,21 @@ AWSM_DI void store_pixel(const FrameDev& f, size_t p, f4 c) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restrict__ sc, FrameDev f) {
     const uint32_t d = blockIdx.x * 256u + threadIdx.x;
+    // Per-light constants, once per frame instead of once per pixel and light (lights.wgsl:70-118 recomputes them in every invocation):
+    // the unit vector towards a directional light / the unit axis of a spot, and colour * intensity.
+    if (f.lights_pre && sc->buf[AWSM_BUF_LIGHTS_INFO] && sc->buf[AWSM_BUF_LIGHTS]) {
+        const uint32_t n_lights = min(*reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]), f.lights_cap);
+        const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
+        for (uint32_t i = d; i < n_lights; i += gridDim.x * 256u) {
+            const float4 dir_inner = lights[i * 4 + 1], color_intensity = lights[i * 4 + 2], kind_outer = lights[i * 4 + 3];
+            const uint32_t kind = (uint32_t)kind_outer.x;
+            f3 v = {dir_inner.x, dir_inner.y, dir_inner.z};
+            if (kind == 1u) v = fm::fsafe_normalize(-v);          // towards the light
+            else v = fm::fnormalize(v);                           // spot axis (unused for point lights)
+            f.lights_pre[i * 2] = make_float4(v.x, v.y, v.z, kind_outer.x);
+            f.lights_pre[i * 2 + 1] = make_float4(color_intensity.x * color_intensity.w, color_intensity.y * color_intensity.w, color_intensity.z * color_intensity.w, 0.0f);
+        }
+    }
     if (d >= f.n_draws) return;
     const DrawDev dr = f.draws[d];
     const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
     o.uv_sets_index = mm[12];
     // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments, so their depth write waits for the shading)
-    o.is_hud = (mm[16] & 1u) | (reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS])[mm[6] / 4u + 1u] == 1u ? 2u : 0u);
+    o.flags = (mm[16] & 1u) | (reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS])[mm[6] / 4u + 1u] == 1u ? 2u : 0u);
     o.color_sets = mm[14];
     f.draw_shade[d] = o;
 }
@@ -654,7 +667,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
     SurfaceOut out;
     out.color = {0.0f, 0.0f, 0.0f, 0.0f};
     out.kind = 0u; out.discard = false;
-    const uint32_t n_lights = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]);
+    const uint32_t n_lights = min(*reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]), f.lights_cap);
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
     const uint32_t shader_id = M[material_word];
     const uint32_t b = material_word + 1u;
@@ -782,7 +795,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
             background = sample_transmission_background(sc, f, frag_x, frag_y, world_position, c.normal, -surface_to_camera, c.ior,
                                                         fmaxf(clampf(c.mr.y, 0.0f, 1.0f), 0.04f), c.volume_thickness);
     }
-    const f3 color = apply_lighting(sc, c, surface_to_camera, world_position, n_lights, background);
+    const f3 color = apply_lighting(sc, f.lights_pre, c, surface_to_camera, world_position, n_lights, background);
     out.color = {color.x, color.y, color.z, base_alpha};
     return out;
 }
@@ -800,7 +813,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     out.color = {0.0f, 0.0f, 0.0f, 0.0f};
     out.kind = 0u; out.discard = false;
     const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
-    const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, is_hud
+    const uint4 ds0 = dsp[0], ds1 = dsp[1];   // first_tri, material_word, attr_indices_word, attr_data_word | stride_words, uv_sets_index, flags
     const uint32_t triangle_index = rank - ds0.x;
     if (check_hud && (ds1.z & 1u)) { out.kind = 2u; return out; }   // is_hud (compute.wgsl:176-179); msaa_process_sample has no such test
     const uint32_t material_word = ds0.y;
@@ -1050,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_forward_tile(const DevScene* __restrict_
                     }
                     TriSetup t;
                     if (!tri_rec_load(f.tri_rec + rank, t)) continue;
-                    const bool may_discard = (f.draw_shade[f.tri_info[rank] & 0x00FFFFFFu].is_hud & 2u) != 0u;     // ALPHA_MODE_MASK
+                    const bool may_discard = (f.draw_shade[f.tri_info[rank] & 0x00FFFFFFu].flags & 2u) != 0u;     // ALPHA_MODE_MASK
                     uint32_t mask = 0u;
                     float z[S];
 #pragma unroll
