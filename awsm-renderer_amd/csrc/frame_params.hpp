@@ -40,6 +40,20 @@ struct DrawShadeDev {
     uint32_t color_sets;          // COLOR_n sets in the mesh's vertex attributes (transparent pass)
 };
 
+// One of a material's five core textures (base colour, metallic-roughness, normal, occlusion, emissive; unlit: base, emissive),
+// resolved once per frame and draw by k_resolve_draws: material words -> TextureInfo -> pool array + sampler + transform become
+// one 48-byte record, so that the shading kernels reach a texel with one dependent load instead of four.
+struct TexSlotDev {
+    const uint32_t* base;   // level-0 texels of the layer (null when the texture is absent or names a missing array / sampler)
+    uint32_t width, height;
+    uint32_t flags;         // bit 0 exists, bit 1 fast path (linear, repeat/repeat, power-of-two), bit 2 dangling reference (samples as zero),
+                            // bits 24..31 uv set; slot 0 only: bits 8..12 exists mask of the five slots, bits 16..20 "uses TEXCOORD_0" mask
+    float tt[6];            // texture transform m00 m01 m10 m11 bx by (the record's first six floats)
+    uint32_t pad;
+};
+static_assert(sizeof(TexSlotDev) == 48, "TexSlotDev must be 48 bytes");
+constexpr int kCoreTextures = 5;
+
 constexpr int kMaxMipLevels = 16;
 struct TexArrayDev {
     const uint8_t* texels;            // [level][layer][h_l][w_l] RGBA8, (w >> l).max(1); levels >= 1 valid after generate_mips
@@ -81,6 +95,7 @@ struct FrameDev {
     const uint8_t* camera;        // the camera UBO this frame is shaded with (a per-frame snapshot in overlap mode)
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
+    TexSlotDev* tex_slots;        // n_draws x kCoreTextures (k_resolve_draws)
     float4* lights_pre;           // 2 x float4 per light (k_resolve_draws): {unit direction to the light (directional) or unit spot axis, kind}, {colour * intensity, 0}
     uint32_t lights_cap;          // records lights_pre can hold
     // transformed vertices (k_deform_transform outputs)

@@ -311,6 +311,25 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
     }
     return acc;
 }
+// A core texture through its per-draw slot (MipmapMode::None): the fast path needs nothing but the slot; any other sampler /
+// size falls back to the general route through the material words.
+AWSM_DI f4 sample_slot(const Attr& a, const TexSlotDev* __restrict__ slot, const uint32_t* __restrict__ M, uint32_t word) {
+    const uint4* q = reinterpret_cast<const uint4*>(slot);
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];        // base lo/hi, width, height | flags, tt0, tt1, tt2 | tt3, tt4, tt5, pad
+    const uint32_t flags = q1.x;
+    if (__builtin_amdgcn_ballot_w64((flags & 6u) != 2u) != 0ull) {       // some lane is not on the fast path
+        if (flags & 4u) return {0.0f, 0.0f, 0.0f, 0.0f};
+        return sample_tex<false>(a, tex_load(M, word));
+    }
+    const uint32_t uv_set = flags >> 24;
+    f2 uv = a.uv0, ddx, ddy;
+    if (!(a.has_uv0 && uv_set == 0u)) uv = attr_uv<false>(a, uv_set, ddx, ddy);
+    const float u = affine2_strict(__uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q2.y), uv.x, uv.y);
+    const float v = affine2_strict(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.z), uv.x, uv.y);
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(((unsigned long long)q0.y << 32) | q0.x);
+    return sample_level_fast(base, q0.z, q0.w, u, v);
+}
+
 AWSM_DI f4 vertex_color(const Attr& a, uint32_t set_index) {               // vertex_color_attrib.wgsl:1-21
     const uint32_t o = set_index * 4u;
     float r[4];
@@ -600,6 +619,43 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     o.flags = (mm[16] & 1u) | (reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS])[mm[6] / 4u + 1u] == 1u ? 2u : 0u);
     o.color_sets = mm[14];
     f.draw_shade[d] = o;
+    // the five core textures of the draw's material, ready to sample (TexSlotDev)
+    const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
+    const uint32_t b = o.material_word + 1u;
+    const bool unlit = M[o.material_word] == 2u;
+    const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
+    uint32_t exists_mask = 0u, uv0_mask = 0u;
+    for (int k = 0; k < kCoreTextures; k++) {
+        TexSlotDev s;
+        s.base = nullptr; s.width = 0u; s.height = 0u; s.flags = 0u; s.pad = 0u;
+        for (int j = 0; j < 6; j++) s.tt[j] = 0.0f;
+        if (!(unlit && k >= 2)) {
+            const TexInfo t = tex_load(M, words[k]);
+            if (t.exists) {
+                s.flags = 1u | (t.uv_set_index << 24);
+                exists_mask |= 1u << k;
+                if (t.uv_set_index == 0u) uv0_mask |= 1u << k;
+                const float* tt = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
+                for (int j = 0; j < 6; j++) s.tt[j] = tt[j];
+                bool ok = t.array_index < sc->n_tex && t.sampler_index < sc->n_samplers;
+                if (ok) {
+                    const TexArrayDev& arr = sc->tex[t.array_index];
+                    const AwsmSampler& smp = sc->samplers[t.sampler_index];
+                    ok = arr.texels != nullptr && arr.width != 0u && arr.height != 0u && arr.layers != 0u;
+                    if (ok) {
+                        const uint32_t layer = min(t.layer_index, arr.layers - 1u);
+                        s.base = reinterpret_cast<const uint32_t*>(arr.texels) + (size_t)layer * arr.width * arr.height;
+                        s.width = arr.width; s.height = arr.height;
+                        const bool common = smp.address_mode_u == 1u && smp.address_mode_v == 1u && (arr.width & (arr.width - 1u)) == 0u && (arr.height & (arr.height - 1u)) == 0u;
+                        if (common && smp.mag_filter != 0u) s.flags |= 2u;
+                    }
+                }
+                if (!ok) s.flags |= 4u;
+            }
+        }
+        f.tex_slots[(size_t)d * kCoreTextures + k] = s;
+    }
+    f.tex_slots[(size_t)d * kCoreTextures].flags |= (exists_mask << 8) | (uv0_mask << 16);
 }
 
 // fragment.wgsl:27-186 (transparent pass): the opaque image behind a transmissive surface, refracted through the volume
@@ -662,8 +718,8 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
 // where the transmission background comes from.  out.color.w = alpha.
 struct SurfaceOut { f4 color; uint32_t kind; bool discard; };
 template <bool GRAD, bool FWD>
-AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TBN& tbn, f3 world_position,
-                                  f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y) {
+AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TexSlotDev* __restrict__ slots, const TBN& tbn,
+                                  f3 world_position, f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y) {
     SurfaceOut out;
     out.color = {0.0f, 0.0f, 0.0f, 0.0f};
     out.kind = 0u; out.discard = false;
@@ -672,11 +728,17 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
     const uint32_t shader_id = M[material_word];
     const uint32_t b = material_word + 1u;
     if (shader_id == 2u) {   // unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580
-        const TexInfo base_tex = tex_load(M, b + 2), em_tex = tex_load(M, b + 11);
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
         f3 em = {mf(M, b + 16), mf(M, b + 17), mf(M, b + 18)};
-        if (base_tex.exists) { const f4 s = sample_tex<GRAD>(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
-        if (em_tex.exists) { const f4 s = sample_tex<GRAD>(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        if (GRAD) {
+            const TexInfo base_tex = tex_load(M, b + 2), em_tex = tex_load(M, b + 11);
+            if (base_tex.exists) { const f4 s = sample_tex<GRAD>(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+            if (em_tex.exists) { const f4 s = sample_tex<GRAD>(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        } else {
+            const uint32_t em_mask = slots[0].flags >> 8;
+            if (em_mask & 1u) { const f4 s = sample_slot(a, slots, M, b + 2); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+            if (em_mask & 2u) { const f4 s = sample_slot(a, slots + 1, M, b + 11); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        }
         float alpha = 1.0f;
         if (FWD) {            // transparent material_color_calc.wgsl:344-372: alpha kept; ALPHA_MODE_MASK discards or forces 1
             if (M[b + 0] == 1u) { if (base.w < mf(M, b + 1)) { out.discard = true; return out; } base.w = 1.0f; }
@@ -694,17 +756,29 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
     const uint32_t idx_vertex_color = abs_index(b, M[fi + 0]), idx_emissive_strength = abs_index(b, M[fi + 1]);
     const uint32_t idx_ior = abs_index(b, M[fi + 2]), idx_specular = abs_index(b, M[fi + 3]), idx_transmission = abs_index(b, M[fi + 4]);
     const uint32_t idx_volume = abs_index(b, M[fi + 6]), idx_clearcoat = abs_index(b, M[fi + 7]), idx_sheen = abs_index(b, M[fi + 8]);
-    const TexInfo tx_base = tex_load(M, b + 2), tx_mr = tex_load(M, b + 11), tx_normal = tex_load(M, b + 18);
-    const TexInfo tx_occ = tex_load(M, b + 24), tx_em = tex_load(M, b + 30);
+    // the five core textures: through the material words (MipmapMode::Gradient) or through the draw's resolved slots
+    TexInfo tx[kCoreTextures];
+    uint32_t exists_mask = 0u, uv0_mask = 0u;
+    if (GRAD) {
+        const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
+#pragma unroll
+        for (int k = 0; k < kCoreTextures; k++) {
+            tx[k] = tex_load(M, words[k]);
+            if (tx[k].exists) { exists_mask |= 1u << k; if (tx[k].uv_set_index == 0u) uv0_mask |= 1u << k; }
+        }
+    } else {
+        const uint32_t fl = slots[0].flags;
+        exists_mask = (fl >> 8) & 31u; uv0_mask = (fl >> 16) & 31u;
+    }
+    auto core = [&](int k, uint32_t word) -> f4 { return GRAD ? sample_tex<GRAD>(a, tx[k]) : sample_slot(a, slots + k, M, word); };
     // TEXCOORD_0 is interpolated once for all the textures that use it (the WGSL re-derives it per texture)
-    if ((tx_base.exists && tx_base.uv_set_index == 0u) || (tx_mr.exists && tx_mr.uv_set_index == 0u) || (tx_normal.exists && tx_normal.uv_set_index == 0u) ||
-        (tx_occ.exists && tx_occ.uv_set_index == 0u) || (tx_em.exists && tx_em.uv_set_index == 0u)) {
+    if (uv0_mask != 0u) {
         a.uv0 = attr_uv<GRAD>(a, 0u, a.duv0_dx, a.duv0_dy);
         a.has_uv0 = true;
     }
     {
         f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
-        if (tx_base.exists) { const f4 s = sample_tex<GRAD>(a, tx_base); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+        if (exists_mask & 1u) { const f4 s = core(0, b + 2); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
         if (!FWD) {
             base.w = 1.0f;
             if (idx_vertex_color != 0u) { const f4 vc = vertex_color(a, M[idx_vertex_color]); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
@@ -721,13 +795,19 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
         c.base = {base.x, base.y, base.z};
     }
     c.mr = {mf(M, b + 16), mf(M, b + 17)};
-    if (tx_mr.exists) { const f4 s = sample_tex<GRAD>(a, tx_mr); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
-    c.normal = normal_map<GRAD>(a, tx_normal, mf(M, b + 23), tbn);
+    if (exists_mask & 2u) { const f4 s = core(1, b + 11); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
+    c.normal = tbn.N;
+    if (exists_mask & 4u) {   // material_color_calc.wgsl:301-322
+        const f4 s = core(2, b + 18);
+        const float scale = mf(M, b + 23);
+        const float ntx = (s.x * 2.0f - 1.0f) * scale, nty = (s.y * 2.0f - 1.0f) * scale, ntz = s.z * 2.0f - 1.0f;
+        c.normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
+    }
     c.occlusion = 1.0f;
-    if (tx_occ.exists) { const f4 s = sample_tex<GRAD>(a, tx_occ); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
+    if (exists_mask & 8u) { const f4 s = core(3, b + 24); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
     {
         f3 em = {mf(M, b + 35), mf(M, b + 36), mf(M, b + 37)};
-        if (tx_em.exists) { const f4 s = sample_tex<GRAD>(a, tx_em); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+        if (exists_mask & 16u) { const f4 s = core(4, b + 30); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
         c.emissive = em * (idx_emissive_strength == 0u ? 1.0f : mf(M, idx_emissive_strength));
     }
     c.ior = idx_ior == 0u ? 1.5f : mf(M, idx_ior);
@@ -852,7 +932,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     }
     const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
 
-    return shade_material<GRAD, false>(sc, f, a, material_word, tbn, world_position, surface_to_camera, 0u, 0.0f, 0.0f);
+    return shade_material<GRAD, false>(sc, f, a, material_word, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, tbn, world_position, surface_to_camera, 0u, 0.0f, 0.0f);
 }
 
 
@@ -934,7 +1014,8 @@ AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const Frame
         else tbn.T = fm::fnormalize(cross(fabsf(tbn.N.z) > 0.999f ? mk3(0.0f, 1.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f), tbn.N));
     }
     tbn.B = cross(tbn.N, tbn.T) * handedness;
-    return shade_material<GRAD, true>(sc, f, a, ds0.y, tbn, world_position, surface_to_camera, ds1.w, (float)px + 0.5f, (float)py + 0.5f);
+    return shade_material<GRAD, true>(sc, f, a, ds0.y, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, tbn, world_position, surface_to_camera, ds1.w,
+                                      (float)px + 0.5f, (float)py + 0.5f);
 }
 
 // A fragment that passed coverage and the depth test, waiting to be shaded: triangle, which samples, their depths.
