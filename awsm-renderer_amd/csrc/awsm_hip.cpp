@@ -48,6 +48,7 @@ enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE, 
 struct FrameBufs {
     DevBuf wpos;                           // transparent pass only
     DevBuf tex_slots;                      // n_draws x kCoreTextures TexSlotDev (k_resolve_draws)
+    DevBuf draw_mat;                       // n_draws DrawMatDev (k_resolve_draws)
     DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
     DevBuf camera;                         // snapshot of the camera UBO taken by the geometry pass (overlap mode)
     uint32_t bin_capacity = 0;
@@ -257,6 +258,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->draws = (const DrawDev*)FB(c).draws_dev.ptr;
     f->draw_shade = (DrawShadeDev*)FB(c).draw_shade.ptr;
     f->tex_slots = (TexSlotDev*)FB(c).tex_slots.ptr;
+    f->draw_mat = (DrawMatDev*)FB(c).draw_mat.ptr;
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     f->tri_rec = (TriRec*)FB(c).tri_rec.ptr;
@@ -351,6 +353,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->draws = (const DrawDev*)t.draws_dev.ptr;
     f->draw_shade = (DrawShadeDev*)t.draw_shade.ptr;
     f->tex_slots = (TexSlotDev*)t.tex_slots.ptr;
+    f->draw_mat = (DrawMatDev*)t.draw_mat.ptr;
     f->clip = (float4*)t.clip.ptr; f->nrm = (float4*)t.nrm.ptr; f->tan = (float4*)t.tan.ptr; f->wpos = (float4*)t.wpos.ptr;
     f->tri_info = (uint32_t*)t.tri_flags.ptr;
     f->tri_rec = (TriRec*)t.tri_rec.ptr;
@@ -446,6 +449,7 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
     if ((rc = dev_reserve(c, b.draws_dev, nd * sizeof(DrawDev)))) return rc;
     if ((rc = dev_reserve(c, b.draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
     if ((rc = dev_reserve(c, b.tex_slots, nd * kCoreTextures * sizeof(TexSlotDev)))) return rc;
+    if ((rc = dev_reserve(c, b.draw_mat, nd * sizeof(DrawMatDev)))) return rc;
     if ((rc = dev_reserve(c, b.clip, nv * 16))) return rc;
     if ((rc = dev_reserve(c, b.nrm, nv * 16))) return rc;
     if ((rc = dev_reserve(c, b.tan, nv * 16))) return rc;
@@ -548,7 +552,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
-        fr(b.vis); fr(b.wpos); fr(b.tex_slots); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
+        fr(b.vis); fr(b.wpos); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);

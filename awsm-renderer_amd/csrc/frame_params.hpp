@@ -54,6 +54,20 @@ struct TexSlotDev {
 static_assert(sizeof(TexSlotDev) == 48, "TexSlotDev must be 48 bytes");
 constexpr int kCoreTextures = 5;
 
+// The factor half of a draw's material, gathered from the word stream (materials/pbr.rs:258-357, unlit.rs:72-105) into four
+// aligned 16-byte loads.  ext_mask = 0 (no optional block: the common case) means the shading never touches the word stream.
+struct DrawMatDev {
+    float base_color[4];
+    float metallic, roughness, normal_scale, occlusion_strength;
+    float emissive[3];            // PBR: factor * emissive_strength; unlit: factor
+    float ior;                    // 1.5 when the material has none
+    uint32_t shader_alpha;        // shader id | alpha_mode << 8
+    uint32_t debug_bitmask;
+    uint32_t ext_mask;            // bit per optional block present: 0 vertex colour, 3 specular, 4 transmission, 6 volume, 7 clearcoat, 8 sheen (feature-index order)
+    float alpha_cutoff;
+};
+static_assert(sizeof(DrawMatDev) == 64, "DrawMatDev must be 64 bytes");
+
 constexpr int kMaxMipLevels = 16;
 struct TexArrayDev {
     const uint8_t* texels;            // [level][layer][h_l][w_l] RGBA8, (w >> l).max(1); levels >= 1 valid after generate_mips
@@ -96,6 +110,7 @@ struct FrameDev {
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
     TexSlotDev* tex_slots;        // n_draws x kCoreTextures (k_resolve_draws)
+    DrawMatDev* draw_mat;         // n_draws (k_resolve_draws)
     float4* lights_pre;           // 2 x float4 per light (k_resolve_draws): {unit direction to the light (directional) or unit spot axis, kind}, {colour * intensity, 0}
     uint32_t lights_cap;          // records lights_pre can hold
     // transformed vertices (k_deform_transform outputs)

@@ -606,56 +606,84 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
             f.lights_pre[i * 2 + 1] = make_float4(color_intensity.x * color_intensity.w, color_intensity.y * color_intensity.w, color_intensity.z * color_intensity.w, 0.0f);
         }
     }
-    if (d >= f.n_draws) return;
-    const DrawDev dr = f.draws[d];
+    // eight threads per draw: roles 0..4 resolve one core texture each, role 5 the per-draw records
+    const uint32_t draw = d >> 3, role = d & 7u;
+    if (draw >= f.n_draws || role > 5u) return;
+    const DrawDev dr = f.draws[draw];
     const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
     const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
-    DrawShadeDev o;
-    o.first_tri = dr.first_tri;
-    o.material_word = mm[6] / 4u;
-    o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
-    o.uv_sets_index = mm[12];
-    // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments, so their depth write waits for the shading)
-    o.flags = (mm[16] & 1u) | (reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS])[mm[6] / 4u + 1u] == 1u ? 2u : 0u);
-    o.color_sets = mm[14];
-    f.draw_shade[d] = o;
-    // the five core textures of the draw's material, ready to sample (TexSlotDev)
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
-    const uint32_t b = o.material_word + 1u;
-    const bool unlit = M[o.material_word] == 2u;
-    const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
-    uint32_t exists_mask = 0u, uv0_mask = 0u;
-    for (int k = 0; k < kCoreTextures; k++) {
-        TexSlotDev s;
-        s.base = nullptr; s.width = 0u; s.height = 0u; s.flags = 0u; s.pad = 0u;
-        for (int j = 0; j < 6; j++) s.tt[j] = 0.0f;
-        if (!(unlit && k >= 2)) {
-            const TexInfo t = tex_load(M, words[k]);
-            if (t.exists) {
-                s.flags = 1u | (t.uv_set_index << 24);
-                exists_mask |= 1u << k;
-                if (t.uv_set_index == 0u) uv0_mask |= 1u << k;
-                const float* tt = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
-                for (int j = 0; j < 6; j++) s.tt[j] = tt[j];
-                bool ok = t.array_index < sc->n_tex && t.sampler_index < sc->n_samplers;
-                if (ok) {
-                    const TexArrayDev& arr = sc->tex[t.array_index];
-                    const AwsmSampler& smp = sc->samplers[t.sampler_index];
-                    ok = arr.texels != nullptr && arr.width != 0u && arr.height != 0u && arr.layers != 0u;
-                    if (ok) {
-                        const uint32_t layer = min(t.layer_index, arr.layers - 1u);
-                        s.base = reinterpret_cast<const uint32_t*>(arr.texels) + (size_t)layer * arr.width * arr.height;
-                        s.width = arr.width; s.height = arr.height;
-                        const bool common = smp.address_mode_u == 1u && smp.address_mode_v == 1u && (arr.width & (arr.width - 1u)) == 0u && (arr.height & (arr.height - 1u)) == 0u;
-                        if (common && smp.mag_filter != 0u) s.flags |= 2u;
-                    }
-                }
-                if (!ok) s.flags |= 4u;
-            }
+    const uint32_t material_word = mm[6] / 4u, b = material_word + 1u;
+    const uint32_t shader_id = M[material_word];
+    const bool unlit = shader_id == 2u;
+    if (role == 5u) {
+        DrawShadeDev o;
+        o.first_tri = dr.first_tri;
+        o.material_word = material_word;
+        o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
+        o.uv_sets_index = mm[12];
+        // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments, so their depth write waits for the shading)
+        o.flags = (mm[16] & 1u) | (M[b] == 1u ? 2u : 0u);
+        o.color_sets = mm[14];
+        f.draw_shade[draw] = o;
+        DrawMatDev m;
+        for (int j = 0; j < 4; j++) m.base_color[j] = mf(M, b + 7 + j);
+        m.shader_alpha = shader_id | (M[b] << 8);
+        m.alpha_cutoff = mf(M, b + 1);
+        m.ext_mask = 0u; m.debug_bitmask = 0u; m.ior = 1.5f;
+        m.metallic = 0.0f; m.roughness = 0.0f; m.normal_scale = 1.0f; m.occlusion_strength = 1.0f;
+        if (unlit) {
+            for (int j = 0; j < 3; j++) m.emissive[j] = mf(M, b + 16 + j);
+        } else {
+            m.metallic = mf(M, b + 16); m.roughness = mf(M, b + 17); m.normal_scale = mf(M, b + 23); m.occlusion_strength = mf(M, b + 29);
+            m.debug_bitmask = M[b + 38];
+            const uint32_t fi = b + 39u;
+            for (int j = 0; j < 12; j++) if (M[fi + j] != 0u) m.ext_mask |= 1u << j;
+            const float strength = M[fi + 1] != 0u ? mf(M, b + M[fi + 1]) : 1.0f;
+            for (int j = 0; j < 3; j++) m.emissive[j] = mf(M, b + 35 + j) * strength;
+            if (M[fi + 2] != 0u) m.ior = mf(M, b + M[fi + 2]);
         }
-        f.tex_slots[(size_t)d * kCoreTextures + k] = s;
+        f.draw_mat[draw] = m;
+        return;
     }
-    f.tex_slots[(size_t)d * kCoreTextures].flags |= (exists_mask << 8) | (uv0_mask << 16);
+    // one of the five core textures of the draw's material, ready to sample (TexSlotDev)
+    const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
+    const int k = (int)role;
+    TexSlotDev s;
+    s.base = nullptr; s.width = 0u; s.height = 0u; s.flags = 0u; s.pad = 0u;
+    for (int j = 0; j < 6; j++) s.tt[j] = 0.0f;
+    if (!(unlit && k >= 2)) {
+        const TexInfo t = tex_load(M, words[k]);
+        if (t.exists) {
+            s.flags = 1u | (t.uv_set_index << 24);
+            const float* tt = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TEXTURE_TRANSFORMS] + (size_t)t.uv_transform_index * 32u);
+            for (int j = 0; j < 6; j++) s.tt[j] = tt[j];
+            bool ok = t.array_index < sc->n_tex && t.sampler_index < sc->n_samplers;
+            if (ok) {
+                const TexArrayDev& arr = sc->tex[t.array_index];
+                const AwsmSampler& smp = sc->samplers[t.sampler_index];
+                ok = arr.texels != nullptr && arr.width != 0u && arr.height != 0u && arr.layers != 0u;
+                if (ok) {
+                    const uint32_t layer = min(t.layer_index, arr.layers - 1u);
+                    s.base = reinterpret_cast<const uint32_t*>(arr.texels) + (size_t)layer * arr.width * arr.height;
+                    s.width = arr.width; s.height = arr.height;
+                    const bool common = smp.address_mode_u == 1u && smp.address_mode_v == 1u && (arr.width & (arr.width - 1u)) == 0u && (arr.height & (arr.height - 1u)) == 0u;
+                    if (common && smp.mag_filter != 0u) s.flags |= 2u;
+                }
+            }
+            if (!ok) s.flags |= 4u;
+        }
+    }
+    if (k == 0) {   // slot 0 also carries which of the five exist and which use TEXCOORD_0
+        uint32_t exists_mask = 0u, uv0_mask = 0u;
+        for (int j = 0; j < kCoreTextures; j++) {
+            if (unlit && j >= 2) break;
+            const uint32_t uv_and_sampler = M[words[j] + 2], extra = M[words[j] + 3];
+            if (extra & 1u) { exists_mask |= 1u << j; if ((uv_and_sampler & 0xFFu) == 0u) uv0_mask |= 1u << j; }
+        }
+        s.flags |= (exists_mask << 8) | (uv0_mask << 16);
+    }
+    f.tex_slots[(size_t)draw * kCoreTextures + k] = s;
 }
 
 // fragment.wgsl:27-186 (transparent pass): the opaque image behind a transmissive surface, refracted through the volume
@@ -718,18 +746,23 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
 // where the transmission background comes from.  out.color.w = alpha.
 struct SurfaceOut { f4 color; uint32_t kind; bool discard; };
 template <bool GRAD, bool FWD>
-AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TexSlotDev* __restrict__ slots, const TBN& tbn,
+AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TexSlotDev* __restrict__ slots,
+                                  const DrawMatDev* __restrict__ draw_mat, const TBN& tbn,
                                   f3 world_position, f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y) {
     SurfaceOut out;
     out.color = {0.0f, 0.0f, 0.0f, 0.0f};
     out.kind = 0u; out.discard = false;
     const uint32_t n_lights = min(*reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]), f.lights_cap);
     const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
-    const uint32_t shader_id = M[material_word];
     const uint32_t b = material_word + 1u;
+    // the factor half of the material: four aligned loads of the per-draw record instead of ~25 scattered words of the stream
+    const float4* dmq = reinterpret_cast<const float4*>(draw_mat);
+    const float4 dm0 = dmq[0], dm1 = dmq[1], dm2 = dmq[2], dm3 = dmq[3];   // base colour | metallic roughness normal_scale occlusion_strength | emissive ior | shader_alpha debug ext cutoff
+    const uint32_t shader_alpha = __float_as_uint(dm3.x), shader_id = shader_alpha & 0xFFu, alpha_mode = shader_alpha >> 8;
+    const float alpha_cutoff = dm3.w;
     if (shader_id == 2u) {   // unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580
-        f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
-        f3 em = {mf(M, b + 16), mf(M, b + 17), mf(M, b + 18)};
+        f4 base = {dm0.x, dm0.y, dm0.z, dm0.w};
+        f3 em = {dm2.x, dm2.y, dm2.z};
         if (GRAD) {
             const TexInfo base_tex = tex_load(M, b + 2), em_tex = tex_load(M, b + 11);
             if (base_tex.exists) { const f4 s = sample_tex<GRAD>(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
@@ -741,7 +774,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
         }
         float alpha = 1.0f;
         if (FWD) {            // transparent material_color_calc.wgsl:344-372: alpha kept; ALPHA_MODE_MASK discards or forces 1
-            if (M[b + 0] == 1u) { if (base.w < mf(M, b + 1)) { out.discard = true; return out; } base.w = 1.0f; }
+            if (alpha_mode == 1u) { if (base.w < alpha_cutoff) { out.discard = true; return out; } base.w = 1.0f; }
             alpha = base.w;
         }
         out.color = {base.x + em.x, base.y + em.y, base.z + em.z, alpha};
@@ -751,11 +784,13 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
     // ---- pbr_material.wgsl:110-216 + material_color_calc.wgsl:25-265 ----
     PbrColor c;
     float base_alpha = 1.0f;
-    const uint32_t debug_bitmask = M[b + 38];
-    const uint32_t fi = b + 39u;
-    const uint32_t idx_vertex_color = abs_index(b, M[fi + 0]), idx_emissive_strength = abs_index(b, M[fi + 1]);
-    const uint32_t idx_ior = abs_index(b, M[fi + 2]), idx_specular = abs_index(b, M[fi + 3]), idx_transmission = abs_index(b, M[fi + 4]);
-    const uint32_t idx_volume = abs_index(b, M[fi + 6]), idx_clearcoat = abs_index(b, M[fi + 7]), idx_sheen = abs_index(b, M[fi + 8]);
+    const uint32_t debug_bitmask = __float_as_uint(dm3.y), ext_mask = __float_as_uint(dm3.z);
+    uint32_t idx_vertex_color = 0u, idx_specular = 0u, idx_transmission = 0u, idx_volume = 0u, idx_clearcoat = 0u, idx_sheen = 0u;
+    if (ext_mask != 0u) {     // optional blocks: their word indices come from the stream (pbr.rs:358-362); most materials have none
+        const uint32_t fi = b + 39u;
+        idx_vertex_color = abs_index(b, M[fi + 0]); idx_specular = abs_index(b, M[fi + 3]); idx_transmission = abs_index(b, M[fi + 4]);
+        idx_volume = abs_index(b, M[fi + 6]); idx_clearcoat = abs_index(b, M[fi + 7]); idx_sheen = abs_index(b, M[fi + 8]);
+    }
     // the five core textures: through the material words (MipmapMode::Gradient) or through the draw's resolved slots
     TexInfo tx[kCoreTextures];
     uint32_t exists_mask = 0u, uv0_mask = 0u;
@@ -777,7 +812,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
         a.has_uv0 = true;
     }
     {
-        f4 base = {mf(M, b + 7), mf(M, b + 8), mf(M, b + 9), mf(M, b + 10)};
+        f4 base = {dm0.x, dm0.y, dm0.z, dm0.w};
         if (exists_mask & 1u) { const f4 s = core(0, b + 2); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
         if (!FWD) {
             base.w = 1.0f;
@@ -789,28 +824,28 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
                 const uint32_t set_index = idx_vertex_color != 0u ? M[idx_vertex_color] : 0u;
                 if (set_index < color_sets) { const f4 vc = vertex_color(a, set_index); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
             }
-            if (M[b + 0] == 1u) { if (base.w < mf(M, b + 1)) { out.discard = true; return out; } base.w = 1.0f; }
+            if (alpha_mode == 1u) { if (base.w < alpha_cutoff) { out.discard = true; return out; } base.w = 1.0f; }
             base_alpha = base.w;
         }
         c.base = {base.x, base.y, base.z};
     }
-    c.mr = {mf(M, b + 16), mf(M, b + 17)};
+    c.mr = {dm1.x, dm1.y};
     if (exists_mask & 2u) { const f4 s = core(1, b + 11); c.mr = {c.mr.x * s.z, c.mr.y * s.y}; }
     c.normal = tbn.N;
     if (exists_mask & 4u) {   // material_color_calc.wgsl:301-322
         const f4 s = core(2, b + 18);
-        const float scale = mf(M, b + 23);
+        const float scale = dm1.z;
         const float ntx = (s.x * 2.0f - 1.0f) * scale, nty = (s.y * 2.0f - 1.0f) * scale, ntz = s.z * 2.0f - 1.0f;
         c.normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
     }
     c.occlusion = 1.0f;
-    if (exists_mask & 8u) { const f4 s = core(3, b + 24); c.occlusion = mixf(1.0f, s.x, mf(M, b + 29)); }
+    if (exists_mask & 8u) { const f4 s = core(3, b + 24); c.occlusion = mixf(1.0f, s.x, dm1.w); }
     {
-        f3 em = {mf(M, b + 35), mf(M, b + 36), mf(M, b + 37)};
+        f3 em = {dm2.x, dm2.y, dm2.z};                 // factor * emissive_strength (k_resolve_draws)
         if (exists_mask & 16u) { const f4 s = core(4, b + 30); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
-        c.emissive = em * (idx_emissive_strength == 0u ? 1.0f : mf(M, idx_emissive_strength));
+        c.emissive = em;
     }
-    c.ior = idx_ior == 0u ? 1.5f : mf(M, idx_ior);
+    c.ior = dm2.w;
     c.specular = 1.0f; c.specular_color = {1.0f, 1.0f, 1.0f};
     if (idx_specular != 0u) {
         const uint32_t i = idx_specular;
@@ -932,7 +967,7 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
     }
     const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
 
-    return shade_material<GRAD, false>(sc, f, a, material_word, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, tbn, world_position, surface_to_camera, 0u, 0.0f, 0.0f);
+    return shade_material<GRAD, false>(sc, f, a, material_word, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, f.draw_mat + (f.tri_info[rank] & 0x00FFFFFFu), tbn, world_position, surface_to_camera, 0u, 0.0f, 0.0f);
 }
 
 
@@ -1014,7 +1049,7 @@ AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const Frame
         else tbn.T = fm::fnormalize(cross(fabsf(tbn.N.z) > 0.999f ? mk3(0.0f, 1.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f), tbn.N));
     }
     tbn.B = cross(tbn.N, tbn.T) * handedness;
-    return shade_material<GRAD, true>(sc, f, a, ds0.y, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, tbn, world_position, surface_to_camera, ds1.w,
+    return shade_material<GRAD, true>(sc, f, a, ds0.y, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, f.draw_mat + (f.tri_info[rank] & 0x00FFFFFFu), tbn, world_position, surface_to_camera, ds1.w,
                                       (float)px + 0.5f, (float)py + 0.5f);
 }
 
@@ -1480,7 +1515,7 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
-    if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
+    if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     if (!nb) return;
     const bool grad = f->mipmap != 0u;      // MipmapMode::Gradient vs None: separate instantiations, as the reference keeps separate pipelines
     if (f->msaa == 4u) {
@@ -1496,7 +1531,7 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
 extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (!n_tiles) return;
-    if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
+    if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     const bool grad = f->mipmap != 0u;
     if (f->msaa == 4u) {
         if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<4, true>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
