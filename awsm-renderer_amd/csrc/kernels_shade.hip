@@ -1512,10 +1512,13 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 
 }  // namespace awsm
 
+// per-draw records (DrawShadeDev, DrawMatDev, TexSlotDev) + per-light constants, before the kernels that shade
+extern "C" void awsm_launch_resolve_draws(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
+    if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
+}
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
-    if (nb && f->has_opaque && f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     if (!nb) return;
     const bool grad = f->mipmap != 0u;      // MipmapMode::Gradient vs None: separate instantiations, as the reference keeps separate pipelines
     if (f->msaa == 4u) {
@@ -1531,7 +1534,6 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
 extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (!n_tiles) return;
-    if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
     const bool grad = f->mipmap != 0u;
     if (f->msaa == 4u) {
         if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<4, true>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
