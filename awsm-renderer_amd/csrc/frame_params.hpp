@@ -42,16 +42,19 @@ struct DrawShadeDev {
 
 // One of a material's five core textures (base colour, metallic-roughness, normal, occlusion, emissive; unlit: base, emissive),
 // resolved once per frame and draw by k_resolve_draws: material words -> TextureInfo -> pool array + sampler + transform become
-// one 48-byte record, so that the shading kernels reach a texel with one dependent load instead of four.
+// one 64-byte record, so that the shading kernels reach a texel with one dependent load instead of four.
 struct TexSlotDev {
     const uint32_t* base;   // level-0 texels of the layer (null when the texture is absent or names a missing array / sampler)
     uint32_t width, height;
-    uint32_t flags;         // bit 0 exists, bit 1 fast path (linear, repeat/repeat, power-of-two), bit 2 dangling reference (samples as zero),
-                            // bits 24..31 uv set; slot 0 only: bits 8..12 exists mask of the five slots, bits 16..20 "uses TEXCOORD_0" mask
+    uint32_t flags;         // bit 0 exists, bit 1 fast path at level 0 (mag linear, repeat/repeat, power-of-two), bit 2 dangling reference (samples as
+                            // zero), bit 3 repeat/repeat + power-of-two, bits 4/5/6 mag / min / mipmap filter linear, bits 13..14 / 21..22 address mode
+                            // u / v, bits 24..31 uv set; slot 0 only: bits 8..12 exists mask of the five slots, bits 16..20 "uses TEXCOORD_0" mask
     float tt[6];            // texture transform m00 m01 m10 m11 bx by (the record's first six floats)
-    uint32_t pad;
+    uint32_t layer_levels;  // layer | mip levels << 24
+    const uint32_t* level_off;   // the array's per-level texel offsets (TexArrayDev::level_off), MipmapMode::Gradient
+    const uint32_t* array_base;  // the array's level chain
 };
-static_assert(sizeof(TexSlotDev) == 48, "TexSlotDev must be 48 bytes");
+static_assert(sizeof(TexSlotDev) == 64, "TexSlotDev must be 64 bytes");
 constexpr int kCoreTextures = 5;
 
 // The factor half of a draw's material, gathered from the word stream (materials/pbr.rs:258-357, unlit.rs:72-105) into four

@@ -311,23 +311,64 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
     }
     return acc;
 }
-// A core texture through its per-draw slot (MipmapMode::None): the fast path needs nothing but the slot; any other sampler /
-// size falls back to the general route through the material words.
+// A core texture through its per-draw slot.  MipmapMode::None: the fast path needs nothing but the slot; any other sampler / size falls
+// back to the general route through the material words.  MipmapMode::Gradient: level selection as sample_tex<true>, with the array's
+// layout and the sampler's modes taken from the slot.
+template <bool GRAD>
 AWSM_DI f4 sample_slot(const Attr& a, const TexSlotDev* __restrict__ slot, const uint32_t* __restrict__ M, uint32_t word) {
     const uint4* q = reinterpret_cast<const uint4*>(slot);
-    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];        // base lo/hi, width, height | flags, tt0, tt1, tt2 | tt3, tt4, tt5, pad
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];        // base lo/hi, width, height | flags, tt0, tt1, tt2 | tt3, tt4, tt5, layer_levels
     const uint32_t flags = q1.x;
-    if (__builtin_amdgcn_ballot_w64((flags & 6u) != 2u) != 0ull) {       // some lane is not on the fast path
-        if (flags & 4u) return {0.0f, 0.0f, 0.0f, 0.0f};
-        return sample_tex<false>(a, tex_load(M, word));
-    }
     const uint32_t uv_set = flags >> 24;
-    f2 uv = a.uv0, ddx, ddy;
-    if (!(a.has_uv0 && uv_set == 0u)) uv = attr_uv<false>(a, uv_set, ddx, ddy);
-    const float u = affine2_strict(__uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q2.y), uv.x, uv.y);
-    const float v = affine2_strict(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.z), uv.x, uv.y);
-    const uint32_t* base = reinterpret_cast<const uint32_t*>(((unsigned long long)q0.y << 32) | q0.x);
-    return sample_level_fast(base, q0.z, q0.w, u, v);
+    const float t0 = __uint_as_float(q1.y), t1 = __uint_as_float(q1.z), t2 = __uint_as_float(q1.w), t3 = __uint_as_float(q2.x), t4 = __uint_as_float(q2.y), t5 = __uint_as_float(q2.z);
+    if (!GRAD) {
+        if (__builtin_amdgcn_ballot_w64((flags & 6u) != 2u) != 0ull) {       // some lane is not on the fast path
+            if (flags & 4u) return {0.0f, 0.0f, 0.0f, 0.0f};
+            return sample_tex<false>(a, tex_load(M, word));
+        }
+        f2 uv = a.uv0, ddx, ddy;
+        if (!(a.has_uv0 && uv_set == 0u)) uv = attr_uv<false>(a, uv_set, ddx, ddy);
+        const float u = affine2_strict(t0, t1, t4, uv.x, uv.y), v = affine2_strict(t2, t3, t5, uv.x, uv.y);
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(((unsigned long long)q0.y << 32) | q0.x);
+        return sample_level_fast(base, q0.z, q0.w, u, v);
+    }
+    if (flags & 4u) return {0.0f, 0.0f, 0.0f, 0.0f};
+    f2 uv = a.uv0, ddx = a.duv0_dx, ddy = a.duv0_dy;
+    if (!(a.has_uv0 && uv_set == 0u)) uv = attr_uv<GRAD>(a, uv_set, ddx, ddy);
+    const float u = affine2_strict(t0, t1, t4, uv.x, uv.y), v = affine2_strict(t2, t3, t5, uv.x, uv.y);
+    const uint4 q3 = q[3];                              // level_off pointer, array base
+    const uint32_t* level_off = reinterpret_cast<const uint32_t*>(((unsigned long long)q3.y << 32) | q3.x);
+    const uint32_t* texels = reinterpret_cast<const uint32_t*>(((unsigned long long)q3.w << 32) | q3.z);
+    const uint32_t W = q0.z, H = q0.w, layer = q2.w & 0xFFFFFFu, levels = q2.w >> 24;
+    const uint32_t mode_u = (flags >> 13) & 3u, mode_v = (flags >> 21) & 3u;
+    // ---- level selection (texture_uvs.wgsl:27-35 + the isotropic LOD contract) ----
+    const float dxu = t0 * ddx.x + t1 * ddx.y, dxv = t2 * ddx.x + t3 * ddx.y;
+    const float dyu = t0 * ddy.x + t1 * ddy.y, dyv = t2 * ddy.x + t3 * ddy.y;
+    const float ax = dxu * (float)W, ay = dxv * (float)H, bx = dyu * (float)W, by = dyv * (float)H;
+    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    float lod = 0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1e-12f));      // log2(max(rho, 1e-6))
+    uint32_t lo = 0u, hi = 0u, linear = (flags >> 4) & 1u;
+    float f = 0.0f;
+    if (lod > 0.0f && levels > 1u) {
+        lod = fminf(lod, (float)(levels - 1u));
+        linear = (flags >> 5) & 1u;
+        if (!(flags & 64u)) { lo = hi = (uint32_t)floorf(lod + 0.5f); }
+        else { const float fl = floorf(lod); lo = (uint32_t)fl; hi = min(lo + 1u, levels - 1u); f = (hi != lo) ? lod - fl : 0.0f; }
+    }
+    const bool fast = (flags & 8u) != 0u && linear != 0u;
+    const bool all_fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int n = f > 0.0f ? 2 : 1;
+    for (int k = 0; k < n; k++) {            // not unrolled: one copy of the samplers per call site
+        const uint32_t level = k ? hi : lo;
+        const float w = k ? f : 1.0f - f;
+        const uint32_t Wl = max(W >> level, 1u), Hl = max(H >> level, 1u);
+        const uint32_t* base = texels + level_off[level] + (size_t)layer * Wl * Hl;
+        const f4 c = all_fast ? sample_level_fast(base, Wl, Hl, u, v)
+                              : sample_level_generic(reinterpret_cast<const uint8_t*>(base), Wl, Hl, mode_u, mode_v, linear, u, v);
+        acc = {acc.x + c.x * w, acc.y + c.y * w, acc.z + c.z * w, acc.w + c.w * w};
+    }
+    return acc;
 }
 
 AWSM_DI f4 vertex_color(const Attr& a, uint32_t set_index) {               // vertex_color_attrib.wgsl:1-21
@@ -650,7 +691,7 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
     const int k = (int)role;
     TexSlotDev s;
-    s.base = nullptr; s.width = 0u; s.height = 0u; s.flags = 0u; s.pad = 0u;
+    s.base = nullptr; s.width = 0u; s.height = 0u; s.flags = 0u; s.layer_levels = 0u; s.level_off = nullptr; s.array_base = nullptr;
     for (int j = 0; j < 6; j++) s.tt[j] = 0.0f;
     if (!(unlit && k >= 2)) {
         const TexInfo t = tex_load(M, words[k]);
@@ -669,6 +710,12 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                     s.width = arr.width; s.height = arr.height;
                     const bool common = smp.address_mode_u == 1u && smp.address_mode_v == 1u && (arr.width & (arr.width - 1u)) == 0u && (arr.height & (arr.height - 1u)) == 0u;
                     if (common && smp.mag_filter != 0u) s.flags |= 2u;
+                    if (common) s.flags |= 8u;
+                    s.flags |= (smp.mag_filter != 0u ? 16u : 0u) | (smp.min_filter != 0u ? 32u : 0u) | (smp.mipmap_filter != 0u ? 64u : 0u);
+                    s.flags |= ((smp.address_mode_u & 3u) << 13) | ((smp.address_mode_v & 3u) << 21);
+                    s.layer_levels = layer | (max(arr.mips, 1u) << 24);
+                    s.level_off = &sc->tex[t.array_index].level_off[0];
+                    s.array_base = reinterpret_cast<const uint32_t*>(arr.texels);
                 }
             }
             if (!ok) s.flags |= 4u;
@@ -763,14 +810,10 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
     if (shader_id == 2u) {   // unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580
         f4 base = {dm0.x, dm0.y, dm0.z, dm0.w};
         f3 em = {dm2.x, dm2.y, dm2.z};
-        if (GRAD) {
-            const TexInfo base_tex = tex_load(M, b + 2), em_tex = tex_load(M, b + 11);
-            if (base_tex.exists) { const f4 s = sample_tex<GRAD>(a, base_tex); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
-            if (em_tex.exists) { const f4 s = sample_tex<GRAD>(a, em_tex); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
-        } else {
+        {
             const uint32_t em_mask = slots[0].flags >> 8;
-            if (em_mask & 1u) { const f4 s = sample_slot(a, slots, M, b + 2); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
-            if (em_mask & 2u) { const f4 s = sample_slot(a, slots + 1, M, b + 11); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
+            if (em_mask & 1u) { const f4 s = sample_slot<GRAD>(a, slots, M, b + 2); base = {base.x * s.x, base.y * s.y, base.z * s.z, base.w * s.w}; }
+            if (em_mask & 2u) { const f4 s = sample_slot<GRAD>(a, slots + 1, M, b + 11); em = {em.x * s.x, em.y * s.y, em.z * s.z}; }
         }
         float alpha = 1.0f;
         if (FWD) {            // transparent material_color_calc.wgsl:344-372: alpha kept; ALPHA_MODE_MASK discards or forces 1
@@ -791,21 +834,10 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
         idx_vertex_color = abs_index(b, M[fi + 0]); idx_specular = abs_index(b, M[fi + 3]); idx_transmission = abs_index(b, M[fi + 4]);
         idx_volume = abs_index(b, M[fi + 6]); idx_clearcoat = abs_index(b, M[fi + 7]); idx_sheen = abs_index(b, M[fi + 8]);
     }
-    // the five core textures: through the material words (MipmapMode::Gradient) or through the draw's resolved slots
-    TexInfo tx[kCoreTextures];
-    uint32_t exists_mask = 0u, uv0_mask = 0u;
-    if (GRAD) {
-        const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
-#pragma unroll
-        for (int k = 0; k < kCoreTextures; k++) {
-            tx[k] = tex_load(M, words[k]);
-            if (tx[k].exists) { exists_mask |= 1u << k; if (tx[k].uv_set_index == 0u) uv0_mask |= 1u << k; }
-        }
-    } else {
-        const uint32_t fl = slots[0].flags;
-        exists_mask = (fl >> 8) & 31u; uv0_mask = (fl >> 16) & 31u;
-    }
-    auto core = [&](int k, uint32_t word) -> f4 { return GRAD ? sample_tex<GRAD>(a, tx[k]) : sample_slot(a, slots + k, M, word); };
+    // the five core textures, through the draw's resolved slots
+    const uint32_t slot_flags = slots[0].flags;
+    const uint32_t exists_mask = (slot_flags >> 8) & 31u, uv0_mask = (slot_flags >> 16) & 31u;
+    auto core = [&](int k, uint32_t word) -> f4 { return sample_slot<GRAD>(a, slots + k, M, word); };
     // TEXCOORD_0 is interpolated once for all the textures that use it (the WGSL re-derives it per texture)
     if (uv0_mask != 0u) {
         a.uv0 = attr_uv<GRAD>(a, 0u, a.duv0_dx, a.duv0_dy);
