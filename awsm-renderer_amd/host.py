@@ -15,7 +15,7 @@ from . import PACKAGE_DIR, hip_backend
 from .hip_backend import AwsmDraw, AwsmEnv, AwsmFrameStats, AwsmSampler
 from .scene_desc import MaterialDesc, SceneDesc, TextureRef, texture_mip_kinds
 
-LIB_PATH = os.path.join(PACKAGE_DIR, "libawsm_host.so")
+LIB_PATH = os.environ.get("AWSM_HOST_LIB") or os.path.join(PACKAGE_DIR, "libawsm_host.so")   # AWSM_HOST_LIB: instrumented builds of the same ABI (tests)
 F32P = C.POINTER(C.c_float)
 U32P = C.POINTER(C.c_uint32)
 

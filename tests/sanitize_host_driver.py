@@ -1,0 +1,74 @@
+"""Run by tests/test_sanitizers_cpu.py in a child process with the AddressSanitizer runtime preloaded: drives the ASan + UBSan build of the
+C++ host layer (glTF reader included) through population, rendering against the mock backend, and a few hundred corrupted glTF files."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from awsm_renderer_amd import gltf_export, scenes  # noqa: E402
+from awsm_renderer_amd import host as H  # noqa: E402
+
+MOCK = os.path.join(ROOT, "tests", "mock", "libmock_backend.so")
+tmp = sys.argv[1]
+
+
+def frame(scene):
+    r = H.Renderer(scene, backend_path=MOCK, lut_rgba16f=np.zeros((4, 4, 4), dtype=np.uint16))
+    r.render()
+    r.host.transform_set_local(r.keys.node_keys[1], (0.1, 0.2, 0.3), (0, 0, 0, 1), (1, 1, 1))
+    r.update()
+    r.render()
+    r.close()
+
+
+frame(scenes.skinned_morph_scene(64, 64, around=8, along=12, tex_size=16))
+frame(scenes.material_zoo_scene(96, 64, tex_size=16))
+frame(scenes.transparent_scene(96, 64, tex_size=16))
+frame(scenes.instanced_scene(96, 64))
+
+# glTF reader: valid files, then corrupted ones (bit flips, truncations): every outcome but a crash / sanitizer report is fine
+sc = scenes.helmet_scene(64, 64, segments=8, rings=6, tex_size=8)
+path = os.path.join(tmp, "h.glb")
+gltf_export.write_glb(sc, path)
+good = open(path, "rb").read()
+h = H.Host(MOCK)
+h.resize(64, 64)
+print("loaded", h.load_gltf(path))
+h.close()
+rng = np.random.default_rng(12345)
+ok = bad = 0
+for case in range(300):
+    data = bytearray(good)
+    kind = case % 3
+    if kind == 0:      # flip bytes inside the JSON chunk
+        n = int.from_bytes(data[12:16], "little")
+        for _ in range(rng.integers(1, 6)):
+            data[20 + int(rng.integers(0, n))] = int(rng.integers(32, 127))
+    elif kind == 1:    # flip bytes anywhere
+        for _ in range(rng.integers(1, 16)):
+            data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+    else:              # truncate
+        data = data[:int(rng.integers(12, len(data)))]
+    p = os.path.join(tmp, "c.glb")
+    open(p, "wb").write(bytes(data))
+    h = H.Host(MOCK)
+    h.resize(64, 64)
+    try:
+        h.load_gltf(p)
+        ok += 1
+    except H.HostError:
+        bad += 1
+    h.close()
+print("corrupted files: loaded", ok, "refused", bad)
+# image decoders on garbage
+for case in range(200):
+    blob = bytes(rng.integers(0, 256, size=int(rng.integers(8, 400)), dtype=np.uint8))
+    blob = (b"\x89PNG\r\n\x1a\n" if case % 2 else b"\xff\xd8\xff") + blob
+    try:
+        H.decode_image(blob)
+    except H.HostError:
+        pass
+print("SANITIZE_OK")
