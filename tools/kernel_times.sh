@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/kt}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-overlap --no-cpu-baseline --steps 60 --warmup 5 --profile-frames 5 > $OUT/bench.json 2> $OUT/err.log || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-overlap --no-cpu-baseline --steps 60 --warmup 5 --profile-frames 5 $AWSM_KT_ARGS > $OUT/bench.json 2> $OUT/err.log || exit 1
 python3 - <<PY
 import csv, glob, json
 f = glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True)[0]
