@@ -50,7 +50,7 @@ def algorithmic_bytes(scene, stats, rows):
     }
 
 
-def pmc_traffic(kernel, n_tris, W, H):
+def pmc_traffic(kernel, n_tris, W, H, field="hbm_traffic_bytes"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/latest_pmc.json, written by
     tools/profile_collect.py from FETCH_SIZE / WRITE_SIZE collected in separate passes on this same workload).  None when
     no profile of this exact workload is committed: counters cannot be read from inside the process."""
@@ -63,10 +63,21 @@ def pmc_traffic(kernel, n_tris, W, H):
         ks = doc["kernels"]
         for name in ("awsm::" + kernel, "awsm::" + kernel + "<false>", "awsm::" + kernel + "<1>"):      # the profiled workload is single-sample, MipmapMode::None
             if name in ks:
-                return ks[name]["hbm_traffic_bytes"]
+                return ks[name][field]
         return None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def valu_issue(kernel, n_tris, W, H, launch_ms):
+    """What actually bounds the dominant kernel (it is ALU work, not a stream): vector-ALU instructions per launch from the committed
+    SQ counter pass, the time the 1024 SIMDs (256 CUs x 4, one wave64 VALU instruction per 4 cycles, 2.4 GHz peak clock) need to
+    issue them, and that time over the measured launch duration."""
+    insts = pmc_traffic(kernel, n_tris, W, H, "SQ_INSTS_VALU")
+    if not insts or launch_ms <= 0:
+        return None
+    min_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
+    return {"insts_per_launch": insts, "issue_bound_ms": min_ms, "frac": min_ms / launch_ms}
 
 
 def cpu_baseline(scene, lut_rg, rows_sample):
@@ -272,6 +283,7 @@ def main():
     traffic = pmc_traffic(dom, n_tris, W, H) if world == 1 else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "launch_ms": kernel_ms[dom],
+                "valu_issue": valu_issue(dom, n_tris, W, H, kernel_ms[dom]) if world == 1 else None,
                 "all_kernels_ms": kernel_ms, "all_kernels_algorithmic_bytes": alg}
 
     cpu = None
