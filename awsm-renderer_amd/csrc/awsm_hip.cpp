@@ -48,6 +48,8 @@ enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE, 
 // Everything the geometry pass produces for one frame and the opaque pass consumes.
 struct FrameBufs {
     DevBuf wpos;                           // transparent pass only
+    DevBuf frag_rec, frag_color, frag_first;   // transparent pass: per-pixel fragment lists
+    uint32_t frag_cap = 0;
     DevBuf tex_slots;                      // n_draws x kCoreTextures TexSlotDev (k_resolve_draws)
     DevBuf draw_mat;                       // n_draws DrawMatDev (k_resolve_draws)
     DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
@@ -369,6 +371,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->big_list = (uint32_t*)t.big_list.ptr;
     f->counters = (uint32_t*)t.counters.ptr;
     f->opaque_rgba16f = f->out_rgba16f;
+    f->frag_rec = (uint4*)t.frag_rec.ptr; f->frag_color = (float4*)t.frag_color.ptr; f->frag_first = (uint32_t*)t.frag_first.ptr; f->frag_cap = t.frag_cap;
     f->out_rgba16f = (uint16_t*)(c->bound_comp ? c->bound_comp : c->comp16.ptr);
     f->out_rgba32f = (float*)c->comp32.ptr;
     f->has_opaque = c->last_opaque.has_opaque;
@@ -388,13 +391,13 @@ int enqueue_transparent(AwsmHipCtx* c) {
         HIPCHK(c, hipMemsetAsync(TR(c).counters.ptr, 0, 8 * sizeof(uint32_t), ss));
         if (n_tiles) HIPCHK(c, hipMemsetAsync(TR(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), ss));
     } else {
+        awsm_launch_resolve_draws(c->scene_dev, &f, ss);      // first: the transform tags each triangle with its draw's alpha mode
         awsm_launch_transform_forward(c->scene_dev, &f, c->tr_n_blocks, ss);
     }
     if (n_tiles) {
         if (f.total_tris) { awsm_launch_bin_count(&f, ss); awsm_launch_bin_big(&f, 0, ss); }
         awsm_launch_bin_scan(&f, ss);
         if (f.total_tris) { awsm_launch_bin_fill(&f, ss); awsm_launch_bin_big(&f, 1, ss); }
-        awsm_launch_resolve_draws(c->scene_dev, &f, ss);
         awsm_launch_forward(c->scene_dev, &f, ss);
     }
     if ((rc = record(c, EV_FWD, ss))) return rc;
@@ -409,6 +412,16 @@ int ensure_bin_capacity_of(AwsmHipCtx* c, FrameBufs& b, uint32_t entries) {
     int rc = dev_realloc(c, b.bin_list, (size_t)cap * 4, false);
     if (rc) return rc;
     b.bin_capacity = cap;
+    return AWSM_OK;
+}
+
+int ensure_fragment_capacity(AwsmHipCtx* c, FrameBufs& b, uint32_t fragments) {
+    if (fragments <= b.frag_cap && b.frag_rec.ptr) return AWSM_OK;
+    const uint32_t cap = std::max(fragments, b.frag_cap + b.frag_cap / 2);
+    int rc = dev_realloc(c, b.frag_rec, (size_t)cap * 16, false);
+    if (!rc) rc = dev_realloc(c, b.frag_color, (size_t)cap * 16, false);
+    if (rc) return rc;
+    b.frag_cap = cap;
     return AWSM_OK;
 }
 
@@ -559,7 +572,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
-        fr(b.vis); fr(b.wpos); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
+        fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
@@ -830,6 +843,8 @@ int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) 
     if (c->bound_comp && c->bound_comp_bytes < px * 8) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "transparent_pass: bound composite holds %zu bytes, the frame needs %zu", c->bound_comp_bytes, px * 8);
     if ((c->flags & AWSM_CFG_PARITY_TAP) && (rc = dev_reserve(c, c->comp32, px * 16))) return rc;
     if ((rc = reserve_pass_buffers(c, TR(c), c->tr_draws_host, c->tr_total_tris, true))) return rc;
+    if ((rc = dev_reserve(c, TR(c).frag_first, px * 4))) return rc;
+    if ((rc = ensure_fragment_capacity(c, TR(c), (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : (uint32_t)std::max<size_t>(px / 2, 1u << 20)))) return rc;
     if (c->overlap) {   // the draw-list upload went to the caller's stream; the pass runs on the shade stream
         HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->shade_stream, c->ev_geom_done[c->slot], 0));
@@ -862,7 +877,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
         if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
-        if ((!geom_over && !fwd_over) || attempt >= 4) break;
+        const bool frag_over = c->transparent_done && c->counters_host[14] != 0;      // a pixel's fragment list did not fit
+        if ((!geom_over && !fwd_over && !frag_over) || attempt >= 4) break;
         // a (triangle, tile) list overflowed: grow to the measured need and replay from the pass that lost entries
         int rc;
         c->overflow_retries++;
@@ -872,9 +888,10 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             if (c->opaque_done && (rc = enqueue_opaque(c))) return rc;
         }
         if (fwd_over && (rc = ensure_bin_capacity_of(c, TR(c), c->counters_host[9] + c->counters_host[9] / 4 + 1024))) return rc;
+        if (frag_over && (rc = ensure_fragment_capacity(c, TR(c), c->counters_host[13] + c->counters_host[13] / 4 + 1024))) return rc;
         if (c->transparent_done && (rc = enqueue_transparent(c))) return rc;
     }
-    if ((c->geometry_done && c->counters_host[2] != 0) || (c->transparent_done && c->counters_host[10] != 0)) return fail(c, AWSM_ERR_DEVICE, "bin list overflow persisted after retries");
+    if ((c->geometry_done && c->counters_host[2] != 0) || (c->transparent_done && (c->counters_host[10] != 0 || c->counters_host[14] != 0))) return fail(c, AWSM_ERR_DEVICE, "bin / fragment list overflow persisted after retries");
     if (out) {
         memset(out, 0, sizeof *out);
         auto ms = [&](int a, int b) { float t = 0.0f; if (c->ev_valid[a] && c->ev_valid[b] && hipEventElapsedTime(&t, c->ev[a], c->ev[b]) == hipSuccess) return t; return 0.0f; };
@@ -884,7 +901,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             out->ms_raster = ms(EV_BIN, EV_RASTER);
         }
         if (c->opaque_done) out->ms_shade = ms(EV_SHADE_BEGIN, EV_SHADE);
-        if (c->transparent_done) { out->ms_forward = ms(EV_FWD_BEGIN, EV_FWD); out->forward_triangles = c->tr_total_tris; }
+        if (c->transparent_done) { out->ms_forward = ms(EV_FWD_BEGIN, EV_FWD); out->forward_triangles = c->tr_total_tris; out->forward_fragment_slots = c->counters_host[13]; }
         out->ms_total = (c->geometry_done ? ms(EV_START, EV_RASTER) : 0.0f) + out->ms_shade + out->ms_forward;   // the two passes may run on different streams
         out->triangles_in = c->total_tris;
         out->triangles_binned = c->counters_host[0];

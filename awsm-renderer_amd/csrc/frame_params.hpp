@@ -122,7 +122,7 @@ struct FrameDev {
     float4* tan;                  // total_verts  (world tangent xyz, handedness)
     float4* wpos;                 // total_verts  (world position xyz, 1): transparent pass only, else null
     TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)
-    uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..31)
+    uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..30, bit 31: ALPHA_MODE_MASK draw — transparent pass)
     // binning
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1
@@ -138,6 +138,11 @@ struct FrameDev {
     float4* msaa_color0;          // MSAA: width*height, f32 colour of sample 0 for the pixels in msaa_edges
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
     const uint16_t* opaque_rgba16f;   // transparent pass: the opaque pass's image (blit source and transmission background); out_rgba16f/32f = composite
+    // transparent pass fragment lists (k_forward_cover -> k_forward_shade -> k_forward_blend): counters[5] = fragments, counters[6] = overflow flag
+    uint4* frag_rec;              // frag_cap records {triangle rank, pixel index, next fragment of the pixel (0xFFFFFFFF = last), sample mask | resolved-mask flag << 8}
+    float4* frag_color;           // frag_cap premultiplied colours (k_forward_shade)
+    uint32_t* frag_first;         // width*height: the pixel's first fragment in submission order (0xFFFFFFFF = none)
+    uint32_t frag_cap;
 };
 
 }  // namespace awsm

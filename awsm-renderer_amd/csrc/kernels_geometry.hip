@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     f.nrm[gv] = make_float4(world_normal.x, world_normal.y, world_normal.z, 0.0f);
     f.tan[gv] = make_float4(tangent_ortho.x, tangent_ortho.y, tangent_ortho.z, tangent.w);
     if (FWD) f.wpos[gv] = make_float4(world_pos.x, world_pos.y, world_pos.z, 1.0f);
-    if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | (d.flags << 24);
+    // transparent pass: bit 31 = the draw's material is ALPHA_MODE_MASK (k_resolve_draws ran before this kernel), so the coverage walk
+    // learns it from the word it loads anyway instead of a second dependent load per triangle
+    if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | (d.flags << 24)  | ((FWD && (f.draw_shade[lo].flags & 2u)) ? 0x80000000u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

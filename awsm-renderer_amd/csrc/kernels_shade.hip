@@ -736,12 +736,13 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
 // fragment.wgsl:27-186 (transparent pass): the opaque image behind a transmissive surface, refracted through the volume
 // (KHR_materials_volume) and blurred by roughness with up to three rings of eight taps (transmission_blur_rings = 3,
 // material_transparent/shader/template.rs:170).  Outside the screen: the (uniform) prefiltered environment.
-AWSM_DI f3 opaque_texel(const FrameDev& f, int x, int y) {
-    x = min(max(x, 0), (int)f.width - 1); y = min(max(y, 0), (int)f.height - 1);
-    const uint2 h = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[(size_t)y * f.width + (size_t)x];
+struct OpaqueImage { const uint2* texels; const uint8_t* camera; int width, height; };      // by value: a FrameDev& into a real call would spill all of it
+AWSM_DI f3 opaque_texel(const OpaqueImage& f, int x, int y) {
+    x = min(max(x, 0), f.width - 1); y = min(max(y, 0), f.height - 1);
+    const uint2 h = f.texels[(size_t)y * (size_t)f.width + (size_t)x];
     return {f16_bits_to_f32((unsigned short)(h.x & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.x >> 16)), f16_bits_to_f32((unsigned short)(h.y & 0xFFFFu))};
 }
-__device__ __attribute__((noinline)) f3 sample_transmission_background(const DevScene* sc, const FrameDev& f, float frag_x, float frag_y, f3 world_position, f3 normal,
+__device__ __attribute__((noinline)) f3 sample_transmission_background(const DevScene* sc, const OpaqueImage f, float frag_x, float frag_y, f3 world_position, f3 normal,
                                                                         f3 view_dir, float ior, float roughness, float thickness) {
     const float Wf = (float)f.width, Hf = (float)f.height;
     f2 screen_uv = {frag_x / Wf, frag_y / Hf};
@@ -779,7 +780,7 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
                 const float oy = (i == 0 ? 0.0f : i == 1 ? 0.707f : i == 2 ? 1.0f : i == 3 ? 0.707f : i == 4 ? 0.0f : i == 5 ? -0.707f : i == 6 ? -1.0f : -0.707f);
                 const float fx = sx + ox * r, fy = sy + oy * r;
                 const int cx = (int)fx, cy = (int)fy;           // vec2<i32>(): truncation toward zero
-                if (cx >= 0 && cx <= (int)f.width - 1 && cy >= 0 && cy <= (int)f.height - 1) { sum = sum + opaque_texel(f, cx, cy) * w; wsum += w; }
+                if (cx >= 0 && cx <= f.width - 1 && cy >= 0 && cy <= f.height - 1) { sum = sum + opaque_texel(f, cx, cy) * w; wsum += w; }
             }
         }
         return sum * fm::rcp(wsum);
@@ -795,7 +796,7 @@ struct SurfaceOut { f4 color; uint32_t kind; bool discard; };
 template <bool GRAD, bool FWD>
 AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TexSlotDev* __restrict__ slots,
                                   const DrawMatDev* __restrict__ draw_mat, const TBN& tbn,
-                                  f3 world_position, f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y) {
+                                  f3 world_position, f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y, bool mask_resolved = false) {
     SurfaceOut out;
     out.color = {0.0f, 0.0f, 0.0f, 0.0f};
     out.kind = 0u; out.discard = false;
@@ -817,7 +818,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
         }
         float alpha = 1.0f;
         if (FWD) {            // transparent material_color_calc.wgsl:344-372: alpha kept; ALPHA_MODE_MASK discards or forces 1
-            if (alpha_mode == 1u) { if (base.w < alpha_cutoff) { out.discard = true; return out; } base.w = 1.0f; }
+            if (alpha_mode == 1u) { if (!mask_resolved && base.w < alpha_cutoff) { out.discard = true; return out; } base.w = 1.0f; }
             alpha = base.w;
         }
         out.color = {base.x + em.x, base.y + em.y, base.z + em.z, alpha};
@@ -856,7 +857,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
                 const uint32_t set_index = idx_vertex_color != 0u ? M[idx_vertex_color] : 0u;
                 if (set_index < color_sets) { const f4 vc = vertex_color(a, set_index); base = {base.x * vc.x, base.y * vc.y, base.z * vc.z, base.w * vc.w}; }
             }
-            if (alpha_mode == 1u) { if (base.w < alpha_cutoff) { out.discard = true; return out; } base.w = 1.0f; }
+            if (alpha_mode == 1u) { if (!mask_resolved && base.w < alpha_cutoff) { out.discard = true; return out; } base.w = 1.0f; }
             base_alpha = base.w;
         }
         c.base = {base.x, base.y, base.z};
@@ -939,7 +940,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
     if (FWD) {     // fragment.wgsl:245-270: screen-space transmission from the opaque image
         const float metallic = clampf(c.mr.x, 0.0f, 1.0f);
         if (c.transmission * (1.0f - metallic) > 0.0f)
-            background = sample_transmission_background(sc, f, frag_x, frag_y, world_position, c.normal, -surface_to_camera, c.ior,
+            background = sample_transmission_background(sc, OpaqueImage{reinterpret_cast<const uint2*>(f.opaque_rgba16f), f.camera, (int)f.width, (int)f.height}, frag_x, frag_y, world_position, c.normal, -surface_to_camera, c.ior,
                                                         fmaxf(clampf(c.mr.y, 0.0f, 1.0f), 0.04f), c.volume_thickness);
     }
     const f3 color = apply_lighting(sc, f.lights_pre, c, surface_to_camera, world_position, n_lights, background);
@@ -1004,27 +1005,39 @@ AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev
 
 
 // ------------------------------------------------------------------------------------------------
-// k_forward_tile: the world transparent pass (render.rs:224-297; material_transparent/{pipeline,render_pass}.rs;
-// material_transparent_wgsl/fragment.wgsl) for one 32x32 tile.
+// The world transparent pass (render.rs:224-297; material_transparent/{pipeline,render_pass}.rs;
+// material_transparent_wgsl/fragment.wgsl) as three kernels over per-pixel fragment lists:
 //
-// Blending is order dependent: fragments must reach a pixel in submission order (the host sorts the meshes back to front,
-// renderable.rs:90,131-135).  One wavefront owns an 8x8 block of the tile and every lane one pixel of it, so a pixel's
-// read-modify-write chain lives in one lane's registers — no atomics, no locks — and the wavefront walks the triangles of
-// the tile's list that touch its block in rank order (coverage and depth first; the shading is queued per lane and run a
-// wavefront at a time).  The binner appends ranks to a tile's list in no particular order; they are sorted here for free:
-// ranks are unique, so setting bit (rank - base) of an LDS bitmap and scanning the bitmap IS the sorted list (windows of
-// kFwdWindow ranks).  Per-sample depth and colour stay in registers for the whole pass (the multisampled colour
-// target of the reference never exists in HBM): initialised from the geometry pass's depth and the opaque image
-// (the opaque -> transparent blit), blended in place, resolved and written once.
+//   k_forward_cover   coverage + depth, in submission order.  Blending is order dependent (the host sorts the meshes back to front,
+//                     renderable.rs:90,131-135), and so is the depth test (depth write is on), so one wavefront owns an 8x8 block of a
+//                     tile, one lane a pixel: per-sample depth lives in that lane's registers and the wavefront walks the triangles
+//                     that touch its block in rank order.  One workgroup (16 wavefronts) serves a 32x32 binning tile: it reads the
+//                     tile's list once, sets bit (rank - base) in an LDS bitmap per block (ranks are unique, so scanning a bitmap IS
+//                     the sorted list; windows of kFwdWindow ranks) and stages the setup records in LDS, so a step of the serial walk
+//                     has no HBM/L2 round trip on its path.  A fragment that passes is appended to the pixel's list — triangle, sample
+//                     mask, link to the next — and the depth is written.  ALPHA_MODE_MASK materials decide here, with the base-colour
+//                     alpha alone (their depth write depends on it); nothing else of the material is evaluated in this kernel.
+//   k_forward_shade   one thread per fragment, in no particular order: the material code of the opaque pass on interpolated varyings
+//                     (shade_material<GRAD, true>), the screen-space transmission taps, premultiplied colour out.  This is where the
+//                     time goes, and it runs like k_shade: full wavefronts, high occupancy, no ordering constraints.
+//   k_forward_blend   one thread per pixel: the opaque colour (that IS the opaque -> transparent blit), the pixel's fragments in list
+//                     order through the RGBA16F "over" blend per covered sample, the MSAA resolve, one store.  The multisampled colour
+//                     target of the reference never exists in HBM.
 //
-// Contract (DESIGN.md "Transparent pass"): coverage/facing/depth as the geometry pass; varyings
-// and implicit derivatives from the pixel centre's barycentrics; RGBA16F target rounding at every blend.
+// Contract (DESIGN.md "Transparent pass"): coverage/facing/depth as the geometry pass; varyings and implicit derivatives from the
+// pixel centre's barycentrics; RGBA16F target rounding at every blend.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kFwdWindow = 16384;       // ranks per bitmap window (2 KB of LDS)
+constexpr int kFwdBlock = 8;                 // one wavefront owns an 8x8 pixel block of the binning tile, one pixel per lane
+constexpr uint32_t kFragNone = 0xFFFFFFFFu;
+constexpr uint32_t kFragChunk = 64;          // fragment slots a wavefront reserves at a time
 
+struct FwdVary { float b0, b1, b2; f4 derivs; uint4 ds0, ds1; uint32_t draw; };
+
+// STRICT: barycentrics (and their quad differences) exactly as the oracle derives them from the setup record; then the attribute context
 template <bool GRAD>
-AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py) {
-    // ---- STRICT: barycentrics (and their quad differences) exactly as the oracle derives them from the setup record ----
+AWSM_DI FwdVary forward_attr(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py, Attr& a) {
+    FwdVary o;
     const double Xc = sample_coord((px << 8) + 128), Yc = sample_coord((py << 8) + 128);
     const EdgeVals ev = tri_edges_d(t, Xc, Yc);
     const float e0 = (float)ev.E[0] * t.iw[0], e1 = (float)ev.E[1] * t.iw[1], e2 = (float)ev.E[2] * t.iw[2];
@@ -1039,22 +1052,53 @@ AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const Frame
         const float hb0 = h0 * ish, hb1 = h1 * ish, vb0 = w0 * isv, vb1 = w1 * isv;
         derivs = {(px & 1) ? b0 - hb0 : hb0 - b0, (py & 1) ? b0 - vb0 : vb0 - b0, (px & 1) ? b1 - hb1 : hb1 - b1, (py & 1) ? b1 - vb1 : vb1 - b1};
     }
-    // ---- RELAXED from here ----
-    const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + (f.tri_info[rank] & 0x00FFFFFFu));
-    const uint4 ds0 = dsp[0], ds1 = dsp[1];
-    const uint32_t triangle_index = rank - ds0.x;
-    Attr a;
+    o.b0 = b0; o.b1 = b1; o.b2 = b2; o.derivs = derivs;
+    o.draw = f.tri_info[rank] & 0x00FFFFFFu;
+    // Keep the masked index opaque to the optimiser.  hipcc 7.2 (clang 22) on gfx950 turned `(x & 0xFFFFFF) * 320` of the slot address
+    // below into a 24-bit multiply, dropped the mask as redundant, and then emitted v_mad_u64_u32 on the UNMASKED word: a triangle
+    // whose info word carries flag bits addressed memory 2^31 draws away (seen in k_forward_cover's ISA; memory access fault).
+    asm volatile("" : "+v"(o.draw));
+    const uint4* dsp = reinterpret_cast<const uint4*>(f.draw_shade + o.draw);
+    o.ds0 = dsp[0]; o.ds1 = dsp[1];
+    const uint32_t triangle_index = rank - o.ds0.x;
     a.sc = sc;
     a.ad = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_ATTR_DATA]);
     a.bary = {b0, b1, b2};
-    a.uv_sets_index = ds1.y;
-    const uint32_t* attr_idx = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + ds0.z + triangle_index * 3u;
-    a.v0 = ds0.w + attr_idx[0] * ds1.x;
-    a.v1 = ds0.w + attr_idx[1] * ds1.x;
-    a.v2 = ds0.w + attr_idx[2] * ds1.x;
+    a.uv_sets_index = o.ds1.y;
+    const uint32_t* attr_idx = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + o.ds0.z + triangle_index * 3u;
+    a.v0 = o.ds0.w + attr_idx[0] * o.ds1.x;
+    a.v1 = o.ds0.w + attr_idx[1] * o.ds1.x;
+    a.v2 = o.ds0.w + attr_idx[2] * o.ds1.x;
     a.has_uv0 = false; a.uv0 = {0.0f, 0.0f};
     a.bary_derivs = derivs; a.duv0_dx = {0.0f, 0.0f}; a.duv0_dy = {0.0f, 0.0f};
+    return o;
+}
 
+// ALPHA_MODE_MASK (transparent material_color_calc.wgsl:38-52,344-362): the base colour's alpha against the cutoff, nothing else of the
+// material.  The coverage kernel decides with this; the shading kernel then treats the fragment's alpha as 1 without testing again.
+template <bool GRAD>
+AWSM_DI bool forward_alpha_test(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py) {
+    Attr a;
+    const FwdVary vy = forward_attr<GRAD>(sc, f, t, rank, px, py, a);
+    const TexSlotDev* slots = f.tex_slots + (size_t)vy.draw * kCoreTextures;
+    const DrawMatDev* dm = f.draw_mat + vy.draw;
+    const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
+    const uint32_t b = vy.ds0.y + 1u;
+    float alpha = dm->base_color[3];
+    if ((slots[0].flags >> 8) & 1u) alpha = alpha * sample_slot<GRAD>(a, slots, M, b + 2).w;
+    if ((dm->shader_alpha & 0xFFu) != 2u && vy.ds1.w != 0u) {        // PBR meshes with colour sets multiply by the vertex colour
+        const uint32_t set_index = (dm->ext_mask & 1u) ? M[b + M[b + 39u]] : 0u;
+        if (set_index < vy.ds1.w) alpha = alpha * vertex_color(a, set_index).w;
+    }
+    return !(alpha < dm->alpha_cutoff);
+}
+
+template <bool GRAD>
+AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py, bool mask_resolved) {
+    Attr a;
+    const FwdVary vy = forward_attr<GRAD>(sc, f, t, rank, px, py, a);
+    const float b0 = vy.b0, b1 = vy.b1, b2 = vy.b2;
+    // ---- RELAXED from here ----
     const size_t v = (size_t)rank * 3;
     const float4 n0 = f.nrm[v], n1 = f.nrm[v + 1], n2 = f.nrm[v + 2];
     const float4 t0 = f.tan[v], t1 = f.tan[v + 1], t2 = f.tan[v + 2];
@@ -1081,137 +1125,141 @@ AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const Frame
         else tbn.T = fm::fnormalize(cross(fabsf(tbn.N.z) > 0.999f ? mk3(0.0f, 1.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f), tbn.N));
     }
     tbn.B = cross(tbn.N, tbn.T) * handedness;
-    return shade_material<GRAD, true>(sc, f, a, ds0.y, f.tex_slots + (size_t)(f.tri_info[rank] & 0x00FFFFFFu) * kCoreTextures, f.draw_mat + (f.tri_info[rank] & 0x00FFFFFFu), tbn, world_position, surface_to_camera, ds1.w,
-                                      (float)px + 0.5f, (float)py + 0.5f);
+    return shade_material<GRAD, true>(sc, f, a, vy.ds0.y, f.tex_slots + (size_t)vy.draw * kCoreTextures, f.draw_mat + vy.draw, tbn, world_position, surface_to_camera, vy.ds1.w,
+                                      (float)px + 0.5f, (float)py + 0.5f, mask_resolved);
 }
 
-// A fragment that passed coverage and the depth test, waiting to be shaded: triangle, which samples, their depths.
-// flags = deferred_depth | sample_mask << 4.
-template <int S> struct FwdFrag { uint32_t rank, flags; float z[S]; };
-constexpr uint32_t kFwdFifo = 8;            // queue entries per thread
-constexpr int kFwdBlock = 8;                // one wavefront owns an 8x8 pixel block of the binning tile, one pixel per lane
-
-template <int S> struct FwdPixel { float depth[S]; uint2 color[S]; };    // the lane's pixel: per-sample depth and RGBA16F colour, in registers
-
-// Shade and blend the wavefront's pending fragments: round j takes entry j of every lane that has one.  Lanes work on
-// different triangles, each in its own submission order — the order per pixel is what blending needs.
-template <int S, bool GRAD>
-AWSM_DI void forward_flush(const DevScene* __restrict__ sc, const FrameDev& f, const FwdFrag<S>* fifo, uint32_t& n_pending, FwdPixel<S>& pix, int px, int py) {
-    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < n_pending) != 0ull; j++) {
-        if (j >= n_pending) continue;
-        const FwdFrag<S> e = fifo[j * 64u];
-        const uint32_t mask = e.flags >> 4;
-        TriSetup t;
-        tri_rec_load(f.tri_rec + e.rank, t);
-        const SurfaceOut o = forward_fragment<GRAD>(sc, f, t, e.rank, px, py);
-        if (o.discard) continue;                                                         // neither colour nor depth
-        const float a = o.color.w, om = 1.0f - a;
-        const float sr = o.color.x * a, sg = o.color.y * a, sb = o.color.z * a;          // fragment.wgsl:283-285 premultiplied
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            if (!(mask & (1u << s))) continue;
-            if (e.flags & 1u) pix.depth[s] = e.z[s];
-            const uint2 d = pix.color[s];
-            const float r = blend_over_f16(sr, f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)), om);
-            const float g = blend_over_f16(sg, f16_bits_to_f32((unsigned short)(d.x >> 16)), om);
-            const float b = blend_over_f16(sb, f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)), om);
-            const float al = blend_over_f16(a, f16_bits_to_f32((unsigned short)(d.y >> 16)), om);
-            pix.color[s] = make_uint2((uint32_t)f16_bits(r) | ((uint32_t)f16_bits(g) << 16), (uint32_t)f16_bits(b) | ((uint32_t)f16_bits(al) << 16));
-        }
-    }
-    n_pending = 0u;
-}
-
-// does triangle `rank` (its setup record's bbox) touch the block [bx0, bx0+8) x [by0, by0+8) ?
-AWSM_DI bool forward_block_hit(const FrameDev& f, uint32_t rank, int bx0, int by0) {
-    const uint32_t bx = f.tri_rec[rank].bbox_x, by = f.tri_rec[rank].bbox_y;
-    const int x0 = (int)(bx & 0xFFFFu), x1 = (int)(bx >> 16), y0 = (int)(by & 0xFFFFu), y1 = (int)((by >> 16) & 0x7FFFu);
-    return x0 <= x1 && x1 >= bx0 && x0 < bx0 + kFwdBlock && y1 >= by0 && y0 < by0 + kFwdBlock;
-}
+// One workgroup per binning tile, one wavefront per 8x8 block of it (16 wavefronts).  The tile's list is read ONCE by the whole
+// workgroup: each entry sets its bit in the bitmap of every block its bbox touches, and its setup record is staged in LDS at the
+// position its rank has among the tile's triangles (prefix popcount of the union bitmap).  Each wavefront then walks its own bitmap
+// with no global load on the path of a step — a dependent HBM/L2 round trip per triangle is what bounds a serial walk otherwise.
+#ifndef AWSM_FWD_NB
+#define AWSM_FWD_NB 16
+#endif
+constexpr int kFwdNB = AWSM_FWD_NB;          // 8x8 blocks (= wavefronts) per workgroup: 16 = the whole 32x32 tile, 8 = a 32x16 half, 4 = a 16x16 quarter
+constexpr int kFwdBW = kFwdNB == 4 ? 2 : 4;  // blocks per row of the workgroup's rectangle
+constexpr int kFwdSubs = 16 / kFwdNB;
+constexpr uint32_t kFwdThreads = 64u * kFwdNB;
+constexpr uint32_t kFwdWords = kFwdWindow / 32;
+constexpr uint32_t kFwdRecCap = 320;         // setup records staged per window (25 KB); triangles beyond that are fetched from HBM by the walk
+constexpr uint32_t kFragPool = 64u * kFwdNB; // fragment slots a workgroup reserves up front (one global atomic per non-empty rectangle)
 
 template <int S, bool GRAD>
-__global__ __launch_bounds__(64) void k_forward_tile(const DevScene* __restrict__ sc, FrameDev f) {
-    constexpr uint32_t D = kFwdFifo;
-    __shared__ FwdFrag<S> fifo_all[D * 64];              // [entry][lane]
-    __shared__ uint32_t bitmap[kFwdWindow / 32];
-    __shared__ uint32_t rmin, rmax;
+__global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* __restrict__ sc, FrameDev f) {
+    __shared__ uint32_t bitmap[kFwdNB][kFwdWords];
+    __shared__ uint32_t ubits[kFwdWords];          // union of the block bitmaps: the rectangle's triangles of this window
+    __shared__ uint32_t wprefix[kFwdWords];        // set bits of ubits below each word = staged position of the word's first triangle
+    __shared__ float4 rec_q[kFwdRecCap * 5];       // TriRec, 80 bytes each
+    __shared__ uint32_t rec_info[kFwdRecCap];
+    __shared__ uint32_t rmin, rmax, pool_next, pool_end;
 
-    const uint32_t tile = f.tile_order[blockIdx.x >> 4];
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x & 15u;
-    const int bx0 = ((int)(tile % f.tiles_x) << kTileShift) + (int)(blk & 3u) * kFwdBlock;                       // origin of this wavefront's block
-    const int by0 = ((int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift) + (int)(blk >> 2) * kFwdBlock;
-    const int px = bx0 + (int)(tid & 7u), py = by0 + (int)(tid >> 3);
+    const uint32_t tile = f.tile_order[blockIdx.x / kFwdSubs], sub = blockIdx.x % kFwdSubs;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, blk = tid >> 6;
+    constexpr int kRectW = kFwdBW * kFwdBlock, kRectH = (kFwdNB / kFwdBW) * kFwdBlock;
+    const int tx0 = ((int)(tile % f.tiles_x) << kTileShift) + (kFwdNB == 4 ? (int)(sub & 1u) * kRectW : 0);
+    const int ty0 = ((int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift) + (kFwdNB == 4 ? (int)(sub >> 1) : (int)sub) * kRectH;
+    const int px = tx0 + (int)(blk % kFwdBW) * kFwdBlock + (int)(lane & 7u), py = ty0 + (int)(blk / kFwdBW) * kFwdBlock + (int)(lane >> 3);
     const bool in_frame = px < (int)f.width && py < (int)f.height;
-    if (__builtin_amdgcn_ballot_w64(in_frame) == 0ull) return;
-    const FwdFrag<S>* fifo = fifo_all + tid;
-    uint32_t n_pending = 0u;
+    const bool wave_active = __builtin_amdgcn_ballot_w64(in_frame) != 0ull;
+    const size_t p = in_frame ? (size_t)py * f.width + (size_t)px : 0;
 
-    // opaque -> transparent blit (every sample gets the opaque colour) + depth LoadOp::Load
-    FwdPixel<S> pix;
-    {
-        const size_t p = in_frame ? (size_t)py * f.width + (size_t)px : 0;
-        const uint2 c = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];
+    float depth[S];                            // depth LoadOp::Load: the geometry pass's depth; out-of-frame lanes fail every test
 #pragma unroll
-        for (int s = 0; s < S; s++) { pix.depth[s] = in_frame ? key_depth(f.vis[p * S + s]) : -1.0f; pix.color[s] = c; }   // out-of-frame lanes fail every depth test
-    }
+    for (int s = 0; s < S; s++) depth[s] = in_frame ? key_depth(f.vis[p * S + s]) : -1.0f;
+    uint32_t first = kFragNone, last = kFragNone;
+    // Fragment slots: same-address device atomics cost ~6 ns each on this part and serialise, so the tile's workgroup takes kFragPool
+    // slots with ONE global atomic; its wavefronts carve exact runs out of that pool with LDS atomics, and only when the pool is dry
+    // does a wavefront fall back to private chunks of kFragChunk.  Unused slots are marked kFragNone for the shading kernel.
+    uint32_t chunk_next = 0u, chunk_end = 0u;      // wave-uniform: the wavefront's private chunk (after the pool ran dry)
+    bool pool_dry = false;
+
     const uint32_t off = f.tile_offset[tile];
     const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, off));
     if (count) {
-        if (tid == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; }
+        uint32_t pool_base = 0u;
+        if (tid == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; pool_base = atomicAdd(&f.counters[5], kFragPool); }
         __syncthreads();
-        {   // rank range of the tile's triangles that touch this block
+        {   // rank range of the tile's list
             uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-            for (uint32_t i = tid; i < count; i += 64u) {
-                const uint32_t r = f.bin_list[off + i];
-                if (forward_block_hit(f, r, bx0, by0)) { lo = min(lo, r); hi = max(hi, r); }
-            }
+            for (uint32_t i = tid; i < count; i += kFwdThreads) { const uint32_t r = f.bin_list[off + i]; lo = min(lo, r); hi = max(hi, r); }
             if (lo <= hi) { atomicMin(&rmin, lo); atomicMax(&rmax, hi); }
         }
+        if (tid == 0) { pool_next = pool_base; pool_end = pool_base + kFragPool; }
         __syncthreads();
         const uint32_t r_lo = rmin, r_hi = rmax;
-        if (r_lo <= r_hi) for (uint32_t wbase = r_lo - (r_lo % kFwdWindow); wbase <= r_hi; wbase += kFwdWindow) {
+        for (uint32_t wbase = r_lo - (r_lo % kFwdWindow); wbase <= r_hi; wbase += kFwdWindow) {
             const uint32_t n_words = min(kFwdWindow, r_hi - wbase + 1u + 31u) / 32u;       // words that can hold a bit
-            for (uint32_t i = tid; i < n_words; i += 64u) bitmap[i] = 0u;
+            for (uint32_t i = lane; i < n_words; i += 64u) bitmap[blk][i] = 0u;
+            for (uint32_t i = tid; i < n_words; i += kFwdThreads) ubits[i] = 0u;
             __syncthreads();
-            for (uint32_t i = tid; i < count; i += 64u) {
+            for (uint32_t i = tid; i < count; i += kFwdThreads) {
                 const uint32_t r = f.bin_list[off + i], rr = r - wbase;      // unsigned: ranks below the window wrap to huge values
-                if (rr < kFwdWindow && forward_block_hit(f, r, bx0, by0)) atomicOr(&bitmap[rr >> 5], 1u << (rr & 31u));
+                if (rr >= kFwdWindow) continue;
+                const uint32_t bx = f.tri_rec[r].bbox_x, by = f.tri_rec[r].bbox_y;
+                const int x0 = (int)(bx & 0xFFFFu), x1 = (int)(bx >> 16), y0 = (int)(by & 0xFFFFu), y1 = (int)((by >> 16) & 0x7FFFu);
+                if (x0 > x1 || x1 < tx0 || x0 > tx0 + (kRectW - 1) || y1 < ty0 || y0 > ty0 + (kRectH - 1)) continue;
+                const int ba = (max(x0, tx0) - tx0) >> 3, bb = (min(x1, tx0 + (kRectW - 1)) - tx0) >> 3, bc = (max(y0, ty0) - ty0) >> 3, bd = (min(y1, ty0 + (kRectH - 1)) - ty0) >> 3;
+                for (int yy = bc; yy <= bd; yy++) for (int xx = ba; xx <= bb; xx++) atomicOr(&bitmap[yy * kFwdBW + xx][rr >> 5], 1u << (rr & 31u));
+                atomicOr(&ubits[rr >> 5], 1u << (rr & 31u));
             }
             __syncthreads();
-            // Coverage + depth run ahead of the shading: a fragment that passes is queued (its depth is written at once unless the
-            // material can discard), and the wavefront shades its queues when one is full — lanes on different triangles —
-            // instead of running the material code once per triangle for the few lanes that triangle covers.  The walk over
-            // the bitmap is a scalar iterator (64 words per step, one per lane; the non-empty ones are visited in order through
-            // the ballot mask) so that the material code has ONE call site: fill the queues, flush, repeat.
-            uint32_t wc = 0u, my_word = 0u, word_index = 0u, bits = 0u, carry = 0u;
-            unsigned long long nz = 0ull;
-            bool have_carry = false, exhausted = false;
-            for (;;) {
-                for (;;) {      // fill: next triangle until a queue cannot take its fragment, a discardable fragment was queued, or the window ends
-                    uint32_t rank;
-                    if (have_carry) { rank = carry; have_carry = false; }
-                    else {
-                        while (bits == 0u && !exhausted) {
-                            if (nz == 0ull) {
-                                if (wc >= n_words) { exhausted = true; break; }
-                                my_word = wc + tid < n_words ? bitmap[wc + tid] : 0u;
-                                nz = __builtin_amdgcn_ballot_w64(my_word != 0u);
-                                wc += 64u;
-                                continue;
-                            }
-                            const uint32_t wl = (uint32_t)__builtin_ctzll(nz);
-                            nz &= nz - 1ull;
-                            bits = (uint32_t)__builtin_amdgcn_readlane((int)my_word, (int)wl);
-                            word_index = wc - 64u + wl;
+            if (blk == 0u) {   // exclusive prefix of the per-word popcounts, 8 words per lane
+                uint32_t c[kFwdWords / 64], sum = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < kFwdWords / 64; k++) { const uint32_t w = lane * (kFwdWords / 64) + k; c[k] = w < n_words ? (uint32_t)__builtin_popcount(ubits[w]) : 0u; sum += c[k]; }
+                uint32_t incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += o; }
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (uint32_t k = 0; k < kFwdWords / 64; k++) { const uint32_t w = lane * (kFwdWords / 64) + k; if (w < n_words) wprefix[w] = run; run += c[k]; }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < count; i += kFwdThreads) {     // stage the records of the triangles that made it into the bitmaps
+                const uint32_t r = f.bin_list[off + i], rr = r - wbase;
+                if (rr >= kFwdWindow) continue;
+                const uint32_t word = ubits[rr >> 5], bit = 1u << (rr & 31u);
+                if (!(word & bit)) continue;
+                const uint32_t pos = wprefix[rr >> 5] + (uint32_t)__builtin_popcount(word & (bit - 1u));
+                if (pos >= kFwdRecCap) continue;
+                const float4* src = reinterpret_cast<const float4*>(f.tri_rec + r);
+#pragma unroll
+                for (int k = 0; k < 5; k++) rec_q[pos * 5u + k] = src[k];
+                rec_info[pos] = f.tri_info[r];
+            }
+            __syncthreads();
+            if (wave_active) {
+                // The set bits of this block's bitmap in ascending order ARE its triangles in submission order (scalar iteration).
+                uint32_t it_wc = 0u, it_word = 0u, it_bits = 0u, it_my = lane < n_words ? bitmap[blk][lane] : 0u;
+                unsigned long long it_nz = __builtin_amdgcn_ballot_w64(it_my != 0u);
+                for (;;) {
+                    if (!it_bits) {
+                        if (it_nz) {
+                            const uint32_t wl = (uint32_t)__builtin_ctzll(it_nz);
+                            it_nz &= it_nz - 1ull;
+                            it_bits = (uint32_t)__builtin_amdgcn_readlane((int)it_my, (int)wl);
+                            it_word = it_wc + wl;
+                            continue;
                         }
-                        if (exhausted) break;
-                        const uint32_t bit = (uint32_t)__builtin_ctz(bits);
-                        bits &= bits - 1u;
-                        rank = wbase + word_index * 32u + bit;
+                        it_wc += 64u;
+                        if (it_wc >= n_words) break;
+                        it_my = it_wc + lane < n_words ? bitmap[blk][it_wc + lane] : 0u;
+                        it_nz = __builtin_amdgcn_ballot_w64(it_my != 0u);
+                        continue;
                     }
+                    const uint32_t bit = (uint32_t)__builtin_ctz(it_bits);
+                    it_bits &= it_bits - 1u;
+                    const uint32_t rank = wbase + it_word * 32u + bit;
+                    const uint32_t pos = wprefix[it_word] + (uint32_t)__builtin_popcount(ubits[it_word] & ((1u << bit) - 1u));
+                    TriRecRaw raw; uint32_t info;
+                    if (pos < kFwdRecCap) {
+                        const float4* q = rec_q + pos * 5u;
+                        raw.q0 = q[0]; raw.q1 = q[1]; raw.q2 = q[2];
+                        raw.d3 = *reinterpret_cast<const double2*>(q + 3); raw.d4 = *reinterpret_cast<const double2*>(q + 4);
+                        info = rec_info[pos];
+                    } else { raw = tri_rec_fetch(f.tri_rec + rank); info = f.tri_info[rank]; }
                     TriSetup t;
-                    if (!tri_rec_load(f.tri_rec + rank, t)) continue;
-                    const bool may_discard = (f.draw_shade[f.tri_info[rank] & 0x00FFFFFFu].flags & 2u) != 0u;     // ALPHA_MODE_MASK
+                    if (!tri_rec_unpack(raw, t)) continue;
                     uint32_t mask = 0u;
                     float z[S];
 #pragma unroll
@@ -1219,47 +1267,97 @@ __global__ __launch_bounds__(64) void k_forward_tile(const DevScene* __restrict_
                         const int ox = S == 1 ? 128 : msaa4_x(s), oy = S == 1 ? 128 : msaa4_y(s);
                         const unsigned long long k = tri_sample_key_at(t, sample_coord((px << 8) + ox), sample_coord((py << 8) + oy), rank);
                         z[s] = __uint_as_float((uint32_t)(k >> 32));
-                        if (k != ~0ull && z[s] <= pix.depth[s]) mask |= 1u << s;       // CompareFunction::LessEqual
+                        if (k != ~0ull && z[s] <= depth[s]) mask |= 1u << s;       // CompareFunction::LessEqual
                     }
-                    // queue full in a lane that has a fragment to add: shade what is pending first, then take this triangle again
-                    if (__builtin_amdgcn_ballot_w64(mask != 0u && n_pending == D) != 0ull) { carry = rank; have_carry = true; break; }
-                    if (mask) {
-                        FwdFrag<S> e;
-                        e.rank = rank; e.flags = (may_discard ? 1u : 0u) | (mask << 4);
+                    const bool may_discard = (info >> 31) != 0u;     // ALPHA_MODE_MASK (uniform; tagged by the transform)
+                    if (may_discard && __builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+                        if (mask != 0u && !forward_alpha_test<GRAD>(sc, f, t, rank, px, py)) mask = 0u;          // discard: neither colour nor depth
+                    }
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(mask != 0u);
+                    if (hit == 0ull) continue;
+                    const uint32_t n_hit = (uint32_t)__builtin_popcountll(hit);
+                    uint32_t base = kFragNone;
+                    if (chunk_next + n_hit <= chunk_end) { base = chunk_next; chunk_next += n_hit; }
+                    else if (!pool_dry) {
+                        uint32_t pb = 0u;
+                        if (lane == 0u) pb = atomicAdd(&pool_next, n_hit);
+                        pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pb);
+                        const uint32_t pe = pool_end;
+                        if (pb + n_hit <= pe) base = pb;
+                        else {      // the pool is dry; what this wavefront took past its end, if anything is inside, stays unused
+                            for (uint32_t i = pb + lane; i < pe; i += 64u) if (i < f.frag_cap) f.frag_rec[i].x = kFragNone;
+                            pool_dry = true;
+                        }
+                    }
+                    if (base == kFragNone) {
+                        for (uint32_t i = chunk_next + lane; i < chunk_end; i += 64u) if (i < f.frag_cap) f.frag_rec[i].x = kFragNone;    // unused tail
+                        uint32_t nb = 0u;
+                        if (lane == 0u) nb = atomicAdd(&f.counters[5], kFragChunk);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                        chunk_next = base + n_hit;
+                        chunk_end = base + kFragChunk;
+                    }
+                    if (mask != 0u) {
 #pragma unroll
-                        for (int s = 0; s < S; s++) { e.z[s] = z[s]; if (!may_discard && (mask & (1u << s))) pix.depth[s] = z[s]; }
-                        fifo_all[n_pending * 64u + tid] = e;
-                        n_pending++;
+                        for (int s = 0; s < S; s++) if (mask & (1u << s)) depth[s] = z[s];
+                        const uint32_t idx = base + (uint32_t)__builtin_popcountll(hit & ((1ull << lane) - 1ull));
+                        if (idx < f.frag_cap) {
+                            f.frag_rec[idx] = make_uint4(rank, (uint32_t)px | ((uint32_t)py << 16), kFragNone, mask | (may_discard ? 0x100u : 0u));
+                            if (last != kFragNone) f.frag_rec[last].z = idx; else first = idx;
+                            last = idx;
+                        } else f.counters[6] = 1u;      // list overflow: the host grows the buffers and replays the pass
                     }
-                    // a discardable fragment must resolve its depth before the next triangle is tested
-                    if (may_discard && __builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) break;
                 }
-                forward_flush<S, GRAD>(sc, f, fifo, n_pending, pix, px, py);
-                if (exhausted && !have_carry) break;
             }
             __syncthreads();
         }
+        for (uint32_t i = min(pool_next, pool_end) + tid; i < pool_end; i += kFwdThreads) if (i < f.frag_cap) f.frag_rec[i].x = kFragNone;      // what is left of the pool
     }
-    // resolve + store (the reference resolves the multisampled `transparent` target into `composite`)
-    if (in_frame) {
-        float c[4];
-        if (S == 1) {
-            const uint2 d = pix.color[0];
-            c[0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); c[1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
-            c[2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); c[3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
-        } else {
-            float v[4][4];
+    for (uint32_t i = chunk_next + lane; i < chunk_end; i += 64u) if (i < f.frag_cap) f.frag_rec[i].x = kFragNone;    // unused tail of the last chunk
+    if (in_frame) f.frag_first[p] = first;
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_forward_shade(const DevScene* __restrict__ sc, FrameDev f) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= min(f.counters[5], f.frag_cap)) return;
+    const uint4 rec = f.frag_rec[i];
+    if (rec.x == kFragNone) return;                       // unused slot of a wavefront's chunk
+    const int px = (int)(rec.y & 0xFFFFu), py = (int)(rec.y >> 16);
+    TriSetup t;
+    tri_rec_load(f.tri_rec + rec.x, t);
+    const SurfaceOut o = forward_fragment<GRAD>(sc, f, t, rec.x, px, py, (rec.w & 0x100u) != 0u);
+    const float a = o.color.w;
+    f.frag_color[i] = make_float4(o.color.x * a, o.color.y * a, o.color.z * a, a);          // fragment.wgsl:283-285 premultiplied
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_forward_blend(FrameDev f) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= f.width * f.height) return;
+    const uint2 c0 = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];       // opaque -> transparent blit: every sample starts as the opaque colour
+    float dst[S][4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const uint2 d = pix.color[S == 1 ? 0 : s];
-                v[s][0] = f16_bits_to_f32((unsigned short)(d.x & 0xFFFFu)); v[s][1] = f16_bits_to_f32((unsigned short)(d.x >> 16));
-                v[s][2] = f16_bits_to_f32((unsigned short)(d.y & 0xFFFFu)); v[s][3] = f16_bits_to_f32((unsigned short)(d.y >> 16));
-            }
+    for (int s = 0; s < S; s++) {
+        dst[s][0] = f16_bits_to_f32((unsigned short)(c0.x & 0xFFFFu)); dst[s][1] = f16_bits_to_f32((unsigned short)(c0.x >> 16));
+        dst[s][2] = f16_bits_to_f32((unsigned short)(c0.y & 0xFFFFu)); dst[s][3] = f16_bits_to_f32((unsigned short)(c0.y >> 16));
+    }
+    for (uint32_t i = f.frag_first[p]; i != kFragNone && i < f.frag_cap;) {
+        const uint4 rec = f.frag_rec[i];
+        const float4 src = f.frag_color[i];
+        const float om = 1.0f - src.w;
 #pragma unroll
-            for (int k = 0; k < 4; k++) c[k] = resolve4_f16(v[0][k], v[1][k], v[2][k], v[3][k]);
+        for (int s = 0; s < S; s++) {
+            if (!(rec.w & (1u << s))) continue;
+            dst[s][0] = blend_over_f16(src.x, dst[s][0], om); dst[s][1] = blend_over_f16(src.y, dst[s][1], om);
+            dst[s][2] = blend_over_f16(src.z, dst[s][2], om); dst[s][3] = blend_over_f16(src.w, dst[s][3], om);
         }
-        store_pixel(f, (size_t)py * f.width + (size_t)px, {c[0], c[1], c[2], c[3]});
+        i = rec.z;
     }
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = S == 1 ? dst[0][k] : resolve4_f16(dst[0][k], dst[S > 1 ? 1 : 0][k], dst[S > 2 ? 2 : 0][k], dst[S > 3 ? 3 : 0][k]);
+    store_pixel(f, p, {c[0], c[1], c[2], c[3]});
 }
 
 // Block of 16x16 pixels -> pixel of this thread.  Workgroup ids are dealt round-robin over the 8 XCDs (blockIdx & 7), each
@@ -1566,14 +1664,12 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
 extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (!n_tiles) return;
-    const bool grad = f->mipmap != 0u;
-    if (f->msaa == 4u) {
-        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<4, true>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
-        else hipLaunchKernelGGL((awsm::k_forward_tile<4, false>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
-    } else {
-        if (grad) hipLaunchKernelGGL((awsm::k_forward_tile<1, true>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
-        else hipLaunchKernelGGL((awsm::k_forward_tile<1, false>), dim3(16u * n_tiles), dim3(64), 0, s, sc, *f);
-    }
+    const bool grad = f->mipmap != 0u, ms = f->msaa == 4u;
+    const uint32_t nb_shade = (f->frag_cap + 255u) / 256u, nb_blend = (f->width * f->height + 255u) / 256u;
+    if (ms) { if (grad) hipLaunchKernelGGL((awsm::k_forward_cover<4, true>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); else hipLaunchKernelGGL((awsm::k_forward_cover<4, false>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); }
+    else { if (grad) hipLaunchKernelGGL((awsm::k_forward_cover<1, true>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); else hipLaunchKernelGGL((awsm::k_forward_cover<1, false>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); }
+    if (nb_shade) { if (grad) hipLaunchKernelGGL(awsm::k_forward_shade<true>, dim3(nb_shade), dim3(256), 0, s, sc, *f); else hipLaunchKernelGGL(awsm::k_forward_shade<false>, dim3(nb_shade), dim3(256), 0, s, sc, *f); }
+    if (ms) hipLaunchKernelGGL(awsm::k_forward_blend<4>, dim3(nb_blend), dim3(256), 0, s, *f); else hipLaunchKernelGGL(awsm::k_forward_blend<1>, dim3(nb_blend), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
     if (f->sy1 > f->sy0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->sy0, f->sy1, f->band_n, f->band_r, f->msaa, f->counters + 3);

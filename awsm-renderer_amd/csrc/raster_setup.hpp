@@ -136,20 +136,25 @@ AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok)
     d[3] = make_double2(t.c[0], t.c[1]);
     d[4] = make_double2(t.c[2], __hiloint2double((int)by, (int)bx));
 }
-AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) {
+struct TriRecRaw { float4 q0, q1, q2; double2 d3, d4; };      // the record as loaded; lets a serial walk fetch the next one early
+AWSM_DI TriRecRaw tri_rec_fetch(const TriRec* __restrict__ src) {
     const float4* q = reinterpret_cast<const float4*>(src);
     const double2* d = reinterpret_cast<const double2*>(src);
-    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-    const double2 d3 = d[3], d4 = d[4];
-    t.a[0] = q0.x; t.a[1] = q0.y; t.a[2] = q0.z; t.b[0] = q0.w;
-    t.b[1] = q1.x; t.b[2] = q1.y; t.zq[0] = q1.z; t.zq[1] = q1.w;
-    t.zq[2] = q2.x; t.iw[0] = q2.y; t.iw[1] = q2.z; t.iw[2] = q2.w;
-    t.c[0] = d3.x; t.c[1] = d3.y; t.c[2] = d4.x;
-    const uint32_t bx = (uint32_t)__double2loint(d4.y), by = (uint32_t)__double2hiint(d4.y);
+    TriRecRaw r;
+    r.q0 = q[0]; r.q1 = q[1]; r.q2 = q[2]; r.d3 = d[3]; r.d4 = d[4];
+    return r;
+}
+AWSM_DI bool tri_rec_unpack(const TriRecRaw& r, TriSetup& t) {
+    t.a[0] = r.q0.x; t.a[1] = r.q0.y; t.a[2] = r.q0.z; t.b[0] = r.q0.w;
+    t.b[1] = r.q1.x; t.b[2] = r.q1.y; t.zq[0] = r.q1.z; t.zq[1] = r.q1.w;
+    t.zq[2] = r.q2.x; t.iw[0] = r.q2.y; t.iw[1] = r.q2.z; t.iw[2] = r.q2.w;
+    t.c[0] = r.d3.x; t.c[1] = r.d3.y; t.c[2] = r.d4.x;
+    const uint32_t bx = (uint32_t)__double2loint(r.d4.y), by = (uint32_t)__double2hiint(r.d4.y);
     t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)(bx >> 16); t.miny = (int)(by & 0xFFFFu); t.maxy = (int)((by >> 16) & 0x7FFFu);
     t.front = (by >> 31) != 0u;
     return t.minx <= t.maxx;
 }
+AWSM_DI bool tri_rec_load(const TriRec* __restrict__ src, TriSetup& t) { return tri_rec_unpack(tri_rec_fetch(src), t); }
 
 // Edge values at a sample given in 1/256-pixel units (pixel centre = px*256 + 128).
 struct EdgeVals { double E[3]; };

@@ -145,7 +145,7 @@ typedef struct AwsmFrameStats {
     uint32_t bin_overflow_retries;
     float ms_forward;           /* transparent pass: transform + binning + k_forward_tile */
     uint32_t forward_triangles; /* sum of tri_count (x instances) over the transparent draws */
-    uint32_t reserved[1];
+    uint32_t forward_fragment_slots; /* fragment-list slots the transparent pass used (fragments + the unused tails of the wavefronts' chunks) */
 } AwsmFrameStats;
 
 /* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */
