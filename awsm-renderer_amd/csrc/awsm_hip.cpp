@@ -54,6 +54,8 @@ struct FrameBufs {
     DevBuf draw_mat;                       // n_draws DrawMatDev (k_resolve_draws)
     DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
     DevBuf camera;                         // snapshot of the camera UBO taken by the geometry pass (overlap mode)
+    DevBuf tile_split, raster_scratch;     // split raster tiles: per-tile {first scratch slot, slices done}; partial tiles (geometry pass only)
+    uint32_t raster_extra_cap = 0, raster_slot_cap = 0;
     uint32_t bin_capacity = 0;
     std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
     void* draws_uploaded_ptr = nullptr;
@@ -268,6 +270,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->tile_count = (uint32_t*)FB(c).tile_count.ptr; f->tile_offset = (uint32_t*)FB(c).tile_offset.ptr;
     f->tile_cursor = (uint32_t*)FB(c).tile_cursor.ptr; f->bin_list = (uint32_t*)FB(c).bin_list.ptr;
     f->tile_order = (uint32_t*)FB(c).tile_order.ptr;
+    f->tile_split = (uint32_t*)FB(c).tile_split.ptr; f->raster_scratch = (unsigned long long*)FB(c).raster_scratch.ptr;
+    f->raster_extra_cap = FB(c).raster_extra_cap; f->raster_slot_cap = FB(c).raster_slot_cap;
     f->big_list = (uint32_t*)FB(c).big_list.ptr;
     f->counters = (uint32_t*)FB(c).counters.ptr;
     f->vis = (unsigned long long*)FB(c).vis.ptr;
@@ -368,6 +372,8 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->tile_count = (uint32_t*)t.tile_count.ptr; f->tile_offset = (uint32_t*)t.tile_offset.ptr;
     f->tile_cursor = (uint32_t*)t.tile_cursor.ptr; f->bin_list = (uint32_t*)t.bin_list.ptr;
     f->tile_order = (uint32_t*)t.tile_order.ptr;
+    f->tile_split = (uint32_t*)t.tile_split.ptr; f->raster_scratch = nullptr;      // the transparent pass has its own tile kernel: nothing is split
+    f->raster_extra_cap = 0; f->raster_slot_cap = 0;
     f->big_list = (uint32_t*)t.big_list.ptr;
     f->counters = (uint32_t*)t.counters.ptr;
     f->opaque_rgba16f = f->out_rgba16f;
@@ -463,6 +469,18 @@ int build_draw_list(AwsmHipCtx* c, const char* pass, const AwsmDraw* draws, uint
 }
 
 // per-pass device state sized for `draws_host` / total_tris; uploads the draw list when it changed
+// raster items: one per tile + one per extra slice of a split tile (<= entries / 256); scratch tiles: one per slice of a split tile
+int reserve_raster_items(AwsmHipCtx* c, FrameBufs& b, bool forward) {
+    const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
+    const size_t n_tiles_full = (size_t)tiles_x * tiles_y_full;
+    const uint32_t extra_cap = forward ? 0u : b.bin_capacity / 256u + 1u, slot_cap = forward ? 0u : b.bin_capacity / 128u + 2u;
+    int rc;
+    if ((rc = dev_reserve(c, b.tile_order, (n_tiles_full + extra_cap) * 4))) return rc;
+    if (!forward && (rc = dev_reserve(c, b.raster_scratch, (size_t)slot_cap * kTile * kTile * 8 * (c->msaa == 4u ? 4u : 1u)))) return rc;
+    b.raster_extra_cap = extra_cap; b.raster_slot_cap = slot_cap;
+    return AWSM_OK;
+}
+
 int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
     int rc;
     const size_t nd = std::max<size_t>(draws_host.size(), 1), nv = std::max<size_t>(3ull * total_tris, 1), nt = std::max<size_t>(total_tris, 1);
@@ -482,8 +500,9 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
     if ((rc = dev_reserve(c, b.tile_count, n_tiles_full * 4))) return rc;
     if ((rc = dev_reserve(c, b.tile_offset, (n_tiles_full + 1) * 4))) return rc;
     if ((rc = dev_reserve(c, b.tile_cursor, n_tiles_full * 4))) return rc;
-    if ((rc = dev_reserve(c, b.tile_order, n_tiles_full * 4))) return rc;
+    if ((rc = dev_reserve(c, b.tile_split, n_tiles_full * 8))) return rc;
     if ((rc = ensure_bin_capacity_of(c, b, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * total_tris + 65536u, 1u << 18)))) return rc;
+    if ((rc = reserve_raster_items(c, b, forward))) return rc;
     // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
     // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
     const bool same_draws = b.draws_uploaded_valid && b.draws_uploaded_ptr == b.draws_dev.ptr && b.draws_uploaded.size() == draws_host.size() &&
@@ -573,7 +592,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
-        fr(b.tile_cursor); fr(b.tile_order); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
+        fr(b.tile_cursor); fr(b.tile_order); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
     for (int i = 0; i < 2; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); }
@@ -884,6 +903,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         c->overflow_retries++;
         if (geom_over) {
             if ((rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024))) return rc;
+            if ((rc = reserve_raster_items(c, FB(c), false))) return rc;
             if ((rc = enqueue_geometry(c))) return rc;
             if (c->opaque_done && (rc = enqueue_opaque(c))) return rc;
         }

@@ -127,10 +127,14 @@ struct FrameDev {
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1
     uint32_t* tile_cursor;        // n_tiles
-    uint32_t* tile_order;         // n_tiles: tile ids, heaviest first (k_bin_scan)
+    uint32_t* tile_order;         // n_tiles: tile ids, heaviest first (k_bin_scan); then raster_extra_cap extra raster items
+                                  // (tile | slice << 20, slice >= 1) for the tiles whose list is split over several workgroups (count in counters[7])
+    uint32_t* tile_split;         // 2 * n_tiles: [2t] first scratch slot of a split tile (0xFFFFFFFF: not split), [2t+1] slices that finished
+    unsigned long long* raster_scratch;   // raster_slot_cap tiles of keys (1024 * samples each): partial tiles of the split ones
+    uint32_t raster_extra_cap, raster_slot_cap;
     uint32_t* bin_list;           // bin_capacity
     uint32_t* big_list;           // total_tris: ranks of the triangles covering > 16 tiles (count in counters[4])
-    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles
+    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles, [7] extra raster items
     // targets
     unsigned long long* vis;      // width*height packed keys
     uint16_t* out_rgba16f;        // width*height*4
@@ -139,7 +143,7 @@ struct FrameDev {
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
     const uint16_t* opaque_rgba16f;   // transparent pass: the opaque pass's image (blit source and transmission background); out_rgba16f/32f = composite
     // transparent pass fragment lists (k_forward_cover -> k_forward_shade -> k_forward_blend): counters[5] = fragments, counters[6] = overflow flag
-    uint4* frag_rec;              // frag_cap records {triangle rank, pixel index, next fragment of the pixel (0xFFFFFFFF = last), sample mask | resolved-mask flag << 8}
+    uint4* frag_rec;              // frag_cap records {triangle rank, pixel x | y << 16, next fragment of the pixel (0xFFFFFFFF = last), sample mask | resolved-mask flag << 8}
     float4* frag_color;           // frag_cap premultiplied colours (k_forward_shade)
     uint32_t* frag_first;         // width*height: the pixel's first fragment in submission order (0xFFFFFFFF = none)
     uint32_t frag_cap;

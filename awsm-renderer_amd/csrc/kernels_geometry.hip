@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     if (FWD) f.wpos[gv] = make_float4(world_pos.x, world_pos.y, world_pos.z, 1.0f);
     // transparent pass: bit 31 = the draw's material is ALPHA_MODE_MASK (k_resolve_draws ran before this kernel), so the coverage walk
     // learns it from the word it loads anyway instead of a second dependent load per triangle
-    if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | (d.flags << 24)  | ((FWD && (f.draw_shade[lo].flags & 2u)) ? 0x80000000u : 0u);
+    if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | ((d.flags & 0x7Fu) << 24) /* 0x80 = kDrawInstanced, internal */ | ((FWD && (f.draw_shade[lo].flags & 2u)) ? 0x80000000u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,11 +355,14 @@ __global__ __launch_bounds__(256) void k_bin_big(FrameDev f) {
 // ids sorted by log2(count), heaviest first.  Workgroups start in blockIdx order, so k_raster_tile begins with the
 // fullest tiles and the light ones fill in behind them (longest-processing-time-first; the fullest tile of a frame holds
 // 20-40x the median number of triangles and would otherwise be the tail of the kernel).
+constexpr uint32_t kRasterSlice = 256;     // triangles of a tile's list one raster workgroup takes (= one batch of k_raster_tile)
 __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
     __shared__ uint32_t part[1024], part2[1024];
     __shared__ uint32_t bucket_n[16][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
     __shared__ uint32_t bucket_at[16][33];
+    __shared__ uint32_t n_extra, n_slots;       // raster items beyond one per tile / scratch tiles (split tiles, see k_raster_tile)
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) { n_extra = 0u; n_slots = 0u; }
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
     for (uint32_t i = tid; i < 16u * 33u; i += 1024u) (&bucket_n[0][0])[i] = 0u;
@@ -397,25 +400,34 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
     if (tid < 33u * 16u) bucket_at[e_wave][e_bucket] = part2[tid] - e_val;
     __syncthreads();
     uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's chunk
-#pragma unroll
-    for (uint32_t j = 0; j < 8u; j++)
-        if (b0 + j < b1) {
-            const uint32_t i = b0 + j, c = cnt[j];
-            f.tile_offset[i] = run; run += c;
-            f.tile_cursor[i] = 0u;
-            f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
-        }
-    for (uint32_t i = b0 + 8u; i < b1; i++) {
-        const uint32_t c = f.tile_count[i];
+    // A tile with more than kRasterSlice triangles is rasterised by ceil(c / kRasterSlice) workgroups (its list in slices): one extra
+    // raster item per slice after the first, one scratch tile per slice.  The caps hold whenever the bin list itself does not overflow.
+    auto place = [&](uint32_t i, uint32_t c) {
         f.tile_offset[i] = run; run += c;
         f.tile_cursor[i] = 0u;
         f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
-    }
+        const uint32_t ns = (c + kRasterSlice - 1u) / kRasterSlice;
+        uint32_t slot = 0xFFFFFFFFu;
+        if (ns > 1u && f.raster_scratch) {
+            const uint32_t eb = atomicAdd(&n_extra, ns - 1u), sb = atomicAdd(&n_slots, ns);
+            const bool fits = eb + ns - 1u <= f.raster_extra_cap && sb + ns <= f.raster_slot_cap && ns <= 4095u;
+            if (fits) slot = sb;
+            for (uint32_t k = 1; k < ns; k++) if (eb + k - 1u < f.raster_extra_cap) f.tile_order[n_tiles + eb + k - 1u] = fits ? (i | (k << 20)) : 0xFFFFFFFFu;
+        }
+        f.tile_split[2u * i] = slot;
+        f.tile_split[2u * i + 1u] = 0u;
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; j++)
+        if (b0 + j < b1) place(b0 + j, cnt[j]);
+    for (uint32_t i = b0 + 8u; i < b1; i++) place(i, f.tile_count[i]);
+    __syncthreads();
     if (tid == 1023u) {
         const uint32_t total = part[1023];
         f.tile_offset[n_tiles] = total;
         f.counters[1] = total;
         if (total > f.bin_capacity) f.counters[2] = 1u;
+        f.counters[7] = min(n_extra, f.raster_extra_cap);
     }
 }
 
@@ -468,7 +480,14 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
 
     // Heaviest tiles first (tile_order, k_bin_scan).  Consecutive ids go to different XCDs (blockIdx & 7), which also
     // spreads the dense band of the screen over all eight of them.
-    const uint32_t tile = f.tile_order[blockIdx.x];
+    // The first counters[7] workgroups take the extra slices of the split tiles (the heaviest work of the frame), the rest one tile each.
+    const uint32_t n_tiles = f.tiles_x * f.tiles_y, n_extra = min(f.counters[7], f.raster_extra_cap);
+    uint32_t item;
+    if (blockIdx.x < n_extra) item = f.tile_order[n_tiles + blockIdx.x];
+    else if (blockIdx.x - n_extra < n_tiles) item = f.tile_order[blockIdx.x - n_extra];
+    else return;
+    if (item == 0xFFFFFFFFu) return;
+    const uint32_t tile = item & 0xFFFFFu, slice = item >> 20;
     const uint32_t tid = threadIdx.x;
     const int tpx = (int)(tile % f.tiles_x) << kTileShift;
     const int tpy = (int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift;
@@ -476,10 +495,16 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
 #pragma unroll
     for (int i = 0; i < 4 * S; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
     const uint32_t off = f.tile_offset[tile];
-    const uint32_t count = min(f.tile_count[tile], f.bin_capacity - min(f.bin_capacity, off));
+    const uint32_t count_all = f.tile_count[tile];
+    const uint32_t slot0 = f.tile_split[2u * tile];
+    const bool split = slot0 != 0xFFFFFFFFu;
+    const uint32_t n_slices = split ? (count_all + kRasterSlice - 1u) / kRasterSlice : 1u;
+    const uint32_t count_fit = min(count_all, f.bin_capacity - min(f.bin_capacity, off));
+    const uint32_t first = split ? min(slice * kRasterSlice, count_fit) : 0u;
+    const uint32_t count = split ? min((slice + 1u) * kRasterSlice, count_fit) : count_fit;
     const int lane = tid & 63, wave = tid >> 6;
 
-    for (uint32_t base = 0; base < count; base += 256u) {
+    for (uint32_t base = first; base < count; base += 256u) {
         if (tid == 0) { n_mid = 0; n_big = 0; }
         __syncthreads();
         const uint32_t idx = base + tid;
@@ -539,6 +564,33 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         __syncthreads();
     }
     __syncthreads();
+    if (split) {
+        // Partial tile of a split list: park it in its scratch slot; the slice that finishes last folds the others into its own
+        // (min over packed keys, the same resolve as inside a tile) and writes the tile.  The slices run on different XCDs, whose L2s
+        // are not coherent for plain stores, and a device-scope release / acquire fence costs a write-back + invalidate of the whole
+        // L2 per wavefront (measured: the raster kernel 40 % slower).  So the scratch traffic itself is device-scope atomic — relaxed
+        // stores and loads that go through to memory (sc1) — ordered against the arrival counter by completion (s_waitcnt via the
+        // workgroup-scope fence) and the barrier; nothing else in the kernel needs to become visible.
+        __shared__ uint32_t arrived;
+        unsigned long long* mine = f.raster_scratch + (size_t)(slot0 + slice) * (kTile * kTile * S);
+#pragma unroll
+        for (int i = 0; i < 4 * S; i++) __hip_atomic_store(mine + tid + i * 256, keys[tid + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) arrived = __hip_atomic_fetch_add(&f.tile_split[2u * tile + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (arrived != n_slices - 1u) return;
+        for (uint32_t k = 0; k < n_slices; k++) {
+            if (k == slice) continue;
+            const unsigned long long* other = f.raster_scratch + (size_t)(slot0 + k) * (kTile * kTile * S);
+#pragma unroll
+            for (int i = 0; i < 4 * S; i++) {
+                const unsigned long long v = __hip_atomic_load(other + tid + i * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v < keys[tid + i * 256]) keys[tid + i * 256] = v;
+            }
+        }
+        __syncthreads();
+    }
     // tile -> HBM, once, row-major image with the samples of a pixel adjacent: each wavefront writes 256 B (S = 1: two
     // 32-pixel rows) or 512 B runs per step
 #pragma unroll
@@ -637,8 +689,8 @@ extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
 }
 extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
-    const uint32_t nb = n_tiles;
-    if (!nb) return;
+    if (!n_tiles) return;
+    const uint32_t nb = n_tiles + (f->raster_scratch ? f->raster_extra_cap : 0u);     // surplus ids exit at once
     if (f->msaa == 4u) hipLaunchKernelGGL(awsm::k_raster_tile<4>, dim3(nb), dim3(256), 0, s, *f);
     else hipLaunchKernelGGL(awsm::k_raster_tile<1>, dim3(nb), dim3(256), 0, s, *f);
 }
