@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_bin_big(FrameDev f) {
 // 20-40x the median number of triangles and would otherwise be the tail of the kernel).
 constexpr uint32_t kRasterSlice = 256;     // triangles of a tile's list one raster workgroup takes (= one batch of k_raster_tile)
 __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
-    __shared__ uint32_t part[1024], part2[1024];
+    __shared__ uint32_t part[16], part2[16];    // wavefront totals of the two scans
     __shared__ uint32_t bucket_n[16][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
     __shared__ uint32_t bucket_at[16][33];
     __shared__ uint32_t n_extra, n_slots;       // raster items beyond one per tile / scratch tiles (split tiles, see k_raster_tile)
@@ -369,9 +369,18 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
     __syncthreads();
     // the first 8 counts of the chunk are loaded together and kept in registers for the second loop (one memory round trip
     // instead of `per` dependent ones); longer chunks (frames beyond 8192 tiles) fall back to re-reading
+    // Frames of up to 8192 tiles (4K: 8160) move counts and offsets through LDS so that the global loads and stores of this single
+    // workgroup are coalesced (thread t touches tiles t, t + 1024, ...) while each thread still owns 8 consecutive tiles of the scan:
+    // one CU's memory pipeline was the bottleneck with 32-byte-strided 4-byte accesses.
+    __shared__ uint32_t stage[8192];
+    const bool staged = n_tiles <= 8192u;          // then per <= 8
+    if (staged) {
+        for (uint32_t i = tid; i < n_tiles; i += 1024u) stage[i] = f.tile_count[i];
+        __syncthreads();
+    }
     uint32_t cnt[8];
 #pragma unroll
-    for (uint32_t j = 0; j < 8u; j++) cnt[j] = (b0 + j < b1) ? f.tile_count[b0 + j] : 0u;
+    for (uint32_t j = 0; j < 8u; j++) cnt[j] = (b0 + j < b1) ? (staged ? stage[b0 + j] : f.tile_count[b0 + j]) : 0u;
     uint32_t sum = 0;
 #pragma unroll
     for (uint32_t j = 0; j < 8u; j++)
@@ -381,49 +390,47 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         sum += c;
         atomicAdd(&bucket_n[wave][32 - __clz(c)], 1u);
     }
-    part[tid] = sum;
     __syncthreads();
-    // second scan, sharing the barriers of the first: start of every (bucket, wave) run in tile_order, buckets descending,
-    // waves ascending inside a bucket — entry e = (32 - bucket) * 16 + wave
+    // Two inclusive scans over the 1024 threads at once — the chunk sums, and the (bucket, wave) histogram entries in tile_order's
+    // order: buckets descending, waves ascending inside a bucket, entry e = (32 - bucket) * 16 + wave.  Wavefront scans through
+    // shuffles plus the 16 wavefront totals: two barriers instead of the twenty of a workgroup-wide Hillis-Steele.
+    const uint32_t lane = tid & 63u;
     const uint32_t e_bucket = 32u - (tid >> 4), e_wave = tid & 15u;
     const uint32_t e_val = tid < 33u * 16u ? bucket_n[e_wave][e_bucket] : 0u;
-    part2[tid] = e_val;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
-        const uint32_t v2 = (tid >= off) ? part2[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        part2[tid] += v2;
-        __syncthreads();
+    uint32_t incl1 = sum, incl2 = e_val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o1 = (uint32_t)__shfl_up((int)incl1, d), o2 = (uint32_t)__shfl_up((int)incl2, d);
+        if ((int)lane >= d) { incl1 += o1; incl2 += o2; }
     }
-    if (tid < 33u * 16u) bucket_at[e_wave][e_bucket] = part2[tid] - e_val;
+    if (lane == 63u) { part[wave] = incl1; part2[wave] = incl2; }
     __syncthreads();
-    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's chunk
+    for (uint32_t w = 0; w < wave; w++) { incl1 += part[w]; incl2 += part2[w]; }
+    if (tid < 33u * 16u) bucket_at[e_wave][e_bucket] = incl2 - e_val;
+    __syncthreads();
+    uint32_t run = incl1 - sum;   // exclusive prefix of this thread's chunk
     // A tile with more than kRasterSlice triangles is rasterised by ceil(c / kRasterSlice) workgroups (its list in slices): one extra
     // raster item per slice after the first, one scratch tile per slice.  The caps hold whenever the bin list itself does not overflow.
     auto place = [&](uint32_t i, uint32_t c) {
-        f.tile_offset[i] = run; run += c;
-        f.tile_cursor[i] = 0u;
+        if (staged) stage[i] = run; else { f.tile_offset[i] = run; f.tile_cursor[i] = 0u; }
+        run += c;
         f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
-        const uint32_t ns = (c + kRasterSlice - 1u) / kRasterSlice;
-        uint32_t slot = 0xFFFFFFFFu;
-        if (ns > 1u && f.raster_scratch) {
+        if (c > kRasterSlice && f.raster_scratch) {     // tile_split is written (and read, k_raster_tile) for these tiles only
+            const uint32_t ns = (c + kRasterSlice - 1u) / kRasterSlice;
             const uint32_t eb = atomicAdd(&n_extra, ns - 1u), sb = atomicAdd(&n_slots, ns);
             const bool fits = eb + ns - 1u <= f.raster_extra_cap && sb + ns <= f.raster_slot_cap && ns <= 4095u;
-            if (fits) slot = sb;
             for (uint32_t k = 1; k < ns; k++) if (eb + k - 1u < f.raster_extra_cap) f.tile_order[n_tiles + eb + k - 1u] = fits ? (i | (k << 20)) : 0xFFFFFFFFu;
+            reinterpret_cast<uint2*>(f.tile_split)[i] = make_uint2(fits ? sb : 0xFFFFFFFFu, 0u);
         }
-        f.tile_split[2u * i] = slot;
-        f.tile_split[2u * i + 1u] = 0u;
     };
 #pragma unroll
     for (uint32_t j = 0; j < 8u; j++)
         if (b0 + j < b1) place(b0 + j, cnt[j]);
     for (uint32_t i = b0 + 8u; i < b1; i++) place(i, f.tile_count[i]);
     __syncthreads();
+    if (staged) for (uint32_t i = tid; i < n_tiles; i += 1024u) { f.tile_offset[i] = stage[i]; f.tile_cursor[i] = 0u; }
     if (tid == 1023u) {
-        const uint32_t total = part[1023];
+        const uint32_t total = incl1;
         f.tile_offset[n_tiles] = total;
         f.counters[1] = total;
         if (total > f.bin_capacity) f.counters[2] = 1u;
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     for (int i = 0; i < 4 * S; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
     const uint32_t off = f.tile_offset[tile];
     const uint32_t count_all = f.tile_count[tile];
-    const uint32_t slot0 = f.tile_split[2u * tile];
+    const uint32_t slot0 = (count_all > kRasterSlice && f.raster_scratch) ? f.tile_split[2u * tile] : 0xFFFFFFFFu;
     const bool split = slot0 != 0xFFFFFFFFu;
     const uint32_t n_slices = split ? (count_all + kRasterSlice - 1u) / kRasterSlice : 1u;
     const uint32_t count_fit = min(count_all, f.bin_capacity - min(f.bin_capacity, off));
