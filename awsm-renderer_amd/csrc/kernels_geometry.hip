@@ -215,10 +215,29 @@ AWSM_DI void bin_tri_load(const FrameDev& f, uint32_t r, BinTri& b) {
     if (r < f.total_tris) {
         if (SETUP) {   // the first phase of the counting pass does the setup once and leaves it for everyone downstream
             const float4 v0 = f.clip[(size_t)r * 3], v1 = f.clip[(size_t)r * 3 + 1], v2 = f.clip[(size_t)r * 3 + 2];
-            const bool cull_back = ((f.tri_info[r] >> 24) & AWSM_DRAW_CULL_BACK) != 0;
-            b.ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, b.t);
-            if (!b.ok) { b.t.minx = 0; b.t.maxx = 0; b.t.miny = 0; b.t.maxy = 0; }
-            tri_rec_store(f.tri_rec + r, b.t, b.ok);
+            // A shard (bands or a row strip) sees most triangles of the frame only to drop them: decide that from a conservative
+            // row range (+-1 pixel around the unsnapped vertices; any w <= 0 or non-finite value keeps the triangle) before the setup,
+            // and leave just the "no fragment" marker.  The exact rows of a kept triangle come from tri_setup as before.
+            bool outside = false;
+            if ((f.band_n > 1u || f.y0 > 0u || f.y1 < f.height) && v0.w > 0.0f && v1.w > 0.0f && v2.w > 0.0f) {
+                const float hh = 0.5f * (float)f.height;
+                const float ya = (1.0f - v0.y / v0.w) * hh, yb = (1.0f - v1.y / v1.w) * hh, yc = (1.0f - v2.y / v2.w) * hh;
+                const float lo = fminf(fminf(ya, yb), yc) - 1.0f, hi = fmaxf(fmaxf(ya, yb), yc) + 1.0f;
+                if (hi < (float)f.y0 || lo >= (float)f.y1) outside = true;
+                else if (f.band_n > 1u && lo >= (float)f.y0 && hi < (float)f.y1) {     // in range (NaN fails this): which owned tile rows can it touch?
+                    const int bn = (int)f.band_n, row0 = (int)f.tile_row0;
+                    const int a0 = ((int)floorf(lo) >> kTileShift) - row0, a1 = ((int)floorf(hi) >> kTileShift) - row0;
+                    const int t0 = (max(a0, 0) + bn - 1) / bn, t1 = a1 >= 0 ? a1 / bn : -1;
+                    outside = t0 > t1;
+                }
+            }
+            if (outside) { tri_rec_store_invalid(f.tri_rec + r); b.ok = false; }
+            else {
+                const bool cull_back = ((f.tri_info[r] >> 24) & AWSM_DRAW_CULL_BACK) != 0;
+                b.ok = tri_setup(v0, v1, v2, cull_back, f.width, f.height, f.y0, f.y1, b.t);
+                if (!b.ok) { b.t.minx = 0; b.t.maxx = 0; b.t.miny = 0; b.t.maxy = 0; }
+                tri_rec_store(f.tri_rec + r, b.t, b.ok);
+            }
         } else {
             b.ok = tri_rec_load(f.tri_rec + r, b.t);
         }

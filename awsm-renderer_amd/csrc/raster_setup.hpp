@@ -136,6 +136,9 @@ AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok)
     d[3] = make_double2(t.c[0], t.c[1]);
     d[4] = make_double2(t.c[2], __hiloint2double((int)by, (int)bx));
 }
+AWSM_DI void tri_rec_store_invalid(TriRec* __restrict__ dst) {     // only the words tri_rec_unpack's validity test reads
+    reinterpret_cast<double2*>(dst)[4] = make_double2(0.0, __hiloint2double(1, 1));
+}
 struct TriRecRaw { float4 q0, q1, q2; double2 d3, d4; };      // the record as loaded; lets a serial walk fetch the next one early
 AWSM_DI TriRecRaw tri_rec_fetch(const TriRec* __restrict__ src) {
     const float4* q = reinterpret_cast<const float4*>(src);
