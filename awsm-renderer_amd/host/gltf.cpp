@@ -15,7 +15,7 @@
 // (mikktspace's vertex weighting), accumulated per vertex, projected off the normal and normalised with the reference's
 // fallbacks and sign vote — mikktspace's splitting of a vertex between smoothing groups is what is not reproduced.
 //
-// Images: PNG (png.hpp, zlib inflate) and baseline JPEG (jpeg.hpp).  Progressive JPEG, KTX2 and anything else return
+// Images: PNG (png.hpp, zlib inflate) and JPEG (jpeg.hpp: baseline, extended sequential and progressive; Huffman, 8 bit).  KTX2 and anything else return
 // AWSM_ERR_UNSUPPORTED with the image index in the message.
 // Not read: cameras (the caller owns the camera), animations, sparse accessors, KHR_mesh_quantization beyond the normalised
 // integer attribute types glTF core already allows, EXT_mesh_gpu_instancing.

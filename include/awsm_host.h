@@ -151,7 +151,7 @@ int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* l
  * or a .glb, decodes the images (PNG), converts every accessor, generates missing normals / tangents, and populates this host
  * through the key API above in the reference's order (transforms, skins, meshes; populate.rs:185-205).  scene_index < 0 = the
  * document's default scene.  The camera is not taken from the file.  On failure returns a negative AwsmStatus and, if err_out is
- * given, the reason (AWSM_ERR_UNSUPPORTED for progressive JPEG / KTX2 images, sparse accessors, point / line primitives, unknown required
+ * given, the reason (AWSM_ERR_UNSUPPORTED for arithmetic-coded / 12-bit / CMYK JPEG and KTX2 images, sparse accessors, point / line primitives, unknown required
  * extensions); objects inserted before the failure stay inserted. ---- */
 typedef struct AwsmGltfInfo {
     uint32_t nodes, meshes, materials, images, samplers, skins, lights, triangles, generated_tangents, reserved[3];

@@ -265,9 +265,31 @@ def test_jpeg_restart_intervals_and_refusals():
     src.save(b, format="JPEG", quality=90, subsampling=0, restart_marker_blocks=3)
     assert b"\xff\xdd" in b.getvalue()
     assert np.array_equal(H.decode_image(a.getvalue()), H.decode_image(b.getvalue()))
-    p = io.BytesIO()
-    src.save(p, format="JPEG", quality=90, progressive=True)
-    with pytest.raises(H.HostError, match="progressive"):
-        H.decode_image(p.getvalue())
     with pytest.raises(H.HostError, match="not supported"):
         H.decode_image(b"GIF89a" + bytes(32))
+
+
+@pytest.mark.parametrize("subsampling,quality,size,gray,restart", [(0, 90, (72, 40), False, 0), (2, 85, (83, 57), False, 0), (1, 75, (37, 29), False, 0),
+                                                                     (0, 95, (40, 40), True, 0), (2, 60, (130, 70), False, 2), (0, 100, (16, 16), False, 0)])
+def test_progressive_jpeg_decodes_to_the_same_pixels_as_its_baseline_twin(subsampling, quality, size, gray, restart):
+    """SOF2 (spectral selection + successive approximation, DC / AC first and refining scans, end-of-band runs, non-interleaved AC scans)
+    carries the same quantised coefficients as the baseline encoding of the same picture at the same quality: the two must decode to
+    identical pixels, and stay as close to libjpeg as the baseline decoder is."""
+    import io
+    from PIL import Image
+    w, h = size
+    src = Image.fromarray(_test_image(w, h)[..., :3], "RGB")
+    if gray:
+        src = src.convert("L")
+    kw = {} if gray else {"subsampling": subsampling}
+    if restart:
+        kw["restart_marker_rows"] = restart
+    base, prog = io.BytesIO(), io.BytesIO()
+    src.save(base, format="JPEG", quality=quality, **kw)
+    src.save(prog, format="JPEG", quality=quality, progressive=True, **kw)
+    assert b"\xff\xc2" in prog.getvalue() and b"\xff\xc2" not in base.getvalue()
+    got = H.decode_image(prog.getvalue())
+    assert np.array_equal(got, H.decode_image(base.getvalue()))
+    want = np.asarray(Image.open(io.BytesIO(prog.getvalue())).convert("RGBA")).astype(np.int32)
+    d = np.abs(got.astype(np.int32)[..., :3] - want[..., :3])
+    assert d.mean() < (1.0 if subsampling == 0 else 3.5), d.mean()
