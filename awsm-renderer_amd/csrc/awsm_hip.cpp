@@ -69,6 +69,7 @@ struct AwsmHipCtx {
     uint32_t flags = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool stage_timers = true;      // hipEventRecord between the stages of a frame (AwsmFrameStats.ms_*); awsm_hip_set_stage_timers
     std::string last_error;
 
     DevBuf bufs[AWSM_BUF_COUNT];
@@ -286,6 +287,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
 }
 
 int record(AwsmHipCtx* c, int which, hipStream_t s = nullptr) {
+    if (!c->stage_timers) { c->ev_valid[which] = false; return AWSM_OK; }     // each record is a ~5 us bubble between two kernels
     HIPCHK(c, hipEventRecord(c->ev[which], s ? s : c->stream));
     c->ev_valid[which] = true;
     return AWSM_OK;
@@ -870,6 +872,12 @@ int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) 
     }
     if ((rc = enqueue_transparent(c))) return rc;
     c->transparent_done = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_set_stage_timers(AwsmHipCtx* c, int enabled) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    c->stage_timers = enabled != 0;
     return AWSM_OK;
 }
 

@@ -190,6 +190,10 @@ class HipDevice:
         self._chk(self.lib.awsm_hip_pick(self.ctx, x, y, out), "pick")
         return ((out[1] << 32) | out[2], out[3]) if out[0] else None
 
+    def set_stage_timers(self, enabled: bool):
+        """hipEventRecord between the stages of a frame (frame_end's ms_* fields); off = no bubbles between the kernels."""
+        self._chk(self.lib.awsm_hip_set_stage_timers(self.ctx, 1 if enabled else 0), "set_stage_timers")
+
     def set_shard_bands(self, n: int, r: int, compact_output: bool = False):
         self._chk(self.lib.awsm_hip_set_shard_bands(self.ctx, n, r, 1 if compact_output else 0), "set_shard_bands")
 

@@ -232,6 +232,12 @@ int awsm_hip_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n
  * fills per-kernel times.  `out` may be NULL. ---- */
 int awsm_hip_frame_end(AwsmHipCtx* ctx, AwsmFrameStats* out);
 
+/* Stage timers: by default every frame records HIP events between its stages so that awsm_hip_frame_end can report
+ * AwsmFrameStats.ms_*.  Each record costs a ~5 us bubble between two kernels; a render loop that does not read the stage times
+ * turns them off (the ms_* fields then read 0; counters are unaffected).  No reference counterpart (the reference's timings are
+ * tracing spans around command encoding, render.rs:150-320). */
+int awsm_hip_set_stage_timers(AwsmHipCtx* ctx, int enabled);
+
 /* ---- frame loop without a host sync (bench / multi-frame pipelines): enqueue only. ---- */
 int awsm_hip_frame_flush(AwsmHipCtx* ctx);
 
