@@ -24,7 +24,7 @@ BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", 
 
 # every symbol include/awsm_hip.h declares (tests/test_abi_symbols.py checks the header against this list too)
 EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
-           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_pick", "awsm_hip_texture_array_upload", "awsm_hip_texture_array_generate_mips", "awsm_hip_texture_array_read_level", "awsm_hip_sampler_set",
+           "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_set_stage_timers", "awsm_hip_pick", "awsm_hip_texture_array_upload", "awsm_hip_texture_array_generate_mips", "awsm_hip_texture_array_read_level", "awsm_hip_sampler_set",
            "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
@@ -96,6 +96,7 @@ def load_library():
     lib.awsm_hip_frame_flush.argtypes = [C.c_void_p]
     lib.awsm_hip_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.awsm_hip_set_shard_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.awsm_hip_set_stage_timers.argtypes = [C.c_void_p, C.c_int]
     lib.awsm_hip_set_shard_bands.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.awsm_hip_pick.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.awsm_hip_texture_array_generate_mips.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
