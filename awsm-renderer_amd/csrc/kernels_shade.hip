@@ -1655,9 +1655,8 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         if (grad) { hipLaunchKernelGGL(awsm::k_shade_msaa<true>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
         else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
     } else {
-        static const uint32_t lds_pad = getenv("AWSM_SHADE_LDS_PAD") ? (uint32_t)atoi(getenv("AWSM_SHADE_LDS_PAD")) : 0u;   // experiment: caps workgroups per CU
-        if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), lds_pad, s, sc, *f);
-        else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), lds_pad, s, sc, *f);
+        if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
     }
 }
 // f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;
