@@ -84,7 +84,7 @@ def load_library():
         "awsm_host_set_ibl_mip_counts": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_camera_update": (C.c_int, [vp, F32P, F32P, F32P]), "awsm_host_env": (C.c_int, [vp, vp]),
         "awsm_host_brdf_lut_generate": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_resize": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
-        "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_set_render_timings": (C.c_int, [vp, C.c_int]),
         "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
         "awsm_host_set_anti_aliasing": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_mesh_set_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]), "awsm_host_mesh_append_instances": (C.c_int, [vp, u64, F32P, C.c_uint32]),
@@ -318,6 +318,10 @@ class Host:
 
     def set_shard_bands(self, n: int, r: int, compact_output: bool = False):
         self._chk(self.lib.awsm_host_set_shard_bands(self.h, n, r, 1 if compact_output else 0), "set_shard_bands")
+
+    def set_render_timings(self, enabled: bool):
+        """AwsmRendererLogging.render_timings (debug.rs:8-12): per-stage times in the frame stats (default on)."""
+        self._chk(self.lib.awsm_host_set_render_timings(self.h, 1 if enabled else 0), "set_render_timings")
 
     # ---- frame ----
     def update_transforms(self):

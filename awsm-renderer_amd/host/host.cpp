@@ -47,6 +47,7 @@ struct Backend {
     int (*resize)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t) = nullptr;
     int (*set_shard_rows)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
     int (*set_shard_bands)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t) = nullptr;
+    int (*set_stage_timers)(AwsmHipCtx*, int) = nullptr;
     int (*pick)(AwsmHipCtx*, int32_t, int32_t, AwsmPick*) = nullptr;
     int (*texture_array_upload)(AwsmHipCtx*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, AwsmTexFormat, const void*) = nullptr;
     int (*texture_array_generate_mips)(AwsmHipCtx*, uint32_t, const uint32_t*) = nullptr;
@@ -463,7 +464,7 @@ int awsm_host_create(const char* backend_path, int device, void* stream, uint32_
     bool ok = load_sym(h.get(), b.create, "awsm_hip_create") && load_sym(h.get(), b.destroy, "awsm_hip_destroy") &&
               load_sym(h.get(), b.last_error, "awsm_hip_last_error") && load_sym(h.get(), b.abi_version, "awsm_hip_abi_version") &&
               load_sym(h.get(), b.buffer_create, "awsm_hip_buffer_create") && load_sym(h.get(), b.buffer_write, "awsm_hip_buffer_write") &&
-              load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") && load_sym(h.get(), b.set_shard_bands, "awsm_hip_set_shard_bands") && load_sym(h.get(), b.pick, "awsm_hip_pick") &&
+              load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") && load_sym(h.get(), b.set_shard_bands, "awsm_hip_set_shard_bands") && load_sym(h.get(), b.set_stage_timers, "awsm_hip_set_stage_timers") && load_sym(h.get(), b.pick, "awsm_hip_pick") &&
               load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.texture_array_generate_mips, "awsm_hip_texture_array_generate_mips") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
               load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
               load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") && load_sym(h.get(), b.transparent_pass, "awsm_hip_transparent_pass") &&
@@ -894,6 +895,7 @@ int awsm_host_pick(AwsmHost* h, int32_t x, int32_t y, uint32_t* hit, uint64_t* m
     *mesh_key = p.valid ? (((uint64_t)p.mesh_key_high << 32) | p.mesh_key_low) : 0;   // KeyData::from_ffi
     return AWSM_OK;
 }
+int awsm_host_set_render_timings(AwsmHost* h, int enabled) { int rc = h->be.set_stage_timers(h->ctx, enabled); return rc ? dev_fail(h, rc, "set_stage_timers") : AWSM_OK; }
 int awsm_host_set_shard_bands(AwsmHost* h, uint32_t n, uint32_t r, uint32_t compact) { int rc = h->be.set_shard_bands(h->ctx, n, r, compact); return rc ? dev_fail(h, rc, "set_shard_bands") : AWSM_OK; }
 
 // ------------------------------------------------------------------------------------------------ frame

@@ -231,7 +231,7 @@ def main():
         torch.cuda.synchronize()
 
     first = r.render(sync=True)            # uploads everything, sizes the bin list
-    dev.set_stage_timers(bool(os.environ.get("AWSM_BENCH_STAGE_TIMERS")))   # the timed loop does not read per-stage times: no event bubbles between the kernels
+    r.host.set_render_timings(bool(os.environ.get("AWSM_BENCH_STAGE_TIMERS")))   # the timed loop does not read per-stage times: no event bubbles between the kernels
     for _ in range(args.warmup):
         step()
     barrier()
@@ -269,7 +269,7 @@ def main():
             raise SystemExit(f"rank {rank}: gathered image differs from the unsharded frame")
 
     # ---- per-kernel launch durations: hipEvents recorded by the library on the kernels' own stream ----
-    dev.set_stage_timers(True)
+    r.host.set_render_timings(True)
     acc = {}
     for _ in range(max(1, args.profile_frames)):
         r.host.camera_update(scene.view, scene.proj, scene.camera_position)

@@ -139,6 +139,9 @@ int awsm_host_mesh_append_instances(AwsmHost* h, AwsmKey mesh, const float* trs1
 /* AwsmRenderer::pick (picker.rs:55-121): *hit = 1 and *mesh_key = the MeshKey (KeyData::as_ffi) under pixel (x, y) of the last frame, else *hit = 0 */
 int awsm_host_pick(AwsmHost* h, int32_t x, int32_t y, uint32_t* hit, uint64_t* mesh_key);
 int awsm_host_set_shard_bands(AwsmHost* h, uint32_t n, uint32_t r, uint32_t compact_output);   /* awsm_hip_set_shard_bands */
+/* AwsmRendererLogging.render_timings (debug.rs:8-12; the spans of render.rs:150-320): per-stage times in the frame stats, on by default;
+ * off = awsm_hip_set_stage_timers(ctx, 0), the ms_* fields of the stats read 0 and the frame loses its event bubbles */
+int awsm_host_set_render_timings(AwsmHost* h, int enabled);
 
 /* ---- frame: update_all (update.rs:8-18) + AwsmRenderer::render (render.rs:53-383, hot path only) ---- */
 int awsm_host_update_transforms(AwsmHost* h);

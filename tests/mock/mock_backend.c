@@ -39,6 +39,7 @@ int awsm_hip_texture_array_generate_mips(AwsmHipCtx* c, uint32_t idx, const uint
 int awsm_hip_texture_array_read_level(AwsmHipCtx* c, uint32_t idx, uint32_t level, void* out) { (void)c; (void)idx; (void)level; (void)out; return AWSM_ERR_UNSUPPORTED; }
 int awsm_hip_pick(AwsmHipCtx* c, int32_t x, int32_t y, AwsmPick* out) { logc(c, 13, 0, (uint32_t)x, (uint32_t)y); out->valid = 0; out->mesh_key_high = 0; out->mesh_key_low = 0; out->triangle_index = 0xFFFFFFFFu; return 0; }
 int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t compact) { logc(c, 12, (int)compact, n, r); return 0; }
+int awsm_hip_set_stage_timers(AwsmHipCtx* c, int enabled) { logc(c, 16, 0, (uint64_t)(enabled != 0), 0); return 0; }
 int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t idx, uint32_t w, uint32_t h, uint32_t layers, uint32_t mips, AwsmTexFormat fmt, const void* t) {
     (void)mips; (void)fmt; (void)t; logc(c, 4, (int)idx, ((uint64_t)w << 32) | h, layers); return 0;
 }

@@ -15,7 +15,7 @@ from tests import helpers
 
 MOCK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock")
 MOCK = os.path.join(MOCK_DIR, "libmock_backend.so")
-OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips", 15: "transparent"}
+OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips", 15: "transparent", 16: "stage_timers"}
 
 
 @pytest.fixture(scope="module")
@@ -241,6 +241,9 @@ def test_pick_and_band_sharding_pass_through(mock):
     mock.mock_log_clear(r.host.device_ctx)
     assert r.host.pick(12, 34) is None
     r.host.set_shard_bands(4, 3, compact_output=True)
+    r.host.set_render_timings(False)          # AwsmRendererLogging.render_timings -> awsm_hip_set_stage_timers
+    r.host.set_render_timings(True)
     log = log_of(mock, r.host.device_ctx)
     assert ("pick", 0, 12, 34) in log and ("shard_bands", 1, 4, 3) in log
+    assert [e for e in log if e[0] == "stage_timers"] == [("stage_timers", 0, 0, 0), ("stage_timers", 0, 1, 0)]
     r.close()
