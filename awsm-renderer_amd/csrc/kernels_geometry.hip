@@ -262,8 +262,9 @@ AWSM_DI bool bin_tile_hit(const FrameDev& f, const TriSetup& t, int ntiles, int 
 }
 
 // kBinBatches x 256 consecutive triangles per workgroup: the more triangles share one LDS window, the fewer global
-// atomics reach the hot tiles (they serialise in L2).  Later phases re-read the 64-byte setup records (L2 hits) instead
-// of keeping kBinBatches setups in registers.
+// atomics reach the hot tiles (they serialise in L2).  With more than one batch the later phases re-read the setup records
+// (L2 hits); with one (the setting that measured best) the triangle stays in registers: the kernel is one wave of workgroups
+// deep, so its duration is the latency chain of a single workgroup and every dependent load shows.
 constexpr uint32_t kBinBatches = 1;
 
 template <bool FILL>
@@ -281,9 +282,10 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
 
     // ---- phase 0: setup (count pass) / load, window of the small triangles, big triangles walked by the wavefront ----
     uint32_t my_ok = 0;
+    BinTri keep;                                  // kBinBatches == 1: the triangle stays in registers for the later phases
     for (uint32_t j = 0; j < kBinBatches; j++) {
         const uint32_t r = r0 + j * 256u;
-        BinTri b;
+        BinTri& b = keep;
         bin_tri_load<!FILL>(f, r, b);
         my_ok += b.ok ? 1u : 0u;
         if (b.small) { atomicMin(&win[0], b.tx0); atomicMin(&win[1], b.ty0); atomicMax(&win[2], b.tx1); atomicMax(&win[3], b.ty1); }
@@ -312,8 +314,9 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     // ---- phase A, small triangles: histogram in LDS (or direct emission when the window is too large) ----
     for (uint32_t j = 0; j < kBinBatches; j++) {
         const uint32_t r = r0 + j * 256u;
-        BinTri b;
-        bin_tri_load<false>(f, r, b);
+        BinTri reload;
+        if (kBinBatches > 1) bin_tri_load<false>(f, r, reload);
+        const BinTri& b = kBinBatches > 1 ? reload : keep;
         if (b.small)
             for (int l = b.ty0; l <= b.ty1; l++)
                 for (int tx = b.tx0; tx <= b.tx1; tx++)
@@ -338,8 +341,9 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     // resolves visibility with a min over packed keys) ----
     for (uint32_t j = 0; j < kBinBatches; j++) {
         const uint32_t r = r0 + j * 256u;
-        BinTri b;
-        bin_tri_load<false>(f, r, b);
+        BinTri reload;
+        if (kBinBatches > 1) bin_tri_load<false>(f, r, reload);
+        const BinTri& b = kBinBatches > 1 ? reload : keep;
         if (b.small)
             for (int l = b.ty0; l <= b.ty1; l++)
                 for (int tx = b.tx0; tx <= b.tx1; tx++)
