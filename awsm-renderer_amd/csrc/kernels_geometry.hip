@@ -267,6 +267,24 @@ AWSM_DI bool bin_tile_hit(const FrameDev& f, const TriSetup& t, int ntiles, int 
 // deep, so its duration is the latency chain of a single workgroup and every dependent load shows.
 constexpr uint32_t kBinBatches = 1;
 
+// The triangles that cover more than 16 tiles: one wavefront per triangle, 64 tiles per step, block-stride over the list k_bin<count> built.
+template <bool FILL>
+AWSM_DI void bin_big_walk(const FrameDev& f, uint32_t block, uint32_t n_blocks) {
+    const uint32_t n_big = f.counters[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = block * 4u + (threadIdx.x >> 6), n_waves = n_blocks * 4u;
+    for (uint32_t i = wave; i < n_big; i += n_waves) {
+        const uint32_t r = f.big_list[i];
+        BinTri b;
+        bin_tri_load<false>(f, r, b);
+        for (int k = lane; k < b.ntiles; k += 64) {
+            const int l = b.ty0 + k / b.wdt, tx = b.tx0 + k % b.wdt;
+            if (bin_tile_hit(f, b.t, b.ntiles, tx, l)) bin_emit<FILL>(f, tx, l, r);
+        }
+    }
+}
+constexpr uint32_t kBinBigBlocks = 64;        // fill pass: the first workgroups of k_bin<true> walk the big triangles (no launch of their own)
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     __shared__ int win[4];                       // tile window of the workgroup's small triangles: x0, y0, x1, y1
@@ -275,7 +293,8 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     __shared__ uint32_t lbase[FILL ? kBinWindow : 1];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t r0 = blockIdx.x * (256u * kBinBatches) + tid;
+    if (FILL && blockIdx.x < kBinBigBlocks) { bin_big_walk<true>(f, blockIdx.x, kBinBigBlocks); return; }     // workgroup-uniform
+    const uint32_t r0 = (blockIdx.x - (FILL ? kBinBigBlocks : 0u)) * (256u * kBinBatches) + tid;
     const int lane = tid & 63;
     if (tid == 0) { win[0] = 0x7fffffff; win[1] = 0x7fffffff; win[2] = -1; win[3] = -1; n_ok = 0; }
     __syncthreads();
@@ -359,20 +378,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
 // in runs — whole workgroups of k_bin were nothing but such triangles and ran 3x longer than the rest of the grid).
 // One wavefront per triangle, 64 tiles per step, grid-stride over the list k_bin<count> built.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin_big(FrameDev f) {
-    const uint32_t n_big = f.counters[4];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-    for (uint32_t i = wave; i < n_big; i += n_waves) {
-        const uint32_t r = f.big_list[i];
-        BinTri b;
-        bin_tri_load<false>(f, r, b);
-        for (int k = lane; k < b.ntiles; k += 64) {
-            const int l = b.ty0 + k / b.wdt, tx = b.tx0 + k % b.wdt;
-            if (bin_tile_hit(f, b.t, b.ntiles, tx, l)) bin_emit<FILL>(f, tx, l, r);
-        }
-    }
-}
+__global__ __launch_bounds__(256) void k_bin_big(FrameDev f) { bin_big_walk<FILL>(f, blockIdx.x, gridDim.x); }
 
 // Exclusive scan of tile_count -> tile_offset (single workgroup; n_tiles is a few thousand), plus tile_order: the tile
 // ids sorted by log2(count), heaviest first.  Workgroups start in blockIdx order, so k_raster_tile begins with the
@@ -707,15 +713,15 @@ extern "C" void awsm_launch_bin_count(const awsm::FrameDev* f, hipStream_t s) {
 }
 extern "C" void awsm_launch_bin_big(const awsm::FrameDev* f, int fill, hipStream_t s) {
     if (!f->total_tris) return;
-    if (fill) hipLaunchKernelGGL(awsm::k_bin_big<true>, dim3(512), dim3(256), 0, s, *f);
-    else hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
+    if (fill) return;       // the fill pass walks them inside k_bin<true> (awsm_launch_bin_fill)
+    hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_bin_scan, dim3(1), dim3(1024), 0, s, *f, f->tiles_x * f->tiles_y);
 }
 extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;
-    if (nb) hipLaunchKernelGGL(awsm::k_bin<true>, dim3(nb), dim3(256), 0, s, *f);
+    if (nb) hipLaunchKernelGGL(awsm::k_bin<true>, dim3(nb + awsm::kBinBigBlocks), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
