@@ -349,7 +349,9 @@ int enqueue_opaque(AwsmHipCtx* c) {
     // geometry kernels — measured: a chain of dependent loads in one workgroup crawls while k_shade of the previous frame owns every CU,
     // and the geometry kernels queue behind it (1906 -> 1675 frames/s).  A scene write between the two passes falls back to the late order.
     const bool want_resolve = f.sy1 > f.sy0 && f.has_opaque;
-    const bool early = c->overlap && want_resolve && c->geometry_done && c->geom_write_seq[c->slot] == c->write_seq;
+    // (With stage timers on the late order stays: an event recorded right behind a cross-stream wait is stamped when the wait is
+    // consumed, not when it is satisfied, and ms_shade would include the tail of the raster kernel — seen: 0.40 instead of 0.36 ms.)
+    const bool early = c->overlap && !c->stage_timers && want_resolve && c->geometry_done && c->geom_write_seq[c->slot] == c->write_seq;
     if (early) {
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_uploads[c->slot], 0));
         awsm_launch_resolve_draws(c->scene_dev, &f, ss);
