@@ -71,4 +71,31 @@ for case in range(200):
         H.decode_image(blob)
     except H.HostError:
         pass
+# real JPEG / PNG streams (baseline and progressive; every scan type of jpeg.hpp) with bit flips and truncations
+try:
+    import io
+    from PIL import Image
+    yy, xx = np.mgrid[0:40, 0:56]
+    pic = np.stack([(xx * 4) % 256, (yy * 6) % 256, (xx * yy) % 256], axis=-1).astype(np.uint8)
+    streams = []
+    for kw in ({"format": "JPEG", "quality": 85, "subsampling": 2}, {"format": "JPEG", "quality": 85, "subsampling": 2, "progressive": True},
+               {"format": "JPEG", "quality": 95, "subsampling": 0, "progressive": True, "restart_marker_rows": 1}, {"format": "PNG"}):
+        b = io.BytesIO()
+        Image.fromarray(pic, "RGB").save(b, **kw)
+        streams.append(b.getvalue())
+    n_ok = n_bad = 0
+    for case in range(600):
+        blob = bytearray(streams[case % len(streams)])
+        for _ in range(int(rng.integers(1, 6))):
+            blob[int(rng.integers(2, len(blob)))] ^= 1 << int(rng.integers(0, 8))
+        if case % 5 == 0:
+            blob = blob[:int(rng.integers(4, len(blob)))]
+        try:
+            H.decode_image(bytes(blob))
+            n_ok += 1
+        except H.HostError:
+            n_bad += 1
+    print("corrupted images: decoded", n_ok, "refused", n_bad)
+except ImportError:
+    print("corrupted images: PIL not importable here, skipped")
 print("SANITIZE_OK")
