@@ -32,6 +32,7 @@ void awsm_launch_raster(const FrameDev* f, hipStream_t s);
 void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
+void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, unsigned long long* out, hipStream_t s);
 void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s);
 void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n, hipStream_t s);
 }
@@ -87,6 +88,7 @@ struct AwsmHipCtx {
     DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
     DevBuf out16, out32;
+    DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
 
@@ -606,7 +608,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
+    fr(c->lut); fr(c->digest); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -971,6 +973,20 @@ int awsm_hip_read_visibility(AwsmHipCtx* c, uint64_t* keys_out) {
     HIPCHK(c, hipSetDevice(c->device));
     { int rcs = sync_all(c); if (rcs) return rcs; }
     HIPCHK(c, hipMemcpy(keys_out, FB(c).vis.ptr, (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1) * 8, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_visibility_digest(AwsmHipCtx* c, uint64_t* out2) {
+    if (!c || !out2) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!FB(c).vis.ptr) return fail(c, AWSM_ERR_NOT_READY, "visibility_digest before resize");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dev_reserve(c, c->digest, 16);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->digest.ptr, 0, 16, c->stream));
+    awsm_launch_vis_digest((const unsigned long long*)FB(c).vis.ptr, (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1), (unsigned long long*)c->digest.ptr, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out2, c->digest.ptr, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return AWSM_OK;
 }
 

@@ -605,13 +605,16 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         // (min over packed keys, the same resolve as inside a tile) and writes the tile.  The slices run on different XCDs, whose L2s
         // are not coherent for plain stores, and a device-scope release / acquire fence costs a write-back + invalidate of the whole
         // L2 per wavefront (measured: the raster kernel 40 % slower).  So the scratch traffic itself is device-scope atomic — relaxed
-        // stores and loads that go through to memory (sc1) — ordered against the arrival counter by completion (s_waitcnt via the
-        // workgroup-scope fence) and the barrier; nothing else in the kernel needs to become visible.
+        // stores and loads that go through to memory (sc1).  Ordering against the arrival counter: EVERY storing wavefront drains its
+        // own stores (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes lane 0's counter add.  s_barrier waits for no
+        // memory counter and a workgroup-scope release fence emits no wait for vector stores on gfx950, so the wait is written out
+        // (inline asm: invisible to the pass that would otherwise drop a wait it believes redundant).  The slice whose add returns
+        // n_slices - 1 knows every other slice's stores have completed; its sc1 loads bypass its CU's L1.
         __shared__ uint32_t arrived;
         unsigned long long* mine = f.raster_scratch + (size_t)(slot0 + slice) * (kTile * kTile * S);
 #pragma unroll
         for (int i = 0; i < 4 * S; i++) __hip_atomic_store(mine + tid + i * 256, keys[tid + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) arrived = __hip_atomic_fetch_add(&f.tile_split[2u * tile + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -619,11 +622,11 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         for (uint32_t k = 0; k < n_slices; k++) {
             if (k == slice) continue;
             const unsigned long long* other = f.raster_scratch + (size_t)(slot0 + k) * (kTile * kTile * S);
+            unsigned long long v[4 * S];      // all loads of a slice in flight together, then the min
 #pragma unroll
-            for (int i = 0; i < 4 * S; i++) {
-                const unsigned long long v = __hip_atomic_load(other + tid + i * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v < keys[tid + i * 256]) keys[tid + i * 256] = v;
-            }
+            for (int i = 0; i < 4 * S; i++) v[i] = __hip_atomic_load(other + tid + i * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 4 * S; i++) if (v[i] < keys[tid + i * 256]) keys[tid + i * 256] = v[i];
         }
         __syncthreads();
     }

@@ -1620,6 +1620,20 @@ __global__ __launch_bounds__(256) void k_count_covered(const unsigned long long*
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
 }
 
+// Position-dependent 128-bit digest of the visibility keys (tests: a re-rendered frame must reproduce every key; comparing two
+// digests on the device costs 16 bytes of read-back instead of 66 MB per 4K frame).  out[0] += key * (2 i + 1), out[1] ^= rotl(key, i).
+__global__ __launch_bounds__(256) void k_vis_digest(const unsigned long long* __restrict__ vis, size_t n, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0ull, x = 0ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long k = vis[i];
+        const uint32_t r = (uint32_t)i & 63u;
+        s += k * (2ull * i + 1ull);
+        x ^= (k << r) | (r ? k >> (64u - r) : 0ull);
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); x ^= __shfl_down(x, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, s); atomicXor(out + 1, x); }
+}
+
 // picker_wgsl/compute.wgsl: one thread; out = {valid, mesh_key_high, mesh_key_low, triangle_index}
 __global__ void k_pick(const DevScene* __restrict__ sc, FrameDev f, int x, int y, uint32_t* __restrict__ out) {
     out[0] = 0u; out[1] = 0u; out[2] = 0u; out[3] = 0xFFFFFFFFu;
@@ -1673,6 +1687,9 @@ extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameD
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
     if (f->sy1 > f->sy0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->sy0, f->sy1, f->band_n, f->band_r, f->msaa, f->counters + 3);
+}
+extern "C" void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, unsigned long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_vis_digest, dim3(1024), dim3(256), 0, s, vis, n, out);
 }
 extern "C" void awsm_launch_pick(const awsm::DevScene* sc, const awsm::FrameDev* f, int x, int y, uint32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_pick, dim3(1), dim3(1), 0, s, sc, *f, x, y, out);

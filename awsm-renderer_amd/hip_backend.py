@@ -29,7 +29,7 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
-           "awsm_hip_read_transformed_forward"]
+           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest"]
 
 
 class AwsmConfig(C.Structure):
@@ -107,6 +107,7 @@ def load_library():
     lib.awsm_hip_brdf_lut_generate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.awsm_hip_read_brdf_lut.argtypes = [C.c_void_p, C.c_void_p]
     lib.awsm_hip_read_visibility.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_visibility_digest.argtypes = [C.c_void_p, C.c_void_p]
     lib.awsm_hip_read_visibility_unpacked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.awsm_hip_read_opaque.argtypes = [C.c_void_p, C.c_void_p]
     lib.awsm_hip_read_opaque_f32.argtypes = [C.c_void_p, C.c_void_p]
@@ -296,6 +297,12 @@ class HipDevice:
         out = np.zeros(self._vis_shape(), dtype=np.uint64)
         self._chk(self.lib.awsm_hip_read_visibility(self.ctx, out.ctypes.data_as(C.c_void_p)), "read_visibility")
         return out
+
+    def visibility_digest(self):
+        """(sum key_i * (2 i + 1) mod 2^64, xor rotl(key_i, i mod 64)) of the last geometry pass's keys, computed on the device."""
+        out = np.zeros(2, dtype=np.uint64)
+        self._chk(self.lib.awsm_hip_visibility_digest(self.ctx, out.ctypes.data_as(C.c_void_p)), "visibility_digest")
+        return int(out[0]), int(out[1])
 
     def read_visibility_unpacked(self):
         tri = np.zeros(self._vis_shape(), dtype=np.uint32)

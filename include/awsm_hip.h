@@ -255,6 +255,10 @@ void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
  * unpack gives the reference's visibility_data texel: triangle_index (primitive-local) and
  * material_mesh_meta_offset, plus the Depth32Float value. ---- */
 int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
+/* 128-bit position-dependent digest of the keys the last geometry pass left (the caller's stream; synchronous):
+ * out2[0] = sum key_i * (2 i + 1) mod 2^64, out2[1] = xor rotl(key_i, i mod 64).  For tests that compare many frames
+ * without reading 8 bytes per pixel back. */
+int awsm_hip_visibility_digest(AwsmHipCtx* ctx, uint64_t* out2);
 int awsm_hip_read_visibility_unpacked(AwsmHipCtx* ctx, uint32_t* tri_id_out, uint32_t* meta_off_out, float* depth_out);
 int awsm_hip_read_opaque(AwsmHipCtx* ctx, uint16_t* rgba16f_out);
 /* the image after the transparent pass == the reference's `composite` render texture (render_textures.rs:49-54; what the

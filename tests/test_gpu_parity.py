@@ -257,6 +257,47 @@ def test_full_size_4k_frame_properties(oracle_lut):
     dev.close()
 
 
+def _digest_of(keys):
+    k = keys.reshape(-1).astype(np.uint64)
+    i = np.arange(k.size, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        s = int((k * (np.uint64(2) * i + np.uint64(1))).sum(dtype=np.uint64))
+        r = i & np.uint64(63)
+        x = int(np.bitwise_xor.reduce((k << r) | np.where(r != 0, k >> ((np.uint64(64) - r) & np.uint64(63)), np.uint64(0))))
+    return s, x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [0, 4])
+def test_split_tile_handoff_is_stable_over_500_frames(msaa, oracle_lut):
+    """k_raster_tile hands partial tiles of lists longer than 256 triangles between workgroups on different XCDs (sc1 scratch stores,
+    every storing wavefront's s_waitcnt vmcnt(0), barrier, arrival counter; the last arriver folds the slices).  geometry/render_pass.rs:51-157:
+    every draw's fragments land, every frame.  500 geometry passes of the 4K atrium (it has tiles with > 256 distinct visible triangles,
+    test_full_size_4k_frame_properties) must reproduce frame 0's key buffer exactly; compared through a device-side digest, which is itself
+    checked against the keys read back."""
+    sc = scenes.atrium_scene(3840, 2160, tex_scale=1 / 16)      # the geometry of BASELINE configs[3]; textures play no part here
+    model = helpers.build_model(sc)
+    dev, _ = helpers.hip_frame(model, oracle_lut, msaa=msaa)
+    keys = dev.read_visibility()
+    k0 = keys[..., 0] if msaa == 4 else keys
+    ranks = (k0[:2144] & np.uint64(0xFFFFFFFF)).astype(np.uint32).reshape(67, 32, 120, 32).transpose(0, 2, 1, 3).reshape(67, 120, 1024)
+    srt = np.sort(ranks, axis=2)
+    assert int((1 + (srt[:, :, 1:] != srt[:, :, :-1]).sum(axis=2)).max()) > 256        # some tile's list is certainly split
+    d0 = dev.visibility_digest()
+    assert d0 == _digest_of(keys)
+    draws = model.collect_draws()
+    bad = []
+    for i in range(500):
+        dev.geometry_pass(draws)
+        d = dev.visibility_digest()
+        if d != d0:
+            bad.append(i)
+    stats = dev.frame_end()
+    dev.close()
+    assert not bad, f"{len(bad)} of 500 frames differ from frame 0 (first: {bad[:5]})"
+    assert stats["bin_overflow_retries"] == 0
+
+
 # ------------------------------------------------------------------------------------------------ MSAA x4 (the reference's default AntiAliasing)
 def _check_msaa(scene, lut):
     model = helpers.build_model(scene)
