@@ -53,6 +53,7 @@ struct FrameBufs {
     uint32_t frag_cap = 0;
     DevBuf tex_slots;                      // n_draws x kCoreTextures TexSlotDev (k_resolve_draws)
     DevBuf draw_mat;                       // n_draws DrawMatDev (k_resolve_draws)
+    DevBuf tri_shade, draw_lean;           // geometry pass: per-triangle attribute offsets (k_deform_transform), per-draw lean records (k_resolve_draws)
     DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
     DevBuf camera;                         // snapshot of the camera UBO taken by the geometry pass (overlap mode)
     DevBuf tile_split, raster_scratch;     // split raster tiles: per-tile {first scratch slot, slices done}; partial tiles (geometry pass only)
@@ -89,6 +90,7 @@ struct AwsmHipCtx {
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
     DevBuf out16, out32;
     DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
+    DevBuf shade_todo;                // [0] count + entries: the 16x4-pixel groups the lean opaque kernel leaves to the general one
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
 
@@ -272,6 +274,13 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->draw_mat = (DrawMatDev*)FB(c).draw_mat.ptr;
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
+    // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo.ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+                         c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
+    f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
+    f->draw_lean = lean_ok ? (LeanDrawDev*)FB(c).draw_lean.ptr : nullptr;
+    f->shade_todo = (uint32_t*)c->shade_todo.ptr;
+    f->shade_todo_cap = c->shade_todo.ptr ? (uint32_t)(c->shade_todo.size / 4 - 4) : 0u;
     f->tri_rec = (TriRec*)FB(c).tri_rec.ptr;
     f->tile_count = (uint32_t*)FB(c).tile_count.ptr; f->tile_offset = (uint32_t*)FB(c).tile_offset.ptr;
     f->tile_cursor = (uint32_t*)FB(c).tile_cursor.ptr; f->bin_list = (uint32_t*)FB(c).bin_list.ptr;
@@ -387,6 +396,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->draw_mat = (DrawMatDev*)t.draw_mat.ptr;
     f->clip = (float4*)t.clip.ptr; f->nrm = (float4*)t.nrm.ptr; f->tan = (float4*)t.tan.ptr; f->wpos = (float4*)t.wpos.ptr;
     f->tri_info = (uint32_t*)t.tri_flags.ptr;
+    f->tri_shade = nullptr; f->draw_lean = nullptr; f->shade_todo = nullptr; f->shade_todo_cap = 0;     // the opaque pass's lean route only
     f->tri_rec = (TriRec*)t.tri_rec.ptr;
     f->tile_count = (uint32_t*)t.tile_count.ptr; f->tile_offset = (uint32_t*)t.tile_offset.ptr;
     f->tile_cursor = (uint32_t*)t.tile_cursor.ptr; f->bin_list = (uint32_t*)t.bin_list.ptr;
@@ -512,6 +522,8 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
     if ((rc = dev_reserve(c, b.tan, nv * 16))) return rc;
     if (forward && (rc = dev_reserve(c, b.wpos, nv * 16))) return rc;
     if ((rc = dev_reserve(c, b.tri_flags, nt * 4))) return rc;
+    if (!forward && (rc = dev_reserve(c, b.tri_shade, nt * 16))) return rc;
+    if (!forward && (rc = dev_reserve(c, b.draw_lean, nd * sizeof(LeanDrawDev)))) return rc;
     if ((rc = dev_reserve(c, b.big_list, nt * 4))) return rc;
     if ((rc = dev_reserve(c, b.tri_rec, nt * kTriRecBytes))) return rc;
     const uint32_t tiles_x = (c->width + kTile - 1) / kTile, tiles_y_full = (c->height + kTile - 1) / kTile;
@@ -608,10 +620,10 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->digest); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
+    fr(c->lut); fr(c->digest); fr(c->shade_todo); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
-        fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
+        fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
@@ -679,6 +691,7 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     }
     if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
     c->msaa = msaa;
+    if ((rc = dev_realloc(c, c->shade_todo, ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
     if ((rc = dev_realloc(c, c->out16, px * 8, true))) return rc;
     if (c->flags & AWSM_CFG_PARITY_TAP) { if ((rc = dev_realloc(c, c->out32, px * 16, true))) return rc; }
     c->width = width; c->height = height;

@@ -71,6 +71,21 @@ struct DrawMatDev {
 };
 static_assert(sizeof(DrawMatDev) == 64, "DrawMatDev must be 64 bytes");
 
+// A draw the lean opaque kernel (k_shade_lean) can shade, in 96 bytes (six 16-byte loads instead of the 21 of DrawShadeDev +
+// DrawMatDev + five TexSlotDev): a PBR material with no optional block and no debug view, not a hud mesh, every core texture it
+// has on TEXCOORD_0 with an identity transform, a repeat / repeat linear sampler and power-of-two extent.  k_resolve_draws decides
+// (flags bit 0); draws that do not qualify keep the general route.
+struct LeanDrawDev {
+    uint32_t flags;               // bit 0: lean; bits 8..12: which of the five core textures exist
+    float metallic, roughness, normal_scale;
+    float base_color[3]; float occlusion_strength;
+    float emissive[3];            // factor * emissive_strength
+    uint32_t pad0;
+    uint32_t tex[kCoreTextures][2];   // level-0 texels of the layer: address bits 0..31 | address bits 32..47, log2(width) << 16, log2(height) << 20
+    uint32_t pad1[2];
+};
+static_assert(sizeof(LeanDrawDev) == 96, "LeanDrawDev must be 96 bytes");
+
 constexpr int kMaxMipLevels = 16;
 struct TexArrayDev {
     const uint8_t* texels;            // [level][layer][h_l][w_l] RGBA8, (w >> l).max(1); levels >= 1 valid after generate_mips
@@ -123,6 +138,11 @@ struct FrameDev {
     float4* wpos;                 // total_verts  (world position xyz, 1): transparent pass only, else null
     TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)
     uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..30, bit 31: ALPHA_MODE_MASK draw — transparent pass)
+    uint4* tri_shade;             // total_tris   (geometry pass only, may be null: {info word, byte offset of TEXCOORD_0 of corner 0 / 1 / 2 in the attribute data}:
+                                  //               what compute.wgsl:182-197 derives per pixel from meta -> indices, once per triangle; k_deform_transform)
+    LeanDrawDev* draw_lean;       // n_draws (k_resolve_draws); null = the lean route is off for this frame
+    uint32_t* shade_todo;         // [0] = count, [4 ..] = (block id << 2 | wavefront) of the 16x4-pixel groups k_shade_lean left to the general kernel
+    uint32_t shade_todo_cap;
     // binning
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1

@@ -175,7 +175,24 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
     if (FWD) f.wpos[gv] = make_float4(world_pos.x, world_pos.y, world_pos.z, 1.0f);
     // transparent pass: bit 31 = the draw's material is ALPHA_MODE_MASK (k_resolve_draws ran before this kernel), so the coverage walk
     // learns it from the word it loads anyway instead of a second dependent load per triangle
-    if (lv % 3u == 0u) f.tri_info[d.first_tri + lv / 3u] = lo | ((d.flags & 0x7Fu) << 24) /* 0x80 = kDrawInstanced, internal */ | ((FWD && (f.draw_shade[lo].flags & 2u)) ? 0x80000000u : 0u);
+    if (lv % 3u == 0u) {
+        const uint32_t info = lo | ((d.flags & 0x7Fu) << 24) /* 0x80 = kDrawInstanced, internal */ | ((FWD && (f.draw_shade[lo].flags & 2u)) ? 0x80000000u : 0u);
+        f.tri_info[d.first_tri + lv / 3u] = info;
+        if (!FWD && f.tri_shade) {
+            // compute.wgsl:182-197 + texture_uvs.wgsl:64-84, once per triangle instead of once per pixel: where each corner's TEXCOORD_0 lives.
+            // Byte offsets into the attribute data (the reference's offsets are u32 as well).
+            uint4 ts = make_uint4(info, 0u, 0u, 0u);
+            if (sc->buf[AWSM_BUF_MATERIAL_META] && sc->buf[AWSM_BUF_ATTR_INDEX]) {
+                const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(gmp[9] / 256u) * 256u);
+                const uint32_t* ai = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + mm[9] / 4u + lv;       // 3 * triangle == lv
+                const uint32_t data_word = mm[10] / 4u, stride_words = mm[11] / 4u, uv0 = mm[12];
+                ts.y = (data_word + ai[0] * stride_words + uv0) * 4u;
+                ts.z = (data_word + ai[1] * stride_words + uv0) * 4u;
+                ts.w = (data_word + ai[2] * stride_words + uv0) * 4u;
+            }
+            f.tri_shade[d.first_tri + lv / 3u] = ts;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,10 @@
 #include "frame_params.hpp"
 #include "raster_setup.hpp"
 
+#ifndef AWSM_LEAN_WAVES
+#define AWSM_LEAN_WAVES 6
+#endif
+
 namespace awsm {
 
 // ================================================================================================
@@ -32,19 +36,15 @@ struct GBufferTexel {
 // A key in the visibility buffer means the triangle's setup record is valid; its edge coefficients are the bits the
 // raster kernel used.
 template <bool DERIVS>
-AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int cx, int cy) {
+AWSM_DI GBufferTexel reconstruct_core(const TriSetup& t, float4 n0, float4 n1, float4 n2, float4 t0, float4 t1, float4 t2, int cx, int cy) {
     GBufferTexel g;
     g.bary_derivs = {0.0f, 0.0f, 0.0f, 0.0f};
-    TriSetup t;
-    tri_rec_load(f.tri_rec + rank, t);
     const double Xc = sample_coord((cx << 8) + 128), Yc = sample_coord((cy << 8) + 128);
     const EdgeVals ev = tri_edges_d(t, Xc, Yc);
     // screen-space edge weights -> perspective-correct barycentrics: one IEEE reciprocal, six products
     const float e0 = (float)ev.E[0] * t.iw[0], e1 = (float)ev.E[1] * t.iw[1], e2 = (float)ev.E[2] * t.iw[2];
     const float inv_esum = 1.0f / ((e0 + e1) + e2);
     const float b0 = e0 * inv_esum, b1 = e1 * inv_esum, b2 = e2 * inv_esum;
-    const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
-    const float4 t0 = f.tan[(size_t)rank * 3], t1 = f.tan[(size_t)rank * 3 + 1], t2 = f.tan[(size_t)rank * 3 + 2];
     const f3 Ni = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y, (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
     const f4 Ti = {(b0 * t0.x + b1 * t1.x) + b2 * t2.x, (b0 * t0.y + b1 * t1.y) + b2 * t2.y,
                    (b0 * t0.z + b1 * t1.z) + b2 * t2.z, (b0 * t0.w + b1 * t1.w) + b2 * t2.w};
@@ -66,6 +66,14 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
         g.bary_derivs = {round_f16(ddx0), round_f16(ddy0), round_f16(ddx1), round_f16(ddy1)};
     }
     return g;
+}
+template <bool DERIVS>
+AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int cx, int cy) {
+    TriSetup t;
+    tri_rec_load(f.tri_rec + rank, t);
+    const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
+    const float4 t0 = f.tan[(size_t)rank * 3], t1 = f.tan[(size_t)rank * 3 + 1], t2 = f.tan[(size_t)rank * 3 + 2];
+    return reconstruct_core<DERIVS>(t, n0, n1, n2, t0, t1, t2, cx, cy);
 }
 
 // ---- MSAA edge predicates (helpers/msaa.wgsl), STRICT: a decision that flips between implementations would swap a
@@ -626,70 +634,8 @@ AWSM_DI void store_pixel(const FrameDev& f, size_t p, f4 c) {
     if (f.out_rgba32f) reinterpret_cast<float4*>(f.out_rgba32f)[p] = make_float4(c.x, c.y, c.z, c.w);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_resolve_draws: one thread per draw.  Follows geometry meta -> material mesh meta once per frame
-// (compute.wgsl:171-181 does it per pixel) and leaves the per-draw constants of the opaque pass in one 32-byte record.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restrict__ sc, FrameDev f) {
-    const uint32_t d = blockIdx.x * 256u + threadIdx.x;
-    // Per-light constants, once per frame instead of once per pixel and light (lights.wgsl:70-118 recomputes them in every invocation):
-    // the unit vector towards a directional light / the unit axis of a spot, and colour * intensity.
-    if (f.lights_pre && sc->buf[AWSM_BUF_LIGHTS_INFO] && sc->buf[AWSM_BUF_LIGHTS]) {
-        const uint32_t n_lights = min(*reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]), f.lights_cap);
-        const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
-        for (uint32_t i = d; i < n_lights; i += gridDim.x * 256u) {
-            const float4 dir_inner = lights[i * 4 + 1], color_intensity = lights[i * 4 + 2], kind_outer = lights[i * 4 + 3];
-            const uint32_t kind = (uint32_t)kind_outer.x;
-            f3 v = {dir_inner.x, dir_inner.y, dir_inner.z};
-            if (kind == 1u) v = fm::fsafe_normalize(-v);          // towards the light
-            else v = fm::fnormalize(v);                           // spot axis (unused for point lights)
-            f.lights_pre[i * 2] = make_float4(v.x, v.y, v.z, kind_outer.x);
-            f.lights_pre[i * 2 + 1] = make_float4(color_intensity.x * color_intensity.w, color_intensity.y * color_intensity.w, color_intensity.z * color_intensity.w, 0.0f);
-        }
-    }
-    // eight threads per draw: roles 0..4 resolve one core texture each, role 5 the per-draw records
-    const uint32_t draw = d >> 3, role = d & 7u;
-    if (draw >= f.n_draws || role > 5u) return;
-    const DrawDev dr = f.draws[draw];
-    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
-    const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
-    const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
-    const uint32_t material_word = mm[6] / 4u, b = material_word + 1u;
-    const uint32_t shader_id = M[material_word];
-    const bool unlit = shader_id == 2u;
-    if (role == 5u) {
-        DrawShadeDev o;
-        o.first_tri = dr.first_tri;
-        o.material_word = material_word;
-        o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
-        o.uv_sets_index = mm[12];
-        // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments, so their depth write waits for the shading)
-        o.flags = (mm[16] & 1u) | (M[b] == 1u ? 2u : 0u);
-        o.color_sets = mm[14];
-        f.draw_shade[draw] = o;
-        DrawMatDev m;
-        for (int j = 0; j < 4; j++) m.base_color[j] = mf(M, b + 7 + j);
-        m.shader_alpha = shader_id | (M[b] << 8);
-        m.alpha_cutoff = mf(M, b + 1);
-        m.ext_mask = 0u; m.debug_bitmask = 0u; m.ior = 1.5f;
-        m.metallic = 0.0f; m.roughness = 0.0f; m.normal_scale = 1.0f; m.occlusion_strength = 1.0f;
-        if (unlit) {
-            for (int j = 0; j < 3; j++) m.emissive[j] = mf(M, b + 16 + j);
-        } else {
-            m.metallic = mf(M, b + 16); m.roughness = mf(M, b + 17); m.normal_scale = mf(M, b + 23); m.occlusion_strength = mf(M, b + 29);
-            m.debug_bitmask = M[b + 38];
-            const uint32_t fi = b + 39u;
-            for (int j = 0; j < 12; j++) if (M[fi + j] != 0u) m.ext_mask |= 1u << j;
-            const float strength = M[fi + 1] != 0u ? mf(M, b + M[fi + 1]) : 1.0f;
-            for (int j = 0; j < 3; j++) m.emissive[j] = mf(M, b + 35 + j) * strength;
-            if (M[fi + 2] != 0u) m.ior = mf(M, b + M[fi + 2]);
-        }
-        f.draw_mat[draw] = m;
-        return;
-    }
-    // one of the five core textures of the draw's material, ready to sample (TexSlotDev)
-    const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
-    const int k = (int)role;
+// One of the five core textures of a draw's material, ready to sample (TexSlotDev).  words = the TextureInfo word index of each.
+AWSM_DI TexSlotDev resolve_tex_slot(const DevScene* __restrict__ sc, const uint32_t* __restrict__ M, const uint32_t (&words)[kCoreTextures], int k, bool unlit) {
     TexSlotDev s;
     s.base = nullptr; s.width = 0u; s.height = 0u; s.flags = 0u; s.layer_levels = 0u; s.level_off = nullptr; s.array_base = nullptr;
     for (int j = 0; j < 6; j++) s.tt[j] = 0.0f;
@@ -721,6 +667,110 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
             if (!ok) s.flags |= 4u;
         }
     }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve_draws: one thread per draw.  Follows geometry meta -> material mesh meta once per frame
+// (compute.wgsl:171-181 does it per pixel) and leaves the per-draw constants of the opaque pass in one 32-byte record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restrict__ sc, FrameDev f) {
+    const uint32_t d = blockIdx.x * 256u + threadIdx.x;
+    // Per-light constants, once per frame instead of once per pixel and light (lights.wgsl:70-118 recomputes them in every invocation):
+    // the unit vector towards a directional light / the unit axis of a spot, and colour * intensity.
+    if (f.lights_pre && sc->buf[AWSM_BUF_LIGHTS_INFO] && sc->buf[AWSM_BUF_LIGHTS]) {
+        const uint32_t n_lights = min(*reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO]), f.lights_cap);
+        const float4* lights = reinterpret_cast<const float4*>(sc->buf[AWSM_BUF_LIGHTS]);
+        for (uint32_t i = d; i < n_lights; i += gridDim.x * 256u) {
+            const float4 dir_inner = lights[i * 4 + 1], color_intensity = lights[i * 4 + 2], kind_outer = lights[i * 4 + 3];
+            const uint32_t kind = (uint32_t)kind_outer.x;
+            f3 v = {dir_inner.x, dir_inner.y, dir_inner.z};
+            if (kind == 1u) v = fm::fsafe_normalize(-v);          // towards the light
+            else v = fm::fnormalize(v);                           // spot axis (unused for point lights)
+            f.lights_pre[i * 2] = make_float4(v.x, v.y, v.z, kind_outer.x);
+            f.lights_pre[i * 2 + 1] = make_float4(color_intensity.x * color_intensity.w, color_intensity.y * color_intensity.w, color_intensity.z * color_intensity.w, 0.0f);
+        }
+    }
+    // eight threads per draw: roles 0..4 resolve one core texture each, role 5 the per-draw records
+    if (d == 0u && f.shade_todo) f.shade_todo[0] = 0u;      // the list k_shade_lean leaves for k_shade_todo (same stream, this frame)
+    const uint32_t draw = d >> 3, role = d & 7u;
+    if (draw >= f.n_draws || role > 6u) return;
+    const DrawDev dr = f.draws[draw];
+    const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
+    const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
+    const uint32_t* M = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIALS]);
+    const uint32_t material_word = mm[6] / 4u, b = material_word + 1u;
+    const uint32_t shader_id = M[material_word];
+    const bool unlit = shader_id == 2u;
+    const uint32_t words[kCoreTextures] = {b + 2u, b + 11u, b + 18u, b + 24u, b + 30u};
+    if (role == 6u) {   // the lean route's record (LeanDrawDev)
+        if (!f.draw_lean) return;
+        LeanDrawDev L;
+        L.flags = 0u; L.pad0 = 0u; L.pad1[0] = 0u; L.pad1[1] = 0u;
+        L.metallic = 0.0f; L.roughness = 0.0f; L.normal_scale = 1.0f; L.occlusion_strength = 1.0f;
+        for (int j = 0; j < 3; j++) { L.base_color[j] = 0.0f; L.emissive[j] = 0.0f; }
+        for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; }
+        bool lean = shader_id == 1u && (mm[16] & 1u) == 0u && M[b + 38] == 0u;     // PBR, not a hud mesh, no debug view
+        if (lean) {
+            const uint32_t fi = b + 39u;
+            for (int j = 0; j < 12; j++) if (M[fi + j] != 0u) lean = false;      // no optional block
+        }
+        if (lean) {
+            uint32_t exists = 0u;
+            for (int k = 0; k < kCoreTextures && lean; k++) {
+                const TexSlotDev s = resolve_tex_slot(sc, M, words, k, false);
+                if (!(s.flags & 1u)) continue;
+                const unsigned long long addr = (unsigned long long)s.base;
+                const bool identity = s.tt[0] == 1.0f && s.tt[1] == 0.0f && s.tt[2] == 0.0f && s.tt[3] == 1.0f && s.tt[4] == 0.0f && s.tt[5] == 0.0f;
+                if ((s.flags & 6u) != 2u || (s.flags >> 24) != 0u || !identity || s.width > 32768u || s.height > 32768u || (addr >> 48) != 0ull || (addr & 3ull) != 0ull) { lean = false; break; }
+                exists |= 1u << k;
+                L.tex[k][0] = (uint32_t)addr;
+                L.tex[k][1] = (uint32_t)(addr >> 32) | ((uint32_t)(31 - __clz((int)s.width)) << 16) | ((uint32_t)(31 - __clz((int)s.height)) << 20);
+            }
+            if (lean) {
+                L.flags = 1u | (exists << 8);
+                L.metallic = mf(M, b + 16); L.roughness = mf(M, b + 17); L.normal_scale = mf(M, b + 23); L.occlusion_strength = mf(M, b + 29);
+                const float strength = M[b + 39u + 1u] != 0u ? mf(M, b + M[b + 39u + 1u]) : 1.0f;    // (no optional block: 1)
+                for (int j = 0; j < 3; j++) { L.base_color[j] = mf(M, b + 7 + j); L.emissive[j] = mf(M, b + 35 + j) * strength; }
+            }
+        }
+        if (!(L.flags & 1u)) for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; }
+        f.draw_lean[draw] = L;
+        return;
+    }
+    if (role == 5u) {
+        DrawShadeDev o;
+        o.first_tri = dr.first_tri;
+        o.material_word = material_word;
+        o.attr_indices_word = mm[9] / 4u; o.attr_data_word = mm[10] / 4u; o.stride_words = mm[11] / 4u;
+        o.uv_sets_index = mm[12];
+        // bit 0: hud mesh; bit 1: ALPHA_MODE_MASK material (the transparent pass may discard its fragments, so their depth write waits for the shading)
+        o.flags = (mm[16] & 1u) | (M[b] == 1u ? 2u : 0u);
+        o.color_sets = mm[14];
+        f.draw_shade[draw] = o;
+        DrawMatDev m;
+        for (int j = 0; j < 4; j++) m.base_color[j] = mf(M, b + 7 + j);
+        m.shader_alpha = shader_id | (M[b] << 8);
+        m.alpha_cutoff = mf(M, b + 1);
+        m.ext_mask = 0u; m.debug_bitmask = 0u; m.ior = 1.5f;
+        m.metallic = 0.0f; m.roughness = 0.0f; m.normal_scale = 1.0f; m.occlusion_strength = 1.0f;
+        if (unlit) {
+            for (int j = 0; j < 3; j++) m.emissive[j] = mf(M, b + 16 + j);
+        } else {
+            m.metallic = mf(M, b + 16); m.roughness = mf(M, b + 17); m.normal_scale = mf(M, b + 23); m.occlusion_strength = mf(M, b + 29);
+            m.debug_bitmask = M[b + 38];
+            const uint32_t fi = b + 39u;
+            for (int j = 0; j < 12; j++) if (M[fi + j] != 0u) m.ext_mask |= 1u << j;
+            const float strength = M[fi + 1] != 0u ? mf(M, b + M[fi + 1]) : 1.0f;
+            for (int j = 0; j < 3; j++) m.emissive[j] = mf(M, b + 35 + j) * strength;
+            if (M[fi + 2] != 0u) m.ior = mf(M, b + M[fi + 2]);
+        }
+        f.draw_mat[draw] = m;
+        return;
+    }
+    // one of the five core textures of the draw's material, ready to sample (TexSlotDev)
+    const int k = (int)role;
+    TexSlotDev s = resolve_tex_slot(sc, M, words, k, unlit);
     if (k == 0) {   // slot 0 also carries which of the five exist and which use TEXCOORD_0
         uint32_t exists_mask = 0u, uv0_mask = 0u;
         for (int j = 0; j < kCoreTextures; j++) {
@@ -1366,11 +1416,11 @@ __global__ __launch_bounds__(256) void k_forward_blend(FrameDev f) {
 // spread over all XCDs).  Block rows are 16 consecutive rows of the shard (row mode) or the two halves of each owned
 // 32-row band (band mode).  Returns false for surplus workgroup ids.
 struct ShadeBlock { uint32_t blk, brow; int x0, y0; };
-AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
+AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b, uint32_t wg = blockIdx.x) {
     const uint32_t bx_n = (f.width + 15u) >> 4;
     const uint32_t by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.sy1 - f.sy0) + 15u) >> 4;
     const uint32_t nblk = bx_n * by_n;
-    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;     // k-th block of this XCD
+    const uint32_t xcd = wg & 7u, k = wg >> 3;     // k-th block of this XCD
     const uint32_t rows_x = (by_n + 7u - xcd) >> 3;                 // block rows owned by this XCD
     if (k >= rows_x * bx_n) return false;
     b.blk = ((k / bx_n) * 8u + xcd) * bx_n + (k % bx_n);
@@ -1386,10 +1436,8 @@ AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b) {
 // 16x4 here).  5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 spills.
 // ------------------------------------------------------------------------------------------------
 template <bool GRAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
-    ShadeBlock b;
-    if (!shade_block(f, b)) return;
-    const int cx = b.x0 + (int)(threadIdx.x & 15u), cy = b.y0 + (int)(threadIdx.x >> 4);
+AWSM_DI void shade_pixel(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, uint32_t tid) {
+    const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
     if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
     const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
     const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
@@ -1401,6 +1449,299 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
     const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
     const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
     store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);   // hud: stays cleared (compute.wgsl:176-179)
+}
+template <bool GRAD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
+    ShadeBlock b;
+    if (!shade_block(f, b)) return;
+    shade_pixel<GRAD>(sc, f, b, threadIdx.x);
+}
+// The 16x4-pixel groups k_shade_lean left behind (a draw that is not lean, or texture coordinates beyond +-32768): one wavefront
+// per list entry, the general code.  A fixed small grid strides over the list; with an all-lean frame every wavefront reads the
+// count and exits.
+constexpr uint32_t kTodoBlocks = 1024;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_todo(const DevScene* __restrict__ sc, FrameDev f) {
+    const uint32_t n = min(f.shade_todo[0], f.shade_todo_cap);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += kTodoBlocks * 4u) {
+        const uint32_t e = f.shade_todo[4u + i];
+        ShadeBlock b;
+        if (!shade_block(f, b, e >> 2)) continue;
+        shade_pixel<false>(sc, f, b, ((e & 3u) << 6) | lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade_lean: the opaque pass for what a frame is mostly made of — PBR materials without optional blocks whose textures sit on
+// TEXCOORD_0 behind a repeat / linear sampler (LeanDrawDev).  Same arithmetic as shade_pixel (STRICT G-buffer reconstruction
+// through reconstruct_core, RELAXED shading with the same formulas), arranged for the machine:
+//   - every pointer is global address space with a 32-bit byte offset from a wave-uniform base (SGPR pair), so a load costs no
+//     64-bit address arithmetic and no flat-address dispatch; uniform data (camera, lights, environment) comes in by scalar loads;
+//   - the dependent-load chain is key -> {setup record, vertex normals / tangents, tri_shade} -> {lean record, three UV pairs}
+//     -> texels: four levels (the general route: key -> tri_info -> draw_shade -> indices -> UVs -> slot -> texels), and every
+//     level is issued in one burst before anything waits;
+//   - all texel fetches of the pixel are in flight together while the view vector and the TBN frame are computed;
+//   - one 96-byte record per draw instead of 336 bytes of per-draw records per pixel.
+// A wavefront (16x4 pixels) that meets a draw that is not lean, or texture coordinates beyond +-32768 (where the general sampler's
+// range guard acts), writes nothing and appends itself to shade_todo; k_shade_todo shades it with the general code.
+// ------------------------------------------------------------------------------------------------
+#define AWSM_AS1 __attribute__((address_space(1)))
+#define AWSM_AS4 __attribute__((address_space(4)))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+// vector memory: uniform base + 32-bit byte offset (global_load ... v_off, s[base:base+1])
+template <typename T> AWSM_DI T gload(const void* base, uint32_t byte_off) { return *(const AWSM_AS1 T*)((const AWSM_AS1 char*)base + byte_off); }
+// per-lane 64-bit base + 32-bit byte offset
+template <typename T> AWSM_DI T gload64(unsigned long long base, uint32_t byte_off) { return *(const AWSM_AS1 T*)((const AWSM_AS1 char*)base + byte_off); }
+// scalar memory: uniform address, data that no kernel writes while this one runs
+template <typename T> AWSM_DI T cload(const void* base, uint32_t byte_off) { return *(const AWSM_AS4 T*)((const AWSM_AS4 char*)base + byte_off); }
+AWSM_DI float4 as_float4(f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+AWSM_DI m4 cload_m4(const void* base, uint32_t byte_off) {
+    m4 m;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const f32x4 v = cload<f32x4>(base, byte_off + 16u * i); m.c[i] = {v.x, v.y, v.z, v.w}; }
+    return m;
+}
+
+namespace lean {
+struct Tap { uint32_t t00, t10, t01, t11; float fx, fy; };
+// A texture entry of the lean record, decoded: base address, log2 extents.  Decoding all five before the first texel load means the
+// record's loads are waited for once, ahead of the burst (a wait inside the burst would also wait for the texels issued so far:
+// vmcnt counts in order).
+struct Tex { unsigned long long base; uint32_t lw, lh; };
+AWSM_DI Tex decode(uint32_t lo, uint32_t hi) { return {((unsigned long long)(hi & 0xFFFFu) << 32) | lo, (hi >> 16) & 15u, (hi >> 20) & 15u}; }
+// sample_level_fast's addressing for a power-of-two repeat texture whose extent comes as log2: texel (i0, j0) and its right / lower
+// neighbours.  The two texels of a row are one 8-byte load; when the footprint wraps around the row end (i0 = W - 1) the second
+// texel of each pair is re-fetched from the row start — a branch almost never taken, and its loads land in the pair's registers
+// under the wrapped lanes' exec mask, so nothing waits.
+AWSM_DI void fetch(const Tex& x, float u, float v, Tap& t) {
+    const float xf = __builtin_amdgcn_ldexpf(u, (int)x.lw) - 0.5f, yf = __builtin_amdgcn_ldexpf(v, (int)x.lh) - 0.5f;     // u * W - 0.5 (W a power of two: exact product)
+    const float flx = floorf(xf), fly = floorf(yf);
+    t.fx = xf - flx; t.fy = yf - fly;
+    const uint32_t xi = (uint32_t)(int)flx, yi = (uint32_t)(int)fly;
+    const uint32_t i0 = __builtin_amdgcn_ubfe(xi, 0u, x.lw), j0 = __builtin_amdgcn_ubfe(yi, 0u, x.lh), j1 = __builtin_amdgcn_ubfe(yi + 1u, 0u, x.lh);
+    const uint32_t sh = x.lw + 2u, i0b = i0 << 2;
+    const u32x2a4 p0 = gload64<u32x2a4>(x.base, (j0 << sh) | i0b), p1 = gload64<u32x2a4>(x.base, (j1 << sh) | i0b);
+    t.t00 = p0.x; t.t10 = p0.y; t.t01 = p1.x; t.t11 = p1.y;
+    if (__builtin_amdgcn_ubfe(xi + 1u, 0u, x.lw) == 0u) {      // i1 wrapped to column 0
+        t.t10 = gload64<uint32_t>(x.base, j0 << sh); t.t11 = gload64<uint32_t>(x.base, j1 << sh);
+    }
+}
+struct Weights { float w00, w10, w01, w11; };
+AWSM_DI Weights weights(const Tap& t) {      // as sample_level_fast: bilinear on the raw 0..255 values, one scale by 1/255 at the end
+    const float gx = 1.0f - t.fx, gy = 1.0f - t.fy;
+    return {gx * gy, t.fx * gy, gx * t.fy, t.fx * t.fy};
+}
+template <int BYTE> AWSM_DI float ub(uint32_t t) {
+    return (float)((t >> (8 * BYTE)) & 255u);      // v_cvt_f32_ubyteN
+}
+template <int BYTE> AWSM_DI float channel(const Tap& t, const Weights& w) {
+    return (ub<BYTE>(t.t00) * w.w00 + ub<BYTE>(t.t10) * w.w10 + ub<BYTE>(t.t01) * w.w01 + ub<BYTE>(t.t11) * w.w11) * (1.0f / 255.0f);
+}
+// brdf.wgsl:293-302 (sample_brdf_lut above, same arithmetic; global-address-space loads)
+AWSM_DI f2 brdf_lut(const uint16_t* lut, uint32_t lut_w, uint32_t lut_h, float n_dot_v, float roughness) {
+    const float u = saturate(n_dot_v), v = saturate(roughness);
+    const int W = (int)lut_w, H = (int)lut_h;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;          // in [-0.5, extent - 0.5]: no range guard needed
+    const float flx = floorf(x), fly = floorf(y);
+    const float fx = x - flx, fy = y - fly;
+    const int xi = (int)flx, yi = (int)fly;
+    const int i0 = max(xi, 0), i1 = min(xi + 1, W - 1), j0 = max(yi, 0), j1 = min(yi + 1, H - 1);
+    const uint32_t r0 = (uint32_t)(j0 * W) << 2, r1 = (uint32_t)(j1 * W) << 2;
+    const uint32_t t00 = gload<uint32_t>(lut, r0 + ((uint32_t)i0 << 2)), t10 = gload<uint32_t>(lut, r0 + ((uint32_t)i1 << 2));
+    const uint32_t t01 = gload<uint32_t>(lut, r1 + ((uint32_t)i0 << 2)), t11 = gload<uint32_t>(lut, r1 + ((uint32_t)i1 << 2));
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float r_top = f16_bits_to_f32((unsigned short)(t00 & 0xFFFFu)) * gx + f16_bits_to_f32((unsigned short)(t10 & 0xFFFFu)) * fx;
+    const float r_bot = f16_bits_to_f32((unsigned short)(t01 & 0xFFFFu)) * gx + f16_bits_to_f32((unsigned short)(t11 & 0xFFFFu)) * fx;
+    const float g_top = f16_bits_to_f32((unsigned short)(t00 >> 16)) * gx + f16_bits_to_f32((unsigned short)(t10 >> 16)) * fx;
+    const float g_bot = f16_bits_to_f32((unsigned short)(t01 >> 16)) * gx + f16_bits_to_f32((unsigned short)(t11 >> 16)) * fx;
+    return {r_top * gy + r_bot * fy, g_top * gy + g_bot * fy};
+}
+}  // namespace lean
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+    ShadeBlock b;
+    if (!shade_block(f, b)) return;
+    const uint32_t tid = threadIdx.x;
+    const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
+    if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
+    const uint32_t pv = (uint32_t)cy * f.width + (uint32_t)cx;
+    const uint32_t p = f.out_compact ? (((b.brow >> 1) << kTileShift) + ((uint32_t)cy & (uint32_t)(kTile - 1))) * f.width + (uint32_t)cx : pv;
+
+    const u32x2 key = gload<u32x2>(f.vis, pv << 3);
+    if ((key.x & key.y) == 0xFFFFFFFFu) {                                // compute.wgsl:149-153: no hit -> skybox (uniform cube)
+        store_pixel(f, p, {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]});
+        return;
+    }
+    const uint32_t rank = ~key.x;                                         // 0xFFFFFFFF - low word
+    const float depth = __uint_as_float(key.y);
+
+    asm volatile("; MARK level1");
+    // ---- level 1: everything addressed by the triangle ----
+    const u32x4 ts = gload<u32x4>(f.tri_shade, rank << 4);          // first: level 2 hangs on it, and vmcnt counts in order
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t ro = rank * (uint32_t)kTriRecBytes, vo = rank * 48u;
+    TriRecRaw raw;
+    raw.q0 = as_float4(gload<f32x4>(f.tri_rec, ro)); raw.q1 = as_float4(gload<f32x4>(f.tri_rec, ro + 16u)); raw.q2 = as_float4(gload<f32x4>(f.tri_rec, ro + 32u));
+    { const f64x2 a = gload<f64x2>(f.tri_rec, ro + 48u), c = gload<f64x2>(f.tri_rec, ro + 64u); raw.d3 = make_double2(a.x, a.y); raw.d4 = make_double2(c.x, c.y); }
+    const float4 n0 = as_float4(gload<f32x4>(f.nrm, vo)), n1 = as_float4(gload<f32x4>(f.nrm, vo + 16u)), n2 = as_float4(gload<f32x4>(f.nrm, vo + 32u));
+    const float4 t0 = as_float4(gload<f32x4>(f.tan, vo)), t1 = as_float4(gload<f32x4>(f.tan, vo + 16u)), t2 = as_float4(gload<f32x4>(f.tan, vo + 32u));
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- level 2: the draw's record and the three corners' TEXCOORD_0 ----
+    const uint32_t lo = (ts.x & 0x00FFFFFFu) * (uint32_t)sizeof(LeanDrawDev);
+    const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
+    const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
+    const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u);
+    const void* attr = sc->buf[AWSM_BUF_ATTR_DATA];
+    const f32x2a4 uva = gload<f32x2a4>(attr, ts.y), uvb = gload<f32x2a4>(attr, ts.z), uvc = gload<f32x2a4>(attr, ts.w);
+
+    asm volatile("; MARK strict");
+    // ---- STRICT: what fs_main wrote for this pixel (before the lean test: the loads above stay ahead of every branch, and the
+    // general route needs the same values) ----
+    TriSetup t;
+    tri_rec_unpack(raw, t);
+    const GBufferTexel g = reconstruct_core<false>(t, n0, n1, n2, t0, t1, t2, cx, cy);
+
+    bool todo = (L0.x & 1u) == 0u;
+    if (__builtin_amdgcn_ballot_w64(todo) == 0ull) {
+        const float bz = (1.0f - g.bx) - g.by;                           // compute.wgsl:185-186
+        const float u = interp3_strict(g.bx, g.by, bz, uva.x, uvb.x, uvc.x), v = interp3_strict(g.bx, g.by, bz, uva.y, uvb.y, uvc.y);
+        todo = !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f);           // beyond: the general sampler's range guard decides (also NaN)
+        if (__builtin_amdgcn_ballot_w64(todo) == 0ull) {
+    asm volatile("; MARK fetch");
+            // ---- all texel fetches of the pixel ----
+            const uint32_t exists = L0.x >> 8;
+            const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
+            lean::Tap tp0, tp1, tp2, tp3, tp4;
+            if (exists & 1u) lean::fetch(x0, u, v, tp0);
+            if (exists & 2u) lean::fetch(x1, u, v, tp1);
+            if (exists & 4u) lean::fetch(x2, u, v, tp2);
+            if (exists & 8u) lean::fetch(x3, u, v, tp3);
+            if (exists & 16u) lean::fetch(x4, u, v, tp4);
+
+    asm volatile("; MARK standard");
+            // ---- standard.wgsl:11-62 (as shade_surface) ----
+            const m4 inv_proj = cload_m4(f.camera, 256u), inv_view = cload_m4(f.camera, 320u);
+            const float proj33 = cload<float>(f.camera, 64u + 60u);
+            const f2 suv = {((float)cx + 0.5f) * fm::rcp((float)f.width), ((float)cy + 0.5f) * fm::rcp((float)f.height)};
+            const f4 view_h = fm::fmul(inv_proj, {suv.x * 2.0f - 1.0f, 1.0f - suv.y * 2.0f, depth, 1.0f});
+            const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
+            const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
+            const f3 world_position = {wp.x, wp.y, wp.z};
+            f3 surface_to_camera;
+            if (proj33 > 0.9f) {
+                surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
+            } else {
+                const f32x4 cp = cload<f32x4>(f.camera, 384u);
+                const f3 to_camera = mk3(cp.x, cp.y, cp.z) - world_position;
+                surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
+            }
+    asm volatile("; MARK tbn");
+            const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
+
+    asm volatile("; MARK material");
+            // ---- material_color_calc.wgsl:25-265 for a material without optional blocks ----
+            f3 base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)};
+            if (exists & 1u) { const lean::Weights w = lean::weights(tp0); base = {base.x * lean::channel<0>(tp0, w), base.y * lean::channel<1>(tp0, w), base.z * lean::channel<2>(tp0, w)}; }
+            float metallic_in = __uint_as_float(L0.y), roughness_in = __uint_as_float(L0.z);
+            if (exists & 2u) { const lean::Weights w = lean::weights(tp1); metallic_in = metallic_in * lean::channel<2>(tp1, w); roughness_in = roughness_in * lean::channel<1>(tp1, w); }
+            f3 normal = tbn.N;
+            if (exists & 4u) {   // material_color_calc.wgsl:301-322
+                const lean::Weights w = lean::weights(tp2);
+                const float scale = __uint_as_float(L0.w);
+                const float ntx = (lean::channel<0>(tp2, w) * 2.0f - 1.0f) * scale, nty = (lean::channel<1>(tp2, w) * 2.0f - 1.0f) * scale, ntz = lean::channel<2>(tp2, w) * 2.0f - 1.0f;
+                normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
+            }
+            float occlusion = 1.0f;
+            if (exists & 8u) { const lean::Weights w = lean::weights(tp3); occlusion = mixf(1.0f, lean::channel<0>(tp3, w), __uint_as_float(L1.w)); }
+            f3 emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)};
+            if (exists & 16u) { const lean::Weights w = lean::weights(tp4); emissive = {emissive.x * lean::channel<0>(tp4, w), emissive.y * lean::channel<1>(tp4, w), emissive.z * lean::channel<2>(tp4, w)}; }
+
+    asm volatile("; MARK surface");
+            // ---- lights.wgsl:121-152 / brdf.wgsl (apply_lighting, brdf_ibl, brdf_direct above, with ior 1.5, specular 1, no transmission / clearcoat / sheen) ----
+            Surface sf;
+            sf.n = fm::fsafe_normalize(normal);
+            sf.v = fm::fsafe_normalize(surface_to_camera);
+            sf.metallic = clampf(metallic_in, 0.0f, 1.0f);
+            sf.roughness = fmaxf(clampf(roughness_in, 0.0f, 1.0f), 0.04f);
+            sf.alpha = sf.roughness * sf.roughness;
+            const float ndv = fm::fdot(sf.n, sf.v);
+            sf.n_dot_v_ibl = saturate(ndv);
+            sf.n_dot_v_dir = fmaxf(ndv, 1e-4f);
+            const float f0b = ior_to_f0(1.5f);
+            sf.F0 = mix3(splat3(fminf(f0b, 1.0f)), base, sf.metallic);
+            sf.f90 = mixf(1.0f, 1.0f, sf.metallic);
+            sf.sheen_scaling_dir = 1.0f;
+            sf.g1_v = geometry_schlick_ggx(saturate(ndv), sf.alpha);
+            sf.cc_n = sf.n;
+            sf.df90 = splat3(sf.f90) - sf.F0;
+            sf.base_diffuse = base * ((1.0f - sf.metallic) * (1.0f / kPi));
+            const float ac = fmaxf(sf.alpha, 0.001f);
+            sf.a2 = ac * ac; sf.a2m1 = sf.a2 - 1.0f;
+            sf.gk = ((ac + 1.0f) * (ac + 1.0f)) * 0.125f; sf.one_m_gk = 1.0f - sf.gk;
+            sf.has_sheen = false; sf.has_clearcoat = false;
+            PbrColor c;
+            c.occlusion = occlusion; c.sheen_roughness = 0.0f; c.sheen_color = {0.0f, 0.0f, 0.0f}; c.clearcoat = 0.0f; c.clearcoat_roughness = 0.0f;
+            f3 color;
+    asm volatile("; MARK ibl");
+            {   // brdf_ibl with the uniform cubes
+                const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
+                const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
+                const float n_dot_v = sf.n_dot_v_ibl;
+                const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
+                const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
+                const f3 base_layer = (base * (1.0f / kPi)) * irradiance;
+                const float k_d = (1.0f - F_view_max) * (1.0f - sf.metallic);
+                const f3 base_contribution = (base_layer * k_d) * occlusion;
+                const f2 lut = lean::brdf_lut(sc->lut_rg16f, sc->lut_w, sc->lut_h, n_dot_v, sf.roughness);
+                const f3 spec_term = sf.F0 * lut.x + splat3(sf.f90 * lut.y);
+                const f3 specular = (prefiltered * spec_term) * mixf(1.0f, occlusion, 0.5f);
+                color = (base_contribution + specular) + emissive;
+            }
+    asm volatile("; MARK lights");
+            const uint32_t n_lights = min(cload<uint32_t>(sc->buf[AWSM_BUF_LIGHTS_INFO], 0u), f.lights_cap);
+            const void* lights = sc->buf[AWSM_BUF_LIGHTS];
+            for (uint32_t i = 0; i < n_lights; i++) {
+                const f32x4 pre0 = cload<f32x4>(f.lights_pre, i * 32u), pre1 = cload<f32x4>(f.lights_pre, i * 32u + 16u);
+                const uint32_t kind = (uint32_t)pre0.w;
+                f3 light_dir = {pre0.x, pre0.y, pre0.z}, radiance = {pre1.x, pre1.y, pre1.z};
+                if (kind == 2u || kind == 3u) {
+                    const f32x4 pos_range = cload<f32x4>(lights, i * 64u);
+                    const f3 stl = mk3(pos_range.x, pos_range.y, pos_range.z) - world_position;
+                    const float d2 = fm::fdot(stl, stl);
+                    const float inv_d = d2 > 0.0f ? fm::rsq(d2) : 0.0f;
+                    const float dist = d2 * inv_d;
+                    float att;   // math.wgsl:12-19 inverse_square
+                    if (pos_range.w == 0.0f) att = fm::rcp(fmaxf(dist * dist, 0.01f));
+                    else { const float fo = 1.0f - fm::fdiv(dist * dist, pos_range.w * pos_range.w); att = fm::fdiv(saturate(fo * fo), dist * dist + 1.0f); }
+                    const f3 to_light = stl * inv_d;
+                    if (kind == 3u) {
+                        const f32x4 dir_inner = cload<f32x4>(lights, i * 64u + 16u), kind_outer = cload<f32x4>(lights, i * 64u + 48u);
+                        const float cos_l = fm::fdot(to_light, -light_dir);
+                        const float sm = saturate(fm::fdiv(cos_l - kind_outer.y, dir_inner.w - kind_outer.y));
+                        att = att * (sm * sm);
+                    }
+                    light_dir = to_light;
+                    radiance = radiance * att;
+                } else if (kind != 1u) { light_dir = {0.0f, 0.0f, 0.0f}; radiance = {0.0f, 0.0f, 0.0f}; }
+                color = color + brdf_direct(c, sf, light_dir, radiance);
+            }
+    asm volatile("; MARK store");
+            store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
+            return;
+        }
+    }
+    // this wavefront goes to the general kernel: nothing has been written
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) {
+        const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
+        if (slot < f.shade_todo_cap) f.shade_todo[4u + slot] = (blockIdx.x << 2) | (tid >> 6);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1670,7 +2011,11 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
     } else {
         if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
-        else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
+        else if (f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws) {
+            // MipmapMode::None: the lean kernel over the screen, then the general code for the wavefronts it declined (k_resolve_draws reset the list)
+            hipLaunchKernelGGL(awsm::k_shade_lean, dim3(nb), dim3(256), 0, s, sc, *f);
+            hipLaunchKernelGGL(awsm::k_shade_todo, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+        } else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
     }
 }
 // f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;

@@ -84,6 +84,8 @@ typedef struct AwsmConfig {
                                      submitted with; any other scene write waits for the opaque passes in flight).  Work the caller
                                      enqueues on its own stream after a frame must be preceded by awsm_hip_frame_flush(); awsm_hip_frame_end
                                      and the read-back calls wait for everything. */
+#define AWSM_CFG_GENERAL_SHADE_ONLY 8u /* never take the lean opaque route (k_shade_lean): every pixel through the general kernel.  For A/B
+                                         measurements and for tests that compare the two routes; results must agree within the shading tolerance. */
 #define AWSM_CFG_SMALL_BIN_LIST 2u /* start with a 4096-entry (triangle, tile) list instead of sizing it from the triangle count:
                                      exercises the overflow -> grow -> replay path of awsm_hip_frame_end (tests) */
 
