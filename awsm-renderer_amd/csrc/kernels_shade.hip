@@ -1561,6 +1561,33 @@ AWSM_DI f2 brdf_lut(const uint16_t* lut, uint32_t lut_w, uint32_t lut_h, float n
     const float g_bot = f16_bits_to_f32((unsigned short)(t01 >> 16)) * gx + f16_bits_to_f32((unsigned short)(t11 >> 16)) * fx;
     return {r_top * gy + r_bot * fy, g_top * gy + g_bot * fy};
 }
+// brdf_direct (brdf.wgsl:308-381) for a material without sheen / clearcoat, the same terms arranged for fewer instructions: one
+// reciprocal for the three denominators of D * G1(l) / (4 n.l n.v), clamps as output modifiers, per-pixel factors hoisted.
+// x -> sat(1 - x) equals 1 - sat(max(x, 0)) for every x, and sat(n.l) serves both as n.l >= 0 and as the saturated value (n, l unit).
+struct Lit {
+    f3 n, v, F0, df90, bd;          // bd = base * (1 - metallic) / pi
+    float ndv_dir, ndv4, a2m1, a2_g1v, gk, one_m_gk, occlusion;
+};
+AWSM_DI void direct(const Lit& s, f3 l, f3 radiance, f3& color) {
+    const float ndl = saturate(fm::fdot(s.n, l));
+    const f3 sum = s.v + l;
+    const float len_sq = fm::fdot(sum, sum);
+    const bool has_half = len_sq > 1e-8f;
+    const float inv_len = has_half ? fm::rsq(len_sq) : 0.0f;
+    const float ndh = saturate(fm::fdot(s.n, sum) * inv_len);
+    const float vdh = fm::fdot(s.v, sum) * inv_len;
+    const float p = saturate(1.0f - (has_half ? vdh : s.ndv_dir));
+    const float p2 = p * p, p5 = (p2 * p2) * p;
+    const f3 F = {s.F0.x + s.df90.x * p5, s.F0.y + s.df90.y * p5, s.F0.z + s.df90.z * p5};
+    const float dd = (ndh * ndh) * s.a2m1 + 1.0f;
+    const float den = (((kPi * dd) * dd + kEps) * (ndl * s.one_m_gk + s.gk)) * fmaxf(s.ndv4 * ndl, kEps);
+    const float spec = has_half ? (s.a2_g1v * ndl) * fm::rcp(den) : 0.0f;
+    const float k_d = 1.0f - fmaxf(fmaxf(F.x, F.y), F.z);
+    const float w = ndl * s.occlusion;
+    color.x += (s.bd.x * k_d + F.x * spec) * (radiance.x * w);
+    color.y += (s.bd.y * k_d + F.y * spec) * (radiance.y * w);
+    color.z += (s.bd.z * k_d + F.z * spec) * (radiance.z * w);
+}
 }  // namespace lean
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
@@ -1685,8 +1712,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_W
             sf.a2 = ac * ac; sf.a2m1 = sf.a2 - 1.0f;
             sf.gk = ((ac + 1.0f) * (ac + 1.0f)) * 0.125f; sf.one_m_gk = 1.0f - sf.gk;
             sf.has_sheen = false; sf.has_clearcoat = false;
-            PbrColor c;
-            c.occlusion = occlusion; c.sheen_roughness = 0.0f; c.sheen_color = {0.0f, 0.0f, 0.0f}; c.clearcoat = 0.0f; c.clearcoat_roughness = 0.0f;
+            lean::Lit lit;
+            lit.n = sf.n; lit.v = sf.v; lit.F0 = sf.F0; lit.df90 = sf.df90; lit.bd = sf.base_diffuse;
+            lit.ndv_dir = sf.n_dot_v_dir; lit.ndv4 = 4.0f * sf.n_dot_v_dir; lit.a2m1 = sf.a2m1; lit.a2_g1v = sf.a2 * sf.g1_v; lit.gk = sf.gk; lit.one_m_gk = sf.one_m_gk;
+            lit.occlusion = occlusion;
             f3 color;
     asm volatile("; MARK ibl");
             {   // brdf_ibl with the uniform cubes
@@ -1729,7 +1758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_W
                     light_dir = to_light;
                     radiance = radiance * att;
                 } else if (kind != 1u) { light_dir = {0.0f, 0.0f, 0.0f}; radiance = {0.0f, 0.0f, 0.0f}; }
-                color = color + brdf_direct(c, sf, light_dir, radiance);
+                lean::direct(lit, light_dir, radiance, color);
             }
     asm volatile("; MARK store");
             store_pixel(f, p, {color.x, color.y, color.z, 1.0f});

@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B builds of libawsm_hip.so with extra -D flags for kernels_shade.hip, into build/variants/ (git-ignored; travels with gpurun).
+# usage: tools/build_variants.sh NAME "-DFLAG=1 ..." [NAME2 "..."] ...   then on the GPU box: tools/ab_bench.sh build/variants/lib_NAME.so ...
+set -e
+cd "$(dirname "$0")/../awsm-renderer_amd/csrc"
+OUT=../../build/variants
+mkdir -p $OUT
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
+make -s ../libawsm_hip.so >/dev/null
+while [ $# -ge 2 ]; do
+  NAME=$1; DEFS=$2; shift 2
+  ( /opt/rocm/bin/hipcc $FLAGS $DEFS -c -o $OUT/shade_$NAME.o kernels_shade.hip 2>&1 | grep -v hip-link || true
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$NAME.so awsm_hip.o kernels_geometry.o $OUT/shade_$NAME.o && rm -f $OUT/shade_$NAME.o && echo built $OUT/lib_$NAME.so ) &
+  while [ $(jobs -r | wc -l) -ge 3 ]; do sleep 1; done
+done
+wait
