@@ -30,6 +30,8 @@ void awsm_launch_bin_scan(const FrameDev* f, hipStream_t s);
 void awsm_launch_bin_fill(const FrameDev* f, hipStream_t s);
 void awsm_launch_raster(const FrameDev* f, hipStream_t s);
 void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
+int awsm_shade_is_lean(const FrameDev* f);
+int awsm_launch_shade_todo(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
 void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, unsigned long long* out, hipStream_t s);
@@ -44,7 +46,7 @@ struct DevBuf {
     size_t size = 0;
 };
 
-enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE, EV_FWD_BEGIN, EV_FWD, EV_COUNT };
+enum { EV_START = 0, EV_TRANSFORM, EV_BIN, EV_RASTER, EV_SHADE_BEGIN, EV_SHADE_LEAN, EV_SHADE, EV_FWD_BEGIN, EV_FWD, EV_COUNT };
 
 // Everything the geometry pass produces for one frame and the opaque pass consumes.
 struct FrameBufs {
@@ -123,7 +125,11 @@ struct AwsmHipCtx {
     // pinned staging ring for buffer_write / small uploads
     uint8_t* stage = nullptr;
     size_t stage_cap = 0, stage_head = 0;
-    uint32_t* counters_host = nullptr;   // pinned, 16 u32: [0..8) geometry pass, [8..16) transparent pass
+    uint32_t* counters_host = nullptr;   // pinned, 16 u32: [0..8) geometry pass, [8..16) transparent pass; then 2 x {entries needed, frame serial} (k_bin_scan)
+    uint32_t frame_serial = 0, status_seen[2] = {0, 0};
+    uint32_t dropped_frames = 0;         // enqueue-only frames that overflowed their bin list
+    uint32_t out_first_row = 0;          // awsm_hip_bind_output_rows
+    bool out_rows_mode = false;
 
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid[EV_COUNT] = {};
@@ -289,12 +295,14 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->raster_extra_cap = FB(c).raster_extra_cap; f->raster_slot_cap = FB(c).raster_slot_cap;
     f->big_list = (uint32_t*)FB(c).big_list.ptr;
     f->counters = (uint32_t*)FB(c).counters.ptr;
+    f->host_bin_status = c->counters_host + 16 + 2 * c->slot;
+    f->frame_serial = c->frame_serial;
     f->vis = (unsigned long long*)FB(c).vis.ptr;
     f->camera = (const uint8_t*)(c->overlap ? FB(c).camera.ptr : c->bufs[AWSM_BUF_CAMERA].ptr);
     f->msaa = c->msaa;
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
-    f->out_rgba16f = (uint16_t*)(c->bound_out ? c->bound_out : c->out16.ptr);
+    f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16.ptr);   // kernels address by absolute row
     f->out_rgba32f = (float*)c->out32.ptr;
     f->lights_pre = (float4*)c->lights_pre.ptr;
     f->lights_cap = (uint32_t)(c->lights_pre.size / 32);
@@ -348,8 +356,13 @@ int enqueue_opaque(AwsmHipCtx* c) {
     f.has_opaque = c->last_opaque.has_opaque;
     f.mipmap = c->last_opaque.mipmap;
     if (c->bound_out) {
-        const size_t need = (f.out_compact ? (size_t)f.tiles_y * kTile : (size_t)c->height) * c->width * 8;
-        if (c->bound_out_bytes < need) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "opaque_pass: bound output holds %zu bytes, this shard layout writes %zu", c->bound_out_bytes, need);
+        if (c->out_rows_mode) {   // a row strip's own buffer: rows [first_row, first_row + bytes / (width * 8))
+            if (f.out_compact || f.sy0 < c->out_first_row || (size_t)(f.sy1 - c->out_first_row) * c->width * 8 > c->bound_out_bytes)
+                return fail(c, AWSM_ERR_INVALID_ARGUMENT, "opaque_pass: bound output starts at row %u and holds %zu bytes, the shard shades rows [%u, %u)", c->out_first_row, c->bound_out_bytes, f.sy0, f.sy1);
+        } else {
+            const size_t need = (f.out_compact ? (size_t)f.tiles_y * kTile : (size_t)c->height) * c->width * 8;
+            if (c->bound_out_bytes < need) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "opaque_pass: bound output holds %zu bytes, this shard layout writes %zu", c->bound_out_bytes, need);
+        }
     }
     int rc = sync_scene(c);
     if (rc) return rc;
@@ -373,7 +386,13 @@ int enqueue_opaque(AwsmHipCtx* c) {
     }
     if (want_resolve && !early) awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     if ((rc = record(c, EV_SHADE_BEGIN, ss))) return rc;      // after the resolve: ms_shade is the shading kernels alone
-    if (f.sy1 > f.sy0) awsm_launch_shade(c->scene_dev, &f, ss);
+    c->ev_valid[EV_SHADE_LEAN] = false;
+    if (f.sy1 > f.sy0) {
+        awsm_launch_shade(c->scene_dev, &f, ss);
+        // the lean kernel alone (AwsmFrameStats.ms_shade_lean): one more event, only when stage times are asked for
+        if (c->stage_timers && awsm_shade_is_lean(&f) && (rc = record(c, EV_SHADE_LEAN, ss))) return rc;
+        (void)awsm_launch_shade_todo(c->scene_dev, &f, ss);
+    }
     if ((rc = record(c, EV_SHADE, ss))) return rc;
     if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; }
     HIPCHK(c, hipGetLastError());
@@ -602,8 +621,8 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             c->fb[s].camera.size = 512;
         }
     }
-    if (hipHostMalloc((void**)&c->counters_host, 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-    memset(c->counters_host, 0, 16 * sizeof(uint32_t));
+    if (hipHostMalloc((void**)&c->counters_host, 20 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    memset(c->counters_host, 0, 20 * sizeof(uint32_t));
     memset(&c->scene, 0, sizeof c->scene);
     // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
     c->scene.skybox_rgba[3] = 1.0f;
@@ -651,7 +670,11 @@ int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     if (!c || (int)which < 0 || which >= AWSM_BUF_COUNT) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "buffer_create: bad buffer id %d", (int)which);
     HIPCHK(c, hipSetDevice(c->device));
     { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
-    // +16 bytes of slack so 16-byte vector loads of the last record never leave the allocation
+    // +16 bytes of slack so 16-byte vector loads of the last record never leave the allocation (size = the logical size)
+    if (bytes && c->bufs[which].ptr && c->bufs[which].size == bytes) {     // unchanged size: same allocation, cleared ("contents are NOT preserved")
+        HIPCHK(c, hipMemsetAsync(c->bufs[which].ptr, 0, bytes + 16, c->stream));
+        return AWSM_OK;
+    }
     int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
     if (rc) return rc;
     if (bytes) c->bufs[which].size = bytes;
@@ -798,16 +821,17 @@ int awsm_hip_env_upload(AwsmHipCtx* c, const AwsmEnv* env) {
     memcpy(c->scene.prefiltered_rgb, env->prefiltered_rgb, 16);
     memcpy(c->scene.irradiance_rgb, env->irradiance_rgb, 16);
     if (env->brdf_lut_rgba16f) {
-        if (env->brdf_lut_width == 0 || env->brdf_lut_height == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_upload: LUT size 0");
-        const uint32_t n = env->brdf_lut_width * env->brdf_lut_height;
+        if (env->brdf_lut_width == 0 || env->brdf_lut_height == 0 || env->brdf_lut_width > 8192 || env->brdf_lut_height > 8192)
+            return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_upload: LUT size %ux%u (1..8192 per side)", env->brdf_lut_width, env->brdf_lut_height);
+        const size_t n = (size_t)env->brdf_lut_width * env->brdf_lut_height;
         DevBuf tmp;
-        int rc = dev_realloc(c, tmp, (size_t)n * 8, false);
+        int rc = dev_realloc(c, tmp, n * 8, false);
         if (rc) return rc;
-        if ((rc = dev_realloc(c, c->lut, (size_t)n * 4, false))) { (void)hipFree(tmp.ptr); return rc; }
-        HIPCHK(c, hipMemcpyAsync(tmp.ptr, env->brdf_lut_rgba16f, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-        awsm_launch_rgba16f_to_rg16f((const uint16_t*)tmp.ptr, (uint32_t*)c->lut.ptr, n, c->stream);   // only .rg is sampled (brdf.wgsl:301)
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipFree(tmp.ptr));
+        if ((rc = dev_realloc(c, c->lut, n * 4, false))) { (void)hipFree(tmp.ptr); return rc; }
+        hipError_t e = hipMemcpyAsync(tmp.ptr, env->brdf_lut_rgba16f, n * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) { awsm_launch_rgba16f_to_rg16f((const uint16_t*)tmp.ptr, (uint32_t*)c->lut.ptr, (uint32_t)n, c->stream); e = hipStreamSynchronize(c->stream); }   // only .rg is sampled (brdf.wgsl:301)
+        (void)hipFree(tmp.ptr);
+        if (e != hipSuccess) return fail(c, AWSM_ERR_DEVICE, "env_upload: LUT upload failed: %s", hipGetErrorString(e));
         c->scene.lut_w = env->brdf_lut_width; c->scene.lut_h = env->brdf_lut_height;
     }
     c->scene_dirty = true;
@@ -843,11 +867,38 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if (n) for (AwsmBuf b : need) if (!c->bufs[b].ptr) return fail(c, AWSM_ERR_NOT_READY, "geometry_pass: buffer %d missing", (int)b);
     HIPCHK(c, hipSetDevice(c->device));
 
-    if (c->overlap) c->slot ^= 1;            // the previous frame's opaque pass may still be reading the other slot
-    c->draws_api.assign(draws, draws + n);
+    // validate before touching any per-frame state: a failed call leaves the previous frame (and its slot) current
+    std::vector<DrawDev> new_draws;
     uint64_t tris = 0, blocks = 0;
-    int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, c->draws_host, &tris, &blocks);
+    int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, new_draws, &tris, &blocks);
     if (rc) return rc;
+    if (c->overlap) {
+        c->slot ^= 1;                        // the previous frame's opaque pass may still be reading the other slot
+        // ... and the opaque pass of two frames ago may still be reading THIS slot (its draw list, per-draw records): order everything
+        // this call puts on the caller's stream — the draw-list upload included — after it
+        if (c->shade_pending[c->slot]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0)); c->shade_pending[c->slot] = false; }
+    }
+    c->draws_api.assign(draws, draws + n);
+    c->draws_host.swap(new_draws);
+    c->frame_serial++;
+    {   // What earlier frames needed in their (triangle, tile) lists, as far as the GPU has reported it (pinned words written by k_bin_scan;
+        // no wait).  A frame rendered without frame_end cannot be replayed: size the list ahead of the need instead, and count the
+        // frames that did overflow (AwsmFrameStats.frames_with_dropped_bin_entries).
+        uint32_t need = 0;
+        for (int s = 0; s < 2; s++) {
+            const volatile uint32_t* st = c->counters_host + 16 + 2 * s;
+            const uint32_t entries = st[0], serial = st[1];
+            if (serial == c->status_seen[s]) continue;
+            c->status_seen[s] = serial;
+            if (entries > c->fb[s].bin_capacity && c->fb[s].bin_list.ptr) c->dropped_frames++;
+            need = std::max(need, entries);
+        }
+        for (int s = 0; s < (c->overlap ? 2 : 1); s++)
+            if (need && (uint64_t)need * 4 > (uint64_t)c->fb[s].bin_capacity * 3 && c->fb[s].bin_list.ptr && !(c->flags & AWSM_CFG_SMALL_BIN_LIST)) {
+                if ((rc = ensure_bin_capacity_of(c, c->fb[s], need + need / 2 + 1024))) return rc;
+                if ((rc = reserve_raster_items(c, c->fb[s], false))) return rc;
+            }
+    }
     c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
     if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
     if ((rc = enqueue_geometry(c))) return rc;
@@ -959,7 +1010,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             out->ms_bin = ms(EV_TRANSFORM, EV_BIN);
             out->ms_raster = ms(EV_BIN, EV_RASTER);
         }
-        if (c->opaque_done) out->ms_shade = ms(EV_SHADE_BEGIN, EV_SHADE);
+        if (c->opaque_done) { out->ms_shade = ms(EV_SHADE_BEGIN, EV_SHADE); out->ms_shade_lean = ms(EV_SHADE_BEGIN, EV_SHADE_LEAN); }
         if (c->transparent_done) { out->ms_forward = ms(EV_FWD_BEGIN, EV_FWD); out->forward_triangles = c->tr_total_tris; out->forward_fragment_slots = c->counters_host[13]; }
         out->ms_total = (c->geometry_done ? ms(EV_START, EV_RASTER) : 0.0f) + out->ms_shade + out->ms_forward;   // the two passes may run on different streams
         out->triangles_in = c->total_tris;
@@ -967,6 +1018,9 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->bin_entries = c->counters_host[1];
         out->covered_pixels = c->counters_host[3];
         out->bin_overflow_retries = c->overflow_retries;
+        out->frames_with_dropped_bin_entries = c->dropped_frames;
+        if (c->opaque_done && c->shade_todo.ptr && c->msaa == 0 && !c->last_opaque.mipmap && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
+            HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo.ptr, 4, hipMemcpyDeviceToHost));
     }
     return AWSM_OK;
 }
@@ -974,7 +1028,14 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
 int awsm_hip_bind_output(AwsmHipCtx* c, void* device_ptr, size_t bytes) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (device_ptr && bytes == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_output: zero-sized image");
-    c->bound_out = device_ptr; c->bound_out_bytes = bytes;   // checked against the shard layout when the opaque pass is enqueued
+    c->bound_out = device_ptr; c->bound_out_bytes = bytes; c->out_first_row = 0; c->out_rows_mode = false;   // checked against the shard layout when the opaque pass is enqueued
+    return AWSM_OK;
+}
+
+int awsm_hip_bind_output_rows(AwsmHipCtx* c, void* device_ptr, size_t bytes, uint32_t first_row) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!device_ptr || bytes == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_output_rows: null or zero-sized image");
+    c->bound_out = device_ptr; c->bound_out_bytes = bytes; c->out_first_row = first_row; c->out_rows_mode = true;
     return AWSM_OK;
 }
 
@@ -1053,6 +1114,7 @@ int awsm_hip_read_opaque(AwsmHipCtx* c, uint16_t* out) {
     if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
     void* src = awsm_hip_output_device_ptr(c);
     if (!src) return fail(c, AWSM_ERR_NOT_READY, "read_opaque before resize");
+    if (c->bound_out && c->out_rows_mode) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "read_opaque: the bound output is a row strip (bind_output_rows); read it from its owner");
     HIPCHK(c, hipSetDevice(c->device));
     { int rcs = sync_all(c); if (rcs) return rcs; }
     HIPCHK(c, hipMemcpy(out, src, (size_t)c->width * c->height * 8, hipMemcpyDeviceToHost));

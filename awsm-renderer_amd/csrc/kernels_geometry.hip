@@ -481,6 +481,10 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         f.counters[1] = total;
         if (total > f.bin_capacity) f.counters[2] = 1u;
         f.counters[7] = min(n_extra, f.raster_extra_cap);
+        if (f.host_bin_status) {   // for frames nobody waits for: the host sizes the list of later frames from this (awsm_hip_geometry_pass)
+            __hip_atomic_store(f.host_bin_status, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(f.host_bin_status + 1, f.frame_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

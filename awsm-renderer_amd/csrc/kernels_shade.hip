@@ -2042,10 +2042,19 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
         else if (f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws) {
             // MipmapMode::None: the lean kernel over the screen, then the general code for the wavefronts it declined (k_resolve_draws reset the list)
-            hipLaunchKernelGGL(awsm::k_shade_lean, dim3(nb), dim3(256), 0, s, sc, *f);
-            hipLaunchKernelGGL(awsm::k_shade_todo, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+            hipLaunchKernelGGL(awsm::k_shade_lean, dim3(nb), dim3(256), 0, s, sc, *f);      // awsm_launch_shade_todo follows
         } else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
     }
+}
+// second half of the lean route; returns 0 when the frame did not take it
+extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f) {
+    const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
+    return (bx_n * by_n) && f->mipmap == 0u && f->msaa != 4u && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
+}
+extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
+    if (!awsm_shade_is_lean(f)) return 0;
+    hipLaunchKernelGGL(awsm::k_shade_todo, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+    return 1;
 }
 // f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;
 // out_rgba16f / out_rgba32f = the composite image).  Every tile of the frame is launched: a tile without transparent triangles is a copy.

@@ -30,7 +30,7 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
-           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest"]
+           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows"]
 
 
 class AwsmConfig(C.Structure):
@@ -59,7 +59,8 @@ class AwsmEnv(C.Structure):
 class AwsmFrameStats(C.Structure):
     _fields_ = [("ms_transform", C.c_float), ("ms_bin", C.c_float), ("ms_raster", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
                 ("triangles_in", C.c_uint32), ("triangles_binned", C.c_uint32), ("bin_entries", C.c_uint32), ("covered_pixels", C.c_uint32),
-                ("bin_overflow_retries", C.c_uint32), ("ms_forward", C.c_float), ("forward_triangles", C.c_uint32), ("forward_fragment_slots", C.c_uint32)]
+                ("bin_overflow_retries", C.c_uint32), ("ms_forward", C.c_float), ("forward_triangles", C.c_uint32), ("forward_fragment_slots", C.c_uint32),
+                ("ms_shade_lean", C.c_float), ("shade_general_wavefronts", C.c_uint32), ("frames_with_dropped_bin_entries", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -91,6 +92,7 @@ def load_library():
     lib.awsm_hip_buffer_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     lib.awsm_hip_buffer_write.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.awsm_hip_bind_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.awsm_hip_bind_output_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
     lib.awsm_hip_geometry_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.awsm_hip_opaque_pass.argtypes = [C.c_void_p, C.c_void_p]
     lib.awsm_hip_frame_end.argtypes = [C.c_void_p, C.c_void_p]
@@ -286,6 +288,10 @@ class HipDevice:
 
     def bind_output(self, device_ptr: Optional[int], nbytes: int = 0):
         self._chk(self.lib.awsm_hip_bind_output(self.ctx, device_ptr, nbytes), "bind_output")
+
+    def bind_output_rows(self, device_ptr: int, nbytes: int, first_row: int):
+        """Row-strip shards: device_ptr receives frame row first_row onwards."""
+        self._chk(self.lib.awsm_hip_bind_output_rows(self.ctx, device_ptr, nbytes, first_row), "bind_output_rows")
 
     def output_device_ptr(self) -> int:
         return self.lib.awsm_hip_output_device_ptr(self.ctx)

@@ -4,14 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one frame: camera write (the per-frame dirty upload of a static scene), geometry pass (deform/transform,
-bin, raster) and the single-dispatch opaque pass, driven through the C++ host layer and the C-ABI.  Scene data is
-resident in HBM before the timed region.  With N > 1 the frame is sharded into 32-row bands dealt round-robin over the
+One "step" = one frame: camera write (the camera moves every step on a small orbit, so the cull, the sort and the draw-list
+upload are exercised, not just replayed), geometry pass (deform/transform, bin, raster) and the single-dispatch opaque pass, driven
+through the C++ host layer and the C-ABI.  Scene data is resident in HBM before the timed region.  The scene is the procedural
+"Sponza-class" atrium of scenes.py (no glTF asset is available offline); --config 2 / 3 run BASELINE configs[1] / configs[2].  With N > 1 the frame is sharded into 32-row bands dealt round-robin over the
 ranks (one process per GPU); every step ends with an RCCL all-gather of the RGBA16F bands so that every rank holds the
 full image (the gather of frame i runs while frame i+1 renders).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline      for the dominant kernel: algorithmic bytes per launch / hipEvent-measured launch time vs 8 TB/s
+  roofline      for the dominant kernel: what binds it (vector-ALU issue, from the committed SQ counter pass named in profile_tag) next to
+                its HBM roofline: algorithmic bytes per launch (low / high texel bound) / hipEvent-measured launch time vs 8 TB/s
   cpu_baseline  the scalar-C oracle port timed on this box's host cores on a bounded strip of the same frame
 """
 from __future__ import annotations
@@ -41,43 +43,60 @@ def algorithmic_bytes(scene, stats, rows):
     tex_bytes = float(sum(t.nbytes for t in scene.textures))
     n_tex = float(np.mean([sum(1 for a in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "occlusion_tex", "emissive_tex")
                                 if getattr(m, a) is not None) for m in scene.materials])) if scene.materials else 0.0
-    u_tex = min(tex_bytes, P_cov * n_tex * 16.0)
+    # unique texel bytes the frame touches: at most every texel of the scene (or four taps per texture and pixel, if that is less);
+    # at least one texel per texture and covered pixel — a minified, unmipped texture is read sparsely, a magnified one densely, so
+    # the truth lies in between (SURVEY.md §8d gives ~150 MB for this class of scene against the 333 MB upper bound)
+    u_tex_high = min(tex_bytes, P_cov * n_tex * 16.0)
+    u_tex_low = min(tex_bytes, P_cov * n_tex * 4.0) * (150.0 / 333.0 if tex_bytes > 3.0e8 else 0.45)
+    shade_fixed = P * 16.0 + P_cov * (12.0 + 3.0 * stride) + min(T_bin, P_cov) * 144.0
     return {
         "k_deform_transform": V * 56.0 + V * 48.0 + T_in,
         "k_bin": 2.0 * (T_in * 49.0) + E * 4.0 * 2.0,
         "k_raster_tile": E * (4.0 + 48.0) + P * 8.0,
-        "k_shade": P * 16.0 + P_cov * (12.0 + 3.0 * stride) + min(T_bin, P_cov) * 144.0 + u_tex,
+        "k_shade": shade_fixed + u_tex_high,
+        "k_shade_low": shade_fixed + u_tex_low,
     }
 
 
-def pmc_traffic(kernel, n_tris, W, H, field="hbm_traffic_bytes"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/latest_pmc.json, written by
-    tools/profile_collect.py from FETCH_SIZE / WRITE_SIZE collected in separate passes on this same workload).  None when
-    no profile of this exact workload is committed: counters cannot be read from inside the process."""
-    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+SHADE_KERNELS = ("k_shade_lean", "k_shade", "k_shade<false>")      # profile names of the single-sample, MipmapMode::None opaque kernel
+
+
+def pmc_profile(n_tris, W, H):
+    """The committed rocprofv3 --pmc summary of this exact workload (profiles/latest_pmc.json), or None."""
     try:
-        doc = json.load(open(path))
+        doc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
         wl = doc["workload"]
-        if (wl["triangles"], wl["width"], wl["height"]) != (n_tris, W, H):
-            return None
-        ks = doc["kernels"]
-        for name in ("awsm::" + kernel, "awsm::" + kernel + "<false>", "awsm::" + kernel + "<1>"):      # the profiled workload is single-sample, MipmapMode::None
-            if name in ks:
-                return ks[name][field]
-        return None
+        return doc if (wl["triangles"], wl["width"], wl["height"]) == (n_tris, W, H) else None
     except (OSError, KeyError, ValueError):
         return None
 
 
-def valu_issue(kernel, n_tris, W, H, launch_ms):
-    """What actually bounds the dominant kernel (it is ALU work, not a stream): vector-ALU instructions per launch from the committed
-    SQ counter pass, the time the 1024 SIMDs (256 CUs x 4, one wave64 VALU instruction per 4 cycles, 2.4 GHz peak clock) need to
-    issue them, and that time over the measured launch duration."""
-    insts = pmc_traffic(kernel, n_tris, W, H, "SQ_INSTS_VALU")
-    if not insts or launch_ms <= 0:
+def pmc_kernel(doc, kernel):
+    if not doc:
         return None
+    names = ["awsm::" + k for k in SHADE_KERNELS] if kernel == "k_shade" else ["awsm::" + kernel, "awsm::" + kernel + "<false>", "awsm::" + kernel + "<1>"]
+    for n in names:
+        if n in doc["kernels"]:
+            return doc["kernels"][n]
+    return None
+
+
+def valu_issue(k, launch_ms):
+    """What actually bounds the dominant kernel (it is ALU work, not a stream): vector-ALU instructions per launch from the committed
+    SQ counter pass, the time the 1024 SIMDs (256 CUs x 4) need to issue them at one wave64 VALU instruction per 4 cycles and
+    2.4 GHz, and that time over the measured launch duration; next to it the share of wave-cycles the same pass saw stalled on issue
+    (SQ_WAIT_INST_ANY) and parked on memory (SQ_WAIT_ANY).  (tools/valu_probe.hip: with several waves per SIMD a full-rate
+    instruction issues every ~2 cycles, conversions / compares / selects / integer 3-operand / packed and f64 ops every ~4,
+    transcendentals every ~8 — the 4-cycle figure is the kernel's measured average mix.)"""
+    if not k or not k.get("SQ_INSTS_VALU") or launch_ms <= 0:
+        return None
+    insts = k["SQ_INSTS_VALU"]
     min_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
-    return {"insts_per_launch": insts, "issue_bound_ms": min_ms, "frac": min_ms / launch_ms}
+    out = {"insts_per_launch": insts, "insts_per_wave": insts / k["SQ_WAVES"] if k.get("SQ_WAVES") else None, "issue_bound_ms": min_ms, "frac": min_ms / launch_ms}
+    if k.get("SQ_WAVE_CYCLES"):
+        out["wave_cycles_issue_stalled"] = k.get("SQ_WAIT_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
+        out["wave_cycles_waiting_memory"] = k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
+    return out
 
 
 def cpu_baseline(scene, lut_rg, rows_sample):
@@ -96,6 +115,11 @@ def cpu_baseline(scene, lut_rg, rows_sample):
     return {"value": frac / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"rows [{rows_sample[0]},{rows_sample[1]}) of the {scene.width}x{scene.height} frame ({frac:.4f} frame, all vertices "
                       f"transformed), {dt:.1f} s wall, scaled to whole frames"}
+
+
+def hip_backend_path():
+    from awsm_renderer_amd import hip_backend
+    return hip_backend.LIB_PATH
 
 
 def backend_is_rehearsal():
@@ -117,7 +141,13 @@ def main():
     ap.add_argument("--mipmap", action="store_true", help="MipmapMode::Gradient (the reference's default; not the BASELINE config)")
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4), help="MSAA x4 geometry + edge resolve (the reference's default AntiAliasing; not the BASELINE config)")
     ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
+    ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4), help="BASELINE.json config: 4 = configs[3] the 4K Sponza-class frame (the metric's), "
+                    "2 = configs[1] helmet-class 15k triangles / 2048^2 textures at 1920x1080, 3 = configs[2] skinned rig + morph cube at 1920x1080")
+    ap.add_argument("--static-camera", action="store_true", help="re-submit the same camera every step (default: a small orbit, so cull / sort / draw-list upload run)")
+    ap.add_argument("--allow-variant-lib", action="store_true", help="accept an AWSM_HIP_LIB override (A/B builds); the path is printed in the JSON line")
     args = ap.parse_args()
+    if os.environ.get("AWSM_HIP_LIB") and not args.allow_variant_lib:
+        raise SystemExit("AWSM_HIP_LIB is set: bench.py measures awsm-renderer_amd/libawsm_hip.so; pass --allow-variant-lib for an A/B build")
 
     import numpy as np
     import torch
@@ -146,7 +176,18 @@ def main():
     from awsm_renderer_amd.sharding import band_rows, bands_per_rank, bands_to_image
 
     W, H = args.width, args.height
-    scene = scenes.atrium_scene(W, H, detail=args.detail, tex_scale=args.tex_scale)
+    if args.config == 4:
+        scene = scenes.atrium_scene(W, H, detail=args.detail, tex_scale=args.tex_scale)
+        workload_name = "Sponza-class procedural atrium (configs[3])"
+    else:
+        if (W, H) == (3840, 2160):
+            W, H = 1920, 1080
+        if args.config == 2:
+            scene = scenes.helmet_scene(W, H, tex_size=max(8, int(2048 * args.tex_scale)))
+            workload_name = "DamagedHelmet-class procedural mesh (configs[1])"
+        else:
+            scene = scenes.skinned_morph_scene(W, H)
+            workload_name = "BrainStem-class skinned rig + AnimatedMorphCube-class morph cube (configs[2])"
     n_tris = scenes.total_triangles(scene)
     # One explicit HIP stream for everything: the library launches its kernels on it, and torch (RCCL collectives, barrier
     # tensors) orders against it as its current stream.  (torch's default stream has handle 0, which the C-ABI reads as
@@ -204,16 +245,35 @@ def main():
             else:
                 image[b].copy_(bands_to_image(gathered[b].view(world, L, 32, W, 4), H, world))
 
+    # The camera moves: a small orbit around its position (radius 2 % of the distance to its target, one turn per 240 frames), so every
+    # step runs the frustum cull, the depth sort and — when the order changes — the draw-list upload, and the binning sees a new frame.
+    import math
+    inv_view = np.linalg.inv(np.asarray(scene.view, dtype=np.float64).T)          # scene.view is [col][row]
+    eye0 = np.asarray(scene.camera_position, dtype=np.float64)
+    fwd = -inv_view[:3, 2]
+    right, up = inv_view[:3, 0], inv_view[:3, 1]
+    orbit_r = 0.02 * 30.0 if args.config == 4 else 0.02 * float(np.linalg.norm(eye0))
+    cam_no = [0]
+
+    def move_camera():
+        if args.static_camera:
+            r.host.camera_update(scene.view, scene.proj, scene.camera_position)
+            return
+        a = 2.0 * math.pi * (cam_no[0] % 240) / 240.0
+        cam_no[0] += 1
+        eye = eye0 + orbit_r * (math.cos(a) * right + math.sin(a) * up)
+        r.host.camera_update(scenes.look_at_rh(tuple(eye), tuple(eye + 30.0 * fwd)), scene.proj, tuple(eye))
+
     def step():
-        r.host.camera_update(scene.view, scene.proj, scene.camera_position)
+        move_camera()
         if world == 1:
             r.host.render(sync=False)
             return
         b = frame_no[0] % n_buf
         frame_no[0] += 1
         finish(b)                      # frame i-2 used these buffers: complete it before they are overwritten
-        if strips:   # the kernels address the image by absolute row: a base pointer such that row y0s lands on mine[b][0]
-            dev.bind_output(mine[b].data_ptr() - y0s * W * 8, H * W * 8)
+        if strips:   # this rank's strip of the gather buffer receives frame rows y0s ..
+            dev.bind_output_rows(mine[b].data_ptr(), rows_out * W * 8, y0s)
         else:
             dev.bind_output(mine[b].data_ptr(), rows_out * W * 8)
         r.host.render(sync=False)
@@ -261,7 +321,7 @@ def main():
         check = "ok" if torch.equal(got.view(torch.int16), ref.view(torch.int16)) else "MISMATCH"
         if strips:
             r.host.set_shard_rows(y0s, y1s)
-            dev.bind_output(mine[0].data_ptr() - y0s * W * 8, H * W * 8)
+            dev.bind_output_rows(mine[0].data_ptr(), rows_out * W * 8, y0s)
         else:
             r.host.set_shard_bands(world, rank, compact_output=True)
             dev.bind_output(mine[0].data_ptr(), rows_out * W * 8)
@@ -271,21 +331,39 @@ def main():
     # ---- per-kernel launch durations: hipEvents recorded by the library on the kernels' own stream ----
     r.host.set_render_timings(True)
     acc = {}
-    for _ in range(max(1, args.profile_frames)):
+    for _ in range(max(1, args.profile_frames)):       # the scene's own camera: the frame the committed PMC passes profiled
         r.host.camera_update(scene.view, scene.proj, scene.camera_position)
         st = r.host.render(sync=True)
         for k, v in st.items():
             acc[k] = acc.get(k, 0.0) + float(v)
     st = {k: v / max(1, args.profile_frames) for k, v in acc.items()}
-    kernel_ms = {"k_deform_transform": st["ms_transform"], "k_bin": st["ms_bin"], "k_raster_tile": st["ms_raster"], "k_shade": st["ms_shade"]}
+    lean = st.get("ms_shade_lean", 0.0) > 0.0
+    kernel_ms = {"k_deform_transform": st["ms_transform"], "k_bin": st["ms_bin"], "k_raster_tile": st["ms_raster"], "k_shade": st["ms_shade_lean"] if lean else st["ms_shade"]}
+    if st.get("frames_with_dropped_bin_entries", 0) or st.get("bin_overflow_retries", 0):
+        raise SystemExit(f"rank {rank}: the timed loop lost geometry or had to replay frames: {st['frames_with_dropped_bin_entries']} dropped, {st['bin_overflow_retries']} replayed")
     rows_mine = H if world == 1 else (y1s - y0s if strips else len(band_rows(H, world, rank)))
     alg = algorithmic_bytes(scene, {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}, rows_mine)
     dom = max(kernel_ms, key=kernel_ms.get)
-    achieved = alg[dom] / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
-    traffic = pmc_traffic(dom, n_tris, W, H) if world == 1 else None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "launch_ms": kernel_ms[dom],
-                "valu_issue": valu_issue(dom, n_tris, W, H, kernel_ms[dom]) if world == 1 else None,
+    alg_low = alg.pop("k_shade_low")
+    sec = kernel_ms[dom] * 1e-3
+    achieved = alg[dom] / sec / 1e9 if sec > 0 else 0.0
+    achieved_low = (alg_low if dom == "k_shade" else alg[dom]) / sec / 1e9 if sec > 0 else 0.0
+    # HBM bytes and SQ counters of the dominant kernel come from the committed rocprofv3 passes of this same workload (counters cannot be
+    # read from inside the process): profiles/latest_pmc.json, collected by tools/profile_round.sh — profile_tag says which run.
+    prof = pmc_profile(n_tris, W, H) if (world == 1 and args.config == 4 and not args.msaa and not args.mipmap) else None
+    pk = pmc_kernel(prof, dom)
+    valu = valu_issue(pk, kernel_ms[dom])
+    traffic_raw = pk.get("hbm_read_bytes_raw", 0.0) + pk.get("hbm_write_bytes", 0.0) if pk else None
+    roofline = {"bound": "valu_issue" if (valu and valu["frac"] > achieved / HBM_PEAK_GBS) else "hbm",
+                "kernel": ("k_shade_lean" if lean else "k_shade") if dom == "k_shade" else dom,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_hbm_low": achieved_low / HBM_PEAK_GBS, "frac_hbm_high": achieved / HBM_PEAK_GBS,
+                "frac_valu": valu["frac"] if valu else None,
+                "traffic": traffic_raw, "traffic_raw": traffic_raw,
+                "traffic_wide_corrected": (2.0 * pk.get("hbm_read_bytes_raw", 0.0) + pk.get("hbm_write_bytes", 0.0)) if pk else None,
+                "profile_tag": prof.get("tag") if prof else None,
+                "algorithmic_bytes_per_launch": alg[dom], "algorithmic_bytes_per_launch_low": alg_low if dom == "k_shade" else alg[dom],
+                "launch_ms": kernel_ms[dom], "valu_issue": valu,
                 "all_kernels_ms": kernel_ms, "all_kernels_algorithmic_bytes": alg}
 
     cpu = None
@@ -309,15 +387,19 @@ def main():
         out = {
             "metric": "frames/sec + shaded Mpix/s, 4K Sponza glTF, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (procedural scene generated in-repo; no glTF asset is available offline)",
             "shaded_mpix_per_s": W * H * fps / 1e6,
-            "config": {"workload": f"Sponza-class procedural atrium (configs[3]): {n_tris} triangles, {len(scene.materials)} materials, "
+            "config": {"workload": f"{workload_name}: {n_tris} triangles, {len(scene.materials)} materials, "
                                    f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + (", MipmapMode::Gradient" if args.mipmap else ", MipmapMode::None"),
                        "triangles": n_tris, "width": W, "height": H,
                        "sharding": sharding_desc,
                        "draws": len(r.host.draw_list()),
-                       "frame_overlap": not args.no_overlap},
-            "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels")},
+                       "frame_overlap": not args.no_overlap, "camera": "static" if args.static_camera else "orbit, one turn per 240 frames",
+                       "opaque_route": "lean (k_shade_lean + k_shade_todo)" if lean else "general (k_shade)",
+                       "library": os.path.relpath(hip_backend_path(), ROOT)},
+            "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels", "shade_general_wavefronts",
+                                                "frames_with_dropped_bin_entries", "bin_overflow_retries")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             **({"check": check} if check else {}),

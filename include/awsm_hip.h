@@ -148,6 +148,12 @@ typedef struct AwsmFrameStats {
     float ms_forward;           /* transparent pass: transform + binning + k_forward_tile */
     uint32_t forward_triangles; /* sum of tri_count (x instances) over the transparent draws */
     uint32_t forward_fragment_slots; /* fragment-list slots the transparent pass used (fragments + the unused tails of the wavefronts' chunks) */
+    float ms_shade_lean;          /* k_shade_lean alone when the opaque pass took the lean route (then ms_shade = this + k_shade_todo), else 0 */
+    uint32_t shade_general_wavefronts; /* 16x4-pixel groups of the last opaque pass that went through the general kernel instead of the lean one */
+    uint32_t frames_with_dropped_bin_entries; /* enqueue-only frames (no frame_end) whose (triangle, tile) list overflowed since the context was created:
+                                         such a frame lost geometry.  The library sizes the list from the need the GPU reports for earlier
+                                         frames (growing it ahead of the need), so this stays 0 unless the need jumps by more than a third
+                                         between two frames; awsm_hip_frame_end additionally replays an overflowed frame. */
 } AwsmFrameStats;
 
 /* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */
@@ -249,6 +255,9 @@ int awsm_hip_frame_flush(AwsmHipCtx* ctx);
  * current shard layout writes: width*height*8, or bands*32*width*8 with awsm_hip_set_shard_bands(compact_output);
  * checked when the opaque pass is enqueued. ---- */
 int awsm_hip_bind_output(AwsmHipCtx* ctx, void* device_ptr, size_t bytes);
+/* The same for a row-strip shard (awsm_hip_set_shard_rows): device_ptr is where frame row `first_row` goes and `bytes` covers the rows from
+ * there on (width*8 each); the shard's rows must lie inside.  Lets a rank hand in its [rows, width] strip of an all-gather buffer. */
+int awsm_hip_bind_output_rows(AwsmHipCtx* ctx, void* device_ptr, size_t bytes, uint32_t first_row);
 void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
 
 /* ---- readback for parity (new).  keys: width*height u64 (x4 with MSAA: the samples of a pixel are adjacent) =
