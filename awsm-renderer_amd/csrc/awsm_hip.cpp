@@ -82,6 +82,7 @@ struct AwsmHipCtx {
     bool scene_dirty = true;
     DevBuf tex[kMaxTexArrays];
     DevBuf lut;
+    DevBuf cube_tex[3];
 
     // frame targets
     uint32_t width = 0, height = 0;
@@ -281,7 +282,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo.ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    const bool texel_cubes = c->scene.cube[0].texels || c->scene.cube[1].texels || c->scene.cube[2].texels;      // sampled by the general kernels only
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !texel_cubes && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo.ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->draw_lean = lean_ok ? (LeanDrawDev*)FB(c).draw_lean.ptr : nullptr;
@@ -639,7 +641,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); fr(c->digest); fr(c->shade_todo); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); fr(c->shade_todo); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -834,6 +836,34 @@ int awsm_hip_env_upload(AwsmHipCtx* c, const AwsmEnv* env) {
         if (e != hipSuccess) return fail(c, AWSM_ERR_DEVICE, "env_upload: LUT upload failed: %s", hipGetErrorString(e));
         c->scene.lut_w = env->brdf_lut_width; c->scene.lut_h = env->brdf_lut_height;
     }
+    c->scene_dirty = true;
+    return AWSM_OK;
+}
+
+int awsm_hip_env_cube_upload(AwsmHipCtx* c, AwsmCube which, uint32_t size, uint32_t mips, const uint16_t* texels) {
+    if (!c || (int)which < 0 || (int)which > 2) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_cube_upload: bad cube id %d", (int)which);
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
+    CubeDev cd{};
+    if (!texels) {   // back to the uniform colour
+        int rc = sync_all(c);
+        if (rc) return rc;
+        rc = dev_realloc(c, c->cube_tex[which], 0, false);
+        if (rc) return rc;
+        c->scene.cube[which] = cd;
+        c->scene_dirty = true;
+        return AWSM_OK;
+    }
+    if (size == 0 || size > 8192 || mips == 0 || mips > (uint32_t)kMaxMipLevels || mips > mip_levels_full(size, size))
+        return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_cube_upload: %u mip levels of a %u^2 cube (1..8192 per side, at most %u levels)", mips, size, size ? mip_levels_full(size, size) : 0u);
+    size_t total = 0;
+    for (uint32_t l = 0; l < mips; l++) { cd.level_off[l] = (uint32_t)total; const size_t n = std::max(1u, size >> l); total += 6 * n * n; }
+    int rc = dev_realloc(c, c->cube_tex[which], total * 8, false);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->cube_tex[which].ptr, texels, total * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // `texels` is not retained
+    cd.texels = (const uint2*)c->cube_tex[which].ptr; cd.size = size; cd.mips = mips;
+    c->scene.cube[which] = cd;
     c->scene_dirty = true;
     return AWSM_OK;
 }

@@ -94,6 +94,16 @@ struct TexArrayDev {
     uint32_t level_off[kMaxMipLevels];   // first texel of each level
 };
 
+// A cubemap with a mip chain (skybox / prefiltered environment / irradiance: opaque bind group 0, bindings 14-19), RGBA16F texels
+// [level][face][y][x], faces in layer order +X -X +Y -Y +Z -Z.  texels == null: the uniform colour of DevScene (what
+// AwsmRendererBuilder creates by default, lib.rs:176-207).
+struct CubeDev {
+    const uint2* texels;              // 4 halfs per texel
+    uint32_t size, mips;
+    uint32_t level_off[kMaxMipLevels];    // first texel of each level
+};
+enum { kCubeSkybox = 0, kCubePrefiltered = 1, kCubeIrradiance = 2 };
+
 struct DevScene {
     const uint8_t* buf[AWSM_BUF_COUNT];
     TexArrayDev tex[kMaxTexArrays];
@@ -104,6 +114,7 @@ struct DevScene {
     float irradiance_rgb[4];
     const uint16_t* lut_rg16f;
     uint32_t lut_w, lut_h;
+    CubeDev cube[3];
 };
 
 struct TriRec;                                   // raster_setup.hpp (device side); 80 bytes

@@ -464,6 +464,91 @@ AWSM_DI f2 sample_brdf_lut(const DevScene* sc, float n_dot_v, float roughness) {
     return {r_top * gy + r_bot * fy, g_top * gy + g_bot * fy};
 }
 
+
+// ---------------- cubemaps: textureSampleLevel(texture_cube<f32>, linear / linear / linear sampler, direction, level) ----------------
+// (skybox.wgsl:37, brdf.wgsl:268-290).  Contract where WebGPU defers to the hardware: the major axis picks the face (z if |z| >= |x|,|y|,
+// else y if |y| >= |x|, else x — the Vulkan / D3D table, as are sc, tc below); bilinear on the level's N x N faces with texel
+// centres at (i + 0.5) / N; a tap that falls off the face comes from the face across that edge (seamless, kCubeEdge; a corner tap,
+// off in both directions, keeps its row); the level is clamped to the chain and the two nearest levels are blended by its fraction.
+// Continuous in the direction everywhere but at the eight corners, which is what lets a relaxed-arithmetic direction stay in tolerance.
+// kCubeEdge[face][edge: 0 left (i = -1), 1 right (i = N), 2 up (j = -1), 3 down (j = N)] = face' | swap << 3 | flip << 4 | far << 5:
+// the running coordinate k (j for left / right, i for up / down), reversed if flip, becomes j' (swap) or i'; the other one is N - 1 (far) or 0.
+__device__ const uint8_t kCubeEdge[6][4] = {{44, 13, 58, 43}, {45, 12, 10, 27}, {1, 16, 21, 4}, {49, 32, 36, 53}, {41, 8, 34, 3}, {40, 9, 18, 51}};
+AWSM_DI f4 cube_texel(const CubeDev& c, uint32_t level_base, int N, uint32_t face, int i, int j) {
+    if (i < 0 || i >= N) j = min(max(j, 0), N - 1);     // corner taps keep their row
+    if (i < 0 || i >= N || j < 0 || j >= N) {
+        const uint32_t e = i < 0 ? 0u : (i >= N ? 1u : (j < 0 ? 2u : 3u));
+        const uint32_t t = kCubeEdge[face][e];
+        int k = e < 2u ? j : i;
+        if (t & 16u) k = N - 1 - k;
+        const int far = (t & 32u) ? N - 1 : 0;
+        face = t & 7u;
+        if (t & 8u) { i = far; j = k; } else { i = k; j = far; }
+    }
+    const uint2 h = c.texels[level_base + ((size_t)face * (size_t)N + (size_t)j) * (size_t)N + (size_t)i];
+    return {f16_bits_to_f32((unsigned short)(h.x & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.x >> 16)), f16_bits_to_f32((unsigned short)(h.y & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.y >> 16))};
+}
+AWSM_DI f4 cube_level(const CubeDev& c, uint32_t level, f3 d) {
+    const int N = (int)max(c.size >> level, 1u);
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    uint32_t face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = d.z < 0.0f ? 5u : 4u; sc = d.z < 0.0f ? -d.x : d.x; tc = -d.y; ma = az; }
+    else if (ay >= ax) { face = d.y < 0.0f ? 3u : 2u; sc = d.x; tc = d.y < 0.0f ? -d.z : d.z; ma = ay; }
+    else { face = d.x < 0.0f ? 1u : 0u; sc = d.x < 0.0f ? d.z : -d.z; tc = -d.y; ma = ax; }
+    const float inv = fm::rcp(ma);
+    float x = (0.5f * (sc * inv) + 0.5f) * (float)N - 0.5f, y = (0.5f * (tc * inv) + 0.5f) * (float)N - 0.5f;
+    if (!(x >= -0.5f)) x = -0.5f;                 // also NaN (zero / non-finite direction): the face's first texel
+    if (!(y >= -0.5f)) y = -0.5f;
+    x = fminf(x, (float)N - 0.5f); y = fminf(y, (float)N - 0.5f);
+    const float flx = floorf(x), fly = floorf(y), fx = x - flx, fy = y - fly;
+    const int i0 = (int)flx, j0 = (int)fly;
+    const uint32_t base = c.level_off[level];
+    const f4 c00 = cube_texel(c, base, N, face, i0, j0), c10 = cube_texel(c, base, N, face, i0 + 1, j0);
+    const f4 c01 = cube_texel(c, base, N, face, i0, j0 + 1), c11 = cube_texel(c, base, N, face, i0 + 1, j0 + 1);
+    return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
+}
+__device__ __attribute__((noinline)) f4 sample_cube(const CubeDev* cp, f3 d, float level) {
+    const CubeDev& c = *cp;
+    const float top = (float)(c.mips - 1u);
+    float lod = level > 0.0f ? level : 0.0f;          // also NaN
+    lod = fminf(lod, top);
+    const float fl = floorf(lod), fr = lod - fl;
+    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, c.mips - 1u);
+    f4 r = cube_level(c, l0, d);
+    if (fr > 0.0f && l1 != l0) r = lerp4(r, cube_level(c, l1, d), fr);
+    return r;
+}
+// skybox.wgsl:1-41
+AWSM_DI f4 skybox_color(const DevScene* sc, const FrameDev& f, int cx, int cy) {
+    if (!sc->cube[kCubeSkybox].texels) return {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+    const uint8_t* cam = f.camera;
+    const m4 proj = load_m4(reinterpret_cast<const float*>(cam + 64)), inv_proj = load_m4(reinterpret_cast<const float*>(cam + 256)), inv_view = load_m4(reinterpret_cast<const float*>(cam + 320));
+    const float ux = ((float)cx + 0.5f) * fm::rcp((float)f.width), uy = ((float)cy + 0.5f) * fm::rcp((float)f.height);
+    const float nx = ux * 2.0f - 1.0f, ny = 1.0f - uy * 2.0f;
+    f3 ray;
+    if (proj.c[2].w != 0.0f) {
+        const f4 vp = fm::fmul(inv_proj, {nx, ny, 0.0f, 1.0f});
+        const float iw = fm::rcp(vp.w);
+        ray = {vp.x * iw, vp.y * iw, vp.z * iw};
+    } else ray = {nx, ny, -1.0f};
+    const f3 w = {inv_view.c[0].x * ray.x + inv_view.c[1].x * ray.y + inv_view.c[2].x * ray.z, inv_view.c[0].y * ray.x + inv_view.c[1].y * ray.y + inv_view.c[2].y * ray.z,
+                  inv_view.c[0].z * ray.x + inv_view.c[1].z * ray.y + inv_view.c[2].z * ray.z};
+    return sample_cube(&sc->cube[kCubeSkybox], fm::fnormalize(w), 0.0f);
+}
+// brdf.wgsl:268-290
+AWSM_DI f3 sample_irradiance(const DevScene* sc, f3 n) {
+    if (!sc->cube[kCubeIrradiance].texels) return {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
+    const f4 c = sample_cube(&sc->cube[kCubeIrradiance], n, 0.0f);
+    return {c.x, c.y, c.z};
+}
+AWSM_DI f3 sample_prefiltered(const DevScene* sc, f3 dir, float roughness) {
+    if (!sc->cube[kCubePrefiltered].texels) return {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
+    const uint32_t mip_count = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_LIGHTS_INFO])[1];      // IblInfo.prefiltered_env_mip_count (lights.rs:300-305)
+    const f4 c = sample_cube(&sc->cube[kCubePrefiltered], dir, roughness * (float)(mip_count - 1u));
+    return {c.x, c.y, c.z};
+}
+AWSM_DI f3 reflect3(f3 i, f3 n) { return i - n * (2.0f * fm::fdot(n, i)); }
+
 // Per-pixel terms shared by the IBL lobe and every punctual light (brdf_direct recomputes them per light in the WGSL;
 // hoisting them is value-preserving up to rounding).
 struct Surface {
@@ -533,10 +618,10 @@ AWSM_DI f3 brdf_direct(const PbrColor& c, const Surface& sf, f3 l, f3 radiance) 
     return result;
 }
 
-// brdf.wgsl:389-576 (brdf_ibl -> brdf_ibl_with_transmission); the three cubes are uniform colours
+// brdf.wgsl:389-576 (brdf_ibl -> brdf_ibl_with_transmission)
 AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf, f3 transmission_background) {
-    const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
-    const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
+    const f3 prefiltered = sample_prefiltered(sc, reflect3(-sf.v, sf.n), sf.roughness);
+    const f3 irradiance = sample_irradiance(sc, sf.n);
     const float n_dot_v = sf.n_dot_v_ibl;
     const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
     const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
@@ -565,7 +650,8 @@ AWSM_DI f3 brdf_ibl(const DevScene* sc, const PbrColor& c, const Surface& sf, f3
         const float cc_n_dot_v = saturate(fm::fdot(sf.cc_n, sf.v));
         const float cc_roughness = fmaxf(c.clearcoat_roughness, 0.04f);
         const f2 cc_lut = sample_brdf_lut(sc, cc_n_dot_v, cc_roughness);
-        const f3 cc_specular = prefiltered * (kClearcoatF0 * cc_lut.x + cc_lut.y);
+        const f3 cc_prefiltered = sc->cube[kCubePrefiltered].texels ? sample_prefiltered(sc, reflect3(-sf.v, sf.cc_n), cc_roughness) : prefiltered;
+        const f3 cc_specular = cc_prefiltered * (kClearcoatF0 * cc_lut.x + cc_lut.y);
         const float cc_fresnel = clearcoat_fresnel(c.clearcoat, n_dot_v);
         result = result * (1.0f - cc_fresnel) + cc_specular * c.clearcoat;
     }
@@ -797,6 +883,7 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
     const float Wf = (float)f.width, Hf = (float)f.height;
     f2 screen_uv = {frag_x / Wf, frag_y / Hf};
     const float ior_val = ior < 1.0f ? 1.5f : ior;
+    f3 sample_dir = view_dir;            // fragment.wgsl:39,50: direction of the IBL fallback
     if (thickness > 0.0f && ior_val != 1.0f) {
         // brdf.wgsl:30-47 refract_direction
         const float eta = 1.0f / ior_val;
@@ -805,6 +892,7 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
         f3 refracted = {0.0f, 0.0f, 0.0f};
         if (!(k < 0.0f)) refracted = view_dir * eta + normal * (eta * cos_i - sqrtf(k));
         if (fm::fdot(refracted, refracted) > 1e-6f) {
+            sample_dir = refracted;
             const f3 exit = world_position + normalize(refracted) * thickness;
             const m4 view_proj = load_m4(reinterpret_cast<const float*>(f.camera + 128));
             const f4 clip_pos = mul(view_proj, {exit.x, exit.y, exit.z, 1.0f});
@@ -812,7 +900,7 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
         }
     }
     if (!(screen_uv.x >= 0.0f && screen_uv.x <= 1.0f && screen_uv.y >= 0.0f && screen_uv.y <= 1.0f))
-        return {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
+        return sample_prefiltered(sc, sample_dir, roughness);      // fragment.wgsl:68-81
     const float sx = screen_uv.x * Wf, sy = screen_uv.y * Hf;
     const int tx = (int)sx, ty = (int)sy;
     const float blur_roughness = roughness * clampf(ior * 2.0f - 2.0f, 0.0f, 1.0f);
@@ -987,6 +1075,22 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
         return out;
     }
     f3 background = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};   // opaque pass: IBL only (brdf.wgsl:531-561)
+    if (!FWD && sc->cube[kCubePrefiltered].texels && c.transmission * (1.0f - clampf(c.mr.x, 0.0f, 1.0f)) > 0.0f) {
+        // brdf.wgsl:531-561 with a texel cube: straight through, or the refracted direction of a volume
+        const f3 n = fm::fsafe_normalize(c.normal), v = fm::fsafe_normalize(surface_to_camera);
+        f3 dir = -v;
+        const float ior_val = c.ior < 1.0f ? 1.5f : c.ior;
+        if (c.volume_thickness > 0.0f && ior_val != 1.0f) {
+            const float eta = fm::rcp(ior_val);
+            f3 refracted = v;                                            // refract_direction(v, n, eta), brdf.wgsl:30-47
+            if (!(fabsf(eta - 1.0f) < 0.001f)) {
+                const float cos_i = -fm::fdot(v, n), sin_t2 = eta * eta * (1.0f - cos_i * cos_i);
+                refracted = sin_t2 > 1.0f ? mk3(0.0f, 0.0f, 0.0f) : v * eta + n * (eta * cos_i - sqrtf(1.0f - sin_t2));
+            }
+            if (fm::fdot(refracted, refracted) > 1e-6f) dir = refracted;
+        }
+        background = sample_prefiltered(sc, dir, fmaxf(clampf(c.mr.y, 0.0f, 1.0f), 0.04f));
+    }
     if (FWD) {     // fragment.wgsl:245-270: screen-space transmission from the opaque image
         const float metallic = clampf(c.mr.x, 0.0f, 1.0f);
         if (c.transmission * (1.0f - metallic) > 0.0f)
@@ -1441,10 +1545,8 @@ AWSM_DI void shade_pixel(const DevScene* __restrict__ sc, const FrameDev& f, con
     if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
     const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
     const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
-    const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};   // skybox.wgsl:1-41, uniform cube
-
     const unsigned long long key = f.vis[pv];
-    if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, sky); return; }   // compute.wgsl:149-153 / empty.wgsl
+    if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, skybox_color(sc, f, cx, cy)); return; }   // compute.wgsl:149-153 / empty.wgsl, skybox.wgsl:1-41
     const uint32_t rank = key_rank(key);
     const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
     const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
@@ -1850,7 +1952,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     uint8_t* edge_rec = reinterpret_cast<uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     bool is_edge = false;
     if (inside) {
-        const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+        const f4 sky = skybox_color(sc, f, cx, cy);
         const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
         if (!f.has_opaque || !any_hit) {
             store_pixel(f, p, sky);                                        // compute.wgsl:121-143
@@ -1912,7 +2014,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __re
     const ulonglong2 ka = kp[0], kb = kp[1];
     const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
     const float depth0 = key_depth(k4[0]);
-    const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+    const f4 sky = skybox_color(sc, f, cx, cy);
     const float4 c0v = f.msaa_color0[p];
     f4 col[4];
     col[0] = {c0v.x, c0v.y, c0v.z, c0v.w};

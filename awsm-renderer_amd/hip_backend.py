@@ -30,7 +30,7 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
-           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows"]
+           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload"]
 
 
 class AwsmConfig(C.Structure):
@@ -107,6 +107,7 @@ def load_library():
     lib.awsm_hip_texture_array_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     lib.awsm_hip_sampler_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.awsm_hip_env_upload.argtypes = [C.c_void_p, C.c_void_p]
+    lib.awsm_hip_env_cube_upload.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.awsm_hip_brdf_lut_generate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.awsm_hip_read_brdf_lut.argtypes = [C.c_void_p, C.c_void_p]
     lib.awsm_hip_read_visibility.argtypes = [C.c_void_p, C.c_void_p]
@@ -226,6 +227,14 @@ class HipDevice:
         smp = AwsmSampler(s.get("address_mode_u", 1), s.get("address_mode_v", 1), s.get("mag_filter", 1), s.get("min_filter", 1),
                           s.get("mipmap_filter", 1), s.get("max_anisotropy", 1))
         self._chk(self.lib.awsm_hip_sampler_set(self.ctx, index, C.byref(smp)), "sampler_set")
+
+    def env_cube_upload(self, which: int, levels):
+        """levels: [level0, level1, ...] of (6, N_l, N_l, 4) float16 (faces +X -X +Y -Y +Z -Z), or None for the uniform colour."""
+        if not levels:
+            self._chk(self.lib.awsm_hip_env_cube_upload(self.ctx, which, 0, 0, None), "env_cube_upload")
+            return
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(a, dtype=np.float16).reshape(-1) for a in levels])).view(np.uint16)
+        self._chk(self.lib.awsm_hip_env_cube_upload(self.ctx, which, levels[0].shape[1], len(levels), flat.ctypes.data), "env_cube_upload")
 
     def env_upload(self, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), lut_rgba16f: Optional[np.ndarray] = None):
         env = AwsmEnv()

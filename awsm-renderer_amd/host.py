@@ -83,6 +83,7 @@ def load_library():
         "awsm_host_light_insert": (u64, [vp, vp]), "awsm_host_light_remove": (C.c_int, [vp, u64]),
         "awsm_host_set_ibl_mip_counts": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_camera_update": (C.c_int, [vp, F32P, F32P, F32P]), "awsm_host_env": (C.c_int, [vp, vp]),
+        "awsm_host_env_cube": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, vp]),
         "awsm_host_brdf_lut_generate": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_resize": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_set_render_timings": (C.c_int, [vp, C.c_int]),
         "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
@@ -279,6 +280,14 @@ class Host:
             env.brdf_lut_height, env.brdf_lut_width = keep.shape[0], keep.shape[1]
             env.brdf_lut_rgba16f = keep.ctypes.data
         self._chk(self.lib.awsm_host_env(self.h, C.byref(env)), "env")
+
+    def env_cube(self, which: int, levels):
+        """levels: [level0, ...] of (6, N_l, N_l, 4) float16 (faces +X -X +Y -Y +Z -Z), or None."""
+        if not levels:
+            self._chk(self.lib.awsm_host_env_cube(self.h, which, 0, 0, None), "env_cube")
+            return
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(a, dtype=np.float16).reshape(-1) for a in levels])).view(np.uint16)
+        self._chk(self.lib.awsm_host_env_cube(self.h, which, levels[0].shape[1], len(levels), flat.ctypes.data), "env_cube")
 
     def brdf_lut_generate(self, w: int, h: int):
         self._chk(self.lib.awsm_host_brdf_lut_generate(self.h, w, h), "brdf_lut_generate")
@@ -531,6 +540,9 @@ class Renderer:
         else:
             self.host.env(scene.skybox_rgba, scene.prefiltered_rgb, scene.irradiance_rgb)
             self.host.brdf_lut_generate(lut_size, lut_size)   # BrdfLut::new at build() time (renderer-core brdf_lut/generate.rs)
+        for k, name in enumerate(("skybox", "prefiltered", "irradiance")):
+            if scene.env_cubes and scene.env_cubes.get(name):
+                self.host.env_cube(k, scene.env_cubes[name])
         self.update()
 
     def update(self):

@@ -53,6 +53,7 @@ struct Backend {
     int (*texture_array_generate_mips)(AwsmHipCtx*, uint32_t, const uint32_t*) = nullptr;
     int (*sampler_set)(AwsmHipCtx*, uint32_t, const AwsmSampler*) = nullptr;
     int (*env_upload)(AwsmHipCtx*, const AwsmEnv*) = nullptr;
+    int (*env_cube_upload)(AwsmHipCtx*, AwsmCube, uint32_t, uint32_t, const uint16_t*) = nullptr;
     int (*brdf_lut_generate)(AwsmHipCtx*, uint32_t, uint32_t) = nullptr;
     int (*geometry_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
     int (*opaque_pass)(AwsmHipCtx*, const AwsmOpaqueParams*) = nullptr;
@@ -466,7 +467,7 @@ int awsm_host_create(const char* backend_path, int device, void* stream, uint32_
               load_sym(h.get(), b.buffer_create, "awsm_hip_buffer_create") && load_sym(h.get(), b.buffer_write, "awsm_hip_buffer_write") &&
               load_sym(h.get(), b.resize, "awsm_hip_resize") && load_sym(h.get(), b.set_shard_rows, "awsm_hip_set_shard_rows") && load_sym(h.get(), b.set_shard_bands, "awsm_hip_set_shard_bands") && load_sym(h.get(), b.set_stage_timers, "awsm_hip_set_stage_timers") && load_sym(h.get(), b.pick, "awsm_hip_pick") &&
               load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.texture_array_generate_mips, "awsm_hip_texture_array_generate_mips") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
-              load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
+              load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.env_cube_upload, "awsm_hip_env_cube_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
               load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") && load_sym(h.get(), b.transparent_pass, "awsm_hip_transparent_pass") &&
               load_sym(h.get(), b.frame_end, "awsm_hip_frame_end");
     if (!ok) { fprintf(stderr, "awsm_host: %s\n", h->last_error.c_str()); dlclose(b.dl); return AWSM_ERR_NOT_READY; }
@@ -866,6 +867,11 @@ int awsm_host_camera_update(AwsmHost* h, const float view[16], const float proje
     return AWSM_OK;
 }
 
+// Environment / Ibl texture swap (environment.rs, lights/ibl.rs: the cubes a caller loaded from KTX2 / EXR replace the builder's colours)
+int awsm_host_env_cube(AwsmHost* h, AwsmCube which, uint32_t size, uint32_t mips, const uint16_t* texels_rgba16f) {
+    int rc = h->be.env_cube_upload(h->ctx, which, size, mips, texels_rgba16f);
+    return rc ? dev_fail(h, rc, "env_cube_upload") : AWSM_OK;
+}
 int awsm_host_env(AwsmHost* h, const AwsmEnv* env) { int rc = h->be.env_upload(h->ctx, env); return rc ? dev_fail(h, rc, "env_upload") : AWSM_OK; }
 int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t ht) { int rc = h->be.brdf_lut_generate(h->ctx, w, ht); return rc ? dev_fail(h, rc, "brdf_lut_generate") : AWSM_OK; }
 int awsm_host_resize(AwsmHost* h, uint32_t w, uint32_t ht) {

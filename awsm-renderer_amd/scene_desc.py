@@ -106,6 +106,8 @@ class SceneDesc:
     skybox_rgba: Tuple[float, float, float, float] = (0, 0, 0, 1)
     prefiltered_rgb: Tuple[float, float, float] = (1, 1, 1)
     irradiance_rgb: Tuple[float, float, float] = (1, 1, 1)
+    env_cubes: Optional[dict] = None  # texel cubemaps: {"skybox" | "prefiltered" | "irradiance": [level0, level1, ...]}, each level (6, N_l, N_l, 4) float16,
+                                      # faces +X -X +Y -Y +Z -Z; a missing entry keeps the uniform colour above
     prefiltered_mip_count: int = 9   # 256^2 cube with a full chain
     irradiance_mip_count: int = 9
     lut_size: int = 64

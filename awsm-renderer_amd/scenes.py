@@ -378,6 +378,42 @@ def atrium_scene(width=3840, height=2160, detail=1.0, tex_scale=1.0, seed=0xA35A
                      view=look_at_rh(eye, target), proj=perspective_rh(math.radians(60), width / height, 0.1, 100.0), camera_position=eye)
 
 
+def cube_face_directions(n: int) -> np.ndarray:
+    """(6, n, n, 3) unit directions through the texel centres of a cube's faces, layer order +X -X +Y -Y +Z -Z, with the (sc, tc)
+    parametrisation WebGPU / Vulkan / D3D share (s, t = (i + 0.5) / n; row 0 is the top of the image)."""
+    c = (np.arange(n, dtype=np.float64) + 0.5) / n * 2.0 - 1.0
+    sc, tc = np.meshgrid(c, c)                      # sc varies along x (columns), tc along y (rows)
+    one = np.ones_like(sc)
+    faces = [(one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one)]
+    d = np.stack([np.stack(f, axis=-1) for f in faces])
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def procedural_environment(size: int = 64, irradiance_size: int = 16, seed: int = 0xA35A0008) -> dict:
+    """A non-uniform HDR environment for the texel-cubemap path: sky gradient, a sun lobe far above 1.0, coloured bands and a darker
+    ground.  Not a physically prefiltered set — the renderer only samples these cubes; what is in them does not matter for parity:
+    skybox one level, "prefiltered" a full chain whose lobes widen per level, irradiance a small smooth cube."""
+    rng = np.random.default_rng(seed)
+    sun = np.array([0.35, 0.75, -0.55]); sun /= np.linalg.norm(sun)
+    tint = rng.uniform(0.6, 1.0, size=(3, 3))
+
+    def radiance(d, sharp):
+        y = d[..., 1:2]
+        up = np.clip(y * 0.5 + 0.5, 0.0, 1.0)
+        sky = (1.0 - up) * np.array([0.9, 0.75, 0.6]) + up * np.array([0.15, 0.35, 0.9])
+        ground = np.array([0.18, 0.14, 0.10]) * (1.0 + 0.5 * np.sin(6.0 * d[..., 0:1]) * np.cos(5.0 * d[..., 2:3]))
+        base = np.where(y > 0.0, sky, ground)
+        bands = 0.25 * (np.sin(9.0 * d[..., 0:1] + 1.0) * tint[0] + np.sin(7.0 * d[..., 2:3] + 2.0) * tint[1] + np.sin(5.0 * d[..., 1:2]) * tint[2]) / max(1.0, 16.0 / sharp)
+        lobe = np.exp(-sharp * (1.0 - np.clip((d * sun).sum(axis=-1, keepdims=True), -1.0, 1.0)))
+        rgb = np.clip(base + bands, 0.0, None) + lobe * np.array([30.0, 26.0, 20.0]) * min(1.0, sharp / 64.0)
+        return np.concatenate([rgb, np.ones_like(y)], axis=-1).astype(np.float16)
+
+    levels = int(math.log2(size)) + 1
+    return {"skybox": [radiance(cube_face_directions(size), 256.0)],
+            "prefiltered": [radiance(cube_face_directions(max(size >> l, 1)), 256.0 / (4.0 ** l)) for l in range(levels)],
+            "irradiance": [radiance(cube_face_directions(irradiance_size), 1.5)]}
+
+
 def total_triangles(scene: SceneDesc) -> int:
     return int(sum(np.asarray(p.indices).reshape(-1, 3).shape[0] for n in scene.nodes for p in n.primitives))
 

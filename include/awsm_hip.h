@@ -124,8 +124,8 @@ typedef struct AwsmSampler {
 
 /* Environment: skybox + IBL cubes + BRDF LUT (opaque bind group 0, bindings 14-21:
  * crates/renderer/src/render_passes/material_opaque/shader/material_opaque_wgsl/bind_groups.wgsl:22-29).
- * Round 1 supports uniform-colour cubes (what AwsmRendererBuilder creates by default,
- * crates/renderer/src/lib.rs:176-207); texel cubemaps return AWSM_ERR_UNSUPPORTED. */
+ * The three colours are the uniform cubes AwsmRendererBuilder creates by default (crates/renderer/src/lib.rs:176-207);
+ * texel cubemaps go through awsm_hip_env_cube_upload. */
 typedef struct AwsmEnv {
     float skybox_rgba[4];
     float prefiltered_rgb[4];
@@ -210,6 +210,14 @@ int awsm_hip_texture_array_generate_mips(AwsmHipCtx* ctx, uint32_t array_idx, co
 int awsm_hip_texture_array_read_level(AwsmHipCtx* ctx, uint32_t array_idx, uint32_t level, void* texels_out);
 int awsm_hip_sampler_set(AwsmHipCtx* ctx, uint32_t sampler_idx, const AwsmSampler* sampler);
 int awsm_hip_env_upload(AwsmHipCtx* ctx, const AwsmEnv* env);
+/* Texel cubemaps for the same three bindings (skybox_tex, ibl_filtered_env_tex, ibl_irradiance_tex: bind_groups.wgsl:22-27; sampled by
+ * helpers/skybox.wgsl:37 and shared_wgsl/lighting/brdf.wgsl:268-290 with the linear / linear / linear clamp samplers of lights/ibl.rs:38-47).
+ * texels: RGBA16F, [mip][face][y][x][4 halfs], mip m has extent max(size >> m, 1), faces in layer order +X -X +Y -Y +Z -Z (what
+ * CubemapImage::create_texture_and_view uploads; decoding KTX2 / EXR files is the caller's business).  mips = levels present (>= 1).
+ * texels == NULL returns the binding to the uniform colour of awsm_hip_env_upload.  The prefiltered lookup's level is
+ * roughness * (IblInfo.prefiltered_env_mip_count - 1) with the count the host wrote into AWSM_BUF_LIGHTS_INFO, clamped to the chain. */
+typedef enum AwsmCube { AWSM_CUBE_SKYBOX = 0, AWSM_CUBE_PREFILTERED = 1, AWSM_CUBE_IRRADIANCE = 2 } AwsmCube;
+int awsm_hip_env_cube_upload(AwsmHipCtx* ctx, AwsmCube which, uint32_t size, uint32_t mips, const uint16_t* texels_rgba16f);
 
 /* ---- BrdfLut::new (crates/renderer-core/src/brdf_lut/generate.rs:47-96 + shader.wgsl): renders the
  * split-sum LUT on the device into the ctx's LUT slot (RGBA16F semantics, RG kept). ---- */

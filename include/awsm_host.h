@@ -125,6 +125,10 @@ int awsm_host_camera_update(AwsmHost* h, const float view[16], const float proje
 
 /* ---- environment pass-through + targets ---- */
 int awsm_host_env(AwsmHost* h, const AwsmEnv* env);
+/* Skybox / Ibl::{prefiltered_env, irradiance} set to a texel cubemap (crates/renderer/src/environment.rs:79-140, lights/ibl.rs:13-96): RGBA16F
+ * [mip][face][y][x][4], faces +X -X +Y -Y +Z -Z; NULL = back to the colour.  The mip counts the shader scales roughness by are the ones of
+ * awsm_host_set_ibl_mip_counts (lights.rs:300-305). */
+int awsm_host_env_cube(AwsmHost* h, AwsmCube which, uint32_t size, uint32_t mips, const uint16_t* texels_rgba16f);
 int awsm_host_brdf_lut_generate(AwsmHost* h, uint32_t w, uint32_t height);
 int awsm_host_resize(AwsmHost* h, uint32_t width, uint32_t height);
 /* AwsmRenderer::set_anti_aliasing (anti_alias.rs:9-45): msaa_sample_count 0 (None) or 4 (recreates the render targets);

@@ -29,6 +29,12 @@ typedef struct OracleTexArray {
     uint32_t mips;           /* 0/1 = level 0 only */
 } OracleTexArray;
 
+/* texture_cube<f32> with a mip chain: RGBA16F [level][face][y][x][4], faces +X -X +Y -Y +Z -Z; texels == NULL: the uniform colour */
+typedef struct OracleCube {
+    const uint16_t* texels;
+    uint32_t size, mips;
+} OracleCube;
+
 typedef struct OracleScene {
     const uint8_t* buf[AWSM_BUF_COUNT];
     uint64_t buf_size[AWSM_BUF_COUNT];
@@ -48,6 +54,7 @@ typedef struct OracleScene {
     uint32_t lut_width, lut_height;
     uint32_t msaa;                   /* 0 (single sample) or 4: keys hold 4 samples per pixel, [pixel][sample] */
     uint32_t mipmap;                 /* 0 = MipmapMode::None, 1 = MipmapMode::Gradient */
+    OracleCube cube[3];              /* 0 skybox, 1 prefiltered environment, 2 irradiance */
 } OracleScene;
 
 /* vert_main for every exploded vertex of every draw, in draw order.

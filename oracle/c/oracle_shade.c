@@ -590,9 +590,77 @@ static float sheen_albedo_scaling(ovec3 sheen_color, float sheen_roughness, floa
     return 1.0f - sheen_max * E;
 }
 
-/* textureSampleLevel on the uniform-colour cubes the builder creates (crates/renderer/src/lib.rs:176-207) */
-static ovec3 sample_irradiance(const OracleScene* s) { return ov3(s->irradiance_rgb[0], s->irradiance_rgb[1], s->irradiance_rgb[2]); }
-static ovec3 sample_prefiltered(const OracleScene* s) { return ov3(s->prefiltered_rgb[0], s->prefiltered_rgb[1], s->prefiltered_rgb[2]); }
+/* ---- cubemaps: textureSampleLevel(texture_cube, linear / linear / linear clamp sampler, direction, level) — skybox.wgsl:37,
+ * brdf.wgsl:268-290.  The contract where WebGPU defers to the hardware (DESIGN.md "Cubemaps"): face by major axis (z if |z| >= |x|, |y|,
+ * else y if |y| >= |x|, else x; sc / tc as in the Vulkan and D3D tables), bilinear over texel centres (i + 0.5) / N, taps beyond a face edge
+ * fetched from the adjacent face (seamless; a corner tap keeps its row), level clamped to the chain, the two nearest levels blended.
+ * CUBE_EDGE[face][edge 0 left, 1 right, 2 up, 3 down] = face' | swap << 3 | flip << 4 | far << 5 (derived from the face parametrisation:
+ * the texel whose centre is the unfolded position of the missing tap). ---- */
+static const uint8_t CUBE_EDGE[6][4] = {{44, 13, 58, 43}, {45, 12, 10, 27}, {1, 16, 21, 4}, {49, 32, 36, 53}, {41, 8, 34, 3}, {40, 9, 18, 51}};
+static ovec4 cube_texel(const OracleCube* c, size_t level_base, int N, uint32_t face, int i, int j) {
+    if (i < 0 || i >= N) { if (j < 0) j = 0; if (j > N - 1) j = N - 1; }
+    if (i < 0 || i >= N || j < 0 || j >= N) {
+        const uint32_t e = i < 0 ? 0u : (i >= N ? 1u : (j < 0 ? 2u : 3u));
+        const uint32_t t = CUBE_EDGE[face][e];
+        int k = e < 2u ? j : i;
+        if (t & 16u) k = N - 1 - k;
+        const int far_ = (t & 32u) ? N - 1 : 0;
+        face = t & 7u;
+        if (t & 8u) { i = far_; j = k; } else { i = k; j = far_; }
+    }
+    const uint16_t* p = c->texels + (level_base + ((size_t)face * (size_t)N + (size_t)j) * (size_t)N + (size_t)i) * 4;
+    return ov4(o_f16_to_f32(p[0]), o_f16_to_f32(p[1]), o_f16_to_f32(p[2]), o_f16_to_f32(p[3]));
+}
+static ovec4 ov4_lerp(ovec4 a, ovec4 b, float t) { float s = 1.0f - t; return ov4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t); }
+static ovec4 cube_level(const OracleCube* c, uint32_t level, ovec3 d) {
+    size_t base = 0;
+    for (uint32_t l = 0; l < level; l++) { size_t n = (c->size >> l) ? (c->size >> l) : 1; base += 6 * n * n; }
+    const int N = (int)((c->size >> level) ? (c->size >> level) : 1);
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    uint32_t face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = d.z < 0.0f ? 5u : 4u; sc = d.z < 0.0f ? -d.x : d.x; tc = -d.y; ma = az; }
+    else if (ay >= ax) { face = d.y < 0.0f ? 3u : 2u; sc = d.x; tc = d.y < 0.0f ? -d.z : d.z; ma = ay; }
+    else { face = d.x < 0.0f ? 1u : 0u; sc = d.x < 0.0f ? d.z : -d.z; tc = -d.y; ma = ax; }
+    float x = (0.5f * (sc / ma) + 0.5f) * (float)N - 0.5f, y = (0.5f * (tc / ma) + 0.5f) * (float)N - 0.5f;
+    if (!(x >= -0.5f)) x = -0.5f;
+    if (!(y >= -0.5f)) y = -0.5f;
+    x = fminf(x, (float)N - 0.5f); y = fminf(y, (float)N - 0.5f);
+    const float flx = floorf(x), fly = floorf(y), fx = x - flx, fy = y - fly;
+    const int i0 = (int)flx, j0 = (int)fly;
+    const ovec4 c00 = cube_texel(c, base, N, face, i0, j0), c10 = cube_texel(c, base, N, face, i0 + 1, j0);
+    const ovec4 c01 = cube_texel(c, base, N, face, i0, j0 + 1), c11 = cube_texel(c, base, N, face, i0 + 1, j0 + 1);
+    return ov4_lerp(ov4_lerp(c00, c10, fx), ov4_lerp(c01, c11, fx), fy);
+}
+static ovec4 sample_cube(const OracleCube* c, ovec3 d, float level) {
+    const float top = (float)(c->mips - 1u);
+    float lod = level > 0.0f ? level : 0.0f;
+    lod = fminf(lod, top);
+    const float fl = floorf(lod), fr = lod - fl;
+    const uint32_t l0 = (uint32_t)fl, l1 = (l0 + 1u < c->mips) ? l0 + 1u : c->mips - 1u;
+    ovec4 r = cube_level(c, l0, d);
+    if (fr > 0.0f && l1 != l0) r = ov4_lerp(r, cube_level(c, l1, d), fr);
+    return r;
+}
+/* the oracle's view of cube sampling for tests (oracle_lib.sample_cube) */
+void oracle_sample_cube(const OracleCube* c, const float* dirs, const float* levels, uint32_t n, float* rgba_out) {
+    for (uint32_t i = 0; i < n; i++) {
+        ovec4 r = sample_cube(c, ov3(dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]), levels[i]);
+        rgba_out[i * 4] = r.x; rgba_out[i * 4 + 1] = r.y; rgba_out[i * 4 + 2] = r.z; rgba_out[i * 4 + 3] = r.w;
+    }
+}
+
+/* brdf.wgsl:268-290 sampleIrradiance / samplePrefilteredEnv (uniform-colour cubes when no texels were provided: lib.rs:176-207) */
+static ovec3 sample_irradiance(const OracleScene* s, ovec3 n) {
+    if (!s->cube[2].texels) return ov3(s->irradiance_rgb[0], s->irradiance_rgb[1], s->irradiance_rgb[2]);
+    ovec4 c = sample_cube(&s->cube[2], n, 0.0f);
+    return ov3(c.x, c.y, c.z);
+}
+static ovec3 sample_prefiltered(const OracleScene* s, ovec3 dir, float roughness) {
+    if (!s->cube[1].texels) return ov3(s->prefiltered_rgb[0], s->prefiltered_rgb[1], s->prefiltered_rgb[2]);
+    const uint32_t mip_count = ((const uint32_t*)s->buf[AWSM_BUF_LIGHTS_INFO])[1];       /* IblInfo.prefiltered_env_mip_count */
+    ovec4 c = sample_cube(&s->cube[1], dir, roughness * (float)(mip_count - 1u));
+    return ov3(c.x, c.y, c.z);
+}
 
 /* brdf.wgsl:293-302 sampleBRDFLUT: linear filter, clamp-to-edge (renderer-core/src/brdf_lut/generate.rs:150-170) */
 static ovec2 sample_brdf_lut(const OracleScene* s, float n_dot_v, float roughness) {
@@ -674,7 +742,7 @@ static ovec3 brdf_ibl_with_transmission(const OracleScene* s, const PbrColor* co
     float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
     float effective_transmission = color->transmission * (1.0f - metallic);
     ovec3 base_layer;
-    ovec3 irradiance = sample_irradiance(s);
+    ovec3 irradiance = sample_irradiance(s, n);
     if (effective_transmission > 0.0f) {
         ovec3 diffuse_brdf = ov3_mul(ov3_scale(base_color, 1.0f / O_PI), irradiance);
         ovec3 attenuation = ov3s(1.0f);
@@ -687,15 +755,15 @@ static ovec3 brdf_ibl_with_transmission(const OracleScene* s, const PbrColor* co
     }
     float k_d = (1.0f - F_view_max) * (1.0f - metallic);
     ovec3 base_contribution = ov3_scale(ov3_scale(base_layer, k_d), color->occlusion);
-    (void)o_reflect;   /* R only selects the cube texel; the cubes are uniform */
-    ovec3 prefiltered = sample_prefiltered(s);
+    ovec3 R = o_reflect(ov3_scale(v, -1.0f), n);
+    ovec3 prefiltered = sample_prefiltered(s, R, roughness);
     ovec2 lut = sample_brdf_lut(s, n_dot_v, roughness);
     ovec3 spec_term = ov3_add(ov3_scale(F0, lut.x), ov3s(f90 * lut.y));
     ovec3 specular = ov3_scale(ov3_mul(prefiltered, spec_term), o_mix(1.0f, color->occlusion, 0.5f));
     float sheen_scaling = sheen_albedo_scaling(color->sheen_color, color->sheen_roughness, n_dot_v);
     ovec3 base_with_sheen = ov3_scale(base_contribution, sheen_scaling);
     if (color->sheen_color.x > 0.0f || color->sheen_color.y > 0.0f || color->sheen_color.z > 0.0f) {
-        ovec3 irradiance_sheen = sample_irradiance(s);
+        ovec3 irradiance_sheen = sample_irradiance(s, n);
         float alpha = color->sheen_roughness * color->sheen_roughness;
         float fresnel_sheen = powf(1.0f - n_dot_v, 3.0f);
         ovec3 sheen_contrib = ov3_scale(ov3_scale(ov3_scale(ov3_mul(color->sheen_color, irradiance_sheen), alpha), fresnel_sheen), color->occlusion);
@@ -706,7 +774,7 @@ static ovec3 brdf_ibl_with_transmission(const OracleScene* s, const PbrColor* co
         ovec3 cc_n = o_safe_normalize(color->clearcoat_normal);
         float cc_n_dot_v = o_saturate(ov3_dot(cc_n, v));
         float cc_roughness = fmaxf(color->clearcoat_roughness, 0.04f);
-        ovec3 cc_prefiltered = sample_prefiltered(s);
+        ovec3 cc_prefiltered = sample_prefiltered(s, o_reflect(ov3_scale(v, -1.0f), cc_n), cc_roughness);
         ovec2 cc_lut = sample_brdf_lut(s, cc_n_dot_v, cc_roughness);
         ovec3 cc_specular = ov3_scale(cc_prefiltered, CLEARCOAT_F0 * cc_lut.x + cc_lut.y);
         float cc_fresnel = clearcoat_fresnel(color->clearcoat, n_dot_v);
@@ -720,11 +788,15 @@ static ovec3 brdf_ibl(const OracleScene* s, const PbrColor* color, ovec3 normal,
     ovec3 transmission_background = ov3(0, 0, 0);
     float effective_transmission = color->transmission * (1.0f - o_clamp(color->metallic_roughness.x, 0.0f, 1.0f));
     if (effective_transmission > 0.0f) {
-        /* direction only selects the texel of a uniform cube; refract_direction kept for completeness */
         ovec3 n = o_safe_normalize(normal), v = o_safe_normalize(surface_to_camera);
+        float roughness = fmaxf(o_clamp(color->metallic_roughness.y, 0.0f, 1.0f), 0.04f);
+        ovec3 sample_dir = ov3_scale(v, -1.0f);
         float ior_val = effective_ior(color->ior);
-        if (color->volume_thickness > 0.0f && ior_val != 1.0f) (void)refract_direction(v, n, 1.0f / ior_val);
-        transmission_background = sample_prefiltered(s);
+        if (color->volume_thickness > 0.0f && ior_val != 1.0f) {
+            ovec3 refracted = refract_direction(v, n, 1.0f / ior_val);
+            if (ov3_dot(refracted, refracted) > 1e-6f) sample_dir = refracted;
+        }
+        transmission_background = sample_prefiltered(s, sample_dir, roughness);
     }
     return brdf_ibl_with_transmission(s, color, normal, surface_to_camera, transmission_background);
 }
@@ -949,11 +1021,28 @@ static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const
     return out;
 }
 
+/* skybox.wgsl:1-41 sample_skybox */
+static ovec4 skybox_color(const OracleScene* s, int cx, int cy) {
+    if (!s->cube[0].texels) return ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
+    const uint8_t* cam = s->buf[AWSM_BUF_CAMERA];
+    omat4 proj = omat4_load((const float*)(cam + 64)), inv_proj = omat4_load((const float*)(cam + 256)), inv_view = omat4_load((const float*)(cam + 320));
+    const float ux = ((float)cx + 0.5f) / (float)s->width, uy = ((float)cy + 0.5f) / (float)s->height;
+    const float nx = ux * 2.0f - 1.0f, ny = 1.0f - uy * 2.0f;
+    ovec3 ray;
+    if (proj.c[2].w != 0.0f) {
+        ovec4 vp = omat4_mul_v4(&inv_proj, ov4(nx, ny, 0.0f, 1.0f));
+        ray = ov3(vp.x / vp.w, vp.y / vp.w, vp.z / vp.w);
+    } else ray = ov3(nx, ny, -1.0f);
+    ovec3 w = ov3((inv_view.c[0].x * ray.x + inv_view.c[1].x * ray.y) + inv_view.c[2].x * ray.z, (inv_view.c[0].y * ray.x + inv_view.c[1].y * ray.y) + inv_view.c[2].y * ray.z,
+                  (inv_view.c[0].z * ray.x + inv_view.c[1].z * ray.y) + inv_view.c[2].z * ray.z);
+    return sample_cube(&s->cube[0], ov3_normalize(w), 0.0f);
+}
+
 /* compute.wgsl:100-322 for one pixel, single-sampled */
 static void shade_pixel(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys,
                         int cx, int cy, float* rgba32f, uint16_t* rgba16f) {
     size_t p = (size_t)cy * s->width + (size_t)cx;
-    ovec4 sky = ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
+    ovec4 sky = skybox_color(s, cx, cy);
     uint64_t key = keys[p];
     if (!s->has_opaque || key == ~0ull) { store_pixel(rgba32f, rgba16f, p, sky); return; }   /* compute.wgsl:149-153; empty.wgsl */
     uint32_t rank = O_U32_MAX - (uint32_t)(key & 0xFFFFFFFFull);
@@ -1034,11 +1123,12 @@ static void msaa_resolve(const OracleScene* s, const float* clip, const float* n
     ovec3 color_sum = ov3(0.0f, 0.0f, 0.0f); float alpha_sum = 0.0f; uint32_t valid = 0;
     for (int sidx = 0; sidx < 4; sidx++) {
         if (k4[sidx] == ~0ull) {   /* sample hit background: skybox colour */
-            color_sum = ov3_add(color_sum, ov3(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2])); alpha_sum += s->skybox_rgba[3]; valid++;
+            const ovec4 sky = skybox_color(s, cx, cy);
+            color_sum = ov3_add(color_sum, ov3(sky.x, sky.y, sky.z)); alpha_sum += sky.w; valid++;
             continue;
         }
         SurfaceColor c = shade_surface(s, clip, nt, key_rank(k4[sidx]), cx, cy, depth0, 0);   /* no hud test per sample */
-        if (c.kind == 3) { c.color = ov3(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2]); c.alpha = s->skybox_rgba[3]; }
+        if (c.kind == 3) { const ovec4 sky = skybox_color(s, cx, cy); c.color = ov3(sky.x, sky.y, sky.z); c.alpha = sky.w; }
         color_sum = ov3_add(color_sum, c.color); alpha_sum += c.alpha; valid++;
     }
     const float n = (float)valid;
@@ -1050,7 +1140,7 @@ static void shade_pixel_msaa(const OracleScene* s, const float* clip, const floa
     const uint32_t W = s->width, H = s->height;
     const size_t p = (size_t)cy * W + (size_t)cx;
     const uint64_t* k4 = keys + p * 4;
-    ovec4 sky = ov4(s->skybox_rgba[0], s->skybox_rgba[1], s->skybox_rgba[2], s->skybox_rgba[3]);
+    ovec4 sky = skybox_color(s, cx, cy);
     const int any_hit = k4[0] != ~0ull || k4[1] != ~0ull || k4[2] != ~0ull || k4[3] != ~0ull;
     if (!s->has_opaque || !any_hit) { store_pixel(rgba32f, rgba16f, p, sky); return; }          /* compute.wgsl:121-143 */
     if (k4[0] == ~0ull) { msaa_resolve(s, clip, nt, k4, cx, cy, rgba32f, rgba16f, p); return; }   /* compute.wgsl:155-170 */
@@ -1103,9 +1193,11 @@ static ovec3 sample_transmission_background(const OracleScene* s, const uint16_t
     const float Wf = (float)s->width, Hf = (float)s->height;
     ovec2 screen_uv = ov2(frag_x / Wf, frag_y / Hf);
     const float ior_val = effective_ior(ior);
+    ovec3 sample_dir = view_dir;         /* fragment.wgsl:39,50 */
     if (thickness > 0.0f && ior_val != 1.0f) {
         ovec3 refracted = refract_direction(view_dir, normal, 1.0f / ior_val);
         if (ov3_dot(refracted, refracted) > 1e-6f) {
+            sample_dir = refracted;
             ovec3 exit = ov3_add(world_position, ov3_scale(ov3_normalize(refracted), thickness));
             ovec4 clip_pos = omat4_mul_v4(view_proj, ov4(exit.x, exit.y, exit.z, 1.0f));
             ovec2 ndc = ov2(clip_pos.x / clip_pos.w, clip_pos.y / clip_pos.w);
@@ -1113,7 +1205,7 @@ static ovec3 sample_transmission_background(const OracleScene* s, const uint16_t
         }
     }
     if (screen_uv.x < 0.0f || screen_uv.x > 1.0f || screen_uv.y < 0.0f || screen_uv.y > 1.0f || screen_uv.x != screen_uv.x || screen_uv.y != screen_uv.y)
-        return sample_prefiltered(s);      /* IBL fallback: the cube is a uniform colour, direction and mip do not matter */
+        return sample_prefiltered(s, sample_dir, roughness);      /* fragment.wgsl:68-81: IBL fallback */
     const float sx = screen_uv.x * Wf, sy = screen_uv.y * Hf;
     const int tx = (int)sx, ty = (int)sy;
     const float blur_roughness = roughness * o_clamp(ior * 2.0f - 2.0f, 0.0f, 1.0f);

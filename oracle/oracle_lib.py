@@ -32,13 +32,29 @@ class OracleTexArray(C.Structure):
     _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("layers", C.c_uint32), ("mips", C.c_uint32)]
 
 
+class OracleCube(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("size", C.c_uint32), ("mips", C.c_uint32)]
+
+
+CUBE_SLOTS = ("skybox", "prefiltered", "irradiance")
+
+
+def pack_cube(levels) -> np.ndarray:
+    """[level0, level1, ...] of (6, N_l, N_l, 4) float16 -> the flat [mip][face][y][x][4] uint16 array both the oracle and the C-ABI take."""
+    size = levels[0].shape[1]
+    for l, a in enumerate(levels):
+        n = max(size >> l, 1)
+        assert a.shape == (6, n, n, 4) and a.dtype == np.float16, (l, a.shape, a.dtype)
+    return np.ascontiguousarray(np.concatenate([a.reshape(-1) for a in levels])).view(np.uint16)
+
+
 class OracleScene(C.Structure):
     _fields_ = [("buf", C.c_void_p * BUF_COUNT), ("buf_size", C.c_uint64 * BUF_COUNT), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("y0", C.c_uint32), ("y1", C.c_uint32), ("draws", C.POINTER(AwsmDraw)), ("n_draws", C.c_uint32), ("has_opaque", C.c_uint32),
                 ("n_tex_arrays", C.c_uint32), ("tex_arrays", OracleTexArray * MAX_TEX), ("n_samplers", C.c_uint32),
                 ("samplers", AwsmSampler * MAX_SAMPLERS), ("skybox_rgba", C.c_float * 4), ("prefiltered_rgb", C.c_float * 4),
                 ("irradiance_rgb", C.c_float * 4), ("brdf_lut_rg16f", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
-                ("msaa", C.c_uint32), ("mipmap", C.c_uint32)]
+                ("msaa", C.c_uint32), ("mipmap", C.c_uint32), ("cube", OracleCube * 3)]
 
 
 def build(force: bool = False) -> str:
@@ -112,7 +128,8 @@ class OracleFrame:
     """Holds the numpy arrays an OracleScene points at and runs the three oracle stages."""
 
     def __init__(self, mirrors: Dict[int, bytes], draws: List[dict], width: int, height: int, tex_arrays: List[dict], samplers: List[dict],
-                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True, msaa=0, mipmap=False):
+                 lut_rg16f: np.ndarray, skybox=(0, 0, 0, 1), prefiltered=(1, 1, 1), irradiance=(1, 1, 1), rows=(0, 0), has_opaque=True, msaa=0, mipmap=False,
+                 env_cubes=None):
         self._keep = []
         s = OracleScene()
         for i in range(BUF_COUNT):
@@ -155,6 +172,12 @@ class OracleFrame:
         for i in range(3):
             s.prefiltered_rgb[i] = prefiltered[i]
             s.irradiance_rgb[i] = irradiance[i]
+        for k, name in enumerate(CUBE_SLOTS):
+            levels = (env_cubes or {}).get(name)
+            if levels:
+                flat = pack_cube(levels)
+                self._keep.append(flat)
+                s.cube[k] = OracleCube(flat.ctypes.data, levels[0].shape[1], len(levels))
         self.lut = np.ascontiguousarray(lut_rg16f, dtype=np.uint16)
         s.brdf_lut_rg16f = self.lut.ctypes.data
         s.lut_height, s.lut_width = self.lut.shape[0], self.lut.shape[1]
@@ -219,4 +242,16 @@ class OracleFrame:
 def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0, mipmap=False) -> OracleFrame:
     sc = model.scene
     return OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,
-                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap)
+                       skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap,
+                       env_cubes=sc.env_cubes)
+
+
+def sample_cube(levels, dirs: np.ndarray, lods: np.ndarray) -> np.ndarray:
+    """textureSampleLevel on a cube by the oracle's contract: dirs (n, 3) f32, lods (n,) f32 -> (n, 4) f32."""
+    flat = pack_cube(levels)
+    cube = OracleCube(flat.ctypes.data, levels[0].shape[1], len(levels))
+    d = np.ascontiguousarray(dirs, dtype=np.float32)
+    l = np.ascontiguousarray(lods, dtype=np.float32)
+    out = np.zeros((d.shape[0], 4), dtype=np.float32)
+    lib().oracle_sample_cube(C.byref(cube), d.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p), C.c_uint32(d.shape[0]), out.ctypes.data_as(C.c_void_p))
+    return out

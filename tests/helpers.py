@@ -35,6 +35,9 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap
     for i, s in enumerate(sc.samplers):
         dev.sampler_set(i, s)
     dev.env_upload(sc.skybox_rgba, sc.prefiltered_rgb, sc.irradiance_rgb, oracle_lib.lut_rg_to_rgba16f(lut))
+    for k, name in enumerate(oracle_lib.CUBE_SLOTS):
+        if sc.env_cubes and sc.env_cubes.get(name):
+            dev.env_cube_upload(k, sc.env_cubes[name])
     if rows != (0, 0):
         dev.set_shard_rows(*rows)
     draws = model.collect_draws()

@@ -45,6 +45,7 @@ int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t idx, uint32_t w, uint3
 }
 int awsm_hip_sampler_set(AwsmHipCtx* c, uint32_t idx, const AwsmSampler* s) { (void)s; logc(c, 5, (int)idx, 0, 0); return 0; }
 int awsm_hip_env_upload(AwsmHipCtx* c, const AwsmEnv* e) { (void)e; logc(c, 6, 0, 0, 0); return 0; }
+int awsm_hip_env_cube_upload(AwsmHipCtx* c, AwsmCube which, uint32_t size, uint32_t mips, const uint16_t* t) { (void)t; logc(c, 6, (int)which + 1, size, mips); return 0; }
 int awsm_hip_brdf_lut_generate(AwsmHipCtx* c, uint32_t w, uint32_t h) { logc(c, 10, 0, w, h); return 0; }
 int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) {
     free(c->draws); c->draws = (AwsmDraw*)malloc((n ? n : 1) * sizeof(AwsmDraw)); if (n) memcpy(c->draws, d, n * sizeof(AwsmDraw)); c->n_draws = n;

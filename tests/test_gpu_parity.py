@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): triangle-id + depth bit-exact; shaded RGB within
 relative (1e-4 * |ref|) for HDR values above 1.0 — checked on the f32 parity tap; the RGBA16F image must be within
 2 f16 ulp of the oracle's (1e-4 is below half an f16 ulp for values above 0.125, so the stored halves can legitimately
 round apart)."""
+import dataclasses
 import math
 
 import numpy as np
@@ -527,6 +528,80 @@ def test_instanced_meshes(msaa, oracle_lut):
     from awsm_renderer_amd import scene_desc  # noqa: F401
     assert rr.host.mirror(helpers.scene_model.BUF_INSTANCES) == model.mirrors()[helpers.scene_model.BUF_INSTANCES]
     rr.close()
+
+
+# ------------------------------------------------------------------------------------------------ texel cubemaps
+
+def _with_environment(sc, size=32):
+    sc.env_cubes = scenes.procedural_environment(size, 8)
+    sc.prefiltered_mip_count = len(sc.env_cubes["prefiltered"])        # what IblTexture.mip_count reports (lights.rs:300-305)
+    sc.irradiance_mip_count = 1
+    return sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,msaa", [("helmet", 0), ("zoo", 0), ("atrium", 0), ("helmet", 4)])
+def test_texel_cubemaps_skybox_and_ibl(name, msaa, oracle_lut):
+    """skybox.wgsl:1-41 + brdf.wgsl:268-290,389-576 with real cubemaps: the background is the skybox cube along the pixel's view ray, the
+    diffuse term samples the irradiance cube along N, the specular (and clearcoat) term the prefiltered chain along the reflection at level
+    roughness * (mips - 1).  A non-uniform HDR environment, so a wrong face, orientation, seam or level shows."""
+    sc = {"helmet": lambda: scenes.helmet_scene(480, 270, segments=64, rings=48, tex_size=128), "zoo": lambda: scenes.material_zoo_scene(400, 300),
+          "atrium": lambda: scenes.atrium_scene(640, 360, detail=0.25, tex_scale=1 / 32)}[name]()
+    _with_environment(sc)
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut, msaa=msaa)
+    flat = helpers.oracle_frame(helpers.build_model(dataclasses.replace(sc, env_cubes=None)), oracle_lut, msaa=msaa)
+    assert float(np.abs(orc.rgba32f - flat.rgba32f).max()) > 0.5                        # the cubes do change the picture
+    dev, stats = helpers.hip_frame(model, oracle_lut, msaa=msaa)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    dev.close()
+    assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["alpha_mismatch"] == 0 and r["f16_max_ulp"] <= 2, r
+    if name == "helmet":
+        assert r["covered"] < sc.width * sc.height * 0.6                                # sky pixels are in the comparison
+    # through the host layer: Renderer uploads the cubes with awsm_host_env_cube
+    rr, hdev, _ = helpers.host_frame(sc, oracle_lut, msaa=msaa)
+    res = helpers.compare_frames(orc, hdev, rgb_tol=RGB_TOL)
+    rr.close()
+    assert res["key_mismatch"] == 0 and res["rgb_over_tol"] == 0, res
+
+
+@pytest.mark.gpu
+def test_texel_cubemap_is_the_transmission_fallback(oracle_lut):
+    """material_transparent fragment.wgsl:68-81: a refracted ray that leaves the screen samples the prefiltered cube along the
+    refracted direction at roughness * (mips - 1)."""
+    sc = _with_environment(scenes.transparent_scene(480, 270, tex_size=64))
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut)
+    orc.forward(model.collect_transparent_draws())
+    dev, _ = helpers.hip_frame(model, oracle_lut, transparent=True)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    c = helpers.compare_composite(orc, dev)
+    dev.close()
+    assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0, r
+    assert c["untouched_changed"] == 0 and c["pixels_over_2ulp"] <= c["touched_pixels"] // 200 and c["pixels_over_bound"] <= c["touched_pixels"] // 200, c
+
+
+@pytest.mark.gpu
+def test_cube_upload_argument_checks_and_reset(oracle_lut):
+    from awsm_renderer_amd.hip_backend import AwsmHipError
+    sc = scenes.box_scene(160, 120)
+    model = helpers.build_model(sc)
+    dev, _ = helpers.hip_frame(model, oracle_lut)
+    base = dev.read_opaque()
+    env = scenes.procedural_environment(16, 8)
+    for k, name in enumerate(("skybox", "prefiltered", "irradiance")):
+        dev.env_cube_upload(k, env[name])
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); dev.frame_end()
+    assert (dev.read_opaque() != base).any()
+    for k in range(3):
+        dev.env_cube_upload(k, None)                                                    # back to the uniform colours
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); dev.frame_end()
+    assert (dev.read_opaque() == base).all()
+    with pytest.raises(AwsmHipError):
+        dev._chk(dev.lib.awsm_hip_env_cube_upload(dev.ctx, 0, 16, 9, env["skybox"][0].ctypes.data), "env_cube_upload")      # a 16^2 cube has 5 levels
+    with pytest.raises(AwsmHipError):
+        dev._chk(dev.lib.awsm_hip_env_cube_upload(dev.ctx, 5, 16, 1, env["skybox"][0].ctypes.data), "env_cube_upload")
+    dev.close()
 
 
 # ------------------------------------------------------------------------------------------------ transparent pass (SURVEY §8f.4)
