@@ -38,7 +38,13 @@ class HostMaterial(C.Structure):
                 ("has_clearcoat", C.c_uint32), ("clearcoat_factor", C.c_float), ("clearcoat_roughness_factor", C.c_float), ("clearcoat_normal_scale", C.c_float),
                 ("clearcoat_tex", TexRef), ("clearcoat_roughness_tex", TexRef), ("clearcoat_normal_tex", TexRef),
                 ("has_sheen", C.c_uint32), ("sheen_roughness_factor", C.c_float), ("sheen_color_factor", C.c_float * 3), ("sheen_roughness_tex", TexRef), ("sheen_color_tex", TexRef),
-                ("alpha_mode", C.c_uint32), ("alpha_cutoff", C.c_float)]
+                ("alpha_mode", C.c_uint32), ("alpha_cutoff", C.c_float),
+                ("has_diffuse_transmission", C.c_uint32), ("diffuse_transmission_factor", C.c_float), ("diffuse_transmission_color_factor", C.c_float * 3),
+                ("diffuse_transmission_tex", TexRef), ("diffuse_transmission_color_tex", TexRef),
+                ("has_dispersion", C.c_uint32), ("dispersion", C.c_float),
+                ("has_anisotropy", C.c_uint32), ("anisotropy_strength", C.c_float), ("anisotropy_rotation", C.c_float), ("anisotropy_tex", TexRef),
+                ("has_iridescence", C.c_uint32), ("iridescence_factor", C.c_float), ("iridescence_ior", C.c_float), ("iridescence_thickness_min", C.c_float),
+                ("iridescence_thickness_max", C.c_float), ("iridescence_tex", TexRef), ("iridescence_thickness_tex", TexRef)]
 
 
 class MorphTarget(C.Structure):
@@ -407,7 +413,8 @@ def material_struct(m: MaterialDesc, host: Host, tt_keys: Dict[tuple, int]) -> H
     hm.occlusion_tex, hm.emissive_tex = tr(m.occlusion_tex), tr(m.emissive_tex)
     none = TexRef(-1, 0, 0, 0, 0)
     for name in ("specular_tex", "specular_color_tex", "transmission_tex", "volume_thickness_tex", "clearcoat_tex", "clearcoat_roughness_tex",
-                 "clearcoat_normal_tex", "sheen_roughness_tex", "sheen_color_tex"):
+                 "clearcoat_normal_tex", "sheen_roughness_tex", "sheen_color_tex", "diffuse_transmission_tex", "diffuse_transmission_color_tex", "anisotropy_tex",
+                 "iridescence_tex", "iridescence_thickness_tex"):
         setattr(hm, name, none)
     if m.vertex_color_set is not None:
         hm.has_vertex_color, hm.vertex_color_set = 1, m.vertex_color_set
@@ -438,6 +445,21 @@ def material_struct(m: MaterialDesc, host: Host, tt_keys: Dict[tuple, int]) -> H
         hm.has_sheen, hm.sheen_roughness_factor = 1, s.get("roughness_factor", 0.0)
         hm.sheen_color_factor = (C.c_float * 3)(*s.get("color_factor", (0, 0, 0)))
         hm.sheen_roughness_tex, hm.sheen_color_tex = tr(s.get("roughness_tex")), tr(s.get("color_tex"))
+    if m.diffuse_transmission is not None:
+        s = m.diffuse_transmission
+        hm.has_diffuse_transmission, hm.diffuse_transmission_factor = 1, s.get("factor", 0.0)
+        hm.diffuse_transmission_color_factor = (C.c_float * 3)(*s.get("color_factor", (1, 1, 1)))
+        hm.diffuse_transmission_tex, hm.diffuse_transmission_color_tex = tr(s.get("tex")), tr(s.get("color_tex"))
+    if m.dispersion is not None:
+        hm.has_dispersion, hm.dispersion = 1, m.dispersion
+    if m.anisotropy is not None:
+        s = m.anisotropy
+        hm.has_anisotropy, hm.anisotropy_strength, hm.anisotropy_rotation, hm.anisotropy_tex = 1, s.get("strength", 0.0), s.get("rotation", 0.0), tr(s.get("tex"))
+    if m.iridescence is not None:
+        s = m.iridescence
+        hm.has_iridescence, hm.iridescence_factor, hm.iridescence_ior = 1, s.get("factor", 0.0), s.get("ior", 1.3)
+        hm.iridescence_thickness_min, hm.iridescence_thickness_max = s.get("thickness_min", 100.0), s.get("thickness_max", 400.0)
+        hm.iridescence_tex, hm.iridescence_thickness_tex = tr(s.get("tex")), tr(s.get("thickness_tex"))
     return hm
 
 

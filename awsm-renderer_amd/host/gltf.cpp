@@ -125,30 +125,98 @@ int type_components(const std::string& t) {
 }
 int component_size(int ct) { return ct == 5120 || ct == 5121 ? 1 : (ct == 5122 || ct == 5123 ? 2 : (ct == 5125 || ct == 5126 ? 4 : 0)); }
 
-struct AccessorView { const uint8_t* base = nullptr; size_t stride = 0, count = 0; int comps = 0, ctype = 0; bool normalized = false; };
+struct AccessorView {
+    const uint8_t* base = nullptr; size_t stride = 0, count = 0; int comps = 0, ctype = 0; bool normalized = false;
+    std::vector<uint8_t> owned;     // sparse / zero-filled accessors: the tightly packed element bytes (accessor.rs:14-66)
+};
+
+// A JSON number that must be a byte offset / size / count: non-negative, integral, below 2^53 (json.hpp keeps doubles; integer() of a
+// negative or huge value used to be cast to size_t and wrap).
+bool nonneg(Loader& L, const Value& v, const char* what, int index, size_t dflt, size_t* out) {
+    if (!v.is_number()) { *out = dflt; return true; }
+    const double d = v.number(0.0);
+    if (!(d >= 0.0) || d > 9007199254740992.0 || d != std::floor(d)) return L.fail("%s %d: offset / size / count %g is not a non-negative integer", what, index, d);
+    *out = (size_t)d;
+    return true;
+}
+// [off, off + len) inside a buffer of `size` bytes, without wrapping
+bool fits(size_t off, size_t len, size_t size) { return off <= size && len <= size - off; }
+
+// bufferView `bvi` -> buffer bytes, start offset and length, all checked against the buffer
+bool buffer_view(Loader& L, const Value& bvv, const char* what, int index, const uint8_t** data, size_t* len, size_t* stride) {
+    if (!bvv.is_number()) return L.fail("%s %d: bufferView missing", what, index);
+    const double bvd = bvv.number(-1.0);
+    const Value& views = L.doc["bufferViews"];
+    if (!(bvd >= 0.0) || bvd >= (double)views.size() || bvd != std::floor(bvd)) return L.fail("%s %d: bufferView index out of range", what, index);
+    const Value& bv = views[(size_t)bvd];
+    if (!bv.is_object()) return L.fail("%s %d: bufferView missing", what, index);
+    const double bid = bv["buffer"].number(-1.0);
+    if (!(bid >= 0.0) || bid >= (double)L.buffers.size() || bid != std::floor(bid)) return L.fail("%s %d: buffer missing", what, index);
+    const std::vector<uint8_t>& buf = L.buffers[(size_t)bid];
+    size_t off = 0, blen = 0, st = 0;
+    if (!nonneg(L, bv["byteOffset"], what, index, 0, &off) || !nonneg(L, bv["byteStride"], what, index, 0, &st)) return false;
+    if (!fits(off, 0, buf.size())) return L.fail("%s %d: bufferView starts beyond its buffer", what, index);
+    if (!nonneg(L, bv["byteLength"], what, index, buf.size() - off, &blen)) return false;
+    if (!fits(off, blen, buf.size())) return L.fail("%s %d: bufferView exceeds its buffer", what, index);
+    if (st > 255) return L.fail("%s %d: byteStride %zu above the 252 the format allows", what, index, st);
+    *data = buf.data() + off; *len = blen;
+    if (stride) *stride = st;
+    return true;
+}
 
 bool accessor_view(Loader& L, int index, AccessorView& v) {
     const Value& a = L.doc["accessors"][(size_t)index];
     if (index < 0 || !a.is_object()) return L.fail("accessor %d missing", index);
-    if (a.has("sparse")) return L.fail("accessor %d: sparse accessors are not supported", index);
     v.comps = type_components(a["type"].string());
     v.ctype = (int)a["componentType"].integer(0);
-    v.count = (size_t)a["count"].integer(0);
     v.normalized = a["normalized"].boolean(false);
     const int cs = component_size(v.ctype);
     if (!v.comps || !cs) return L.fail("accessor %d: bad type", index);
-    if (!a.has("bufferView")) return L.fail("accessor %d: no bufferView (zero-filled accessors are not supported)", index);
-    const Value& bv = L.doc["bufferViews"][(size_t)a["bufferView"].integer(-1)];
-    if (!bv.is_object()) return L.fail("accessor %d: bufferView missing", index);
-    const size_t bi = (size_t)bv["buffer"].integer(-1);
-    if (bi >= L.buffers.size()) return L.fail("accessor %d: buffer missing", index);
-    const size_t off = (size_t)bv["byteOffset"].integer(0) + (size_t)a["byteOffset"].integer(0);
-    size_t elem = (size_t)v.comps * cs;
     if ((a["type"].string() == "MAT2" && cs == 1) || (a["type"].string() == "MAT3" && cs <= 2)) return L.fail("accessor %d: padded matrix layouts are not supported", index);
-    v.stride = (size_t)bv["byteStride"].integer(0);
-    if (v.stride == 0) v.stride = elem;
-    if (v.count && off + (v.count - 1) * v.stride + elem > L.buffers[bi].size()) return L.fail("accessor %d exceeds its buffer", index);
-    v.base = L.buffers[bi].data() + off;
+    if (!nonneg(L, a["count"], "accessor", index, 0, &v.count)) return false;
+    const size_t elem = (size_t)v.comps * cs;
+    if (v.count > (size_t)1 << 32) return L.fail("accessor %d: %zu elements", index, v.count);
+    const bool sparse = a.has("sparse");
+    if (a.has("bufferView")) {
+        const uint8_t* data; size_t len, stride, aoff;
+        if (!buffer_view(L, a["bufferView"], "accessor", index, &data, &len, &stride)) return false;
+        if (!nonneg(L, a["byteOffset"], "accessor", index, 0, &aoff)) return false;
+        v.stride = stride ? stride : elem;
+        if (v.stride < elem) return L.fail("accessor %d: byteStride %zu below the element size %zu", index, v.stride, elem);
+        // the last element ends at aoff + (count - 1) * stride + elem: inside the VIEW (which is inside its buffer)
+        if (v.count && (!fits(aoff, elem, len) || (v.count - 1) > (len - aoff - elem) / v.stride)) return L.fail("accessor %d exceeds its bufferView", index);
+        v.base = data + aoff;
+    } else {
+        // "if we have no view, fill it with zeroes" — which a sparse block or an extension may then overwrite (accessor.rs:37-43)
+        v.owned.assign(v.count * elem, 0);
+        v.base = v.owned.data(); v.stride = elem;
+    }
+    if (sparse) {   // accessor.rs:45-63: substitute `count` elements at the listed indices
+        const Value& sp = a["sparse"];
+        size_t n = 0;
+        if (!nonneg(L, sp["count"], "sparse accessor", index, 0, &n)) return false;
+        if (n > v.count) return L.fail("accessor %d: %zu sparse elements in an accessor of %zu", index, n, v.count);
+        if (v.owned.empty() && v.count) {     // repack the dense data first (the view is borrowed, and may be strided)
+            v.owned.resize(v.count * elem);
+            for (size_t i = 0; i < v.count; i++) memcpy(v.owned.data() + i * elem, v.base + i * v.stride, elem);
+        }
+        v.base = v.owned.data(); v.stride = elem;
+        const uint8_t *idata, *vdata; size_t ilen, vlen, ioff, voff;
+        if (!buffer_view(L, sp["indices"]["bufferView"], "sparse indices of accessor", index, &idata, &ilen, nullptr)) return false;
+        if (!buffer_view(L, sp["values"]["bufferView"], "sparse values of accessor", index, &vdata, &vlen, nullptr)) return false;
+        if (!nonneg(L, sp["indices"]["byteOffset"], "sparse accessor", index, 0, &ioff) || !nonneg(L, sp["values"]["byteOffset"], "sparse accessor", index, 0, &voff)) return false;
+        const int ict = (int)sp["indices"]["componentType"].integer(0);
+        const size_t isz = ict == 5121 ? 1 : (ict == 5123 ? 2 : (ict == 5125 ? 4 : 0));
+        if (!isz) return L.fail("accessor %d: sparse index type %d (u8 / u16 / u32 only)", index, ict);
+        if (n && (!fits(ioff, n * isz, ilen) || !fits(voff, n * elem, vlen))) return L.fail("accessor %d: sparse data exceeds its bufferView", index);
+        for (size_t k = 0; k < n; k++) {
+            size_t target = 0;
+            const uint8_t* p = idata + ioff + k * isz;
+            if (isz == 1) target = p[0]; else if (isz == 2) { uint16_t t; memcpy(&t, p, 2); target = t; } else { uint32_t t; memcpy(&t, p, 4); target = t; }
+            if (target >= v.count) return L.fail("accessor %d: sparse index %zu outside its %zu elements", index, target, v.count);
+            memcpy(v.owned.data() + target * elem, vdata + voff + k * elem, elem);
+        }
+    }
     return true;
 }
 
@@ -164,9 +232,10 @@ float component_f32(const uint8_t* p, int ctype, bool normalized) {
     return 0.0f;
 }
 
-bool read_floats(Loader& L, int accessor, int want_comps, std::vector<float>& out, size_t* count) {
+bool read_floats(Loader& L, int accessor, int want_comps, std::vector<float>& out, size_t* count, bool raw_integers = false) {
     AccessorView v;
     if (!accessor_view(L, accessor, v)) return false;
+    if (raw_integers) v.normalized = false;      // `value as f32`, whatever the accessor's normalized flag says
     if (v.comps != want_comps) return L.fail("accessor %d: expected %d components, found %d", accessor, want_comps, v.comps);
     const int cs = component_size(v.ctype);
     out.resize(v.count * (size_t)want_comps);
@@ -197,10 +266,9 @@ bool read_uints(Loader& L, int accessor, int want_comps, std::vector<uint32_t>& 
 // ---- images and samplers ----
 bool image_bytes(Loader& L, const Value& img, std::vector<uint8_t>& out) {
     if (img.has("bufferView")) {
-        const Value& bv = L.doc["bufferViews"][(size_t)img["bufferView"].integer(-1)];
-        const size_t bi = (size_t)bv["buffer"].integer(-1), off = (size_t)bv["byteOffset"].integer(0), len = (size_t)bv["byteLength"].integer(0);
-        if (!bv.is_object() || bi >= L.buffers.size() || off + len > L.buffers[bi].size()) return L.fail("image bufferView out of range");
-        out.assign(L.buffers[bi].begin() + (long)off, L.buffers[bi].begin() + (long)(off + len));
+        const uint8_t* data; size_t len;
+        if (!buffer_view(L, img["bufferView"], "image", 0, &data, &len, nullptr)) return false;
+        out.assign(data, data + len);
         return true;
     }
     if (img.has("uri")) return load_uri(L, img["uri"].string(), out);
@@ -527,7 +595,8 @@ bool add_transforms(Loader& L, size_t node, AwsmKey parent) {
 
 // populate/mesh.rs + gltf/buffers/mesh.rs for one primitive
 bool add_primitive(Loader& L, const Value& node, size_t node_index, const Value& mesh, const Value& prim, AwsmKey transform, bool is_joint_node) {
-    (void)node_index; (void)is_joint_node;
+    (void)node_index;
+    const bool mesh_on_joint_node = is_joint_node;
     const int64_t mode = prim["mode"].integer(4);
     if (mode != 4 && mode != 5 && mode != 6) return L.fail("primitive mode %lld is not supported (triangles, strips and fans only; buffers/index.rs:203-206)", (long long)mode);
     const Value& attrs = prim["attributes"];
@@ -638,7 +707,35 @@ bool add_primitive(Loader& L, const Value& node, size_t node_index, const Value&
     const AwsmKey mesh_key = awsm_host_mesh_insert(L.h, &p, transform, mk, skin_key, 0);
     if (!mesh_key) return L.fail("mesh: %s", awsm_host_last_error(L.h));
     L.info.meshes++; L.info.triangles += p.triangle_count;
-    // GPU instancing carried by scenes this repo exports (EXT_mesh_gpu_instancing is not read): extras.instances = [[t3, r4, s3], ...]
+    // EXT_mesh_gpu_instancing on the node (gltf/populate/extensions/instancing.rs:9-160): TRANSLATION / SCALE are float VEC3, ROTATION is a
+    // VEC4 of floats or of integers cast as they are (`v as f32`: the reference does not normalise them); the count is that of the first
+    // attribute present, missing ones are identity; every mesh that hangs on the node's own transform becomes instanced (a skinned mesh
+    // on a joint node has a transform of its own, populate/mesh.rs:36-52, and stays single).
+    const Value& ext_inst = node["extensions"]["EXT_mesh_gpu_instancing"]["attributes"];
+    if (ext_inst.is_object() && !mesh_on_joint_node) {
+        auto attr = [&](const char* upper, const char* lower) -> const Value& { return ext_inst.has(lower) ? ext_inst[lower] : ext_inst[upper]; };
+        std::vector<float> tr, ro, sc;
+        size_t nt = 0, nr = 0, ns = 0;
+        const Value &at = attr("TRANSLATION", "translation"), &ar = attr("ROTATION", "rotation"), &as = attr("SCALE", "scale");
+        const auto is_f32 = [&](const Value& a) { return L.doc["accessors"][(size_t)a.integer(-1)]["componentType"].integer(0) == 5126; };
+        if (at.is_number()) { if (!is_f32(at)) return L.fail("EXT_mesh_gpu_instancing: translation isn't a Vec3F32"); if (!read_floats(L, (int)at.integer(-1), 3, tr, &nt)) return false; }
+        if (ar.is_number() && !read_floats(L, (int)ar.integer(-1), 4, ro, &nr, true)) return false;
+        if (as.is_number()) { if (!is_f32(as)) return L.fail("EXT_mesh_gpu_instancing: scale isn't a Vec3F32"); if (!read_floats(L, (int)as.integer(-1), 3, sc, &ns)) return false; }
+        const size_t count = at.is_number() ? nt : (ar.is_number() ? nr : (as.is_number() ? ns : 0));
+        if ((ar.is_number() && nr < count) || (as.is_number() && ns < count)) return L.fail("EXT_mesh_gpu_instancing: attribute shorter than the instance count %zu", count);
+        if (count) {
+            std::vector<float> trs(count * 10);
+            for (size_t i = 0; i < count; i++) {
+                float* o = &trs[i * 10];
+                for (int c = 0; c < 3; c++) o[c] = at.is_number() ? tr[i * 3 + c] : 0.0f;
+                for (int c = 0; c < 4; c++) o[3 + c] = ar.is_number() ? ro[i * 4 + c] : (c == 3 ? 1.0f : 0.0f);
+                for (int c = 0; c < 3; c++) o[7 + c] = as.is_number() ? sc[i * 3 + c] : 1.0f;
+            }
+            if (awsm_host_mesh_set_instances(L.h, mesh_key, trs.data(), (uint32_t)count)) return L.fail("EXT_mesh_gpu_instancing: %s", awsm_host_last_error(L.h));
+            L.info.instanced_meshes++;
+        }
+    }
+    // the same carried per primitive by scenes this repo exports (a SceneDesc can instance one primitive of a node): extras.instances = [[t3, r4, s3], ...]
     const Value& inst = prim["extras"]["instances"];
     if (inst.is_array() && inst.size()) {
         std::vector<float> trs(inst.size() * 10);

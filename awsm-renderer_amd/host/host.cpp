@@ -335,6 +335,11 @@ std::vector<uint8_t> material_bytes(AwsmHost* h, const AwsmHostMaterial& m) {
         for (int i = 0; i < 3; i++) push_f32(d, m.specular_color_factor[i]);
     }
     if (m.has_transmission) { fi[4] = cur(); write_tex(h, d, m.transmission_tex); push_f32(d, m.transmission_factor); }
+    if (m.has_diffuse_transmission) {   // pbr.rs:418-447
+        fi[5] = cur();
+        write_tex(h, d, m.diffuse_transmission_tex); push_f32(d, m.diffuse_transmission_factor); write_tex(h, d, m.diffuse_transmission_color_tex);
+        for (int i = 0; i < 3; i++) push_f32(d, m.diffuse_transmission_color_factor[i]);
+    }
     if (m.has_volume) {
         fi[6] = cur();
         write_tex(h, d, m.volume_thickness_tex); push_f32(d, m.volume_thickness_factor); push_f32(d, m.volume_attenuation_distance);
@@ -350,6 +355,16 @@ std::vector<uint8_t> material_bytes(AwsmHost* h, const AwsmHostMaterial& m) {
         fi[8] = cur();
         write_tex(h, d, m.sheen_roughness_tex); push_f32(d, m.sheen_roughness_factor); write_tex(h, d, m.sheen_color_tex);
         for (int i = 0; i < 3; i++) push_f32(d, m.sheen_color_factor[i]);
+    }
+    if (m.has_dispersion) { fi[9] = cur(); push_f32(d, m.dispersion); }                         // pbr.rs:529-532
+    if (m.has_anisotropy) {                                                                       // pbr.rs:534-551
+        fi[10] = cur();
+        write_tex(h, d, m.anisotropy_tex); push_f32(d, m.anisotropy_strength); push_f32(d, m.anisotropy_rotation);
+    }
+    if (m.has_iridescence) {                                                                      // pbr.rs:553-581
+        fi[11] = cur();
+        write_tex(h, d, m.iridescence_tex); push_f32(d, m.iridescence_factor); push_f32(d, m.iridescence_ior);
+        write_tex(h, d, m.iridescence_thickness_tex); push_f32(d, m.iridescence_thickness_min); push_f32(d, m.iridescence_thickness_max);
     }
     memcpy(d.data() + indices_offset, fi, 48);
     return d;

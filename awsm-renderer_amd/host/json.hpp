@@ -35,7 +35,9 @@ struct Value {
     }
     bool has(const char* key) const { return !(*this)[key].is_null(); }
     double number(double dflt) const { return kind == Number ? num : dflt; }
-    int64_t integer(int64_t dflt) const { return kind == Number ? (int64_t)std::llround(num) : dflt; }
+    int64_t integer(int64_t dflt) const {      // non-finite or beyond +-2^62: the default (llround of those is undefined)
+        return kind == Number && num >= -4.0e18 && num <= 4.0e18 ? (int64_t)std::llround(num) : dflt;
+    }
     bool boolean(bool dflt) const { return kind == Bool ? b : dflt; }
     const std::string& string() const { return str; }
 };

@@ -47,6 +47,10 @@ class MaterialDesc:
     volume: Optional[dict] = None         # {thickness_tex, thickness_factor, attenuation_distance, attenuation_color}
     clearcoat: Optional[dict] = None      # {tex, factor, roughness_tex, roughness_factor, normal_tex, normal_scale}
     sheen: Optional[dict] = None          # {roughness_tex, roughness_factor, color_tex, color_factor}
+    diffuse_transmission: Optional[dict] = None   # {tex, factor, color_tex, color_factor}          (packed, not shaded: pbr.rs:418-447)
+    dispersion: Optional[float] = None            #                                                  (pbr.rs:529-532)
+    anisotropy: Optional[dict] = None             # {tex, strength, rotation}                        (pbr.rs:534-551)
+    iridescence: Optional[dict] = None            # {tex, factor, ior, thickness_tex, thickness_min, thickness_max}   (pbr.rs:553-581)
 
     def is_transparency_pass(self) -> bool:
         """materials/pbr.rs:213-224, materials/unlit.rs:36-38"""

@@ -80,6 +80,15 @@ typedef struct AwsmHostMaterial {
      * meshes that use the material to the transparent pass (pbr.rs:213-224, unlit.rs:36-38; decided when the mesh is inserted,
      * as the glTF loader does: gltf/buffers/mesh.rs:33-57). */
     uint32_t alpha_mode; float alpha_cutoff;
+    /* the remaining optional blocks of the word stream (pbr.rs:418-447,529-573): the reference's shaders do not read them yet and its
+     * glTF mapper leaves them unset (gltf/populate/material.rs:621-625), but a material built through the API carries them, and the
+     * Materials mirror must hold the same bytes */
+    uint32_t has_diffuse_transmission; float diffuse_transmission_factor; float diffuse_transmission_color_factor[3];
+    AwsmHostTexRef diffuse_transmission_tex, diffuse_transmission_color_tex;
+    uint32_t has_dispersion; float dispersion;
+    uint32_t has_anisotropy; float anisotropy_strength, anisotropy_rotation; AwsmHostTexRef anisotropy_tex;
+    uint32_t has_iridescence; float iridescence_factor, iridescence_ior, iridescence_thickness_min, iridescence_thickness_max;
+    AwsmHostTexRef iridescence_tex, iridescence_thickness_tex;
 } AwsmHostMaterial;
 
 AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m);
@@ -161,7 +170,7 @@ int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* l
  * given, the reason (AWSM_ERR_UNSUPPORTED for arithmetic-coded / 12-bit / CMYK JPEG and KTX2 images, sparse accessors, point / line primitives, unknown required
  * extensions); objects inserted before the failure stay inserted. ---- */
 typedef struct AwsmGltfInfo {
-    uint32_t nodes, meshes, materials, images, samplers, skins, lights, triangles, generated_tangents, reserved[3];
+    uint32_t nodes, meshes, materials, images, samplers, skins, lights, triangles, generated_tangents, instanced_meshes, reserved[2];
 } AwsmGltfInfo;
 int awsm_host_load_gltf(AwsmHost* h, const char* path, int scene_index, AwsmGltfInfo* info_out, char* err_out, size_t err_cap);
 /* the image decoders the reader uses (PNG: all colour types / bit depths, non-interlaced; JPEG: baseline / extended sequential Huffman,

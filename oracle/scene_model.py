@@ -338,6 +338,9 @@ class MaterialPacker:
         if m.transmission is not None:
             s = m.transmission
             fi[4] = cur(); d += self._tex(s.get("tex")) + self._f(s.get("factor", 0.0))
+        if m.diffuse_transmission is not None:      # pbr.rs:418-447
+            s = m.diffuse_transmission
+            fi[5] = cur(); d += self._tex(s.get("tex")) + self._f(s.get("factor", 0.0)) + self._tex(s.get("color_tex")) + self._f(*s.get("color_factor", (1, 1, 1)))
         if m.volume is not None:
             s = m.volume
             fi[6] = cur(); d += self._tex(s.get("thickness_tex")) + self._f(s.get("thickness_factor", 0.0), s.get("attenuation_distance", 0.0)) + self._f(*s.get("attenuation_color", (1, 1, 1)))
@@ -348,6 +351,15 @@ class MaterialPacker:
         if m.sheen is not None:
             s = m.sheen
             fi[8] = cur(); d += self._tex(s.get("roughness_tex")) + self._f(s.get("roughness_factor", 0.0)) + self._tex(s.get("color_tex")) + self._f(*s.get("color_factor", (0, 0, 0)))
+        if m.dispersion is not None:                # pbr.rs:529-532
+            fi[9] = cur(); d += self._f(m.dispersion)
+        if m.anisotropy is not None:                # pbr.rs:534-551
+            s = m.anisotropy
+            fi[10] = cur(); d += self._tex(s.get("tex")) + self._f(s.get("strength", 0.0), s.get("rotation", 0.0))
+        if m.iridescence is not None:               # pbr.rs:553-581
+            s = m.iridescence
+            fi[11] = cur(); d += (self._tex(s.get("tex")) + self._f(s.get("factor", 0.0), s.get("ior", 1.3)) + self._tex(s.get("thickness_tex"))
+                                  + self._f(s.get("thickness_min", 100.0), s.get("thickness_max", 400.0)))
         d[indices_offset:indices_offset + 48] = struct.pack("<12I", *fi)
         return bytes(d)
 

@@ -63,6 +63,42 @@ for case in range(300):
         bad += 1
     h.close()
 print("corrupted files: loaded", ok, "refused", bad)
+# hostile numbers in an otherwise well-formed document: every byteOffset / byteStride / byteLength / count / index replaced, one at a time,
+# by negative, fractional, huge and just-too-large values (a wrapped bounds check would read outside the heap buffer: ASan sees it)
+import json
+import struct
+jlen = int.from_bytes(good[12:16], "little")
+doc0, rest = json.loads(good[20:20 + jlen]), good[20 + jlen:]
+sites = []
+for key in ("bufferViews", "accessors", "images"):
+    for i, obj in enumerate(doc0.get(key, [])[:4]):
+        for field in ("byteOffset", "byteStride", "byteLength", "count", "bufferView", "buffer"):
+            if field in obj or field in ("byteOffset", "byteStride"):
+                sites.append((key, i, field))
+for i, acc in enumerate(doc0.get("accessors", [])[:2]):
+    sites.append(("sparse", i, "count"))
+n_ok = n_bad = 0
+for (key, i, field) in sites:
+    for value in (-4096, 2.5, 2048, 2 ** 32 + 4, 1.8e19):
+        d = json.loads(json.dumps(doc0))
+        if key == "sparse":
+            d["accessors"][i]["sparse"] = {"count": value, "indices": {"bufferView": 0, "componentType": 5125}, "values": {"bufferView": 0}}
+        else:
+            d[key][i][field] = value
+        js = json.dumps(d).encode()
+        js += b" " * ((4 - len(js) % 4) % 4)
+        blob = struct.pack("<4sII", b"glTF", 2, 20 + len(js) + len(rest)) + struct.pack("<II", len(js), 0x4E4F534A) + js + rest
+        p = os.path.join(tmp, "n.glb")
+        open(p, "wb").write(blob)
+        h = H.Host(MOCK)
+        h.resize(64, 64)
+        try:
+            h.load_gltf(p)
+            n_ok += 1
+        except H.HostError:
+            n_bad += 1
+        h.close()
+print("hostile numbers: loaded", n_ok, "refused", n_bad)
 # image decoders on garbage
 for case in range(200):
     blob = bytes(rng.integers(0, 256, size=int(rng.integers(8, 400)), dtype=np.uint8))

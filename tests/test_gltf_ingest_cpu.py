@@ -172,6 +172,140 @@ def test_tangents_are_generated_for_normal_mapped_primitives(tmp_path):
     h.close()
 
 
+def test_sparse_and_zero_filled_accessors(tmp_path):
+    """gltf/buffers/accessor.rs:14-66: a sparse block substitutes elements of the (repacked) view data; an accessor without a bufferView
+    starts as zeros.  Here: POSITION is dense + sparse (two vertices moved, u16 indices), TEXCOORD_0 is zero-filled + sparse (u8 indices),
+    and the morph target — the way sample assets use sparse accessors — is zero-filled + sparse."""
+    doc, blob = _quad_doc()
+    sp_idx16 = np.array([1, 3], dtype=np.uint16).tobytes()
+    sp_pos = np.array([[2, 0, 0], [0, 3, 0]], dtype=np.float32).tobytes()
+    sp_idx8 = np.array([2], dtype=np.uint8).tobytes() + b"\0\0\0"
+    sp_uv = np.array([[0.25, 0.75]], dtype=np.float32).tobytes()
+    sp_dpos = np.array([[0, 0, 1], [0, 0, 2]], dtype=np.float32).tobytes()
+    base = len(blob) + (4 - len(blob) % 4) % 4
+    blob = blob + b"\0" * (base - len(blob))
+    extra = sp_idx16 + sp_pos + sp_idx8 + sp_uv + sp_dpos
+    o = [base, base + 4, base + 4 + 24, base + 4 + 24 + 4, base + 4 + 24 + 4 + 8]
+    doc["bufferViews"] += [{"buffer": 0, "byteOffset": o[0], "byteLength": 4}, {"buffer": 0, "byteOffset": o[1], "byteLength": 24},
+                           {"buffer": 0, "byteOffset": o[2], "byteLength": 1}, {"buffer": 0, "byteOffset": o[3], "byteLength": 8},
+                           {"buffer": 0, "byteOffset": o[4], "byteLength": 24}]
+    doc["accessors"][0]["sparse"] = {"count": 2, "indices": {"bufferView": 2, "componentType": 5123}, "values": {"bufferView": 3}}
+    doc["accessors"][0]["max"] = [2, 3, 0]
+    doc["accessors"][1] = {"componentType": 5126, "count": 4, "type": "VEC2", "sparse": {"count": 1, "indices": {"bufferView": 4, "componentType": 5121}, "values": {"bufferView": 5}}}
+    doc["accessors"].append({"componentType": 5126, "count": 4, "type": "VEC3", "sparse": {"count": 2, "indices": {"bufferView": 2, "componentType": 5123}, "values": {"bufferView": 6}}})
+    doc["meshes"][0]["primitives"][0]["targets"] = [{"POSITION": 4}]
+    doc["meshes"][0]["weights"] = [0.5]
+    doc["buffers"][0]["byteLength"] = len(blob) + len(extra)
+    path = str(tmp_path / "sparse.glb")
+    _write_raw_glb(path, doc, blob + extra)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    info = h.load_gltf(path)
+    assert info["triangles"] == 2
+    attr = np.frombuffer(h.mirror(sm.BUF_ATTR_DATA)[:4 * 6 * 4], dtype=np.float32).reshape(4, 6)
+    assert np.array_equal(attr[:, 4:], np.array([[0, 0], [0, 0], [0.25, 0.75], [0, 0]], dtype=np.float32))            # zeros, one element substituted
+    vis = np.frombuffer(h.mirror(sm.BUF_VIS_GEOM_DATA)[:6 * 56], dtype=np.float32).reshape(6, 14)
+    want_pos = np.array([[0, 0, 0], [2, 0, 0], [1, 1, 0], [0, 3, 0]], dtype=np.float32)                                # vertices 1 and 3 replaced
+    assert np.array_equal(vis[:, :3], want_pos[[0, 1, 2, 0, 2, 3]])
+    morph = np.frombuffer(h.mirror(sm.BUF_MORPH_VALUES)[:4 * 40], dtype=np.float32).reshape(4, 10)                     # 10 floats / target / vertex
+    assert np.array_equal(morph[:, :3], np.array([[0, 0, 0], [0, 0, 1], [0, 0, 0], [0, 0, 2]], dtype=np.float32))
+    h.close()
+    # a sparse index beyond the accessor, and sparse data beyond its view, are refused
+    for mutate, msg in ((lambda d: d["accessors"][0]["sparse"].__setitem__("count", 9), "sparse"),
+                        (lambda d: d["bufferViews"][2].__setitem__("byteLength", 2), "sparse data exceeds")):
+        d2 = json.loads(json.dumps(doc))
+        mutate(d2)
+        _write_raw_glb(path, d2, blob + extra)
+        h = H.Host(MOCK)
+        h.resize(32, 32)
+        with pytest.raises(H.HostError, match=msg):
+            h.load_gltf(path)
+        h.close()
+
+
+def test_ext_mesh_gpu_instancing(tmp_path):
+    """gltf/populate/extensions/instancing.rs: per-node TRANSLATION / ROTATION / SCALE accessors -> the instance-transform mirror of the
+    node's meshes; a missing attribute is identity, integer rotations are cast without normalisation (the reference's `as f32`)."""
+    doc, blob = _quad_doc()
+    tr = np.array([[0, 0, 0], [3, 0, 0], [0, 4, 0]], dtype=np.float32).tobytes()
+    ro = np.array([[0, 0, 0, 1], [0, 0, 1, 0], [0, 1, 0, 0]], dtype=np.int8).tobytes()          # i8, declared normalized: still cast raw
+    base = len(blob) + (4 - len(blob) % 4) % 4
+    blob = blob + b"\0" * (base - len(blob)) + tr + ro
+    doc["bufferViews"] += [{"buffer": 0, "byteOffset": base, "byteLength": 36}, {"buffer": 0, "byteOffset": base + 36, "byteLength": 12}]
+    doc["accessors"] += [{"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 3, "componentType": 5120, "normalized": True, "count": 3, "type": "VEC4"}]
+    doc["nodes"][0]["extensions"] = {"EXT_mesh_gpu_instancing": {"attributes": {"TRANSLATION": 4, "ROTATION": 5}}}
+    doc["extensionsUsed"] = ["EXT_mesh_gpu_instancing"]
+    doc["buffers"][0]["byteLength"] = len(blob)
+    path = str(tmp_path / "inst.glb")
+    _write_raw_glb(path, doc, blob)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    h.load_gltf(path)
+    h.update_transforms()
+    h.camera_update(scenes.look_at_rh((0, 0, 30), (0, 0, 0)), scenes.perspective_rh(1.0, 1.0, 0.1, 100.0), (0, 0, 30))
+    h.render()
+    inst = np.frombuffer(h.mirror(sm.BUF_INSTANCES)[:3 * 64], dtype=np.float32).reshape(3, 4, 4)
+    def trs(t, q):       # glam Mat4::from_scale_rotation_translation with unit scale, column-major [col][row]
+        x, y, z, w = q
+        r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y), 0], [2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x), 0],
+                      [2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y), 0], [t[0], t[1], t[2], 1]], dtype=np.float32)
+        return r
+    assert np.allclose(inst[0], trs((0, 0, 0), (0, 0, 0, 1))) and np.allclose(inst[1], trs((3, 0, 0), (0, 0, 1, 0))) and np.allclose(inst[2], trs((0, 4, 0), (0, 1, 0, 0)))
+    dl = h.draw_list()
+    assert len(dl) == 1 and dl[0]["inst_count"] == 3
+    h.close()
+    doc["accessors"][4]["componentType"] = 5123            # translation must be f32
+    _write_raw_glb(path, doc, blob)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    with pytest.raises(H.HostError, match="Vec3F32"):
+        h.load_gltf(path)
+    h.close()
+
+
+def test_hostile_offsets_and_counts_are_refused(tmp_path):
+    """Negative, fractional or enormous byteOffset / byteStride / byteLength / count values must end in an error message, not in a read
+    outside the buffer (they used to be cast to size_t and wrap around the bounds check)."""
+    cases = [
+        (lambda d: d["bufferViews"][0].__setitem__("byteOffset", -4096), "non-negative"),
+        (lambda d: d["bufferViews"][0].__setitem__("byteStride", 2048), "byteStride"),
+        (lambda d: d["bufferViews"][0].__setitem__("byteOffset", 1.8e19), "non-negative|beyond|exceeds"),
+        (lambda d: d["bufferViews"][0].__setitem__("byteLength", 10**9), "exceeds"),
+        (lambda d: d["accessors"][0].__setitem__("byteOffset", 2**40), "exceeds"),
+        (lambda d: d["accessors"][0].__setitem__("count", 2**31), "exceeds"),
+        (lambda d: d["accessors"][0].__setitem__("count", -3), "non-negative"),
+        (lambda d: d["accessors"][0].__setitem__("count", 2.5), "non-negative"),
+        (lambda d: d["accessors"][3].__setitem__("byteOffset", 7), "exceeds"),
+        (lambda d: d["bufferViews"][0].__setitem__("byteLength", 30), "exceeds"),          # accessor runs past the view although the buffer is long enough
+        (lambda d: d["accessors"][0].__setitem__("bufferView", 1e300), "bufferView"),
+        (lambda d: d["bufferViews"][1].__setitem__("buffer", -1), "buffer missing"),
+    ]
+    for mutate, msg in cases:
+        doc, blob = _quad_doc()
+        mutate(doc)
+        path = str(tmp_path / "h.glb")
+        _write_raw_glb(path, doc, blob)
+        h = H.Host(MOCK)
+        h.resize(32, 32)
+        with pytest.raises(H.HostError, match=msg):
+            h.load_gltf(path)
+        h.close()
+    # the image bufferView path has the same checks
+    doc, blob = _quad_doc()
+    doc["bufferViews"].append({"buffer": 0, "byteOffset": 8, "byteLength": 2**33})
+    doc["images"] = [{"bufferView": 2, "mimeType": "image/png"}]
+    doc["textures"] = [{"source": 0}]
+    doc["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    doc["meshes"][0]["primitives"][0]["material"] = 0
+    path = str(tmp_path / "i.glb")
+    _write_raw_glb(path, doc, blob)
+    h = H.Host(MOCK)
+    h.resize(32, 32)
+    with pytest.raises(H.HostError, match="exceeds"):
+        h.load_gltf(path)
+    h.close()
+
+
 def test_unsupported_inputs_fail_loudly(tmp_path):
     doc, blob = _quad_doc()
     jpeg = bytes([0xFF, 0xD8, 0xFF, 0xE0]) + bytes(32)

@@ -79,6 +79,56 @@ def test_mirrors_and_draw_list_match_the_model(name, mock):
     r.close()
 
 
+def _all_blocks_scene():
+    """A box scene whose materials carry every optional block of the PBR word stream (pbr.rs:364-581), the four the shaders do not read
+    (diffuse transmission, dispersion, anisotropy, iridescence) included, alone and all together."""
+    import dataclasses
+    from awsm_renderer_amd.scene_desc import MaterialDesc, NodeDesc, TextureRef
+    sc = scenes.helmet_scene(64, 64, segments=8, rings=6, tex_size=16)
+    T = lambda i: TextureRef(i)   # noqa: E731
+    prim = sc.nodes[-1].primitives[0]
+    extra = [
+        MaterialDesc(diffuse_transmission={"tex": T(0), "factor": 0.4, "color_tex": T(1), "color_factor": (0.9, 0.5, 0.2)}),
+        MaterialDesc(dispersion=0.35),
+        MaterialDesc(anisotropy={"tex": T(2), "strength": 0.7, "rotation": 1.2}),
+        MaterialDesc(iridescence={"tex": T(3), "factor": 0.8, "ior": 1.33, "thickness_tex": T(4), "thickness_min": 120.0, "thickness_max": 380.0}),
+        MaterialDesc(vertex_color_set=None, emissive_strength=2.0, ior=1.45, specular={"factor": 0.8, "color_factor": (1, 0.9, 0.8)},
+                     transmission={"factor": 0.0}, diffuse_transmission={"factor": 0.1}, volume={"thickness_factor": 0.2, "attenuation_distance": 3.0},
+                     clearcoat={"factor": 0.5, "roughness_factor": 0.1}, sheen={"roughness_factor": 0.4, "color_factor": (0.1, 0.2, 0.3)},
+                     dispersion=0.1, anisotropy={"strength": 0.2, "rotation": 0.3}, iridescence={"factor": 0.3}),
+    ]
+    for k, m in enumerate(extra):
+        sc.materials.append(m)
+        sc.nodes.append(NodeDesc(parent=0, translation=(0.1 * k, 0.0, 0.0), primitives=[dataclasses.replace(prim, material=len(sc.materials) - 1)]))
+    return sc
+
+
+def test_every_optional_pbr_block_reaches_the_materials_mirror(mock):
+    """materials/pbr.rs:258-589: the Materials mirror of the C++ host equals the model's word stream, feature indices and block contents,
+    for the blocks the shaders read and for the four they do not (diffuse_transmission 14 words, dispersion 1, anisotropy 7, iridescence 14)."""
+    import struct
+    scene = _all_blocks_scene()
+    r = H.Renderer(scene, backend_path=MOCK, lut_rgba16f=np.zeros((4, 4, 4), dtype=np.uint16))
+    r.render()
+    model = helpers.build_model(scene)
+    got, want = r.host.mirror(sm.BUF_MATERIALS), bytes(model.mirrors()[sm.BUF_MATERIALS])
+    assert got == want
+    assert device_bytes(mock, r.host.device_ctx, sm.BUF_MATERIALS) == want
+    # the last material has all twelve feature indices set, in stream order, with the block sizes of the reference
+    packer = sm.MaterialPacker(model.pool, scene.samplers, model.tex_transforms) if hasattr(model, "pool") else None
+    words = None
+    for off in range(0, len(want), 256):
+        w = struct.unpack_from("<64I", want, off)
+        if w[0] == 1 and all(w[40 + i] != 0 for i in range(12) if i != 0):       # PBR with every block but vertex colour
+            words = w
+    assert words is not None
+    fi = list(words[40:52])
+    sizes = {1: 1, 2: 1, 3: 14, 4: 6, 5: 14, 6: 10, 7: 18, 8: 14, 9: 1, 10: 7}
+    for i, n in sizes.items():
+        assert fi[i + 1] - fi[i] == n, (i, fi)
+    r.close()
+
+
 def test_write_gpu_order_and_frame_sequence(mock):
     """render.rs:73-97 then geometry -> opaque -> submit."""
     r = H.Renderer(scenes.skinned_morph_scene(64, 64, around=8, along=12, tex_size=16), backend_path=MOCK, lut_rgba16f=np.zeros((4, 4, 4), dtype=np.uint16))
