@@ -533,7 +533,7 @@ template <int S>
 __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     __shared__ unsigned long long keys[kTile * kTile * S];   // 8 KB, or 32 KB with 4 samples per pixel: [pixel][sample]
     __shared__ WorkTri work[256];      // mid triangles from the front, big triangles from the back
-    __shared__ uint32_t n_mid, n_big;
+    __shared__ uint32_t n_mid, n_big, next_mid, next_big;
 
     // Heaviest tiles first (tile_order, k_bin_scan).  Consecutive ids go to different XCDs (blockIdx & 7), which also
     // spreads the dense band of the screen over all eight of them.
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     const int lane = tid & 63, wave = tid >> 6;
 
     for (uint32_t base = first; base < count; base += 256u) {
-        if (tid == 0) { n_mid = 0; n_big = 0; }
+        if (tid == 0) { n_mid = 0; n_big = 0; next_mid = 16u; next_big = 4u; }
         __syncthreads();
         const uint32_t idx = base + tid;
         if (idx < count) {
@@ -589,10 +589,12 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         }
         __syncthreads();
         const uint32_t nm = n_mid, nb = n_big;
-        {   // mid: 16 groups of 16 lanes, 4x4 pixel blocks
+        {   // mid: 16 groups of 16 lanes, 4x4 pixel blocks.  The first triangle of a group is its own number; the next ones come from a
+            // shared counter, so a group that drew small triangles takes more of them (they differ 60x in area: a static deal leaves
+            // most of the workgroup waiting at the barrier for the group that drew the large ones).
             const uint32_t group = tid >> 4;
             const int lx = (int)(tid & 3u), ly = (int)((tid >> 2) & 3u);
-            for (uint32_t j = group; j < nm; j += 16u) {
+            for (uint32_t j = group; j < nm; ) {
                 const WorkTri& g = work[j];
                 TriSetup t;
                 load_work_tri(g, t);
@@ -603,9 +605,12 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                         const int px = bx + lx, py = by + ly;
                         if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
                     }
+                uint32_t nx = 0u;
+                if ((tid & 15u) == 0u) nx = atomicAdd(&next_mid, 1u);
+                j = (uint32_t)__shfl((int)nx, 0, 16);
             }
         }
-        for (uint32_t j = wave; j < nb; j += 4u) {   // big: one wavefront per triangle, 8x8 pixel blocks
+        for (uint32_t j = wave; j < nb; ) {   // big: one wavefront per triangle, 8x8 pixel blocks
             const WorkTri& g = work[255u - j];
             TriSetup t;
             load_work_tri(g, t);
@@ -617,6 +622,9 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                     const int px = bx + lx, py = by + ly;
                     if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
                 }
+            uint32_t nx = 0u;
+            if (lane == 0) nx = atomicAdd(&next_big, 1u);
+            j = (uint32_t)__shfl((int)nx, 0, 64);
         }
         __syncthreads();
     }

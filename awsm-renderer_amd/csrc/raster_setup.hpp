@@ -177,11 +177,19 @@ AWSM_DI bool edge_inside(double e, float a, float b) {
 AWSM_DI int msaa4_x(int k) { return k == 0 ? 96 : (k == 1 ? 224 : (k == 2 ? 32 : 160)); }
 AWSM_DI int msaa4_y(int k) { return k == 0 ? 32 : (k == 1 ? 96 : (k == 2 ? 160 : 224)); }
 
+// The top-left rule as one comparison per edge: an edge that owns its zero line (a > 0, or a == 0 and b > 0) accepts E >= 0, the others
+// E > 0.  E >= 0 is E > -(smallest f64 subnormal): nothing lies between that and zero (f64 subnormals are never flushed on gfx950), so
+// edge_inside(E, a, b) == (E > edge_threshold(a, b)) for every E, exact integers (kind 0) and rounded values (kind 1) alike.
+AWSM_DI double edge_threshold(float a, float b) {
+    return (a > 0.0f || (a == 0.0f && b > 0.0f)) ? __longlong_as_double((long long)0x8000000000000001ull) : 0.0;
+}
+
 // Coverage + depth at the sample (X, Y) (pixels, f64).  Returns the packed 64-bit key or ~0 if not covered.
 AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, double X, double Y, uint32_t rank) {
     const EdgeVals ev = tri_edges_d(t, X, Y);
-    if (!edge_inside(ev.E[0], t.a[0], t.b[0]) || !edge_inside(ev.E[1], t.a[1], t.b[1]) || !edge_inside(ev.E[2], t.a[2], t.b[2]))
-        return ~0ull;
+    // all three edges, then one decision (no short-circuit: a nest of exec-masked branches costs more than the two FMAs it may skip)
+    const bool in = ((int)(ev.E[0] > edge_threshold(t.a[0], t.b[0])) & (int)(ev.E[1] > edge_threshold(t.a[1], t.b[1])) & (int)(ev.E[2] > edge_threshold(t.a[2], t.b[2]))) != 0;
+    if (!in) return ~0ull;
     const float e0 = (float)ev.E[0], e1 = (float)ev.E[1], e2 = (float)ev.E[2];
     float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];
     if (!(zn >= 0.0f && zn <= 1.0f)) return ~0ull;
