@@ -297,6 +297,15 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->raster_extra_cap = FB(c).raster_extra_cap; f->raster_slot_cap = FB(c).raster_slot_cap;
     f->big_list = (uint32_t*)FB(c).big_list.ptr;
     f->counters = (uint32_t*)FB(c).counters.ptr;
+#ifdef AWSM_STAMP
+    {
+        static unsigned long long* stamps = nullptr;
+        if (!stamps && hipMalloc((void**)&stamps, 4ull * 16384 * 8 * 8) == hipSuccess) (void)hipMemset(stamps, 0, 4ull * 16384 * 8 * 8);
+        f->stamps = stamps;
+        static bool told = false;
+        if (!told) { told = true; FILE* fp = fopen("/tmp/awsm_stamps_ptr", "w"); if (fp) { fprintf(fp, "%llu\n", (unsigned long long)(uintptr_t)stamps); fclose(fp); } }
+    }
+#endif
     f->host_bin_status = c->counters_host + 16 + 2 * c->slot;
     f->frame_serial = c->frame_serial;
     f->vis = (unsigned long long*)FB(c).vis.ptr;
@@ -1079,6 +1088,16 @@ int awsm_hip_read_visibility(AwsmHipCtx* c, uint64_t* keys_out) {
     HIPCHK(c, hipMemcpy(keys_out, FB(c).vis.ptr, (size_t)c->width * c->height * (c->msaa == 4 ? 4 : 1) * 8, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
+
+#ifdef AWSM_STAMP
+// diagnostic builds only: the geometry kernels' stamps of the last frame, [4 kernels][16384 workgroups][8] u64
+extern "C" int awsm_hip_debug_read_stamps(AwsmHipCtx* c, unsigned long long* out) {
+    FrameDev f;
+    fill_frame(c, &f);
+    if (sync_all(c)) return AWSM_ERR_DEVICE;
+    return hipMemcpy(out, f.stamps, 4ull * 16384 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? AWSM_OK : AWSM_ERR_DEVICE;
+}
+#endif
 
 int awsm_hip_visibility_digest(AwsmHipCtx* c, uint64_t* out2) {
     if (!c || !out2) return AWSM_ERR_INVALID_ARGUMENT;

@@ -165,6 +165,9 @@ struct FrameDev {
     uint32_t raster_extra_cap, raster_slot_cap;
     uint32_t* bin_list;           // bin_capacity
     uint32_t* big_list;           // total_tris: ranks of the triangles covering > 16 tiles (count in counters[4])
+#ifdef AWSM_STAMP
+    unsigned long long* stamps;   // diagnostic builds only (tools/stamp_geometry.sh): [kernel][workgroup][8] s_memrealtime stamps
+#endif
     uint32_t* host_bin_status;    // pinned host memory, 2 words per frame slot: (triangle, tile) entries this frame needed, the frame's serial (k_bin_scan)
     uint32_t frame_serial;
     uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles, [7] extra raster items

@@ -16,6 +16,14 @@
 
 namespace awsm {
 
+// Diagnostic builds (-DAWSM_STAMP, tools/stamp_geometry.sh): where a geometry kernel's workgroups spend their time.  Stamps are the
+// 100 MHz s_memrealtime counter (one time base for the whole chip), written by thread 0 to a buffer nothing else reads.
+#ifdef AWSM_STAMP
+#define AWSM_STAMP_AT(f, kernel, slot) do { if (threadIdx.x == 0 && (f).stamps && blockIdx.x < 16384u) (f).stamps[((size_t)(kernel) * 16384u + blockIdx.x) * 8u + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AWSM_STAMP_AT(f, kernel, slot) do { } while (0)
+#endif
+
 struct GeomMetaDev {
     uint32_t mesh_key_high, mesh_key_low;
     uint32_t morph_len, morph_weights_off, morph_values_off;
@@ -283,6 +291,7 @@ AWSM_DI bool bin_tile_hit(const FrameDev& f, const TriSetup& t, int ntiles, int 
 // (L2 hits); with one (the setting that measured best) the triangle stays in registers: the kernel is one wave of workgroups
 // deep, so its duration is the latency chain of a single workgroup and every dependent load shows.
 constexpr uint32_t kBinBatches = 1;
+static_assert(kBinBatches == 1, "k_bin keeps its triangle in registers across the phases");
 
 // The triangles that cover more than 16 tiles: one wavefront per triangle, 64 tiles per step, block-stride over the list k_bin<count> built.
 template <bool FILL>
@@ -305,15 +314,16 @@ constexpr uint32_t kBinBigBlocks = 64;        // fill pass: the first workgroups
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     __shared__ int win[4];                       // tile window of the workgroup's small triangles: x0, y0, x1, y1
-    __shared__ uint32_t n_ok;
+    __shared__ uint32_t n_ok, n_big_wg, big_base;
     __shared__ uint32_t lcount[kBinWindow];
     __shared__ uint32_t lbase[FILL ? kBinWindow : 1];
 
     const uint32_t tid = threadIdx.x;
-    if (FILL && blockIdx.x < kBinBigBlocks) { bin_big_walk<true>(f, blockIdx.x, kBinBigBlocks); return; }     // workgroup-uniform
+    AWSM_STAMP_AT(f, FILL ? 2 : 0, 0);
+    if (FILL && blockIdx.x < kBinBigBlocks) { bin_big_walk<true>(f, blockIdx.x, kBinBigBlocks); AWSM_STAMP_AT(f, 2, 7); return; }     // workgroup-uniform
     const uint32_t r0 = (blockIdx.x - (FILL ? kBinBigBlocks : 0u)) * (256u * kBinBatches) + tid;
     const int lane = tid & 63;
-    if (tid == 0) { win[0] = 0x7fffffff; win[1] = 0x7fffffff; win[2] = -1; win[3] = -1; n_ok = 0; }
+    if (tid == 0) { win[0] = 0x7fffffff; win[1] = 0x7fffffff; win[2] = -1; win[3] = -1; n_ok = 0; n_big_wg = 0; }
     __syncthreads();
 
     // ---- phase 0: setup (count pass) / load, window of the small triangles, big triangles walked by the wavefront ----
@@ -323,23 +333,40 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
         const uint32_t r = r0 + j * 256u;
         BinTri& b = keep;
         bin_tri_load<!FILL>(f, r, b);
+        AWSM_STAMP_AT(f, FILL ? 2 : 0, 7);
         my_ok += b.ok ? 1u : 0u;
-        if (b.small) { atomicMin(&win[0], b.tx0); atomicMin(&win[1], b.ty0); atomicMax(&win[2], b.tx1); atomicMax(&win[3], b.ty1); }
-        if (!FILL) {   // big triangles go to a global list that k_bin_big walks with one wavefront per triangle
-            const unsigned long long mask = __ballot(b.big);
-            if (mask) {
-                uint32_t base = 0;
-                if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&f.counters[4], (uint32_t)__popcll(mask));
-                base = __shfl(base, __ffsll((long long)mask) - 1);
-                if (b.big) f.big_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+        {   // tile window of the workgroup's small triangles: reduced inside the wavefront first — 256 threads updating the same four LDS
+            // words serialise (measured with in-kernel stamps: 5+ us of an 11 us phase), four atomics per wavefront do not
+            int wx0 = b.small ? b.tx0 : 0x7fffffff, wy0 = b.small ? b.ty0 : 0x7fffffff, wx1 = b.small ? b.tx1 : -1, wy1 = b.small ? b.ty1 : -1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                wx0 = min(wx0, __shfl_xor(wx0, off)); wy0 = min(wy0, __shfl_xor(wy0, off));
+                wx1 = max(wx1, __shfl_xor(wx1, off)); wy1 = max(wy1, __shfl_xor(wy1, off));
             }
+            if (lane == 0 && wx1 >= 0) { atomicMin(&win[0], wx0); atomicMin(&win[1], wy0); atomicMax(&win[2], wx1); atomicMax(&win[3], wy1); }
+        }
+    }
+    uint32_t big_slot = 0;
+    if (!FILL) {   // big triangles go to a global list that k_bin_big walks with one wavefront per triangle: a slot inside the workgroup first
+        const unsigned long long mask = __ballot(keep.big);
+        if (mask) {
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&n_big_wg, (uint32_t)__popcll(mask));
+            big_slot = (uint32_t)__shfl((int)base, __ffsll((long long)mask) - 1) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         }
     }
     if (!FILL) {
         for (int off = 32; off > 0; off >>= 1) my_ok += __shfl_down(my_ok, off);
         if (lane == 0 && my_ok) atomicAdd(&n_ok, my_ok);
     }
+    AWSM_STAMP_AT(f, FILL ? 2 : 0, 1);
     __syncthreads();
+    AWSM_STAMP_AT(f, FILL ? 2 : 0, 2);
+    if (!FILL && n_big_wg) {   // (workgroup-uniform) ... then one returning device atomic per workgroup instead of one per wavefront
+        if (tid == 0) big_base = atomicAdd(&f.counters[4], n_big_wg);
+        __syncthreads();
+        if (keep.big) f.big_list[big_base + big_slot] = r0;
+    }
     const int wx0 = win[0], wy0 = win[1], ww = win[2] - wx0 + 1, wh = win[3] - wy0 + 1;
     const uint32_t nwin = (ww > 0 && wh > 0) ? (uint32_t)ww * (uint32_t)wh : 0u;
     const bool use_lds = nwin <= kBinWindow;                          // workgroup-uniform
@@ -363,6 +390,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     }
     if (!use_lds) return;
     __syncthreads();
+    AWSM_STAMP_AT(f, FILL ? 2 : 0, 3);
     for (uint32_t i = tid; i < nwin; i += 256u) {   // one global atomic per distinct tile of the workgroup
         const uint32_t c = lcount[i];
         if (c) {
@@ -371,8 +399,10 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
             else { lbase[i] = f.tile_offset[gidx] + atomicAdd(&f.tile_cursor[gidx], c); lcount[i] = 0u; }
         }
     }
+    AWSM_STAMP_AT(f, FILL ? 2 : 0, 4);
     if (!FILL) return;
     __syncthreads();
+    AWSM_STAMP_AT(f, 2, 5);
     // ---- phase B: write the ranks into the reserved runs (order inside a tile's list is irrelevant: the raster kernel
     // resolves visibility with a min over packed keys) ----
     for (uint32_t j = 0; j < kBinBatches; j++) {
@@ -389,6 +419,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
                         if (pos < f.bin_capacity) f.bin_list[pos] = r;
                     }
     }
+    AWSM_STAMP_AT(f, 2, 6);
 }
 
 // k_bin_big<FILL>: the triangles that cover more than 16 tiles (near the camera: few, but each a long walk, and they come
@@ -408,6 +439,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
     __shared__ uint32_t bucket_at[16][33];
     __shared__ uint32_t n_extra, n_slots;       // raster items beyond one per tile / scratch tiles (split tiles, see k_raster_tile)
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    AWSM_STAMP_AT(f, 1, 0);
     if (tid == 0) { n_extra = 0u; n_slots = 0u; }
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
@@ -424,6 +456,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         for (uint32_t i = tid; i < n_tiles; i += 1024u) stage[i] = f.tile_count[i];
         __syncthreads();
     }
+    AWSM_STAMP_AT(f, 1, 1);
     uint32_t cnt[8];
 #pragma unroll
     for (uint32_t j = 0; j < 8u; j++) cnt[j] = (b0 + j < b1) ? (staged ? stage[b0 + j] : f.tile_count[b0 + j]) : 0u;
@@ -449,11 +482,13 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         const uint32_t o1 = (uint32_t)__shfl_up((int)incl1, d), o2 = (uint32_t)__shfl_up((int)incl2, d);
         if ((int)lane >= d) { incl1 += o1; incl2 += o2; }
     }
+    AWSM_STAMP_AT(f, 1, 2);
     if (lane == 63u) { part[wave] = incl1; part2[wave] = incl2; }
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) { incl1 += part[w]; incl2 += part2[w]; }
     if (tid < 33u * 16u) bucket_at[e_wave][e_bucket] = incl2 - e_val;
     __syncthreads();
+    AWSM_STAMP_AT(f, 1, 3);
     uint32_t run = incl1 - sum;   // exclusive prefix of this thread's chunk
     // A tile with more than kRasterSlice triangles is rasterised by ceil(c / kRasterSlice) workgroups (its list in slices): one extra
     // raster item per slice after the first, one scratch tile per slice.  The caps hold whenever the bin list itself does not overflow.
@@ -473,6 +508,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
     for (uint32_t j = 0; j < 8u; j++)
         if (b0 + j < b1) place(b0 + j, cnt[j]);
     for (uint32_t i = b0 + 8u; i < b1; i++) place(i, f.tile_count[i]);
+    AWSM_STAMP_AT(f, 1, 4);
     __syncthreads();
     if (staged) for (uint32_t i = tid; i < n_tiles; i += 1024u) { f.tile_offset[i] = stage[i]; f.tile_cursor[i] = 0u; }
     if (tid == 1023u) {
@@ -481,6 +517,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         f.counters[1] = total;
         if (total > f.bin_capacity) f.counters[2] = 1u;
         f.counters[7] = min(n_extra, f.raster_extra_cap);
+        AWSM_STAMP_AT(f, 1, 5);
         if (f.host_bin_status) {   // for frames nobody waits for: the host sizes the list of later frames from this (awsm_hip_geometry_pass)
             __hip_atomic_store(f.host_bin_status, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(f.host_bin_status + 1, f.frame_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -544,6 +581,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     else if (blockIdx.x - n_extra < n_tiles) item = f.tile_order[blockIdx.x - n_extra];
     else return;
     if (item == 0xFFFFFFFFu) return;
+    AWSM_STAMP_AT(f, 3, 0);
     const uint32_t tile = item & 0xFFFFFu, slice = item >> 20;
     const uint32_t tid = threadIdx.x;
     const int tpx = (int)(tile % f.tiles_x) << kTileShift;
@@ -565,6 +603,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         if (tid == 0) { n_mid = 0; n_big = 0; next_mid = 16u; next_big = 4u; }
         __syncthreads();
         const uint32_t idx = base + tid;
+        if (base == first) AWSM_STAMP_AT(f, 3, 1);
         if (idx < count) {
             const uint32_t r = f.bin_list[off + idx];
             TriSetup t;
@@ -588,6 +627,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
             }
         }
         __syncthreads();
+        if (base == first) AWSM_STAMP_AT(f, 3, 2);
         const uint32_t nm = n_mid, nb = n_big;
         {   // mid: 16 groups of 16 lanes, 4x4 pixel blocks.  The first triangle of a group is its own number; the next ones come from a
             // shared counter, so a group that drew small triangles takes more of them (they differ 60x in area: a static deal leaves
@@ -629,6 +669,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         __syncthreads();
     }
     __syncthreads();
+    AWSM_STAMP_AT(f, 3, 3);
     if (split) {
         // Partial tile of a split list: park it in its scratch slot; the slice that finishes last folds the others into its own
         // (min over packed keys, the same resolve as inside a tile) and writes the tile.  The slices run on different XCDs, whose L2s
@@ -668,6 +709,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         const int px = tpx + (p & (kTile - 1)), py = tpy + (p >> kTileShift);
         if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) f.vis[((size_t)py * f.width + px) * S + s] = keys[e];
     }
+    AWSM_STAMP_AT(f, 3, 4);
 }
 
 // Small host->device uploads (dirty ranges of the scene mirrors, the draw list) read the pinned staging ring directly
