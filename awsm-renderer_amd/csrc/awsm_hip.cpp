@@ -114,6 +114,8 @@ struct AwsmHipCtx {
     DevBuf lights_pre;           // per-light constants (k_resolve_draws), sized with the lights buffer
     void* bound_comp = nullptr;
     size_t bound_comp_bytes = 0;
+    const void* opaque_src = nullptr;      // awsm_hip_bind_opaque_source: the gathered full-frame opaque image (sharded transparent pass)
+    size_t opaque_src_bytes = 0;
     int slot = 0;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
@@ -435,7 +437,8 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->raster_extra_cap = 0; f->raster_slot_cap = 0;
     f->big_list = (uint32_t*)t.big_list.ptr;
     f->counters = (uint32_t*)t.counters.ptr;
-    f->opaque_rgba16f = f->out_rgba16f;
+    f->opaque_rgba16f = c->opaque_src ? (const uint16_t*)c->opaque_src : f->out_rgba16f;
+    f->out_compact = 0;                    // the composite is addressed by absolute row
     f->frag_rec = (uint4*)t.frag_rec.ptr; f->frag_color = (float4*)t.frag_color.ptr; f->frag_first = (uint32_t*)t.frag_first.ptr; f->frag_cap = t.frag_cap;
     f->out_rgba16f = (uint16_t*)(c->bound_comp ? c->bound_comp : c->comp16.ptr);
     f->out_rgba32f = (float*)c->comp32.ptr;
@@ -967,8 +970,11 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
 int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->geometry_done || !c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass needs the geometry and opaque passes of the same frame first");
-    if (c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height)))
-        return fail(c, AWSM_ERR_UNSUPPORTED, "transparent_pass on a sharded context (screen-space transmission reads the whole opaque image)");
+    const bool sharded = c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height));
+    if (sharded && !c->opaque_src)
+        return fail(c, AWSM_ERR_UNSUPPORTED, "transparent_pass on a sharded context: screen-space transmission reads the whole opaque image — gather it and bind it with awsm_hip_bind_opaque_source first");
+    if (c->opaque_src && c->opaque_src_bytes < (size_t)c->width * c->height * 8)
+        return fail(c, AWSM_ERR_INVALID_ARGUMENT, "transparent_pass: the bound opaque source holds %zu bytes, the frame needs %zu", c->opaque_src_bytes, (size_t)c->width * c->height * 8);
     static const AwsmBuf need[] = {AWSM_BUF_TRANSFORMS, AWSM_BUF_CAMERA, AWSM_BUF_GEOM_META, AWSM_BUF_MATERIAL_META, AWSM_BUF_MATERIALS, AWSM_BUF_ATTR_INDEX,
                                    AWSM_BUF_ATTR_DATA, AWSM_BUF_TEXTURE_TRANSFORMS, AWSM_BUF_LIGHTS_INFO, AWSM_BUF_LIGHTS, AWSM_BUF_TRANSPARENCY_GEOM_DATA};
     if (n) {
@@ -1176,6 +1182,13 @@ int awsm_hip_read_opaque_f32(AwsmHipCtx* c, float* out) {
     HIPCHK(c, hipSetDevice(c->device));
     { int rcs = sync_all(c); if (rcs) return rcs; }
     HIPCHK(c, hipMemcpy(out, c->out32.ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+    return AWSM_OK;
+}
+
+int awsm_hip_bind_opaque_source(AwsmHipCtx* c, const void* device_ptr, size_t bytes) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (device_ptr && bytes == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "bind_opaque_source: zero-sized image");
+    c->opaque_src = device_ptr; c->opaque_src_bytes = bytes;
     return AWSM_OK;
 }
 

@@ -76,6 +76,12 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
     return reconstruct_core<DERIVS>(t, n0, n1, n2, t0, t1, t2, cx, cy);
 }
 
+// Is pixel row `py` one this shard shades (row strip: [sy0, sy1); bands: the 32-row tile rows r, r + n, ...)?
+AWSM_DI bool row_owned(const FrameDev& f, int py) {
+    if (py < (int)f.sy0 || py >= (int)f.sy1) return false;
+    return f.band_n <= 1u || (((uint32_t)py >> kTileShift) % f.band_n) == f.band_r;
+}
+
 // ---- MSAA edge predicates (helpers/msaa.wgsl), STRICT: a decision that flips between implementations would swap a
 // pixel between one-sample and four-sample shading, so every value feeding a threshold follows the arithmetic contract ----
 constexpr float kEdgeNormalThreshold = 0.95f, kEdgeDepthThreshold = 0.02f, kEdgeMsaaDepthThreshold = 0.02f;
@@ -1313,7 +1319,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
     const int tx0 = ((int)(tile % f.tiles_x) << kTileShift) + (kFwdNB == 4 ? (int)(sub & 1u) * kRectW : 0);
     const int ty0 = ((int)(f.tile_row0 + (tile / f.tiles_x) * f.band_n) << kTileShift) + (kFwdNB == 4 ? (int)(sub >> 1) : (int)sub) * kRectH;
     const int px = tx0 + (int)(blk % kFwdBW) * kFwdBlock + (int)(lane & 7u), py = ty0 + (int)(blk / kFwdBW) * kFwdBlock + (int)(lane >> 3);
-    const bool in_frame = px < (int)f.width && py < (int)f.height;
+    const bool in_frame = px < (int)f.width && py < (int)f.height && row_owned(f, py);       // a strip's edge tiles hold rows of the neighbouring shard
     const bool wave_active = __builtin_amdgcn_ballot_w64(in_frame) != 0ull;
     const size_t p = in_frame ? (size_t)py * f.width + (size_t)px : 0;
 
@@ -1489,6 +1495,7 @@ template <int S>
 __global__ __launch_bounds__(256) void k_forward_blend(FrameDev f) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= f.width * f.height) return;
+    if (!row_owned(f, (int)(p / f.width))) return;                               // sharded: only this shard's rows of the composite
     const uint2 c0 = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];       // opaque -> transparent blit: every sample starts as the opaque colour
     float dst[S][4];
 #pragma unroll

@@ -240,9 +240,15 @@ int awsm_hip_opaque_pass(AwsmHipCtx* ctx, const AwsmOpaqueParams* params);
  * (One / OneMinusSrcAlpha), depth test LessEqual against the geometry pass's depth, depth write, screen-space transmission from
  * the opaque image.  Call after awsm_hip_opaque_pass of the same frame (it uses that call's mipmap mode and the context's MSAA
  * mode).  The result is the `composite` image (awsm_hip_read_composite / awsm_hip_bind_composite); the opaque image is
- * unchanged.  n_draws = 0 is valid (composite = opaque).  Not available on a sharded context (transmission reads the whole
- * opaque image): AWSM_ERR_UNSUPPORTED. ---- */
+ * unchanged.  n_draws = 0 is valid (composite = opaque).
+ * On a sharded context (row strip or bands) the pass covers, shades and blends this shard's rows only, but screen-space transmission
+ * reads the WHOLE opaque image: gather the ranks' opaque rows first and hand the full [height][width] RGBA16F image in with
+ * awsm_hip_bind_opaque_source (without it: AWSM_ERR_UNSUPPORTED).  The composite is addressed by absolute row (full-size target),
+ * whatever layout the opaque output has. ---- */
 int awsm_hip_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
+/* the full-frame opaque image the transparent pass of a sharded context blits from and refracts through (device memory, width*height*8
+ * bytes, kept by reference until replaced; NULL = this context's own opaque output, which is complete only when unsharded) */
+int awsm_hip_bind_opaque_source(AwsmHipCtx* ctx, const void* device_ptr, size_t bytes);
 
 /* ---- gpu.submit_commands(encoder.finish()) (crates/renderer/src/render.rs:370): waits for the frame,
  * fills per-kernel times.  `out` may be NULL. ---- */

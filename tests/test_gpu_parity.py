@@ -564,6 +564,42 @@ def test_instanced_meshes(msaa, oracle_lut):
     rr.close()
 
 
+# ------------------------------------------------------------------------------------------------ the two opaque routes
+
+@pytest.mark.gpu
+def test_lean_and_general_opaque_routes_agree(oracle_lut):
+    """k_shade_lean + k_shade_todo against k_shade (AWSM_CFG_GENERAL_SHADE_ONLY) on the same frames: same keys, colours within a tenth of
+    the shading tolerance of each other (same formulas, different instruction order).  The atrium is all lean; the zoo mixes lean
+    draws with every kind that is not (unlit, optional blocks, debug views, non-repeat samplers, texture transforms), so wavefronts that
+    straddle both kinds go to the general kernel; the scene below adds texture coordinates in the millions, beyond the lean sampler's range."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    big_uv = scenes.helmet_scene(320, 180, segments=32, rings=24, tex_size=32)
+    for n in big_uv.nodes:
+        for p in n.primitives:
+            p.uvs = [uv * np.float32(3.0e6) for uv in p.uvs]
+    cases = {"atrium": scenes.atrium_scene(640, 360, detail=0.25, tex_scale=1 / 32), "zoo": scenes.material_zoo_scene(400, 300), "huge_uv": big_uv}
+    for name, sc in cases.items():
+        model = helpers.build_model(sc)
+        lean, st_lean = helpers.hip_frame(model, oracle_lut)
+        gen, st_gen = helpers.hip_frame(model, oracle_lut, dev=HipDevice(parity_tap=True, general_shade_only=True))
+        a, b = lean.read_opaque_f32().astype(np.float64), gen.read_opaque_f32().astype(np.float64)
+        assert (lean.read_visibility() == gen.read_visibility()).all()
+        waves = int(st_lean["shade_general_wavefronts"])
+        lean.close(); gen.close()
+        bound = 1e-5 * np.maximum(1.0, np.abs(b))
+        assert (np.abs(a - b) <= bound).all(), (name, float((np.abs(a - b) / bound).max()))
+        assert st_gen["shade_general_wavefronts"] == 0
+        total_waves = ((sc.width + 15) // 16) * ((sc.height + 15) // 16) * 4
+        if name == "atrium":
+            assert waves == 0
+        elif name == "zoo":
+            assert 0 < waves < total_waves                     # both kernels shaded part of the frame
+        else:
+            assert waves > 0                                   # the range guard sent covered wavefronts to the general kernel
+            orc = helpers.oracle_frame(model, oracle_lut)
+            assert (np.abs(a - orc.rgba32f.astype(np.float64)) <= RGB_TOL * np.maximum(1.0, np.abs(orc.rgba32f))).all()
+
+
 # ------------------------------------------------------------------------------------------------ texel cubemaps (SURVEY §8 a21 / a23)
 
 def _with_environment(sc, size=32):
@@ -680,6 +716,65 @@ def test_transparent_pass_through_the_host_layer(oracle_lut):
     assert c["clip_mismatch"] == 0 and c["nt_mismatch"] == 0 and c["wpos_mismatch"] == 0 and c["untouched_changed"] == 0, c
     assert c["pixels_over_2ulp"] <= c["touched_pixels"] // 200 and c["pixels_over_bound"] <= c["touched_pixels"] // 200, c
     assert stats["forward_triangles"] > 0 and stats["ms_forward"] > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n,msaa", [("bands", 2, 0), ("bands", 3, 0), ("rows", 2, 0), ("rows", 3, 4)])
+def test_transparent_pass_on_sharded_contexts(mode, n, msaa, oracle_lut):
+    """N contexts, each shading its rows (bands or strips): opaque pass per shard, the ranks' opaque rows gathered into one full image
+    (here: row copies between torch tensors on the one GPU; with real ranks an all-gather), awsm_hip_bind_opaque_source, transparent
+    pass per shard, composite rows gathered — must equal the unsharded composite bit for bit (screen-space transmission samples the
+    opaque image anywhere on the screen, the blend is per pixel)."""
+    import torch
+    from awsm_renderer_amd import sharding
+    from awsm_renderer_amd.hip_backend import HipDevice
+    sc = scenes.transparent_scene(480, 270, tex_size=64)
+    W, H = sc.width, sc.height
+    model = helpers.build_model(sc)
+    model.collect_draws()
+    tr = model.collect_transparent_draws()
+    ref, _ = helpers.hip_frame(model, oracle_lut, msaa=msaa, transparent=True)
+    want = ref.read_composite()
+    want_opaque = ref.read_opaque()
+    ref.close()
+    assert (want != want_opaque).any()
+    per = (H + n - 1) // n
+    rows_of = [np.array(sharding.band_rows(H, n, r)) if mode == "bands" else np.arange(min(r * per, H), min(r * per + per, H)) for r in range(n)]
+    devs, opaque, comp = [], [], []
+    gathered = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+    for r in range(n):
+        dev = HipDevice(parity_tap=False)
+        opaque.append(torch.zeros((H, W, 4), dtype=torch.float16, device="cuda"))
+        comp.append(torch.zeros((H, W, 4), dtype=torch.float16, device="cuda"))
+        dev.resize(W, H, msaa)
+        dev.upload_mirrors(model.mirrors())
+        for i, t in enumerate(model.texture_arrays()):
+            dev.texture_array_upload(i, t["texels"])
+        for i, smp in enumerate(sc.samplers):
+            dev.sampler_set(i, smp)
+        dev.env_upload(sc.skybox_rgba, sc.prefiltered_rgb, sc.irradiance_rgb, oracle_lib_rgba16f(oracle_lut))
+        if mode == "bands":
+            dev.set_shard_bands(n, r)
+        else:
+            dev.set_shard_rows(int(rows_of[r][0]), int(rows_of[r][-1]) + 1)
+        dev.bind_output(opaque[r].data_ptr(), H * W * 8)
+        dev.bind_composite(comp[r].data_ptr(), H * W * 8)
+        dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); dev.frame_end()
+        idx = torch.as_tensor(rows_of[r], device="cuda")
+        gathered[idx] = opaque[r][idx]                         # the "all-gather" of the opaque rows
+        devs.append(dev)
+    torch.cuda.synchronize()
+    assert (gathered.cpu().numpy().view(np.uint16) == want_opaque).all()
+    final = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+    for r, dev in enumerate(devs):
+        dev.bind_opaque_source(gathered.data_ptr(), H * W * 8)
+        dev.transparent_pass(tr); dev.frame_end()
+        idx = torch.as_tensor(rows_of[r], device="cuda")
+        final[idx] = comp[r][idx]
+        dev.close()
+    torch.cuda.synchronize()
+    got = final.cpu().numpy().view(np.uint16)
+    assert (got == want).all(), int((got != want).any(axis=2).sum())
 
 
 @pytest.mark.gpu
