@@ -34,6 +34,7 @@ int awsm_shade_is_lean(const FrameDev* f);
 int awsm_launch_shade_todo(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
+void awsm_launch_msaa_halo_export(const FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s);
 void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, unsigned long long* out, hipStream_t s);
 void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s);
 void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n, hipStream_t s);
@@ -114,6 +115,8 @@ struct AwsmHipCtx {
     DevBuf lights_pre;           // per-light constants (k_resolve_draws), sized with the lights buffer
     void* bound_comp = nullptr;
     size_t bound_comp_bytes = 0;
+    const void* msaa_halo = nullptr;       // awsm_hip_msaa_halo_bind
+    size_t msaa_halo_bytes = 0;
     const void* opaque_src = nullptr;      // awsm_hip_bind_opaque_source: the gathered full-frame opaque image (sharded transparent pass)
     size_t opaque_src_bytes = 0;
     int slot = 0;
@@ -315,6 +318,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa = c->msaa;
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
+    f->msaa_halo = (const unsigned long long*)c->msaa_halo;
+    f->halo_bands = c->band_n > 1 ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16.ptr);   // kernels address by absolute row
     f->out_rgba32f = (float*)c->out32.ptr;
     f->lights_pre = (float4*)c->lights_pre.ptr;
@@ -743,9 +748,33 @@ int awsm_hip_set_shard_bands(AwsmHipCtx* c, uint32_t n, uint32_t r, uint32_t com
     if (c->width == 0) return fail(c, AWSM_ERR_NOT_READY, "set_shard_bands before resize");
     if (n == 0 || r >= n) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "set_shard_bands: need r < n (got n=%u r=%u)", n, r);
     { int rcs = sync_all(c); if (rcs) return rcs; }
-    if (n > 1 && c->msaa) return fail(c, AWSM_ERR_UNSUPPORTED, "set_shard_bands: with MSAA use set_shard_rows (row strips carry the one-row halo the edge detector needs; bands would need one per band)");
     c->y0 = c->y1 = 0;                                   // bands and row ranges are alternatives
     c->band_n = n; c->band_r = n > 1 ? r : 0; c->band_compact = (n > 1 && compact_output) ? 1u : 0u;
+    return AWSM_OK;
+}
+
+uint32_t awsm_hip_msaa_halo_bands(AwsmHipCtx* c) {
+    return (c && c->band_n > 1 && c->height) ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
+}
+
+int awsm_hip_msaa_halo_export(AwsmHipCtx* c, void* dst, size_t bytes) {
+    if (!c || !dst) return AWSM_ERR_INVALID_ARGUMENT;
+    if (c->msaa != 4 || c->band_n <= 1) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "msaa_halo_export: only for MSAA x4 with band sharding");
+    if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "msaa_halo_export before geometry_pass");
+    const uint32_t bands = awsm_hip_msaa_halo_bands(c);
+    if (bytes < (size_t)bands * 2 * c->width * 8) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "msaa_halo_export: %zu bytes, %zu needed (%u bands x 2 rows x %u keys)", bytes, (size_t)bands * 2 * c->width * 8, bands, c->width);
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameDev f;
+    fill_frame(c, &f);
+    awsm_launch_msaa_halo_export(&f, (unsigned long long*)dst, bands, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return AWSM_OK;
+}
+
+int awsm_hip_msaa_halo_bind(AwsmHipCtx* c, const void* gathered, size_t bytes) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    if (gathered && bytes == 0) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "msaa_halo_bind: zero-sized array");
+    c->msaa_halo = gathered; c->msaa_halo_bytes = bytes;
     return AWSM_OK;
 }
 
@@ -958,6 +987,11 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
                                        AWSM_BUF_ATTR_DATA, AWSM_BUF_TEXTURE_TRANSFORMS, AWSM_BUF_LIGHTS_INFO, AWSM_BUF_LIGHTS};
         for (AwsmBuf b : need) if (!c->bufs[b].ptr) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass: buffer %d missing", (int)b);
         if (!c->lut.ptr) return fail(c, AWSM_ERR_NOT_READY, "opaque_pass: no BRDF LUT (env_upload or brdf_lut_generate)");
+    }
+    if (c->msaa == 4 && c->band_n > 1 && p->has_opaque) {
+        const size_t need = (size_t)c->band_n * awsm_hip_msaa_halo_bands(c) * 2 * c->width * 8;
+        if (!c->msaa_halo || c->msaa_halo_bytes < need)
+            return fail(c, AWSM_ERR_NOT_READY, "opaque_pass: MSAA with band sharding needs the gathered halo keys (awsm_hip_msaa_halo_export -> all-gather -> awsm_hip_msaa_halo_bind, %zu bytes)", need);
     }
     HIPCHK(c, hipSetDevice(c->device));
     c->last_opaque = *p;

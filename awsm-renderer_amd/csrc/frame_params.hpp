@@ -177,6 +177,8 @@ struct FrameDev {
     float* out_rgba32f;           // optional parity tap (may be null)
     float4* msaa_color0;          // MSAA: width*height, f32 colour of sample 0 for the pixels in msaa_edges
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
+    const unsigned long long* msaa_halo;   // MSAA + bands: sample-0 keys of the first / last row of EVERY rank's bands, [rank][band][2][width] (gathered)
+    uint32_t halo_bands;          // bands per rank in that array
     const uint16_t* opaque_rgba16f;   // transparent pass: the opaque pass's image (blit source and transmission background); out_rgba16f/32f = composite
     // transparent pass fragment lists (k_forward_cover -> k_forward_shade -> k_forward_blend): counters[5] = fragments, counters[6] = overflow flag
     uint4* frag_rec;              // frag_cap records {triangle rank, pixel x | y << 16, next fragment of the pixel (0xFFFFFFFF = last), sample mask | resolved-mask flag << 8}

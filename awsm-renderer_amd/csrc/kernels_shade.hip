@@ -1902,7 +1902,12 @@ struct NeighbourCell { float nx, ny, nz; uint32_t depth_bits; uint32_t state; };
 AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& f, int px, int py) {
     NeighbourCell c = {0.0f, 0.0f, 0.0f, 0u, 0u};
     if (px >= 0 && px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) {   // rasterised rows: the shard's + one halo row each side
-        const unsigned long long k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
+        unsigned long long k;
+        if (f.band_n > 1u && (((uint32_t)py >> kTileShift) % f.band_n) != f.band_r) {
+            // band sharding: the row belongs to another rank's band; its sample-0 keys came through the halo exchange (first / last row of a band)
+            const uint32_t ty = (uint32_t)py >> kTileShift, which = ((uint32_t)py & (uint32_t)(kTile - 1)) == 0u ? 0u : 1u;
+            k = f.msaa_halo ? f.msaa_halo[((((size_t)(ty % f.band_n) * f.halo_bands + ty / f.band_n) * 2u + which) * f.width) + (size_t)px] : ~0ull;
+        } else k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
         c.state = 1u;
         if (k != ~0ull) {
             const GBufferTexel g = reconstruct_gbuffer<false>(f, key_rank(k), px, py);
@@ -2083,6 +2088,21 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t* __restrict__ out_rg1
     out_rg16f[(size_t)j * width + i] = (uint32_t)f16_bits(a) | ((uint32_t)f16_bits(bsum) << 16);
 }
 
+// MSAA + band sharding: the sample-0 keys of the first and the last row of each band this shard owns, [band][2][width]; bands beyond
+// the shard's own count (ranks own unequal numbers) are filled with "no hit".  What the ranks all-gather between the two passes.
+__global__ __launch_bounds__(256) void k_msaa_halo_export(FrameDev f, unsigned long long* __restrict__ dst, uint32_t bands_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= bands_out * 2u * f.width) return;
+    const uint32_t x = i % f.width, which = (i / f.width) & 1u, l = i / (2u * f.width);
+    unsigned long long k = ~0ull;
+    if (l < f.tiles_y) {
+        const uint32_t ty = f.tile_row0 + l * f.band_n;
+        const uint32_t y = which ? min((ty << kTileShift) + (uint32_t)(kTile - 1), f.height - 1u) : (ty << kTileShift);
+        k = f.vis[((size_t)y * f.width + x) * 4];
+    }
+    dst[i] = k;
+}
+
 // covered-pixel count for AwsmFrameStats: runs only when the caller asks for stats (frame_end), never in the frame itself.
 // (A per-wave atomicAdd on one counter inside k_shade serialised ~130k same-address atomics per 4K frame.)
 __global__ __launch_bounds__(256) void k_count_covered(const unsigned long long* __restrict__ vis, uint32_t width, uint32_t y0, uint32_t y1,
@@ -2176,6 +2196,10 @@ extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameD
     else { if (grad) hipLaunchKernelGGL((awsm::k_forward_cover<1, true>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); else hipLaunchKernelGGL((awsm::k_forward_cover<1, false>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); }
     if (nb_shade) { if (grad) hipLaunchKernelGGL(awsm::k_forward_shade<true>, dim3(nb_shade), dim3(256), 0, s, sc, *f); else hipLaunchKernelGGL(awsm::k_forward_shade<false>, dim3(nb_shade), dim3(256), 0, s, sc, *f); }
     if (ms) hipLaunchKernelGGL(awsm::k_forward_blend<4>, dim3(nb_blend), dim3(256), 0, s, *f); else hipLaunchKernelGGL(awsm::k_forward_blend<1>, dim3(nb_blend), dim3(256), 0, s, *f);
+}
+extern "C" void awsm_launch_msaa_halo_export(const awsm::FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s) {
+    const uint32_t n = bands_out * 2u * f->width;
+    if (n) hipLaunchKernelGGL(awsm::k_msaa_halo_export, dim3((n + 255u) / 256u), dim3(256), 0, s, *f, dst, bands_out);
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
     if (f->sy1 > f->sy0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->sy0, f->sy1, f->band_n, f->band_r, f->msaa, f->counters + 3);

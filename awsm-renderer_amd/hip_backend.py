@@ -30,7 +30,7 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
-           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload", "awsm_hip_bind_opaque_source"]
+           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload", "awsm_hip_bind_opaque_source", "awsm_hip_msaa_halo_bands", "awsm_hip_msaa_halo_export", "awsm_hip_msaa_halo_bind"]
 
 
 class AwsmConfig(C.Structure):
@@ -123,6 +123,10 @@ def load_library():
     lib.awsm_hip_read_composite_f32.argtypes = [C.c_void_p, C.c_void_p]
     lib.awsm_hip_bind_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.awsm_hip_bind_opaque_source.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.awsm_hip_msaa_halo_bands.argtypes = [C.c_void_p]
+    lib.awsm_hip_msaa_halo_bands.restype = C.c_uint32
+    lib.awsm_hip_msaa_halo_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.awsm_hip_msaa_halo_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.awsm_hip_read_transformed_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     _lib = lib
     return lib
@@ -298,6 +302,17 @@ class HipDevice:
 
     def bind_output(self, device_ptr: Optional[int], nbytes: int = 0):
         self._chk(self.lib.awsm_hip_bind_output(self.ctx, device_ptr, nbytes), "bind_output")
+
+    def msaa_halo_bands(self) -> int:
+        return int(self.lib.awsm_hip_msaa_halo_bands(self.ctx))
+
+    def msaa_halo_export(self, device_ptr: int, nbytes: int):
+        """MSAA + bands: this rank's [bands][2][width] u64 boundary keys into device memory (to be all-gathered)."""
+        self._chk(self.lib.awsm_hip_msaa_halo_export(self.ctx, device_ptr, nbytes), "msaa_halo_export")
+
+    def msaa_halo_bind(self, device_ptr: Optional[int], nbytes: int = 0):
+        """The gathered [n][bands][2][width] u64 array the next opaque pass reads its neighbours' rows from."""
+        self._chk(self.lib.awsm_hip_msaa_halo_bind(self.ctx, device_ptr, nbytes), "msaa_halo_bind")
 
     def bind_opaque_source(self, device_ptr: Optional[int], nbytes: int = 0):
         """Sharded transparent pass: the gathered full-frame opaque image (None = the context's own output)."""

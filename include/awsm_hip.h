@@ -178,7 +178,7 @@ int awsm_hip_buffer_write(AwsmHipCtx* ctx, AwsmBuf which, size_t dst_off, const 
  * are evaluated at the pixel centre, as @interpolate(perspective, center) does), and the opaque pass runs the edge
  * detector + per-sample resolve of material_opaque_wgsl/helpers/{msaa,material_shading}.wgsl.  The output image stays
  * single-sampled.  Sharding with MSAA: row strips (awsm_hip_set_shard_rows; one halo row each side is rasterised for the
- * edge detector); bands are refused. ---- */
+ * edge detector), or bands with the halo exchange below. ---- */
 int awsm_hip_resize(AwsmHipCtx* ctx, uint32_t width, uint32_t height, uint32_t msaa);
 
 /* ---- multi-GPU screen sharding (new; no reference counterpart): this ctx rasterises and shades only
@@ -193,6 +193,17 @@ int awsm_hip_set_shard_rows(AwsmHipCtx* ctx, uint32_t y0, uint32_t y1);
  * layout an all-gather wants; otherwise rows keep their absolute position.  The visibility buffer is always
  * addressed by absolute row.  Rows owned by a shard are bit-identical to the same rows of the unsharded frame. */
 int awsm_hip_set_shard_bands(AwsmHipCtx* ctx, uint32_t n, uint32_t r, uint32_t compact_output);
+/* MSAA x4 with band sharding.  The edge detector (helpers/msaa.wgsl:42-112) compares a pixel with sample 0 of its four neighbours; for the
+ * first and last row of a band the vertical neighbour lies in a band another rank rasterised.  So the frame gets ONE exchange step:
+ * after the geometry pass every rank exports the sample-0 keys of the first and last row of each of its bands
+ * (awsm_hip_msaa_halo_export: awsm_hip_msaa_halo_bands() x 2 x width u64, enqueued on the context's stream), the ranks all-gather those
+ * arrays in rank order (RCCL), and every rank binds the gathered [n][bands][2][width] array before its opaque pass
+ * (awsm_hip_msaa_halo_bind; kept by reference).  Every rank holds every triangle's setup record and vertex normals (the scene is
+ * replicated, vertices are transformed redundantly), so a key is all a neighbour needs.  Without a bound array the opaque pass of an
+ * MSAA band shard fails with AWSM_ERR_NOT_READY. */
+uint32_t awsm_hip_msaa_halo_bands(AwsmHipCtx* ctx);     /* ceil(ceil(height / 32) / n): bands per rank in both arrays */
+int awsm_hip_msaa_halo_export(AwsmHipCtx* ctx, void* dst_device, size_t bytes);
+int awsm_hip_msaa_halo_bind(AwsmHipCtx* ctx, const void* gathered_device, size_t bytes);
 
 /* ---- texture pool bind (crates/renderer/src/render_passes/material_opaque/bind_group.rs:331-360):
  * array `array_idx` is a texture_2d_array of `layers` w x h images; texels = layers*h*w*4 bytes, layer-major: mip

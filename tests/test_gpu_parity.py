@@ -362,13 +362,15 @@ def test_msaa4_geometry_and_edge_resolve(name, oracle_lut):
 
 
 @pytest.mark.gpu
-def test_msaa4_excludes_band_sharding_and_switches_back(oracle_lut):
+def test_msaa4_band_sharding_needs_the_halo_and_switching_back(oracle_lut):
     from awsm_renderer_amd.hip_backend import HipDevice, AwsmHipError
     sc = scenes.box_scene(96, 64)
     model = helpers.build_model(sc)
     dev, _ = helpers.hip_frame(model, oracle_lut, msaa=4)
-    with pytest.raises(AwsmHipError):
-        dev.set_shard_bands(2, 0)                          # bands + MSAA: not supported (each band would need its own halo rows)
+    dev.set_shard_bands(2, 0)                              # bands + MSAA: allowed, but the opaque pass needs the neighbours' boundary keys
+    dev.geometry_pass(model.collect_draws())
+    with pytest.raises(AwsmHipError, match="halo"):
+        dev.opaque_pass()
     dev.resize(sc.width, sc.height, 0)                       # back to single-sample on the same context
     dev.geometry_pass(model.collect_draws()); dev.opaque_pass(); dev.frame_end()
     orc = helpers.oracle_frame(model, oracle_lut)
@@ -376,6 +378,53 @@ def test_msaa4_excludes_band_sharding_and_switches_back(oracle_lut):
     with pytest.raises(AwsmHipError):
         dev.resize(sc.width, sc.height, 2)
     dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3])
+def test_msaa4_band_sharding_with_halo_exchange(n, oracle_lut):
+    """MSAA x4 + bands: after the geometry pass every rank exports the sample-0 keys of its bands' first and last rows, the arrays are
+    gathered in rank order (here: a torch.stack on the one GPU; with real ranks the frame's one RCCL all-gather), bound, and the opaque
+    pass's edge detector reads its vertical neighbours across band borders from them.  Every owned row must equal the unsharded
+    MSAA frame bit for bit — keys (4 samples) and resolved colours; 363 rows: the last band is partial, n = 3 leaves ranks with
+    unequal band counts."""
+    import torch
+    from awsm_renderer_amd import sharding
+    from awsm_renderer_amd.hip_backend import HipDevice
+    sc = scenes.atrium_scene(641, 363, detail=0.25, tex_scale=1 / 32)
+    W, H = sc.width, sc.height
+    model = helpers.build_model(sc)
+    ref, _ = helpers.hip_frame(model, oracle_lut, msaa=4)
+    want_keys, want = ref.read_visibility(), ref.read_opaque()
+    ref.close()
+    devs, mine = [], []
+    for r in range(n):
+        dev = HipDevice(parity_tap=False)
+        dev.resize(W, H, 4)
+        dev.upload_mirrors(model.mirrors())
+        for i, t in enumerate(model.texture_arrays()):
+            dev.texture_array_upload(i, t["texels"])
+        for i, smp in enumerate(sc.samplers):
+            dev.sampler_set(i, smp)
+        dev.env_upload(sc.skybox_rgba, sc.prefiltered_rgb, sc.irradiance_rgb, oracle_lib_rgba16f(oracle_lut))
+        dev.set_shard_bands(n, r)
+        dev.geometry_pass(model.collect_draws())
+        L = dev.msaa_halo_bands()
+        assert L == -(-(-(-H // 32)) // n)
+        buf = torch.zeros((L, 2, W), dtype=torch.int64, device="cuda")
+        dev.msaa_halo_export(buf.data_ptr(), L * 2 * W * 8)
+        devs.append(dev); mine.append(buf)
+    for dev in devs:
+        dev.frame_end()
+    gathered = torch.stack(mine).contiguous()                       # [n][L][2][W]
+    for r, dev in enumerate(devs):
+        dev.msaa_halo_bind(gathered.data_ptr(), gathered.numel() * 8)
+        dev.opaque_pass(); dev.frame_end()
+        rows = np.array(sharding.band_rows(H, n, r))
+        assert (dev.read_visibility()[rows] == want_keys[rows]).all()
+        got = dev.read_opaque()
+        assert (got[rows] == want[rows]).all(), (r, int((got[rows] != want[rows]).any(axis=2).sum()))
+        dev.close()
 
 
 @pytest.mark.gpu
