@@ -1961,20 +1961,21 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 
     // ---- phase 2: compute.wgsl main ----
     const size_t p = (size_t)cy * f.width + (size_t)cx;
+    const size_t po = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : p;   // output pixel (compact band layout)
     uint8_t* edge_rec = reinterpret_cast<uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     bool is_edge = false;
     if (inside) {
         const f4 sky = skybox_color(sc, f, cx, cy);
         const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
         if (!f.has_opaque || !any_hit) {
-            store_pixel(f, p, sky);                                        // compute.wgsl:121-143
+            store_pixel(f, po, sky);                                        // compute.wgsl:121-143
         } else if (k4[0] == ~0ull) {
             f.msaa_color0[p] = make_float4(sky.x, sky.y, sky.z, sky.w);   // compute.wgsl:155-170: sample 0 is background, others are not
             is_edge = true;
         } else {
             const SurfaceOut o = shade_surface<GRAD>(sc, f, key_rank(k4[0]), cx, cy, key_depth(k4[0]), g0, true);
-            if (o.kind == 2u) store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f});   // hud
-            else if (o.kind == 1u) store_pixel(f, p, o.color);                 // debug view: written before the edge test
+            if (o.kind == 2u) store_pixel(f, po, f4{0.0f, 0.0f, 0.0f, 0.0f});   // hud
+            else if (o.kind == 1u) store_pixel(f, po, o.color);                 // debug view: written before the edge test
             else {
                 // compute.wgsl:303-318 + msaa.wgsl:201-237 (STRICT)
                 const m4 inv_proj = load_m4(reinterpret_cast<const float*>(f.camera + 256));
@@ -2001,7 +2002,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
                     }
                 }
                 if (is_edge) f.msaa_color0[p] = make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
-                else store_pixel(f, p, o.color);
+                else store_pixel(f, po, o.color);
             }
         }
     }
@@ -2022,6 +2023,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __re
     const uint32_t slot = edge_rec[4u + threadIdx.x];
     const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
     const size_t p = (size_t)cy * f.width + (size_t)cx;
+    const size_t po = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : p;
     const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + p * 4);
     const ulonglong2 ka = kp[0], kb = kp[1];
     const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
@@ -2043,7 +2045,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __re
     }
     const f4 sum = {((col[0].x + col[1].x) + col[2].x) + col[3].x, ((col[0].y + col[1].y) + col[2].y) + col[3].y,
                     ((col[0].z + col[1].z) + col[2].z) + col[3].z, ((col[0].w + col[1].w) + col[2].w) + col[3].w};
-    store_pixel(f, p, {sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f});
+    store_pixel(f, po, {sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f});
 }
 #pragma clang fp contract(off)
 

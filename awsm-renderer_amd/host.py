@@ -90,6 +90,7 @@ def load_library():
         "awsm_host_set_ibl_mip_counts": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_camera_update": (C.c_int, [vp, F32P, F32P, F32P]), "awsm_host_env": (C.c_int, [vp, vp]),
         "awsm_host_env_cube": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, vp]),
+        "awsm_host_set_render_hooks": (C.c_int, [vp, vp, vp, vp, vp]),
         "awsm_host_brdf_lut_generate": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_resize": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_set_shard_rows": (C.c_int, [vp, C.c_uint32, C.c_uint32]), "awsm_host_set_shard_bands": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]), "awsm_host_set_render_timings": (C.c_int, [vp, C.c_int]),
         "awsm_host_pick": (C.c_int, [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
@@ -339,6 +340,26 @@ class Host:
         self._chk(self.lib.awsm_host_set_render_timings(self.h, 1 if enabled else 0), "set_render_timings")
 
     # ---- frame ----
+    def set_render_hooks(self, after_geometry_pass=None, after_opaque_pass=None):
+        """RenderHooks: Python callables (no arguments; an exception aborts the frame) run between the passes of render()."""
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+        def wrap(fn):
+            if fn is None:
+                return None
+
+            def call(_user):
+                try:
+                    fn()
+                    return 0
+                except Exception as e:      # noqa: BLE001 — reported through the status code
+                    self._hook_error = e
+                    return -3
+            return HOOK(call)
+        self._hooks = (wrap(after_geometry_pass), wrap(after_opaque_pass))     # kept alive as long as they are installed
+        self._chk(self.lib.awsm_host_set_render_hooks(self.h, C.cast(self._hooks[0], C.c_void_p) if self._hooks[0] else None, None,
+                                                      C.cast(self._hooks[1], C.c_void_p) if self._hooks[1] else None, None), "set_render_hooks")
+
     def update_transforms(self):
         self._chk(self.lib.awsm_host_update_transforms(self.h), "update_transforms")
 

@@ -120,6 +120,8 @@ struct AwsmHost {
     Backend be;
     AwsmHipCtx* ctx = nullptr;
     std::string last_error;
+    AwsmHostHook after_geometry = nullptr, after_opaque = nullptr;     // RenderHooks (render.rs:54-63,181-190)
+    void* after_geometry_user = nullptr; void* after_opaque_user = nullptr;
 
     // ---- transforms.rs ----
     SlotMap<Transform> locals;
@@ -1018,13 +1020,22 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
     // ---- collect_renderables -> geometry pass -> opaque pass (render.rs:144-221) ----
     collect_draws(h, h->last_draws, &h->last_transparent_draws);
     if ((rc = h->be.geometry_pass(h->ctx, h->last_draws.data(), (uint32_t)h->last_draws.size()))) return dev_fail(h, rc, "geometry_pass");
+    if (h->after_geometry && (rc = h->after_geometry(h->after_geometry_user))) { h->last_error = "after_geometry_pass hook failed"; return rc; }   // hooks.after_geometry_pass (render.rs:181-190)
     AwsmOpaqueParams op{};
     op.mipmap = h->mipmap ? 1u : 0u; op.has_opaque = h->last_draws.empty() ? 0u : 1u;   // material_opaque/render_pass.rs:64-71
     if ((rc = h->be.opaque_pass(h->ctx, &op))) return dev_fail(h, rc, "opaque_pass");
+    if (h->after_opaque && (rc = h->after_opaque(h->after_opaque_user))) { h->last_error = "after_opaque_pass hook failed"; return rc; }
     // ---- opaque -> transparent blit + world transparent pass (render.rs:224-297).  A scene without transparent meshes skips it:
     // the composite image then IS the opaque image (the reference would copy it). ----
     if (h->has_transparent_meshes) { if ((rc = h->be.transparent_pass(h->ctx, h->last_transparent_draws.data(), (uint32_t)h->last_transparent_draws.size()))) return dev_fail(h, rc, "transparent_pass"); }
     if (sync) { if ((rc = h->be.frame_end(h->ctx, stats))) return dev_fail(h, rc, "frame_end"); }   // gpu.submit_commands (render.rs:370)
+    return AWSM_OK;
+}
+
+int awsm_host_set_render_hooks(AwsmHost* h, AwsmHostHook after_geometry_pass, void* user_geometry, AwsmHostHook after_opaque_pass, void* user_opaque) {
+    if (!h) return AWSM_ERR_INVALID_ARGUMENT;
+    h->after_geometry = after_geometry_pass; h->after_geometry_user = user_geometry;
+    h->after_opaque = after_opaque_pass; h->after_opaque_user = user_opaque;
     return AWSM_OK;
 }
 

@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the opaque pass of frame i with the geometry pass of frame i+1")
     ap.add_argument("--mipmap", action="store_true", help="MipmapMode::Gradient (the reference's default; not the BASELINE config)")
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4), help="MSAA x4 geometry + edge resolve (the reference's default AntiAliasing; not the BASELINE config)")
+    ap.add_argument("--strips", action="store_true", help="with --msaa 4 and N > 1: shard by contiguous row strips (each carries its own halo rows) instead of bands + halo exchange")
     ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4), help="BASELINE.json config: 4 = configs[3] the 4K Sponza-class frame (the metric's), "
                     "2 = configs[1] helmet-class 15k triangles / 2048^2 textures at 1920x1080, 3 = configs[2] skinned rig + morph cube at 1920x1080")
@@ -201,8 +202,10 @@ def main():
     # N > 1: 32-row bands dealt round-robin over the ranks (rank r owns tile rows r, r+N, ...: every rank gets 1/N of the
     # dense part of the screen), compact [L*32, W] output per rank, RCCL all-gather -> [N, L, 32, W], de-interleaved by
     # bands_to_image.  Double-buffered: frame i is gathered (RCCL's stream) while frame i+1 renders.
-    # With --msaa 4 the shards are contiguous row strips instead (they carry the one-row halo the MSAA edge detector needs).
-    strips = bool(args.msaa) and world > 1
+    # With --msaa 4 the edge detector needs the rows next to every band: the ranks all-gather the sample-0 keys of their bands' first and
+    # last rows between the two passes (the frame's one exchange step; awsm_hip_msaa_halo_*).  --strips: contiguous row strips
+    # instead, which rasterise their own halo rows and need no exchange (but balance the load badly).
+    strips = bool(args.msaa) and world > 1 and args.strips
     L = bands_per_rank(H, world)
     per = (H + world - 1) // world                      # rows per strip
     y0s, y1s = min(rank * per, H), min(rank * per + per, H)
@@ -223,6 +226,26 @@ def main():
     class _Done:
         def wait(self):
             return True
+
+    if args.msaa and world > 1 and not strips:
+        Lh = dev.msaa_halo_bands()
+        halo_mine = [torch.zeros((Lh, 2, W), dtype=torch.int64, device="cuda") for _ in range(2)]
+        halo_all = [torch.zeros((world, Lh, 2, W), dtype=torch.int64, device="cuda") for _ in range(2)]
+        halo_no = [0]
+
+        def exchange_halo():      # RenderHooks.after_geometry_pass: two buffers, because frame i's opaque pass may still read while frame i+1 renders
+            b = halo_no[0] % 2
+            halo_no[0] += 1
+            dev.msaa_halo_export(halo_mine[b].data_ptr(), halo_mine[b].numel() * 8)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(halo_all[b].view(world * Lh, 2, W), halo_mine[b])      # RCCL, on the stream the library renders on
+            else:
+                torch.cuda.current_stream().synchronize()
+                host_dst = torch.empty((world * Lh, 2, W), dtype=torch.int64)
+                dist.all_gather_into_tensor(host_dst, halo_mine[b].cpu())
+                halo_all[b].copy_(host_dst.view(world, Lh, 2, W))
+            dev.msaa_halo_bind(halo_all[b].data_ptr(), halo_all[b].numel() * 8)
+        r.host.set_render_hooks(after_geometry_pass=exchange_halo)
 
     def all_gather(dst, src):
         if backend == "nccl":
@@ -316,6 +339,9 @@ def main():
             r.host.set_shard_rows(0, 0)
         else:
             r.host.set_shard_bands(1, 0)
+        halo_hook = args.msaa and not strips
+        if halo_hook:
+            r.host.set_render_hooks()                    # the unsharded reference frame has no exchange
         dev.bind_output(ref.data_ptr(), H * W * 8)
         r.host.render(sync=True)
         check = "ok" if torch.equal(got.view(torch.int16), ref.view(torch.int16)) else "MISMATCH"
@@ -325,6 +351,8 @@ def main():
         else:
             r.host.set_shard_bands(world, rank, compact_output=True)
             dev.bind_output(mine[0].data_ptr(), rows_out * W * 8)
+            if halo_hook:
+                r.host.set_render_hooks(after_geometry_pass=exchange_halo)
         if check != "ok":
             raise SystemExit(f"rank {rank}: gathered image differs from the unsharded frame")
 
@@ -382,7 +410,8 @@ def main():
         sharding_desc = f"{world} row strips of {per} rows (+1-row halo for the MSAA edge detector) + RCCL all-gather of the RGBA16F image, overlapped with the next frame"
     else:
         sharding_desc = (f"32-row bands round-robin over {world} ranks ({L} bands each) + RCCL all-gather of the RGBA16F image + de-interleave; "
-                         f"gather of frame i overlapped with the render of frame i+1 (double-buffered)")
+                         f"gather of frame i overlapped with the render of frame i+1 (double-buffered)"
+                         + ("; MSAA: all-gather of the bands' boundary sample-0 keys between the geometry and the opaque pass" if args.msaa else ""))
     if rank == 0:
         out = {
             "metric": "frames/sec + shaded Mpix/s, 4K Sponza glTF, 1/2/4/8 MI355X",

@@ -160,6 +160,12 @@ int awsm_host_set_render_timings(AwsmHost* h, int enabled);
 int awsm_host_update_transforms(AwsmHost* h);
 /* sync != 0: ends with awsm_hip_frame_end (stats filled if non-NULL); sync == 0: enqueue only */
 int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats);
+/* RenderHooks (crates/renderer/src/render.rs:54-63,181-190: pre_render / after_geometry_pass / ...): callbacks render() makes between
+ * its passes, on the calling thread, after the pass has been enqueued.  A multi-GPU caller uses them for the exchanges the passes of a
+ * sharded frame need (MSAA + bands: the halo keys after the geometry pass; a sharded transparent pass: the opaque image after the opaque
+ * pass).  A hook returning non-zero aborts the frame with that status.  NULL removes a hook. */
+typedef int (*AwsmHostHook)(void* user);
+int awsm_host_set_render_hooks(AwsmHost* h, AwsmHostHook after_geometry_pass, void* user_geometry, AwsmHostHook after_opaque_pass, void* user_opaque);
 
 /* ---- introspection (tests, parity, INTEGRATION) ---- */
 int awsm_host_mirror(AwsmHost* h, AwsmBuf which, const uint8_t** data, size_t* len);

@@ -147,8 +147,8 @@ def test_band_sharding_rows_identical_to_full_frame(oracle_lut, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("msaa", [0, 4])
-def test_bench_two_rank_rehearsal_on_one_gpu(msaa):
+@pytest.mark.parametrize("msaa,extra", [(0, []), (4, []), (4, ["--strips"])])
+def test_bench_two_rank_rehearsal_on_one_gpu(msaa, extra):
     """bench.py's N > 1 path (band sharding, compact outputs, double-buffered gather, de-interleave) run as two processes
     sharing this box's one GPU, with the collectives staged through gloo; --check compares the gathered image with an
     unsharded render bit for bit.  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)"""
@@ -158,12 +158,13 @@ def test_bench_two_rank_rehearsal_on_one_gpu(msaa):
     env = dict(os.environ, AWSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--width", "640", "--height", "363", "--detail", "0.125",
-           "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1", "--msaa", str(msaa)]
+           "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1", "--msaa", str(msaa)] + extra
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["check"] == "ok" and out["n_gpus"] == 2 and out["value"] > 0
+    assert ("row strips" in out["config"]["sharding"]) == bool(extra) and ("boundary sample-0 keys" in out["config"]["sharding"]) == (msaa == 4 and not extra)
 
 
 @pytest.mark.gpu
