@@ -42,6 +42,7 @@ void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n,
 
 namespace {
 
+constexpr int kLeanWgsPerCu = 0;   // measured: the one-wavefront-per-strip grid wins once the geometry kernels fit beside it
 struct DevBuf {
     void* ptr = nullptr;
     size_t size = 0;
@@ -94,7 +95,8 @@ struct AwsmHipCtx {
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
     DevBuf out16, out32;
     DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
-    DevBuf shade_todo;                // [0] count + entries: the 16x4-pixel groups the lean opaque kernel leaves to the general one
+    uint32_t lean_grid = 0;           // persistent k_shade_lean grid (workgroups), 0 = one workgroup per block
+    DevBuf shade_todo[2];             // per frame slot (the per-draw resolve of frame i + 1 resets one while frame i's opaque pass appends to the other); [0] count + entries: the 16x4-pixel groups the lean opaque kernel leaves to the general one
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
 
@@ -103,7 +105,8 @@ struct AwsmHipCtx {
     // already runs the geometry pass of frame i+1 into the other slot.
     bool overlap = false;
     hipStream_t shade_stream = nullptr;
-    hipEvent_t ev_geom_done[2] = {}, ev_shade_done[2] = {}, ev_uploads[2] = {};
+    hipStream_t prep_stream = nullptr;     // the per-draw resolve of frame i + 1, beside frame i's opaque pass (enqueue_opaque)
+    hipEvent_t ev_geom_done[2] = {}, ev_shade_done[2] = {}, ev_uploads[2] = {}, ev_resolved[2] = {};
     uint64_t write_seq = 0, geom_write_seq[2] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
     bool shade_pending[2] = {false, false};
     FrameBufs fb[2];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
@@ -112,7 +115,7 @@ struct AwsmHipCtx {
     uint32_t tr_total_tris = 0, tr_n_blocks = 0;
     bool transparent_done = false;
     DevBuf comp16, comp32;       // composite image (after the transparent pass) + parity tap
-    DevBuf lights_pre;           // per-light constants (k_resolve_draws), sized with the lights buffer
+    DevBuf lights_pre[2];        // per frame slot: per-light constants (k_resolve_draws), sized with the lights buffer
     void* bound_comp = nullptr;
     size_t bound_comp_bytes = 0;
     const void* msaa_halo = nullptr;       // awsm_hip_msaa_halo_bind
@@ -288,12 +291,14 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
     const bool texel_cubes = c->scene.cube[0].texels || c->scene.cube[1].texels || c->scene.cube[2].texels;      // sampled by the general kernels only
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !texel_cubes && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo.ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !texel_cubes && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->draw_lean = lean_ok ? (LeanDrawDev*)FB(c).draw_lean.ptr : nullptr;
-    f->shade_todo = (uint32_t*)c->shade_todo.ptr;
-    f->shade_todo_cap = c->shade_todo.ptr ? (uint32_t)(c->shade_todo.size / 4 - 4) : 0u;
+    f->shade_todo = (uint32_t*)c->shade_todo[c->slot].ptr;
+    f->shade_todo_cap = f->shade_todo ? (uint32_t)(c->shade_todo[c->slot].size / 4 - 4 - 1024) : 0u;
+    f->lean_next = f->shade_todo ? f->shade_todo + 4 + f->shade_todo_cap : nullptr;
+    f->lean_grid = c->lean_grid;
     f->tri_rec = (TriRec*)FB(c).tri_rec.ptr;
     f->tile_count = (uint32_t*)FB(c).tile_count.ptr; f->tile_offset = (uint32_t*)FB(c).tile_offset.ptr;
     f->tile_cursor = (uint32_t*)FB(c).tile_cursor.ptr; f->bin_list = (uint32_t*)FB(c).bin_list.ptr;
@@ -315,6 +320,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->frame_serial = c->frame_serial;
     f->vis = (unsigned long long*)FB(c).vis.ptr;
     f->camera = (const uint8_t*)(c->overlap ? FB(c).camera.ptr : c->bufs[AWSM_BUF_CAMERA].ptr);
+    f->camera_snap = nullptr; f->camera_snap_words = 0;
     f->msaa = c->msaa;
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
@@ -322,8 +328,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->halo_bands = c->band_n > 1 ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16.ptr);   // kernels address by absolute row
     f->out_rgba32f = (float*)c->out32.ptr;
-    f->lights_pre = (float4*)c->lights_pre.ptr;
-    f->lights_cap = (uint32_t)(c->lights_pre.size / 32);
+    f->lights_pre = (float4*)c->lights_pre[c->slot].ptr;
+    f->lights_cap = (uint32_t)(c->lights_pre[c->slot].size / 32);
 }
 
 int record(AwsmHipCtx* c, int which, hipStream_t s = nullptr) {
@@ -343,7 +349,12 @@ int enqueue_geometry(AwsmHipCtx* c) {
         // this slot's buffers were last read by the opaque pass two frames ago
         if (c->shade_pending[c->slot]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0)); c->shade_pending[c->slot] = false; }
         // the camera the frame is shaded with = the camera it was submitted with
-        if (c->bufs[AWSM_BUF_CAMERA].ptr) HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size), hipMemcpyDeviceToDevice, c->stream));
+        // (copied by k_deform_transform when the frame has geometry: a 512-byte hipMemcpyAsync costs the stream 18 us of gap + copy)
+        if (c->bufs[AWSM_BUF_CAMERA].ptr) {
+            const size_t cam_bytes = std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size);
+            if (c->total_tris && n_tiles) { f.camera_snap = (uint32_t*)FB(c).camera.ptr; f.camera_snap_words = (uint32_t)(cam_bytes / 4); }
+            else HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, cam_bytes, hipMemcpyDeviceToDevice, c->stream));
+        }
         // everything the per-draw resolve of this frame reads (draw list, scene buffers) is on the stream by now
         HIPCHK(c, hipEventRecord(c->ev_uploads[c->slot], c->stream));
         c->geom_write_seq[c->slot] = c->write_seq;
@@ -385,18 +396,20 @@ int enqueue_opaque(AwsmHipCtx* c) {
     int rc = sync_scene(c);
     if (rc) return rc;
     hipStream_t ss = shade_stream_of(c);
-    // The per-draw resolve only needs the uploads, not the geometry pass.  In overlap mode it goes to the shade stream BEFORE the wait for
-    // the geometry pass: it then runs as soon as the previous frame's shading has drained, next to this frame's binning / raster, instead
-    // of between the raster and the shading kernels (8.7 us on the critical path of a frame; +0.9 % frames/s, same box).  Not on the caller's stream ahead of the
-    // geometry kernels — measured: a chain of dependent loads in one workgroup crawls while k_shade of the previous frame owns every CU,
-    // and the geometry kernels queue behind it (1906 -> 1675 frames/s).  A scene write between the two passes falls back to the late order.
+    // The per-draw resolve only needs the uploads, not the geometry pass, and nothing of the previous frame: its outputs are per frame
+    // slot.  In overlap mode it runs on a stream of its own, beside the previous frame's opaque pass, and the shade stream waits for its
+    // event: on the shade stream it sat between two frames' shading kernels (todo -> 14 us launch gap -> resolve 30 us -> gap -> lean:
+    // the shade stream is the critical path of an overlapped frame, tools/frame_timeline.sh); on the caller's stream it would lengthen
+    // the geometry chain, the other critical path.  A scene write between the two passes falls back to the late order.
     const bool want_resolve = f.sy1 > f.sy0 && f.has_opaque;
     // (With stage timers on the late order stays: an event recorded right behind a cross-stream wait is stamped when the wait is
     // consumed, not when it is satisfied, and ms_shade would include the tail of the raster kernel — seen: 0.40 instead of 0.36 ms.)
     const bool early = c->overlap && !c->stage_timers && want_resolve && c->geometry_done && c->geom_write_seq[c->slot] == c->write_seq;
     if (early) {
-        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_uploads[c->slot], 0));
-        awsm_launch_resolve_draws(c->scene_dev, &f, ss);
+        HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_uploads[c->slot], 0));
+        awsm_launch_resolve_draws(c->scene_dev, &f, c->prep_stream);
+        HIPCHK(c, hipEventRecord(c->ev_resolved[c->slot], c->prep_stream));
+        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_resolved[c->slot], 0));
     }
     if (c->overlap) {   // the shade stream picks up where the caller's stream is now (geometry pass + uploads of this frame)
         HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
@@ -433,7 +446,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->draw_mat = (DrawMatDev*)t.draw_mat.ptr;
     f->clip = (float4*)t.clip.ptr; f->nrm = (float4*)t.nrm.ptr; f->tan = (float4*)t.tan.ptr; f->wpos = (float4*)t.wpos.ptr;
     f->tri_info = (uint32_t*)t.tri_flags.ptr;
-    f->tri_shade = nullptr; f->draw_lean = nullptr; f->shade_todo = nullptr; f->shade_todo_cap = 0;     // the opaque pass's lean route only
+    f->tri_shade = nullptr; f->draw_lean = nullptr; f->shade_todo = nullptr; f->shade_todo_cap = 0; f->lean_next = nullptr; f->lean_grid = 0;     // the opaque pass's lean route only
     f->tri_rec = (TriRec*)t.tri_rec.ptr;
     f->tile_count = (uint32_t*)t.tile_count.ptr; f->tile_offset = (uint32_t*)t.tile_offset.ptr;
     f->tile_cursor = (uint32_t*)t.tile_cursor.ptr; f->bin_list = (uint32_t*)t.bin_list.ptr;
@@ -624,6 +637,12 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     for (int i = 0; i < EV_COUNT; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(AWSM_ERR_DEVICE);
     if (hipMalloc((void**)&c->scene_dev, sizeof(DevScene)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
     c->overlap = (cfg->flags & AWSM_CFG_OVERLAP_FRAMES) != 0;
+    {   // k_shade_lean as a persistent grid of N workgroups per CU (it is VALU-bound from 4 waves/SIMD up): the rest of each CU's
+        // wave slots, registers and LDS stays free for the next frame's geometry kernels on the other stream
+        const char* e = getenv("AWSM_LEAN_WGS_PER_CU");
+        const int per_cu = e ? atoi(e) : (c->overlap ? kLeanWgsPerCu : 0);
+        c->lean_grid = per_cu > 0 ? (uint32_t)(per_cu * prop.multiProcessorCount) & ~7u : 0u;
+    }
     for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
         if (hipMalloc(&c->fb[s].counters.ptr, 12 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words
         c->fb[s].counters.size = 12 * sizeof(uint32_t);
@@ -632,10 +651,10 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     }
 
     if (c->overlap) {
-        if (hipStreamCreateWithFlags(&c->shade_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        if (hipStreamCreateWithFlags(&c->shade_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
         for (int s = 0; s < 2; s++) {
             if (hipEventCreateWithFlags(&c->ev_geom_done[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_uploads[s], hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+                hipEventCreateWithFlags(&c->ev_uploads[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_resolved[s], hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             if (hipMalloc(&c->fb[s].camera.ptr, 512) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
             c->fb[s].camera.size = 512;
         }
@@ -655,17 +674,19 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->shade_stream) (void)hipStreamSynchronize(c->shade_stream);
+    if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); fr(c->shade_todo); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre);
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); fr(c->shade_todo[0]); fr(c->shade_todo[1]); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre[0]); fr(c->lights_pre[1]);
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
-    for (int i = 0; i < 2; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); }
+    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
+    for (int i = 0; i < 2; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); if (c->ev_resolved[i]) (void)hipEventDestroy(c->ev_resolved[i]); }
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
@@ -697,7 +718,7 @@ int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
     if (rc) return rc;
     if (bytes) c->bufs[which].size = bytes;
-    if (which == AWSM_BUF_LIGHTS && (rc = dev_realloc(c, c->lights_pre, std::max<size_t>(bytes / 64, 1) * 32, true))) return rc;   // 2 x float4 per 64-byte light
+    if (which == AWSM_BUF_LIGHTS) for (int sl = 0; sl < (c->overlap ? 2 : 1); sl++) if ((rc = dev_realloc(c, c->lights_pre[sl], std::max<size_t>(bytes / 64, 1) * 32, true))) return rc;   // 2 x float4 per 64-byte light
     c->scene_dirty = true;
     return AWSM_OK;
 }
@@ -733,7 +754,7 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     }
     if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
     c->msaa = msaa;
-    if ((rc = dev_realloc(c, c->shade_todo, ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
+    for (int sl = 0; sl < (c->overlap ? 2 : 1); sl++) if ((rc = dev_realloc(c, c->shade_todo[sl], ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4 + 1024) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
     if ((rc = dev_realloc(c, c->out16, px * 8, true))) return rc;
     if (c->flags & AWSM_CFG_PARITY_TAP) { if ((rc = dev_realloc(c, c->out32, px * 16, true))) return rc; }
     c->width = width; c->height = height;
@@ -1098,8 +1119,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->covered_pixels = c->counters_host[3];
         out->bin_overflow_retries = c->overflow_retries;
         out->frames_with_dropped_bin_entries = c->dropped_frames;
-        if (c->opaque_done && c->shade_todo.ptr && c->msaa == 0 && !c->last_opaque.mipmap && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
-            HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo.ptr, 4, hipMemcpyDeviceToHost));
+        if (c->opaque_done && c->shade_todo[c->slot].ptr && c->msaa == 0 && !c->last_opaque.mipmap && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
+            HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo[c->slot].ptr, 4, hipMemcpyDeviceToHost));
     }
     return AWSM_OK;
 }

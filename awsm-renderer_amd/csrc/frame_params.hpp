@@ -154,6 +154,10 @@ struct FrameDev {
     LeanDrawDev* draw_lean;       // n_draws (k_resolve_draws); null = the lean route is off for this frame
     uint32_t* shade_todo;         // [0] = count, [4 ..] = (block id << 2 | wavefront) of the 16x4-pixel groups k_shade_lean left to the general kernel
     uint32_t shade_todo_cap;
+    uint32_t* camera_snap;        // geometry pass, overlap mode: k_deform_transform copies camera_snap_words words of the camera UBO here (the camera the frame
+    uint32_t camera_snap_words;   // is shaded with = the camera it was submitted with); null / 0 otherwise
+    uint32_t* lean_next;          // 64 x 16 words: strip counter c of XCD x at [(x * kLeanCounters + c) * 16] (persistent k_shade_lean grid; zeroed by k_resolve_draws)
+    uint32_t lean_grid;           // 0: one workgroup per 16x16 block; else the persistent grid's workgroup count (multiple of 8)
     // binning
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1

@@ -39,7 +39,9 @@ struct GeomMetaDev {
 // vertices (AWSM_BUF_TRANSPARENCY_GEOM_DATA at draw.vis_data_off) through the custom-attribute index buffer
 // (meshes/mesh.rs:129-200); one thread per triangle corner, which also leaves the world position for the fragment stage.
 template <bool FWD>
-__global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
+// FWD = false: capped at 80 VGPRs (122 uncapped; the spills sit in the skinning branch) so that two wavefronts per SIMD fit next to the
+// previous frame's persistent opaque-pass grid — with one, the kernel ran 209 us beside it (31 alone).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6))) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[FWD ? 4 : 256 * 14];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(256) void k_deform_transform(const DevScene* __rest
         const uint32_t n_tiles = f.tiles_x * f.tiles_y, gsz = gridDim.x * 256u, g0 = b * 256u + tid;
         for (uint32_t i = g0; i < n_tiles; i += gsz) f.tile_count[i] = 0u;
         if (g0 < 8u) f.counters[g0] = 0u;
+        if (!FWD && g0 < f.camera_snap_words) f.camera_snap[g0] = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_CAMERA])[g0];   // overlap mode: the frame's camera
     }
     uint32_t lo = 0, hi = f.n_draws;
     while (hi - lo > 1) {
@@ -433,49 +436,52 @@ __global__ __launch_bounds__(256) void k_bin_big(FrameDev f) { bin_big_walk<FILL
 // fullest tiles and the light ones fill in behind them (longest-processing-time-first; the fullest tile of a frame holds
 // 20-40x the median number of triangles and would otherwise be the tail of the kernel).
 constexpr uint32_t kRasterSlice = 256;     // triangles of a tile's list one raster workgroup takes (= one batch of k_raster_tile)
-__global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
-    __shared__ uint32_t part[16], part2[16];    // wavefront totals of the two scans
-    __shared__ uint32_t bucket_n[16][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
-    __shared__ uint32_t bucket_at[16][33];
+// 512 threads (8 wavefronts, 2 per SIMD, < 80 VGPRs): the workgroup also fits on a CU that the persistent opaque-pass grid of the
+// previous frame occupies with 4 x 88 VGPRs per lane — a 1024-thread workgroup (4 wavefronts per SIMD x 64) waited for that grid to drain.
+constexpr uint32_t kScanThreads = 512, kScanWaves = kScanThreads / 64, kScanPer = 8192 / kScanThreads;
+__global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
+    __shared__ uint32_t part[kScanWaves], part2[kScanWaves];    // wavefront totals of the two scans
+    __shared__ uint32_t bucket_n[kScanWaves][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
+    __shared__ uint32_t bucket_at[kScanWaves][33];
     __shared__ uint32_t n_extra, n_slots;       // raster items beyond one per tile / scratch tiles (split tiles, see k_raster_tile)
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     AWSM_STAMP_AT(f, 1, 0);
     if (tid == 0) { n_extra = 0u; n_slots = 0u; }
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t per = (n_tiles + kScanThreads - 1u) / kScanThreads;
     const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
-    for (uint32_t i = tid; i < 16u * 33u; i += 1024u) (&bucket_n[0][0])[i] = 0u;
+    for (uint32_t i = tid; i < kScanWaves * 33u; i += kScanThreads) (&bucket_n[0][0])[i] = 0u;
     __syncthreads();
     // the first 8 counts of the chunk are loaded together and kept in registers for the second loop (one memory round trip
     // instead of `per` dependent ones); longer chunks (frames beyond 8192 tiles) fall back to re-reading
     // Frames of up to 8192 tiles (4K: 8160) move counts and offsets through LDS so that the global loads and stores of this single
-    // workgroup are coalesced (thread t touches tiles t, t + 1024, ...) while each thread still owns 8 consecutive tiles of the scan:
+    // workgroup are coalesced (thread t touches tiles t, t + 512, ...) while each thread still owns 16 consecutive tiles of the scan:
     // one CU's memory pipeline was the bottleneck with 32-byte-strided 4-byte accesses.
     __shared__ uint32_t stage[8192];
-    const bool staged = n_tiles <= 8192u;          // then per <= 8
+    const bool staged = n_tiles <= 8192u;          // then per <= kScanPer
     if (staged) {
-        for (uint32_t i = tid; i < n_tiles; i += 1024u) stage[i] = f.tile_count[i];
+        for (uint32_t i = tid; i < n_tiles; i += kScanThreads) stage[i] = f.tile_count[i];
         __syncthreads();
     }
     AWSM_STAMP_AT(f, 1, 1);
-    uint32_t cnt[8];
+    uint32_t cnt[kScanPer];
 #pragma unroll
-    for (uint32_t j = 0; j < 8u; j++) cnt[j] = (b0 + j < b1) ? (staged ? stage[b0 + j] : f.tile_count[b0 + j]) : 0u;
+    for (uint32_t j = 0; j < kScanPer; j++) cnt[j] = (b0 + j < b1) ? (staged ? stage[b0 + j] : f.tile_count[b0 + j]) : 0u;
     uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < 8u; j++)
+    for (uint32_t j = 0; j < kScanPer; j++)
         if (b0 + j < b1) { sum += cnt[j]; atomicAdd(&bucket_n[wave][32 - __clz(cnt[j])], 1u); }   // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
-    for (uint32_t i = b0 + 8u; i < b1; i++) {
+    for (uint32_t i = b0 + kScanPer; i < b1; i++) {
         const uint32_t c = f.tile_count[i];
         sum += c;
         atomicAdd(&bucket_n[wave][32 - __clz(c)], 1u);
     }
     __syncthreads();
-    // Two inclusive scans over the 1024 threads at once — the chunk sums, and the (bucket, wave) histogram entries in tile_order's
-    // order: buckets descending, waves ascending inside a bucket, entry e = (32 - bucket) * 16 + wave.  Wavefront scans through
-    // shuffles plus the 16 wavefront totals: two barriers instead of the twenty of a workgroup-wide Hillis-Steele.
+    // Two inclusive scans over the workgroup's threads at once — the chunk sums, and the (bucket, wave) histogram entries in tile_order's
+    // order: buckets descending, waves ascending inside a bucket, entry e = (32 - bucket) * kScanWaves + wave.  Wavefront scans through
+    // shuffles plus the wavefront totals: two barriers instead of the twenty of a workgroup-wide Hillis-Steele.
     const uint32_t lane = tid & 63u;
-    const uint32_t e_bucket = 32u - (tid >> 4), e_wave = tid & 15u;
-    const uint32_t e_val = tid < 33u * 16u ? bucket_n[e_wave][e_bucket] : 0u;
+    const uint32_t e_bucket = 32u - tid / kScanWaves, e_wave = tid % kScanWaves;
+    const uint32_t e_val = tid < 33u * kScanWaves ? bucket_n[e_wave][e_bucket] : 0u;
     uint32_t incl1 = sum, incl2 = e_val;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
     if (lane == 63u) { part[wave] = incl1; part2[wave] = incl2; }
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) { incl1 += part[w]; incl2 += part2[w]; }
-    if (tid < 33u * 16u) bucket_at[e_wave][e_bucket] = incl2 - e_val;
+    if (tid < 33u * kScanWaves) bucket_at[e_wave][e_bucket] = incl2 - e_val;
     __syncthreads();
     AWSM_STAMP_AT(f, 1, 3);
     uint32_t run = incl1 - sum;   // exclusive prefix of this thread's chunk
@@ -505,13 +511,13 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev f, uint32_t n_tiles)
         }
     };
 #pragma unroll
-    for (uint32_t j = 0; j < 8u; j++)
+    for (uint32_t j = 0; j < kScanPer; j++)
         if (b0 + j < b1) place(b0 + j, cnt[j]);
-    for (uint32_t i = b0 + 8u; i < b1; i++) place(i, f.tile_count[i]);
+    for (uint32_t i = b0 + kScanPer; i < b1; i++) place(i, f.tile_count[i]);
     AWSM_STAMP_AT(f, 1, 4);
     __syncthreads();
-    if (staged) for (uint32_t i = tid; i < n_tiles; i += 1024u) { f.tile_offset[i] = stage[i]; f.tile_cursor[i] = 0u; }
-    if (tid == 1023u) {
+    if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) { f.tile_offset[i] = stage[i]; f.tile_cursor[i] = 0u; }
+    if (tid == kScanThreads - 1u) {
         const uint32_t total = incl1;
         f.tile_offset[n_tiles] = total;
         f.counters[1] = total;
@@ -791,7 +797,7 @@ extern "C" void awsm_launch_bin_big(const awsm::FrameDev* f, int fill, hipStream
     hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
-    hipLaunchKernelGGL(awsm::k_bin_scan, dim3(1), dim3(1024), 0, s, *f, f->tiles_x * f->tiles_y);
+    hipLaunchKernelGGL(awsm::k_bin_scan, dim3(1), dim3(awsm::kScanThreads), 0, s, *f, f->tiles_x * f->tiles_y);
 }
 extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;

@@ -785,6 +785,7 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     }
     // eight threads per draw: roles 0..4 resolve one core texture each, role 5 the per-draw records
     if (d == 0u && f.shade_todo) f.shade_todo[0] = 0u;      // the list k_shade_lean leaves for k_shade_todo (same stream, this frame)
+    if (d < 64u && f.lean_next) f.lean_next[d * 16u] = 0u;  // the persistent lean grid's strip counters
     const uint32_t draw = d >> 3, role = d & 7u;
     if (draw >= f.n_draws || role > 6u) return;
     const DrawDev dr = f.draws[draw];
@@ -1541,6 +1542,14 @@ AWSM_DI bool shade_block(const FrameDev& f, ShadeBlock& b, uint32_t wg = blockId
     b.y0 = f.band_n > 1u ? (int)(((f.tile_row0 + (b.brow >> 1) * f.band_n) << kTileShift) + ((b.brow & 1u) << 4)) : (int)f.sy0 + (int)(b.brow << 4);
     return true;
 }
+// the same block from its row and column (no division: the persistent grid numbers blocks on a power-of-two pitch)
+AWSM_DI void shade_block_at(const FrameDev& f, ShadeBlock& b, uint32_t brow, uint32_t bcol) {
+    const uint32_t bx_n = (f.width + 15u) >> 4;
+    b.blk = brow * bx_n + bcol;
+    b.brow = brow;
+    b.x0 = (int)(bcol << 4);
+    b.y0 = f.band_n > 1u ? (int)(((f.tile_row0 + (brow >> 1) * f.band_n) << kTileShift) + ((brow & 1u) << 4)) : (int)f.sy0 + (int)(brow << 4);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_shade: single-sampled opaque pass, 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers
@@ -1699,10 +1708,7 @@ AWSM_DI void direct(const Lit& s, f3 l, f3 radiance, f3& color) {
 }
 }  // namespace lean
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
-    ShadeBlock b;
-    if (!shade_block(f, b)) return;
-    const uint32_t tid = threadIdx.x;
+AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid) {
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
     if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
     const uint32_t pv = (uint32_t)cy * f.width + (uint32_t)cx;
@@ -1764,7 +1770,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_W
             // ---- standard.wgsl:11-62 (as shade_surface) ----
             const m4 inv_proj = cload_m4(f.camera, 256u), inv_view = cload_m4(f.camera, 320u);
             const float proj33 = cload<float>(f.camera, 64u + 60u);
-            const f2 suv = {((float)cx + 0.5f) * fm::rcp((float)f.width), ((float)cy + 0.5f) * fm::rcp((float)f.height)};
+            uint32_t fw = f.width, fh = f.height;
+            asm volatile("" : "+s"(fw), "+s"(fh));                          // keeps the two reciprocals out of the persistent loop's live registers (they were spilled)
+            const f2 suv = {((float)cx + 0.5f) * fm::rcp((float)fw), ((float)cy + 0.5f) * fm::rcp((float)fh)};
             const f4 view_h = fm::fmul(inv_proj, {suv.x * 2.0f - 1.0f, 1.0f - suv.y * 2.0f, depth, 1.0f});
             const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
             const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
@@ -1878,7 +1886,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_LEAN_W
     const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
     if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) {
         const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
-        if (slot < f.shade_todo_cap) f.shade_todo[4u + slot] = (blockIdx.x << 2) | (tid >> 6);
+        if (slot < f.shade_todo_cap) f.shade_todo[4u + slot] = (wg << 2) | (tid >> 6);
+    }
+}
+// k_shade_lean<false>: a wavefront per 16x4-pixel strip.  k_shade_lean<true>: a persistent grid (lean_grid workgroups; workgroup w
+// runs on XCD w & 7, as the hardware deals them) whose wavefronts take strips from counters until the XCD's share is used up —
+// a grid of 4 workgroups per CU leaves the rest of every CU (wave slots, 160 of 512 VGPRs per lane, all LDS) to the next frame's
+// geometry kernels on the other stream, which a grid of 34 k workgroups starves.
+// XCD x owns the block rows x, x + 8, ...; its strips are numbered row-major on a power-of-two block pitch (strip -> block row /
+// column by shifts; ids in the padding are skipped), four strips per block, so wavefronts running together shade neighbouring
+// strips.  A same-address atomic costs ~25 ns at the L2 — one counter per XCD would take longer than the shading — so every XCD
+// has kLeanCounters of them on separate cache lines, counter c handing out the strips c, c + kLeanCounters, ...; a wavefront
+// starts on counter w % kLeanCounters and moves on when it runs dry.  The request for the next strip is issued before the current
+// one is shaded.  No barrier, no LDS.
+#ifndef AWSM_LEAN_COUNTERS
+#define AWSM_LEAN_COUNTERS 8
+#endif
+constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
+template <bool PERSIST>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PERSIST ? 5 : AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+    const uint32_t xcd = blockIdx.x & 7u, lane = threadIdx.x & 63u;
+    const uint32_t bx_n = (f.width + 15u) >> 4, by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.sy1 - f.sy0) + 15u) >> 4;
+    const uint32_t lp = 32u - (uint32_t)__builtin_clz((bx_n - 1u) | 1u);  // log2 of the block pitch
+    const uint32_t share = (((by_n + 7u - xcd) >> 3) << lp) * 4u;         // strip ids of this XCD (padding included)
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));    // wavefront of this XCD
+    uint32_t zero;                                                        // opaque to the compiler: with a provably uniform address its atomic optimiser
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));                         // broadcasts the result right behind the atomic (s_waitcnt + readfirstlane)
+    uint32_t c = w % kLeanCounters, tried = 0u;
+    uint32_t* ctr0 = f.lean_next + (xcd * kLeanCounters) * 16u + zero;
+    uint32_t nxt = 0u;
+    if (PERSIST && lane == 0u) nxt = atomicAdd(ctr0 + c * 16u, 1u);
+    for (uint32_t j = w;;) {
+        if (PERSIST) {
+            j = __builtin_amdgcn_readfirstlane(nxt) * kLeanCounters + c;
+            while (j >= share && ++tried < kLeanCounters) {               // this counter's strips are gone: the next one (once per wavefront and counter)
+                c = (c + 1u) % kLeanCounters;
+                if (lane == 0u) nxt = atomicAdd(ctr0 + c * 16u, 1u);
+                j = __builtin_amdgcn_readfirstlane(nxt) * kLeanCounters + c;
+            }
+            if (j >= share) break;
+            if (lane == 0u) nxt = atomicAdd(ctr0 + c * 16u, 1u);
+        }
+        const uint32_t kb = j >> 2, bcol = kb & ((1u << lp) - 1u), brow = (kb >> lp) * 8u + xcd;
+        if (bcol < bx_n && j < share) {
+            ShadeBlock b;
+            shade_block_at(f, b, brow, bcol);
+            lean_block(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane);
+        }
+        if (!PERSIST) break;
     }
 }
 
@@ -2173,7 +2228,11 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
         else if (f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws) {
             // MipmapMode::None: the lean kernel over the screen, then the general code for the wavefronts it declined (k_resolve_draws reset the list)
-            hipLaunchKernelGGL(awsm::k_shade_lean, dim3(nb), dim3(256), 0, s, sc, *f);      // awsm_launch_shade_todo follows
+            // strip ids sit on a power-of-two block pitch: a wavefront per id (the padding exits), or the persistent grid
+            uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
+            const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
+            if (f->lean_grid && f->lean_next) hipLaunchKernelGGL(awsm::k_shade_lean<true>, dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
+            else hipLaunchKernelGGL(awsm::k_shade_lean<false>, dim3(nb_ids), dim3(256), 0, s, sc, *f);      // awsm_launch_shade_todo follows
         } else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
     }
 }

@@ -646,6 +646,29 @@ def test_lean_and_general_opaque_routes_agree(oracle_lut):
             assert 0 < waves < total_waves                     # both kernels shaded part of the frame
         else:
             assert waves > 0                                   # the range guard sent covered wavefronts to the general kernel
+
+
+@pytest.mark.gpu
+def test_persistent_lean_grid_is_bit_identical(oracle_lut, monkeypatch):
+    """k_shade_lean<true> (AWSM_LEAN_WGS_PER_CU workgroups per CU taking 16x4-pixel strips from per-XCD counters; off by default, see
+    DESIGN section 6) shades every pixel with the code of the one-wavefront-per-strip grid: same bits, same list for the general kernel.  Frame
+    widths below, at and above a power of two of 16-pixel blocks exercise the padded strip numbering; two frames per device reuse the counters."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    for name, sc in (("atrium", scenes.atrium_scene(640, 360, detail=0.25, tex_scale=1 / 32)), ("zoo", scenes.material_zoo_scene(400, 300)),
+                     ("zoo_pow2", scenes.material_zoo_scene(512, 256)), ("zoo_odd", scenes.material_zoo_scene(531, 173))):
+        model = helpers.build_model(sc)
+        monkeypatch.delenv("AWSM_LEAN_WGS_PER_CU", raising=False)
+        ref, st_ref = helpers.hip_frame(model, oracle_lut)
+        want = ref.read_opaque_f32()
+        ref.close()
+        monkeypatch.setenv("AWSM_LEAN_WGS_PER_CU", "4")
+        dev = HipDevice(parity_tap=True)
+        for _ in range(2):
+            _, st = helpers.hip_frame(model, oracle_lut, dev=dev)
+            got = dev.read_opaque_f32()
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), name
+            assert st["shade_general_wavefronts"] == st_ref["shade_general_wavefronts"]
+        dev.close()
             orc = helpers.oracle_frame(model, oracle_lut)
             assert (np.abs(a - orc.rgba32f.astype(np.float64)) <= RGB_TOL * np.maximum(1.0, np.abs(orc.rgba32f))).all()
 
