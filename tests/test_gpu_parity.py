@@ -646,6 +646,8 @@ def test_lean_and_general_opaque_routes_agree(oracle_lut):
             assert 0 < waves < total_waves                     # both kernels shaded part of the frame
         else:
             assert waves > 0                                   # the range guard sent covered wavefronts to the general kernel
+            orc = helpers.oracle_frame(model, oracle_lut)
+            assert (np.abs(a - orc.rgba32f.astype(np.float64)) <= RGB_TOL * np.maximum(1.0, np.abs(orc.rgba32f))).all()
 
 
 @pytest.mark.gpu
@@ -669,8 +671,6 @@ def test_persistent_lean_grid_is_bit_identical(oracle_lut, monkeypatch):
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), name
             assert st["shade_general_wavefronts"] == st_ref["shade_general_wavefronts"]
         dev.close()
-            orc = helpers.oracle_frame(model, oracle_lut)
-            assert (np.abs(a - orc.rgba32f.astype(np.float64)) <= RGB_TOL * np.maximum(1.0, np.abs(orc.rgba32f))).all()
 
 
 # ------------------------------------------------------------------------------------------------ texel cubemaps
