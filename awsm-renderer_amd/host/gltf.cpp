@@ -9,16 +9,15 @@
 //
 // Per primitive, as gltf/buffers/mesh.rs does: indices are read (u8/u16/u32) or generated, triangle strips and fans become
 // lists (buffers/index.rs:116-205); missing normals are accumulated from face normals (buffers/normals.rs:46-126); missing
-// tangents are generated when the material has a normal map (buffers/tangents.rs:11-98).  The reference calls
-// bevy_mikktspace there and then averages its per-corner output per shared vertex (tangents.rs:165-205,295-312); this file
-// restates that as the per-triangle UV-gradient tangent (mikktspace's per-face tangent), angle-weighted per corner
-// (mikktspace's vertex weighting), accumulated per vertex, projected off the normal and normalised with the reference's
-// fallbacks and sign vote — mikktspace's splitting of a vertex between smoothing groups is what is not reproduced.
+// tangents are generated when the material has a normal map (buffers/tangents.rs:11-98): the reference calls
+// bevy_mikktspace there and then averages its per-corner output per shared vertex (tangents.rs:165-205,295-312); mikktspace.hpp
+// restates the crate's algorithm (welding, orientation groups around each vertex, angle-weighted evaluation), compute_tangents
+// below the averaging, the fallbacks and the sign vote.
 //
 // Images: PNG (png.hpp, zlib inflate) and JPEG (jpeg.hpp: baseline, extended sequential and progressive; Huffman, 8 bit).  KTX2 and anything else return
 // AWSM_ERR_UNSUPPORTED with the image index in the message.
-// Not read: cameras (the caller owns the camera), animations, sparse accessors, KHR_mesh_quantization beyond the normalised
-// integer attribute types glTF core already allows, EXT_mesh_gpu_instancing.
+// Not read: cameras (the caller owns the camera), animations, KHR_mesh_quantization beyond the normalised integer attribute
+// types glTF core already allows.
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -31,6 +30,7 @@
 
 #include "../../include/awsm_host.h"
 #include "json.hpp"
+#include "mikktspace.hpp"
 #include "jpeg.hpp"
 #include "png.hpp"
 
@@ -496,34 +496,21 @@ void compute_normals(const std::vector<float>& pos, const std::vector<uint32_t>&
     }
 }
 
-// buffers/tangents.rs (see the header of this file for what is and is not reproduced of mikktspace)
+// buffers/tangents.rs:268-364: mikktspace per triangle corner (mikktspace.hpp), then MikkTSpaceGeometry::set_tangent_encoded's
+// accumulation per shared vertex (tangents.rs:295-312) and finalize_tangents (tangents.rs:170-211)
 void compute_tangents(const std::vector<float>& pos, const std::vector<float>& nrm, const std::vector<float>& uv, const std::vector<uint32_t>& idx, std::vector<float>& tan) {
-    const size_t V = pos.size() / 3;
+    const size_t V = pos.size() / 3, T = idx.size() / 3;
     std::vector<V3> sum(V, V3{0, 0, 0});
     std::vector<float> sign_sum(V, 0.0f);
     std::vector<uint32_t> pos_count(V, 0), neg_count(V, 0), count(V, 0);
-    auto P = [&](uint32_t i) { return V3{pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]}; };
-    for (size_t t = 0; t + 2 < idx.size(); t += 3) {
-        const uint32_t i0 = idx[t], i1 = idx[t + 1], i2 = idx[t + 2];
-        const V3 e1 = sub(P(i1), P(i0)), e2 = sub(P(i2), P(i0));
-        const float du1 = uv[i1 * 2] - uv[i0 * 2], dv1 = uv[i1 * 2 + 1] - uv[i0 * 2 + 1], du2 = uv[i2 * 2] - uv[i0 * 2], dv2 = uv[i2 * 2 + 1] - uv[i0 * 2 + 1];
-        const float det = du1 * dv2 - du2 * dv1;
-        if (!(std::fabs(det) > 1e-30f)) continue;                              // degenerate UV triangle: contributes nothing
-        const float r = 1.0f / det;
-        const V3 tdir = normalize3(scale(sub(scale(e1, dv2), scale(e2, dv1)), r));      // dP/du
-        const V3 bdir = scale(sub(scale(e2, du1), scale(e1, du2)), r);                   // dP/dv
-        const uint32_t tri[3] = {i0, i1, i2};
-        for (int c = 0; c < 3; c++) {
-            const uint32_t v = tri[c];
-            const V3 a = normalize3(sub(P(tri[(c + 1) % 3]), P(v))), b = normalize3(sub(P(tri[(c + 2) % 3]), P(v)));
-            const float w = std::acos(std::min(1.0f, std::max(-1.0f, dot(a, b))));      // angle weight at this corner
-            const V3 n = {nrm[v * 3], nrm[v * 3 + 1], nrm[v * 3 + 2]};
-            const float sgn = dot(cross(n, tdir), bdir) < 0.0f ? -1.0f : 1.0f;
-            sum[v].x += tdir.x * w; sum[v].y += tdir.y * w; sum[v].z += tdir.z * w;
-            sign_sum[v] += sgn;
-            if (sgn > 0.0f) pos_count[v]++; else neg_count[v]++;
-            count[v]++;
-        }
+    std::vector<std::array<float, 4>> corner;
+    awsm_mikk::generate(pos.data(), nrm.data(), uv.data(), idx.data(), T, corner);
+    for (size_t c = 0; c < T * 3; c++) {
+        const uint32_t v = idx[c];
+        sum[v].x += corner[c][0]; sum[v].y += corner[c][1]; sum[v].z += corner[c][2];
+        sign_sum[v] += corner[c][3];
+        if (corner[c][3] > 0.0f) pos_count[v]++; else if (corner[c][3] < 0.0f) neg_count[v]++;
+        count[v]++;
     }
     tan.assign(V * 4, 0.0f);
     for (size_t v = 0; v < V; v++) {
