@@ -546,13 +546,14 @@ struct WorkTri {
     float zq[3];
     uint32_t rank;
     uint32_t bbox;   // x0 | x1<<8 | y0<<16 | y1<<24, tile-local, inclusive
-    uint32_t pad;
+    uint32_t exact;  // TriSetup::exact
 };
 static_assert(sizeof(WorkTri) == 72, "WorkTri");
 
 AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 #pragma unroll
     for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.zq[i] = g.zq[i]; }
+    t.exact = g.exact != 0u;
 }
 
 // One pixel of the tile against one triangle: S = 1 samples the pixel centre, S = 4 the four standard MSAA positions
@@ -570,6 +571,40 @@ AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, 
             if (k != ~0ull) atomicMin(&keys[(py * kTile + px) * S + s], k);
         }
     }
+}
+
+// The pixels of (bbox ∩ tile) in STEP x STEP blocks, this lane at (lx, ly) inside every block.  Single-sampled exact triangles (all but the
+// near-plane crossers): E_i at the lane's pixel of the first block of a row by the two FMAs, then E_i += STEP * a_i from block to block —
+// integers below 2^49 throughout, so the sums are the values the FMAs would give, at one f64 add per edge and pixel instead of two FMAs and
+// the coordinate conversions.
+template <int S, int STEP>
+AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
+    if (S == 1 && t.exact) {
+        const double step[3] = {(double)t.a[0] * (double)STEP, (double)t.a[1] * (double)STEP, (double)t.a[2] * (double)STEP};
+        const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5;
+        for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
+            const int py = by + ly;
+            const double Y = (double)(tpy + py) + 0.5;
+            EdgeVals ev;
+#pragma unroll
+            for (int i = 0; i < 3; i++) ev.E[i] = fma((double)t.a[i], X0, fma((double)t.b[i], Y, t.c[i]));
+            for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+                const int px = bx + lx;
+                if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+                    const unsigned long long k = tri_key_from_edges(t, ev, r);
+                    if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) ev.E[i] += step[i];
+            }
+        }
+        return;
+    }
+    for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP)
+        for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+            const int px = bx + lx, py = by + ly;
+            if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
+        }
 }
 
 template <int S>
@@ -626,7 +661,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                         WorkTri& g = work[slot];
 #pragma unroll
                         for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
-                        g.rank = r;
+                        g.rank = r; g.exact = t.exact ? 1u : 0u;
                         g.bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
                     }
                 }
@@ -646,11 +681,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                 load_work_tri(g, t);
                 const uint32_t bb = g.bbox, r = g.rank;
                 const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
-                for (int by = y0 & ~3; by <= y1; by += 4)
-                    for (int bx = x0 & ~3; bx <= x1; bx += 4) {
-                        const int px = bx + lx, py = by + ly;
-                        if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
-                    }
+                raster_walk<S, 4>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r);
                 uint32_t nx = 0u;
                 if ((tid & 15u) == 0u) nx = atomicAdd(&next_mid, 1u);
                 j = (uint32_t)__shfl((int)nx, 0, 16);
@@ -663,11 +694,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
             const uint32_t bb = g.bbox, r = g.rank;
             const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
             const int lx = lane & 7, ly = lane >> 3;
-            for (int by = y0 & ~7; by <= y1; by += 8)
-                for (int bx = x0 & ~7; bx <= x1; bx += 8) {
-                    const int px = bx + lx, py = by + ly;
-                    if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
-                }
+            raster_walk<S, 8>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r);
             uint32_t nx = 0u;
             if (lane == 0) nx = atomicAdd(&next_big, 1u);
             j = (uint32_t)__shfl((int)nx, 0, 64);
