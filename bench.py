@@ -81,22 +81,36 @@ def pmc_kernel(doc, kernel):
     return None
 
 
-def valu_issue(k, launch_ms):
-    """What actually bounds the dominant kernel (it is ALU work, not a stream): vector-ALU instructions per launch from the committed
-    SQ counter pass, the time the 1024 SIMDs (256 CUs x 4) need to issue them at one wave64 VALU instruction per 4 cycles and
-    2.4 GHz, and that time over the measured launch duration; next to it the share of wave-cycles the same pass saw stalled on issue
-    (SQ_WAIT_INST_ANY) and parked on memory (SQ_WAIT_ANY).  (tools/valu_probe.hip: with several waves per SIMD a full-rate
-    instruction issues every ~2 cycles, conversions / compares / selects / integer 3-operand / packed and f64 ops every ~4,
-    transcendentals every ~8 — the 4-cycle figure is the kernel's measured average mix.)"""
+def valu_issue(k, launch_ms, mix=None):
+    """What bounds the dominant kernel beside its memory traffic (it is ALU work, not a stream): vector-ALU instructions per launch from
+    the committed SQ counter pass, the time the 1024 SIMDs (256 CUs x 4) need to issue them, and that time over the measured launch
+    duration; next to it the share of wave-cycles the same pass saw stalled on issue (SQ_WAIT_INST_ANY) and parked on memory (SQ_WAIT_ANY).
+    Cycles per wave64 instruction: gfx950 issues a full-rate FP32 instruction in 2 cycles (157 TFLOP/s vector FP32 = 32 FMA lanes per SIMD
+    and clock), conversions / compares / selects / 3-operand integer / packed / f64 ops and anything with an SGPR or literal source at about
+    half that rate, transcendentals at about a quarter (tools/valu_probe.hip); `mix` is the kernel's static ISA mix weighted that way
+    (tools/isa_cost.py through tools/profile_collect.py).  Without a mix the classic 4 cycles per instruction is used."""
     if not k or not k.get("SQ_INSTS_VALU") or launch_ms <= 0:
         return None
     insts = k["SQ_INSTS_VALU"]
-    min_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
-    out = {"insts_per_launch": insts, "insts_per_wave": insts / k["SQ_WAVES"] if k.get("SQ_WAVES") else None, "issue_bound_ms": min_ms, "frac": min_ms / launch_ms}
+    cpi = mix["cycles_per_wave64_instruction"] if mix else 4.0
+    min_ms = insts * cpi / (1024 * 2.4e9) * 1e3
+    out = {"insts_per_launch": insts, "insts_per_wave": insts / k["SQ_WAVES"] if k.get("SQ_WAVES") else None, "cycles_per_instruction_model": cpi,
+           "model": "static ISA mix x measured issue classes" if mix else "4 cycles per wave64 instruction", "issue_bound_ms": min_ms, "frac": min_ms / launch_ms,
+           "frac_at_4_cycles_per_instruction": insts * 4.0 / (1024 * 2.4e9) * 1e3 / launch_ms}
     if k.get("SQ_WAVE_CYCLES"):
         out["wave_cycles_issue_stalled"] = k.get("SQ_WAIT_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
         out["wave_cycles_waiting_memory"] = k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
     return out
+
+
+def pmc_mix(doc, kernel):
+    if not doc or "valu_mix" not in doc:
+        return None
+    names = ["awsm::" + k for k in SHADE_KERNELS] if kernel == "k_shade" else ["awsm::" + kernel, "awsm::" + kernel + "<false>", "awsm::" + kernel + "<1>"]
+    for n in names:
+        if n in doc["valu_mix"]:
+            return doc["valu_mix"][n]
+    return None
 
 
 def cpu_baseline(scene, lut_rg, rows_sample):
@@ -380,7 +394,7 @@ def main():
     # read from inside the process): profiles/latest_pmc.json, collected by tools/profile_round.sh — profile_tag says which run.
     prof = pmc_profile(n_tris, W, H) if (world == 1 and args.config == 4 and not args.msaa and not args.mipmap) else None
     pk = pmc_kernel(prof, dom)
-    valu = valu_issue(pk, kernel_ms[dom])
+    valu = valu_issue(pk, kernel_ms[dom], pmc_mix(prof, dom))
     traffic_raw = pk.get("hbm_read_bytes_raw", 0.0) + pk.get("hbm_write_bytes", 0.0) if pk else None
     roofline = {"bound": "valu_issue" if (valu and valu["frac"] > achieved / HBM_PEAK_GBS) else "hbm",
                 "kernel": ("k_shade_lean" if lean else "k_shade") if dom == "k_shade" else dom,

@@ -13,8 +13,23 @@ FULL = {"v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_
 TRANS = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
 
 
+def analyse(path, name):
+    """(valu_instructions, weighted_cost, classes, sgpr_slowed, sections) of the kernel whose mangled name contains `name`."""
+    return _walk(path, name)[:5]
+
+
 def main():
     path, name = sys.argv[1], sys.argv[2]
+    n_valu, cost, cls, sgpr_src, sections, ops, n_lines = _walk(path, name)
+    sect_n, sect_cost = sections
+    print(f"{name}: lines {n_lines}, weighted VALU cost {cost:.0f}, classes {dict(cls)}, full-rate ops slowed by an SGPR/literal source {sgpr_src}")
+    print("  sections (VALU count / weighted):", ", ".join(f"{k} {sect_n[k]}/{sect_cost[k]:.0f}" for k in sect_n))
+    print("  waitcnt", ops["s_waitcnt"], " branches", sum(v for k, v in ops.items() if k.startswith("s_cbranch")), " s_nop", ops["s_nop"])
+    for k, v in ops.most_common(45):
+        print(f"  {v:5d} {k}")
+
+
+def _walk(path, name):
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(name) + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
@@ -54,11 +69,7 @@ def main():
             cls[op.split("_")[0] + ("_load" if "load" in op else "_store" if "store" in op else "_atomic")] += 1
         elif op.startswith("ds_"):
             cls["lds"] += 1
-    print(f"{name}: lines {end - start}, weighted VALU cost {cost:.0f}, classes {dict(cls)}, full-rate ops slowed by an SGPR/literal source {sgpr_src}")
-    print("  sections (VALU count / weighted):", ", ".join(f"{k} {sect_n[k]}/{sect_cost[k]:.0f}" for k in sect_n))
-    print("  waitcnt", ops["s_waitcnt"], " branches", sum(v for k, v in ops.items() if k.startswith("s_cbranch")), " s_nop", ops["s_nop"])
-    for k, v in ops.most_common(45):
-        print(f"  {v:5d} {k}")
+    return sum(sect_n.values()), cost, cls, sgpr_src, (sect_n, sect_cost), ops, end - start
 
 
 if __name__ == "__main__":

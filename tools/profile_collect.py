@@ -34,6 +34,28 @@ for k, c in sorted(ctr.items()):
     out[k] = m
 bench = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
 doc = {"tag": tag, "workload": bench["config"], "kernels": out}
+# Static VALU mix of the kernels the roofline talks about, from the ISA of the sources as they are now (hipcc -S here; no GPU needed),
+# weighted by the issue classes tools/valu_probe.hip measured on gfx950: full rate 1 (= 2 cycles per wave64 instruction: the part's
+# 157 TFLOP/s of vector FP32 are 32 FMA lanes per SIMD and clock), half rate 1.8, transcendental 3.5 (tools/isa_cost.py).
+try:
+    import subprocess, tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import isa_cost
+    mix = {}
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "awsm-renderer_amd", "csrc")
+    flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function --cuda-device-only -S".split()
+    for src, kernels in (("kernels_shade.hip", {"awsm::k_shade_lean<false>": "k_shade_leanILb0", "awsm::k_shade<false>": "k_shadeILb0"}),
+                         ("kernels_geometry.hip", {"awsm::k_raster_tile<1>": "k_raster_tileILi1"})):
+        with tempfile.TemporaryDirectory() as td:
+            asm = os.path.join(td, "k.s")
+            subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-o", asm, src], cwd=csrc, check=True, capture_output=True)
+            for pretty, mangled in kernels.items():
+                n, cost, cls, slowed, _ = isa_cost.analyse(asm, mangled)
+                mix[pretty] = {"static_valu_instructions": n, "weighted_cost": cost, "avg_weight": cost / n, "cycles_per_wave64_instruction": 2.0 * cost / n,
+                               "full": cls["full"], "half": cls["half"], "transcendental": cls["trans"], "full_rate_ops_slowed_by_sgpr_or_literal": slowed}
+    doc["valu_mix"] = mix
+except Exception as e:      # no compiler here: the bench falls back to 4 cycles per instruction
+    print("valu_mix not computed:", e)
 json.dump(doc, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 shutil.copy(f"profiles/{tag}_pmc.json", "profiles/latest_pmc.json")
 print(json.dumps({k: {n: v[n] for n in ("hbm_traffic_bytes", "FETCH_SIZE", "WRITE_SIZE") if n in v} for k, v in out.items()}, indent=1))
