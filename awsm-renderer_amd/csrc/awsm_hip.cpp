@@ -104,7 +104,8 @@ struct AwsmHipCtx {
     // Frame overlap (AWSM_CFG_OVERLAP_FRAMES): the opaque pass of frame i runs on shade_stream while the caller's stream
     // already runs the geometry pass of frame i+1 into the other slot.
     bool overlap = false;
-    hipStream_t shade_stream = nullptr;
+    hipStream_t shade_streams[2] = {};     // one per frame slot: the waits in front of frame i + 1's opaque pass are consumed while frame i's still runs (enqueue_opaque)
+    bool shade_recorded[2] = {false, false};   // ev_shade_done[slot] has been recorded since the last full synchronisation
     hipStream_t prep_stream = nullptr;     // the per-draw resolve of frame i + 1, beside frame i's opaque pass (enqueue_opaque)
     hipEvent_t ev_geom_done[2] = {}, ev_shade_done[2] = {}, ev_uploads[2] = {}, ev_resolved[2] = {};
     uint64_t write_seq = 0, geom_write_seq[2] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
@@ -147,7 +148,12 @@ struct AwsmHipCtx {
 namespace {
 
 inline FrameBufs& FB(AwsmHipCtx* c) { return c->fb[c->slot]; }
-inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade_stream : c->stream; }
+inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade_streams[c->slot] : c->stream; }
+inline hipError_t sync_shade_streams(AwsmHipCtx* c) {
+    for (hipStream_t s : c->shade_streams) if (s) { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e; }
+    c->shade_recorded[0] = c->shade_recorded[1] = false;
+    return hipSuccess;
+}
 
 int fail(AwsmHipCtx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -174,7 +180,7 @@ int dev_realloc(AwsmHipCtx* c, DevBuf& b, size_t bytes, bool zero) {
     }
     if (b.ptr) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->shade_stream) HIPCHK(c, hipStreamSynchronize(c->shade_stream));
+        HIPCHK(c, sync_shade_streams(c));
         HIPCHK(c, hipFree(b.ptr));
         b.ptr = nullptr; b.size = 0;
     }
@@ -245,7 +251,7 @@ int scene_write_barrier(AwsmHipCtx* c, bool is_write = true) {
 }
 int sync_all(AwsmHipCtx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->shade_stream) HIPCHK(c, hipStreamSynchronize(c->shade_stream));
+    HIPCHK(c, sync_shade_streams(c));
     c->shade_pending[0] = c->shade_pending[1] = false;
     return AWSM_OK;
 }
@@ -414,6 +420,10 @@ int enqueue_opaque(AwsmHipCtx* c) {
     if (c->overlap) {   // the shade stream picks up where the caller's stream is now (geometry pass + uploads of this frame)
         HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
+        // ... and behind the previous frame's passes on the other slot's shade stream (they share the output images, the MSAA scratch and
+        // the fragment lists).  Last of the three waits on purpose: the first two are consumed while the previous frame still shades, so
+        // one barrier packet stands between its last kernel and this frame's first instead of three (18 -> 6 us per frame, tools/frame_timeline.sh).
+        if (c->shade_recorded[c->slot ^ 1]) HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade_done[c->slot ^ 1], 0));
     }
     if (want_resolve && !early) awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     if ((rc = record(c, EV_SHADE_BEGIN, ss))) return rc;      // after the resolve: ms_shade is the shading kernels alone
@@ -425,7 +435,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
         (void)awsm_launch_shade_todo(c->scene_dev, &f, ss);
     }
     if ((rc = record(c, EV_SHADE, ss))) return rc;
-    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; }
+    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true; }
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -487,7 +497,7 @@ int enqueue_transparent(AwsmHipCtx* c) {
         awsm_launch_forward(c->scene_dev, &f, ss);
     }
     if ((rc = record(c, EV_FWD, ss))) return rc;
-    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; }
+    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true; }
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -651,7 +661,8 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     }
 
     if (c->overlap) {
-        if (hipStreamCreateWithFlags(&c->shade_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        if (hipStreamCreateWithFlags(&c->shade_streams[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->shade_streams[1], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
         for (int s = 0; s < 2; s++) {
             if (hipEventCreateWithFlags(&c->ev_geom_done[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_uploads[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_resolved[s], hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
@@ -673,7 +684,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->shade_stream) (void)hipStreamSynchronize(c->shade_stream);
+    (void)sync_shade_streams(c);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
@@ -684,7 +695,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
-    if (c->shade_stream) (void)hipStreamDestroy(c->shade_stream);
+    for (hipStream_t st : c->shade_streams) if (st) (void)hipStreamDestroy(st);
     if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     for (int i = 0; i < 2; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); if (c->ev_resolved[i]) (void)hipEventDestroy(c->ev_resolved[i]); }
     if (c->scene_dev) (void)hipFree(c->scene_dev);
@@ -1050,7 +1061,7 @@ int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) 
     if ((rc = ensure_fragment_capacity(c, TR(c), (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : (uint32_t)std::max<size_t>(px / 2, 1u << 20)))) return rc;
     if (c->overlap) {   // the draw-list upload went to the caller's stream; the pass runs on the shade stream
         HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->shade_stream, c->ev_geom_done[c->slot], 0));
+        HIPCHK(c, hipStreamWaitEvent(shade_stream_of(c), c->ev_geom_done[c->slot], 0));
     }
     if ((rc = enqueue_transparent(c))) return rc;
     c->transparent_done = true;
@@ -1082,7 +1093,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         }
         HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->shade_stream) { HIPCHK(c, hipStreamSynchronize(c->shade_stream)); c->shade_pending[0] = c->shade_pending[1] = false; }
+        if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); c->shade_pending[0] = c->shade_pending[1] = false; }
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
         if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;

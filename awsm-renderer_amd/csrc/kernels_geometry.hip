@@ -436,9 +436,11 @@ __global__ __launch_bounds__(256) void k_bin_big(FrameDev f) { bin_big_walk<FILL
 // fullest tiles and the light ones fill in behind them (longest-processing-time-first; the fullest tile of a frame holds
 // 20-40x the median number of triangles and would otherwise be the tail of the kernel).
 constexpr uint32_t kRasterSlice = 256;     // triangles of a tile's list one raster workgroup takes (= one batch of k_raster_tile)
-// 512 threads (8 wavefronts, 2 per SIMD, < 80 VGPRs): the workgroup also fits on a CU that the persistent opaque-pass grid of the
-// previous frame occupies with 4 x 88 VGPRs per lane — a 1024-thread workgroup (4 wavefronts per SIMD x 64) waited for that grid to drain.
-constexpr uint32_t kScanThreads = 512, kScanWaves = kScanThreads / 64, kScanPer = 8192 / kScanThreads;
+// 256 threads (one wavefront per SIMD): the workgroup is placed as soon as ONE workgroup of the previous frame's opaque pass leaves a CU (80
+// VGPRs x 6 waves: an exit frees 80 + 32 spare registers per lane).  With 1,024 threads (4 waves per SIMD) it waited for that kernel's tail, with
+// 512 (2 x 80 registers) for two exits on one CU that the opaque queue did not refill first: 40-190 us beside the opaque pass, 26 alone.
+constexpr uint32_t kScanThreads = 256, kScanWaves = kScanThreads / 64;
+AWSM_DI uint32_t scan_slot(uint32_t i) { return i + (i >> 5); }     // a thread walks 32 consecutive tiles: skewed so that the lanes of a step hit 32 different LDS banks
 __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
     __shared__ uint32_t part[kScanWaves], part2[kScanWaves];    // wavefront totals of the two scans
     __shared__ uint32_t bucket_n[kScanWaves][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
@@ -450,30 +452,19 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
     const uint32_t per = (n_tiles + kScanThreads - 1u) / kScanThreads;
     const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
     for (uint32_t i = tid; i < kScanWaves * 33u; i += kScanThreads) (&bucket_n[0][0])[i] = 0u;
-    __syncthreads();
-    // the first 8 counts of the chunk are loaded together and kept in registers for the second loop (one memory round trip
-    // instead of `per` dependent ones); longer chunks (frames beyond 8192 tiles) fall back to re-reading
     // Frames of up to 8192 tiles (4K: 8160) move counts and offsets through LDS so that the global loads and stores of this single
-    // workgroup are coalesced (thread t touches tiles t, t + 512, ...) while each thread still owns 16 consecutive tiles of the scan:
-    // one CU's memory pipeline was the bottleneck with 32-byte-strided 4-byte accesses.
-    __shared__ uint32_t stage[8192];
-    const bool staged = n_tiles <= 8192u;          // then per <= kScanPer
-    if (staged) {
-        for (uint32_t i = tid; i < n_tiles; i += kScanThreads) stage[i] = f.tile_count[i];
-        __syncthreads();
-    }
+    // workgroup are coalesced (thread t touches tiles t, t + 256, ...) while each thread still owns `per` consecutive tiles of the scan
+    // (one CU's memory pipeline was the bottleneck with strided 4-byte accesses); larger frames read and write global memory per tile.
+    __shared__ uint32_t stage[8192 + 256];
+    const bool staged = n_tiles <= 8192u;
+    if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) stage[scan_slot(i)] = f.tile_count[i];
+    __syncthreads();
     AWSM_STAMP_AT(f, 1, 1);
-    uint32_t cnt[kScanPer];
-#pragma unroll
-    for (uint32_t j = 0; j < kScanPer; j++) cnt[j] = (b0 + j < b1) ? (staged ? stage[b0 + j] : f.tile_count[b0 + j]) : 0u;
     uint32_t sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kScanPer; j++)
-        if (b0 + j < b1) { sum += cnt[j]; atomicAdd(&bucket_n[wave][32 - __clz(cnt[j])], 1u); }   // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
-    for (uint32_t i = b0 + kScanPer; i < b1; i++) {
-        const uint32_t c = f.tile_count[i];
+    for (uint32_t i = b0; i < b1; i++) {
+        const uint32_t c = staged ? stage[scan_slot(i)] : f.tile_count[i];
         sum += c;
-        atomicAdd(&bucket_n[wave][32 - __clz(c)], 1u);
+        atomicAdd(&bucket_n[wave][32 - __clz(c)], 1u);      // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
     }
     __syncthreads();
     // Two inclusive scans over the workgroup's threads at once — the chunk sums, and the (bucket, wave) histogram entries in tile_order's
@@ -499,7 +490,7 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
     // A tile with more than kRasterSlice triangles is rasterised by ceil(c / kRasterSlice) workgroups (its list in slices): one extra
     // raster item per slice after the first, one scratch tile per slice.  The caps hold whenever the bin list itself does not overflow.
     auto place = [&](uint32_t i, uint32_t c) {
-        if (staged) stage[i] = run; else { f.tile_offset[i] = run; f.tile_cursor[i] = 0u; }
+        if (staged) stage[scan_slot(i)] = run; else { f.tile_offset[i] = run; f.tile_cursor[i] = 0u; }
         run += c;
         f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
         if (c > kRasterSlice && f.raster_scratch) {     // tile_split is written (and read, k_raster_tile) for these tiles only
@@ -510,13 +501,10 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
             reinterpret_cast<uint2*>(f.tile_split)[i] = make_uint2(fits ? sb : 0xFFFFFFFFu, 0u);
         }
     };
-#pragma unroll
-    for (uint32_t j = 0; j < kScanPer; j++)
-        if (b0 + j < b1) place(b0 + j, cnt[j]);
-    for (uint32_t i = b0 + kScanPer; i < b1; i++) place(i, f.tile_count[i]);
+    for (uint32_t i = b0; i < b1; i++) place(i, staged ? stage[scan_slot(i)] : f.tile_count[i]);
     AWSM_STAMP_AT(f, 1, 4);
     __syncthreads();
-    if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) { f.tile_offset[i] = stage[i]; f.tile_cursor[i] = 0u; }
+    if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) { f.tile_offset[i] = stage[scan_slot(i)]; f.tile_cursor[i] = 0u; }
     if (tid == kScanThreads - 1u) {
         const uint32_t total = incl1;
         f.tile_offset[n_tiles] = total;
