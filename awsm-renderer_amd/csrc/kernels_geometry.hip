@@ -460,11 +460,16 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
     if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) stage[scan_slot(i)] = f.tile_count[i];
     __syncthreads();
     AWSM_STAMP_AT(f, 1, 1);
+    // one wavefront per SIMD hides no latency: the per-tile LDS reads, histogram atomics and (second loop) slot atomics go in batches of 8
+    // independent operations instead of 32 dependent round trips per thread
     uint32_t sum = 0;
-    for (uint32_t i = b0; i < b1; i++) {
-        const uint32_t c = staged ? stage[scan_slot(i)] : f.tile_count[i];
-        sum += c;
-        atomicAdd(&bucket_n[wave][32 - __clz(c)], 1u);      // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
+    for (uint32_t i0 = b0; i0 < b1; i0 += 8u) {
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) c[j] = i0 + j < b1 ? (staged ? stage[scan_slot(i0 + j)] : f.tile_count[i0 + j]) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++)
+            if (i0 + j < b1) { sum += c[j]; atomicAdd(&bucket_n[wave][32 - __clz(c[j])], 1u); }      // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
     }
     __syncthreads();
     // Two inclusive scans over the workgroup's threads at once — the chunk sums, and the (bucket, wave) histogram entries in tile_order's
@@ -489,19 +494,29 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
     uint32_t run = incl1 - sum;   // exclusive prefix of this thread's chunk
     // A tile with more than kRasterSlice triangles is rasterised by ceil(c / kRasterSlice) workgroups (its list in slices): one extra
     // raster item per slice after the first, one scratch tile per slice.  The caps hold whenever the bin list itself does not overflow.
-    auto place = [&](uint32_t i, uint32_t c) {
-        if (staged) stage[scan_slot(i)] = run; else { f.tile_offset[i] = run; f.tile_cursor[i] = 0u; }
-        run += c;
-        f.tile_order[atomicAdd(&bucket_at[wave][32 - __clz(c)], 1u)] = i;
-        if (c > kRasterSlice && f.raster_scratch) {     // tile_split is written (and read, k_raster_tile) for these tiles only
-            const uint32_t ns = (c + kRasterSlice - 1u) / kRasterSlice;
-            const uint32_t eb = atomicAdd(&n_extra, ns - 1u), sb = atomicAdd(&n_slots, ns);
-            const bool fits = eb + ns - 1u <= f.raster_extra_cap && sb + ns <= f.raster_slot_cap && ns <= 4095u;
-            for (uint32_t k = 1; k < ns; k++) if (eb + k - 1u < f.raster_extra_cap) f.tile_order[n_tiles + eb + k - 1u] = fits ? (i | (k << 20)) : 0xFFFFFFFFu;
-            reinterpret_cast<uint2*>(f.tile_split)[i] = make_uint2(fits ? sb : 0xFFFFFFFFu, 0u);
-        }
+    auto split = [&](uint32_t i, uint32_t c) {     // tile_split is written (and read, k_raster_tile) for these tiles only
+        const uint32_t ns = (c + kRasterSlice - 1u) / kRasterSlice;
+        const uint32_t eb = atomicAdd(&n_extra, ns - 1u), sb = atomicAdd(&n_slots, ns);
+        const bool fits = eb + ns - 1u <= f.raster_extra_cap && sb + ns <= f.raster_slot_cap && ns <= 4095u;
+        for (uint32_t k = 1; k < ns; k++) if (eb + k - 1u < f.raster_extra_cap) f.tile_order[n_tiles + eb + k - 1u] = fits ? (i | (k << 20)) : 0xFFFFFFFFu;
+        reinterpret_cast<uint2*>(f.tile_split)[i] = make_uint2(fits ? sb : 0xFFFFFFFFu, 0u);
     };
-    for (uint32_t i = b0; i < b1; i++) place(i, staged ? stage[scan_slot(i)] : f.tile_count[i]);
+    for (uint32_t i0 = b0; i0 < b1; i0 += 8u) {
+        uint32_t c[8], at[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) c[j] = i0 + j < b1 ? (staged ? stage[scan_slot(i0 + j)] : f.tile_count[i0 + j]) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) at[j] = i0 + j < b1 ? atomicAdd(&bucket_at[wave][32 - __clz(c[j])], 1u) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            const uint32_t i = i0 + j;
+            if (i >= b1) break;
+            if (staged) stage[scan_slot(i)] = run; else { f.tile_offset[i] = run; f.tile_cursor[i] = 0u; }
+            run += c[j];
+            f.tile_order[at[j]] = i;
+            if (c[j] > kRasterSlice && f.raster_scratch) split(i, c[j]);
+        }
+    }
     AWSM_STAMP_AT(f, 1, 4);
     __syncthreads();
     if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) { f.tile_offset[i] = stage[scan_slot(i)]; f.tile_cursor[i] = 0u; }

@@ -1,6 +1,7 @@
 """Static instruction mix of one kernel of an AMDGPU .s file, weighted by the issue classes tools/valu_probe.hip measured on gfx950
 (profiles/r02_valu_probe.txt): full rate = 1 (v_fma/add/mul/sub_f32, v_mov, v_add_u32, and/or/xor), half rate = 1.8 (conversions,
-min/max, compares, selects, shifts, 3-operand integer, f64, packed f32, anything with an SGPR/literal operand), transcendental = 3.5.
+min/max, compares, selects, shifts, 3-operand integer, f64, packed f32, anything with an SGPR source operand — literal and inline
+constants cost nothing), transcendental = 3.5.
 
 usage: python tools/isa_cost.py file.s kernel_substring [--loop LABEL]   (straight-line kernels: static ~ dynamic)
 """
@@ -52,7 +53,7 @@ def _walk(path, name):
         if op.startswith("v_") and not op.startswith("v_readfirstlane") and not op.startswith("v_readlane"):
             args = t[len(op):]
             srcs = args.split(",")[1:] if "," in args else []
-            has_s = any(re.search(r"\bs\d+|\bs\[|\bvcc\b|0x[0-9a-f]+", a) for a in srcs) and not base.startswith(("v_cmp", "v_cndmask"))
+            has_s = any(re.search(r"\bs\d+|\bs\[|\bvcc\b", a) for a in srcs) and not base.startswith(("v_cmp", "v_cndmask"))     # literals and inline constants are free (probe)
             if base in TRANS:
                 c = 3.5; cls["trans"] += 1
             elif base in FULL and not has_s:
