@@ -60,6 +60,7 @@ struct FrameBufs {
     DevBuf tri_shade, draw_lean;           // geometry pass: per-triangle attribute offsets (k_deform_transform), per-draw lean records (k_resolve_draws)
     DevBuf clip, nrm, tan, tri_rec, tri_flags, draws_dev, draw_shade, tile_count, tile_offset, tile_cursor, tile_order, bin_list, big_list, counters, vis;
     DevBuf camera;                         // snapshot of the camera UBO taken by the geometry pass (overlap mode)
+    DevBuf scan_tmp;                       // k_bin_scan's cross-workgroup tables
     DevBuf tile_split, raster_scratch;     // split raster tiles: per-tile {first scratch slot, slices done}; partial tiles (geometry pass only)
     uint32_t raster_extra_cap = 0, raster_slot_cap = 0;
     uint32_t bin_capacity = 0;
@@ -309,6 +310,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->tile_count = (uint32_t*)FB(c).tile_count.ptr; f->tile_offset = (uint32_t*)FB(c).tile_offset.ptr;
     f->tile_cursor = (uint32_t*)FB(c).tile_cursor.ptr; f->bin_list = (uint32_t*)FB(c).bin_list.ptr;
     f->tile_order = (uint32_t*)FB(c).tile_order.ptr;
+    f->scan_tmp = (uint32_t*)FB(c).scan_tmp.ptr;
     f->tile_split = (uint32_t*)FB(c).tile_split.ptr; f->raster_scratch = (unsigned long long*)FB(c).raster_scratch.ptr;
     f->raster_extra_cap = FB(c).raster_extra_cap; f->raster_slot_cap = FB(c).raster_slot_cap;
     f->big_list = (uint32_t*)FB(c).big_list.ptr;
@@ -368,6 +370,7 @@ int enqueue_geometry(AwsmHipCtx* c) {
     const bool has_geometry = c->total_tris && n_tiles;
     if (!has_geometry) {   // otherwise k_deform_transform clears counters + tile_count and k_bin_scan clears tile_cursor
         HIPCHK(c, hipMemsetAsync(FB(c).counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 12, 0, 2 * sizeof(uint32_t), c->stream));
         if (n_tiles) HIPCHK(c, hipMemsetAsync(FB(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
     }
     if ((rc = record(c, EV_START))) return rc;
@@ -461,6 +464,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->tile_count = (uint32_t*)t.tile_count.ptr; f->tile_offset = (uint32_t*)t.tile_offset.ptr;
     f->tile_cursor = (uint32_t*)t.tile_cursor.ptr; f->bin_list = (uint32_t*)t.bin_list.ptr;
     f->tile_order = (uint32_t*)t.tile_order.ptr;
+    f->scan_tmp = (uint32_t*)t.scan_tmp.ptr;
     f->tile_split = (uint32_t*)t.tile_split.ptr; f->raster_scratch = nullptr;      // the transparent pass has its own tile kernel: nothing is split
     f->raster_extra_cap = 0; f->raster_slot_cap = 0;
     f->big_list = (uint32_t*)t.big_list.ptr;
@@ -485,6 +489,7 @@ int enqueue_transparent(AwsmHipCtx* c) {
     const bool has_geometry = f.total_tris && n_tiles;
     if (!has_geometry) {
         HIPCHK(c, hipMemsetAsync(TR(c).counters.ptr, 0, 8 * sizeof(uint32_t), ss));
+        HIPCHK(c, hipMemsetAsync((uint32_t*)TR(c).counters.ptr + 12, 0, 2 * sizeof(uint32_t), ss));
         if (n_tiles) HIPCHK(c, hipMemsetAsync(TR(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), ss));
     } else {
         awsm_launch_resolve_draws(c->scene_dev, &f, ss);      // first: the transform tags each triangle with its draw's alpha mode
@@ -593,6 +598,7 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
     if ((rc = dev_reserve(c, b.tile_offset, (n_tiles_full + 1) * 4))) return rc;
     if ((rc = dev_reserve(c, b.tile_cursor, n_tiles_full * 4))) return rc;
     if ((rc = dev_reserve(c, b.tile_split, n_tiles_full * 8))) return rc;
+    if ((rc = dev_reserve(c, b.scan_tmp, (((n_tiles_full + 255) / 256) * 2 + 1) * 40 * 4))) return rc;      // kScanWords = 40: aggregates, bases, run starts (kernels_geometry.hip)
     if ((rc = ensure_bin_capacity_of(c, b, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * total_tris + 65536u, 1u << 18)))) return rc;
     if ((rc = reserve_raster_items(c, b, forward))) return rc;
     // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
@@ -654,10 +660,10 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         c->lean_grid = per_cu > 0 ? (uint32_t)(per_cu * prop.multiProcessorCount) & ~7u : 0u;
     }
     for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
-        if (hipMalloc(&c->fb[s].counters.ptr, 12 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words
-        c->fb[s].counters.size = 12 * sizeof(uint32_t);
-        if (hipMalloc(&c->tr[s].counters.ptr, 8 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-        c->tr[s].counters.size = 8 * sizeof(uint32_t);
+        if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13]
+        c->fb[s].counters.size = 16 * sizeof(uint32_t);
+        if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        c->tr[s].counters.size = 16 * sizeof(uint32_t);
     }
 
     if (c->overlap) {
@@ -693,7 +699,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (int k = 0; k < 4; k++) {
         FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
-        fr(b.tile_cursor); fr(b.tile_order); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
+        fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     for (hipStream_t st : c->shade_streams) if (st) (void)hipStreamDestroy(st);
     if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);

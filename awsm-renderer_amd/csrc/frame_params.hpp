@@ -162,6 +162,7 @@ struct FrameDev {
     uint32_t* tile_count;         // n_tiles
     uint32_t* tile_offset;        // n_tiles + 1
     uint32_t* tile_cursor;        // n_tiles
+    uint32_t* scan_tmp;           // k_bin_scan: per scan workgroup (256 tiles) kScanWords words of aggregates, then as many of bases (see there)
     uint32_t* tile_order;         // n_tiles: tile ids, heaviest first (k_bin_scan); then raster_extra_cap extra raster items
                                   // (tile | slice << 20, slice >= 1) for the tiles whose list is split over several workgroups (count in counters[7])
     uint32_t* tile_split;         // 2 * n_tiles: [2t] first scratch slot of a split tile (0xFFFFFFFF: not split), [2t+1] slices that finished

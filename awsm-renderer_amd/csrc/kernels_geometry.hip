@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
         const uint32_t n_tiles = f.tiles_x * f.tiles_y, gsz = gridDim.x * 256u, g0 = b * 256u + tid;
         for (uint32_t i = g0; i < n_tiles; i += gsz) f.tile_count[i] = 0u;
         if (g0 < 8u) f.counters[g0] = 0u;
+        if (g0 == 12u || g0 == 13u) f.counters[g0] = 0u;      // k_bin_scan's arrival counter and ready flag
         if (!FWD && g0 < f.camera_snap_words) f.camera_snap[g0] = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_CAMERA])[g0];   // overlap mode: the frame's camera
     }
     uint32_t lo = 0, hi = f.n_draws;
@@ -436,102 +437,118 @@ __global__ __launch_bounds__(256) void k_bin_big(FrameDev f) { bin_big_walk<FILL
 // fullest tiles and the light ones fill in behind them (longest-processing-time-first; the fullest tile of a frame holds
 // 20-40x the median number of triangles and would otherwise be the tail of the kernel).
 constexpr uint32_t kRasterSlice = 256;     // triangles of a tile's list one raster workgroup takes (= one batch of k_raster_tile)
-// 256 threads (one wavefront per SIMD): the workgroup is placed as soon as ONE workgroup of the previous frame's opaque pass leaves a CU (80
-// VGPRs x 6 waves: an exit frees 80 + 32 spare registers per lane).  With 1,024 threads (4 waves per SIMD) it waited for that kernel's tail, with
-// 512 (2 x 80 registers) for two exits on one CU that the opaque queue did not refill first: 40-190 us beside the opaque pass, 26 alone.
-constexpr uint32_t kScanThreads = 256, kScanWaves = kScanThreads / 64;
-AWSM_DI uint32_t scan_slot(uint32_t i) { return i + (i >> 5); }     // a thread walks 32 consecutive tiles: skewed so that the lanes of a step hit 32 different LDS banks
+// Multi-workgroup, one launch: workgroup k owns the tiles [256 k, 256 k + 256), one per thread.
+//   1. local: the thread's count c, its bucket (0: empty, b: 2^(b-1) <= c < 2^b), the split quantities (a tile with more than kRasterSlice
+//      triangles is rasterised by ns = ceil(c / kRasterSlice) workgroups: ns - 1 extra raster items, ns scratch tiles); workgroup-exclusive
+//      prefixes of c / extras / slots (wavefront shuffles + 4 partials), a 33-bucket LDS histogram that also hands each thread its rank;
+//      the workgroup's aggregates (3 totals + 33 bucket counts) go to scan_tmp[k] with stores that reach memory (sc1), every wavefront drains
+//      them (s_waitcnt vmcnt(0)) before the barrier in front of the arrival counter.
+//   2. the workgroup that arrives last turns the aggregates into bases — per quantity the exclusive prefix over workgroups (lane = workgroup,
+//      shuffles) — and per bucket the sizes of all heavier buckets (tile_order is heaviest first), writes both behind the aggregates (sc1),
+//      writes the frame totals, drains, raises the ready flag.  The others poll the flag (s_sleep); the last arriver never waits, so no order of
+//      placement can deadlock, and every workgroup is small (256 threads, < 64 VGPRs): it is placed on the first exit of an opaque-pass workgroup.
+//   3. every workgroup: tile_offset, tile_cursor, tile_order position, split records from its bases.
+// The single-workgroup scan this replaces spent 35 us of its 40 in 32 serial steps per thread of same-address LDS atomics (19 us with 1,024
+// threads, which then had to wait for room beside the previous frame's opaque pass: 40-190 us).
+constexpr uint32_t kScanThreads = 256, kScanWords = 40;     // per workgroup: [0] sum c, [1] sum extras, [2] sum slots, [3 + b] bucket b (b = 0..32), pad
+AWSM_DI uint32_t ld_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+AWSM_DI void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
-    __shared__ uint32_t part[kScanWaves], part2[kScanWaves];    // wavefront totals of the two scans
-    __shared__ uint32_t bucket_n[kScanWaves][33];      // per-wavefront histograms: 8 k LDS atomics on 33 shared words serialise (measured 18 us)
-    __shared__ uint32_t bucket_at[kScanWaves][33];
-    __shared__ uint32_t n_extra, n_slots;       // raster items beyond one per tile / scratch tiles (split tiles, see k_raster_tile)
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    __shared__ uint32_t hist[36], part[3][4], base[kScanWords], last_flag;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, k = blockIdx.x, G = gridDim.x;
+    const uint32_t i = k * kScanThreads + tid;
+    const bool live = i < n_tiles;
     AWSM_STAMP_AT(f, 1, 0);
-    if (tid == 0) { n_extra = 0u; n_slots = 0u; }
-    const uint32_t per = (n_tiles + kScanThreads - 1u) / kScanThreads;
-    const uint32_t b0 = min(tid * per, n_tiles), b1 = min(b0 + per, n_tiles);
-    for (uint32_t i = tid; i < kScanWaves * 33u; i += kScanThreads) (&bucket_n[0][0])[i] = 0u;
-    // Frames of up to 8192 tiles (4K: 8160) move counts and offsets through LDS so that the global loads and stores of this single
-    // workgroup are coalesced (thread t touches tiles t, t + 256, ...) while each thread still owns `per` consecutive tiles of the scan
-    // (one CU's memory pipeline was the bottleneck with strided 4-byte accesses); larger frames read and write global memory per tile.
-    __shared__ uint32_t stage[8192 + 256];
-    const bool staged = n_tiles <= 8192u;
-    if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) stage[scan_slot(i)] = f.tile_count[i];
+    if (tid < 36u) hist[tid] = 0u;
+    const uint32_t c = live ? f.tile_count[i] : 0u;
+    const uint32_t b = 32u - (uint32_t)__clz(c);
+    const uint32_t ns = (live && c > kRasterSlice && f.raster_scratch) ? (c + kRasterSlice - 1u) / kRasterSlice : 0u;
+    const uint32_t v[3] = {c, ns ? ns - 1u : 0u, ns};
+    __syncthreads();
+    const uint32_t rank = live ? atomicAdd(&hist[b], 1u) : 0u;
+    uint32_t incl[3] = {v[0], v[1], v[2]};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+#pragma unroll
+        for (int q = 0; q < 3; q++) { const uint32_t o = (uint32_t)__shfl_up((int)incl[q], d); if ((int)lane >= d) incl[q] += o; }
+    if (lane == 63u) { part[0][wave] = incl[0]; part[1][wave] = incl[1]; part[2][wave] = incl[2]; }
+    __syncthreads();
+    uint32_t excl[3], total[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        uint32_t before = 0u, all = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) { const uint32_t p = part[q][w]; all += p; if (w < wave) before += p; }
+        excl[q] = before + incl[q] - v[q]; total[q] = all;
+    }
+    uint32_t* agg = f.scan_tmp + (size_t)k * kScanWords;
+    uint32_t* bases = f.scan_tmp + (size_t)(G + k) * kScanWords;
+    if (tid < 3u) st_sc1(agg + tid, total[tid]);
+    else if (tid < 36u) st_sc1(agg + tid, hist[tid - 3u]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0u) last_flag = atomicAdd(&f.counters[12], 1u) == G - 1u ? 1u : 0u;
     __syncthreads();
     AWSM_STAMP_AT(f, 1, 1);
-    // one wavefront per SIMD hides no latency: the per-tile LDS reads, histogram atomics and (second loop) slot atomics go in batches of 8
-    // independent operations instead of 32 dependent round trips per thread
-    uint32_t sum = 0;
-    for (uint32_t i0 = b0; i0 < b1; i0 += 8u) {
-        uint32_t c[8];
+    if (last_flag) {      // workgroup-uniform
+        // quantity q (36 of them): exclusive prefix over the workgroups, 64 workgroups per pass with lane = workgroup; wavefront w takes q = w, w + 4, ...
+        __shared__ uint32_t q_total[36];
+        for (uint32_t q = wave; q < 36u; q += 4u) {
+            uint32_t carry = 0u;
+            for (uint32_t k0 = 0; k0 < G; k0 += 64u) {
+                const uint32_t kk = k0 + lane;
+                const uint32_t a = kk < G ? ld_sc1(f.scan_tmp + (size_t)kk * kScanWords + q) : 0u;
+                uint32_t in = a;
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) c[j] = i0 + j < b1 ? (staged ? stage[scan_slot(i0 + j)] : f.tile_count[i0 + j]) : 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++)
-            if (i0 + j < b1) { sum += c[j]; atomicAdd(&bucket_n[wave][32 - __clz(c[j])], 1u); }      // bucket 0: empty tile, bucket k: 2^(k-1) <= c < 2^k
-    }
-    __syncthreads();
-    // Two inclusive scans over the workgroup's threads at once — the chunk sums, and the (bucket, wave) histogram entries in tile_order's
-    // order: buckets descending, waves ascending inside a bucket, entry e = (32 - bucket) * kScanWaves + wave.  Wavefront scans through
-    // shuffles plus the wavefront totals: two barriers instead of the twenty of a workgroup-wide Hillis-Steele.
-    const uint32_t lane = tid & 63u;
-    const uint32_t e_bucket = 32u - tid / kScanWaves, e_wave = tid % kScanWaves;
-    const uint32_t e_val = tid < 33u * kScanWaves ? bucket_n[e_wave][e_bucket] : 0u;
-    uint32_t incl1 = sum, incl2 = e_val;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o1 = (uint32_t)__shfl_up((int)incl1, d), o2 = (uint32_t)__shfl_up((int)incl2, d);
-        if ((int)lane >= d) { incl1 += o1; incl2 += o2; }
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)in, d); if ((int)lane >= d) in += o; }
+                if (kk < G) st_sc1(f.scan_tmp + (size_t)(G + kk) * kScanWords + q, carry + in - a);
+                carry += (uint32_t)__shfl((int)in, 63);
+            }
+            if (lane == 0u) q_total[q] = carry;
+        }
+        __syncthreads();
+        if (tid < 33u) {      // bucket b's run of tile_order starts behind all heavier buckets
+            uint32_t heavier = 0u;
+            for (uint32_t bb = tid + 1u; bb < 33u; bb++) heavier += q_total[3u + bb];
+            st_sc1(f.scan_tmp + (size_t)2u * G * kScanWords + tid, heavier);
+        }
+        if (tid == 0u) {
+            const uint32_t total_entries = q_total[0];
+            f.tile_offset[n_tiles] = total_entries;
+            f.counters[1] = total_entries;
+            if (total_entries > f.bin_capacity) f.counters[2] = 1u;
+            f.counters[7] = min(q_total[1], f.raster_extra_cap);
+            if (f.host_bin_status) {   // for frames nobody waits for: the host sizes the list of later frames from this (awsm_hip_geometry_pass)
+                __hip_atomic_store(f.host_bin_status, total_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(f.host_bin_status + 1, f.frame_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // bases and run starts went out with sc1 stores: in memory once every wavefront has drained
+        __syncthreads();
+        if (tid == 0u) st_sc1(&f.counters[13], 1u);
+    } else {
+        if (tid == 0u) {      // bounded (~1 s): a grid whose counters were not reset must end, not hang the device; the frame is then flagged as overflowed
+            uint32_t spins = 0u;
+            while (ld_sc1(&f.counters[13]) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(8);
+            if (spins >= (1u << 22)) f.counters[2] = 1u;
+        }
+        __syncthreads();
     }
     AWSM_STAMP_AT(f, 1, 2);
-    if (lane == 63u) { part[wave] = incl1; part2[wave] = incl2; }
+    if (tid < 36u) base[tid] = ld_sc1(bases + tid) + (tid >= 3u ? ld_sc1(f.scan_tmp + (size_t)2u * G * kScanWords + tid - 3u) : 0u);
     __syncthreads();
-    for (uint32_t w = 0; w < wave; w++) { incl1 += part[w]; incl2 += part2[w]; }
-    if (tid < 33u * kScanWaves) bucket_at[e_wave][e_bucket] = incl2 - e_val;
-    __syncthreads();
-    AWSM_STAMP_AT(f, 1, 3);
-    uint32_t run = incl1 - sum;   // exclusive prefix of this thread's chunk
-    // A tile with more than kRasterSlice triangles is rasterised by ceil(c / kRasterSlice) workgroups (its list in slices): one extra
-    // raster item per slice after the first, one scratch tile per slice.  The caps hold whenever the bin list itself does not overflow.
-    auto split = [&](uint32_t i, uint32_t c) {     // tile_split is written (and read, k_raster_tile) for these tiles only
-        const uint32_t ns = (c + kRasterSlice - 1u) / kRasterSlice;
-        const uint32_t eb = atomicAdd(&n_extra, ns - 1u), sb = atomicAdd(&n_slots, ns);
-        const bool fits = eb + ns - 1u <= f.raster_extra_cap && sb + ns <= f.raster_slot_cap && ns <= 4095u;
-        for (uint32_t k = 1; k < ns; k++) if (eb + k - 1u < f.raster_extra_cap) f.tile_order[n_tiles + eb + k - 1u] = fits ? (i | (k << 20)) : 0xFFFFFFFFu;
-        reinterpret_cast<uint2*>(f.tile_split)[i] = make_uint2(fits ? sb : 0xFFFFFFFFu, 0u);
-    };
-    for (uint32_t i0 = b0; i0 < b1; i0 += 8u) {
-        uint32_t c[8], at[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) c[j] = i0 + j < b1 ? (staged ? stage[scan_slot(i0 + j)] : f.tile_count[i0 + j]) : 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) at[j] = i0 + j < b1 ? atomicAdd(&bucket_at[wave][32 - __clz(c[j])], 1u) : 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) {
-            const uint32_t i = i0 + j;
-            if (i >= b1) break;
-            if (staged) stage[scan_slot(i)] = run; else { f.tile_offset[i] = run; f.tile_cursor[i] = 0u; }
-            run += c[j];
-            f.tile_order[at[j]] = i;
-            if (c[j] > kRasterSlice && f.raster_scratch) split(i, c[j]);
+    if (live) {
+        f.tile_offset[i] = base[0] + excl[0];
+        f.tile_cursor[i] = 0u;
+        f.tile_order[base[3u + b] + rank] = i;
+        if (ns) {     // tile_split is written (and read, k_raster_tile) for these tiles only.  The caps hold whenever the bin list itself does not overflow.
+            const uint32_t eb = base[1] + excl[1], sb = base[2] + excl[2];
+            const bool fits = eb + ns - 1u <= f.raster_extra_cap && sb + ns <= f.raster_slot_cap && ns <= 4095u;
+            for (uint32_t s = 1; s < ns; s++) if (eb + s - 1u < f.raster_extra_cap) f.tile_order[n_tiles + eb + s - 1u] = fits ? (i | (s << 20)) : 0xFFFFFFFFu;
+            reinterpret_cast<uint2*>(f.tile_split)[i] = make_uint2(fits ? sb : 0xFFFFFFFFu, 0u);
         }
     }
     AWSM_STAMP_AT(f, 1, 4);
-    __syncthreads();
-    if (staged) for (uint32_t i = tid; i < n_tiles; i += kScanThreads) { f.tile_offset[i] = stage[scan_slot(i)]; f.tile_cursor[i] = 0u; }
-    if (tid == kScanThreads - 1u) {
-        const uint32_t total = incl1;
-        f.tile_offset[n_tiles] = total;
-        f.counters[1] = total;
-        if (total > f.bin_capacity) f.counters[2] = 1u;
-        f.counters[7] = min(n_extra, f.raster_extra_cap);
-        AWSM_STAMP_AT(f, 1, 5);
-        if (f.host_bin_status) {   // for frames nobody waits for: the host sizes the list of later frames from this (awsm_hip_geometry_pass)
-            __hip_atomic_store(f.host_bin_status, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(f.host_bin_status + 1, f.frame_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -827,7 +844,8 @@ extern "C" void awsm_launch_bin_big(const awsm::FrameDev* f, int fill, hipStream
     hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
-    hipLaunchKernelGGL(awsm::k_bin_scan, dim3(1), dim3(awsm::kScanThreads), 0, s, *f, f->tiles_x * f->tiles_y);
+    const uint32_t n_tiles = f->tiles_x * f->tiles_y;
+    if (n_tiles) hipLaunchKernelGGL(awsm::k_bin_scan, dim3((n_tiles + awsm::kScanThreads - 1u) / awsm::kScanThreads), dim3(awsm::kScanThreads), 0, s, *f, n_tiles);
 }
 extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;
