@@ -173,3 +173,59 @@ def test_the_hip_path_meets_the_same_closed_forms_without_the_oracle():
         got = dev.read_opaque_f32()[c, c, :3].astype(np.float64)
         want = _cook_torrance(base, metallic, rough, (0, 0, 1), (0, 0, 1), np.asarray(l, dtype=np.float64), radiance)
         assert np.allclose(got, want, rtol=2e-4, atol=2e-6), (light["kind"], got, want)
+
+
+def test_brdf_lut_against_a_quadrature_of_the_split_sum_integrals():
+    """crates/renderer-core/src/brdf_lut/shader.wgsl:46-78 estimates A = E[(1 - Fc) G_vis], B = E[Fc G_vis] over GGX-importance-sampled half
+    vectors with 1,024 Hammersley points.  Here the same expectation as a midpoint rule over the unit square of the sampling variables
+    (no Hammersley sequence, f64, no f16 rounding): the two must agree to the estimator's error.  Texel row j holds v = 1 - (j + 0.5) / H
+    (the full-screen triangle's uv, shader.wgsl:4-12), column i holds n.v = (i + 0.5) / W."""
+    W = H = 32
+    lut = oracle_lib.brdf_lut(W, H).view(np.float16).astype(np.float64)
+    n = 384
+    x1 = (np.arange(n) + 0.5) / n
+    X, Y = np.meshgrid(x1, x1, indexing="ij")                      # xi.x -> phi, xi.y -> theta
+    worst = 0.0
+    for (i, j) in ((0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1), (W // 2, H // 2), (5, 20), (27, 9), (16, 2), (3, 29)):
+        nov = min(max((i + 0.5) / W, 1e-3), 1 - 1e-3)
+        rough = min(max(1.0 - (j + 0.5) / H, 1e-3), 1 - 1e-3)
+        alpha = rough * rough
+        v = np.array([math.sqrt(max(0.0, 1 - nov * nov)), 0.0, nov])
+        cos_t = np.sqrt((1 - Y) / (1 + (alpha * alpha - 1) * Y))
+        sin_t = np.sqrt(np.maximum(0.0, 1 - cos_t * cos_t))
+        phi = 2 * math.pi * X
+        h = np.stack([np.cos(phi) * sin_t, np.sin(phi) * sin_t, cos_t], axis=-1)
+        voh_signed = h @ v
+        l = 2 * voh_signed[..., None] * h - v
+        l = l / np.linalg.norm(l, axis=-1, keepdims=True)
+        nol, noh, voh = np.maximum(l[..., 2], 0), np.maximum(h[..., 2], 0), np.maximum(voh_signed, 0)
+        a_ = max(alpha, 0.001)
+        k = (a_ + 1) ** 2 / 8
+        g = (nov / (nov * (1 - k) + k)) * (nol / (nol * (1 - k) + k))
+        g_vis = np.where(nol > 0, g * voh / np.maximum(noh * nov, 1e-4), 0.0)
+        fc = (1 - voh) ** 5
+        A, B = float(((1 - fc) * g_vis).mean()), float((fc * g_vis).mean())
+        worst = max(worst, abs(lut[j, i, 0] - A), abs(lut[j, i, 1] - B))
+        assert abs(lut[j, i, 0] - A) < 0.02 and abs(lut[j, i, 1] - B) < 0.02, ((i, j), lut[j, i], (A, B))
+    assert worst < 0.02
+
+
+def test_bilinear_repeat_sampling_of_a_known_texture():
+    """texture_uvs.wgsl:144-187 at level 0 with a linear / repeat sampler: a 4x4 texture whose red channel is the column index and green the
+    row index, on a quad that maps uv = position.  At the pixel on the optical axis uv = (0.5, 0.5): x = u W - 0.5 = 1.5 -> texels 1 and 2
+    averaged -> base colour r = 1.5 / 255 * 17 (texel value = 17 * index), and the same for g.  Unlit material: the pixel is the texel."""
+    tex = np.zeros((1, 4, 4, 4), np.uint8)
+    for yy in range(4):
+        for xx in range(4):
+            tex[0, yy, xx] = (17 * xx, 17 * yy, 0, 255)
+    mat = MaterialDesc(kind="unlit", base_color_factor=(1.0, 1.0, 1.0, 1.0))
+    sc = _quad_scene(mat, [])
+    sc.textures, sc.samplers = [tex[0]], [dict(scenes.REPEAT_LINEAR)]
+    from awsm_renderer_amd.scene_desc import TextureRef
+    mat.base_color_tex = TextureRef(texture=0, sampler=0, uv_index=0)
+    prim = [p for nd in sc.nodes for p in nd.primitives][0]
+    prim.uvs = [((np.asarray(prim.positions)[:, :2] + 1.0) * 0.5).astype(F)]       # the quad spans [-1, 1]^2
+    fr = helpers.oracle_frame(helpers.build_model(sc), oracle_lib.brdf_lut(16, 16))
+    c = sc.width // 2
+    got = fr.rgba32f[c, c, :3].astype(np.float64)
+    assert np.allclose(got[:2], [1.5 * 17 / 255, 1.5 * 17 / 255], atol=2e-4), got
