@@ -255,7 +255,10 @@ int awsm_hip_opaque_pass(AwsmHipCtx* ctx, const AwsmOpaqueParams* params);
  * On a sharded context (row strip or bands) the pass covers, shades and blends this shard's rows only, but screen-space transmission
  * reads the WHOLE opaque image: gather the ranks' opaque rows first and hand the full [height][width] RGBA16F image in with
  * awsm_hip_bind_opaque_source (without it: AWSM_ERR_UNSUPPORTED).  The composite is addressed by absolute row (full-size target),
- * whatever layout the opaque output has. ---- */
+ * whatever layout the opaque output has.
+ * Overflow of the pass's own lists (its (triangle, tile) list, the fragment slots) is detected and replayed by awsm_hip_frame_end only: a
+ * pipelined loop that never calls frame_end must call it at least once after the transparent workload changes size (the lists then stay
+ * sized for it), or check AwsmFrameStats.bin_overflow_retries from time to time — an overflowed enqueue-only frame drops fragments. ---- */
 int awsm_hip_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
 /* the full-frame opaque image the transparent pass of a sharded context blits from and refracts through (device memory, width*height*8
  * bytes, kept by reference until replaced; NULL = this context's own opaque output, which is complete only when unsharded) */
