@@ -329,6 +329,12 @@ def main():
 
     first = r.render(sync=True)            # uploads everything, sizes the bin list
     r.host.set_render_timings(bool(os.environ.get("AWSM_BENCH_STAGE_TIMERS")))   # the timed loop does not read per-stage times: no event bubbles between the kernels
+    # No Python garbage collection inside the warm-up and the timed loop: a generation-2 pass over the scene's objects takes ~35 ms, and
+    # whether one lands in a 25-70 ms loop depends on the allocation count of everything before it (seen: configs[1] at 3,100 or 8,300
+    # frames/s depending on an unrelated command-line flag).  The loop itself allocates a few tuples per step.
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -337,6 +343,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
