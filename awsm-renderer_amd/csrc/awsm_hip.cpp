@@ -42,6 +42,9 @@ void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n,
 
 namespace {
 
+// Frame slots of the overlap mode: frame i's opaque pass reads slot i % kSlots while the geometry pass of frame i + 1 fills the next.  (Three
+// slots — the geometry pass of frame i + 2 no longer waiting for frame i's opaque pass — measured no different, and cost a fifth stream.)
+constexpr int kSlots = 2;
 constexpr int kLeanWgsPerCu = 0;   // measured: the one-wavefront-per-strip grid wins once the geometry kernels fit beside it
 struct DevBuf {
     void* ptr = nullptr;
@@ -67,6 +70,7 @@ struct FrameBufs {
     std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
     void* draws_uploaded_ptr = nullptr;
     bool draws_uploaded_valid = false;
+    uint64_t draws_version = 0;            // bumped whenever draws_dev receives a new list
 };
 
 }  // namespace
@@ -94,10 +98,10 @@ struct AwsmHipCtx {
     uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
     DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
-    DevBuf out16, out32;
+    DevBuf out16[kSlots], out32[kSlots];        // the opaque image (+ f32 parity tap) per frame slot: with two images two frames' opaque passes need no order between them
     DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
     uint32_t lean_grid = 0;           // persistent k_shade_lean grid (workgroups), 0 = one workgroup per block
-    DevBuf shade_todo[2];             // per frame slot (the per-draw resolve of frame i + 1 resets one while frame i's opaque pass appends to the other); [0] count + entries: the 16x4-pixel groups the lean opaque kernel leaves to the general one
+    DevBuf shade_todo[kSlots];             // per frame slot (the per-draw resolve of frame i + 1 resets one while frame i's opaque pass appends to the other); [0] count + entries: the 16x4-pixel groups the lean opaque kernel leaves to the general one
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
 
@@ -105,19 +109,22 @@ struct AwsmHipCtx {
     // Frame overlap (AWSM_CFG_OVERLAP_FRAMES): the opaque pass of frame i runs on shade_stream while the caller's stream
     // already runs the geometry pass of frame i+1 into the other slot.
     bool overlap = false;
-    hipStream_t shade_streams[2] = {};     // one per frame slot: the waits in front of frame i + 1's opaque pass are consumed while frame i's still runs (enqueue_opaque)
-    bool shade_recorded[2] = {false, false};   // ev_shade_done[slot] has been recorded since the last full synchronisation
-    hipStream_t prep_stream = nullptr;     // the per-draw resolve of frame i + 1, beside frame i's opaque pass (enqueue_opaque)
-    hipEvent_t ev_geom_done[2] = {}, ev_shade_done[2] = {}, ev_uploads[2] = {}, ev_resolved[2] = {};
-    uint64_t write_seq = 0, geom_write_seq[2] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
-    bool shade_pending[2] = {false, false};
-    FrameBufs fb[2];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
-    FrameBufs tr[2];             // the same for the transparent pass's own draws (vertices, setup records, bins); no visibility buffer
+    hipStream_t shade_streams[kSlots] = {};     // one per frame slot: the waits in front of frame i + 1's opaque pass are consumed while frame i's still runs (enqueue_opaque)
+    bool shade_recorded[kSlots] = {};
+    bool uploads_recorded[kSlots] = {};  // ev_uploads[slot] was recorded by this frame's geometry pass
+    // What a slot's per-draw records (k_resolve_draws: draw_shade / draw_mat / tex_slots / draw_lean / lights_pre) were computed from: they are
+    // recomputed only when that changed — a frame that moved nothing but the camera reuses them (no kernel, no event).
+    struct ResolveKey { uint64_t write_seq, draws_version; const void* ptrs[5]; uint32_t n_draws, mipmap, has_opaque, lights_cap; } resolved[kSlots] = {};   // ev_shade_done[slot] has been recorded since the last full synchronisation
+    hipEvent_t ev_geom_done[kSlots] = {}, ev_shade_done[kSlots] = {}, ev_uploads[kSlots] = {} ;
+    uint64_t write_seq = 0, geom_write_seq[kSlots] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
+    bool shade_pending[kSlots] = {};
+    FrameBufs fb[kSlots];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
+    FrameBufs tr[kSlots];             // the same for the transparent pass's own draws (vertices, setup records, bins); no visibility buffer
     std::vector<DrawDev> tr_draws_host;
     uint32_t tr_total_tris = 0, tr_n_blocks = 0;
     bool transparent_done = false;
     DevBuf comp16, comp32;       // composite image (after the transparent pass) + parity tap
-    DevBuf lights_pre[2];        // per frame slot: per-light constants (k_resolve_draws), sized with the lights buffer
+    DevBuf lights_pre[kSlots];        // per frame slot: per-light constants (k_resolve_draws), sized with the lights buffer
     void* bound_comp = nullptr;
     size_t bound_comp_bytes = 0;
     const void* msaa_halo = nullptr;       // awsm_hip_msaa_halo_bind
@@ -136,8 +143,8 @@ struct AwsmHipCtx {
     // pinned staging ring for buffer_write / small uploads
     uint8_t* stage = nullptr;
     size_t stage_cap = 0, stage_head = 0;
-    uint32_t* counters_host = nullptr;   // pinned, 16 u32: [0..8) geometry pass, [8..16) transparent pass; then 2 x {entries needed, frame serial} (k_bin_scan)
-    uint32_t frame_serial = 0, status_seen[2] = {0, 0};
+    uint32_t* counters_host = nullptr;   // pinned, 16 u32: [0..8) geometry pass, [8..16) transparent pass; then kSlots x {entries needed, frame serial} (k_bin_scan)
+    uint32_t frame_serial = 0, status_seen[kSlots] = {};
     uint32_t dropped_frames = 0;         // enqueue-only frames that overflowed their bin list
     uint32_t out_first_row = 0;          // awsm_hip_bind_output_rows
     bool out_rows_mode = false;
@@ -150,9 +157,11 @@ namespace {
 
 inline FrameBufs& FB(AwsmHipCtx* c) { return c->fb[c->slot]; }
 inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade_streams[c->slot] : c->stream; }
+inline int n_slots(const AwsmHipCtx* c) { return c->overlap ? kSlots : 1; }
+inline int prev_slot(const AwsmHipCtx* c) { return (c->slot + kSlots - 1) % kSlots; }
 inline hipError_t sync_shade_streams(AwsmHipCtx* c) {
     for (hipStream_t s : c->shade_streams) if (s) { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e; }
-    c->shade_recorded[0] = c->shade_recorded[1] = false;
+    for (bool& b : c->shade_recorded) b = false;
     return hipSuccess;
 }
 
@@ -246,14 +255,14 @@ void shard(const AwsmHipCtx* c, uint32_t* y0, uint32_t* y1) {
 int scene_write_barrier(AwsmHipCtx* c, bool is_write = true) {
     if (is_write) c->write_seq++;
     if (!c->overlap) return AWSM_OK;
-    for (int s = 0; s < 2; s++)
+    for (int s = 0; s < kSlots; s++)
         if (c->shade_pending[s]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[s], 0)); c->shade_pending[s] = false; }
     return AWSM_OK;
 }
 int sync_all(AwsmHipCtx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, sync_shade_streams(c));
-    c->shade_pending[0] = c->shade_pending[1] = false;
+    for (bool& b : c->shade_pending) b = false;
     return AWSM_OK;
 }
 
@@ -334,8 +343,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
     f->msaa_halo = (const unsigned long long*)c->msaa_halo;
     f->halo_bands = c->band_n > 1 ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
-    f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16.ptr);   // kernels address by absolute row
-    f->out_rgba32f = (float*)c->out32.ptr;
+    f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16[c->slot].ptr);   // kernels address by absolute row
+    f->out_rgba32f = (float*)c->out32[c->slot].ptr;
     f->lights_pre = (float4*)c->lights_pre[c->slot].ptr;
     f->lights_cap = (uint32_t)(c->lights_pre[c->slot].size / 32);
 }
@@ -345,6 +354,19 @@ int record(AwsmHipCtx* c, int which, hipStream_t s = nullptr) {
     HIPCHK(c, hipEventRecord(c->ev[which], s ? s : c->stream));
     c->ev_valid[which] = true;
     return AWSM_OK;
+}
+
+AwsmHipCtx::ResolveKey resolve_key(AwsmHipCtx* c, const FrameDev& f) {
+    AwsmHipCtx::ResolveKey k;
+    memset(&k, 0, sizeof k);      // padding too: the keys are compared bytewise
+    k.write_seq = c->write_seq + (c->scene_dirty ? 1u : 0u); k.draws_version = FB(c).draws_version;
+    k.ptrs[0] = f.draw_shade; k.ptrs[1] = f.draw_mat; k.ptrs[2] = f.tex_slots; k.ptrs[3] = f.draw_lean; k.ptrs[4] = f.lights_pre;
+    k.n_draws = f.n_draws; k.mipmap = c->last_opaque.mipmap; k.has_opaque = c->last_opaque.has_opaque; k.lights_cap = f.lights_cap;
+    return k;
+}
+bool resolve_stale(AwsmHipCtx* c, const FrameDev& f) {
+    const AwsmHipCtx::ResolveKey k = resolve_key(c, f);
+    return memcmp(&k, &c->resolved[c->slot], sizeof k) != 0;
 }
 
 int enqueue_geometry(AwsmHipCtx* c) {
@@ -364,7 +386,10 @@ int enqueue_geometry(AwsmHipCtx* c) {
             else HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, cam_bytes, hipMemcpyDeviceToDevice, c->stream));
         }
         // everything the per-draw resolve of this frame reads (draw list, scene buffers) is on the stream by now
-        HIPCHK(c, hipEventRecord(c->ev_uploads[c->slot], c->stream));
+        // everything the per-draw resolve of this frame reads (draw list, scene buffers) is on the stream by now — an event only when a resolve
+        // will run (resolve_key): a record packet costs the caller's stream ~19 us between the camera upload and the transform kernel
+        c->uploads_recorded[c->slot] = false;
+        if (resolve_stale(c, f)) { HIPCHK(c, hipEventRecord(c->ev_uploads[c->slot], c->stream)); c->uploads_recorded[c->slot] = true; }
         c->geom_write_seq[c->slot] = c->write_seq;
     }
     const bool has_geometry = c->total_tris && n_tiles;
@@ -406,27 +431,30 @@ int enqueue_opaque(AwsmHipCtx* c) {
     if (rc) return rc;
     hipStream_t ss = shade_stream_of(c);
     // The per-draw resolve only needs the uploads, not the geometry pass, and nothing of the previous frame: its outputs are per frame
-    // slot.  In overlap mode it runs on a stream of its own, beside the previous frame's opaque pass, and the shade stream waits for its
-    // event: on the shade stream it sat between two frames' shading kernels (todo -> 14 us launch gap -> resolve 30 us -> gap -> lean:
-    // the shade stream is the critical path of an overlapped frame, tools/frame_timeline.sh); on the caller's stream it would lengthen
-    // the geometry chain, the other critical path.  A scene write between the two passes falls back to the late order.
-    const bool want_resolve = f.sy1 > f.sy0 && f.has_opaque;
+    // slot.  In overlap mode it goes first onto this slot's shade stream — idle since the frame before last — and so runs beside the
+    // previous frame's opaque pass (on the single shade stream of round 1 it sat between two frames' shading kernels: todo -> 14 us gap ->
+    // resolve 30 us -> gap -> lean; on the caller's stream it would lengthen the geometry chain).  No stream of its own: the process has
+    // four hardware queues (GPU_MAX_HW_QUEUES), and a fifth stream shares one of them with another stream — seen as 25-30 us of idle GPU
+    // at every frame boundary.  A scene write between the two passes falls back to the late order.
+    // (with stage timers on it always runs: EV_SHADE_BEGIN must sit behind a kernel of this stream, not right behind the cross-stream wait — see below)
+    const bool want_resolve = f.sy1 > f.sy0 && f.has_opaque && (resolve_stale(c, f) || c->stage_timers);
+    if (want_resolve) c->resolved[c->slot] = resolve_key(c, f);
     // (With stage timers on the late order stays: an event recorded right behind a cross-stream wait is stamped when the wait is
     // consumed, not when it is satisfied, and ms_shade would include the tail of the raster kernel — seen: 0.40 instead of 0.36 ms.)
-    const bool early = c->overlap && !c->stage_timers && want_resolve && c->geometry_done && c->geom_write_seq[c->slot] == c->write_seq;
-    if (early) {
-        HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_uploads[c->slot], 0));
-        awsm_launch_resolve_draws(c->scene_dev, &f, c->prep_stream);
-        HIPCHK(c, hipEventRecord(c->ev_resolved[c->slot], c->prep_stream));
-        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_resolved[c->slot], 0));
+    const bool early = c->uploads_recorded[c->slot] && c->overlap && !c->stage_timers && want_resolve && c->geometry_done && c->geom_write_seq[c->slot] == c->write_seq;
+    if (early) {      // on this slot's shade stream, ahead of the wait for the geometry pass
+        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_uploads[c->slot], 0));
+        awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     }
     if (c->overlap) {   // the shade stream picks up where the caller's stream is now (geometry pass + uploads of this frame)
         HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
-        // ... and behind the previous frame's passes on the other slot's shade stream (they share the output images, the MSAA scratch and
-        // the fragment lists).  Last of the three waits on purpose: the first two are consumed while the previous frame still shades, so
-        // one barrier packet stands between its last kernel and this frame's first instead of three (18 -> 6 us per frame, tools/frame_timeline.sh).
-        if (c->shade_recorded[c->slot ^ 1]) HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade_done[c->slot ^ 1], 0));
+        // ... and, only where two frames' opaque passes share something, behind the previous frame's passes on the other slot's shade
+        // stream: the MSAA scratch (per context), or an output image the caller bound (it may be the same one).  The library's own
+        // images, the per-draw records and the todo lists are per slot, so single-sampled frames into the library's images need no order
+        // at all — frame i + 1's opaque pass starts when its raster is done, whatever frame i's k_shade_todo is doing.  (Last of the
+        // waits on purpose: the first two are consumed while the previous frame still shades.)
+        if ((c->msaa != 0 || c->bound_out) && c->shade_recorded[prev_slot(c)]) HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade_done[prev_slot(c)], 0));
     }
     if (want_resolve && !early) awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     if ((rc = record(c, EV_SHADE_BEGIN, ss))) return rc;      // after the resolve: ms_shade is the shading kernels alone
@@ -485,6 +513,8 @@ int enqueue_transparent(AwsmHipCtx* c) {
     int rc = sync_scene(c);
     if (rc) return rc;
     hipStream_t ss = shade_stream_of(c);          // in order after the opaque pass
+    // the composite image and the fragment lists' bookkeeping are per context: behind the previous frame's passes on the other slot's stream
+    if (c->overlap && c->shade_recorded[prev_slot(c)]) HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade_done[prev_slot(c)], 0));
     if ((rc = record(c, EV_FWD_BEGIN, ss))) return rc;
     const bool has_geometry = f.total_tris && n_tiles;
     if (!has_geometry) {
@@ -606,7 +636,7 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
     const bool same_draws = b.draws_uploaded_valid && b.draws_uploaded_ptr == b.draws_dev.ptr && b.draws_uploaded.size() == draws_host.size() &&
                             (draws_host.empty() || memcmp(b.draws_uploaded.data(), draws_host.data(), draws_host.size() * sizeof(DrawDev)) == 0);
     if (!draws_host.empty() && !same_draws) {
-        b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true;
+        b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true; b.draws_version++;
         const size_t bytes = draws_host.size() * sizeof(DrawDev);
         if (bytes <= (1u << 20)) { if ((rc = upload_small(c, b.draws_dev.ptr, draws_host.data(), bytes))) return rc; }
         else { HIPCHK(c, hipMemcpyAsync(b.draws_dev.ptr, draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
@@ -659,7 +689,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         const int per_cu = e ? atoi(e) : (c->overlap ? kLeanWgsPerCu : 0);
         c->lean_grid = per_cu > 0 ? (uint32_t)(per_cu * prop.multiProcessorCount) & ~7u : 0u;
     }
-    for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
+    for (int s = 0; s < n_slots(c); s++) {
         if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13]
         c->fb[s].counters.size = 16 * sizeof(uint32_t);
         if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
@@ -667,17 +697,20 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     }
 
     if (c->overlap) {
-        if (hipStreamCreateWithFlags(&c->shade_streams[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->shade_streams[1], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
-        for (int s = 0; s < 2; s++) {
-            if (hipEventCreateWithFlags(&c->ev_geom_done[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_uploads[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_resolved[s], hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        for (int s = 0; s < kSlots; s++) {
+            if (hipStreamCreateWithFlags(&c->shade_streams[s], hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+            // These events order streams of this device among themselves.  Recorded with the default (system-scope) release they write the
+            // L2s back and invalidate them each time — behind a raster or shading kernel that is 66 MB of dirty lines: 8-28 us per record on
+            // the path between two frames (tools/frame_timeline.sh) — so: device-scope release.
+            const unsigned ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
+            if (hipEventCreateWithFlags(&c->ev_geom_done[s], ev_flags) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], ev_flags) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_uploads[s], ev_flags) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             if (hipMalloc(&c->fb[s].camera.ptr, 512) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
             c->fb[s].camera.size = 512;
         }
     }
-    if (hipHostMalloc((void**)&c->counters_host, 20 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-    memset(c->counters_host, 0, 20 * sizeof(uint32_t));
+    if (hipHostMalloc((void**)&c->counters_host, (16 + 2 * kSlots) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+    memset(c->counters_host, 0, (16 + 2 * kSlots) * sizeof(uint32_t));
     memset(&c->scene, 0, sizeof c->scene);
     // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
     c->scene.skybox_rgba[3] = 1.0f;
@@ -691,19 +724,17 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)sync_shade_streams(c);
-    if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); fr(c->shade_todo[0]); fr(c->shade_todo[1]); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); fr(c->out16); fr(c->out32); fr(c->comp16); fr(c->comp32); fr(c->lights_pre[0]); fr(c->lights_pre[1]);
-    for (int k = 0; k < 4; k++) {
-        FrameBufs& b = k < 2 ? c->fb[k] : c->tr[k - 2];
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
+    for (int k = 0; k < 2 * kSlots; k++) {
+        FrameBufs& b = k < kSlots ? c->fb[k] : c->tr[k - kSlots];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     for (hipStream_t st : c->shade_streams) if (st) (void)hipStreamDestroy(st);
-    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
-    for (int i = 0; i < 2; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); if (c->ev_resolved[i]) (void)hipEventDestroy(c->ev_resolved[i]); }
+    for (int i = 0; i < kSlots; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); }
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
@@ -735,7 +766,7 @@ int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
     if (rc) return rc;
     if (bytes) c->bufs[which].size = bytes;
-    if (which == AWSM_BUF_LIGHTS) for (int sl = 0; sl < (c->overlap ? 2 : 1); sl++) if ((rc = dev_realloc(c, c->lights_pre[sl], std::max<size_t>(bytes / 64, 1) * 32, true))) return rc;   // 2 x float4 per 64-byte light
+    if (which == AWSM_BUF_LIGHTS) for (int sl = 0; sl < n_slots(c); sl++) if ((rc = dev_realloc(c, c->lights_pre[sl], std::max<size_t>(bytes / 64, 1) * 32, true))) return rc;   // 2 x float4 per 64-byte light
     c->scene_dirty = true;
     return AWSM_OK;
 }
@@ -765,15 +796,17 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     const size_t px = (size_t)width * height, samples = msaa == 4 ? 4 : 1;
     int rc;
     if ((rc = sync_all(c))) return rc;
-    for (int s = 0; s < (c->overlap ? 2 : 1); s++) {
+    for (int s = 0; s < n_slots(c); s++) {
         if ((rc = dev_realloc(c, c->fb[s].vis, px * samples * 8, false))) return rc;
         HIPCHK(c, hipMemsetAsync(c->fb[s].vis.ptr, 0xFF, px * samples * 8, c->stream));
     }
     if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
     c->msaa = msaa;
-    for (int sl = 0; sl < (c->overlap ? 2 : 1); sl++) if ((rc = dev_realloc(c, c->shade_todo[sl], ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4 + 1024) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
-    if ((rc = dev_realloc(c, c->out16, px * 8, true))) return rc;
-    if (c->flags & AWSM_CFG_PARITY_TAP) { if ((rc = dev_realloc(c, c->out32, px * 16, true))) return rc; }
+    for (int sl = 0; sl < n_slots(c); sl++) if ((rc = dev_realloc(c, c->shade_todo[sl], ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4 + 1024) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
+    for (int sl = 0; sl < n_slots(c); sl++) {
+        if ((rc = dev_realloc(c, c->out16[sl], px * 8, true))) return rc;
+        if ((c->flags & AWSM_CFG_PARITY_TAP) && (rc = dev_realloc(c, c->out32[sl], px * 16, true))) return rc;
+    }
     c->width = width; c->height = height;
     c->y0 = c->y1 = 0;
     c->band_n = 1; c->band_r = 0; c->band_compact = 0;
@@ -982,10 +1015,14 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, new_draws, &tris, &blocks);
     if (rc) return rc;
     if (c->overlap) {
-        c->slot ^= 1;                        // the previous frame's opaque pass may still be reading the other slot
-        // ... and the opaque pass of two frames ago may still be reading THIS slot (its draw list, per-draw records): order everything
+        c->slot = (c->slot + 1) % kSlots;    // the opaque passes of the previous frames may still be reading the other slots
+        // ... and the opaque pass of kSlots frames ago may still be reading THIS slot (its draw list, per-draw records): order everything
         // this call puts on the caller's stream — the draw-list upload included — after it
-        if (c->shade_pending[c->slot]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0)); c->shade_pending[c->slot] = false; }
+        // (asked on the host first: kSlots frames back it has usually finished, and a barrier packet on the caller's stream costs the frame 6-9 us)
+        if (c->shade_pending[c->slot]) {
+            if (hipEventQuery(c->ev_shade_done[c->slot]) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0));
+            c->shade_pending[c->slot] = false;
+        }
     }
     c->draws_api.assign(draws, draws + n);
     c->draws_host.swap(new_draws);
@@ -994,7 +1031,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
         // no wait).  A frame rendered without frame_end cannot be replayed: size the list ahead of the need instead, and count the
         // frames that did overflow (AwsmFrameStats.frames_with_dropped_bin_entries).
         uint32_t need = 0;
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < kSlots; s++) {
             const volatile uint32_t* st = c->counters_host + 16 + 2 * s;
             const uint32_t entries = st[0], serial = st[1];
             if (serial == c->status_seen[s]) continue;
@@ -1002,7 +1039,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
             if (entries > c->fb[s].bin_capacity && c->fb[s].bin_list.ptr) c->dropped_frames++;
             need = std::max(need, entries);
         }
-        for (int s = 0; s < (c->overlap ? 2 : 1); s++)
+        for (int s = 0; s < n_slots(c); s++)
             if (need && (uint64_t)need * 4 > (uint64_t)c->fb[s].bin_capacity * 3 && c->fb[s].bin_list.ptr && !(c->flags & AWSM_CFG_SMALL_BIN_LIST)) {
                 if ((rc = ensure_bin_capacity_of(c, c->fb[s], need + need / 2 + 1024))) return rc;
                 if ((rc = reserve_raster_items(c, c->fb[s], false))) return rc;
@@ -1099,7 +1136,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         }
         HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); c->shade_pending[0] = c->shade_pending[1] = false; }
+        if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
         if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
@@ -1156,7 +1193,7 @@ int awsm_hip_bind_output_rows(AwsmHipCtx* c, void* device_ptr, size_t bytes, uin
     return AWSM_OK;
 }
 
-void* awsm_hip_output_device_ptr(AwsmHipCtx* c) { return c ? (c->bound_out ? c->bound_out : c->out16.ptr) : nullptr; }
+void* awsm_hip_output_device_ptr(AwsmHipCtx* c) { return c ? (c->bound_out ? c->bound_out : c->out16[c->slot].ptr) : nullptr; }
 
 int awsm_hip_read_visibility(AwsmHipCtx* c, uint64_t* keys_out) {
     if (!c || !keys_out) return AWSM_ERR_INVALID_ARGUMENT;
@@ -1250,10 +1287,10 @@ int awsm_hip_read_opaque(AwsmHipCtx* c, uint16_t* out) {
 
 int awsm_hip_read_opaque_f32(AwsmHipCtx* c, float* out) {
     if (!c || !out) return AWSM_ERR_INVALID_ARGUMENT;
-    if (!c->out32.ptr) return fail(c, AWSM_ERR_NOT_READY, "read_opaque_f32 needs AWSM_CFG_PARITY_TAP and a resize");
+    if (!c->out32[c->slot].ptr) return fail(c, AWSM_ERR_NOT_READY, "read_opaque_f32 needs AWSM_CFG_PARITY_TAP and a resize");
     HIPCHK(c, hipSetDevice(c->device));
     { int rcs = sync_all(c); if (rcs) return rcs; }
-    HIPCHK(c, hipMemcpy(out, c->out32.ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->out32[c->slot].ptr, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
     return AWSM_OK;
 }
 

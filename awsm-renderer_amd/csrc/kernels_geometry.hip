@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
         for (uint32_t i = g0; i < n_tiles; i += gsz) f.tile_count[i] = 0u;
         if (g0 < 8u) f.counters[g0] = 0u;
         if (g0 == 12u || g0 == 13u) f.counters[g0] = 0u;      // k_bin_scan's arrival counter and ready flag
+        // the opaque pass's lean route (same slot, after this frame's raster): its list for the general kernel and the persistent grid's strip
+        // counters start empty — here and not in k_resolve_draws, which is skipped when nothing but the camera changed
+        if (!FWD && f.shade_todo && g0 == 14u) f.shade_todo[0] = 0u;
+        if (!FWD && f.lean_next && g0 >= 64u && g0 < 128u) f.lean_next[(g0 - 64u) * 16u] = 0u;
         if (!FWD && g0 < f.camera_snap_words) f.camera_snap[g0] = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_CAMERA])[g0];   // overlap mode: the frame's camera
     }
     uint32_t lo = 0, hi = f.n_draws;
@@ -115,36 +119,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
         const float* jm = reinterpret_cast<const float*>(sc->buf[AWSM_BUF_SKIN_MATRICES]);
         const uint32_t base = gm.skin_index_weights_off / 4u + vertex_index * gm.skin_sets * 8u;
         const uint32_t moff = gm.skin_matrices_off / 64u;
-        float sk[16];
-        for (uint32_t set = 0; set < gm.skin_sets; set++) {
-            const float4* p = reinterpret_cast<const float4*>(iw + base + set * 8u);   // 32-B records, 16-B aligned
-            const float4 q0 = p[0], q1 = p[1];
-            const uint32_t j0 = __float_as_uint(q0.x), j1 = __float_as_uint(q0.z), j2 = __float_as_uint(q1.x), j3 = __float_as_uint(q1.z);
-            const float w0 = q0.y, w1 = q0.w, w2 = q1.y, w3 = q1.w;
-            const float4* m0 = reinterpret_cast<const float4*>(jm + (size_t)(j0 + moff) * 16u);
-            const float4* m1 = reinterpret_cast<const float4*>(jm + (size_t)(j1 + moff) * 16u);
-            const float4* m2 = reinterpret_cast<const float4*>(jm + (size_t)(j2 + moff) * 16u);
-            const float4* m3 = reinterpret_cast<const float4*>(jm + (size_t)(j3 + moff) * 16u);
+        // Column by column: column c of the blended matrix (summed over the sets in order, as skin.wgsl does) is used at once for position,
+        // normal and tangent — ((c0 x + c1 y) + c2 z) + c3 w accumulates in that very order — instead of building all sixteen elements first:
+        // under the kernel's 80-VGPR cap that spilled to scratch, and a kernel with a scratch segment costs ~20 us more to dispatch.
+        f3 op = {0.0f, 0.0f, 0.0f}, on = op, ot = op;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float4 a = m0[c], bq = m1[c], cq = m2[c], dq = m3[c];
-                float e0 = ((w0 * a.x + w1 * bq.x) + w2 * cq.x) + w3 * dq.x;
-                float e1 = ((w0 * a.y + w1 * bq.y) + w2 * cq.y) + w3 * dq.y;
-                float e2 = ((w0 * a.z + w1 * bq.z) + w2 * cq.z) + w3 * dq.z;
-                float e3 = ((w0 * a.w + w1 * bq.w) + w2 * cq.w) + w3 * dq.w;
-                if (set == 0) { sk[c * 4 + 0] = e0; sk[c * 4 + 1] = e1; sk[c * 4 + 2] = e2; sk[c * 4 + 3] = e3; }
-                else { sk[c * 4 + 0] += e0; sk[c * 4 + 1] += e1; sk[c * 4 + 2] += e2; sk[c * 4 + 3] += e3; }
+        for (int c = 0; c < 4; c++) {
+            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+            for (uint32_t set = 0; set < gm.skin_sets; set++) {
+                const float4* p = reinterpret_cast<const float4*>(iw + base + set * 8u);   // 32-B records, 16-B aligned
+                const float4 q0 = p[0], q1 = p[1];
+                const uint32_t j0 = __float_as_uint(q0.x), j1 = __float_as_uint(q0.z), j2 = __float_as_uint(q1.x), j3 = __float_as_uint(q1.z);
+                const float w0 = q0.y, w1 = q0.w, w2 = q1.y, w3 = q1.w;
+                const float4 a = reinterpret_cast<const float4*>(jm + (size_t)(j0 + moff) * 16u)[c], bq = reinterpret_cast<const float4*>(jm + (size_t)(j1 + moff) * 16u)[c];
+                const float4 cq = reinterpret_cast<const float4*>(jm + (size_t)(j2 + moff) * 16u)[c], dq = reinterpret_cast<const float4*>(jm + (size_t)(j3 + moff) * 16u)[c];
+                const float s0 = ((w0 * a.x + w1 * bq.x) + w2 * cq.x) + w3 * dq.x;
+                const float s1 = ((w0 * a.y + w1 * bq.y) + w2 * cq.y) + w3 * dq.y;
+                const float s2 = ((w0 * a.z + w1 * bq.z) + w2 * cq.z) + w3 * dq.z;
+                if (set == 0) { e0 = s0; e1 = s1; e2 = s2; } else { e0 += s0; e1 += s1; e2 += s2; }
+            }
+            const float px = c == 0 ? pos.x : (c == 1 ? pos.y : (c == 2 ? pos.z : 1.0f));
+            if (c == 0) op = {e0 * px, e1 * px, e2 * px}; else op = {op.x + e0 * px, op.y + e1 * px, op.z + e2 * px};
+            if (c < 3) {      // skin.wgsl:150-156: normal and tangent through the raw upper 3x3, no inverse-transpose
+                const float nx = c == 0 ? normal.x : (c == 1 ? normal.y : normal.z), tx = c == 0 ? tangent.x : (c == 1 ? tangent.y : tangent.z);
+                if (c == 0) { on = {e0 * nx, e1 * nx, e2 * nx}; ot = {e0 * tx, e1 * tx, e2 * tx}; }
+                else { on = {on.x + e0 * nx, on.y + e1 * nx, on.z + e2 * nx}; ot = {ot.x + e0 * tx, ot.y + e1 * tx, ot.z + e2 * tx}; }
             }
         }
-        m4 skin;
-#pragma unroll
-        for (int c = 0; c < 4; c++) skin.c[c] = {sk[c * 4], sk[c * 4 + 1], sk[c * 4 + 2], sk[c * 4 + 3]};
-        const f4 p = mul(skin, {pos.x, pos.y, pos.z, 1.0f});
-        pos = {p.x, p.y, p.z};
-        const m3 nm = upper3(skin);        // skin.wgsl:150-156: raw 3x3, no inverse-transpose
-        normal = mul(nm, normal);
-        const f3 t = mul(nm, {tangent.x, tangent.y, tangent.z});
-        tangent = {t.x, t.y, t.z, tangent.w};
+        pos = op; normal = on;
+        tangent = {ot.x, ot.y, ot.z, tangent.w};
     }
 
     m4 model = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_TRANSFORMS] + (size_t)(gm.transform_off / 64u) * 64u));

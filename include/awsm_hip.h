@@ -286,6 +286,8 @@ int awsm_hip_bind_output(AwsmHipCtx* ctx, void* device_ptr, size_t bytes);
 /* The same for a row-strip shard (awsm_hip_set_shard_rows): device_ptr is where frame row `first_row` goes and `bytes` covers the rows from
  * there on (width*8 each); the shard's rows must lie inside.  Lets a rank hand in its [rows, width] strip of an all-gather buffer. */
 int awsm_hip_bind_output_rows(AwsmHipCtx* ctx, void* device_ptr, size_t bytes, uint32_t first_row);
+/* the image the last submitted frame's opaque pass writes (the bound one, else the library's; with AWSM_CFG_OVERLAP_FRAMES the library keeps
+ * one image per frame slot, so the pointer alternates from frame to frame) */
 void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
 
 /* ---- readback for parity (new).  keys: width*height u64 (x4 with MSAA: the samples of a pixel are adjacent) =
