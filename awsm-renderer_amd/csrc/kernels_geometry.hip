@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
         const int e = (int)tid + i * 256;
         const int p = e / S, s = e % S;
         const int px = tpx + (p & (kTile - 1)), py = tpy + (p >> kTileShift);
-        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) f.vis[((size_t)py * f.width + px) * S + s] = keys[e];
+        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) __builtin_nontemporal_store(keys[e], &f.vis[((size_t)py * f.width + px) * S + s]);      // written once, read by the next kernel
     }
     AWSM_STAMP_AT(f, 3, 4);
 }

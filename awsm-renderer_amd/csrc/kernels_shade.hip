@@ -722,7 +722,7 @@ AWSM_DI f3 apply_lighting(const DevScene* sc, const float4* __restrict__ lights_
 
 AWSM_DI void store_pixel(const FrameDev& f, size_t p, f4 c) {
     ushort4 h = make_ushort4(f16_bits(c.x), f16_bits(c.y), f16_bits(c.z), f16_bits(c.w));
-    reinterpret_cast<ushort4*>(f.out_rgba16f)[p] = h;
+    __builtin_nontemporal_store(*reinterpret_cast<unsigned long long*>(&h), reinterpret_cast<unsigned long long*>(f.out_rgba16f) + p);      // the image is not read again by this pass
     if (f.out_rgba32f) reinterpret_cast<float4*>(f.out_rgba32f)[p] = make_float4(c.x, c.y, c.z, c.w);
 }
 
