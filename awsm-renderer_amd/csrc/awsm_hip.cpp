@@ -376,7 +376,7 @@ int enqueue_geometry(AwsmHipCtx* c) {
     int rc = sync_scene(c);
     if (rc) return rc;
     if (c->overlap) {
-        // this slot's buffers were last read by the opaque pass two frames ago
+        // this slot's buffers were last read by the opaque pass kSlots frames ago (already ordered by awsm_hip_geometry_pass; a replay comes here directly)
         if (c->shade_pending[c->slot]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0)); c->shade_pending[c->slot] = false; }
         // the camera the frame is shaded with = the camera it was submitted with
         // (copied by k_deform_transform when the frame has geometry: a 512-byte hipMemcpyAsync costs the stream 18 us of gap + copy)
@@ -385,7 +385,6 @@ int enqueue_geometry(AwsmHipCtx* c) {
             if (c->total_tris && n_tiles) { f.camera_snap = (uint32_t*)FB(c).camera.ptr; f.camera_snap_words = (uint32_t)(cam_bytes / 4); }
             else HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, cam_bytes, hipMemcpyDeviceToDevice, c->stream));
         }
-        // everything the per-draw resolve of this frame reads (draw list, scene buffers) is on the stream by now
         // everything the per-draw resolve of this frame reads (draw list, scene buffers) is on the stream by now — an event only when a resolve
         // will run (resolve_key): a record packet costs the caller's stream ~19 us between the camera upload and the transform kernel
         c->uploads_recorded[c->slot] = false;
