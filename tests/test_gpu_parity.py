@@ -581,6 +581,22 @@ def test_overlapped_frames_shade_what_was_submitted(oracle_lut):
         assert (a == q).all(), f"frame {i} without stage timers: {(a != q).sum()} values differ"
     assert not (plain[0] == plain[5]).all() and not (plain[2] == plain[3]).all()
 
+    # The same six frames into the library's own images (one per frame slot: nothing orders two frames' opaque passes then, and the per-draw
+    # records are reused while only the camera moves): after any number of frames read_opaque is the last one submitted.
+    r = Renderer(sc, lut_rgba16f=lut, overlap_frames=True)
+    r.host.set_render_timings(False)
+    dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
+    for i, eye in enumerate(eyes):
+        r.host.camera_update(look_at_rh(eye, (-0.2, 3.4, -18.0)), sc.proj, eye)
+        if i == 3:
+            m = sc.materials[0]
+            r.host.material_update(r.keys.material_keys[0], material_struct(type(m)(**{**m.__dict__, "base_color_factor": (0.2, 0.9, 0.3, 1.0)}), r.host, {}))
+        r.host.render(sync=False)
+        if i in (1, 4, 5):
+            got = dev.read_opaque()
+            assert (got == plain[i]).all(), f"own image, frame {i}: {(got != plain[i]).sum()} values differ"
+    r.close()
+
 
 def oracle_lib_rgba16f(lut):
     from oracle import oracle_lib
