@@ -32,6 +32,7 @@ void awsm_launch_raster(const FrameDev* f, hipStream_t s);
 void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
 int awsm_shade_is_lean(const FrameDev* f);
 int awsm_launch_shade_todo(const DevScene* sc, const FrameDev* f, hipStream_t s);
+void awsm_launch_gbuffer_dump(const FrameDev* f, float* out, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
 void awsm_launch_msaa_halo_export(const FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s);
@@ -1212,6 +1213,25 @@ extern "C" int awsm_hip_debug_read_stamps(AwsmHipCtx* c, unsigned long long* out
     return hipMemcpy(out, f.stamps, 4ull * 16384 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? AWSM_OK : AWSM_ERR_DEVICE;
 }
 #endif
+
+int awsm_hip_read_gbuffer(AwsmHipCtx* c, float* out6) {
+    if (!c || !out6) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->geometry_done) return fail(c, AWSM_ERR_NOT_READY, "read_gbuffer before geometry_pass");
+    if (c->msaa != 0 || c->band_n > 1) return fail(c, AWSM_ERR_UNSUPPORTED, "read_gbuffer: single-sampled, unsharded-by-bands frames only");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    FrameDev f;
+    fill_frame(c, &f);
+    const size_t bytes = (size_t)c->width * c->height * 6 * sizeof(float);
+    float* dev = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dev, bytes));
+    awsm_launch_gbuffer_dump(&f, dev, c->stream);
+    hipError_t e = hipMemcpyAsync(out6, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dev);
+    HIPCHK(c, e);
+    return AWSM_OK;
+}
 
 int awsm_hip_visibility_digest(AwsmHipCtx* c, uint64_t* out2) {
     if (!c || !out2) return AWSM_ERR_INVALID_ARGUMENT;

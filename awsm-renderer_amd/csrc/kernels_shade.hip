@@ -138,8 +138,15 @@ AWSM_DI TBN funpack_normal_tangent(f4 rgba) {  // math.wgsl:104-116
     const float theta = rgba.z * kTau - kPi;
     const float s = (rgba.w >= 0.5f) ? 1.0f : -1.0f;
     f3 tt, tb;
-    if (r.N.z < -0.9999999f) { tt = {0.0f, -1.0f, 0.0f}; tb = {-1.0f, 0.0f, 0.0f}; }
-    else {
+    if (r.N.z < -0.98f) {
+        // canonical_tb (math.wgsl:73-84) divides by 1 + N.z: towards N = (0, 0, -1) a one-ulp difference in the decoded normal moves the basis
+        // by 6e-8 / (1 + N.z) — percent of a radian in the last degrees — so there the normal and the basis are computed with the oracle's
+        // operations (IEEE division and square root, no contraction; decode_octahedral / canonical_tb of the STRICT section).  Found by
+        // rendering from random viewpoints (tests/diagnostics/viewpoint_survey.py): surfaces facing -z were off by up to 6e-2 in single pixels.
+        r.N = decode_octahedral({rgba.x, rgba.y});
+        const TB cb = canonical_tb(r.N);
+        tt = cb.t; tb = cb.b;
+    } else {
         const float a = rcp(1.0f + r.N.z), bb = (-r.N.x * r.N.y) * a;
         tt = {1.0f - (r.N.x * r.N.x) * a, bb, -r.N.x};
         tb = {bb, 1.0f - (r.N.y * r.N.y) * a, -r.N.y};
@@ -2176,6 +2183,16 @@ __global__ __launch_bounds__(256) void k_count_covered(const unsigned long long*
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
 }
 
+// Test aid (awsm_hip_read_gbuffer): the STRICT G-buffer texel of every single-sampled pixel, as the opaque pass reconstructs it.
+__global__ __launch_bounds__(256) void k_gbuffer_dump(FrameDev f, float* __restrict__ out) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= f.width * f.height) return;
+    float* o = out + (size_t)p * 6u;
+    const unsigned long long key = f.vis[p];
+    if (key == ~0ull) { for (int i = 0; i < 6; i++) o[i] = 0.0f; return; }
+    const GBufferTexel g = reconstruct_gbuffer<false>(f, key_rank(key), (int)(p % f.width), (int)(p / f.width));
+    o[0] = g.packed_nt.x; o[1] = g.packed_nt.y; o[2] = g.packed_nt.z; o[3] = g.packed_nt.w; o[4] = g.bx; o[5] = g.by;
+}
 // Position-dependent 128-bit digest of the visibility keys (tests: a re-rendered frame must reproduce every key; comparing two
 // digests on the device costs 16 bytes of read-back instead of 66 MB per 4K frame).  out[0] += key * (2 i + 1), out[1] ^= rotl(key, i).
 __global__ __launch_bounds__(256) void k_vis_digest(const unsigned long long* __restrict__ vis, size_t n, unsigned long long* __restrict__ out) {
@@ -2264,6 +2281,10 @@ extern "C" void awsm_launch_msaa_halo_export(const awsm::FrameDev* f, unsigned l
 }
 extern "C" void awsm_launch_count_covered(const awsm::FrameDev* f, hipStream_t s) {
     if (f->sy1 > f->sy0) hipLaunchKernelGGL(awsm::k_count_covered, dim3(1024), dim3(256), 0, s, f->vis, f->width, f->sy0, f->sy1, f->band_n, f->band_r, f->msaa, f->counters + 3);
+}
+// Test aid: the STRICT G-buffer texel of every single-sampled pixel, 6 floats {packed_nt.xyzw, bx, by} (zeros = no hit)
+extern "C" void awsm_launch_gbuffer_dump(const awsm::FrameDev* f, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_gbuffer_dump, dim3((f->width * f->height + 255u) / 256u), dim3(256), 0, s, *f, out);
 }
 extern "C" void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, unsigned long long* out, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_vis_digest, dim3(1024), dim3(256), 0, s, vis, n, out);

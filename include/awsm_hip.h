@@ -300,6 +300,10 @@ int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
  * out2[0] = sum key_i * (2 i + 1) mod 2^64, out2[1] = xor rotl(key_i, i mod 64).  For tests that compare many frames
  * without reading 8 bytes per pixel back. */
 int awsm_hip_visibility_digest(AwsmHipCtx* ctx, uint64_t* out2);
+/* test aid: the G-buffer texel fs_main would have written for every pixel of the last geometry pass (fragment.wgsl:23-54) as the opaque pass
+ * reconstructs it — 6 floats / pixel: normal_tangent RGBA16F and barycentric RG16F, each already rounded to f16; zeros where nothing was hit.
+ * Single-sampled frames, no band sharding. */
+int awsm_hip_read_gbuffer(AwsmHipCtx* ctx, float* out6);
 int awsm_hip_read_visibility_unpacked(AwsmHipCtx* ctx, uint32_t* tri_id_out, uint32_t* meta_off_out, float* depth_out);
 int awsm_hip_read_opaque(AwsmHipCtx* ctx, uint16_t* rgba16f_out);
 /* the image after the transparent pass == the reference's `composite` render texture (render_textures.rs:49-54; what the

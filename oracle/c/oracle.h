@@ -71,6 +71,9 @@ int oracle_raster(const OracleScene* s, const float* clip_in, uint64_t* keys_out
 int oracle_shade(const OracleScene* s, const float* clip_in, const float* nt_in, const uint64_t* keys,
                  float* rgba32f_out, uint16_t* rgba16f_out, int threads);
 
+/* Test aid: 6 floats / pixel {packed normal-tangent RGBA16F as f32, barycentric RG16F as f32} of the single-sampled G-buffer (zeros = no hit). */
+int oracle_gbuffer(const OracleScene* s, const float* clip_in, const float* nt_in, const uint64_t* keys, float* gbuf_out, int threads);
+
 /* World transparent pass (render.rs:224-297; material_transparent/): `draws` is the back-to-front list, draw.vis_data_off = byte
  * offset of the mesh's 40-byte vertices in AWSM_BUF_TRANSPARENCY_GEOM_DATA.  oracle_forward_transform: vert_main per triangle
  * corner (clip 4, nt 8, wpos 4 floats / vertex).  oracle_forward: blit + forward pass + resolve -> the `composite` image. */

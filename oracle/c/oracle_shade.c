@@ -1438,3 +1438,24 @@ int oracle_shade(const OracleScene* s, const float* clip, const float* nt, const
         }
     return 0;
 }
+
+/* Test aid: the G-buffer texel of every single-sampled pixel (what fs_main wrote: packed normal / tangent RGBA16F as f32, barycentric RG16F as
+ * f32; zeros where nothing was hit) — lets the tests compare the STRICT reconstruction of the HIP path value for value instead of through
+ * the shaded colour.  gbuf_out: 6 floats / pixel {packed_nt.xyzw, bx, by}. */
+int oracle_gbuffer(const OracleScene* s, const float* clip, const float* nt, const uint64_t* keys, float* gbuf_out, int threads) {
+    uint32_t W = s->width, H = s->height;
+    if (s->msaa == 4u) return -1;
+    if (threads < 1) threads = 1;
+    memset(gbuf_out, 0, (size_t)W * H * 6 * sizeof(float));
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+    for (int cy = 0; cy < (int)H; cy++)
+        for (int cx = 0; cx < (int)W; cx++) {
+            uint64_t k = keys[(size_t)cy * W + cx];
+            if (k == ~0ull) continue;
+            uint32_t rank = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+            GBufferTexel g = gbuffer_texel(s, clip, nt, rank, cx, cy);
+            float* o = gbuf_out + ((size_t)cy * W + cx) * 6;
+            o[0] = g.packed_nt.x; o[1] = g.packed_nt.y; o[2] = g.packed_nt.z; o[3] = g.packed_nt.w; o[4] = g.bx; o[5] = g.by;
+        }
+    return 0;
+}

@@ -198,6 +198,13 @@ class OracleFrame:
         assert lib().oracle_raster(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.keys.ctypes.data_as(C.c_void_p), C.c_int(threads)) == 0
         return self
 
+    def gbuffer(self, threads=8):
+        """(height, width, 6) f32: packed normal / tangent (RGBA16F values), barycentric (RG16F values) per pixel; zeros where nothing was hit."""
+        out = np.zeros(self.keys.shape + (6,), dtype=np.float32)
+        assert lib().oracle_gbuffer(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.nt.ctypes.data_as(C.c_void_p),
+                                    self.keys.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(threads)) == 0
+        return out
+
     def shade(self, threads=8):
         assert lib().oracle_shade(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.nt.ctypes.data_as(C.c_void_p),
                                   self.keys.ctypes.data_as(C.c_void_p), self.rgba32f.ctypes.data_as(C.c_void_p),

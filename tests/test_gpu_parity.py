@@ -667,6 +667,52 @@ def test_lean_and_general_opaque_routes_agree(oracle_lut):
 
 
 @pytest.mark.gpu
+def test_random_viewpoints_gbuffer_exact_and_routes_agree(oracle_lut):
+    """A dozen random viewpoints inside the atrium — along walls, up into the arches, through columns at grazing angles, triangles crossing
+    the near plane — instead of the scenes' own cameras (tests/diagnostics/viewpoint_survey.py is the exploratory version; it found the basis of
+    unpack_normal_tangent blowing one-ulp differences up to 6e-2 where N.z -> -1, now computed with the oracle's operations there):
+      * keys and the reconstructed G-buffer texel (packed normal / tangent, barycentric: awsm_hip_read_gbuffer) equal the oracle's bit for bit
+        in every pixel of every view — the STRICT section, checked value for value rather than through the colour;
+      * the lean and the general route (separate code over the same formulas) give the same colours within a tenth of the shading tolerance,
+        and both are within the tolerance of the oracle, except in isolated ill-conditioned pixels — a GGX peak on a near-mirror texel
+        (relative error of D ~ 2e-7 / alpha^4), a silhouette with n.v -> 0 — which are bounded in number (<= 16 per 0.9 Mpixel view) and size."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    from awsm_renderer_amd.scenes import look_at_rh
+    from oracle import oracle_lib
+    rng = np.random.default_rng(20260104)
+    sc = scenes.atrium_scene(1280, 720, detail=0.5, tex_scale=1 / 16)
+    lean_dev, gen_dev = HipDevice(parity_tap=True), HipDevice(parity_tap=True, general_shade_only=True)
+    no_hit = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for k in range(12):
+        eye = (float(rng.uniform(-5.5, 5.5)), float(rng.uniform(0.3, 9.5)), float(rng.uniform(-17.0, 17.0)))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        if abs(d[1]) > 0.95:
+            d = np.array([0.6, 0.5, -0.62])
+        target = tuple(float(v) for v in np.asarray(eye) + 10.0 * d)
+        sc.view, sc.camera_position = look_at_rh(eye, target), eye
+        model = helpers.build_model(sc)
+        helpers.hip_frame(model, oracle_lut, dev=lean_dev)
+        helpers.hip_frame(model, oracle_lut, dev=gen_dev)
+        keys = lean_dev.read_visibility()
+        assert (keys == gen_dev.read_visibility()).all(), k
+        a, b = lean_dev.read_opaque_f32().astype(np.float64), gen_dev.read_opaque_f32().astype(np.float64)
+        r = np.abs(a - b) / (1e-5 * np.maximum(1.0, np.abs(b)))
+        assert int((r > 1).any(axis=2).sum()) <= 16 and float(r.max()) <= 60.0, (k, eye, target, int((r > 1).any(axis=2).sum()), float(r.max()))
+        if k % 3 == 1:      # the oracle on a third of the views (a few seconds each)
+            fr = oracle_lib.frame_from_model(model, oracle_lut).transform().raster(16)
+            assert (keys == fr.keys).all(), k
+            go, gh = fr.gbuffer(16), lean_dev.read_gbuffer()
+            hit = keys != no_hit
+            assert not ((go.view(np.uint32) != gh.view(np.uint32)) & hit[..., None]).any(), k
+            fr.shade(16)
+            o = fr.rgba32f.astype(np.float64)
+            for name, x in (("lean", a), ("general", b)):
+                ro = np.abs(x - o) / (RGB_TOL * np.maximum(1.0, np.abs(o)))
+                assert int((ro > 1).any(axis=2).sum()) <= 16 and float(ro.max()) <= 15.0, (k, name, int((ro > 1).any(axis=2).sum()), float(ro.max()))
+    lean_dev.close(); gen_dev.close()
+
+
+@pytest.mark.gpu
 def test_persistent_lean_grid_is_bit_identical(oracle_lut, monkeypatch):
     """k_shade_lean<true> (AWSM_LEAN_WGS_PER_CU workgroups per CU taking 16x4-pixel strips from per-XCD counters; off by default, see
     DESIGN section 6) shades every pixel with the code of the one-wavefront-per-strip grid: same bits, same list for the general kernel.  Frame

@@ -4,7 +4,6 @@ import numpy as np
 from awsm_renderer_amd import scenes
 from awsm_renderer_amd.hip_backend import HipDevice
 from tests import helpers
-from oracle import oracle_lib
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20

@@ -16,8 +16,7 @@ dev.resize(W, H, msaa)
 dev.upload_mirrors(model.mirrors())
 for i, t in enumerate(model.texture_arrays()):
     if mip:
-        from oracle import oracle_lib
-        dev.texture_array_upload(i, t["texels"], mips=oracle_lib.mip_levels(t["width"], t["height"]))
+        dev.texture_array_upload(i, t["texels"], mips=max(t["width"], t["height"]).bit_length())
         dev.texture_array_generate_mips(i, t["kinds"])
     else:
         dev.texture_array_upload(i, t["texels"])
