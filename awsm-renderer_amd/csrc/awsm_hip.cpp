@@ -33,6 +33,8 @@ void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
 int awsm_shade_is_lean(const FrameDev* f);
 int awsm_launch_shade_todo(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_gbuffer_dump(const FrameDev* f, float* out, hipStream_t s);
+void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, hipStream_t s);
+void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
 void awsm_launch_msaa_halo_export(const FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s);
@@ -119,6 +121,14 @@ struct AwsmHipCtx {
     hipEvent_t ev_geom_done[kSlots] = {}, ev_shade_done[kSlots] = {}, ev_uploads[kSlots] = {} ;
     uint64_t write_seq = 0, geom_write_seq[kSlots] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
     bool shade_pending[kSlots] = {};
+    // Device-side hand-off between the streams (kernels_geometry.hip: k_handoff_signal / k_handoff_wait) in place of the two cross-stream events
+    // on a frame's critical path: geometry pass -> opaque pass of the same frame, opaque pass of frame i -> geometry pass of frame i + kSlots.
+    bool handoff = false;
+    uint32_t* handoff_flags = nullptr;          // device: [slot] geometry done, [kSlots + slot] shading done — the serial number last signalled
+    uint32_t geom_sig[kSlots] = {}, shade_sig[kSlots] = {};
+    uint32_t handoff_polls = 1u << 20;          // ~2 s of polling: longer than any frame, short enough that a gate nobody opens ends
+    uint32_t handoff_timeouts_seen = 0;
+    uint32_t handoff_test_drop = 0;             // AWSM_TEST_HANDOFF_DROP: that many geometry-done signals are withheld (tests of the timeout path)
     FrameBufs fb[kSlots];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
     FrameBufs tr[kSlots];             // the same for the transparent pass's own draws (vertices, setup records, bins); no visibility buffer
     std::vector<DrawDev> tr_draws_host;
@@ -160,6 +170,19 @@ inline FrameBufs& FB(AwsmHipCtx* c) { return c->fb[c->slot]; }
 inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade_streams[c->slot] : c->stream; }
 inline int n_slots(const AwsmHipCtx* c) { return c->overlap ? kSlots : 1; }
 inline int prev_slot(const AwsmHipCtx* c) { return (c->slot + kSlots - 1) % kSlots; }
+inline uint32_t* handoff_timeouts(AwsmHipCtx* c) { return c->counters_host + 16 + 2 * kSlots; }
+// the slot's shading is finished: for the host and the rarely taken waits an event, for the next user of the slot's buffers the flag
+inline hipError_t mark_shade_done(AwsmHipCtx* c, hipStream_t ss) {
+    if (c->handoff) awsm_launch_handoff_signal(c->handoff_flags + kSlots + c->slot, ++c->shade_sig[c->slot], ss);
+    const hipError_t e = hipEventRecord(c->ev_shade_done[c->slot], ss);
+    c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true;
+    return e;
+}
+// the caller's stream goes on once the slot's last opaque (or transparent) pass has finished
+inline hipError_t wait_slot_free(AwsmHipCtx* c) {
+    if (c->handoff) { awsm_launch_handoff_wait(c->handoff_flags + kSlots + c->slot, c->shade_sig[c->slot], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, c->stream); return hipSuccess; }
+    return hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0);
+}
 inline hipError_t sync_shade_streams(AwsmHipCtx* c) {
     for (hipStream_t s : c->shade_streams) if (s) { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e; }
     for (bool& b : c->shade_recorded) b = false;
@@ -378,7 +401,7 @@ int enqueue_geometry(AwsmHipCtx* c) {
     if (rc) return rc;
     if (c->overlap) {
         // this slot's buffers were last read by the opaque pass kSlots frames ago (already ordered by awsm_hip_geometry_pass; a replay comes here directly)
-        if (c->shade_pending[c->slot]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0)); c->shade_pending[c->slot] = false; }
+        if (c->shade_pending[c->slot]) { HIPCHK(c, wait_slot_free(c)); c->shade_pending[c->slot] = false; }
         // the camera the frame is shaded with = the camera it was submitted with
         // (copied by k_deform_transform when the frame has geometry: a 512-byte hipMemcpyAsync costs the stream 18 us of gap + copy)
         if (c->bufs[AWSM_BUF_CAMERA].ptr) {
@@ -447,8 +470,15 @@ int enqueue_opaque(AwsmHipCtx* c) {
         awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     }
     if (c->overlap) {   // the shade stream picks up where the caller's stream is now (geometry pass + uploads of this frame)
-        HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
+        if (c->handoff) {
+            ++c->geom_sig[c->slot];
+            if (c->handoff_test_drop) c->handoff_test_drop--;
+            else awsm_launch_handoff_signal(c->handoff_flags + c->slot, c->geom_sig[c->slot], c->stream);
+            awsm_launch_handoff_wait(c->handoff_flags + c->slot, c->geom_sig[c->slot], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, ss);
+        } else {
+            HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
+        }
         // ... and, only where two frames' opaque passes share something, behind the previous frame's passes on the other slot's shade
         // stream: the MSAA scratch (per context), or an output image the caller bound (it may be the same one).  The library's own
         // images, the per-draw records and the todo lists are per slot, so single-sampled frames into the library's images need no order
@@ -466,7 +496,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
         (void)awsm_launch_shade_todo(c->scene_dev, &f, ss);
     }
     if ((rc = record(c, EV_SHADE, ss))) return rc;
-    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true; }
+    if (c->overlap) HIPCHK(c, mark_shade_done(c, ss));
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -532,7 +562,7 @@ int enqueue_transparent(AwsmHipCtx* c) {
         awsm_launch_forward(c->scene_dev, &f, ss);
     }
     if ((rc = record(c, EV_FWD, ss))) return rc;
-    if (c->overlap) { HIPCHK(c, hipEventRecord(c->ev_shade_done[c->slot], ss)); c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true; }
+    if (c->overlap) HIPCHK(c, mark_shade_done(c, ss));
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -709,8 +739,27 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             c->fb[s].camera.size = 512;
         }
     }
-    if (hipHostMalloc((void**)&c->counters_host, (16 + 2 * kSlots) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-    memset(c->counters_host, 0, (16 + 2 * kSlots) * sizeof(uint32_t));
+    if (hipHostMalloc((void**)&c->counters_host, (16 + 2 * kSlots + 1) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // last word: hand-off gates that timed out
+    memset(c->counters_host, 0, (16 + 2 * kSlots + 1) * sizeof(uint32_t));
+    if (c->overlap) {
+        const char* e = getenv("AWSM_DEVICE_HANDOFF");      // "0": cross-stream events instead (for a profiler that serialises kernels: tools/pmc_*.sh)
+        c->handoff = !(e && e[0] == '0');
+        if (const char* p = getenv("AWSM_HANDOFF_POLLS")) { const long v = atol(p); if (v > 0) c->handoff_polls = (uint32_t)v; }
+        if (hipMalloc((void**)&c->handoff_flags, 2 * kSlots * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        if (hipMemset(c->handoff_flags, 0, 2 * kSlots * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        if (const char* d = getenv("AWSM_TEST_HANDOFF_DROP")) c->handoff_test_drop = (uint32_t)atoi(d);
+        // Probe: a gate on one stream, its signal on the other, both directions of every pair the frames will use.  Where the two do not run
+        // side by side (kernels serialised by a counter-collecting profiler; two streams on one hardware queue) the gate gives up after ~10 ms
+        // and the context orders its streams with events.
+        for (int k = 0; c->handoff && k < 2 * kSlots; k++) {
+            hipStream_t ss = c->shade_streams[k % kSlots], waiter = k < kSlots ? ss : c->stream, setter = k < kSlots ? c->stream : ss;
+            const uint32_t serial = ++c->geom_sig[0];
+            awsm_launch_handoff_wait(c->handoff_flags, serial, 1u << 13, handoff_timeouts(c), 0u, waiter);
+            awsm_launch_handoff_signal(c->handoff_flags, serial, setter);
+            if (hipStreamSynchronize(waiter) != hipSuccess || hipStreamSynchronize(setter) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+            if (*(volatile uint32_t*)handoff_timeouts(c) != 0u) { c->handoff = false; c->handoff_timeouts_seen = *(volatile uint32_t*)handoff_timeouts(c); }
+        }
+    }
     memset(&c->scene, 0, sizeof c->scene);
     // defaults == AwsmRendererBuilder::new (crates/renderer/src/lib.rs:168-207): black skybox, white IBL
     c->scene.skybox_rgba[3] = 1.0f;
@@ -738,6 +787,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
+    if (c->handoff_flags) (void)hipFree(c->handoff_flags);
     for (int i = 0; i < EV_COUNT; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1015,12 +1065,13 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, new_draws, &tris, &blocks);
     if (rc) return rc;
     if (c->overlap) {
+        if (c->handoff && *(volatile uint32_t*)handoff_timeouts(c) != c->handoff_timeouts_seen) c->handoff = false;      // reported by the next awsm_hip_frame_end
         c->slot = (c->slot + 1) % kSlots;    // the opaque passes of the previous frames may still be reading the other slots
         // ... and the opaque pass of kSlots frames ago may still be reading THIS slot (its draw list, per-draw records): order everything
         // this call puts on the caller's stream — the draw-list upload included — after it
         // (asked on the host first: kSlots frames back it has usually finished, and a barrier packet on the caller's stream costs the frame 6-9 us)
         if (c->shade_pending[c->slot]) {
-            if (hipEventQuery(c->ev_shade_done[c->slot]) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0));
+            if (hipEventQuery(c->ev_shade_done[c->slot]) != hipSuccess) HIPCHK(c, wait_slot_free(c));
             c->shade_pending[c->slot] = false;
         }
     }
@@ -1137,6 +1188,12 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
+        if (c->overlap && *(volatile uint32_t*)handoff_timeouts(c) != c->handoff_timeouts_seen) {      // a gate ended unopened: its stream ran ahead of the data it waited for
+            c->handoff_timeouts_seen = *(volatile uint32_t*)handoff_timeouts(c);
+            c->handoff = false;
+            return fail(c, AWSM_ERR_DEVICE, "a device-side stream hand-off timed out (kernels serialised by a profiler, or the streams share a hardware queue): "
+                                            "frames since the last frame_end may be incomplete; this context uses events from here on (AWSM_DEVICE_HANDOFF=0 selects them from the start)");
+        }
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
         if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
@@ -1231,6 +1288,11 @@ int awsm_hip_read_gbuffer(AwsmHipCtx* c, float* out6) {
     (void)hipFree(dev);
     HIPCHK(c, e);
     return AWSM_OK;
+}
+
+int awsm_hip_stream_handoff(AwsmHipCtx* c) {
+    if (!c) return AWSM_ERR_INVALID_ARGUMENT;
+    return c->overlap && c->handoff ? 1 : 0;
 }
 
 int awsm_hip_visibility_digest(AwsmHipCtx* c, uint64_t* out2) {

@@ -818,6 +818,30 @@ __global__ __launch_bounds__(256) void k_gen_mip_level(uint32_t* __restrict__ ch
     chain[dst_off + ((size_t)layer * dh + y) * dw + x] = to_unorm8(o0) | (to_unorm8(o1) << 8) | (to_unorm8(o2) << 16) | (to_unorm8(o3) << 24);
 }
 
+// Device-side hand-off between the streams of an overlapped frame pipeline (awsm_hip.cpp: enqueue_opaque).  A cross-stream hipEvent costs the
+// waiting queue 20-30 us after the event has fired (the command processor resolves barrier packets on a timer: both queues of a frame boundary
+// were seen to resume at the same instant, 19.6 us after the last kernel ended, the GPU idle in between).  Here the producer stream ends with a
+// one-lane kernel that stores the frame's serial number, and the consumer stream begins with a one-lane kernel that polls it: the stream's own
+// in-order execution does the rest, and the hand-off costs a memory round trip.  Visibility of the producer's data is what the kernel boundaries
+// give (release at the end of the producer's last kernel, which the signalling kernel follows in order; acquire at the start of the consumer's
+// next kernel); the flag itself is read and written past the non-coherent L2s (sc1).  The poll is bounded: a gate that is never opened — kernels
+// serialised by a counter-collecting profiler, or two streams folded onto one hardware queue — ends, counts itself in a pinned word, and the host
+// falls back to events (awsm_hip_frame_end reports the frame).  Gates enqueued before the host noticed see the count differ from the one they
+// were enqueued with and give up after a few polls, so a run-ahead host costs one timeout, not one per queued frame.  awsm_hip_create probes the
+// mechanism on the context's own streams first and leaves it off when a gate and its signal do not run side by side.
+__global__ __launch_bounds__(64) void k_handoff_signal(uint32_t* flag, uint32_t serial) {
+    if (threadIdx.x == 0) st_sc1(flag, serial);
+}
+__global__ __launch_bounds__(64) void k_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known) {
+    if (threadIdx.x != 0) return;
+    if (__hip_atomic_load(timeouts_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != timeouts_known) max_polls = min(max_polls, 64u);
+    uint32_t polls = 0u;
+    while ((int32_t)(ld_sc1(flag) - serial) < 0) {
+        if (++polls >= max_polls) { __hip_atomic_fetch_add(timeouts_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 }  // namespace awsm
 
 extern "C" void awsm_launch_gen_mip_level(uint8_t* chain, uint32_t src_off, uint32_t dst_off, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, uint32_t layers,
@@ -831,6 +855,12 @@ extern "C" void awsm_launch_upload_words(void* dst, const void* src_pinned, uint
 }
 
 // ---- launch wrappers (called from awsm_hip.cpp) ----
+extern "C" void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_handoff_signal, dim3(1), dim3(64), 0, s, flag, serial);
+}
+extern "C" void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_handoff_wait, dim3(1), dim3(64), 0, s, flag, serial, max_polls, timeouts_host, timeouts_known);
+}
 extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
     if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform<false>, dim3(n_blocks), dim3(256), 0, s, sc, *f);
 }

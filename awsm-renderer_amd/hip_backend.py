@@ -27,7 +27,7 @@ BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", 
 EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_hip_abi_version", "awsm_hip_buffer_create",
            "awsm_hip_buffer_write", "awsm_hip_resize", "awsm_hip_set_shard_rows", "awsm_hip_set_shard_bands", "awsm_hip_set_stage_timers", "awsm_hip_pick", "awsm_hip_texture_array_upload", "awsm_hip_texture_array_generate_mips", "awsm_hip_texture_array_read_level", "awsm_hip_sampler_set",
            "awsm_hip_env_upload", "awsm_hip_brdf_lut_generate", "awsm_hip_read_brdf_lut", "awsm_hip_geometry_pass", "awsm_hip_opaque_pass",
-           "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_read_gbuffer", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
+           "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_read_gbuffer", "awsm_hip_stream_handoff", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
            "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload", "awsm_hip_bind_opaque_source", "awsm_hip_msaa_halo_bands", "awsm_hip_msaa_halo_export", "awsm_hip_msaa_halo_bind"]
@@ -328,6 +328,11 @@ class HipDevice:
     # ---- readback ----
     def _vis_shape(self):
         return (self.height, self.width, 4) if getattr(self, "msaa", 0) == 4 else (self.height, self.width)
+
+    def stream_handoff(self) -> int:
+        """1: the overlapped pipeline hands frames between its streams through device-side flags, 0: through hipEvents (awsm_hip.h)."""
+        self.lib.awsm_hip_stream_handoff.argtypes = [C.c_void_p]
+        return int(self.lib.awsm_hip_stream_handoff(self.ctx))
 
     def read_gbuffer(self) -> np.ndarray:
         """(height, width, 6) f32: the reconstructed G-buffer texel per pixel (packed normal / tangent, barycentric), zeros where nothing was hit."""

@@ -445,7 +445,9 @@ def main():
                        "triangles": n_tris, "width": W, "height": H,
                        "sharding": sharding_desc,
                        "draws": len(r.host.draw_list()),
-                       "frame_overlap": not args.no_overlap, "camera": "static" if args.static_camera else "orbit, one turn per 240 frames",
+                       "frame_overlap": not args.no_overlap,
+                       "stream_handoff": ("device flags (k_handoff_signal / k_handoff_wait)" if dev.stream_handoff() == 1 else "hipEvents") if not args.no_overlap else "none (one stream)",
+                       "camera": "static" if args.static_camera else "orbit, one turn per 240 frames",
                        "opaque_route": "lean (k_shade_lean + k_shade_todo)" if lean else "general (k_shade)",
                        "library": os.path.relpath(hip_backend_path(), ROOT)},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels", "shade_general_wavefronts",

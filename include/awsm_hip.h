@@ -300,6 +300,13 @@ int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
  * out2[0] = sum key_i * (2 i + 1) mod 2^64, out2[1] = xor rotl(key_i, i mod 64).  For tests that compare many frames
  * without reading 8 bytes per pixel back. */
 int awsm_hip_visibility_digest(AwsmHipCtx* ctx, uint64_t* out2);
+/* AWSM_CFG_OVERLAP_FRAMES: how the context orders its streams at the two hand-offs on a frame's critical path (geometry pass -> opaque pass of
+ * the same frame; opaque pass -> the geometry pass that reuses its frame slot).  1 = device-side flags (a one-lane kernel at the end of the
+ * producer stream stores the frame's serial number, a one-lane kernel at the head of the consumer stream polls it: ~2 us instead of the
+ * 20-30 us a cross-stream hipEvent takes to release the waiting queue), 0 = hipEvents (contexts without overlap; AWSM_DEVICE_HANDOFF=0 in
+ * the environment; the probe at create found that kernels of two streams do not run side by side, e.g. under a counter-collecting
+ * profiler; or a gate timed out later, which awsm_hip_frame_end reports once with AWSM_ERR_DEVICE).  Negative = AWSM_ERR_*. */
+int awsm_hip_stream_handoff(AwsmHipCtx* ctx);
 /* test aid: the G-buffer texel fs_main would have written for every pixel of the last geometry pass (fragment.wgsl:23-54) as the opaque pass
  * reconstructs it — 6 floats / pixel: normal_tangent RGBA16F and barycentric RG16F, each already rounded to f16; zeros where nothing was hit.
  * Single-sampled frames, no band sharding. */

@@ -527,6 +527,82 @@ def test_reference_default_anti_aliasing_through_host_layer(oracle_lut):
 
 
 @pytest.mark.gpu
+def test_stream_handoff_flags_events_and_timeout_fallback(oracle_lut, monkeypatch):
+    """The overlapped pipeline hands a frame from stream to stream through device-side flags (k_handoff_signal / k_handoff_wait) instead of
+    cross-stream events.  48 frames with a moving camera, submitted without a synchronisation, each into its own image: bit-identical to a
+    plain context's frames with the flags (the default: awsm_hip_stream_handoff() == 1) and with AWSM_DEVICE_HANDOFF=0 (events).  Then the
+    failure path: one geometry-done signal withheld (AWSM_TEST_HANDOFF_DROP) with a short poll budget — the gate gives up, awsm_hip_frame_end
+    reports it once, the context goes on with events and renders correct frames again."""
+    import ctypes as C
+    from awsm_renderer_amd.hip_backend import HipDevice
+    from awsm_renderer_amd.host import Renderer
+    from awsm_renderer_amd.scenes import look_at_rh
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    sc = scenes.atrium_scene(480, 270, detail=0.25, tex_scale=1 / 16)
+    n = 48
+    eyes = [(0.4 + 0.11 * i, 3.1 + 0.03 * i, 17.0 - 0.6 * i) for i in range(n)]
+    lut = oracle_lib_rgba16f(oracle_lut)
+    nbytes = sc.height * sc.width * 8
+
+    def run(overlap, want_handoff):
+        r = Renderer(sc, lut_rgba16f=lut, overlap_frames=overlap)
+        r.host.set_render_timings(False)
+        dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
+        assert dev.stream_handoff() == want_handoff
+        outs = []
+        for _ in eyes:
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), nbytes) == 0
+            outs.append(p)
+        for i, eye in enumerate(eyes):
+            r.host.camera_update(look_at_rh(eye, (-0.2, 3.4, -18.0)), sc.proj, eye)
+            dev.bind_output(outs[i].value, nbytes)
+            r.host.render(sync=not overlap)
+        dev.frame_flush()
+        assert hip.hipDeviceSynchronize() == 0
+        imgs = []
+        for p in outs:
+            a = np.zeros((sc.height, sc.width, 4), dtype=np.uint16)
+            assert hip.hipMemcpy(a.ctypes.data_as(C.c_void_p), p, nbytes, 2) == 0
+            imgs.append(a)
+            hip.hipFree(p)
+        dev.bind_output(None)
+        r.close()
+        return imgs
+
+    plain = run(False, 0)
+    flags = run(True, 1)
+    monkeypatch.setenv("AWSM_DEVICE_HANDOFF", "0")
+    events = run(True, 0)
+    monkeypatch.delenv("AWSM_DEVICE_HANDOFF")
+    for i, (a, b, e) in enumerate(zip(plain, flags, events)):
+        assert (a == b).all(), f"flags, frame {i}: {(a != b).sum()} values differ"
+        assert (a == e).all(), f"events, frame {i}: {(a != e).sum()} values differ"
+    assert not (plain[0] == plain[n - 1]).all()
+
+    monkeypatch.setenv("AWSM_TEST_HANDOFF_DROP", "1")
+    monkeypatch.setenv("AWSM_HANDOFF_POLLS", "3000")
+    r = Renderer(sc, lut_rgba16f=lut, overlap_frames=True)
+    r.host.set_render_timings(False)
+    dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
+    assert dev.stream_handoff() == 1
+    r.host.camera_update(look_at_rh(eyes[0], (-0.2, 3.4, -18.0)), sc.proj, eyes[0])
+    r.host.render(sync=False)            # its opaque pass starts behind a gate nobody opens
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        r.host.render(sync=True)
+    assert dev.stream_handoff() == 0
+    for i in (5, 17):
+        r.host.camera_update(look_at_rh(eyes[i], (-0.2, 3.4, -18.0)), sc.proj, eyes[i])
+        r.host.render(sync=False)
+        r.host.render(sync=True)
+        assert (dev.read_opaque() == plain[i]).all(), i
+    r.close()
+
+
+@pytest.mark.gpu
 def test_overlapped_frames_shade_what_was_submitted(oracle_lut):
     """AWSM_CFG_OVERLAP_FRAMES: the opaque pass of frame i runs on the library's shade stream while the geometry pass of frame
     i+1 is already enqueued.  Six frames with a moving camera (and a material change half-way) are submitted without any
@@ -710,6 +786,26 @@ def test_random_viewpoints_gbuffer_exact_and_routes_agree(oracle_lut):
                 ro = np.abs(x - o) / (RGB_TOL * np.maximum(1.0, np.abs(o)))
                 assert int((ro > 1).any(axis=2).sum()) <= 16 and float(ro.max()) <= 15.0, (k, name, int((ro > 1).any(axis=2).sum()), float(ro.max()))
     lean_dev.close(); gen_dev.close()
+
+
+@pytest.mark.gpu
+def test_random_viewpoints_in_every_mode(oracle_lut):
+    """The same idea through the other modes (tests/diagnostics/mode_survey.py): three random viewpoints each around the material zoo (every optional
+    PBR block, unlit, debug views, sampler modes, point + spot lights; single-sampled and with gradient mipmaps), the helmet, the skinned + morphed
+    strip, inside the atrium with MSAA x4 / gradient mipmaps / both, and around the transparent scene with its forward pass (single-sampled, MSAA).
+    Vertices and keys bit-exact in every view; colours within the tolerance except for at most 4 isolated pixels per view (measured: 0-2, <= 2.6x);
+    the composite within two f16 steps everywhere, pixels no fragment reached untouched."""
+    from tests.diagnostics import mode_survey
+    seen = 0
+    for name, k, eye, c, cc in mode_survey.survey(3, lut=oracle_lut):
+        tag = (name, k, eye, c, cc)
+        assert c["key_mismatch"] == 0 and c["clip_mismatch"] == 0 and c["nt_mismatch"] == 0, tag
+        assert c["rgb_over_tol"] <= 4 and c["rgb_max_rel_to_bound"] <= 10.0 and c["f16_max_ulp"] <= 8, tag
+        if cc is not None:
+            assert cc["clip_mismatch"] == 0 and cc["nt_mismatch"] == 0 and cc["wpos_mismatch"] == 0 and cc["untouched_changed"] == 0, tag
+            assert cc["pixels_over_2ulp"] <= 4 and cc["pixels_over_bound"] <= 4 and cc["alpha_mismatch"] == 0, tag
+        seen += 1
+    assert seen == 3 * len(mode_survey.MODES)
 
 
 @pytest.mark.gpu
