@@ -30,7 +30,38 @@ def build_hip(jobs: int = 3) -> str:
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc build failed:\n{proc.stdout[-4000:]}")
+    check_register_budgets(hipcc)
     return os.path.join(PACKAGE_DIR, "libawsm_hip.so")
+
+
+# Kernels that must be placed beside a running k_shade_lean (80 VGPRs x 6 waves per SIMD: one exiting lean workgroup leaves 112 registers per
+# SIMD free) — the next frame's geometry kernels and the previous frame's k_shade_todo — keep within that, or the overlapped pipeline falls back
+# to running them after the lean kernel has drained (kernels_shade.hip: k_shade_todo).  Read from the code object's metadata after every build.
+VGPR_BUDGETS = {"kernels_shade.o": {"k_shade_leanILb0E": 80, "k_shade_todo": 112},
+                "kernels_geometry.o": {"k_deform_transformILb0E": 80, "k_binILb0E": 112, "k_binILb1E": 112, "k_bin_bigILb0E": 112, "k_bin_scan": 112, "k_raster_tileILi1E": 112,
+                                       "k_handoff_signal": 32, "k_handoff_wait": 32}}
+
+
+def check_register_budgets(hipcc: str) -> None:
+    import re
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin")
+    if not os.path.exists(os.path.join(llvm, "llvm-objcopy")):
+        llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj, budgets in VGPR_BUDGETS.items():
+            fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "code.co")
+            subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", os.path.join(PACKAGE_DIR, "csrc", obj)])
+            subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+            found = dict(re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", notes))
+            for key, budget in budgets.items():
+                hits = {n: int(v) for n, v in found.items() if key in n}
+                if not hits:
+                    raise RuntimeError(f"{obj}: no kernel matching {key} in the code object")
+                for n, v in hits.items():
+                    if v > budget:
+                        raise RuntimeError(f"{obj}: {n} uses {v} VGPRs, more than the {budget} it may use to be placed beside k_shade_lean")
 
 
 def build_host() -> str:

@@ -107,6 +107,7 @@ struct AwsmHipCtx {
     DevBuf shade_todo[kSlots];             // per frame slot (the per-draw resolve of frame i + 1 resets one while frame i's opaque pass appends to the other); [0] count + entries: the 16x4-pixel groups the lean opaque kernel leaves to the general one
     void* bound_out = nullptr;
     size_t bound_out_bytes = 0;
+    const uint8_t* slot_out_lo[kSlots] = {}; const uint8_t* slot_out_hi[kSlots] = {};     // the bound image each slot's last opaque pass wrote (null: the library's own)
 
     // geometry-pass resources
     // Frame overlap (AWSM_CFG_OVERLAP_FRAMES): the opaque pass of frame i runs on shade_stream while the caller's stream
@@ -124,8 +125,9 @@ struct AwsmHipCtx {
     // Device-side hand-off between the streams (kernels_geometry.hip: k_handoff_signal / k_handoff_wait) in place of the two cross-stream events
     // on a frame's critical path: geometry pass -> opaque pass of the same frame, opaque pass of frame i -> geometry pass of frame i + kSlots.
     bool handoff = false;
-    uint32_t* handoff_flags = nullptr;          // device: [slot] geometry done, [kSlots + slot] shading done — the serial number last signalled
-    uint32_t geom_sig[kSlots] = {}, shade_sig[kSlots] = {};
+    uint32_t* handoff_flags = nullptr;          // device: [slot] geometry done, [kSlots + slot] shading done, [2 kSlots + slot] k_shade_lean done — the serial number last signalled
+    uint32_t geom_sig[kSlots] = {}, shade_sig[kSlots] = {}, lean_sig[kSlots] = {};   // flags [2 kSlots + slot]: the slot's k_shade_lean has ended (stored by k_shade_todo as it starts)
+    bool lean_flagged[kSlots] = {};             // the slot's last opaque pass took the lean route with the flag: the next frame's pass may start on lean_sig
     uint32_t handoff_polls = 1u << 20;          // ~2 s of polling: longer than any frame, short enough that a gate nobody opens ends
     uint32_t handoff_timeouts_seen = 0;
     uint32_t handoff_test_drop = 0;             // AWSM_TEST_HANDOFF_DROP: that many geometry-done signals are withheld (tests of the timeout path)
@@ -177,6 +179,17 @@ inline hipError_t mark_shade_done(AwsmHipCtx* c, hipStream_t ss) {
     const hipError_t e = hipEventRecord(c->ev_shade_done[c->slot], ss);
     c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true;
     return e;
+}
+// a shade stream goes on once the OTHER slot's passes have finished (shared MSAA scratch, one bound image for both frames, the composite) —
+// or, main_kernel_only, once its k_shade_lean has (its k_shade_todo may still run: per-slot images and lists)
+inline hipError_t wait_prev_slot(AwsmHipCtx* c, hipStream_t ss, bool main_kernel_only = false) {
+    const int p = prev_slot(c);
+    if (c->handoff && c->shade_sig[p]) {
+        const bool lean = main_kernel_only && c->lean_flagged[p];
+        awsm_launch_handoff_wait(c->handoff_flags + (lean ? 2 * kSlots : kSlots) + p, lean ? c->lean_sig[p] : c->shade_sig[p], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, ss);
+        return hipSuccess;
+    }
+    return hipStreamWaitEvent(ss, c->ev_shade_done[p], 0);
 }
 // the caller's stream goes on once the slot's last opaque (or transparent) pass has finished
 inline hipError_t wait_slot_free(AwsmHipCtx* c) {
@@ -479,16 +492,27 @@ int enqueue_opaque(AwsmHipCtx* c) {
             HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
             HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
         }
-        // ... and, only where two frames' opaque passes share something, behind the previous frame's passes on the other slot's shade
-        // stream: the MSAA scratch (per context), or an output image the caller bound (it may be the same one).  The library's own
-        // images, the per-draw records and the todo lists are per slot, so single-sampled frames into the library's images need no order
-        // at all — frame i + 1's opaque pass starts when its raster is done, whatever frame i's k_shade_todo is doing.  (Last of the
-        // waits on purpose: the first two are consumed while the previous frame still shades.)
-        if ((c->msaa != 0 || c->bound_out) && c->shade_recorded[prev_slot(c)]) HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade_done[prev_slot(c)], 0));
+        // ... and behind the previous frame's opaque pass on the other slot's shade stream.  Where the two share something — the MSAA scratch
+        // (per context), one bound output image for both — behind all of it.  Otherwise (the library's own images, or a caller alternating
+        // between two bound ones: images, per-draw records and todo lists are per slot) behind its main kernel only: frame i + 1's
+        // k_shade_lean starts when frame i's has ended, beside frame i's k_shade_todo.  Not earlier, although nothing shared would forbid it:
+        // with two frame slots the geometry pass of frame i + 2 waits for frame i's shading, and two opaque passes running into each other
+        // push that out — measured 2,780 frames/s free-running against 2,980 in step.  (Last of the waits on purpose: the first two are
+        // consumed while the previous frame still shades.)
+        const uint8_t* lo = (const uint8_t*)c->bound_out; const uint8_t* hi = lo ? lo + c->bound_out_bytes : nullptr;
+        const int p = prev_slot(c);
+        const bool same_image = lo && c->slot_out_lo[p] && lo < c->slot_out_hi[p] && c->slot_out_lo[p] < hi;
+        if (c->shade_recorded[p]) HIPCHK(c, wait_prev_slot(c, ss, !(c->msaa != 0 || same_image)));
+        c->slot_out_lo[c->slot] = lo; c->slot_out_hi[c->slot] = hi;
     }
     if (want_resolve && !early) awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     if ((rc = record(c, EV_SHADE_BEGIN, ss))) return rc;      // after the resolve: ms_shade is the shading kernels alone
     c->ev_valid[EV_SHADE_LEAN] = false;
+    c->lean_flagged[c->slot] = false;
+    if (c->overlap && c->handoff && f.sy1 > f.sy0 && awsm_shade_is_lean(&f)) {
+        f.lean_done_flag = c->handoff_flags + 2 * kSlots + c->slot; f.lean_done_serial = ++c->lean_sig[c->slot];
+        c->lean_flagged[c->slot] = true;
+    }
     if (f.sy1 > f.sy0) {
         awsm_launch_shade(c->scene_dev, &f, ss);
         // the lean kernel alone (AwsmFrameStats.ms_shade_lean): one more event, only when stage times are asked for
@@ -544,7 +568,7 @@ int enqueue_transparent(AwsmHipCtx* c) {
     if (rc) return rc;
     hipStream_t ss = shade_stream_of(c);          // in order after the opaque pass
     // the composite image and the fragment lists' bookkeeping are per context: behind the previous frame's passes on the other slot's stream
-    if (c->overlap && c->shade_recorded[prev_slot(c)]) HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade_done[prev_slot(c)], 0));
+    if (c->overlap && c->shade_recorded[prev_slot(c)]) HIPCHK(c, wait_prev_slot(c, ss));
     if ((rc = record(c, EV_FWD_BEGIN, ss))) return rc;
     const bool has_geometry = f.total_tris && n_tiles;
     if (!has_geometry) {
@@ -745,8 +769,8 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         const char* e = getenv("AWSM_DEVICE_HANDOFF");      // "0": cross-stream events instead (for a profiler that serialises kernels: tools/pmc_*.sh)
         c->handoff = !(e && e[0] == '0');
         if (const char* p = getenv("AWSM_HANDOFF_POLLS")) { const long v = atol(p); if (v > 0) c->handoff_polls = (uint32_t)v; }
-        if (hipMalloc((void**)&c->handoff_flags, 2 * kSlots * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-        if (hipMemset(c->handoff_flags, 0, 2 * kSlots * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        if (hipMalloc((void**)&c->handoff_flags, 3 * kSlots * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        if (hipMemset(c->handoff_flags, 0, 3 * kSlots * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(AWSM_ERR_DEVICE);
         if (const char* d = getenv("AWSM_TEST_HANDOFF_DROP")) c->handoff_test_drop = (uint32_t)atoi(d);
         // Probe: a gate on one stream, its signal on the other, both directions of every pair the frames will use.  Where the two do not run
         // side by side (kernels serialised by a counter-collecting profiler; two streams on one hardware queue) the gate gives up after ~10 ms

@@ -154,6 +154,8 @@ struct FrameDev {
     LeanDrawDev* draw_lean;       // n_draws (k_resolve_draws); null = the lean route is off for this frame
     uint32_t* shade_todo;         // [0] = count, [4 ..] = (block id << 2 | wavefront) of the 16x4-pixel groups k_shade_lean left to the general kernel
     uint32_t shade_todo_cap;
+    uint32_t* lean_done_flag;     // overlapped pipeline: k_shade_todo's first workgroup stores lean_done_serial here as it starts (= k_shade_lean of this frame has
+    uint32_t lean_done_serial;    // ended): the gate in front of the next frame's opaque pass (awsm_hip.cpp: wait_prev_pass); null = not used
     uint32_t* camera_snap;        // geometry pass, overlap mode: k_deform_transform copies camera_snap_words words of the camera UBO here (the camera the frame
     uint32_t camera_snap_words;   // is shaded with = the camera it was submitted with); null / 0 otherwise
     uint32_t* lean_next;          // 64 x 16 words: strip counter c of XCD x at [(x * kLeanCounters + c) * 16] (persistent k_shade_lean grid; zeroed by k_resolve_draws)

@@ -1584,12 +1584,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
 // The 16x4-pixel groups k_shade_lean left behind (a draw that is not lean, or texture coordinates beyond +-32768): one wavefront
 // per list entry, the general code.  A fixed small grid strides over the list; with an all-lean frame every wavefront reads the
 // count and exits.
+// 112 VGPRs at most (109 as compiled; the list walk sits in scalar registers for that): frame i's list is shaded while frame i + 1's k_shade_lean
+// (80 VGPRs x 6 waves per SIMD) already fills the machine, and a waiting workgroup is only placed when all of it fits — 112 is what one exiting
+// lean workgroup leaves free on each SIMD (32 + 80).  At 120 (114 used) this kernel waited for the whole lean kernel to drain — 228 us for an
+// empty list — and held up everything ordered behind the frame.  No occupancy step of the compiler yields a 112 budget (waves_per_eu(5): 96 and
+// a spill), so the count is checked after the build (awsm_renderer_amd/build.py).
 constexpr uint32_t kTodoBlocks = 1024;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_todo(const DevScene* __restrict__ sc, FrameDev f) {
+    // This kernel starting means this frame's k_shade_lean has ended (same stream): the next frame's opaque pass, gated on that, goes ahead
+    // while the list is shaded (k_handoff_wait, kernels_geometry.hip; the two frames write different images).
+    if (f.lean_done_flag && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(f.lean_done_flag, f.lean_done_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t n = min(f.shade_todo[0], f.shade_todo_cap);
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += kTodoBlocks * 4u) {
-        const uint32_t e = f.shade_todo[4u + i];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the list walk in scalar registers
+    for (uint32_t i = blockIdx.x * 4u + wave; i < n; i += kTodoBlocks * 4u) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.shade_todo[4u + i]);
         ShadeBlock b;
         if (!shade_block(f, b, e >> 2)) continue;
         shade_pixel<false>(sc, f, b, ((e & 3u) << 6) | lane);

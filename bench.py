@@ -234,8 +234,9 @@ def main():
         r.host.set_shard_rows(y0s, y1s)
     elif world > 1:
         r.host.set_shard_bands(world, rank, compact_output=True)
-    else:
-        dev.bind_output(image[0].data_ptr(), H * W * 8)
+    # one GPU: the frames go to the library's own images, one per frame slot (awsm_hip_output_device_ptr after awsm_hip_frame_flush is what a
+    # consumer reads): two frames' opaque passes then share nothing and frame i + 1's may start while frame i's still drains.  (Binding ONE image
+    # for every frame, as this script did until round 2, makes the library order the two passes: the second would write into the first's image.)
 
     class _Done:
         def wait(self):
