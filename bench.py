@@ -334,17 +334,42 @@ def main():
     # whether one lands in a 25-70 ms loop depends on the allocation count of everything before it (seen: configs[1] at 3,100 or 8,300
     # frames/s depending on an unrelated command-line flag).  The loop itself allocates a few tuples per step.
     import gc
-    gc.collect()
-    gc.disable()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
+
+    def timed_loop():
+        gc.collect()
+        gc.disable()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt
+
+    handoff_mode = dev.stream_handoff()
+    dt = timed_loop()
+    # A device-side hand-off gate that gave up during the loop (kernels of two streams not running side by side: a profiler that serialises
+    # them attached after the context's probe, a hardware queue shared with a stream created later) leaves frames that may be incomplete and
+    # the context on events: the measurement is then repeated, on events, and the line says so.
+    handoff_fault = 0
+    try:
+        r.host.render(sync=True)
+    except Exception as e:      # HostError: the library reports the timed-out gate once, at the next awsm_hip_frame_end
+        if "hand-off" not in str(e):
+            raise
+        handoff_fault = 1
+    if dev.stream_handoff() != handoff_mode:
+        handoff_fault = 1
+    if world > 1:
+        t = torch.tensor([handoff_fault], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        handoff_fault = int(t.item())
+    if handoff_fault:
+        print(f"rank {rank}: a stream hand-off gate timed out during the timed loop; repeating the measurement on hipEvents", file=sys.stderr)
+        dt = timed_loop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -447,7 +472,7 @@ def main():
                        "sharding": sharding_desc,
                        "draws": len(r.host.draw_list()),
                        "frame_overlap": not args.no_overlap,
-                       "stream_handoff": ("device flags (k_handoff_signal / k_handoff_wait)" if dev.stream_handoff() == 1 else "hipEvents") if not args.no_overlap else "none (one stream)",
+                       "stream_handoff": ("device flags (k_handoff_signal / k_handoff_wait)" if dev.stream_handoff() == 1 else "hipEvents" + (" (a device-flag gate timed out: measurement repeated)" if handoff_fault else "")) if not args.no_overlap else "none (one stream)",
                        "camera": "static" if args.static_camera else "orbit, one turn per 240 frames",
                        "opaque_route": "lean (k_shade_lean + k_shade_todo)" if lean else "general (k_shade)",
                        "library": os.path.relpath(hip_backend_path(), ROOT)},
