@@ -64,14 +64,19 @@ def survey(n_views, only=(), lut=None, seed=20260105):
             if transparent:
                 orc.forward(model.collect_transparent_draws(), 64)
             helpers.hip_frame(model, lut, dev=dev, transparent=transparent, **kw)
-            yield name, k, eye, helpers.compare_frames(orc, dev), (helpers.compare_composite(orc, dev) if transparent else None)
+            c = helpers.compare_frames(orc, dev)
+            if not kw.get("msaa"):      # the STRICT G-buffer texel, value for value (awsm_hip_read_gbuffer: single-sampled frames)
+                go, gh = orc.gbuffer(64), dev.read_gbuffer()
+                hit = orc.keys != np.uint64(0xFFFFFFFFFFFFFFFF)
+                c["gbuffer_mismatch"] = int(((go.view(np.uint32) != gh.view(np.uint32)) & hit[..., None]).any(axis=-1).sum())
+            yield name, k, eye, c, (helpers.compare_composite(orc, dev) if transparent else None)
         dev.close()
 
 
 if __name__ == "__main__":
     for name, k, eye, c, cc in survey(int(sys.argv[1]) if len(sys.argv) > 1 else 4, set(sys.argv[2:])):
-        line = "%-18s view %d eye (%.2f %.2f %.2f): covered %7d keys %d verts %d/%d | rgb over %4d worst %8.2f alpha %d f16ulp %d" % (
-            name, k, *eye, c["covered"], c["key_mismatch"], c["clip_mismatch"], c["nt_mismatch"], c["rgb_over_tol"], c["rgb_max_rel_to_bound"], c["alpha_mismatch"], c["f16_max_ulp"])
+        line = "%-18s view %d eye (%.2f %.2f %.2f): covered %7d keys %d verts %d/%d gbuffer %s | rgb over %4d worst %8.2f alpha %d f16ulp %d" % (
+            name, k, *eye, c["covered"], c["key_mismatch"], c["clip_mismatch"], c["nt_mismatch"], c.get("gbuffer_mismatch", "-"), c["rgb_over_tol"], c["rgb_max_rel_to_bound"], c["alpha_mismatch"], c["f16_max_ulp"])
         if cc:
             line += " | composite: touched %d over2ulp %d max_ulp %d over_bound %d alpha %d untouched_changed %d" % (
                 cc["touched_pixels"], cc["pixels_over_2ulp"], cc["max_ulp"], cc["pixels_over_bound"], cc["alpha_mismatch"], cc["untouched_changed"])
