@@ -569,14 +569,14 @@ struct WorkTri {
     float zq[3];
     uint32_t rank;
     uint32_t bbox;   // x0 | x1<<8 | y0<<16 | y1<<24, tile-local, inclusive
-    uint32_t exact;  // TriSetup::exact
+    uint32_t exact;  // 0: edge values by FMA per sample; 1: TriSetup::exact (stepped in f64); 2: TriSetup::small (stepped in 32-bit integers)
 };
 static_assert(sizeof(WorkTri) == 72, "WorkTri");
 
 AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 #pragma unroll
     for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.zq[i] = g.zq[i]; }
-    t.exact = g.exact != 0u;
+    t.exact = g.exact != 0u; t.small = g.exact == 2u;
 }
 
 // One pixel of the tile against one triangle: S = 1 samples the pixel centre, S = 4 the four standard MSAA positions
@@ -600,8 +600,42 @@ AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, 
 // near-plane crossers): E_i at the lane's pixel of the first block of a row by the two FMAs, then E_i += STEP * a_i from block to block —
 // integers below 2^49 throughout, so the sums are the values the FMAs would give, at one f64 add per edge and pixel instead of two FMAs and
 // the coordinate conversions.
+// The same walk for a small exact triangle (TriSetup::small) in 32-bit integers: every E it meets is an integer below 2^30, so E at the lane's
+// first pixel comes from the two FMAs once, converted, and rows and columns are integer adds.  The top-left rule is a bias: an edge that owns
+// its zero line accepts E >= 0, the others E >= 1, so with e = E - bias the pixel is covered when no e is negative — one OR3 and one compare
+// for the three f64 comparisons.  The depth is computed from (float)E as before: an integer converts to the same f32 from i32 as from f64.
+template <int STEP>
+AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
+    const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5, Y0 = (double)(tpy + (y0 & ~(STEP - 1)) + ly) + 0.5;
+    int e[3], bias[3], sx[3], sy[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        bias[i] = (t.a[i] > 0.0f || (t.a[i] == 0.0f && t.b[i] > 0.0f)) ? 0 : 1;
+        e[i] = (int)fma((double)t.a[i], X0, fma((double)t.b[i], Y0, t.c[i])) - bias[i];
+        sx[i] = (int)t.a[i] * STEP; sy[i] = (int)t.b[i] * STEP;      // a, b: integers times 256, below 2^23
+    }
+    for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
+        const int py = by + ly;
+        int r0 = e[0], r1 = e[1], r2 = e[2];
+        for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+            const int px = bx + lx;
+            if (px >= x0 && px <= x1 && py >= y0 && py <= y1 && (r0 | r1 | r2) >= 0) {
+                const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
+                float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
+                if (zn >= 0.0f && zn <= 1.0f) {
+                    if (zn == 0.0f) zn = 0.0f;
+                    atomicMin(&keys[py * kTile + px], ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - r));
+                }
+            }
+            r0 += sx[0]; r1 += sx[1]; r2 += sx[2];
+        }
+        e[0] += sy[0]; e[1] += sy[1]; e[2] += sy[2];
+    }
+}
+
 template <int S, int STEP>
 AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
+    if (S == 1 && t.small) { raster_walk_i32<STEP>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r); return; }
     if (S == 1 && t.exact) {
         const double step[3] = {(double)t.a[0] * (double)STEP, (double)t.a[1] * (double)STEP, (double)t.a[2] * (double)STEP};
         const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5;
@@ -684,7 +718,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                         WorkTri& g = work[slot];
 #pragma unroll
                         for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
-                        g.rank = r; g.exact = t.exact ? 1u : 0u;
+                        g.rank = r; g.exact = t.small ? 2u : (t.exact ? 1u : 0u);
                         g.bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
                     }
                 }

@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
                 const uint32_t r = f.bin_list[off + i], rr = r - wbase;      // unsigned: ranks below the window wrap to huge values
                 if (rr >= kFwdWindow) continue;
                 const uint32_t bx = f.tri_rec[r].bbox_x, by = f.tri_rec[r].bbox_y;
-                const int x0 = (int)(bx & 0xFFFFu), x1 = (int)((bx >> 16) & 0x7FFFu), y0 = (int)(by & 0xFFFFu), y1 = (int)((by >> 16) & 0x7FFFu);   // bit 31 of each word is a flag
+                const int x0 = (int)(bx & 0x7FFFu), x1 = (int)((bx >> 16) & 0x7FFFu), y0 = (int)(by & 0xFFFFu), y1 = (int)((by >> 16) & 0x7FFFu);   // bits 15 and 31 of bbox_x, 31 of bbox_y are flags
                 if (x0 > x1 || x1 < tx0 || x0 > tx0 + (kRectW - 1) || y1 < ty0 || y0 > ty0 + (kRectH - 1)) continue;
                 const int ba = (max(x0, tx0) - tx0) >> 3, bb = (min(x1, tx0 + (kRectW - 1)) - tx0) >> 3, bc = (max(y0, ty0) - ty0) >> 3, bd = (min(y1, ty0 + (kRectH - 1)) - ty0) >> 3;
                 for (int yy = bc; yy <= bd; yy++) for (int xx = ba; xx <= bb; xx++) atomicOr(&bitmap[yy * kFwdBW + xx][rr >> 5], 1u << (rr & 31u));

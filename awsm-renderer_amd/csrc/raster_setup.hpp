@@ -25,6 +25,7 @@ struct TriSetup {
     int minx, maxx, miny, maxy;   // inclusive, conservative, clamped to the target rect
     bool front;                   // @builtin(front_facing): counter-clockwise in NDC (FrontFace::Ccw)
     bool exact;                   // kind 0: a, b, c and every E at a pixel centre are integers below 2^49 (E can be stepped by adding: still exact)
+    bool small;                   // exact, and every |E| within 8 pixels of the triangle's bounding box is below 2^30: the walk may step in 32-bit integers
 };
 
 AWSM_DI bool finite4(float4 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w); }
@@ -68,6 +69,11 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
         const bool flip = A2 < 0;
         t.front = flip;
         t.exact = true;
+        {   // E_i(P) = a_i (Px - x_j) + b_i (Py - y_j) in sub-pixel units, |a_i|, |b_i| <= S (the extent), |P - v_j| <= S + 2048 within 8 pixels of the box:
+            // |E| <= 2 S (S + 2048) < 2^30 for S <= 21000 (82 pixels)
+            const int ext = max(max(max(x[0], x[1]), x[2]) - min(min(x[0], x[1]), x[2]), max(max(y[0], y[1]), y[2]) - min(min(y[0], y[1]), y[2]));
+            t.small = ext <= 21000;
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const int j = (i + 1) % 3, k = (i + 2) % 3;                       // weight of vertex i = edge j -> k
@@ -97,7 +103,7 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
         if (!(det != 0.0f) || !isfinite(det)) return false;
         if (cull_back && det > 0.0f) return false;      // y-down framebuffer: det < 0 <=> CCW on screen <=> front
         t.front = det < 0.0f;
-        t.exact = false;
+        t.exact = false; t.small = false;
         if (det < 0.0f) {
             a0 = -a0; b0 = -b0; c0 = -c0; a1 = -a1; b1 = -b1; c1 = -c1; a2 = -a2; b2 = -b2; c2 = -c2;
             det = -det;
@@ -123,14 +129,14 @@ struct alignas(16) TriRec {
     float zq[3];
     float iw[3];
     double c[3];
-    uint32_t bbox_x;   // minx | maxx << 16 | exact << 31   (inclusive, clamped to the target rect; frame width <= 16384)
+    uint32_t bbox_x;   // minx | small << 15 | maxx << 16 | exact << 31   (inclusive, clamped to the target rect; frame width <= 16384)
     uint32_t bbox_y;   // miny | maxy << 16 | front_facing << 31   (frame height <= 32768)
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
 AWSM_DI void tri_rec_store(TriRec* __restrict__ dst, const TriSetup& t, bool ok) {
     float4* q = reinterpret_cast<float4*>(dst);
-    const uint32_t bx = ok ? ((uint32_t)t.minx | ((uint32_t)t.maxx << 16) | (t.exact ? 0x80000000u : 0u)) : 1u;   // minx 1 > maxx 0
+    const uint32_t bx = ok ? ((uint32_t)t.minx | (t.small ? 0x8000u : 0u) | ((uint32_t)t.maxx << 16) | (t.exact ? 0x80000000u : 0u)) : 1u;   // minx 1 > maxx 0
     const uint32_t by = ok ? ((uint32_t)t.miny | ((uint32_t)t.maxy << 16) | (t.front ? 0x80000000u : 0u)) : 1u;
     q[0] = make_float4(t.a[0], t.a[1], t.a[2], t.b[0]);
     q[1] = make_float4(t.b[1], t.b[2], t.zq[0], t.zq[1]);
@@ -156,7 +162,7 @@ AWSM_DI bool tri_rec_unpack(const TriRecRaw& r, TriSetup& t) {
     t.zq[2] = r.q2.x; t.iw[0] = r.q2.y; t.iw[1] = r.q2.z; t.iw[2] = r.q2.w;
     t.c[0] = r.d3.x; t.c[1] = r.d3.y; t.c[2] = r.d4.x;
     const uint32_t bx = (uint32_t)__double2loint(r.d4.y), by = (uint32_t)__double2hiint(r.d4.y);
-    t.minx = (int)(bx & 0xFFFFu); t.maxx = (int)((bx >> 16) & 0x7FFFu); t.exact = (bx >> 31) != 0u; t.miny = (int)(by & 0xFFFFu); t.maxy = (int)((by >> 16) & 0x7FFFu);
+    t.minx = (int)(bx & 0x7FFFu); t.small = (bx & 0x8000u) != 0u; t.maxx = (int)((bx >> 16) & 0x7FFFu); t.exact = (bx >> 31) != 0u; t.miny = (int)(by & 0xFFFFu); t.maxy = (int)((by >> 16) & 0x7FFFu);
     t.front = (by >> 31) != 0u;
     return t.minx <= t.maxx;
 }
