@@ -25,7 +25,7 @@ struct TriSetup {
     int minx, maxx, miny, maxy;   // inclusive, conservative, clamped to the target rect
     bool front;                   // @builtin(front_facing): counter-clockwise in NDC (FrontFace::Ccw)
     bool exact;                   // kind 0: a, b, c and every E at a pixel centre are integers below 2^49 (E can be stepped by adding: still exact)
-    bool small;                   // exact, and every |E| within 8 pixels of the triangle's bounding box is below 2^30: the walk may step in 32-bit integers
+    bool small;                   // exact, and every |E| within 16 pixels of the triangle's bounding box is below 2^30: the walk may step in 32-bit integers
 };
 
 AWSM_DI bool finite4(float4 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w); }
@@ -69,8 +69,9 @@ AWSM_DI bool tri_setup(float4 v0, float4 v1, float4 v2, bool cull_back, uint32_t
         const bool flip = A2 < 0;
         t.front = flip;
         t.exact = true;
-        {   // E_i(P) = a_i (Px - x_j) + b_i (Py - y_j) in sub-pixel units, |a_i|, |b_i| <= S (the extent), |P - v_j| <= S + 2048 within 8 pixels of the box:
-            // |E| <= 2 S (S + 2048) < 2^30 for S <= 21000 (82 pixels)
+        {   // E_i(P) = a_i (Px - x_j) + b_i (Py - y_j) in sub-pixel units, |a_i|, |b_i| <= S (the extent), |P - v_j| <= S + 4096 within 16 pixels of
+            // the box (the walk's 8x8 blocks reach 7 pixels past it, and the stepped value one block further before the loop ends):
+            // |E| <= 2 S (S + 4096) = 1.054e9 < 2^30 for S <= 21000 (82 pixels)
             const int ext = max(max(max(x[0], x[1]), x[2]) - min(min(x[0], x[1]), x[2]), max(max(y[0], y[1]), y[2]) - min(min(y[0], y[1]), y[2]));
             t.small = ext <= 21000;
         }
