@@ -527,6 +527,53 @@ def test_reference_default_anti_aliasing_through_host_layer(oracle_lut):
 
 
 @pytest.mark.gpu
+def test_integer_raster_walk_around_its_size_limit(oracle_lut):
+    """k_raster_tile steps the edge functions of 'small' exact triangles (extent <= 21000 sub-pixels = 82 px, raster_setup.hpp) in 32-bit integers,
+    the others in f64.  900 random triangles whose screen extents straddle that limit (40 .. 130 px), at every screen position of a 1920x1080
+    frame including across its borders, double-sided, overlapping at random depths, a third of them sharing edges with a neighbour (top-left
+    rule): every key equals the oracle's (which knows one arithmetic only), single-sampled and — the f64 route for everything — with MSAA."""
+    import math
+    from awsm_renderer_amd.scene_desc import SceneDesc, NodeDesc, PrimitiveDesc, MaterialDesc
+    from awsm_renderer_amd.scenes import look_at_rh, perspective_rh, REPEAT_LINEAR, DEFAULT_LIGHTS
+    rng = np.random.default_rng(82)
+    W, H = 1920, 1080
+    fov = math.radians(50.0)
+    dist = 10.0
+    px_per_unit = (H / 2) / (math.tan(fov / 2) * dist)          # pixels per world unit on the plane z = 0
+    pos, idx = [], []
+    for k in range(900):
+        ext = rng.uniform(40.0, 130.0) / px_per_unit
+        c = np.array([rng.uniform(-1.05, 1.05) * (W / 2) / px_per_unit, rng.uniform(-1.05, 1.05) * (H / 2) / px_per_unit, rng.uniform(-2.0, 2.0)])
+        a = c + np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3)]) * ext
+        b = a + np.array([ext, rng.uniform(-1.0, 1.0) * ext * 0.5, rng.uniform(-0.3, 0.3) * ext])
+        d = a + np.array([rng.uniform(0.0, 1.0) * ext, rng.choice([-1.0, 1.0]) * rng.uniform(0.3, 1.0) * ext, rng.uniform(-0.3, 0.3) * ext])
+        o = len(pos)
+        pos += [a, b, d]
+        idx.append([o, o + 1, o + 2])
+        if k % 3 == 0:      # a neighbour across the edge a-b
+            e = a + b - d + np.array([0.0, 0.0, rng.uniform(-0.2, 0.2) * ext])
+            pos.append(e)
+            idx.append([o + 1, o, o + 3])
+    pos = np.array(pos, dtype=np.float32)
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (pos.shape[0], 1))
+    prim = PrimitiveDesc(positions=pos, normals=nrm, indices=np.array(idx, dtype=np.uint32), material=0)
+    eye = (0.0, 0.0, dist)
+    sc = SceneDesc(nodes=[NodeDesc(primitives=[prim])], materials=[MaterialDesc(base_color_factor=(0.7, 0.6, 0.5, 1.0), metallic_factor=0.0, double_sided=True)],
+                   samplers=[dict(REPEAT_LINEAR)], lights=list(DEFAULT_LIGHTS), width=W, height=H,
+                   view=look_at_rh(eye, (0, 0, 0)), proj=perspective_rh(fov, W / H, 0.1, 100.0), camera_position=eye)
+    model = helpers.build_model(sc)
+    from oracle import oracle_lib
+    for msaa in (0, 4):
+        fr = oracle_lib.frame_from_model(model, oracle_lut, msaa=msaa).transform().raster(16)
+        dev, _ = helpers.hip_frame(model, oracle_lut, msaa=msaa)
+        keys = dev.read_visibility()
+        assert keys.shape == fr.keys.shape
+        assert (keys == fr.keys).all(), (msaa, int((keys != fr.keys).sum()))
+        assert int((fr.keys != np.uint64(0xFFFFFFFFFFFFFFFF)).sum()) > 200000
+        dev.close()
+
+
+@pytest.mark.gpu
 def test_stream_handoff_flags_events_and_timeout_fallback(oracle_lut, monkeypatch):
     """The overlapped pipeline hands a frame from stream to stream through device-side flags (k_handoff_signal / k_handoff_wait) instead of
     cross-stream events.  48 frames with a moving camera, submitted without a synchronisation, each into its own image: bit-identical to a
