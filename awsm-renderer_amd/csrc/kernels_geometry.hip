@@ -604,8 +604,47 @@ AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, 
 // first pixel comes from the two FMAs once, converted, and rows and columns are integer adds.  The top-left rule is a bias: an edge that owns
 // its zero line accepts E >= 0, the others E >= 1, so with e = E - bias the pixel is covered when no e is negative — one OR3 and one compare
 // for the three f64 comparisons.  The depth is computed from (float)E as before: an integer converts to the same f32 from i32 as from f64.
-template <int STEP>
+// With four samples per pixel the stepped value is E at the pixel's corner and each sample adds its own constant, (a ox + b oy) / 256 — an integer,
+// a and b being multiples of 256 — so a sample costs three adds, the OR3 and the compare where it cost six f64 FMAs and three f64 comparisons.
+template <int S, int STEP>
 AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
+    if (S == 4) {
+        const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx), Y0 = (double)(tpy + (y0 & ~(STEP - 1)) + ly);
+        int e[3], bias[3], sx[3], sy[3], d[4][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            bias[i] = (t.a[i] > 0.0f || (t.a[i] == 0.0f && t.b[i] > 0.0f)) ? 0 : 1;
+            e[i] = (int)fma((double)t.a[i], X0, fma((double)t.b[i], Y0, t.c[i])) - bias[i];
+            sx[i] = (int)t.a[i] * STEP; sy[i] = (int)t.b[i] * STEP;
+            const int ai = (int)t.a[i] >> 8, bi = (int)t.b[i] >> 8;      // exact: multiples of 256
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k][i] = ai * msaa4_x(k) + bi * msaa4_y(k);
+        }
+        for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
+            const int py = by + ly;
+            int r0 = e[0], r1 = e[1], r2 = e[2];
+            for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+                const int px = bx + lx;
+                if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
+                        if ((q0 | q1 | q2) >= 0) {
+                            const float e0 = (float)(q0 + bias[0]), e1 = (float)(q1 + bias[1]), e2 = (float)(q2 + bias[2]);
+                            float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
+                            if (zn >= 0.0f && zn <= 1.0f) {
+                                if (zn == 0.0f) zn = 0.0f;
+                                atomicMin(&keys[(py * kTile + px) * 4 + k], ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - r));
+                            }
+                        }
+                    }
+                }
+                r0 += sx[0]; r1 += sx[1]; r2 += sx[2];
+            }
+            e[0] += sy[0]; e[1] += sy[1]; e[2] += sy[2];
+        }
+        return;
+    }
     const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5, Y0 = (double)(tpy + (y0 & ~(STEP - 1)) + ly) + 0.5;
     int e[3], bias[3], sx[3], sy[3];
 #pragma unroll
@@ -635,7 +674,7 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
 
 template <int S, int STEP>
 AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
-    if (S == 1 && t.small) { raster_walk_i32<STEP>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r); return; }
+    if (t.small) { raster_walk_i32<S, STEP>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r); return; }
     if (S == 1 && t.exact) {
         const double step[3] = {(double)t.a[0] * (double)STEP, (double)t.a[1] * (double)STEP, (double)t.a[2] * (double)STEP};
         const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5;

@@ -531,7 +531,7 @@ def test_integer_raster_walk_around_its_size_limit(oracle_lut):
     """k_raster_tile steps the edge functions of 'small' exact triangles (extent <= 21000 sub-pixels = 82 px, raster_setup.hpp) in 32-bit integers,
     the others in f64.  900 random triangles whose screen extents straddle that limit (40 .. 130 px), at every screen position of a 1920x1080
     frame including across its borders, double-sided, overlapping at random depths, a third of them sharing edges with a neighbour (top-left
-    rule): every key equals the oracle's (which knows one arithmetic only), single-sampled and — the f64 route for everything — with MSAA."""
+    rule): every key equals the oracle's (which knows one arithmetic only), single-sampled and with MSAA (per-sample constants on the same integers)."""
     import math
     from awsm_renderer_amd.scene_desc import SceneDesc, NodeDesc, PrimitiveDesc, MaterialDesc
     from awsm_renderer_amd.scenes import look_at_rh, perspective_rh, REPEAT_LINEAR, DEFAULT_LIGHTS
