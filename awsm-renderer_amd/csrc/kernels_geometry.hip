@@ -653,20 +653,25 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
         e[i] = (int)fma((double)t.a[i], X0, fma((double)t.b[i], Y0, t.c[i])) - bias[i];
         sx[i] = (int)t.a[i] * STEP; sy[i] = (int)t.b[i] * STEP;      // a, b: integers times 256, below 2^23
     }
+    // a lane outside the box in y sits out the whole row of blocks: the row test folds into the sign test as an all-ones word
+    const uint32_t dx = (uint32_t)(x1 - x0);
+    const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
     for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
         const int py = by + ly;
+        const int row_out = (py >= y0 && py <= y1) ? 0 : -1;
         int r0 = e[0], r1 = e[1], r2 = e[2];
+        uint32_t ux = (uint32_t)((x0 & ~(STEP - 1)) + lx - x0);      // px - x0 as unsigned: one compare for both sides of the box
+        unsigned long long* row = keys + py * kTile + x0;
         for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
-            const int px = bx + lx;
-            if (px >= x0 && px <= x1 && py >= y0 && py <= y1 && (r0 | r1 | r2) >= 0) {
+            if (ux <= dx && (r0 | r1 | r2 | row_out) >= 0) {
                 const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
                 float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
                 if (zn >= 0.0f && zn <= 1.0f) {
                     if (zn == 0.0f) zn = 0.0f;
-                    atomicMin(&keys[py * kTile + px], ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - r));
+                    atomicMin(&row[ux], ((unsigned long long)__float_as_uint(zn) << 32) | key_lo);
                 }
             }
-            r0 += sx[0]; r1 += sx[1]; r2 += sx[2];
+            r0 += sx[0]; r1 += sx[1]; r2 += sx[2]; ux += (uint32_t)STEP;
         }
         e[0] += sy[0]; e[1] += sy[1]; e[2] += sy[2];
     }
