@@ -572,6 +572,17 @@ struct WorkTri {
     uint32_t exact;  // 0: edge values by FMA per sample; 1: TriSetup::exact (stepped in f64); 2: TriSetup::small (stepped in 32-bit integers)
 };
 static_assert(sizeof(WorkTri) == 72, "WorkTri");
+// A `small` mid triangle of a single-sampled frame, set up for the integer walk by the thread that classified it (one pass over the batch,
+// instead of once per 16-lane group inside the walk phase): e = E - bias at the centre of the first pixel of its first 4x4 block, the
+// per-pixel steps.  Same size as WorkTri, rank / bbox / exact (= 2) at the same offsets.
+struct WorkSmall {
+    int e[3], a[3], b[3];
+    float zq[3];
+    uint32_t bias;   // bit i: edge i does not own its zero line (accepts E >= 1)
+    uint32_t pad[2];
+    uint32_t rank, bbox, exact;
+};
+static_assert(sizeof(WorkSmall) == sizeof(WorkTri) && offsetof(WorkSmall, rank) == offsetof(WorkTri, rank) && offsetof(WorkSmall, exact) == offsetof(WorkTri, exact), "WorkSmall");
 
 AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 #pragma unroll
@@ -677,6 +688,42 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
     }
 }
 
+// raster_walk_i32<1, 4> from a WorkSmall record
+AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int lx, int ly) {
+    const uint32_t bb = g.bbox, r = g.rank, bw = g.bias;
+    const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+    int e[3], bias[3], sx[3], sy[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int a = g.a[i], b = g.b[i];      // |.| < 2^23
+        bias[i] = (int)((bw >> i) & 1u);
+        e[i] = g.e[i] + __mul24(lx, a) + __mul24(ly, b);
+        sx[i] = a << 2; sy[i] = b << 2;
+    }
+    const float zq0 = g.zq[0], zq1 = g.zq[1], zq2 = g.zq[2];
+    const uint32_t dx = (uint32_t)(x1 - x0);
+    const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
+    for (int by = y0 & ~3; by <= y1; by += 4) {
+        const int py = by + ly;
+        const int row_out = (py >= y0 && py <= y1) ? 0 : -1;
+        int r0 = e[0], r1 = e[1], r2 = e[2];
+        uint32_t ux = (uint32_t)((x0 & ~3) + lx - x0);
+        unsigned long long* row = keys + py * kTile + x0;
+        for (int bx = x0 & ~3; bx <= x1; bx += 4) {
+            if (ux <= dx && (r0 | r1 | r2 | row_out) >= 0) {
+                const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
+                float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
+                if (zn >= 0.0f && zn <= 1.0f) {
+                    if (zn == 0.0f) zn = 0.0f;
+                    atomicMin(&row[ux], ((unsigned long long)__float_as_uint(zn) << 32) | key_lo);
+                }
+            }
+            r0 += sx[0]; r1 += sx[1]; r2 += sx[2]; ux += 4u;
+        }
+        e[0] += sy[0]; e[1] += sy[1]; e[2] += sy[2];
+    }
+}
+
 template <int S, int STEP>
 AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
     if (t.small) { raster_walk_i32<S, STEP>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r); return; }
@@ -759,11 +806,26 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                             for (int px = x0; px <= x1; px++) raster_pixel<S>(keys, t, tpx, tpy, px - tpx, py - tpy, r);
                     } else {
                         const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : 255u - atomicAdd(&n_big, 1u);
-                        WorkTri& g = work[slot];
+                        const uint32_t bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
+                        if (S == 1 && area <= 256 && t.small) {
+                            WorkSmall& g = reinterpret_cast<WorkSmall&>(work[slot]);
+                            const double X = (double)(tpx + ((x0 - tpx) & ~3)) + 0.5, Y = (double)(tpy + ((y0 - tpy) & ~3)) + 0.5;
+                            uint32_t bw = 0u;
 #pragma unroll
-                        for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
-                        g.rank = r; g.exact = t.small ? 2u : (t.exact ? 1u : 0u);
-                        g.bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
+                            for (int i = 0; i < 3; i++) {
+                                const int bias = (t.a[i] > 0.0f || (t.a[i] == 0.0f && t.b[i] > 0.0f)) ? 0 : 1;
+                                g.e[i] = (int)fma((double)t.a[i], X, fma((double)t.b[i], Y, t.c[i])) - bias;
+                                g.a[i] = (int)t.a[i]; g.b[i] = (int)t.b[i]; g.zq[i] = t.zq[i];
+                                bw |= (uint32_t)bias << i;
+                            }
+                            g.bias = bw; g.rank = r; g.bbox = bbox; g.exact = 2u;
+                        } else {
+                            WorkTri& g = work[slot];
+#pragma unroll
+                            for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
+                            g.rank = r; g.exact = (t.small && !(S == 1 && area <= 256)) ? 2u : (t.exact ? 1u : 0u);
+                            g.bbox = bbox;
+                        }
                     }
                 }
             }
@@ -778,11 +840,14 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
             const int lx = (int)(tid & 3u), ly = (int)((tid >> 2) & 3u);
             for (uint32_t j = group; j < nm; ) {
                 const WorkTri& g = work[j];
+                if (S == 1 && g.exact == 2u) raster_walk_small(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly);      // (every mid entry marked 2 is a WorkSmall)
+                else {
                 TriSetup t;
                 load_work_tri(g, t);
                 const uint32_t bb = g.bbox, r = g.rank;
                 const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
                 raster_walk<S, 4>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r);
+                }
                 uint32_t nx = 0u;
                 if ((tid & 15u) == 0u) nx = atomicAdd(&next_mid, 1u);
                 j = (uint32_t)__shfl((int)nx, 0, 16);
