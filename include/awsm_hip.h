@@ -305,7 +305,9 @@ int awsm_hip_visibility_digest(AwsmHipCtx* ctx, uint64_t* out2);
  * producer stream stores the frame's serial number, a one-lane kernel at the head of the consumer stream polls it: ~2 us instead of the
  * 20-30 us a cross-stream hipEvent takes to release the waiting queue), 0 = hipEvents (contexts without overlap; AWSM_DEVICE_HANDOFF=0 in
  * the environment; the probe at create found that kernels of two streams do not run side by side, e.g. under a counter-collecting
- * profiler; or a gate timed out later, which awsm_hip_frame_end reports once with AWSM_ERR_DEVICE).  Negative = AWSM_ERR_*. */
+ * profiler; or a gate timed out later, which awsm_hip_frame_end reports once with AWSM_ERR_DEVICE).  Negative = AWSM_ERR_*.
+ * Environment, read at create: AWSM_DEVICE_HANDOFF=0 (events from the start), AWSM_HANDOFF_POLLS=n (a gate's poll budget, default 2^20 ~ 2 s),
+ * AWSM_TEST_HANDOFF_DROP=n (tests: withhold the first n geometry-done signals to exercise the timeout path). */
 int awsm_hip_stream_handoff(AwsmHipCtx* ctx);
 /* test aid: the G-buffer texel fs_main would have written for every pixel of the last geometry pass (fragment.wgsl:23-54) as the opaque pass
  * reconstructs it — 6 floats / pixel: normal_tangent RGBA16F and barycentric RG16F, each already rounded to f16; zeros where nothing was hit.
