@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,7 @@ void awsm_launch_shade(const DevScene* sc, const FrameDev* f, hipStream_t s);
 int awsm_shade_is_lean(const FrameDev* f);
 int awsm_launch_shade_todo(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_gbuffer_dump(const FrameDev* f, float* out, hipStream_t s);
-void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, hipStream_t s);
+void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, unsigned long long* stamp, hipStream_t s);
 void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
@@ -70,6 +71,8 @@ struct FrameBufs {
     DevBuf tile_split, raster_scratch;     // split raster tiles: per-tile {first scratch slot, slices done}; partial tiles (geometry pass only)
     uint32_t raster_extra_cap = 0, raster_slot_cap = 0;
     uint32_t bin_capacity = 0;
+    size_t tri_cap = 0, draw_cap = 0;      // triangles / draws the per-pass buffers below are sized for (reserve_pass_buffers)
+    uint32_t sized_w = 0, sized_h = 0;     // ... and the frame size their tile tables are sized for
     std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
     void* draws_uploaded_ptr = nullptr;
     bool draws_uploaded_valid = false;
@@ -164,6 +167,11 @@ struct AwsmHipCtx {
 
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid[EV_COUNT] = {};
+
+    // frame trace (awsm_hip_frame_trace): device-clock stamps [3][trace_cap] — geometry pass begins / geometry pass done / shading done —
+    // of frame `serial` at index serial % trace_cap, written by one-lane kernels in stream order (the hand-off's signal kernels where they exist)
+    unsigned long long* trace_dev = nullptr;
+    uint32_t trace_cap = 0;
 };
 
 namespace {
@@ -173,9 +181,11 @@ inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade
 inline int n_slots(const AwsmHipCtx* c) { return c->overlap ? kSlots : 1; }
 inline int prev_slot(const AwsmHipCtx* c) { return (c->slot + kSlots - 1) % kSlots; }
 inline uint32_t* handoff_timeouts(AwsmHipCtx* c) { return c->counters_host + 16 + 2 * kSlots; }
+inline unsigned long long* trace_slot(AwsmHipCtx* c, int which) { return c->trace_dev ? c->trace_dev + (size_t)which * c->trace_cap + c->frame_serial % c->trace_cap : nullptr; }
 // the slot's shading is finished: for the host and the rarely taken waits an event, for the next user of the slot's buffers the flag
 inline hipError_t mark_shade_done(AwsmHipCtx* c, hipStream_t ss) {
-    if (c->handoff) awsm_launch_handoff_signal(c->handoff_flags + kSlots + c->slot, ++c->shade_sig[c->slot], ss);
+    if (c->handoff) awsm_launch_handoff_signal(c->handoff_flags + kSlots + c->slot, ++c->shade_sig[c->slot], trace_slot(c, 2), ss);
+    else if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 2), ss);
     const hipError_t e = hipEventRecord(c->ev_shade_done[c->slot], ss);
     c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true;
     return e;
@@ -201,6 +211,22 @@ inline hipError_t sync_shade_streams(AwsmHipCtx* c) {
     for (bool& b : c->shade_recorded) b = false;
     return hipSuccess;
 }
+
+// AWSM_HOST_TRACE=<microseconds>: report (stderr) every section of an enqueue call that kept the host longer than that — the HIP runtime
+// growing a pool, a full queue, a synchronisation nobody asked for.  Diagnostic; off by default.
+struct HostTrace {
+    static long threshold() { static long t = [] { const char* e = getenv("AWSM_HOST_TRACE"); return e ? atol(e) : 0L; }(); return t; }
+    timespec last{};
+    uint32_t serial;
+    explicit HostTrace(uint32_t frame_serial) : serial(frame_serial) { if (threshold()) clock_gettime(CLOCK_MONOTONIC, &last); }
+    void mark(const char* what) {
+        if (!threshold()) return;
+        timespec now; clock_gettime(CLOCK_MONOTONIC, &now);
+        const long us = (now.tv_sec - last.tv_sec) * 1000000L + (now.tv_nsec - last.tv_nsec) / 1000L;
+        if (us >= threshold()) fprintf(stderr, "awsm_hip host trace: frame %u: %s took %ld us\n", serial, what, us);
+        last = now;
+    }
+};
 
 int fail(AwsmHipCtx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -407,11 +433,13 @@ bool resolve_stale(AwsmHipCtx* c, const FrameDev& f) {
 }
 
 int enqueue_geometry(AwsmHipCtx* c) {
+    HostTrace ht(c->frame_serial);
     FrameDev f;
     fill_frame(c, &f);
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     int rc = sync_scene(c);
     if (rc) return rc;
+    ht.mark("geometry: sync_scene");
     if (c->overlap) {
         // this slot's buffers were last read by the opaque pass kSlots frames ago (already ordered by awsm_hip_geometry_pass; a replay comes here directly)
         if (c->shade_pending[c->slot]) { HIPCHK(c, wait_slot_free(c)); c->shade_pending[c->slot] = false; }
@@ -428,28 +456,34 @@ int enqueue_geometry(AwsmHipCtx* c) {
         if (resolve_stale(c, f)) { HIPCHK(c, hipEventRecord(c->ev_uploads[c->slot], c->stream)); c->uploads_recorded[c->slot] = true; }
         c->geom_write_seq[c->slot] = c->write_seq;
     }
+    ht.mark("geometry: slot wait + upload event");
     const bool has_geometry = c->total_tris && n_tiles;
     if (!has_geometry) {   // otherwise k_deform_transform clears counters + tile_count and k_bin_scan clears tile_cursor
         HIPCHK(c, hipMemsetAsync(FB(c).counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 12, 0, 2 * sizeof(uint32_t), c->stream));
         if (n_tiles) HIPCHK(c, hipMemsetAsync(FB(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
     }
+    if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 0), c->stream);
     if ((rc = record(c, EV_START))) return rc;
     if (c->total_tris && n_tiles) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
     if ((rc = record(c, EV_TRANSFORM))) return rc;
+    ht.mark("geometry: transform launch");
     if (n_tiles) {
         if (c->total_tris) { awsm_launch_bin_count(&f, c->stream); awsm_launch_bin_big(&f, 0, c->stream); }
         awsm_launch_bin_scan(&f, c->stream);
         if (c->total_tris) { awsm_launch_bin_fill(&f, c->stream); awsm_launch_bin_big(&f, 1, c->stream); }
     }
     if ((rc = record(c, EV_BIN))) return rc;
+    ht.mark("geometry: bin launches");
     if (n_tiles) awsm_launch_raster(&f, c->stream);
     if ((rc = record(c, EV_RASTER))) return rc;
+    ht.mark("geometry: raster launch");
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
 
 int enqueue_opaque(AwsmHipCtx* c) {
+    HostTrace ht(c->frame_serial);
     FrameDev f;
     fill_frame(c, &f);
     f.has_opaque = c->last_opaque.has_opaque;
@@ -482,13 +516,15 @@ int enqueue_opaque(AwsmHipCtx* c) {
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_uploads[c->slot], 0));
         awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     }
+    ht.mark("opaque: sync_scene + early resolve");
     if (c->overlap) {   // the shade stream picks up where the caller's stream is now (geometry pass + uploads of this frame)
         if (c->handoff) {
             ++c->geom_sig[c->slot];
             if (c->handoff_test_drop) c->handoff_test_drop--;
-            else awsm_launch_handoff_signal(c->handoff_flags + c->slot, c->geom_sig[c->slot], c->stream);
+            else awsm_launch_handoff_signal(c->handoff_flags + c->slot, c->geom_sig[c->slot], trace_slot(c, 1), c->stream);
             awsm_launch_handoff_wait(c->handoff_flags + c->slot, c->geom_sig[c->slot], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, ss);
         } else {
+            if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 1), c->stream);
             HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
             HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
         }
@@ -505,6 +541,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
         if (c->shade_recorded[p]) HIPCHK(c, wait_prev_slot(c, ss, !(c->msaa != 0 || same_image)));
         c->slot_out_lo[c->slot] = lo; c->slot_out_hi[c->slot] = hi;
     }
+    ht.mark("opaque: hand-off launches");
     if (want_resolve && !early) awsm_launch_resolve_draws(c->scene_dev, &f, ss);
     if ((rc = record(c, EV_SHADE_BEGIN, ss))) return rc;      // after the resolve: ms_shade is the shading kernels alone
     c->ev_valid[EV_SHADE_LEAN] = false;
@@ -520,7 +557,10 @@ int enqueue_opaque(AwsmHipCtx* c) {
         (void)awsm_launch_shade_todo(c->scene_dev, &f, ss);
     }
     if ((rc = record(c, EV_SHADE, ss))) return rc;
+    ht.mark("opaque: shade launches");
     if (c->overlap) HIPCHK(c, mark_shade_done(c, ss));
+    else if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 2), ss);
+    ht.mark("opaque: shade-done signal + event");
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -660,9 +700,10 @@ int reserve_raster_items(AwsmHipCtx* c, FrameBufs& b, bool forward) {
     return AWSM_OK;
 }
 
-int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
+// Device state of one pass in one frame slot, sized for `tri_cap` triangles and `draw_cap` draws.
+int size_pass_buffers(AwsmHipCtx* c, FrameBufs& b, size_t tri_cap, size_t draw_cap, bool forward) {
     int rc;
-    const size_t nd = std::max<size_t>(draws_host.size(), 1), nv = std::max<size_t>(3ull * total_tris, 1), nt = std::max<size_t>(total_tris, 1);
+    const size_t nd = std::max<size_t>(draw_cap, 1), nv = std::max<size_t>(3 * tri_cap, 1), nt = std::max<size_t>(tri_cap, 1);
     if ((rc = dev_reserve(c, b.draws_dev, nd * sizeof(DrawDev)))) return rc;
     if ((rc = dev_reserve(c, b.draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
     if ((rc = dev_reserve(c, b.tex_slots, nd * kCoreTextures * sizeof(TexSlotDev)))) return rc;
@@ -683,8 +724,33 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
     if ((rc = dev_reserve(c, b.tile_cursor, n_tiles_full * 4))) return rc;
     if ((rc = dev_reserve(c, b.tile_split, n_tiles_full * 8))) return rc;
     if ((rc = dev_reserve(c, b.scan_tmp, (((n_tiles_full + 255) / 256) * 2 + 1) * 40 * 4))) return rc;      // kScanWords = 40: aggregates, bases, run starts (kernels_geometry.hip)
-    if ((rc = ensure_bin_capacity_of(c, b, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : std::max<uint32_t>(4u * total_tris + 65536u, 1u << 18)))) return rc;
+    if ((rc = ensure_bin_capacity_of(c, b, (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : (uint32_t)std::min<size_t>(std::max<size_t>(4 * tri_cap + 65536u, 1u << 18), 0xFFFFFFF0u)))) return rc;
     if ((rc = reserve_raster_items(c, b, forward))) return rc;
+    b.tri_cap = tri_cap; b.draw_cap = draw_cap; b.sized_w = c->width; b.sized_h = c->height;
+    return AWSM_OK;
+}
+
+// Per-pass device state for `draws_host` / total_tris; uploads the draw list when it changed.  A frame that fits what the slot was sized for
+// touches nothing (the common case: one comparison).  When it does not fit, EVERY frame slot of the pass is re-sized at once and with
+// headroom — a re-allocation synchronises all streams, so a camera move that un-culls a few more triangles every frame must not pay it
+// per frame and per slot (seen in round 2's driver run: frames 9, 10 and 13 of the process stalled the host for 2.1 / 1.8 / 0.9 ms, a third
+// of a 20-frame measurement).  Triangles: need + 25 % + 4096, but no more than the vertex buffer can hold when no draw is instanced
+// (then the pass can never outgrow its buffers again); draws: need + 25 % + 64.
+int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
+    int rc;
+    if (total_tris > b.tri_cap || draws_host.size() > b.draw_cap || b.sized_w != c->width || b.sized_h != c->height || !b.bin_list.ptr) {
+        bool instanced = false;
+        for (const DrawDev& d : draws_host) instanced |= (d.flags & kDrawInstanced) != 0;
+        const size_t tri_bound = forward || instanced ? ~size_t(0) : c->bufs[AWSM_BUF_VIS_GEOM_DATA].size / 168u;
+        const size_t tri_cap = std::max<size_t>(std::min<size_t>((size_t)total_tris + total_tris / 4 + 4096, std::max<size_t>(tri_bound, total_tris)), b.tri_cap);
+        const size_t draw_cap = std::max<size_t>(draws_host.size() + draws_host.size() / 4 + 64, b.draw_cap);
+        FrameBufs* set = forward ? c->tr : c->fb;
+        for (int sl = 0; sl < n_slots(c); sl++) {
+            // (the slot in use first: if memory runs out half-way the current frame still has its buffers)
+            FrameBufs& t = set[(c->slot + sl) % kSlots];
+            if ((rc = size_pass_buffers(c, t, std::max(tri_cap, t.tri_cap), std::max(draw_cap, t.draw_cap), forward))) return rc;
+        }
+    }
     // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
     // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
     const bool same_draws = b.draws_uploaded_valid && b.draws_uploaded_ptr == b.draws_dev.ptr && b.draws_uploaded.size() == draws_host.size() &&
@@ -779,7 +845,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             hipStream_t ss = c->shade_streams[k % kSlots], waiter = k < kSlots ? ss : c->stream, setter = k < kSlots ? c->stream : ss;
             const uint32_t serial = ++c->geom_sig[0];
             awsm_launch_handoff_wait(c->handoff_flags, serial, 1u << 13, handoff_timeouts(c), 0u, waiter);
-            awsm_launch_handoff_signal(c->handoff_flags, serial, setter);
+            awsm_launch_handoff_signal(c->handoff_flags, serial, nullptr, setter);
             if (hipStreamSynchronize(waiter) != hipSuccess || hipStreamSynchronize(setter) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             if (*(volatile uint32_t*)handoff_timeouts(c) != 0u) { c->handoff = false; c->handoff_timeouts_seen = *(volatile uint32_t*)handoff_timeouts(c); }
         }
@@ -812,6 +878,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
     if (c->handoff_flags) (void)hipFree(c->handoff_flags);
+    if (c->trace_dev) (void)hipFree(c->trace_dev);
     for (int i = 0; i < EV_COUNT; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1084,10 +1151,12 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     HIPCHK(c, hipSetDevice(c->device));
 
     // validate before touching any per-frame state: a failed call leaves the previous frame (and its slot) current
+    HostTrace ht(c->frame_serial + 1u);
     std::vector<DrawDev> new_draws;
     uint64_t tris = 0, blocks = 0;
     int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, new_draws, &tris, &blocks);
     if (rc) return rc;
+    ht.mark("geometry_pass: draw list");
     if (c->overlap) {
         if (c->handoff && *(volatile uint32_t*)handoff_timeouts(c) != c->handoff_timeouts_seen) c->handoff = false;      // reported by the next awsm_hip_frame_end
         c->slot = (c->slot + 1) % kSlots;    // the opaque passes of the previous frames may still be reading the other slots
@@ -1099,6 +1168,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
             c->shade_pending[c->slot] = false;
         }
     }
+    ht.mark("geometry_pass: slot-free wait");
     c->draws_api.assign(draws, draws + n);
     c->draws_host.swap(new_draws);
     c->frame_serial++;
@@ -1121,7 +1191,9 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
             }
     }
     c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
+    ht.mark("geometry_pass: bin capacity");
     if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
+    ht.mark("geometry_pass: reserve + draw-list upload");
     if ((rc = enqueue_geometry(c))) return rc;
     c->geometry_done = true; c->opaque_done = false; c->transparent_done = false;
     return AWSM_OK;
@@ -1189,6 +1261,35 @@ int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) 
 int awsm_hip_set_stage_timers(AwsmHipCtx* c, int enabled) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     c->stage_timers = enabled != 0;
+    return AWSM_OK;
+}
+
+int awsm_hip_frame_trace(AwsmHipCtx* c, uint32_t capacity) {
+    if (!c || capacity > (1u << 20)) return AWSM_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    if (c->trace_dev) { HIPCHK(c, hipFree(c->trace_dev)); c->trace_dev = nullptr; c->trace_cap = 0; }
+    if (!capacity) return AWSM_OK;
+    HIPCHK(c, hipMalloc((void**)&c->trace_dev, (size_t)3 * capacity * 8));
+    HIPCHK(c, hipMemset(c->trace_dev, 0, (size_t)3 * capacity * 8));
+    c->trace_cap = capacity;
+    return AWSM_OK;
+}
+
+int awsm_hip_read_frame_trace(AwsmHipCtx* c, uint64_t* ticks_out, uint32_t n_frames, uint32_t* last_serial_out, uint32_t* ticks_per_ms_out) {
+    if (!c || !ticks_out) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->trace_dev) return fail(c, AWSM_ERR_NOT_READY, "read_frame_trace: tracing is off (awsm_hip_frame_trace)");
+    if (n_frames == 0 || n_frames > c->trace_cap) return fail(c, AWSM_ERR_OUT_OF_RANGE, "read_frame_trace: %u frames asked, the ring holds %u", n_frames, c->trace_cap);
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcs = sync_all(c); if (rcs) return rcs; }
+    std::vector<uint64_t> ring((size_t)3 * c->trace_cap);
+    HIPCHK(c, hipMemcpy(ring.data(), c->trace_dev, ring.size() * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_frames; i++) {      // oldest first: frames serial - n + 1 .. serial
+        const uint32_t serial = c->frame_serial - (n_frames - 1u - i);
+        for (int w = 0; w < 3; w++) ticks_out[(size_t)i * 3 + w] = ring[(size_t)w * c->trace_cap + serial % c->trace_cap];
+    }
+    if (last_serial_out) *last_serial_out = c->frame_serial;
+    if (ticks_per_ms_out) { int khz = 0; *ticks_per_ms_out = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0 ? (uint32_t)khz : 100000u; }
     return AWSM_OK;
 }
 

@@ -972,8 +972,11 @@ __global__ __launch_bounds__(256) void k_gen_mip_level(uint32_t* __restrict__ ch
 // falls back to events (awsm_hip_frame_end reports the frame).  Gates enqueued before the host noticed see the count differ from the one they
 // were enqueued with and give up after a few polls, so a run-ahead host costs one timeout, not one per queued frame.  awsm_hip_create probes the
 // mechanism on the context's own streams first and leaves it off when a gate and its signal do not run side by side.
-__global__ __launch_bounds__(64) void k_handoff_signal(uint32_t* flag, uint32_t serial) {
-    if (threadIdx.x == 0) st_sc1(flag, serial);
+// `stamp` (frame trace, awsm_hip_frame_trace): the constant-rate device clock at the moment the producer stream reached this point.
+__global__ __launch_bounds__(64) void k_handoff_signal(uint32_t* flag, uint32_t serial, unsigned long long* stamp) {
+    if (threadIdx.x != 0) return;
+    if (stamp) *stamp = wall_clock64();
+    if (flag) st_sc1(flag, serial);
 }
 __global__ __launch_bounds__(64) void k_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known) {
     if (threadIdx.x != 0) return;
@@ -998,8 +1001,8 @@ extern "C" void awsm_launch_upload_words(void* dst, const void* src_pinned, uint
 }
 
 // ---- launch wrappers (called from awsm_hip.cpp) ----
-extern "C" void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, hipStream_t s) {
-    hipLaunchKernelGGL(awsm::k_handoff_signal, dim3(1), dim3(64), 0, s, flag, serial);
+extern "C" void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, unsigned long long* stamp, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_handoff_signal, dim3(1), dim3(64), 0, s, flag, serial, stamp);
 }
 extern "C" void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_handoff_wait, dim3(1), dim3(64), 0, s, flag, serial, max_polls, timeouts_host, timeouts_known);

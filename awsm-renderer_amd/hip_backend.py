@@ -30,7 +30,8 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_frame_end", "awsm_hip_frame_flush", "awsm_hip_read_gbuffer", "awsm_hip_stream_handoff", "awsm_hip_bind_output", "awsm_hip_output_device_ptr", "awsm_hip_read_visibility",
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
-           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload", "awsm_hip_bind_opaque_source", "awsm_hip_msaa_halo_bands", "awsm_hip_msaa_halo_export", "awsm_hip_msaa_halo_bind"]
+           "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload", "awsm_hip_bind_opaque_source", "awsm_hip_msaa_halo_bands", "awsm_hip_msaa_halo_export", "awsm_hip_msaa_halo_bind",
+           "awsm_hip_frame_trace", "awsm_hip_read_frame_trace"]
 
 
 class AwsmConfig(C.Structure):
@@ -128,6 +129,8 @@ def load_library():
     lib.awsm_hip_msaa_halo_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.awsm_hip_msaa_halo_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.awsm_hip_read_transformed_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.awsm_hip_frame_trace.argtypes = [C.c_void_p, C.c_uint32]
+    lib.awsm_hip_read_frame_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -299,6 +302,18 @@ class HipDevice:
     def frame_flush(self):
         """Order everything enqueued so far (incl. overlapped opaque passes) before later work on the caller's stream."""
         self._chk(self.lib.awsm_hip_frame_flush(self.ctx), "frame_flush")
+
+    def frame_trace(self, capacity: int):
+        """Device-clock stamps per frame (geometry begins / geometry done / shading done) in a ring of `capacity` frames; 0 = off."""
+        self._chk(self.lib.awsm_hip_frame_trace(self.ctx, capacity), "frame_trace")
+
+    def read_frame_trace(self, n_frames: int):
+        """-> (ms[n_frames, 3] relative to the first stamp of the oldest frame, serial of the newest frame); synchronises."""
+        ticks = np.zeros((n_frames, 3), dtype=np.uint64)
+        serial, rate = C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.awsm_hip_read_frame_trace(self.ctx, ticks.ctypes.data_as(C.c_void_p), n_frames, C.byref(serial), C.byref(rate)), "read_frame_trace")
+        t0 = int(ticks[ticks > 0].min()) if (ticks > 0).any() else 0
+        return (ticks.astype(np.int64) - t0) / float(rate.value), int(serial.value)
 
     def bind_output(self, device_ptr: Optional[int], nbytes: int = 0):
         self._chk(self.lib.awsm_hip_bind_output(self.ctx, device_ptr, nbytes), "bind_output")

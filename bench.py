@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4), help="BASELINE.json config: 4 = configs[3] the 4K Sponza-class frame (the metric's), "
                     "2 = configs[1] helmet-class 15k triangles / 2048^2 textures at 1920x1080, 3 = configs[2] skinned rig + morph cube at 1920x1080")
     ap.add_argument("--static-camera", action="store_true", help="re-submit the same camera every step (default: a small orbit, so cull / sort / draw-list upload run)")
+    ap.add_argument("--trace", action="store_true", help="add `frame_trace` to the JSON line: per frame of warm-up + timed loop the host time at which step() returned and the "
+                    "device-clock times of geometry begin / geometry done / shading done (awsm_hip_frame_trace), ms from the first")
     ap.add_argument("--allow-variant-lib", action="store_true", help="accept an AWSM_HIP_LIB override (A/B builds); the path is printed in the JSON line")
     args = ap.parse_args()
     if os.environ.get("AWSM_HIP_LIB") and not args.allow_variant_lib:
@@ -335,22 +337,43 @@ def main():
     # frames/s depending on an unrelated command-line flag).  The loop itself allocates a few tuples per step.
     import gc
 
+    host_t = []                            # --trace: perf_counter at every step() return (and around the barriers)
+
     def timed_loop():
         gc.collect()
         gc.disable()
+        del host_t[:]
+        if args.trace:
+            dev.frame_trace(args.warmup + args.steps + 8)
+        host_t.append(("loop_begin", time.perf_counter()))
         for _ in range(args.warmup):
             step()
+            if args.trace:
+                host_t.append(("w", time.perf_counter()))
         barrier()
         t0 = time.perf_counter()
+        host_t.append(("t0", t0))
         for _ in range(args.steps):
             step()
+            if args.trace:
+                host_t.append(("s", time.perf_counter()))
+        host_t.append(("enqueued", time.perf_counter()))
         barrier()
         dt = time.perf_counter() - t0
+        host_t.append(("t1", t0 + dt))
         gc.enable()
         return dt
 
     handoff_mode = dev.stream_handoff()
     dt = timed_loop()
+    frame_trace = None
+    if args.trace:
+        dev_ms, _ = dev.read_frame_trace(args.warmup + args.steps)
+        base = host_t[0][1]
+        frame_trace = {"host_ms": [[k, round((t - base) * 1e3, 4)] for k, t in host_t],
+                       "device_ms_geometry_begin_done_shade_done": [[round(float(x), 4) for x in row] for row in dev_ms],
+                       "note": "host and device clocks have different origins: compare intervals, not instants"}
+        dev.frame_trace(0)
     # A device-side hand-off gate that gave up during the loop (kernels of two streams not running side by side: a profiler that serialises
     # them attached after the context's probe, a hardware queue shared with a stream created later) leaves frames that may be incomplete and
     # the context on events: the measurement is then repeated, on events, and the line says so.
@@ -481,6 +504,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             **({"check": check} if check else {}),
+            **({"frame_trace": frame_trace} if frame_trace else {}),
         }
         print(json.dumps(out))
     dev.close()

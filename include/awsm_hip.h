@@ -274,6 +274,14 @@ int awsm_hip_frame_end(AwsmHipCtx* ctx, AwsmFrameStats* out);
  * tracing spans around command encoding, render.rs:150-320). */
 int awsm_hip_set_stage_timers(AwsmHipCtx* ctx, int enabled);
 
+/* Frame trace (measurement aid; the reference's counterpart are the tracing spans of render.rs:150-320): with capacity > 0 every frame
+ * leaves three device-clock stamps in a ring of `capacity` frames — geometry pass begins, geometry pass done, shading (+ transparent pass)
+ * done — written in stream order by one-lane kernels (the hand-off's own signal kernels where the pipeline has them: no extra launch on
+ * the critical path).  capacity = 0 turns it off.  read_frame_trace synchronises and returns the last n_frames frames, oldest first, as
+ * ticks_out[n_frames][3] in ticks of the constant-rate device clock (ticks_per_ms_out), plus the serial number of the newest frame. */
+int awsm_hip_frame_trace(AwsmHipCtx* ctx, uint32_t capacity);
+int awsm_hip_read_frame_trace(AwsmHipCtx* ctx, uint64_t* ticks_out, uint32_t n_frames, uint32_t* last_serial_out, uint32_t* ticks_per_ms_out);
+
 /* ---- frame loop without a host sync (bench / multi-frame pipelines): enqueue only. ---- */
 int awsm_hip_frame_flush(AwsmHipCtx* ctx);
 
