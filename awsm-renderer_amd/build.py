@@ -8,6 +8,7 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+import sys
 
 from . import PACKAGE_DIR
 
@@ -22,15 +23,25 @@ def _run_make(directory: str, target: str, env=None):
     return proc.stdout
 
 
-def build_hip(jobs: int = 3) -> str:
+def build_hip(jobs: int = 3, arch: str = "gfx950") -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libawsm_hip.so cannot be built and there is no CPU fallback")
-    proc = subprocess.run(["make", "-C", os.path.join(PACKAGE_DIR, "csrc"), f"-j{jobs}", "../libawsm_hip.so", f"HIPCC={hipcc}"],
+    proc = subprocess.run(["make", "-C", os.path.join(PACKAGE_DIR, "csrc"), f"-j{jobs}", "../libawsm_hip.so", f"HIPCC={hipcc}", f"ARCH={arch}"],
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc build failed:\n{proc.stdout[-4000:]}")
-    check_register_budgets(hipcc)
+    # The register budgets are a performance property of the overlapped pipeline, not a correctness one: over budget the library is slower,
+    # not wrong.  A build reports them (stderr) and goes on; AWSM_STRICT_VGPR=1 (what this repo's own rounds build with) turns a miss into an error.
+    try:
+        over = check_register_budgets(hipcc, arch)
+    except (OSError, subprocess.CalledProcessError) as e:      # llvm-objcopy / clang-offload-bundler / llvm-readelf missing or changed
+        print(f"awsm-renderer_amd build: VGPR budgets not checked ({e})", file=sys.stderr)
+        over = []
+    for line in over:
+        print("awsm-renderer_amd build: " + line, file=sys.stderr)
+    if over and os.environ.get("AWSM_STRICT_VGPR") == "1":
+        raise RuntimeError("VGPR budgets exceeded (AWSM_STRICT_VGPR=1):\n" + "\n".join(over))
     return os.path.join(PACKAGE_DIR, "libawsm_hip.so")
 
 
@@ -42,26 +53,29 @@ VGPR_BUDGETS = {"kernels_shade.o": {"k_shade_leanILb0E": 80, "k_shade_todo": 112
                                        "k_handoff_signal": 32, "k_handoff_wait": 32}}
 
 
-def check_register_budgets(hipcc: str) -> None:
+def check_register_budgets(hipcc: str, arch: str = "gfx950") -> list:
+    """-> one line per kernel over its budget (empty: all within)."""
     import re
     import tempfile
     llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin")
     if not os.path.exists(os.path.join(llvm, "llvm-objcopy")):
         llvm = "/opt/rocm/lib/llvm/bin"
+    over = []
     with tempfile.TemporaryDirectory() as tmp:
         for obj, budgets in VGPR_BUDGETS.items():
             fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "code.co")
             subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", os.path.join(PACKAGE_DIR, "csrc", obj)])
-            subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
+            subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{arch}", f"--input={fat}", f"--output={co}"])
             notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, text=True, check=True).stdout
             found = dict(re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", notes))
             for key, budget in budgets.items():
                 hits = {n: int(v) for n, v in found.items() if key in n}
                 if not hits:
-                    raise RuntimeError(f"{obj}: no kernel matching {key} in the code object")
+                    over.append(f"{obj}: no kernel matching {key} in the code object (budget list out of date?)")
                 for n, v in hits.items():
                     if v > budget:
-                        raise RuntimeError(f"{obj}: {n} uses {v} VGPRs, more than the {budget} it may use to be placed beside k_shade_lean")
+                        over.append(f"{obj}: {n} uses {v} VGPRs, more than the {budget} it may use to be placed beside k_shade_lean (slower overlap, same results)")
+    return over
 
 
 def build_host() -> str:

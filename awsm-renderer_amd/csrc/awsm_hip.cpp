@@ -35,7 +35,8 @@ int awsm_shade_is_lean(const FrameDev* f);
 int awsm_launch_shade_todo(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_gbuffer_dump(const FrameDev* f, float* out, hipStream_t s);
 void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, unsigned long long* stamp, hipStream_t s);
-void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known, hipStream_t s);
+void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, unsigned long long budget_ticks, uint32_t* timeouts_host, uint32_t timeouts_known,
+                              uint32_t* poison, uint32_t poison_serial, hipStream_t s);
 void awsm_launch_resolve_draws(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
 void awsm_launch_msaa_halo_export(const FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s);
@@ -123,6 +124,7 @@ struct AwsmHipCtx {
     // recomputed only when that changed — a frame that moved nothing but the camera reuses them (no kernel, no event).
     struct ResolveKey { uint64_t write_seq, draws_version; const void* ptrs[5]; uint32_t n_draws, mipmap, has_opaque, lights_cap; } resolved[kSlots] = {};   // ev_shade_done[slot] has been recorded since the last full synchronisation
     hipEvent_t ev_geom_done[kSlots] = {}, ev_shade_done[kSlots] = {}, ev_uploads[kSlots] = {} ;
+    hipEvent_t ev_flush = nullptr;             // awsm_hip_frame_flush: system-scope release in front of what the CALLER enqueues next (a collective, a peer / host copy)
     uint64_t write_seq = 0, geom_write_seq[kSlots] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
     bool shade_pending[kSlots] = {};
     // Device-side hand-off between the streams (kernels_geometry.hip: k_handoff_signal / k_handoff_wait) in place of the two cross-stream events
@@ -131,8 +133,13 @@ struct AwsmHipCtx {
     uint32_t* handoff_flags = nullptr;          // device: [slot] geometry done, [kSlots + slot] shading done, [2 kSlots + slot] k_shade_lean done — the serial number last signalled
     uint32_t geom_sig[kSlots] = {}, shade_sig[kSlots] = {}, lean_sig[kSlots] = {};   // flags [2 kSlots + slot]: the slot's k_shade_lean has ended (stored by k_shade_todo as it starts)
     bool lean_flagged[kSlots] = {};             // the slot's last opaque pass took the lean route with the flag: the next frame's pass may start on lean_sig
-    uint32_t handoff_polls = 1u << 20;          // ~2 s of polling: longer than any frame, short enough that a gate nobody opens ends
+    unsigned long long handoff_budget_ticks = 400000000ull;   // a gate's time budget in device-clock ticks (AWSM_HANDOFF_TIMEOUT_MS; default 4 s at 100 MHz):
+                                                // far longer than any frame or host stall, short enough that a gate nobody opens ends
+    uint32_t clock_khz = 100000;                // hipDeviceAttributeWallClockRate
+    uint32_t* handoff_poison = nullptr;         // device: [slot] serial of the slot's last frame whose gate timed out (FrameDev.poison)
     uint32_t handoff_timeouts_seen = 0;
+    uint32_t handoff_dropped_frames = 0;        // gates that timed out = frames dropped whole (AwsmFrameStats.frames_dropped_by_handoff)
+    bool handoff_error_pending = false;         // a time-out has been counted but not yet reported to the caller
     uint32_t handoff_test_drop = 0;             // AWSM_TEST_HANDOFF_DROP: that many geometry-done signals are withheld (tests of the timeout path)
     FrameBufs fb[kSlots];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
     FrameBufs tr[kSlots];             // the same for the transparent pass's own draws (vertices, setup records, bins); no visibility buffer
@@ -196,14 +203,16 @@ inline hipError_t wait_prev_slot(AwsmHipCtx* c, hipStream_t ss, bool main_kernel
     const int p = prev_slot(c);
     if (c->handoff && c->shade_sig[p]) {
         const bool lean = main_kernel_only && c->lean_flagged[p];
-        awsm_launch_handoff_wait(c->handoff_flags + (lean ? 2 * kSlots : kSlots) + p, lean ? c->lean_sig[p] : c->shade_sig[p], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, ss);
+        awsm_launch_handoff_wait(c->handoff_flags + (lean ? 2 * kSlots : kSlots) + p, lean ? c->lean_sig[p] : c->shade_sig[p], c->handoff_budget_ticks, handoff_timeouts(c), c->handoff_timeouts_seen,
+                                 c->handoff_poison + c->slot, c->frame_serial, ss);
         return hipSuccess;
     }
     return hipStreamWaitEvent(ss, c->ev_shade_done[p], 0);
 }
 // the caller's stream goes on once the slot's last opaque (or transparent) pass has finished
 inline hipError_t wait_slot_free(AwsmHipCtx* c) {
-    if (c->handoff) { awsm_launch_handoff_wait(c->handoff_flags + kSlots + c->slot, c->shade_sig[c->slot], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, c->stream); return hipSuccess; }
+    if (c->handoff) { awsm_launch_handoff_wait(c->handoff_flags + kSlots + c->slot, c->shade_sig[c->slot], c->handoff_budget_ticks, handoff_timeouts(c), c->handoff_timeouts_seen,
+                                               c->handoff_poison + c->slot, c->frame_serial, c->stream); return hipSuccess; }
     return hipStreamWaitEvent(c->stream, c->ev_shade_done[c->slot], 0);
 }
 inline hipError_t sync_shade_streams(AwsmHipCtx* c) {
@@ -236,6 +245,25 @@ int fail(AwsmHipCtx* c, int code, const char* fmt, ...) {
     va_end(ap);
     if (c) c->last_error = buf;
     return code;
+}
+
+// A hand-off gate that ran out of time has dropped the frame it guarded (fail closed: k_handoff_wait poisons it, its kernels exit).  The host
+// learns of it from a pinned counter: count the gates, order the streams with events from here on, and tell the caller once — at the next
+// awsm_hip_geometry_pass, awsm_hip_frame_flush or awsm_hip_frame_end, whichever comes first, so that an enqueue-only loop hears of it too.
+int handoff_check(AwsmHipCtx* c) {
+    if (!c->overlap) return AWSM_OK;
+    const uint32_t now = *(volatile uint32_t*)handoff_timeouts(c);
+    if (now != c->handoff_timeouts_seen) {
+        c->handoff_dropped_frames += now - c->handoff_timeouts_seen;
+        c->handoff_timeouts_seen = now;
+        c->handoff = false;
+        c->handoff_error_pending = true;
+    }
+    if (!c->handoff_error_pending) return AWSM_OK;
+    c->handoff_error_pending = false;
+    return fail(c, AWSM_ERR_DEVICE, "a device-side stream hand-off timed out (kernels serialised by a profiler, the streams folded onto one hardware queue, or a stall longer than "
+                                    "AWSM_HANDOFF_TIMEOUT_MS): %u gate(s) so far, each dropped the frame it guarded whole — that frame's image was not written; this context orders "
+                                    "its streams with events from here on (AWSM_DEVICE_HANDOFF=0 selects them from the start)", c->handoff_dropped_frames);
 }
 
 #define HIPCHK(c, call)                                                                            \
@@ -396,6 +424,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
         if (!told) { told = true; FILE* fp = fopen("/tmp/awsm_stamps_ptr", "w"); if (fp) { fprintf(fp, "%llu\n", (unsigned long long)(uintptr_t)stamps); fclose(fp); } }
     }
 #endif
+    f->poison = c->handoff_poison ? c->handoff_poison + c->slot : nullptr;
     f->host_bin_status = c->counters_host + 16 + 2 * c->slot;
     f->frame_serial = c->frame_serial;
     f->vis = (unsigned long long*)FB(c).vis.ptr;
@@ -522,7 +551,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
             ++c->geom_sig[c->slot];
             if (c->handoff_test_drop) c->handoff_test_drop--;
             else awsm_launch_handoff_signal(c->handoff_flags + c->slot, c->geom_sig[c->slot], trace_slot(c, 1), c->stream);
-            awsm_launch_handoff_wait(c->handoff_flags + c->slot, c->geom_sig[c->slot], c->handoff_polls, handoff_timeouts(c), c->handoff_timeouts_seen, ss);
+            awsm_launch_handoff_wait(c->handoff_flags + c->slot, c->geom_sig[c->slot], c->handoff_budget_ticks, handoff_timeouts(c), c->handoff_timeouts_seen, c->handoff_poison + c->slot, c->frame_serial, ss);
         } else {
             if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 1), c->stream);
             HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
@@ -825,6 +854,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             const unsigned ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
             if (hipEventCreateWithFlags(&c->ev_geom_done[s], ev_flags) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], ev_flags) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_uploads[s], ev_flags) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+            if (s == 0 && hipEventCreateWithFlags(&c->ev_flush, hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             if (hipMalloc(&c->fb[s].camera.ptr, 512) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
             c->fb[s].camera.size = 512;
         }
@@ -834,9 +864,13 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     if (c->overlap) {
         const char* e = getenv("AWSM_DEVICE_HANDOFF");      // "0": cross-stream events instead (for a profiler that serialises kernels: tools/pmc_*.sh)
         c->handoff = !(e && e[0] == '0');
-        if (const char* p = getenv("AWSM_HANDOFF_POLLS")) { const long v = atol(p); if (v > 0) c->handoff_polls = (uint32_t)v; }
-        if (hipMalloc((void**)&c->handoff_flags, 3 * kSlots * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-        if (hipMemset(c->handoff_flags, 0, 3 * kSlots * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(AWSM_ERR_DEVICE);
+        { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->clock_khz = (uint32_t)khz; }
+        double budget_ms = 4000.0;
+        if (const char* p = getenv("AWSM_HANDOFF_TIMEOUT_MS")) { const double v = atof(p); if (v > 0.0) budget_ms = v; }
+        c->handoff_budget_ticks = (unsigned long long)(budget_ms * (double)c->clock_khz) + 1ull;
+        if (hipMalloc((void**)&c->handoff_flags, 3 * kSlots * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&c->handoff_poison, kSlots * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        if (hipMemset(c->handoff_flags, 0, 3 * kSlots * sizeof(uint32_t)) != hipSuccess || hipMemset(c->handoff_poison, 0xFF, kSlots * sizeof(uint32_t)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) return bail(AWSM_ERR_DEVICE);
         if (const char* d = getenv("AWSM_TEST_HANDOFF_DROP")) c->handoff_test_drop = (uint32_t)atoi(d);
         // Probe: a gate on one stream, its signal on the other, both directions of every pair the frames will use.  Where the two do not run
         // side by side (kernels serialised by a counter-collecting profiler; two streams on one hardware queue) the gate gives up after ~10 ms
@@ -844,7 +878,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         for (int k = 0; c->handoff && k < 2 * kSlots; k++) {
             hipStream_t ss = c->shade_streams[k % kSlots], waiter = k < kSlots ? ss : c->stream, setter = k < kSlots ? c->stream : ss;
             const uint32_t serial = ++c->geom_sig[0];
-            awsm_launch_handoff_wait(c->handoff_flags, serial, 1u << 13, handoff_timeouts(c), 0u, waiter);
+            awsm_launch_handoff_wait(c->handoff_flags, serial, 10ull * c->clock_khz /* 10 ms */, handoff_timeouts(c), 0u, nullptr, 0u, waiter);
             awsm_launch_handoff_signal(c->handoff_flags, serial, nullptr, setter);
             if (hipStreamSynchronize(waiter) != hipSuccess || hipStreamSynchronize(setter) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             if (*(volatile uint32_t*)handoff_timeouts(c) != 0u) { c->handoff = false; c->handoff_timeouts_seen = *(volatile uint32_t*)handoff_timeouts(c); }
@@ -874,10 +908,12 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     }
     for (hipStream_t st : c->shade_streams) if (st) (void)hipStreamDestroy(st);
     for (int i = 0; i < kSlots; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); }
+    if (c->ev_flush) (void)hipEventDestroy(c->ev_flush);
     if (c->scene_dev) (void)hipFree(c->scene_dev);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->counters_host) (void)hipHostFree(c->counters_host);
     if (c->handoff_flags) (void)hipFree(c->handoff_flags);
+    if (c->handoff_poison) (void)hipFree(c->handoff_poison);
     if (c->trace_dev) (void)hipFree(c->trace_dev);
     for (int i = 0; i < EV_COUNT; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1157,8 +1193,9 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     int rc = build_draw_list(c, "geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, new_draws, &tris, &blocks);
     if (rc) return rc;
     ht.mark("geometry_pass: draw list");
+    if ((rc = handoff_check(c))) return rc;      // an earlier frame was dropped by a timed-out gate: said once, here or in frame_flush / frame_end
+    c->frame_serial++;
     if (c->overlap) {
-        if (c->handoff && *(volatile uint32_t*)handoff_timeouts(c) != c->handoff_timeouts_seen) c->handoff = false;      // reported by the next awsm_hip_frame_end
         c->slot = (c->slot + 1) % kSlots;    // the opaque passes of the previous frames may still be reading the other slots
         // ... and the opaque pass of kSlots frames ago may still be reading THIS slot (its draw list, per-draw records): order everything
         // this call puts on the caller's stream — the draw-list upload included — after it
@@ -1171,17 +1208,16 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     ht.mark("geometry_pass: slot-free wait");
     c->draws_api.assign(draws, draws + n);
     c->draws_host.swap(new_draws);
-    c->frame_serial++;
     {   // What earlier frames needed in their (triangle, tile) lists, as far as the GPU has reported it (pinned words written by k_bin_scan;
         // no wait).  A frame rendered without frame_end cannot be replayed: size the list ahead of the need instead, and count the
         // frames that did overflow (AwsmFrameStats.frames_with_dropped_bin_entries).
         uint32_t need = 0;
         for (int s = 0; s < kSlots; s++) {
             const volatile uint32_t* st = c->counters_host + 16 + 2 * s;
-            const uint32_t entries = st[0], serial = st[1];
+            const uint32_t entries = st[0], serial = st[1];      // serial: bit 31 = that frame overflowed the list it ran with (k_bin_scan's own verdict)
             if (serial == c->status_seen[s]) continue;
             c->status_seen[s] = serial;
-            if (entries > c->fb[s].bin_capacity && c->fb[s].bin_list.ptr) c->dropped_frames++;
+            if (serial >> 31) c->dropped_frames++;
             need = std::max(need, entries);
         }
         for (int s = 0; s < n_slots(c); s++)
@@ -1297,7 +1333,13 @@ int awsm_hip_frame_flush(AwsmHipCtx* c) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     // Nothing is batched host-side.  In overlap mode the opaque passes run on an internal stream: order them before whatever the
     // caller enqueues next on its own stream (a collective over the image, a copy, ...).
-    return scene_write_barrier(c, false);
+    { int rch = handoff_check(c); if (rch) return rch; }
+    int rc = scene_write_barrier(c, false);
+    if (rc || !c->overlap) return rc;
+    // The streams' internal events release to device scope only (no cache write-back per record: see awsm_hip_create).  What follows a flush on the
+    // caller's stream may be a DMA engine, a peer GPU or the host: one system-scope release here, where the caller asked for it.
+    HIPCHK(c, hipEventRecord(c->ev_flush, c->stream));
+    return AWSM_OK;
 }
 
 int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
@@ -1313,12 +1355,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
-        if (c->overlap && *(volatile uint32_t*)handoff_timeouts(c) != c->handoff_timeouts_seen) {      // a gate ended unopened: its stream ran ahead of the data it waited for
-            c->handoff_timeouts_seen = *(volatile uint32_t*)handoff_timeouts(c);
-            c->handoff = false;
-            return fail(c, AWSM_ERR_DEVICE, "a device-side stream hand-off timed out (kernels serialised by a profiler, or the streams share a hardware queue): "
-                                            "frames since the last frame_end may be incomplete; this context uses events from here on (AWSM_DEVICE_HANDOFF=0 selects them from the start)");
-        }
+        { int rch = handoff_check(c); if (rch) return rch; }      // a gate ended unopened: the frame it guarded was dropped
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
         if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
@@ -1339,6 +1376,12 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
     }
     if ((c->geometry_done && c->counters_host[2] != 0) || (c->transparent_done && (c->counters_host[10] != 0 || c->counters_host[14] != 0))) return fail(c, AWSM_ERR_DEVICE, "bin / fragment list overflow persisted after retries");
     if (out) {
+        // the caller says how much of the struct it knows (struct_size, ABI 2): nothing beyond that is written
+        const uint32_t caller_size = out->struct_size;
+        if (caller_size < 8u || caller_size > 4096u) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "frame_end: AwsmFrameStats.struct_size = %u (set it to sizeof(AwsmFrameStats))", caller_size);
+        AwsmFrameStats st_local;
+        AwsmFrameStats* const caller_out = out;
+        out = &st_local;
         memset(out, 0, sizeof *out);
         auto ms = [&](int a, int b) { float t = 0.0f; if (c->ev_valid[a] && c->ev_valid[b] && hipEventElapsedTime(&t, c->ev[a], c->ev[b]) == hipSuccess) return t; return 0.0f; };
         if (c->geometry_done) {
@@ -1355,8 +1398,11 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->covered_pixels = c->counters_host[3];
         out->bin_overflow_retries = c->overflow_retries;
         out->frames_with_dropped_bin_entries = c->dropped_frames;
+        out->handoff_gate_timeouts = c->handoff_dropped_frames;
         if (c->opaque_done && c->shade_todo[c->slot].ptr && c->msaa == 0 && !c->last_opaque.mipmap && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
             HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo[c->slot].ptr, 4, hipMemcpyDeviceToHost));
+        out->struct_size = (uint32_t)std::min<size_t>(caller_size, sizeof(AwsmFrameStats));
+        memcpy(caller_out, out, out->struct_size);
     }
     return AWSM_OK;
 }

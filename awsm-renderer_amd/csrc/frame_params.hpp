@@ -175,6 +175,8 @@ struct FrameDev {
 #ifdef AWSM_STAMP
     unsigned long long* stamps;   // diagnostic builds only (tools/stamp_geometry.sh): [kernel][workgroup][8] s_memrealtime stamps
 #endif
+    const uint32_t* poison;       // overlapped pipeline, fail-closed hand-off: the serial of the last frame of this slot whose gate timed out (k_handoff_wait);
+                                  // every kernel of that frame exits at once (frame_poisoned).  null: no device-side hand-off
     uint32_t* host_bin_status;    // pinned host memory, 2 words per frame slot: (triangle, tile) entries this frame needed, the frame's serial (k_bin_scan)
     uint32_t frame_serial;
     uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles, [7] extra raster items
@@ -193,5 +195,13 @@ struct FrameDev {
     uint32_t* frag_first;         // width*height: the pixel's first fragment in submission order (0xFFFFFFFF = none)
     uint32_t frag_cap;
 };
+
+#ifdef __HIPCC__
+// A hand-off gate that gave up (its signal never came within the time budget) has poisoned the frame it guarded: its kernels must not run on
+// buffers that are half written, or still being read.  Wave-uniform, one scalar load.
+__device__ __forceinline__ bool frame_poisoned(const FrameDev& f) {
+    return f.poison != nullptr && *(const __attribute__((address_space(4))) uint32_t*)f.poison == f.frame_serial;
+}
+#endif
 
 }  // namespace awsm

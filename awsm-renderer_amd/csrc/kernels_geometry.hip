@@ -43,6 +43,7 @@ template <bool FWD>
 // previous frame's persistent opaque-pass grid — with one, the kernel ran 209 us beside it (31 alone).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6))) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[FWD ? 4 : 256 * 14];
+    if (frame_poisoned(f)) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     {   // per-frame clears folded into the first kernel of the frame (saves three memset launches per frame)
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     __shared__ uint32_t lbase[FILL ? kBinWindow : 1];
 
     const uint32_t tid = threadIdx.x;
+    if (frame_poisoned(f)) return;
     AWSM_STAMP_AT(f, FILL ? 2 : 0, 0);
     if (FILL && blockIdx.x < kBinBigBlocks) { bin_big_walk<true>(f, blockIdx.x, kBinBigBlocks); AWSM_STAMP_AT(f, 2, 7); return; }     // workgroup-uniform
     const uint32_t r0 = (blockIdx.x - (FILL ? kBinBigBlocks : 0u)) * (256u * kBinBatches) + tid;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
 // in runs — whole workgroups of k_bin were nothing but such triangles and ran 3x longer than the rest of the grid).
 // One wavefront per triangle, 64 tiles per step, grid-stride over the list k_bin<count> built.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin_big(FrameDev f) { bin_big_walk<FILL>(f, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_bin_big(FrameDev f) { if (frame_poisoned(f)) return; bin_big_walk<FILL>(f, blockIdx.x, gridDim.x); }
 
 // Exclusive scan of tile_count -> tile_offset (single workgroup; n_tiles is a few thousand), plus tile_order: the tile
 // ids sorted by log2(count), heaviest first.  Workgroups start in blockIdx order, so k_raster_tile begins with the
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, k = blockIdx.x, G = gridDim.x;
     const uint32_t i = k * kScanThreads + tid;
     const bool live = i < n_tiles;
+    if (frame_poisoned(f)) return;
     AWSM_STAMP_AT(f, 1, 0);
     if (tid < 36u) hist[tid] = 0u;
     const uint32_t c = live ? f.tile_count[i] : 0u;
@@ -523,7 +526,8 @@ __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t 
             f.counters[7] = min(q_total[1], f.raster_extra_cap);
             if (f.host_bin_status) {   // for frames nobody waits for: the host sizes the list of later frames from this (awsm_hip_geometry_pass)
                 __hip_atomic_store(f.host_bin_status, total_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(f.host_bin_status + 1, f.frame_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // bit 31: THIS frame ran with a list too short for it (the host may have grown the list since, so it cannot tell from the size it sees)
+                __hip_atomic_store(f.host_bin_status + 1, (f.frame_serial & 0x7FFFFFFFu) | (total_entries > f.bin_capacity ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // bases and run starts went out with sc1 stores: in memory once every wavefront has drained
@@ -764,6 +768,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     // Heaviest tiles first (tile_order, k_bin_scan).  Consecutive ids go to different XCDs (blockIdx & 7), which also
     // spreads the dense band of the screen over all eight of them.
     // The first counters[7] workgroups take the extra slices of the split tiles (the heaviest work of the frame), the rest one tile each.
+    if (frame_poisoned(f)) return;
     const uint32_t n_tiles = f.tiles_x * f.tiles_y, n_extra = min(f.counters[7], f.raster_extra_cap);
     uint32_t item;
     if (blockIdx.x < n_extra) item = f.tile_order[n_tiles + blockIdx.x];
@@ -978,12 +983,21 @@ __global__ __launch_bounds__(64) void k_handoff_signal(uint32_t* flag, uint32_t 
     if (stamp) *stamp = wall_clock64();
     if (flag) st_sc1(flag, serial);
 }
-__global__ __launch_bounds__(64) void k_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known) {
+// The budget is time (ticks of the constant-rate device clock, 100 MHz on this part), not a poll count: a count means whatever the memory system's
+// latency makes of it.  A gate that ends unopened FAILS CLOSED: it stores the serial of the frame it guarded in that frame slot's poison word,
+// and every kernel of the frame exits at its first instruction (frame_poisoned) — the frame is dropped whole, its image untouched, instead of
+// being shaded from half-written buffers.  The stream goes on, its own signal kernels included, so the frames behind it are not held up.
+__global__ __launch_bounds__(64) void k_handoff_wait(const uint32_t* flag, uint32_t serial, unsigned long long budget_ticks, uint32_t* timeouts_host, uint32_t timeouts_known,
+                                                     uint32_t* poison, uint32_t poison_serial) {
     if (threadIdx.x != 0) return;
-    if (__hip_atomic_load(timeouts_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != timeouts_known) max_polls = min(max_polls, 64u);
-    uint32_t polls = 0u;
+    if (__hip_atomic_load(timeouts_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != timeouts_known) budget_ticks = min(budget_ticks, 2000ull);   // 20 us: the pipeline is already broken
+    const unsigned long long t0 = wall_clock64();
     while ((int32_t)(ld_sc1(flag) - serial) < 0) {
-        if (++polls >= max_polls) { __hip_atomic_fetch_add(timeouts_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        if (wall_clock64() - t0 >= budget_ticks) {
+            if (poison) st_sc1(poison, poison_serial);
+            __hip_atomic_fetch_add(timeouts_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -1004,8 +1018,9 @@ extern "C" void awsm_launch_upload_words(void* dst, const void* src_pinned, uint
 extern "C" void awsm_launch_handoff_signal(uint32_t* flag, uint32_t serial, unsigned long long* stamp, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_handoff_signal, dim3(1), dim3(64), 0, s, flag, serial, stamp);
 }
-extern "C" void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, uint32_t max_polls, uint32_t* timeouts_host, uint32_t timeouts_known, hipStream_t s) {
-    hipLaunchKernelGGL(awsm::k_handoff_wait, dim3(1), dim3(64), 0, s, flag, serial, max_polls, timeouts_host, timeouts_known);
+extern "C" void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, unsigned long long budget_ticks, uint32_t* timeouts_host, uint32_t timeouts_known,
+                                         uint32_t* poison, uint32_t poison_serial, hipStream_t s) {
+    hipLaunchKernelGGL(awsm::k_handoff_wait, dim3(1), dim3(64), 0, s, flag, serial, budget_ticks, timeouts_host, timeouts_known, poison, poison_serial);
 }
 extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
     if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform<false>, dim3(n_blocks), dim3(256), 0, s, sc, *f);

@@ -1321,6 +1321,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
     __shared__ uint32_t rec_info[kFwdRecCap];
     __shared__ uint32_t rmin, rmax, pool_next, pool_end;
 
+    if (frame_poisoned(f)) return;
     const uint32_t tile = f.tile_order[blockIdx.x / kFwdSubs], sub = blockIdx.x % kFwdSubs;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, blk = tid >> 6;
     constexpr int kRectW = kFwdBW * kFwdBlock, kRectH = (kFwdNB / kFwdBW) * kFwdBlock;
@@ -1488,6 +1489,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_forward_shade(const DevScene* __restrict__ sc, FrameDev f) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (frame_poisoned(f)) return;
     if (i >= min(f.counters[5], f.frag_cap)) return;
     const uint4 rec = f.frag_rec[i];
     if (rec.x == kFragNone) return;                       // unused slot of a wavefront's chunk
@@ -1502,7 +1504,7 @@ __global__ __launch_bounds__(256) void k_forward_shade(const DevScene* __restric
 template <int S>
 __global__ __launch_bounds__(256) void k_forward_blend(FrameDev f) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= f.width * f.height) return;
+    if (p >= f.width * f.height || frame_poisoned(f)) return;
     if (!row_owned(f, (int)(p / f.width))) return;                               // sharded: only this shard's rows of the composite
     const uint2 c0 = reinterpret_cast<const uint2*>(f.opaque_rgba16f)[p];       // opaque -> transparent blit: every sample starts as the opaque colour
     float dst[S][4];
@@ -1578,7 +1580,7 @@ AWSM_DI void shade_pixel(const DevScene* __restrict__ sc, const FrameDev& f, con
 template <bool GRAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
     ShadeBlock b;
-    if (!shade_block(f, b)) return;
+    if (frame_poisoned(f) || !shade_block(f, b)) return;
     shade_pixel<GRAD>(sc, f, b, threadIdx.x);
 }
 // The 16x4-pixel groups k_shade_lean left behind (a draw that is not lean, or texture coordinates beyond +-32768): one wavefront
@@ -1594,6 +1596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // This kernel starting means this frame's k_shade_lean has ended (same stream): the next frame's opaque pass, gated on that, goes ahead
     // while the list is shaded (k_handoff_wait, kernels_geometry.hip; the two frames write different images).
     if (f.lean_done_flag && blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(f.lean_done_flag, f.lean_done_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (frame_poisoned(f)) return;        // (after the flag: the next frame's gate must still open)
     const uint32_t n = min(f.shade_todo[0], f.shade_todo_cap);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the list walk in scalar registers
@@ -1921,6 +1924,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
 template <bool PERSIST>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PERSIST ? 5 : AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+    if (frame_poisoned(f)) return;
     const uint32_t xcd = blockIdx.x & 7u, lane = threadIdx.x & 63u;
     const uint32_t bx_n = (f.width + 15u) >> 4, by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.sy1 - f.sy0) + 15u) >> 4;
     const uint32_t lp = 32u - (uint32_t)__builtin_clz((bx_n - 1u) | 1u);  // log2 of the block pitch
@@ -1994,7 +1998,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     __shared__ NeighbourCell cells[18 * 18];
     __shared__ uint32_t n_edges;
     ShadeBlock b;
-    if (!shade_block(f, b)) return;                                       // workgroup-uniform
+    if (frame_poisoned(f) || !shade_block(f, b)) return;                  // workgroup-uniform
     const uint32_t tid = threadIdx.x;
     const int lx = (int)(tid & 15u), ly = (int)(tid >> 4);
     const int cx = b.x0 + lx, cy = b.y0 + ly;
@@ -2087,7 +2091,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
     ShadeBlock b;
-    if (!shade_block(f, b)) return;
+    if (frame_poisoned(f) || !shade_block(f, b)) return;
     const uint8_t* edge_rec = reinterpret_cast<const uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     const uint32_t n = *reinterpret_cast<const uint32_t*>(edge_rec);
     if (threadIdx.x >= n) return;

@@ -58,13 +58,14 @@ class AwsmEnv(C.Structure):
 
 
 class AwsmFrameStats(C.Structure):
-    _fields_ = [("ms_transform", C.c_float), ("ms_bin", C.c_float), ("ms_raster", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
+    _fields_ = [("struct_size", C.c_uint32), ("ms_transform", C.c_float), ("ms_bin", C.c_float), ("ms_raster", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
                 ("triangles_in", C.c_uint32), ("triangles_binned", C.c_uint32), ("bin_entries", C.c_uint32), ("covered_pixels", C.c_uint32),
                 ("bin_overflow_retries", C.c_uint32), ("ms_forward", C.c_float), ("forward_triangles", C.c_uint32), ("forward_fragment_slots", C.c_uint32),
-                ("ms_shade_lean", C.c_float), ("shade_general_wavefronts", C.c_uint32), ("frames_with_dropped_bin_entries", C.c_uint32)]
+                ("ms_shade_lean", C.c_float), ("shade_general_wavefronts", C.c_uint32), ("frames_with_dropped_bin_entries", C.c_uint32),
+                ("handoff_gate_timeouts", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "struct_size")}
 
 
 class AwsmHipError(RuntimeError):
@@ -296,6 +297,7 @@ class HipDevice:
 
     def frame_end(self) -> dict:
         st = AwsmFrameStats()
+        st.struct_size = C.sizeof(AwsmFrameStats)
         self._chk(self.lib.awsm_hip_frame_end(self.ctx, C.byref(st)), "frame_end")
         return st.as_dict()
 

@@ -25,7 +25,7 @@ class TexRef(C.Structure):
 
 
 class HostMaterial(C.Structure):
-    _fields_ = [("shader", C.c_uint32), ("double_sided", C.c_uint32), ("base_color_factor", C.c_float * 4), ("metallic_factor", C.c_float),
+    _fields_ = [("struct_size", C.c_uint32), ("shader", C.c_uint32), ("double_sided", C.c_uint32), ("base_color_factor", C.c_float * 4), ("metallic_factor", C.c_float),
                 ("roughness_factor", C.c_float), ("normal_scale", C.c_float), ("occlusion_strength", C.c_float), ("emissive_factor", C.c_float * 3),
                 ("debug_bitmask", C.c_uint32), ("base_color_tex", TexRef), ("metallic_roughness_tex", TexRef), ("normal_tex", TexRef),
                 ("occlusion_tex", TexRef), ("emissive_tex", TexRef),
@@ -365,6 +365,7 @@ class Host:
 
     def render(self, sync: bool = True) -> Optional[dict]:
         st = AwsmFrameStats()
+        st.struct_size = C.sizeof(AwsmFrameStats)
         self._chk(self.lib.awsm_host_render(self.h, 1 if sync else 0, C.byref(st) if sync else None), "render")
         return st.as_dict() if sync else None
 
@@ -422,6 +423,7 @@ def _texref(ref: Optional[TextureRef], tt_keys: Dict[tuple, int], host: Host) ->
 def material_struct(m: MaterialDesc, host: Host, tt_keys: Dict[tuple, int]) -> HostMaterial:
     tr = lambda r: _texref(r, tt_keys, host)   # noqa: E731
     hm = HostMaterial()
+    hm.struct_size = C.sizeof(HostMaterial)
     hm.shader = 2 if m.kind == "unlit" else 1
     hm.double_sided = 1 if m.double_sided else 0
     hm.base_color_factor = (C.c_float * 4)(*m.base_color_factor)

@@ -411,6 +411,7 @@ bool material_key(Loader& L, int index, AwsmKey* out) {
     const Value& ext = m["extensions"];
     AwsmHostMaterial hm;
     memset(&hm, 0, sizeof hm);
+    hm.struct_size = (uint32_t)sizeof hm;
     AwsmHostTexRef none; none.texture = -1; none.sampler = 0; none.uv_index = 0; none.pad = 0; none.transform = 0;
     hm.base_color_tex = hm.metallic_roughness_tex = hm.normal_tex = hm.occlusion_tex = hm.emissive_tex = none;
     hm.specular_tex = hm.specular_color_tex = hm.transmission_tex = hm.volume_thickness_tex = none;

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -615,8 +616,31 @@ AwsmKey awsm_host_texture_transform_insert(AwsmHost* h, const float offset[2], c
 }
 
 // ------------------------------------------------------------------------------------------------ materials
-AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m) {   // materials.rs:120-128
-    if (!m || (m->shader != 1u && m->shader != 2u)) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "material_insert: bad shader id"); return 0; }
+// The caller's struct may be shorter than this library's (AwsmHostMaterial.struct_size: fields are only appended): read what it has, the rest
+// means "block absent" (has_* = 0, no texture).
+static bool material_in(AwsmHost* h, const AwsmHostMaterial* in, AwsmHostMaterial* full, const char* who) {
+    if (!in || in->struct_size < offsetof(AwsmHostMaterial, has_vertex_color) || in->struct_size > 4096u) {
+        fail(h, AWSM_ERR_INVALID_ARGUMENT, "%s: AwsmHostMaterial.struct_size = %u (set it to sizeof(AwsmHostMaterial))", who, in ? in->struct_size : 0u);
+        return false;
+    }
+    memset(full, 0, sizeof *full);
+    AwsmHostTexRef none; none.texture = -1; none.sampler = 0; none.uv_index = 0; none.pad = 0; none.transform = 0;
+    AwsmHostTexRef* refs[] = {&full->specular_tex, &full->specular_color_tex, &full->transmission_tex, &full->volume_thickness_tex, &full->clearcoat_tex, &full->clearcoat_roughness_tex,
+                              &full->clearcoat_normal_tex, &full->sheen_roughness_tex, &full->sheen_color_tex, &full->diffuse_transmission_tex, &full->diffuse_transmission_color_tex,
+                              &full->anisotropy_tex, &full->iridescence_tex, &full->iridescence_thickness_tex};
+    for (AwsmHostTexRef* r : refs) *r = none;
+    memcpy(full, in, std::min<size_t>(in->struct_size, sizeof *full));
+    full->struct_size = (uint32_t)sizeof *full;
+    return true;
+}
+
+uint32_t awsm_host_abi_version(void) { return AWSM_HOST_ABI_VERSION; }
+
+AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m_in) {   // materials.rs:120-128
+    AwsmHostMaterial mfull;
+    if (!material_in(h, m_in, &mfull, "material_insert")) return 0;
+    const AwsmHostMaterial* m = &mfull;
+    if (m->shader != 1u && m->shader != 2u) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "material_insert: bad shader id"); return 0; }
     SlotKey k = h->materials.insert(*m);
     const std::vector<uint8_t> d = material_bytes(h, *m);
     h->materials_buf.update(k, d.data(), d.size());
@@ -624,9 +648,12 @@ AwsmKey awsm_host_material_insert(AwsmHost* h, const AwsmHostMaterial* m) {   //
     return k;
 }
 
-int awsm_host_material_update(AwsmHost* h, AwsmKey key, const AwsmHostMaterial* m) {   // materials.rs:147-186
+int awsm_host_material_update(AwsmHost* h, AwsmKey key, const AwsmHostMaterial* m_in) {   // materials.rs:147-186
     AwsmHostMaterial* cur = h->materials.get(key);
-    if (!cur || !m) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[material] not found");
+    if (!cur || !m_in) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[material] not found");
+    AwsmHostMaterial mfull;
+    if (!material_in(h, m_in, &mfull, "material_update")) return AWSM_ERR_INVALID_ARGUMENT;
+    const AwsmHostMaterial* m = &mfull;
     *cur = *m;
     const std::vector<uint8_t> d = material_bytes(h, *m);
     h->materials_buf.update(key, d.data(), d.size());

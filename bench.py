@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--mipmap", action="store_true", help="MipmapMode::Gradient (the reference's default; not the BASELINE config)")
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4), help="MSAA x4 geometry + edge resolve (the reference's default AntiAliasing; not the BASELINE config)")
     ap.add_argument("--strips", action="store_true", help="with --msaa 4 and N > 1: shard by contiguous row strips (each carries its own halo rows) instead of bands + halo exchange")
+    ap.add_argument("--gather", choices=("all", "root"), default="all", help="N > 1: how the image leaves the ranks — 'all': RCCL all-gather, every rank ends up with the frame "
+                    "(BASELINE.json north_star); 'root': gather to rank 0 only (one consumer: N-1 bands travel over N-1 separate xGMI links into one GPU instead of "
+                    "N(N-1) band transfers; SURVEY.md 8e's alternative)")
     ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4), help="BASELINE.json config: 4 = configs[3] the 4K Sponza-class frame (the metric's), "
                     "2 = configs[1] helmet-class 15k triangles / 2048^2 textures at 1920x1080, 3 = configs[2] skinned rig + morph cube at 1920x1080")
@@ -264,14 +267,24 @@ def main():
             dev.msaa_halo_bind(halo_all[b].data_ptr(), halo_all[b].numel() * 8)
         r.host.set_render_hooks(after_geometry_pass=exchange_halo)
 
+    to_root = args.gather == "root"
+
     def all_gather(dst, src):
+        """dst [world * rows_out, W, 4] <- every rank's src [rows_out, W, 4], in rank order: on every rank, or (--gather root) on rank 0 only."""
         if backend == "nccl":
+            if to_root:
+                return dist.gather(src, gather_list=list(dst.view(world, *src.shape).unbind(0)) if rank == 0 else None, dst=0, async_op=True)
             return dist.all_gather_into_tensor(dst, src, async_op=True)
         # rehearsal backend (AWSM_BENCH_BACKEND=gloo, several ranks sharing one GPU): staged through the host, synchronous
         torch.cuda.current_stream().synchronize()
         host_src = src.view(torch.int32).cpu()
         host_dst = torch.empty((world,) + tuple(host_src.shape), dtype=torch.int32)
-        dist.all_gather_into_tensor(host_dst.view(world * host_src.shape[0], *host_src.shape[1:]), host_src)
+        if to_root:
+            dist.gather(host_src, gather_list=list(host_dst.unbind(0)) if rank == 0 else None, dst=0)
+            if rank != 0:
+                return _Done()
+        else:
+            dist.all_gather_into_tensor(host_dst.view(world * host_src.shape[0], *host_src.shape[1:]), host_src)
         dst.copy_(host_dst.view(world * host_src.shape[0], *host_src.shape[1:]).view(torch.float16).view(dst.shape))
         return _Done()
 
@@ -280,6 +293,8 @@ def main():
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
+            if to_root and rank != 0:
+                return                 # only rank 0 holds the frame
             if strips:
                 image[b].copy_(gathered[b].view(world * rows_out, W, 4)[:H])
             else:
@@ -414,7 +429,7 @@ def main():
             r.host.set_render_hooks()                    # the unsharded reference frame has no exchange
         dev.bind_output(ref.data_ptr(), H * W * 8)
         r.host.render(sync=True)
-        check = "ok" if torch.equal(got.view(torch.int16), ref.view(torch.int16)) else "MISMATCH"
+        check = "ok" if (to_root and rank != 0) or torch.equal(got.view(torch.int16), ref.view(torch.int16)) else "MISMATCH"
         if strips:
             r.host.set_shard_rows(y0s, y1s)
             dev.bind_output_rows(mine[0].data_ptr(), rows_out * W * 8, y0s)
@@ -477,9 +492,9 @@ def main():
     if world == 1:
         sharding_desc = "none"
     elif strips:
-        sharding_desc = f"{world} row strips of {per} rows (+1-row halo for the MSAA edge detector) + RCCL all-gather of the RGBA16F image, overlapped with the next frame"
+        sharding_desc = f"{world} row strips of {per} rows (+1-row halo for the MSAA edge detector) + RCCL {'gather to rank 0' if to_root else 'all-gather'} of the RGBA16F image, overlapped with the next frame"
     else:
-        sharding_desc = (f"32-row bands round-robin over {world} ranks ({L} bands each) + RCCL all-gather of the RGBA16F image + de-interleave; "
+        sharding_desc = (f"32-row bands round-robin over {world} ranks ({L} bands each) + RCCL {'gather to rank 0' if to_root else 'all-gather'} of the RGBA16F image + de-interleave; "
                          f"gather of frame i overlapped with the render of frame i+1 (double-buffered)"
                          + ("; MSAA: all-gather of the bands' boundary sample-0 keys between the geometry and the opaque pass" if args.msaa else ""))
     if rank == 0:

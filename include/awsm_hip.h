@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define AWSM_HIP_ABI_VERSION 1u
+/* 2: AwsmFrameStats carries struct_size (the caller sets it; awsm_hip_frame_end writes no byte beyond it) and handoff_gate_timeouts;
+ *    awsm_hip_frame_trace / awsm_hip_read_frame_trace; a timed-out hand-off gate drops its frame (fail closed) and is reported by
+ *    awsm_hip_geometry_pass / awsm_hip_frame_flush as well.  A library and a caller of different versions refuse each other in awsm_hip_create. */
+#define AWSM_HIP_ABI_VERSION 2u
 
 typedef struct AwsmHipCtx AwsmHipCtx;
 
@@ -135,6 +138,7 @@ typedef struct AwsmEnv {
 } AwsmEnv;
 
 typedef struct AwsmFrameStats {
+    uint32_t struct_size; /* IN: sizeof(AwsmFrameStats) as the caller was compiled (fields are only ever appended); OUT: bytes written */
     float ms_transform;   /* k_deform_transform */
     float ms_bin;         /* k_bin_count + scan + k_bin_fill */
     float ms_raster;      /* k_raster_tile */
@@ -154,6 +158,9 @@ typedef struct AwsmFrameStats {
                                          such a frame lost geometry.  The library sizes the list from the need the GPU reports for earlier
                                          frames (growing it ahead of the need), so this stays 0 unless the need jumps by more than a third
                                          between two frames; awsm_hip_frame_end additionally replays an overflowed frame. */
+    uint32_t handoff_gate_timeouts;  /* AWSM_CFG_OVERLAP_FRAMES with device-side hand-off: gates that ran out of time since the context was created.  Each one
+                                         dropped the frame it guarded whole (its kernels exit at once: the image is not written, nothing is shaded from
+                                         half-written buffers) and was reported once with AWSM_ERR_DEVICE. */
 } AwsmFrameStats;
 
 /* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */
@@ -314,8 +321,11 @@ int awsm_hip_visibility_digest(AwsmHipCtx* ctx, uint64_t* out2);
  * 20-30 us a cross-stream hipEvent takes to release the waiting queue), 0 = hipEvents (contexts without overlap; AWSM_DEVICE_HANDOFF=0 in
  * the environment; the probe at create found that kernels of two streams do not run side by side, e.g. under a counter-collecting
  * profiler; or a gate timed out later, which awsm_hip_frame_end reports once with AWSM_ERR_DEVICE).  Negative = AWSM_ERR_*.
- * Environment, read at create: AWSM_DEVICE_HANDOFF=0 (events from the start), AWSM_HANDOFF_POLLS=n (a gate's poll budget, default 2^20 ~ 2 s),
- * AWSM_TEST_HANDOFF_DROP=n (tests: withhold the first n geometry-done signals to exercise the timeout path). */
+ * A gate that runs out of time fails closed: the frame it guarded is dropped whole (every kernel of it exits at its first instruction, its image
+ * is not written), the streams go on, the context falls back to events, and the next awsm_hip_geometry_pass / awsm_hip_frame_flush /
+ * awsm_hip_frame_end returns AWSM_ERR_DEVICE once (AwsmFrameStats.handoff_gate_timeouts counts them).
+ * Environment, read at create: AWSM_DEVICE_HANDOFF=0 (events from the start), AWSM_HANDOFF_TIMEOUT_MS=x (a gate's time budget on the device clock,
+ * default 4000), AWSM_TEST_HANDOFF_DROP=n (tests: withhold the first n geometry-done signals to exercise the timeout path). */
 int awsm_hip_stream_handoff(AwsmHipCtx* ctx);
 /* test aid: the G-buffer texel fs_main would have written for every pixel of the last geometry pass (fragment.wgsl:23-54) as the opaque pass
  * reconstructs it — 6 floats / pixel: normal_tangent RGBA16F and barycentric RG16F, each already rounded to f16; zeros where nothing was hit.

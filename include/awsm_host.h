@@ -23,6 +23,11 @@
 extern "C" {
 #endif
 
+/* 2: AwsmHostMaterial carries struct_size (fields are only ever appended; a caller compiled against a shorter struct is read up to its
+ *    size, the rest defaults to "block absent"); awsm_host_render passes AwsmFrameStats.struct_size through (awsm_hip.h). */
+#define AWSM_HOST_ABI_VERSION 2u
+uint32_t awsm_host_abi_version(void);
+
 typedef struct AwsmHost AwsmHost;
 typedef uint64_t AwsmKey;
 
@@ -59,6 +64,7 @@ typedef struct AwsmHostTexRef {
 } AwsmHostTexRef;
 
 typedef struct AwsmHostMaterial {
+    uint32_t struct_size;     /* sizeof(AwsmHostMaterial) as the caller was compiled */
     uint32_t shader;          /* 1 = PBR, 2 = unlit (MaterialShaderId) */
     uint32_t double_sided;
     float base_color_factor[4];

@@ -28,7 +28,7 @@ def test_hip_library_exports_every_declared_symbol():
     lib = C.CDLL(hip_backend.LIB_PATH)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.awsm_hip_abi_version() == 1
+    assert lib.awsm_hip_abi_version() == 2
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -6,11 +6,13 @@ relative (1e-4 * |ref|) for HDR values above 1.0 — checked on the f32 parity t
 round apart)."""
 import dataclasses
 import math
+import os
 
 import numpy as np
 import pytest
 
 from awsm_renderer_amd import scenes
+from oracle import oracle_lib
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
@@ -147,11 +149,11 @@ def test_band_sharding_rows_identical_to_full_frame(oracle_lut, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("msaa,extra", [(0, []), (4, []), (4, ["--strips"])])
+@pytest.mark.parametrize("msaa,extra", [(0, []), (4, []), (4, ["--strips"]), (0, ["--gather", "root"])])
 def test_bench_two_rank_rehearsal_on_one_gpu(msaa, extra):
     """bench.py's N > 1 path (band sharding, compact outputs, double-buffered gather, de-interleave) run as two processes
     sharing this box's one GPU, with the collectives staged through gloo; --check compares the gathered image with an
-    unsharded render bit for bit.  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)"""
+    unsharded render bit for bit (with --gather root: on rank 0, the only rank that holds the frame).  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)"""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -164,7 +166,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu(msaa, extra):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["check"] == "ok" and out["n_gpus"] == 2 and out["value"] > 0
-    assert ("row strips" in out["config"]["sharding"]) == bool(extra) and ("boundary sample-0 keys" in out["config"]["sharding"]) == (msaa == 4 and not extra)
+    assert ("gather to rank 0" in out["config"]["sharding"]) == ("root" in extra)
+    assert ("row strips" in out["config"]["sharding"]) == ("--strips" in extra) and ("boundary sample-0 keys" in out["config"]["sharding"]) == (msaa == 4 and not extra)
 
 
 @pytest.mark.gpu
@@ -578,8 +581,9 @@ def test_stream_handoff_flags_events_and_timeout_fallback(oracle_lut, monkeypatc
     """The overlapped pipeline hands a frame from stream to stream through device-side flags (k_handoff_signal / k_handoff_wait) instead of
     cross-stream events.  48 frames with a moving camera, submitted without a synchronisation, each into its own image: bit-identical to a
     plain context's frames with the flags (the default: awsm_hip_stream_handoff() == 1) and with AWSM_DEVICE_HANDOFF=0 (events).  Then the
-    failure path: one geometry-done signal withheld (AWSM_TEST_HANDOFF_DROP) with a short poll budget — the gate gives up, awsm_hip_frame_end
-    reports it once, the context goes on with events and renders correct frames again."""
+    failure path: one geometry-done signal withheld (AWSM_TEST_HANDOFF_DROP) with a short time budget — the gate gives up and FAILS CLOSED: the
+    frame it guarded is dropped whole (its image keeps the pattern it held), awsm_hip_frame_flush / frame_end report it once, the counter says one
+    gate, the context goes on with events and renders correct frames again."""
     import ctypes as C
     from awsm_renderer_amd.hip_backend import HipDevice
     from awsm_renderer_amd.host import Renderer
@@ -631,22 +635,65 @@ def test_stream_handoff_flags_events_and_timeout_fallback(oracle_lut, monkeypatc
     assert not (plain[0] == plain[n - 1]).all()
 
     monkeypatch.setenv("AWSM_TEST_HANDOFF_DROP", "1")
-    monkeypatch.setenv("AWSM_HANDOFF_POLLS", "3000")
+    monkeypatch.setenv("AWSM_HANDOFF_TIMEOUT_MS", "5")
     r = Renderer(sc, lut_rgba16f=lut, overlap_frames=True)
     r.host.set_render_timings(False)
     dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
     assert dev.stream_handoff() == 1
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    img = C.c_void_p()
+    assert hip.hipMalloc(C.byref(img), nbytes) == 0 and hip.hipMemset(img, 0x5A, nbytes) == 0 and hip.hipDeviceSynchronize() == 0
     r.host.camera_update(look_at_rh(eyes[0], (-0.2, 3.4, -18.0)), sc.proj, eyes[0])
-    r.host.render(sync=False)            # its opaque pass starts behind a gate nobody opens
-    with pytest.raises(RuntimeError, match="hand-off timed out"):
-        r.host.render(sync=True)
+    dev.bind_output(img.value, nbytes)
+    r.host.render(sync=False)            # its opaque pass starts behind a gate nobody opens: the gate times out and poisons the frame
+    assert hip.hipDeviceSynchronize() == 0
+    got = np.zeros((sc.height, sc.width, 4), dtype=np.uint16)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), img, nbytes, 2) == 0
+    assert (got == 0x5A5A).all(), f"the withheld frame wrote {(got != 0x5A5A).sum()} values: a timed-out gate must drop its frame, not shade it"
+    with pytest.raises(Exception, match="hand-off timed out"):      # an enqueue-only caller hears of it too
+        dev.frame_flush()
     assert dev.stream_handoff() == 0
+    dev.bind_output(None)
+    hip.hipFree(img)
     for i in (5, 17):
         r.host.camera_update(look_at_rh(eyes[i], (-0.2, 3.4, -18.0)), sc.proj, eyes[i])
         r.host.render(sync=False)
-        r.host.render(sync=True)
+        st = r.host.render(sync=True)      # said once: no second error
+        assert st["handoff_gate_timeouts"] == 1, st
         assert (dev.read_opaque() == plain[i]).all(), i
     r.close()
+
+
+@pytest.mark.gpu
+def test_device_brdf_lut_against_the_oracle(oracle_lut):
+    """BrdfLut::new (renderer-core/src/brdf_lut/generate.rs:47-96, shader.wgsl:1-78) on the device: k_brdf_lut through
+    awsm_hip_brdf_lut_generate / awsm_hip_read_brdf_lut against oracle/c/oracle_brdf_lut.c, at the test size (64^2) and at the reference's default
+    (1024^2).  The kernel and the oracle sum the same 1,024 samples per texel in the same order; what differs is the math library (device sin / cos /
+    pow against glibc's), so the bound is stated in f16 steps of the stored texel: at most 1 step, and all but a fraction of the texels identical.
+    Then a frame shaded with the DEVICE's LUT against the oracle's frame with the ORACLE's LUT, within the shading tolerance: what a caller
+    without a LUT of its own (bench.py, Renderer(lut_rgba16f=None)) gets."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    for n in (64, 1024):
+        dev = HipDevice()
+        dev.brdf_lut_generate(n, n)
+        got = dev.read_brdf_lut()
+        dev.close()
+        want = oracle_lut if n == 64 else oracle_lib.brdf_lut(n, n, threads=os.cpu_count() or 8)
+        assert got.shape == want.shape == (n, n, 2)
+        step = np.abs(got.astype(np.int32) - want.astype(np.int32))      # positive finite f16 values: the bit patterns are ordered like the values
+        assert (got < 0x7C00).all() and (want < 0x7C00).all()
+        assert step.max() <= 1, f"{n}^2: a texel differs by {step.max()} f16 steps"
+        assert (step != 0).mean() < 0.02, f"{n}^2: {(step != 0).mean():.4f} of the values differ by one step"
+    from awsm_renderer_amd.host import Renderer
+    scene = scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=64)
+    r = Renderer(scene, parity_tap=True, lut_rgba16f=None, lut_size=64)       # the device generates its own LUT
+    r.render(sync=True)
+    dev = HipDevice.from_ctx(r.host.device_ctx, scene.width, scene.height)
+    res = helpers.compare_frames(helpers.oracle_frame(helpers.build_model(scene), oracle_lut), dev)
+    dev.close()
+    r.close()
+    assert res["key_mismatch"] == 0 and res["clip_mismatch"] == 0, res
+    assert res["rgb_over_tol"] == 0 and res["f16_max_ulp"] <= 2, res
 
 
 @pytest.mark.gpu
