@@ -401,6 +401,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !texel_cubes && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
+    f->attr_data_bytes = (uint32_t)std::min<size_t>(c->bufs[AWSM_BUF_ATTR_DATA].size, 0xFFFFFFFFu);
     f->draw_lean = lean_ok ? (LeanDrawDev*)FB(c).draw_lean.ptr : nullptr;
     f->shade_todo = (uint32_t*)c->shade_todo[c->slot].ptr;
     f->shade_todo_cap = f->shade_todo ? (uint32_t)(c->shade_todo[c->slot].size / 4 - 4 - 1024) : 0u;
@@ -742,7 +743,7 @@ int size_pass_buffers(AwsmHipCtx* c, FrameBufs& b, size_t tri_cap, size_t draw_c
     if ((rc = dev_reserve(c, b.tan, nv * 16))) return rc;
     if (forward && (rc = dev_reserve(c, b.wpos, nv * 16))) return rc;
     if ((rc = dev_reserve(c, b.tri_flags, nt * 4))) return rc;
-    if (!forward && (rc = dev_reserve(c, b.tri_shade, nt * 16))) return rc;
+    if (!forward && (rc = dev_reserve(c, b.tri_shade, nt * 32))) return rc;
     if (!forward && (rc = dev_reserve(c, b.draw_lean, nd * sizeof(LeanDrawDev)))) return rc;
     if ((rc = dev_reserve(c, b.big_list, nt * 4))) return rc;
     if ((rc = dev_reserve(c, b.tri_rec, nt * kTriRecBytes))) return rc;

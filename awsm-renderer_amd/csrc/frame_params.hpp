@@ -149,8 +149,10 @@ struct FrameDev {
     float4* wpos;                 // total_verts  (world position xyz, 1): transparent pass only, else null
     TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)
     uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..30, bit 31: ALPHA_MODE_MASK draw — transparent pass)
-    uint4* tri_shade;             // total_tris   (geometry pass only, may be null: {info word, byte offset of TEXCOORD_0 of corner 0 / 1 / 2 in the attribute data}:
-                                  //               what compute.wgsl:182-197 derives per pixel from meta -> indices, once per triangle; k_deform_transform)
+    uint4* tri_shade;             // 2 x total_tris (geometry pass only, may be null: {info word, 0, TEXCOORD_0 of corner 0} {TEXCOORD_0 of corner 1, of corner 2}: what
+                                  //               compute.wgsl:182-197 + texture_uvs.wgsl:64-84 fetch per pixel through meta -> indices -> attribute data, once per
+                                  //               triangle; k_deform_transform)
+    uint32_t attr_data_bytes;     // size of the attribute data buffer (k_deform_transform reads the corners' TEXCOORD_0 from it, bounds-checked)
     LeanDrawDev* draw_lean;       // n_draws (k_resolve_draws); null = the lean route is off for this frame
     uint32_t* shade_todo;         // [0] = count, [4 ..] = (block id << 2 | wavefront) of the 16x4-pixel groups k_shade_lean left to the general kernel
     uint32_t shade_todo_cap;

@@ -197,16 +197,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
         if (!FWD && f.tri_shade) {
             // compute.wgsl:182-197 + texture_uvs.wgsl:64-84, once per triangle instead of once per pixel: where each corner's TEXCOORD_0 lives.
             // Byte offsets into the attribute data (the reference's offsets are u32 as well).
-            uint4 ts = make_uint4(info, 0u, 0u, 0u);
-            if (sc->buf[AWSM_BUF_MATERIAL_META] && sc->buf[AWSM_BUF_ATTR_INDEX]) {
+            // The three corners' TEXCOORD_0 themselves (the values the opaque pass interpolates): a pixel then needs no index or attribute load at all.
+            // A mesh without that set (or a stream shorter than its indices claim) leaves zeros; such a draw has no texture to look up with them.
+            uint4 ts0 = make_uint4(info, 0u, 0u, 0u), ts1 = make_uint4(0u, 0u, 0u, 0u);
+            if (sc->buf[AWSM_BUF_MATERIAL_META] && sc->buf[AWSM_BUF_ATTR_INDEX] && sc->buf[AWSM_BUF_ATTR_DATA]) {
                 const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(gmp[9] / 256u) * 256u);
                 const uint32_t* ai = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_INDEX]) + mm[9] / 4u + lv;       // 3 * triangle == lv
                 const uint32_t data_word = mm[10] / 4u, stride_words = mm[11] / 4u, uv0 = mm[12];
-                ts.y = (data_word + ai[0] * stride_words + uv0) * 4u;
-                ts.z = (data_word + ai[1] * stride_words + uv0) * 4u;
-                ts.w = (data_word + ai[2] * stride_words + uv0) * 4u;
+                const uint32_t* ad = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_ATTR_DATA]);
+                const uint32_t w0 = data_word + ai[0] * stride_words + uv0, w1 = data_word + ai[1] * stride_words + uv0, w2 = data_word + ai[2] * stride_words + uv0;
+                const uint32_t n_words = f.attr_data_bytes >> 2;
+                if (w0 < n_words && w0 + 1u < n_words) { ts0.z = ad[w0]; ts0.w = ad[w0 + 1u]; }
+                if (w1 < n_words && w1 + 1u < n_words) { ts1.x = ad[w1]; ts1.y = ad[w1 + 1u]; }
+                if (w2 < n_words && w2 + 1u < n_words) { ts1.z = ad[w2]; ts1.w = ad[w2 + 1u]; }
             }
-            f.tri_shade[d.first_tri + lv / 3u] = ts;
+            f.tri_shade[2u * (d.first_tri + lv / 3u)] = ts0;
+            f.tri_shade[2u * (d.first_tri + lv / 3u) + 1u] = ts1;
         }
     }
 }

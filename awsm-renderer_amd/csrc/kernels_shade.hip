@@ -1727,186 +1727,268 @@ AWSM_DI void direct(const Lit& s, f3 l, f3 radiance, f3& color) {
 }
 }  // namespace lean
 
-AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid) {
+// Per-wavefront LDS staging of the per-triangle records (level 1 of the chain).  A 16x4 strip holds a handful of distinct triangles, and the
+// 208 bytes that belong to one — setup record 80, three vertex normals 48, three tangents 48, {info word, three TEXCOORD_0} 32 — used to be
+// loaded by every lane that shows it (13 vector loads of 16 bytes per lane: 60 % of what a pixel pulled through its CU's L1 / TA path).  Now the
+// wavefront finds its distinct triangles (one ballot per triangle: ranks are wave-uniform scalars then), lanes 0..12 bring each record in ONCE
+// with one LDS-DMA instruction (global_load_lds_dwordx4: global -> LDS without a register; 13 active lanes x 16 bytes land at slot + lane * 16),
+// nothing waits inside the loop, and after one s_waitcnt every lane reads its triangle's record from LDS (ds_read_b128, lanes of one triangle
+// read one address: a broadcast).  kLeanSlots distinct triangles per wavefront are staged; the lanes of a busier strip (distant, finely
+// tessellated geometry) load theirs directly as before.
+constexpr uint32_t kLeanSlots = 16u, kLeanChunks = 13u, kLeanNone = 0xFFFFFFFFu;
+struct LeanStage { uint4 q[kLeanSlots][kLeanChunks]; };      // one per wavefront: 3,328 bytes
+#define AWSM_AS3 __attribute__((address_space(3)))
+AWSM_DI float4 bits_float4(uint4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+AWSM_DI double2 bits_double2(uint4 v) { return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)); }
+AWSM_DI uint4 as_uint4(u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
+
+namespace lean {
+// fetch() for a texture whose record sits in scalar registers (the draw is wave-uniform inside the draw loop): base address in an SGPR pair,
+// 32-bit byte offsets per lane -> global_load ... v_off, s[base]: no 64-bit address arithmetic at all.
+struct TexS { const void* base; uint32_t lw, lh; };
+AWSM_DI TexS decode_s(uint32_t lo, uint32_t hi) { return {reinterpret_cast<const void*>(((unsigned long long)(hi & 0xFFFFu) << 32) | lo), (hi >> 16) & 15u, (hi >> 20) & 15u}; }
+AWSM_DI void fetch_s(const TexS& x, float u, float v, Tap& t) {
+    const float xf = __builtin_amdgcn_ldexpf(u, (int)x.lw) - 0.5f, yf = __builtin_amdgcn_ldexpf(v, (int)x.lh) - 0.5f;     // u * W - 0.5 (W a power of two: exact product)
+    const float flx = floorf(xf), fly = floorf(yf);
+    t.fx = xf - flx; t.fy = yf - fly;
+    const uint32_t xi = (uint32_t)(int)flx, yi = (uint32_t)(int)fly;
+    const uint32_t i0 = __builtin_amdgcn_ubfe(xi, 0u, x.lw), j0 = __builtin_amdgcn_ubfe(yi, 0u, x.lh), j1 = __builtin_amdgcn_ubfe(yi + 1u, 0u, x.lh);
+    const uint32_t sh = x.lw + 2u, i0b = i0 << 2;
+    const u32x2a4 p0 = gload<u32x2a4>(x.base, (j0 << sh) | i0b), p1 = gload<u32x2a4>(x.base, (j1 << sh) | i0b);
+    t.t00 = p0.x; t.t10 = p0.y; t.t01 = p1.x; t.t11 = p1.y;
+    if (__builtin_amdgcn_ubfe(xi + 1u, 0u, x.lw) == 0u) {      // i1 wrapped to column 0
+        t.t10 = gload<uint32_t>(x.base, j0 << sh); t.t11 = gload<uint32_t>(x.base, j1 << sh);
+    }
+}
+}  // namespace lean
+
+AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
+    const uint32_t lane = tid & 63u;
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
-    if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
+    const bool inside = cx < (int)f.width && cy < (int)f.sy1;            // compute.wgsl:111-113 (no early exit: lanes 0..12 stage records for the whole wavefront)
     const uint32_t pv = (uint32_t)cy * f.width + (uint32_t)cx;
     const uint32_t p = f.out_compact ? (((b.brow >> 1) << kTileShift) + ((uint32_t)cy & (uint32_t)(kTile - 1))) * f.width + (uint32_t)cx : pv;
 
-    const u32x2 key = gload<u32x2>(f.vis, pv << 3);
-    if ((key.x & key.y) == 0xFFFFFFFFu) {                                // compute.wgsl:149-153: no hit -> skybox (uniform cube)
+    u32x2 key = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (inside) key = gload<u32x2>(f.vis, pv << 3);
+    const bool hit = inside && (key.x & key.y) != 0xFFFFFFFFu;
+    if (inside && !hit)                                                   // compute.wgsl:149-153: no hit -> skybox (uniform cube)
         store_pixel(f, p, {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]});
-        return;
-    }
-    const uint32_t rank = ~key.x;                                         // 0xFFFFFFFF - low word
+    unsigned long long rem = __builtin_amdgcn_ballot_w64(hit);
+    if (rem == 0ull) return;                                              // wave-uniform
+    const uint32_t rank = hit ? ~key.x : 0xFFFFFFFFu;                     // 0xFFFFFFFF - low word; no triangle has the sentinel's rank
     const float depth = __uint_as_float(key.y);
 
     asm volatile("; MARK level1");
-    // ---- level 1: everything addressed by the triangle ----
-    const u32x4 ts = gload<u32x4>(f.tri_shade, rank << 4);          // first: level 2 hangs on it, and vmcnt counts in order
-    __builtin_amdgcn_sched_barrier(0);
-    const uint32_t ro = rank * (uint32_t)kTriRecBytes, vo = rank * 48u;
+    // ---- level 1: the distinct triangles' records, once each, global -> LDS ----
+    unsigned long long src_base; uint32_t src_stride;                    // lane j < 13 fetches chunk j of a record: where that chunk lives
+    {
+        const uint32_t j = lane;
+        const unsigned long long rec = (unsigned long long)f.tri_rec, nr = (unsigned long long)f.nrm, tn = (unsigned long long)f.tan, tsh = (unsigned long long)f.tri_shade;
+        src_base = j < 5u ? rec + j * 16u : (j < 8u ? nr + (j - 5u) * 16u : (j < 11u ? tn + (j - 8u) * 16u : tsh + (j - 11u) * 16u));
+        src_stride = j < 5u ? (uint32_t)kTriRecBytes : (j < 11u ? 48u : 32u);
+    }
+    uint32_t my_slot = kLeanNone, n_slots = 0u;
+    while (rem != 0ull && n_slots < kLeanSlots) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)__builtin_ctzll(rem));
+        if (rank == r) my_slot = n_slots;
+        if (lane < kLeanChunks)
+            __builtin_amdgcn_global_load_lds((const AWSM_AS1 void*)(src_base + (unsigned long long)r * src_stride), (AWSM_AS3 void*)&st->q[n_slots][0], 16, 0, 0);
+        rem &= ~__builtin_amdgcn_uicmp(rank, r, 32 /* ICMP_EQ */);
+        n_slots++;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the DMA writes have landed in LDS
+    const bool staged = my_slot != kLeanNone;
+    const uint4* rec = &st->q[staged ? my_slot : 0u][0];
+    uint4 ts0 = rec[11], ts1 = rec[12];
     TriRecRaw raw;
-    raw.q0 = as_float4(gload<f32x4>(f.tri_rec, ro)); raw.q1 = as_float4(gload<f32x4>(f.tri_rec, ro + 16u)); raw.q2 = as_float4(gload<f32x4>(f.tri_rec, ro + 32u));
-    { const f64x2 a = gload<f64x2>(f.tri_rec, ro + 48u), c = gload<f64x2>(f.tri_rec, ro + 64u); raw.d3 = make_double2(a.x, a.y); raw.d4 = make_double2(c.x, c.y); }
-    const float4 n0 = as_float4(gload<f32x4>(f.nrm, vo)), n1 = as_float4(gload<f32x4>(f.nrm, vo + 16u)), n2 = as_float4(gload<f32x4>(f.nrm, vo + 32u));
-    const float4 t0 = as_float4(gload<f32x4>(f.tan, vo)), t1 = as_float4(gload<f32x4>(f.tan, vo + 16u)), t2 = as_float4(gload<f32x4>(f.tan, vo + 32u));
-
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- level 2: the draw's record and the three corners' TEXCOORD_0 ----
-    const uint32_t lo = (ts.x & 0x00FFFFFFu) * (uint32_t)sizeof(LeanDrawDev);
-    const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
-    const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
-    const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u);
-    const void* attr = sc->buf[AWSM_BUF_ATTR_DATA];
-    const f32x2a4 uva = gload<f32x2a4>(attr, ts.y), uvb = gload<f32x2a4>(attr, ts.z), uvc = gload<f32x2a4>(attr, ts.w);
+    raw.q0 = bits_float4(rec[0]); raw.q1 = bits_float4(rec[1]); raw.q2 = bits_float4(rec[2]); raw.d3 = bits_double2(rec[3]); raw.d4 = bits_double2(rec[4]);
+    float4 n0 = bits_float4(rec[5]), n1 = bits_float4(rec[6]), n2 = bits_float4(rec[7]);
+    float4 t0 = bits_float4(rec[8]), t1 = bits_float4(rec[9]), t2 = bits_float4(rec[10]);
+    if (hit && !staged) {                                                  // more distinct triangles in this strip than slots: these lanes load their own
+        ts0 = as_uint4(gload<u32x4>(f.tri_shade, rank << 5)); ts1 = as_uint4(gload<u32x4>(f.tri_shade, (rank << 5) + 16u));
+        const uint32_t ro = rank * (uint32_t)kTriRecBytes, vo = rank * 48u;
+        raw.q0 = as_float4(gload<f32x4>(f.tri_rec, ro)); raw.q1 = as_float4(gload<f32x4>(f.tri_rec, ro + 16u)); raw.q2 = as_float4(gload<f32x4>(f.tri_rec, ro + 32u));
+        { const f64x2 a = gload<f64x2>(f.tri_rec, ro + 48u), c = gload<f64x2>(f.tri_rec, ro + 64u); raw.d3 = make_double2(a.x, a.y); raw.d4 = make_double2(c.x, c.y); }
+        n0 = as_float4(gload<f32x4>(f.nrm, vo)); n1 = as_float4(gload<f32x4>(f.nrm, vo + 16u)); n2 = as_float4(gload<f32x4>(f.nrm, vo + 32u));
+        t0 = as_float4(gload<f32x4>(f.tan, vo)); t1 = as_float4(gload<f32x4>(f.tan, vo + 16u)); t2 = as_float4(gload<f32x4>(f.tan, vo + 32u));
+    }
 
     asm volatile("; MARK strict");
-    // ---- STRICT: what fs_main wrote for this pixel (before the lean test: the loads above stay ahead of every branch, and the
-    // general route needs the same values) ----
+    // ---- STRICT: what fs_main wrote for this pixel ----
     TriSetup t;
     tri_rec_unpack(raw, t);
     const GBufferTexel g = reconstruct_core<false>(t, n0, n1, n2, t0, t1, t2, cx, cy);
+    const float bz = (1.0f - g.bx) - g.by;                               // compute.wgsl:185-186
+    const float u = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.z), __uint_as_float(ts1.x), __uint_as_float(ts1.z));
+    const float v = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.w), __uint_as_float(ts1.y), __uint_as_float(ts1.w));
+    // beyond +-32768 the general sampler's range guard decides (also NaN): the wavefront goes to the general kernel
+    bool todo = __builtin_amdgcn_ballot_w64(hit && !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f)) != 0ull;
 
-    bool todo = (L0.x & 1u) == 0u;
-    if (__builtin_amdgcn_ballot_w64(todo) == 0ull) {
-        const float bz = (1.0f - g.bx) - g.by;                           // compute.wgsl:185-186
-        const float u = interp3_strict(g.bx, g.by, bz, uva.x, uvb.x, uvc.x), v = interp3_strict(g.bx, g.by, bz, uva.y, uvb.y, uvc.y);
-        todo = !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f);           // beyond: the general sampler's range guard decides (also NaN)
-        if (__builtin_amdgcn_ballot_w64(todo) == 0ull) {
     asm volatile("; MARK fetch");
-            // ---- all texel fetches of the pixel ----
-            const uint32_t exists = L0.x >> 8;
-            const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
-            lean::Tap tp0, tp1, tp2, tp3, tp4;
-            if (exists & 1u) lean::fetch(x0, u, v, tp0);
-            if (exists & 2u) lean::fetch(x1, u, v, tp1);
-            if (exists & 4u) lean::fetch(x2, u, v, tp2);
-            if (exists & 8u) lean::fetch(x3, u, v, tp3);
-            if (exists & 16u) lean::fetch(x4, u, v, tp4);
+    // ---- levels 2 and 3: the draw's 96-byte lean record and all texel fetches of the pixel.  A strip almost always lies inside ONE draw: the record
+    // then comes in by scalar loads — texture bases, extents and flags sit in scalar registers, texel addresses are 32-bit offsets from an SGPR
+    // base, the branches on what the material has are scalar.  A strip that straddles draws takes the per-lane form of the same loads. ----
+    const uint32_t draw = ts0.x & 0x00FFFFFFu;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)draw, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(hit)));
+    const bool one_draw = __builtin_amdgcn_ballot_w64(hit && draw != d0) == 0ull;
+    f3 base, emissive;
+    float metallic_in, roughness_in, normal_scale, occlusion_strength;
+    uint32_t exists;
+    lean::Tap tp0, tp1, tp2, tp3, tp4;
+    if (one_draw) {
+        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
+        const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
+        const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
+        const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u);
+        todo = todo || (L0.x & 1u) == 0u;
+        const uint32_t ex = todo ? 0u : L0.x >> 8;                        // scalar
+        if (ex & 1u) lean::fetch_s(lean::decode_s(L3.x, L3.y), u, v, tp0);
+        if (ex & 2u) lean::fetch_s(lean::decode_s(L3.z, L3.w), u, v, tp1);
+        if (ex & 4u) lean::fetch_s(lean::decode_s(L4.x, L4.y), u, v, tp2);
+        if (ex & 8u) lean::fetch_s(lean::decode_s(L4.z, L4.w), u, v, tp3);
+        if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), u, v, tp4);
+        exists = ex;
+        metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
+        base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
+        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)};
+    } else {
+        const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
+        const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
+        const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
+        const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u);
+        todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & 1u) == 0u) != 0ull;
+        const uint32_t ex = (todo || !hit) ? 0u : L0.x >> 8;
+        const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
+        if (ex & 1u) lean::fetch(x0, u, v, tp0);
+        if (ex & 2u) lean::fetch(x1, u, v, tp1);
+        if (ex & 4u) lean::fetch(x2, u, v, tp2);
+        if (ex & 8u) lean::fetch(x3, u, v, tp3);
+        if (ex & 16u) lean::fetch(x4, u, v, tp4);
+        exists = ex;
+        metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
+        base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
+        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)};
+    }
+    if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
+        if (lane == 0u) {
+            const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
+            if (slot < f.shade_todo_cap) f.shade_todo[4u + slot] = (wg << 2) | (tid >> 6);
+        }
+        return;
+    }
+    if (!hit) return;
 
     asm volatile("; MARK standard");
-            // ---- standard.wgsl:11-62 (as shade_surface) ----
-            const m4 inv_proj = cload_m4(f.camera, 256u), inv_view = cload_m4(f.camera, 320u);
-            const float proj33 = cload<float>(f.camera, 64u + 60u);
-            uint32_t fw = f.width, fh = f.height;
-            asm volatile("" : "+s"(fw), "+s"(fh));                          // keeps the two reciprocals out of the persistent loop's live registers (they were spilled)
-            const f2 suv = {((float)cx + 0.5f) * fm::rcp((float)fw), ((float)cy + 0.5f) * fm::rcp((float)fh)};
-            const f4 view_h = fm::fmul(inv_proj, {suv.x * 2.0f - 1.0f, 1.0f - suv.y * 2.0f, depth, 1.0f});
-            const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
-            const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
-            const f3 world_position = {wp.x, wp.y, wp.z};
-            f3 surface_to_camera;
-            if (proj33 > 0.9f) {
-                surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
-            } else {
-                const f32x4 cp = cload<f32x4>(f.camera, 384u);
-                const f3 to_camera = mk3(cp.x, cp.y, cp.z) - world_position;
-                surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
-            }
+    // ---- standard.wgsl:11-62 (as shade_surface) ----
+    const m4 inv_proj = cload_m4(f.camera, 256u), inv_view = cload_m4(f.camera, 320u);
+    const float proj33 = cload<float>(f.camera, 64u + 60u);
+    uint32_t fw = f.width, fh = f.height;
+    asm volatile("" : "+s"(fw), "+s"(fh));                          // keeps the two reciprocals out of the persistent loop's live registers (they were spilled)
+    const f2 suv = {((float)cx + 0.5f) * fm::rcp((float)fw), ((float)cy + 0.5f) * fm::rcp((float)fh)};
+    const f4 view_h = fm::fmul(inv_proj, {suv.x * 2.0f - 1.0f, 1.0f - suv.y * 2.0f, depth, 1.0f});
+    const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
+    const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
+    const f3 world_position = {wp.x, wp.y, wp.z};
+    f3 surface_to_camera;
+    if (proj33 > 0.9f) {
+        surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
+    } else {
+        const f32x4 cp = cload<f32x4>(f.camera, 384u);
+        const f3 to_camera = mk3(cp.x, cp.y, cp.z) - world_position;
+        surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
+    }
     asm volatile("; MARK tbn");
-            const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
+    const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
 
     asm volatile("; MARK material");
-            // ---- material_color_calc.wgsl:25-265 for a material without optional blocks ----
-            f3 base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)};
-            if (exists & 1u) { const lean::Weights w = lean::weights(tp0); base = {base.x * lean::channel<0>(tp0, w), base.y * lean::channel<1>(tp0, w), base.z * lean::channel<2>(tp0, w)}; }
-            float metallic_in = __uint_as_float(L0.y), roughness_in = __uint_as_float(L0.z);
-            if (exists & 2u) { const lean::Weights w = lean::weights(tp1); metallic_in = metallic_in * lean::channel<2>(tp1, w); roughness_in = roughness_in * lean::channel<1>(tp1, w); }
-            f3 normal = tbn.N;
-            if (exists & 4u) {   // material_color_calc.wgsl:301-322
-                const lean::Weights w = lean::weights(tp2);
-                const float scale = __uint_as_float(L0.w);
-                const float ntx = (lean::channel<0>(tp2, w) * 2.0f - 1.0f) * scale, nty = (lean::channel<1>(tp2, w) * 2.0f - 1.0f) * scale, ntz = lean::channel<2>(tp2, w) * 2.0f - 1.0f;
-                normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
-            }
-            float occlusion = 1.0f;
-            if (exists & 8u) { const lean::Weights w = lean::weights(tp3); occlusion = mixf(1.0f, lean::channel<0>(tp3, w), __uint_as_float(L1.w)); }
-            f3 emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)};
-            if (exists & 16u) { const lean::Weights w = lean::weights(tp4); emissive = {emissive.x * lean::channel<0>(tp4, w), emissive.y * lean::channel<1>(tp4, w), emissive.z * lean::channel<2>(tp4, w)}; }
+    // ---- material_color_calc.wgsl:25-265 for a material without optional blocks ----
+    if (exists & 1u) { const lean::Weights w = lean::weights(tp0); base = {base.x * lean::channel<0>(tp0, w), base.y * lean::channel<1>(tp0, w), base.z * lean::channel<2>(tp0, w)}; }
+    if (exists & 2u) { const lean::Weights w = lean::weights(tp1); metallic_in = metallic_in * lean::channel<2>(tp1, w); roughness_in = roughness_in * lean::channel<1>(tp1, w); }
+    f3 normal = tbn.N;
+    if (exists & 4u) {   // material_color_calc.wgsl:301-322
+        const lean::Weights w = lean::weights(tp2);
+        const float scale = normal_scale;
+        const float ntx = (lean::channel<0>(tp2, w) * 2.0f - 1.0f) * scale, nty = (lean::channel<1>(tp2, w) * 2.0f - 1.0f) * scale, ntz = lean::channel<2>(tp2, w) * 2.0f - 1.0f;
+        normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
+    }
+    float occlusion = 1.0f;
+    if (exists & 8u) { const lean::Weights w = lean::weights(tp3); occlusion = mixf(1.0f, lean::channel<0>(tp3, w), occlusion_strength); }
+    if (exists & 16u) { const lean::Weights w = lean::weights(tp4); emissive = {emissive.x * lean::channel<0>(tp4, w), emissive.y * lean::channel<1>(tp4, w), emissive.z * lean::channel<2>(tp4, w)}; }
 
     asm volatile("; MARK surface");
-            // ---- lights.wgsl:121-152 / brdf.wgsl (apply_lighting, brdf_ibl, brdf_direct above, with ior 1.5, specular 1, no transmission / clearcoat / sheen) ----
-            Surface sf;
-            sf.n = fm::fsafe_normalize(normal);
-            sf.v = fm::fsafe_normalize(surface_to_camera);
-            sf.metallic = clampf(metallic_in, 0.0f, 1.0f);
-            sf.roughness = fmaxf(clampf(roughness_in, 0.0f, 1.0f), 0.04f);
-            sf.alpha = sf.roughness * sf.roughness;
-            const float ndv = fm::fdot(sf.n, sf.v);
-            sf.n_dot_v_ibl = saturate(ndv);
-            sf.n_dot_v_dir = fmaxf(ndv, 1e-4f);
-            const float f0b = ior_to_f0(1.5f);
-            sf.F0 = mix3(splat3(fminf(f0b, 1.0f)), base, sf.metallic);
-            sf.f90 = mixf(1.0f, 1.0f, sf.metallic);
-            sf.sheen_scaling_dir = 1.0f;
-            sf.g1_v = geometry_schlick_ggx(saturate(ndv), sf.alpha);
-            sf.cc_n = sf.n;
-            sf.df90 = splat3(sf.f90) - sf.F0;
-            sf.base_diffuse = base * ((1.0f - sf.metallic) * (1.0f / kPi));
-            const float ac = fmaxf(sf.alpha, 0.001f);
-            sf.a2 = ac * ac; sf.a2m1 = sf.a2 - 1.0f;
-            sf.gk = ((ac + 1.0f) * (ac + 1.0f)) * 0.125f; sf.one_m_gk = 1.0f - sf.gk;
-            sf.has_sheen = false; sf.has_clearcoat = false;
-            lean::Lit lit;
-            lit.n = sf.n; lit.v = sf.v; lit.F0 = sf.F0; lit.df90 = sf.df90; lit.bd = sf.base_diffuse;
-            lit.ndv_dir = sf.n_dot_v_dir; lit.ndv4 = 4.0f * sf.n_dot_v_dir; lit.a2m1 = sf.a2m1; lit.a2_g1v = sf.a2 * sf.g1_v; lit.gk = sf.gk; lit.one_m_gk = sf.one_m_gk;
-            lit.occlusion = occlusion;
-            f3 color;
+    // ---- lights.wgsl:121-152 / brdf.wgsl (apply_lighting, brdf_ibl, brdf_direct above, with ior 1.5, specular 1, no transmission / clearcoat / sheen) ----
+    Surface sf;
+    sf.n = fm::fsafe_normalize(normal);
+    sf.v = fm::fsafe_normalize(surface_to_camera);
+    sf.metallic = clampf(metallic_in, 0.0f, 1.0f);
+    sf.roughness = fmaxf(clampf(roughness_in, 0.0f, 1.0f), 0.04f);
+    sf.alpha = sf.roughness * sf.roughness;
+    const float ndv = fm::fdot(sf.n, sf.v);
+    sf.n_dot_v_ibl = saturate(ndv);
+    sf.n_dot_v_dir = fmaxf(ndv, 1e-4f);
+    const float f0b = ior_to_f0(1.5f);
+    sf.F0 = mix3(splat3(fminf(f0b, 1.0f)), base, sf.metallic);
+    sf.f90 = mixf(1.0f, 1.0f, sf.metallic);
+    sf.sheen_scaling_dir = 1.0f;
+    sf.g1_v = geometry_schlick_ggx(saturate(ndv), sf.alpha);
+    sf.cc_n = sf.n;
+    sf.df90 = splat3(sf.f90) - sf.F0;
+    sf.base_diffuse = base * ((1.0f - sf.metallic) * (1.0f / kPi));
+    const float ac = fmaxf(sf.alpha, 0.001f);
+    sf.a2 = ac * ac; sf.a2m1 = sf.a2 - 1.0f;
+    sf.gk = ((ac + 1.0f) * (ac + 1.0f)) * 0.125f; sf.one_m_gk = 1.0f - sf.gk;
+    sf.has_sheen = false; sf.has_clearcoat = false;
+    lean::Lit lit;
+    lit.n = sf.n; lit.v = sf.v; lit.F0 = sf.F0; lit.df90 = sf.df90; lit.bd = sf.base_diffuse;
+    lit.ndv_dir = sf.n_dot_v_dir; lit.ndv4 = 4.0f * sf.n_dot_v_dir; lit.a2m1 = sf.a2m1; lit.a2_g1v = sf.a2 * sf.g1_v; lit.gk = sf.gk; lit.one_m_gk = sf.one_m_gk;
+    lit.occlusion = occlusion;
+    f3 color;
     asm volatile("; MARK ibl");
-            {   // brdf_ibl with the uniform cubes
-                const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
-                const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
-                const float n_dot_v = sf.n_dot_v_ibl;
-                const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
-                const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
-                const f3 base_layer = (base * (1.0f / kPi)) * irradiance;
-                const float k_d = (1.0f - F_view_max) * (1.0f - sf.metallic);
-                const f3 base_contribution = (base_layer * k_d) * occlusion;
-                const f2 lut = lean::brdf_lut(sc->lut_rg16f, sc->lut_w, sc->lut_h, n_dot_v, sf.roughness);
-                const f3 spec_term = sf.F0 * lut.x + splat3(sf.f90 * lut.y);
-                const f3 specular = (prefiltered * spec_term) * mixf(1.0f, occlusion, 0.5f);
-                color = (base_contribution + specular) + emissive;
-            }
+    {   // brdf_ibl with the uniform cubes
+        const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
+        const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
+        const float n_dot_v = sf.n_dot_v_ibl;
+        const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
+        const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
+        const f3 base_layer = (base * (1.0f / kPi)) * irradiance;
+        const float k_d = (1.0f - F_view_max) * (1.0f - sf.metallic);
+        const f3 base_contribution = (base_layer * k_d) * occlusion;
+        const f2 lut = lean::brdf_lut(sc->lut_rg16f, sc->lut_w, sc->lut_h, n_dot_v, sf.roughness);
+        const f3 spec_term = sf.F0 * lut.x + splat3(sf.f90 * lut.y);
+        const f3 specular = (prefiltered * spec_term) * mixf(1.0f, occlusion, 0.5f);
+        color = (base_contribution + specular) + emissive;
+    }
     asm volatile("; MARK lights");
-            const uint32_t n_lights = min(cload<uint32_t>(sc->buf[AWSM_BUF_LIGHTS_INFO], 0u), f.lights_cap);
-            const void* lights = sc->buf[AWSM_BUF_LIGHTS];
-            for (uint32_t i = 0; i < n_lights; i++) {
-                const f32x4 pre0 = cload<f32x4>(f.lights_pre, i * 32u), pre1 = cload<f32x4>(f.lights_pre, i * 32u + 16u);
-                const uint32_t kind = (uint32_t)pre0.w;
-                f3 light_dir = {pre0.x, pre0.y, pre0.z}, radiance = {pre1.x, pre1.y, pre1.z};
-                if (kind == 2u || kind == 3u) {
-                    const f32x4 pos_range = cload<f32x4>(lights, i * 64u);
-                    const f3 stl = mk3(pos_range.x, pos_range.y, pos_range.z) - world_position;
-                    const float d2 = fm::fdot(stl, stl);
-                    const float inv_d = d2 > 0.0f ? fm::rsq(d2) : 0.0f;
-                    const float dist = d2 * inv_d;
-                    float att;   // math.wgsl:12-19 inverse_square
-                    if (pos_range.w == 0.0f) att = fm::rcp(fmaxf(dist * dist, 0.01f));
-                    else { const float fo = 1.0f - fm::fdiv(dist * dist, pos_range.w * pos_range.w); att = fm::fdiv(saturate(fo * fo), dist * dist + 1.0f); }
-                    const f3 to_light = stl * inv_d;
-                    if (kind == 3u) {
-                        const f32x4 dir_inner = cload<f32x4>(lights, i * 64u + 16u), kind_outer = cload<f32x4>(lights, i * 64u + 48u);
-                        const float cos_l = fm::fdot(to_light, -light_dir);
-                        const float sm = saturate(fm::fdiv(cos_l - kind_outer.y, dir_inner.w - kind_outer.y));
-                        att = att * (sm * sm);
-                    }
-                    light_dir = to_light;
-                    radiance = radiance * att;
-                } else if (kind != 1u) { light_dir = {0.0f, 0.0f, 0.0f}; radiance = {0.0f, 0.0f, 0.0f}; }
-                lean::direct(lit, light_dir, radiance, color);
+    const uint32_t n_lights = min(cload<uint32_t>(sc->buf[AWSM_BUF_LIGHTS_INFO], 0u), f.lights_cap);
+    const void* lights = sc->buf[AWSM_BUF_LIGHTS];
+    for (uint32_t i = 0; i < n_lights; i++) {
+        const f32x4 pre0 = cload<f32x4>(f.lights_pre, i * 32u), pre1 = cload<f32x4>(f.lights_pre, i * 32u + 16u);
+        const uint32_t kind = (uint32_t)pre0.w;
+        f3 light_dir = {pre0.x, pre0.y, pre0.z}, radiance = {pre1.x, pre1.y, pre1.z};
+        if (kind == 2u || kind == 3u) {
+            const f32x4 pos_range = cload<f32x4>(lights, i * 64u);
+            const f3 stl = mk3(pos_range.x, pos_range.y, pos_range.z) - world_position;
+            const float d2 = fm::fdot(stl, stl);
+            const float inv_d = d2 > 0.0f ? fm::rsq(d2) : 0.0f;
+            const float dist = d2 * inv_d;
+            float att;   // math.wgsl:12-19 inverse_square
+            if (pos_range.w == 0.0f) att = fm::rcp(fmaxf(dist * dist, 0.01f));
+            else { const float fo = 1.0f - fm::fdiv(dist * dist, pos_range.w * pos_range.w); att = fm::fdiv(saturate(fo * fo), dist * dist + 1.0f); }
+            const f3 to_light = stl * inv_d;
+            if (kind == 3u) {
+                const f32x4 dir_inner = cload<f32x4>(lights, i * 64u + 16u), kind_outer = cload<f32x4>(lights, i * 64u + 48u);
+                const float cos_l = fm::fdot(to_light, -light_dir);
+                const float sm = saturate(fm::fdiv(cos_l - kind_outer.y, dir_inner.w - kind_outer.y));
+                att = att * (sm * sm);
             }
+            light_dir = to_light;
+            radiance = radiance * att;
+        } else if (kind != 1u) { light_dir = {0.0f, 0.0f, 0.0f}; radiance = {0.0f, 0.0f, 0.0f}; }
+        lean::direct(lit, light_dir, radiance, color);
+    }
     asm volatile("; MARK store");
-            store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
-            return;
-        }
-    }
-    // this wavefront goes to the general kernel: nothing has been written
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-    if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) {
-        const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
-        if (slot < f.shade_todo_cap) f.shade_todo[4u + slot] = (wg << 2) | (tid >> 6);
-    }
+    store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
 }
 // k_shade_lean<false>: a wavefront per 16x4-pixel strip.  k_shade_lean<true>: a persistent grid (lean_grid workgroups; workgroup w
 // runs on XCD w & 7, as the hardware deals them) whose wavefronts take strips from counters until the XCD's share is used up —
@@ -1924,7 +2006,9 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
 template <bool PERSIST>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PERSIST ? 5 : AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+    __shared__ LeanStage stage[4];                                         // one per wavefront (no barrier anywhere: the four are independent)
     if (frame_poisoned(f)) return;
+    LeanStage* const st = &stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     const uint32_t xcd = blockIdx.x & 7u, lane = threadIdx.x & 63u;
     const uint32_t bx_n = (f.width + 15u) >> 4, by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.sy1 - f.sy0) + 15u) >> 4;
     const uint32_t lp = 32u - (uint32_t)__builtin_clz((bx_n - 1u) | 1u);  // log2 of the block pitch
@@ -1951,7 +2035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PERSIST ? 5
         if (bcol < bx_n && j < share) {
             ShadeBlock b;
             shade_block_at(f, b, brow, bcol);
-            lean_block(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane);
+            lean_block(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane, st);
         }
         if (!PERSIST) break;
     }

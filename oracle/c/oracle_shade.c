@@ -935,6 +935,15 @@ static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const
 /* The shading of one visibility sample: compute.wgsl:171-299 (main sample) == material_shading.wgsl:69-168
  * (msaa_process_sample).  `depth_sample` is the depth the standard coordinates are built from (always sample 0's,
  * standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug colour, 2 hud mesh (main path only), 3 no G-buffer texel. */
+/* Conditioning probe (tests only; oracle_set_perturbation): with k != 0 the two inputs of the lighting that a relaxed-arithmetic implementation
+ * cannot reproduce to the last bit are moved by 16 ulps — k = 1, 2: the decoded normal tilted along the frame's tangent / bitangent;
+ * k = 3, 4: the reconstructed world position shifted across the view ray (16 ulps of the largest coordinate involved).  The difference between
+ * such a frame and the unperturbed one says, per pixel, what that much input noise does to the oracle's OWN result: the pixel's condition
+ * number times epsilon, measured, not modelled.  A GGX peak on a near-mirror texel or a silhouette with n.v -> 0 shows up as a large
+ * response; an ordinary pixel as a response far below the 1e-4 bar.  (oracle_lib.OracleFrame.conditioning) */
+static int g_perturb = 0;
+void oracle_set_perturbation(int k) { g_perturb = k; }
+
 typedef struct { ovec3 color; float alpha; int kind; ovec4 packed_nt; } SurfaceColor;
 static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const float* nt, uint32_t rank, int cx, int cy,
                                   float depth_sample, int check_hud) {
@@ -993,6 +1002,22 @@ static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const
 
     o_tbn tbn = o_unpack_normal_tangent(g.packed_nt);
     uint32_t n_lights = rd_u32(s->buf[AWSM_BUF_LIGHTS_INFO]);   /* lights.wgsl:38-47 */
+    if (g_perturb != 0) {      /* conditioning probe, see above: never set in a parity run */
+        const float th = 16.0f * 1.1920929e-7f;
+        if (g_perturb <= 2) {
+            tbn.N = ov3_normalize(ov3_add(tbn.N, ov3_scale(g_perturb == 1 ? tbn.T : tbn.B, th)));
+        } else {
+            float m = fmaxf(fmaxf(fabsf(world_position.x), fabsf(world_position.y)), fabsf(world_position.z));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(cam_pos[0]), fabsf(cam_pos[1])), fabsf(cam_pos[2])));
+            ovec3 axis = fabsf(surface_to_camera.y) < 0.9f ? ov3(0.0f, 1.0f, 0.0f) : ov3(1.0f, 0.0f, 0.0f);
+            ovec3 p1 = ov3_normalize(ov3_cross(surface_to_camera, axis)), p2 = ov3_cross(surface_to_camera, p1);
+            world_position = ov3_add(world_position, ov3_scale(g_perturb == 3 ? p1 : p2, th * m));
+            if (!is_ortho) {
+                ovec3 to_camera = ov3_sub(ov3(cam_pos[0], cam_pos[1], cam_pos[2]), world_position);
+                surface_to_camera = ov3_dot(to_camera, to_camera) > 0.0f ? o_safe_normalize(to_camera) : ov3(0.0f, 0.0f, 1.0f);
+            }
+        }
+    }
 
     if (shader_id == 2u) {
         /* unlit_material.wgsl:28-73 + material_color_calc.wgsl:517-580 */

@@ -214,6 +214,24 @@ class OracleFrame:
     def run(self, threads=8):
         return self.transform().raster(threads).shade(threads)
 
+    def conditioning(self, threads=8) -> np.ndarray:
+        """(height, width, 4) f64: per pixel and channel, how far the oracle's own colour moves when the decoded normal (two tilts) or the
+        reconstructed world position (two shifts across the view ray) is off by 16 ulps — the pixel's condition number times epsilon, measured
+        (oracle_shade.c: oracle_set_perturbation).  Call after shade(); leaves rgba32f / rgba16f as shade() made them."""
+        base32, base16 = self.rgba32f.copy(), self.rgba16f.copy()
+        worst = np.zeros(base32.shape, dtype=np.float64)
+        try:
+            for k in (1, 2, 3, 4):
+                lib().oracle_set_perturbation(C.c_int(k))
+                self.shade(threads)
+                d = np.abs(self.rgba32f.astype(np.float64) - base32.astype(np.float64))
+                worst = np.maximum(worst, np.where(np.isfinite(d), d, np.inf))
+        finally:
+            lib().oracle_set_perturbation(C.c_int(0))
+            self.rgba32f[...] = base32
+            self.rgba16f[...] = base16
+        return worst
+
     def forward(self, draws: List[dict], threads=8):
         """World transparent pass over `draws` (HostModel.collect_transparent_draws()), after run(): fills fwd_clip / fwd_nt / fwd_wpos
         and the composite image (composite32f holds the f16 values, composite16f their bits)."""

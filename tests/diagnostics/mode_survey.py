@@ -64,7 +64,7 @@ def survey(n_views, only=(), lut=None, seed=20260105):
             if transparent:
                 orc.forward(model.collect_transparent_draws(), 64)
             helpers.hip_frame(model, lut, dev=dev, transparent=transparent, **kw)
-            c = helpers.compare_frames(orc, dev)
+            c = helpers.compare_frames(orc, dev, cond=orc.conditioning(64))      # the opaque image; conditioned bound (helpers.compare_frames)
             if not kw.get("msaa"):      # the STRICT G-buffer texel, value for value (awsm_hip_read_gbuffer: single-sampled frames)
                 go, gh = orc.gbuffer(64), dev.read_gbuffer()
                 hit = orc.keys != np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -93,8 +93,11 @@ def f16_ulp_distance(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
     return np.abs(mono(a_bits) - mono(b_bits))
 
 
-def compare_frames(orc, dev, rows=None, rgb_tol=1e-4):
-    """Returns a dict of mismatch counts / max errors between an OracleFrame and a HipDevice frame."""
+def compare_frames(orc, dev, rows=None, rgb_tol=1e-4, cond=None):
+    """Returns a dict of mismatch counts / max errors between an OracleFrame and a HipDevice frame.
+    cond: OracleFrame.conditioning() of the same frame — what 16 ulps of noise in the decoded normal / the reconstructed position do to the
+    oracle's own colour, per pixel.  With it the bound is conditioned: rgb_tol * max(1, |ref|) + cond, and the f16 distance is taken over the
+    well-conditioned pixels (cond <= 1e-5) only; `rgb_over_base` then counts the pixels that needed their condition number."""
     H = orc.height
     y0, y1 = rows if rows else (0, H)
     out = {}
@@ -111,11 +114,16 @@ def compare_frames(orc, dev, rows=None, rgb_tol=1e-4):
     diff = np.where(np.isfinite(diff), diff, np.inf)
     # the bar: 1e-4 absolute for values up to 1.0, 1e-4 relative for HDR values above 1.0 (the output is linear HDR; a GGX
     # highlight amplifies 1e-7 differences in the normal ~100x, so bright specular pixels cannot hold an absolute bound)
-    bound = rgb_tol * np.maximum(1.0, np.abs(ref))
+    base = rgb_tol * np.maximum(1.0, np.abs(ref))
+    bound = base if cond is None else base + cond[y0:y1]
     out["rgb_max_abs"] = float(diff[..., :3].max()) if diff.size else 0.0
     out["rgb_max_rel_to_bound"] = float((diff[..., :3] / bound[..., :3]).max()) if diff.size else 0.0
     out["rgb_over_tol"] = int((diff[..., :3] > bound[..., :3]).any(axis=-1).sum())
+    out["rgb_over_base"] = int((diff[..., :3] > base[..., :3]).any(axis=-1).sum())
     out["alpha_mismatch"] = int((f32[y0:y1, :, 3] != orc.rgba32f[y0:y1, :, 3]).sum())
     h16 = dev.read_opaque()
-    out["f16_max_ulp"] = int(f16_ulp_distance(h16[y0:y1], orc.rgba16f[y0:y1]).max()) if h16.size else 0
+    ulp = f16_ulp_distance(h16[y0:y1], orc.rgba16f[y0:y1]) if h16.size else np.zeros((1,), dtype=np.int32)
+    if cond is not None and ulp.ndim == 3:
+        ulp = np.where((cond[y0:y1, :, :3].max(axis=-1) <= 1e-5)[..., None], ulp, 0)
+    out["f16_max_ulp"] = int(ulp.max()) if ulp.size else 0
     return out
