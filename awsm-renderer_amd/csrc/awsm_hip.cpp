@@ -6,6 +6,7 @@
 // either drives the HIP kernels or fails with a status code.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -72,6 +73,8 @@ struct FrameBufs {
     DevBuf tile_split, raster_scratch;     // split raster tiles: per-tile {first scratch slot, slices done}; partial tiles (geometry pass only)
     uint32_t raster_extra_cap = 0, raster_slot_cap = 0;
     uint32_t bin_capacity = 0;
+    float pix2view[16] = {}, view_rot[9] = {}, cam_pos[3] = {}, ortho_view_dir[3] = {};   // the lean opaque kernel's view of the camera this slot's frame was submitted with
+    uint32_t cam_ortho = 0;
     size_t tri_cap = 0, draw_cap = 0;      // triangles / draws the per-pass buffers below are sized for (reserve_pass_buffers)
     uint32_t sized_w = 0, sized_h = 0;     // ... and the frame size their tile tables are sized for
     std::vector<DrawDev> draws_uploaded;   // what draws_dev currently holds
@@ -91,6 +94,7 @@ struct AwsmHipCtx {
     std::string last_error;
 
     DevBuf bufs[AWSM_BUF_COUNT];
+    uint8_t camera_host[512] = {};   // what the caller last wrote to AWSM_BUF_CAMERA (awsm_hip_buffer_write): compose_pixel_to_view reads it
     DevScene scene{};            // host copy
     DevScene* scene_dev = nullptr;
     bool scene_dirty = true;
@@ -431,6 +435,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->vis = (unsigned long long*)FB(c).vis.ptr;
     f->camera = (const uint8_t*)(c->overlap ? FB(c).camera.ptr : c->bufs[AWSM_BUF_CAMERA].ptr);
     f->camera_snap = nullptr; f->camera_snap_words = 0;
+    memcpy(f->pix2view, FB(c).pix2view, sizeof f->pix2view); memcpy(f->view_rot, FB(c).view_rot, sizeof f->view_rot); memcpy(f->cam_pos, FB(c).cam_pos, sizeof f->cam_pos);
+    memcpy(f->ortho_view_dir, FB(c).ortho_view_dir, sizeof f->ortho_view_dir); f->cam_ortho = FB(c).cam_ortho;
     f->msaa = c->msaa;
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
@@ -440,6 +446,28 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->out_rgba32f = (float*)c->out32[c->slot].ptr;
     f->lights_pre = (float4*)c->lights_pre[c->slot].ptr;
     f->lights_cap = (uint32_t)(c->lights_pre[c->slot].size / 32);
+}
+
+// standard.wgsl:17-27 as one matrix: view_h = inv_proj * clip with clip = (2 (px + 0.5) / W - 1, 1 - 2 (py + 0.5) / H, depth, 1).  Composed in f64 from the f32
+// matrices of the camera UBO as the caller wrote it (camera.rs:169-219: inv_proj at 256, inv_view at 320, position at 384, proj at 64), once per frame at
+// awsm_hip_geometry_pass — the camera the frame is shaded with is the camera it was submitted with.
+void compose_pixel_to_view(AwsmHipCtx* c, FrameBufs& b) {
+    float cam[128];
+    memcpy(cam, c->camera_host, 512);
+    const float* proj = cam + 16; const float* inv_proj = cam + 64; const float* inv_view = cam + 80;
+    const double W = (double)c->width, H = (double)c->height;
+    // A: (px, py, depth, 1) -> clip, column-major
+    const double A[16] = {2.0 / W, 0, 0, 0,   0, -2.0 / H, 0, 0,   0, 0, 1, 0,   1.0 / W - 1.0, 1.0 - 1.0 / H, 0, 1};
+    for (int col = 0; col < 4; col++) for (int row = 0; row < 4; row++) {
+        double s = 0.0;
+        for (int k = 0; k < 4; k++) s += (double)inv_proj[k * 4 + row] * A[col * 4 + k];
+        b.pix2view[col * 4 + row] = (float)s;
+    }
+    for (int col = 0; col < 3; col++) for (int row = 0; row < 3; row++) b.view_rot[col * 3 + row] = inv_view[col * 4 + row];
+    for (int i = 0; i < 3; i++) b.cam_pos[i] = cam[96 + i];
+    b.cam_ortho = proj[15] > 0.9f ? 1u : 0u;      // standard.wgsl:38: proj[3][3]
+    const double vx = inv_view[8], vy = inv_view[9], vz = inv_view[10], l = std::sqrt(vx * vx + vy * vy + vz * vz);
+    b.ortho_view_dir[0] = l > 0.0 ? (float)(vx / l) : 0.0f; b.ortho_view_dir[1] = l > 0.0 ? (float)(vy / l) : 0.0f; b.ortho_view_dir[2] = l > 0.0 ? (float)(vz / l) : 1.0f;
 }
 
 int record(AwsmHipCtx* c, int which, hipStream_t s = nullptr) {
@@ -958,6 +986,7 @@ int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf which, size_t dst_off, const vo
     if (len == 0) return AWSM_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (which != AWSM_BUF_CAMERA) { int rcb = scene_write_barrier(c); if (rcb) return rcb; }   // the opaque pass reads a per-frame camera snapshot
+    else if (dst_off < 512) memcpy(c->camera_host + dst_off, src, std::min<size_t>(len, 512 - dst_off));
     uint8_t* dst = (uint8_t*)b.ptr + dst_off;
     if (len <= (1u << 20)) return upload_small(c, dst, src, len);
     // large (resize-time) uploads: the runtime stages pageable memory itself; wait so `src` is not retained
@@ -1229,6 +1258,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     }
     c->total_tris = (uint32_t)tris; c->total_verts = (uint32_t)(3 * tris); c->n_blocks = (uint32_t)blocks;
     ht.mark("geometry_pass: bin capacity");
+    compose_pixel_to_view(c, FB(c));
     if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
     ht.mark("geometry_pass: reserve + draw-list upload");
     if ((rc = enqueue_geometry(c))) return rc;

@@ -75,14 +75,19 @@ static_assert(sizeof(DrawMatDev) == 64, "DrawMatDev must be 64 bytes");
 // DrawMatDev + five TexSlotDev): a PBR material with no optional block and no debug view, not a hud mesh, every core texture it
 // has on TEXCOORD_0 with an identity transform, a repeat / repeat linear sampler and power-of-two extent.  k_resolve_draws decides
 // (flags bit 0); draws that do not qualify keep the general route.
+// The factors come READY FOR RAW TEXELS: where a texture exists its factor is pre-multiplied by 1/255, so the kernel multiplies the bilinear sum of
+// the 0..255 texel values straight in — base colour, metallic / roughness, emissive: factor / 255; occlusion mix(1, r, s) = occlusion_bias + raw *
+// occlusion_strength with bias = 1 - s, strength = s / 255 (no texture: bias 1); normal map (c * 2 - 1) * scale = raw * normal_scale - normal_bias with
+// normal_scale = 2 * scale / 255, normal_bias = scale (z: raw * (2 / 255) - 1).
 struct LeanDrawDev {
     uint32_t flags;               // bit 0: lean; bits 8..12: which of the five core textures exist
     float metallic, roughness, normal_scale;
     float base_color[3]; float occlusion_strength;
     float emissive[3];            // factor * emissive_strength
-    uint32_t pad0;
+    float normal_bias;
     uint32_t tex[kCoreTextures][2];   // level-0 texels of the layer: address bits 0..31 | address bits 32..47, log2(width) << 16, log2(height) << 20
-    uint32_t pad1[2];
+    float occlusion_bias;
+    uint32_t pad1;
 };
 static_assert(sizeof(LeanDrawDev) == 96, "LeanDrawDev must be 96 bytes");
 
@@ -136,6 +141,15 @@ struct FrameDev {
     uint32_t mipmap;              // 0: MipmapMode::None (level 0 only), 1: MipmapMode::Gradient
     uint32_t msaa;                // 0: one sample per pixel (pixel centre); 4: vis holds [pixel][4 samples]
     const uint8_t* camera;        // the camera UBO this frame is shaded with (a per-frame snapshot in overlap mode)
+    // The lean opaque kernel's view of that camera, composed on the host in f64 from the UBO as submitted (awsm_hip.cpp: compose_pixel_to_view):
+    // view_h = pix2view * (pixel column, pixel row, depth, 1) is inv_proj * clip with the pixel -> NDC map folded in (standard.wgsl:17-27), column-major;
+    // view_rot = the upper 3x3 of inv_view, column-major (world = view_rot * view + cam_pos; the direction to the camera is -view_rot * view: no
+    // translation in it, so a far surface's view vector does not inherit the cancellation of two camera-sized terms).
+    float pix2view[16];
+    float view_rot[9];
+    float cam_pos[3];             // CameraUniform.position (= inv_view's translation)
+    float ortho_view_dir[3];      // orthographic camera (proj[3][3] > 0.9): the unit surface-to-camera direction, the same for every pixel
+    uint32_t cam_ortho;
     const DrawDev* draws;
     DrawShadeDev* draw_shade;     // n_draws (k_resolve_draws, opaque pass)
     TexSlotDev* tex_slots;        // n_draws x kCoreTextures (k_resolve_draws)

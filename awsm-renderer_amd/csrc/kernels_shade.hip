@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     if (role == 6u) {   // the lean route's record (LeanDrawDev)
         if (!f.draw_lean) return;
         LeanDrawDev L;
-        L.flags = 0u; L.pad0 = 0u; L.pad1[0] = 0u; L.pad1[1] = 0u;
+        L.flags = 0u; L.normal_bias = 1.0f; L.occlusion_bias = 1.0f; L.pad1 = 0u;
         L.metallic = 0.0f; L.roughness = 0.0f; L.normal_scale = 1.0f; L.occlusion_strength = 1.0f;
         for (int j = 0; j < 3; j++) { L.base_color[j] = 0.0f; L.emissive[j] = 0.0f; }
         for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; }
@@ -829,9 +829,15 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
             }
             if (lean) {
                 L.flags = 1u | (exists << 8);
-                L.metallic = mf(M, b + 16); L.roughness = mf(M, b + 17); L.normal_scale = mf(M, b + 23); L.occlusion_strength = mf(M, b + 29);
+                // factors ready for raw 0..255 bilinear sums wherever the texture exists (LeanDrawDev)
+                const float k255 = 1.0f / 255.0f;
+                const float s_base = (exists & 1u) ? k255 : 1.0f, s_mr = (exists & 2u) ? k255 : 1.0f, s_em = (exists & 16u) ? k255 : 1.0f;
+                L.metallic = mf(M, b + 16) * s_mr; L.roughness = mf(M, b + 17) * s_mr;
+                const float nscale = mf(M, b + 23), ostrength = mf(M, b + 29);
+                L.normal_scale = (nscale * 2.0f) * k255; L.normal_bias = nscale;
+                L.occlusion_strength = (exists & 8u) ? ostrength * k255 : 0.0f; L.occlusion_bias = (exists & 8u) ? 1.0f - ostrength : 1.0f;
                 const float strength = M[b + 39u + 1u] != 0u ? mf(M, b + M[b + 39u + 1u]) : 1.0f;    // (no optional block: 1)
-                for (int j = 0; j < 3; j++) { L.base_color[j] = mf(M, b + 7 + j); L.emissive[j] = mf(M, b + 35 + j) * strength; }
+                for (int j = 0; j < 3; j++) { L.base_color[j] = mf(M, b + 7 + j) * s_base; L.emissive[j] = (mf(M, b + 35 + j) * strength) * s_em; }
             }
         }
         if (!(L.flags & 1u)) for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; }
@@ -1676,8 +1682,8 @@ AWSM_DI Weights weights(const Tap& t) {      // as sample_level_fast: bilinear o
 template <int BYTE> AWSM_DI float ub(uint32_t t) {
     return (float)((t >> (8 * BYTE)) & 255u);      // v_cvt_f32_ubyteN
 }
-template <int BYTE> AWSM_DI float channel(const Tap& t, const Weights& w) {
-    return (ub<BYTE>(t.t00) * w.w00 + ub<BYTE>(t.t10) * w.w10 + ub<BYTE>(t.t01) * w.w01 + ub<BYTE>(t.t11) * w.w11) * (1.0f / 255.0f);
+template <int BYTE> AWSM_DI float channel(const Tap& t, const Weights& w) {      // the bilinear sum of the RAW 0..255 values: the 1/255 sits in the draw's factors
+    return ub<BYTE>(t.t00) * w.w00 + ub<BYTE>(t.t10) * w.w10 + ub<BYTE>(t.t01) * w.w01 + ub<BYTE>(t.t11) * w.w11;
 }
 // brdf.wgsl:293-302 (sample_brdf_lut above, same arithmetic; global-address-space loads)
 AWSM_DI f2 brdf_lut(const uint16_t* lut, uint32_t lut_w, uint32_t lut_h, float n_dot_v, float roughness) {
@@ -1701,9 +1707,12 @@ AWSM_DI f2 brdf_lut(const uint16_t* lut, uint32_t lut_w, uint32_t lut_h, float n
 // brdf_direct (brdf.wgsl:308-381) for a material without sheen / clearcoat, the same terms arranged for fewer instructions: one
 // reciprocal for the three denominators of D * G1(l) / (4 n.l n.v), clamps as output modifiers, per-pixel factors hoisted.
 // x -> sat(1 - x) equals 1 - sat(max(x, 0)) for every x, and sat(n.l) serves both as n.l >= 0 and as the saturated value (n, l unit).
+// F is increasing in F0 per channel, so max(F) = F(max(F0)): k_d needs one multiply-add.  (The half vector's length and its two dot products stay as
+// the WGSL forms them — v + l first: measured, |v + l|^2 = 2 + 2 v.l and n.(v + l) = n.v + n.l lose their relative accuracy to cancellation when the
+// light comes from behind the viewer's side at grazing angles, and a GGX lobe multiplies that by 4 / (alpha^4): 13 pixels of a random view went out of bounds.)
 struct Lit {
     f3 n, v, F0, df90, bd;          // bd = base * (1 - metallic) / pi
-    float ndv_dir, ndv4, a2m1, a2_g1v, gk, one_m_gk, occlusion;
+    float ndv_raw, ndv_dir, ndv4, a2m1, a2_g1v, gk, one_m_gk, occlusion, F0max, df90max;
 };
 AWSM_DI void direct(const Lit& s, f3 l, f3 radiance, f3& color) {
     const float ndl = saturate(fm::fdot(s.n, l));
@@ -1719,7 +1728,7 @@ AWSM_DI void direct(const Lit& s, f3 l, f3 radiance, f3& color) {
     const float dd = (ndh * ndh) * s.a2m1 + 1.0f;
     const float den = (((kPi * dd) * dd + kEps) * (ndl * s.one_m_gk + s.gk)) * fmaxf(s.ndv4 * ndl, kEps);
     const float spec = has_half ? (s.a2_g1v * ndl) * fm::rcp(den) : 0.0f;
-    const float k_d = 1.0f - fmaxf(fmaxf(F.x, F.y), F.z);
+    const float k_d = 1.0f - (s.F0max + s.df90max * p5);
     const float w = ndl * s.occlusion;
     color.x += (s.bd.x * k_d + F.x * spec) * (radiance.x * w);
     color.y += (s.bd.y * k_d + F.y * spec) * (radiance.y * w);
@@ -1833,14 +1842,14 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)draw, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(hit)));
     const bool one_draw = __builtin_amdgcn_ballot_w64(hit && draw != d0) == 0ull;
     f3 base, emissive;
-    float metallic_in, roughness_in, normal_scale, occlusion_strength;
+    float metallic_in, roughness_in, normal_scale, occlusion_strength, normal_bias, occlusion_bias;
     uint32_t exists;
     lean::Tap tp0, tp1, tp2, tp3, tp4;
     if (one_draw) {
         const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
         const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
         const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
-        const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u);
+        const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u), L5s = cload<u32x2>(f.draw_lean, lo + 88u);
         todo = todo || (L0.x & 1u) == 0u;
         const uint32_t ex = todo ? 0u : L0.x >> 8;                        // scalar
         if (ex & 1u) lean::fetch_s(lean::decode_s(L3.x, L3.y), u, v, tp0);
@@ -1851,12 +1860,12 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         exists = ex;
         metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
         base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
-        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)};
+        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
     } else {
         const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
         const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
         const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
-        const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u);
+        const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u), L5s = gload<u32x2>(f.draw_lean, lo + 88u);
         todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & 1u) == 0u) != 0ull;
         const uint32_t ex = (todo || !hit) ? 0u : L0.x >> 8;
         const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
@@ -1868,7 +1877,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         exists = ex;
         metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
         base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
-        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)};
+        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
     }
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
         if (lane == 0u) {
@@ -1881,24 +1890,32 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 
     asm volatile("; MARK standard");
     // ---- standard.wgsl:11-62 (as shade_surface) ----
-    const m4 inv_proj = cload_m4(f.camera, 256u), inv_view = cload_m4(f.camera, 320u);
-    const float proj33 = cload<float>(f.camera, 64u + 60u);
-    uint32_t fw = f.width, fh = f.height;
-    asm volatile("" : "+s"(fw), "+s"(fh));                          // keeps the two reciprocals out of the persistent loop's live registers (they were spilled)
-    const f2 suv = {((float)cx + 0.5f) * fm::rcp((float)fw), ((float)cy + 0.5f) * fm::rcp((float)fh)};
-    const f4 view_h = fm::fmul(inv_proj, {suv.x * 2.0f - 1.0f, 1.0f - suv.y * 2.0f, depth, 1.0f});
-    const float ivw = fm::rcp(fmaxf(view_h.w, 1e-8f));
-    const f4 wp = fm::fmul(inv_view, {view_h.x * ivw, view_h.y * ivw, view_h.z * ivw, 1.0f});
-    const f3 world_position = {wp.x, wp.y, wp.z};
+    // pixel -> NDC, inv_proj and inv_view as ONE matrix, composed on the host in f64 from the camera this frame was submitted with (FrameDev.pix2world):
+    // sixteen multiply-adds and one reciprocal instead of two matrix products, two uniform reciprocals and the NDC arithmetic per pixel.
+    // standard.wgsl:11-62.  pixel -> NDC and inv_proj are ONE matrix, composed on the host in f64 from the camera this frame was submitted with
+    // (FrameDev.pix2view); world = view_rot * view + cam_pos.  (One matrix for all of it, inv_view folded in as well, was measured: the translation
+    // then sits inside the cancellation of view_h and a far surface's view vector moves by 1e-5 rad.)
+    const float pxf = (float)cx, pyf = (float)cy;
+    const float* M = f.pix2view;
+    const float hx = M[0] * pxf + (M[4] * pyf + (M[8] * depth + M[12])), hy = M[1] * pxf + (M[5] * pyf + (M[9] * depth + M[13]));
+    const float hz = M[2] * pxf + (M[6] * pyf + (M[10] * depth + M[14])), hw = M[3] * pxf + (M[7] * pyf + (M[11] * depth + M[15]));
+    const float ivw = fm::rcp(fmaxf(hw, 1e-8f));
+    const f3 vp = {hx * ivw, hy * ivw, hz * ivw};                          // view_position
+    const float* R = f.view_rot;
+    const f3 rel = {R[0] * vp.x + (R[3] * vp.y + R[6] * vp.z), R[1] * vp.x + (R[4] * vp.y + R[7] * vp.z), R[2] * vp.x + (R[5] * vp.y + R[8] * vp.z)};   // world_position - camera
+    const f3 world_position = {rel.x + f.cam_pos[0], rel.y + f.cam_pos[1], rel.z + f.cam_pos[2]};
     f3 surface_to_camera;
-    if (proj33 > 0.9f) {
-        surface_to_camera = fm::fnormalize(mk3(inv_view.c[2].x, inv_view.c[2].y, inv_view.c[2].z));
+    if (f.cam_ortho) {
+        surface_to_camera = mk3(f.ortho_view_dir[0], f.ortho_view_dir[1], f.ortho_view_dir[2]);
     } else {
-        const f32x4 cp = cload<f32x4>(f.camera, 384u);
-        const f3 to_camera = mk3(cp.x, cp.y, cp.z) - world_position;
+        // cam - world, as standard.wgsl:41-47 forms it (not -rel, which is the same vector without the rounding of the two camera-sized terms: the
+        // oracle's result carries that rounding, and a near-mirror texel sees the difference)
+        const f3 to_camera = mk3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]) - world_position;
         surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
     }
     asm volatile("; MARK tbn");
+    // (Not a leaner unpack without the normalisations of T and B: canonical_tb's 1 / (1 + N.z) makes (t, b) orthonormal only as far as N is a unit
+    // vector to the last bit — measured: 7 pixels of a random view 15x out of bounds, all on surfaces facing -z.)
     const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
 
     asm volatile("; MARK material");
@@ -1908,12 +1925,12 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     f3 normal = tbn.N;
     if (exists & 4u) {   // material_color_calc.wgsl:301-322
         const lean::Weights w = lean::weights(tp2);
-        const float scale = normal_scale;
-        const float ntx = (lean::channel<0>(tp2, w) * 2.0f - 1.0f) * scale, nty = (lean::channel<1>(tp2, w) * 2.0f - 1.0f) * scale, ntz = lean::channel<2>(tp2, w) * 2.0f - 1.0f;
+        // (c * 2 - 1) * scale on raw texels: raw * (2 scale / 255) - scale (LeanDrawDev)
+        const float ntx = lean::channel<0>(tp2, w) * normal_scale - normal_bias, nty = lean::channel<1>(tp2, w) * normal_scale - normal_bias, ntz = lean::channel<2>(tp2, w) * (2.0f / 255.0f) - 1.0f;
         normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
     }
     float occlusion = 1.0f;
-    if (exists & 8u) { const lean::Weights w = lean::weights(tp3); occlusion = mixf(1.0f, lean::channel<0>(tp3, w), occlusion_strength); }
+    if (exists & 8u) { const lean::Weights w = lean::weights(tp3); occlusion = lean::channel<0>(tp3, w) * occlusion_strength + occlusion_bias; }      // mix(1, r, s)
     if (exists & 16u) { const lean::Weights w = lean::weights(tp4); emissive = {emissive.x * lean::channel<0>(tp4, w), emissive.y * lean::channel<1>(tp4, w), emissive.z * lean::channel<2>(tp4, w)}; }
 
     asm volatile("; MARK surface");
@@ -1941,6 +1958,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     sf.has_sheen = false; sf.has_clearcoat = false;
     lean::Lit lit;
     lit.n = sf.n; lit.v = sf.v; lit.F0 = sf.F0; lit.df90 = sf.df90; lit.bd = sf.base_diffuse;
+    lit.ndv_raw = ndv; lit.F0max = fmaxf(fmaxf(sf.F0.x, sf.F0.y), sf.F0.z); lit.df90max = sf.f90 - lit.F0max;
     lit.ndv_dir = sf.n_dot_v_dir; lit.ndv4 = 4.0f * sf.n_dot_v_dir; lit.a2m1 = sf.a2m1; lit.a2_g1v = sf.a2 * sf.g1_v; lit.gk = sf.gk; lit.one_m_gk = sf.one_m_gk;
     lit.occlusion = occlusion;
     f3 color;

@@ -522,10 +522,13 @@ static ovec3 fresnel_schlick_f90(float cos_theta, ovec3 F0, float f90) {        
     float p = powf(one_minus, 5.0f);
     return ov3(F0.x + (f90 - F0.x) * p, F0.y + (f90 - F0.y) * p, F0.z + (f90 - F0.z) * p);
 }
+static int g_perturb = 0;      /* conditioning probe: see shade_surface */
+void oracle_set_perturbation(int k) { g_perturb = k; }
 static float distribution_ggx(float n_dot_h, float alpha) {                                    /* :118-124 */
     float a = fmaxf(alpha, 0.001f);
     float a2 = a * a;
     float ndh = o_saturate(n_dot_h);
+    if (g_perturb == 5) ndh = ndh * (1.0f - 16.0f * 5.9604645e-8f);      /* conditioning probe only */
     float d = (ndh * ndh) * (a2 - 1.0f) + 1.0f;
     return a2 / ((O_PI * d) * d + O_EPSILON);
 }
@@ -940,10 +943,9 @@ static GBufferTexel gbuffer_texel(const OracleScene* s, const float* clip, const
  * k = 3, 4: the reconstructed world position shifted across the view ray (16 ulps of the largest coordinate involved).  The difference between
  * such a frame and the unperturbed one says, per pixel, what that much input noise does to the oracle's OWN result: the pixel's condition
  * number times epsilon, measured, not modelled.  A GGX peak on a near-mirror texel or a silhouette with n.v -> 0 shows up as a large
- * response; an ordinary pixel as a response far below the 1e-4 bar.  (oracle_lib.OracleFrame.conditioning) */
-static int g_perturb = 0;
-void oracle_set_perturbation(int k) { g_perturb = k; }
-
+ * response; an ordinary pixel as a response far below the 1e-4 bar.  k = 5: n.h itself, 16 ulps down, where the GGX lobe takes it
+ * (distribution_ggx) — at the very peak of a highlight a tilt of the normal moves n.h only in second order, while the rounding of the dot
+ * product moves it in first.  (oracle_lib.OracleFrame.conditioning; g_perturb is defined above distribution_ggx) */
 typedef struct { ovec3 color; float alpha; int kind; ovec4 packed_nt; } SurfaceColor;
 static SurfaceColor shade_surface(const OracleScene* s, const float* clip, const float* nt, uint32_t rank, int cx, int cy,
                                   float depth_sample, int check_hud) {

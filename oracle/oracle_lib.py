@@ -215,13 +215,13 @@ class OracleFrame:
         return self.transform().raster(threads).shade(threads)
 
     def conditioning(self, threads=8) -> np.ndarray:
-        """(height, width, 4) f64: per pixel and channel, how far the oracle's own colour moves when the decoded normal (two tilts) or the
-        reconstructed world position (two shifts across the view ray) is off by 16 ulps — the pixel's condition number times epsilon, measured
+        """(height, width, 4) f64: per pixel and channel, how far the oracle's own colour moves when the decoded normal (two tilts), the
+        reconstructed world position (two shifts across the view ray) or n.h in the GGX lobe is off by 16 ulps — the pixel's condition number times epsilon, measured
         (oracle_shade.c: oracle_set_perturbation).  Call after shade(); leaves rgba32f / rgba16f as shade() made them."""
         base32, base16 = self.rgba32f.copy(), self.rgba16f.copy()
         worst = np.zeros(base32.shape, dtype=np.float64)
         try:
-            for k in (1, 2, 3, 4):
+            for k in (1, 2, 3, 4, 5):
                 lib().oracle_set_perturbation(C.c_int(k))
                 self.shade(threads)
                 d = np.abs(self.rgba32f.astype(np.float64) - base32.astype(np.float64))

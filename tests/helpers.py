@@ -95,9 +95,14 @@ def f16_ulp_distance(a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
 
 def compare_frames(orc, dev, rows=None, rgb_tol=1e-4, cond=None):
     """Returns a dict of mismatch counts / max errors between an OracleFrame and a HipDevice frame.
-    cond: OracleFrame.conditioning() of the same frame — what 16 ulps of noise in the decoded normal / the reconstructed position do to the
-    oracle's own colour, per pixel.  With it the bound is conditioned: rgb_tol * max(1, |ref|) + cond, and the f16 distance is taken over the
-    well-conditioned pixels (cond <= 1e-5) only; `rgb_over_base` then counts the pixels that needed their condition number."""
+
+    The colour bar is 1e-4 * max(1, |ref|) (BASELINE.json north_star; relative above 1.0 because the output is linear HDR).  A pixel over it is
+    accepted only if its CONDITION NUMBER explains it: cond = OracleFrame.conditioning() — how far the oracle's own colour moves when the decoded
+    normal, the reconstructed position or n.h of the GGX lobe is off by 16 ulps (five perturbed oracle frames; measured, not modelled) — and the
+    bound for that pixel becomes 1e-4 * max(1, |ref|) + cond.  The conditioning is computed only when some pixel needs it (or passed in), and only a
+    handful may: more than max(8, 4e-5 of the covered pixels) over the plain bar count as failures whatever their condition numbers say.
+      rgb_over_base  pixels over the plain bar;   rgb_over_tol  pixels over the conditioned bound (what the tests assert to be 0);
+      f16_max_ulp    over the well-conditioned pixels (cond <= 1e-5) once the conditioning is known."""
     H = orc.height
     y0, y1 = rows if rows else (0, H)
     out = {}
@@ -112,14 +117,18 @@ def compare_frames(orc, dev, rows=None, rgb_tol=1e-4, cond=None):
     ref = orc.rgba32f[y0:y1].astype(np.float64)
     diff = np.abs(f32[y0:y1].astype(np.float64) - ref)
     diff = np.where(np.isfinite(diff), diff, np.inf)
-    # the bar: 1e-4 absolute for values up to 1.0, 1e-4 relative for HDR values above 1.0 (the output is linear HDR; a GGX
-    # highlight amplifies 1e-7 differences in the normal ~100x, so bright specular pixels cannot hold an absolute bound)
     base = rgb_tol * np.maximum(1.0, np.abs(ref))
+    over_base = (diff[..., :3] > base[..., :3]).any(axis=-1)
+    out["rgb_over_base"] = int(over_base.sum())
+    if cond is None and out["rgb_over_base"] and out["key_mismatch"] == 0:
+        import os
+        cond = orc.conditioning(os.cpu_count() or 16)
     bound = base if cond is None else base + cond[y0:y1]
     out["rgb_max_abs"] = float(diff[..., :3].max()) if diff.size else 0.0
     out["rgb_max_rel_to_bound"] = float((diff[..., :3] / bound[..., :3]).max()) if diff.size else 0.0
     out["rgb_over_tol"] = int((diff[..., :3] > bound[..., :3]).any(axis=-1).sum())
-    out["rgb_over_base"] = int((diff[..., :3] > base[..., :3]).any(axis=-1).sum())
+    if out["rgb_over_base"] > max(8, int(4e-5 * out["covered"])):
+        out["rgb_over_tol"] = max(out["rgb_over_tol"], out["rgb_over_base"])      # a population over the bar is a failure, not ill conditioning
     out["alpha_mismatch"] = int((f32[y0:y1, :, 3] != orc.rgba32f[y0:y1, :, 3]).sum())
     h16 = dev.read_opaque()
     ulp = f16_ulp_distance(h16[y0:y1], orc.rgba16f[y0:y1]) if h16.size else np.zeros((1,), dtype=np.int32)
