@@ -1430,7 +1430,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->bin_overflow_retries = c->overflow_retries;
         out->frames_with_dropped_bin_entries = c->dropped_frames;
         out->handoff_gate_timeouts = c->handoff_dropped_frames;
-        if (c->opaque_done && c->shade_todo[c->slot].ptr && c->msaa == 0 && !c->last_opaque.mipmap && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
+        if (c->opaque_done && c->shade_todo[c->slot].ptr && c->msaa == 0 && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
             HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo[c->slot].ptr, 4, hipMemcpyDeviceToHost));
         out->struct_size = (uint32_t)std::min<size_t>(caller_size, sizeof(AwsmFrameStats));
         memcpy(caller_out, out, out->struct_size);

@@ -80,7 +80,7 @@ static_assert(sizeof(DrawMatDev) == 64, "DrawMatDev must be 64 bytes");
 // occlusion_strength with bias = 1 - s, strength = s / 255 (no texture: bias 1); normal map (c * 2 - 1) * scale = raw * normal_scale - normal_bias with
 // normal_scale = 2 * scale / 255, normal_bias = scale (z: raw * (2 / 255) - 1).
 struct LeanDrawDev {
-    uint32_t flags;               // bit 0: lean; bits 8..12: which of the five core textures exist
+    uint32_t flags;               // bit 0: lean; bit 1: lean under MipmapMode::Gradient too (gtex valid); bits 8..12: which of the five core textures exist
     float metallic, roughness, normal_scale;
     float base_color[3]; float occlusion_strength;
     float emissive[3];            // factor * emissive_strength
@@ -88,8 +88,12 @@ struct LeanDrawDev {
     uint32_t tex[kCoreTextures][2];   // level-0 texels of the layer: address bits 0..31 | address bits 32..47, log2(width) << 16, log2(height) << 20
     float occlusion_bias;
     uint32_t pad1;
+    // MipmapMode::Gradient (flags bit 1): the texture's pool array as the trilinear fetch needs it — square power-of-two layers, so the first texel of
+    // level l is layers * (G(lw + 1) - G(lw + 1 - l)) with G(k) = (4^k - 1) / 3 = 0x55555555 & (4^k - 1), and level l of layer i starts i << 2 (lw - l)
+    // texels further: {array address bits 0..31, bits 32..47 | levels << 16 | log2(width) << 24, layer, layers}
+    uint32_t gtex[kCoreTextures][4];
 };
-static_assert(sizeof(LeanDrawDev) == 96, "LeanDrawDev must be 96 bytes");
+static_assert(sizeof(LeanDrawDev) == 176, "LeanDrawDev must be 176 bytes");
 
 constexpr int kMaxMipLevels = 16;
 struct TexArrayDev {

@@ -809,7 +809,8 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
         L.flags = 0u; L.normal_bias = 1.0f; L.occlusion_bias = 1.0f; L.pad1 = 0u;
         L.metallic = 0.0f; L.roughness = 0.0f; L.normal_scale = 1.0f; L.occlusion_strength = 1.0f;
         for (int j = 0; j < 3; j++) { L.base_color[j] = 0.0f; L.emissive[j] = 0.0f; }
-        for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; }
+        for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; for (int j = 0; j < 4; j++) L.gtex[k][j] = 0u; }
+        bool lean_grad = true;
         bool lean = shader_id == 1u && (mm[16] & 1u) == 0u && M[b + 38] == 0u;     // PBR, not a hud mesh, no debug view
         if (lean) {
             const uint32_t fi = b + 39u;
@@ -826,9 +827,22 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                 exists |= 1u << k;
                 L.tex[k][0] = (uint32_t)addr;
                 L.tex[k][1] = (uint32_t)(addr >> 32) | ((uint32_t)(31 - __clz((int)s.width)) << 16) | ((uint32_t)(31 - __clz((int)s.height)) << 20);
+                {   // MipmapMode::Gradient: square layers, linear min + mipmap filters, the whole chain addressable with 32-bit byte offsets
+                    const TexInfo ti = tex_load(M, words[k]);
+                    const TexArrayDev& arr = sc->tex[ti.array_index];
+                    const unsigned long long abase = (unsigned long long)s.array_base;
+                    const uint32_t levels = s.layer_levels >> 24, layer = s.layer_levels & 0xFFFFFFu, lw = (uint32_t)(31 - __clz((int)s.width));
+                    unsigned long long chain_texels = 0ull;
+                    for (uint32_t l = 0; l < levels; l++) chain_texels += (unsigned long long)arr.layers * max(arr.width >> l, 1u) * max(arr.height >> l, 1u);
+                    const bool ok = s.width == s.height && (s.flags & (32u | 64u)) == (32u | 64u) && levels >= 1u && levels <= 15u && levels <= lw + 1u && arr.layers < 4096u &&
+                                    chain_texels * 4ull < 0xFFFFFFF0ull && (abase >> 48) == 0ull && (abase & 3ull) == 0ull;
+                    if (!ok) lean_grad = false;
+                    L.gtex[k][0] = (uint32_t)abase; L.gtex[k][1] = (uint32_t)(abase >> 32) | (levels << 16) | (lw << 24);
+                    L.gtex[k][2] = layer; L.gtex[k][3] = arr.layers;
+                }
             }
             if (lean) {
-                L.flags = 1u | (exists << 8);
+                L.flags = 1u | (lean_grad ? 2u : 0u) | (exists << 8);
                 // factors ready for raw 0..255 bilinear sums wherever the texture exists (LeanDrawDev)
                 const float k255 = 1.0f / 255.0f;
                 const float s_base = (exists & 1u) ? k255 : 1.0f, s_mr = (exists & 2u) ? k255 : 1.0f, s_em = (exists & 16u) ? k255 : 1.0f;
@@ -840,7 +854,7 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                 for (int j = 0; j < 3; j++) { L.base_color[j] = mf(M, b + 7 + j) * s_base; L.emissive[j] = (mf(M, b + 35 + j) * strength) * s_em; }
             }
         }
-        if (!(L.flags & 1u)) for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; }
+        if (!(L.flags & 1u)) for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; for (int j = 0; j < 4; j++) L.gtex[k][j] = 0u; }
         f.draw_lean[draw] = L;
         return;
     }
@@ -1598,6 +1612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
 // empty list — and held up everything ordered behind the frame.  No occupancy step of the compiler yields a 112 budget (waves_per_eu(5): 96 and
 // a spill), so the count is checked after the build (awsm_renderer_amd/build.py).
 constexpr uint32_t kTodoBlocks = 1024;
+template <bool GRAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_todo(const DevScene* __restrict__ sc, FrameDev f) {
     // This kernel starting means this frame's k_shade_lean has ended (same stream): the next frame's opaque pass, gated on that, goes ahead
     // while the list is shaded (k_handoff_wait, kernels_geometry.hip; the two frames write different images).
@@ -1610,7 +1625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.shade_todo[4u + i]);
         ShadeBlock b;
         if (!shade_block(f, b, e >> 2)) continue;
-        shade_pixel<false>(sc, f, b, ((e & 3u) << 6) | lane);
+        shade_pixel<GRAD>(sc, f, b, ((e & 3u) << 6) | lane);
     }
 }
 
@@ -1769,8 +1784,59 @@ AWSM_DI void fetch_s(const TexS& x, float u, float v, Tap& t) {
         t.t10 = gload<uint32_t>(x.base, j0 << sh); t.t11 = gload<uint32_t>(x.base, j1 << sh);
     }
 }
+// MipmapMode::Gradient: textureSampleGrad by the contract of sample_slot<true> (isotropic LOD from the larger of the two gradient lengths, min / mipmap
+// filters linear, repeat addressing), on a square power-of-two pool array whose record sits in scalar registers (LeanDrawDev.gtex).
+struct TexG { const void* base; uint32_t lw, levels, layer, layers; };
+AWSM_DI TexG decode_g(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return {reinterpret_cast<const void*>(((unsigned long long)(w1 & 0xFFFFu) << 32) | w0), w1 >> 24, (w1 >> 16) & 15u, w2, w3};
+}
+struct Lod { uint32_t lo, hi; float f; };
+// m2 = max(|d uv / dx|^2, |d uv / dy|^2) in uv units; scaling by the extent is exact (a power of two), so rho2 has sample_slot<true>'s bits
+AWSM_DI Lod select_lod(const TexG& x, float m2) {
+    const float rho2 = __builtin_amdgcn_ldexpf(m2, (int)(2u * x.lw));
+    float lod = 0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1e-12f));      // log2(max(rho, 1e-6))
+    Lod r = {0u, 0u, 0.0f};
+    if (lod > 0.0f && x.levels > 1u) {
+        lod = fminf(lod, (float)(x.levels - 1u));
+        const float fl = floorf(lod);
+        r.lo = (uint32_t)fl; r.hi = min(r.lo + 1u, x.levels - 1u); r.f = (r.hi != r.lo) ? lod - fl : 0.0f;
+    }
+    return r;
+}
+// the bilinear footprint on level `level` (per lane) of the layer
+AWSM_DI void fetch_g(const TexG& x, uint32_t level, float u, float v, Tap& t) {
+    const uint32_t lwl = x.lw - level;                                       // log2 of the level's extent
+    // first texel of the level: layers * (G(lw + 1) - G(lwl + 1)); of the layer inside it: layer << 2 lwl
+    const uint32_t g_all = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (x.lw + 1u)), g_rest = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (lwl + 1u));
+    const uint32_t first = x.layers * (g_all - g_rest) + (x.layer << (2u * lwl));
+    const float xf = __builtin_amdgcn_ldexpf(u, (int)lwl) - 0.5f, yf = __builtin_amdgcn_ldexpf(v, (int)lwl) - 0.5f;
+    const float flx = floorf(xf), fly = floorf(yf);
+    t.fx = xf - flx; t.fy = yf - fly;
+    const uint32_t xi = (uint32_t)(int)flx, yi = (uint32_t)(int)fly;
+    const uint32_t i0 = __builtin_amdgcn_ubfe(xi, 0u, lwl), j0 = __builtin_amdgcn_ubfe(yi, 0u, lwl), j1 = __builtin_amdgcn_ubfe(yi + 1u, 0u, lwl);
+    const uint32_t r0 = (first + (j0 << lwl)) << 2, r1 = (first + (j1 << lwl)) << 2, i0b = i0 << 2;
+    const u32x2a4 p0 = gload<u32x2a4>(x.base, r0 + i0b), p1 = gload<u32x2a4>(x.base, r1 + i0b);
+    t.t00 = p0.x; t.t10 = p0.y; t.t01 = p1.x; t.t11 = p1.y;
+    if (__builtin_amdgcn_ubfe(xi + 1u, 0u, lwl) == 0u) {      // i1 wrapped to column 0 (always on the 1 x 1 level)
+        t.t10 = gload<uint32_t>(x.base, r0); t.t11 = gload<uint32_t>(x.base, r1);
+    }
+}
+struct TapG { Tap lo, hi; float f; };
+// both levels of a texture: the second only when some lane of the wavefront blends (f > 0) — a magnified strip fetches level 0 once
+AWSM_DI void fetch_trilinear(const TexG& x, float m2, float u, float v, TapG& t) {
+    const Lod l = select_lod(x, m2);
+    t.f = l.f;
+    fetch_g(x, l.lo, u, v, t.lo);
+    if (__builtin_amdgcn_ballot_w64(l.f > 0.0f) != 0ull) fetch_g(x, l.hi, u, v, t.hi);
+    else t.hi = t.lo;
+}
+template <int BYTE> AWSM_DI float channel(const TapG& t, const Weights& wl, const Weights& wh) {
+    const float a = channel<BYTE>(t.lo, wl), b = channel<BYTE>(t.hi, wh);
+    return a * (1.0f - t.f) + b * t.f;                                        // sample_slot<true>: acc = c_lo (1 - f) + c_hi f
+}
 }  // namespace lean
 
+template <bool GRAD>
 AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
     const uint32_t lane = tid & 63u;
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
@@ -1827,10 +1893,22 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     // ---- STRICT: what fs_main wrote for this pixel ----
     TriSetup t;
     tri_rec_unpack(raw, t);
-    const GBufferTexel g = reconstruct_core<false>(t, n0, n1, n2, t0, t1, t2, cx, cy);
+    const GBufferTexel g = reconstruct_core<GRAD>(t, n0, n1, n2, t0, t1, t2, cx, cy);
     const float bz = (1.0f - g.bx) - g.by;                               // compute.wgsl:185-186
     const float u = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.z), __uint_as_float(ts1.x), __uint_as_float(ts1.z));
     const float v = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.w), __uint_as_float(ts1.y), __uint_as_float(ts1.w));
+    float m2 = 0.0f;      // MipmapMode::Gradient: max(|d uv / dx|^2, |d uv / dy|^2), get_uv_derivatives (helpers/mipmap.wgsl:113-205) as attr_uv<true> forms it
+    if (GRAD) {
+        const float x0 = __uint_as_float(ts0.z), y0 = __uint_as_float(ts0.w), x1 = __uint_as_float(ts1.x), y1 = __uint_as_float(ts1.y), x2 = __uint_as_float(ts1.z), y2 = __uint_as_float(ts1.w);
+        const float dAlphaDx = g.bary_derivs.x, dAlphaDy = g.bary_derivs.y, dBetaDx = g.bary_derivs.z, dBetaDy = g.bary_derivs.w;
+        const float dGammaDx = -dAlphaDx - dBetaDx, dGammaDy = -dAlphaDy - dBetaDy;
+        f2 ddx = {x0 * dAlphaDx + x1 * dBetaDx + x2 * dGammaDx, y0 * dAlphaDx + y1 * dBetaDx + y2 * dGammaDx};
+        f2 ddy = {x0 * dAlphaDy + x1 * dBetaDy + x2 * dGammaDy, y0 * dAlphaDy + y1 * dBetaDy + y2 * dGammaDy};
+        const bool tiny = (fabsf(dAlphaDx) + fabsf(dAlphaDy) + fabsf(dBetaDx) + fabsf(dBetaDy)) < 1e-20f;
+        const bool ok = (ddx.x == ddx.x) && (ddx.y == ddx.y) && (ddy.x == ddy.x) && (ddy.y == ddy.y);   // NaN guard
+        if (tiny || !ok) { ddx = {0.0f, 0.0f}; ddy = {0.0f, 0.0f}; }
+        m2 = fmaxf(ddx.x * ddx.x + ddx.y * ddx.y, ddy.x * ddy.x + ddy.y * ddy.y);
+    }
     // beyond +-32768 the general sampler's range guard decides (also NaN): the wavefront goes to the general kernel
     bool todo = __builtin_amdgcn_ballot_w64(hit && !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f)) != 0ull;
 
@@ -1845,23 +1923,35 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     float metallic_in, roughness_in, normal_scale, occlusion_strength, normal_bias, occlusion_bias;
     uint32_t exists;
     lean::Tap tp0, tp1, tp2, tp3, tp4;
+    lean::TapG tg0, tg1, tg2, tg3, tg4;                                   // MipmapMode::Gradient: two levels per texture
+    if (GRAD && !one_draw) todo = true;                                   // (a strip over several draws, with mipmaps: the general kernel)
     if (one_draw) {
         const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
         const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
         const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
         const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u), L5s = cload<u32x2>(f.draw_lean, lo + 88u);
-        todo = todo || (L0.x & 1u) == 0u;
+        todo = todo || (L0.x & (GRAD ? 3u : 1u)) != (GRAD ? 3u : 1u);
         const uint32_t ex = todo ? 0u : L0.x >> 8;                        // scalar
-        if (ex & 1u) lean::fetch_s(lean::decode_s(L3.x, L3.y), u, v, tp0);
-        if (ex & 2u) lean::fetch_s(lean::decode_s(L3.z, L3.w), u, v, tp1);
-        if (ex & 4u) lean::fetch_s(lean::decode_s(L4.x, L4.y), u, v, tp2);
-        if (ex & 8u) lean::fetch_s(lean::decode_s(L4.z, L4.w), u, v, tp3);
-        if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), u, v, tp4);
+        if (GRAD) {
+            const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
+            const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
+            if (ex & 1u) lean::fetch_trilinear(lean::decode_g(G0.x, G0.y, G0.z, G0.w), m2, u, v, tg0);
+            if (ex & 2u) lean::fetch_trilinear(lean::decode_g(G1.x, G1.y, G1.z, G1.w), m2, u, v, tg1);
+            if (ex & 4u) lean::fetch_trilinear(lean::decode_g(G2.x, G2.y, G2.z, G2.w), m2, u, v, tg2);
+            if (ex & 8u) lean::fetch_trilinear(lean::decode_g(G3.x, G3.y, G3.z, G3.w), m2, u, v, tg3);
+            if (ex & 16u) lean::fetch_trilinear(lean::decode_g(G4.x, G4.y, G4.z, G4.w), m2, u, v, tg4);
+        } else {
+            if (ex & 1u) lean::fetch_s(lean::decode_s(L3.x, L3.y), u, v, tp0);
+            if (ex & 2u) lean::fetch_s(lean::decode_s(L3.z, L3.w), u, v, tp1);
+            if (ex & 4u) lean::fetch_s(lean::decode_s(L4.x, L4.y), u, v, tp2);
+            if (ex & 8u) lean::fetch_s(lean::decode_s(L4.z, L4.w), u, v, tp3);
+            if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), u, v, tp4);
+        }
         exists = ex;
         metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
         base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
         emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
-    } else {
+    } else if (!GRAD) {
         const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
         const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
         const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
@@ -1920,18 +2010,23 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 
     asm volatile("; MARK material");
     // ---- material_color_calc.wgsl:25-265 for a material without optional blocks ----
-    if (exists & 1u) { const lean::Weights w = lean::weights(tp0); base = {base.x * lean::channel<0>(tp0, w), base.y * lean::channel<1>(tp0, w), base.z * lean::channel<2>(tp0, w)}; }
-    if (exists & 2u) { const lean::Weights w = lean::weights(tp1); metallic_in = metallic_in * lean::channel<2>(tp1, w); roughness_in = roughness_in * lean::channel<1>(tp1, w); }
+    // one texture's channel BYTE: bilinear on level 0 (MipmapMode::None) or the blend of two levels' bilinear values (MipmapMode::Gradient)
+#define AWSM_LEAN_TEX(K, W0, W1) const lean::Weights W0 = lean::weights(GRAD ? tg##K.lo : tp##K), W1 = lean::weights(GRAD ? tg##K.hi : tp##K)
+#define AWSM_LEAN_CH(K, BYTE, W0, W1) (GRAD ? lean::channel<BYTE>(tg##K, W0, W1) : lean::channel<BYTE>(tp##K, W0))
+    if (exists & 1u) { AWSM_LEAN_TEX(0, w, wh); base = {base.x * AWSM_LEAN_CH(0, 0, w, wh), base.y * AWSM_LEAN_CH(0, 1, w, wh), base.z * AWSM_LEAN_CH(0, 2, w, wh)}; }
+    if (exists & 2u) { AWSM_LEAN_TEX(1, w, wh); metallic_in = metallic_in * AWSM_LEAN_CH(1, 2, w, wh); roughness_in = roughness_in * AWSM_LEAN_CH(1, 1, w, wh); }
     f3 normal = tbn.N;
     if (exists & 4u) {   // material_color_calc.wgsl:301-322
-        const lean::Weights w = lean::weights(tp2);
+        AWSM_LEAN_TEX(2, w, wh);
         // (c * 2 - 1) * scale on raw texels: raw * (2 scale / 255) - scale (LeanDrawDev)
-        const float ntx = lean::channel<0>(tp2, w) * normal_scale - normal_bias, nty = lean::channel<1>(tp2, w) * normal_scale - normal_bias, ntz = lean::channel<2>(tp2, w) * (2.0f / 255.0f) - 1.0f;
+        const float ntx = AWSM_LEAN_CH(2, 0, w, wh) * normal_scale - normal_bias, nty = AWSM_LEAN_CH(2, 1, w, wh) * normal_scale - normal_bias, ntz = AWSM_LEAN_CH(2, 2, w, wh) * (2.0f / 255.0f) - 1.0f;
         normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
     }
     float occlusion = 1.0f;
-    if (exists & 8u) { const lean::Weights w = lean::weights(tp3); occlusion = lean::channel<0>(tp3, w) * occlusion_strength + occlusion_bias; }      // mix(1, r, s)
-    if (exists & 16u) { const lean::Weights w = lean::weights(tp4); emissive = {emissive.x * lean::channel<0>(tp4, w), emissive.y * lean::channel<1>(tp4, w), emissive.z * lean::channel<2>(tp4, w)}; }
+    if (exists & 8u) { AWSM_LEAN_TEX(3, w, wh); occlusion = AWSM_LEAN_CH(3, 0, w, wh) * occlusion_strength + occlusion_bias; }      // mix(1, r, s)
+    if (exists & 16u) { AWSM_LEAN_TEX(4, w, wh); emissive = {emissive.x * AWSM_LEAN_CH(4, 0, w, wh), emissive.y * AWSM_LEAN_CH(4, 1, w, wh), emissive.z * AWSM_LEAN_CH(4, 2, w, wh)}; }
+#undef AWSM_LEAN_TEX
+#undef AWSM_LEAN_CH
 
     asm volatile("; MARK surface");
     // ---- lights.wgsl:121-152 / brdf.wgsl (apply_lighting, brdf_ibl, brdf_direct above, with ior 1.5, specular 1, no transmission / clearcoat / sheen) ----
@@ -2022,8 +2117,10 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 #define AWSM_LEAN_COUNTERS 8
 #endif
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
-template <bool PERSIST>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PERSIST ? 5 : AWSM_LEAN_WAVES))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+// GRAD: MipmapMode::Gradient (the reference's default): barycentric derivatives, isotropic LOD, two levels per texture — a separate instantiation, as the
+// reference keeps separate pipelines; its ten footprints in flight want more registers than six waves per SIMD leave.
+template <bool PERSIST, bool GRAD>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : (PERSIST ? 5 : AWSM_LEAN_WAVES)))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ LeanStage stage[4];                                         // one per wavefront (no barrier anywhere: the four are independent)
     if (frame_poisoned(f)) return;
     LeanStage* const st = &stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
@@ -2053,7 +2150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PERSIST ? 5
         if (bcol < bx_n && j < share) {
             ShadeBlock b;
             shade_block_at(f, b, brow, bcol);
-            lean_block(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane, st);
+            lean_block<GRAD>(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane, st);
         }
         if (!PERSIST) break;
     }
@@ -2357,25 +2454,27 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         if (grad) { hipLaunchKernelGGL(awsm::k_shade_msaa<true>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
         else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
     } else {
-        if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
-        else if (f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws) {
+        if (f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws) {
             // MipmapMode::None: the lean kernel over the screen, then the general code for the wavefronts it declined (k_resolve_draws reset the list)
             // strip ids sit on a power-of-two block pitch: a wavefront per id (the padding exits), or the persistent grid
             uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
             const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
-            if (f->lean_grid && f->lean_next) hipLaunchKernelGGL(awsm::k_shade_lean<true>, dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
-            else hipLaunchKernelGGL(awsm::k_shade_lean<false>, dim3(nb_ids), dim3(256), 0, s, sc, *f);      // awsm_launch_shade_todo follows
-        } else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
+            if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+            else if (f->lean_grid && f->lean_next) hipLaunchKernelGGL((awsm::k_shade_lean<true, false>), dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
+            else hipLaunchKernelGGL((awsm::k_shade_lean<false, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);      // awsm_launch_shade_todo follows
+        } else if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
     }
 }
 // second half of the lean route; returns 0 when the frame did not take it
 extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
-    return (bx_n * by_n) && f->mipmap == 0u && f->msaa != 4u && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
+    return (bx_n * by_n) && f->msaa != 4u && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
 }
 extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     if (!awsm_shade_is_lean(f)) return 0;
-    hipLaunchKernelGGL(awsm::k_shade_todo, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+    if (f->mipmap) hipLaunchKernelGGL(awsm::k_shade_todo<true>, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+    else hipLaunchKernelGGL(awsm::k_shade_todo<false>, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
     return 1;
 }
 // f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;

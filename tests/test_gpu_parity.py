@@ -806,7 +806,7 @@ def test_instanced_meshes(msaa, oracle_lut):
 @pytest.mark.gpu
 def test_lean_and_general_opaque_routes_agree(oracle_lut):
     """k_shade_lean + k_shade_todo against k_shade (AWSM_CFG_GENERAL_SHADE_ONLY) on the same frames: same keys, colours within the
-    shading tolerance of each other (same formulas, different instruction order; all but a handful of pixels within a fifth of it).  The atrium is all lean; the zoo mixes lean
+    shading tolerance of each other (same formulas, different instruction order; all but a thousandth of the pixels within a fifth of it).  The atrium is all lean; the zoo mixes lean
     draws with every kind that is not (unlit, optional blocks, debug views, non-repeat samplers, texture transforms), so wavefronts that
     straddle both kinds go to the general kernel; the scene below adds texture coordinates in the millions, beyond the lean sampler's range."""
     from awsm_renderer_amd.hip_backend import HipDevice
@@ -824,12 +824,12 @@ def test_lean_and_general_opaque_routes_agree(oracle_lut):
         waves = int(st_lean["shade_general_wavefronts"])
         lean.close(); gen.close()
         # each route is within the bar + the pixel's conditioning term of the oracle (the parity tests), so within twice that of the other; asserted
-        # here: the plain bar + twice the conditioning term between them, and at most a handful of pixels beyond a fifth of the bar
+        # here: the plain bar + twice the conditioning term between them, and at most a thousandth of the pixels beyond a fifth of the bar
         orc = helpers.oracle_frame(model, oracle_lut)
         cond = orc.conditioning(os.cpu_count() or 16)
         bound = RGB_TOL * np.maximum(1.0, np.abs(b)) + 2.0 * cond
         assert (np.abs(a - b) <= bound).all(), (name, float((np.abs(a - b) / bound).max()))
-        assert int((np.abs(a - b) > 2e-5 * np.maximum(1.0, np.abs(b))).any(axis=2).sum()) <= 16, name
+        assert int((np.abs(a - b) > 2e-5 * np.maximum(1.0, np.abs(b))).any(axis=2).sum()) <= 1e-3 * a.shape[0] * a.shape[1], name
         assert st_gen["shade_general_wavefronts"] == 0
         total_waves = ((sc.width + 15) // 16) * ((sc.height + 15) // 16) * 4
         if name == "atrium":
