@@ -109,6 +109,7 @@ struct AwsmHipCtx {
     uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
     DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
+    DevBuf msaa_edge_bits;            // MSAA, lean route: one u64 per 16x4 strip (FrameDev.msaa_edge_bits)
     DevBuf out16[kSlots], out32[kSlots];        // the opaque image (+ f32 parity tap) per frame slot: with two images two frames' opaque passes need no order between them
     DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
     uint32_t lean_grid = 0;           // persistent k_shade_lean grid (workgroups), 0 = one workgroup per block
@@ -402,7 +403,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
     const bool texel_cubes = c->scene.cube[0].texels || c->scene.cube[1].texels || c->scene.cube[2].texels;      // sampled by the general kernels only
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !texel_cubes && c->msaa == 0 && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !texel_cubes && (c->msaa == 0 || c->msaa_edge_bits.ptr) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->attr_data_bytes = (uint32_t)std::min<size_t>(c->bufs[AWSM_BUF_ATTR_DATA].size, 0xFFFFFFFFu);
@@ -440,6 +441,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa = c->msaa;
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
+    f->msaa_edge_bits = (lean_ok && c->msaa == 4) ? (unsigned long long*)c->msaa_edge_bits.ptr : nullptr;
     f->msaa_halo = (const unsigned long long*)c->msaa_halo;
     f->halo_bands = c->band_n > 1 ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16[c->slot].ptr);   // kernels address by absolute row
@@ -929,7 +931,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->msaa_edge_bits); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
     for (int k = 0; k < 2 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : c->tr[k - kSlots];
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -1007,6 +1009,7 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
         if ((rc = dev_realloc(c, c->fb[s].vis, px * samples * 8, false))) return rc;
         HIPCHK(c, hipMemsetAsync(c->fb[s].vis.ptr, 0xFF, px * samples * 8, c->stream));
     }
+    if (msaa == 4 && (rc = dev_realloc(c, c->msaa_edge_bits, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 * 8, true))) return rc;
     if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
     c->msaa = msaa;
     for (int sl = 0; sl < n_slots(c); sl++) if ((rc = dev_realloc(c, c->shade_todo[sl], ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4 + 1024) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
@@ -1430,7 +1433,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->bin_overflow_retries = c->overflow_retries;
         out->frames_with_dropped_bin_entries = c->dropped_frames;
         out->handoff_gate_timeouts = c->handoff_dropped_frames;
-        if (c->opaque_done && c->shade_todo[c->slot].ptr && c->msaa == 0 && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
+        if (c->opaque_done && c->shade_todo[c->slot].ptr && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
             HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo[c->slot].ptr, 4, hipMemcpyDeviceToHost));
         out->struct_size = (uint32_t)std::min<size_t>(caller_size, sizeof(AwsmFrameStats));
         memcpy(caller_out, out, out->struct_size);

@@ -206,6 +206,8 @@ struct FrameDev {
     float* out_rgba32f;           // optional parity tap (may be null)
     float4* msaa_color0;          // MSAA: width*height, f32 colour of sample 0 for the pixels in msaa_edges
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
+    unsigned long long* msaa_edge_bits;   // MSAA, lean route: per 16x4-pixel strip (block * 4 + wavefront) the lanes whose pixel is an edge pixel (k_msaa_edges ->
+                                  // k_shade_lean<.., MSAA>, k_shade_todo<.., MSAA>); null = the fused general kernel (k_shade_msaa)
     const unsigned long long* msaa_halo;   // MSAA + bands: sample-0 keys of the first / last row of EVERY rank's bands, [rank][band][2][width] (gathered)
     uint32_t halo_bands;          // bands per rank in that array
     const uint16_t* opaque_rgba16f;   // transparent pass: the opaque pass's image (blit source and transmission background); out_rgba16f/32f = composite

@@ -1611,8 +1611,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
 // lean workgroup leaves free on each SIMD (32 + 80).  At 120 (114 used) this kernel waited for the whole lean kernel to drain — 228 us for an
 // empty list — and held up everything ordered behind the frame.  No occupancy step of the compiler yields a 112 budget (waves_per_eu(5): 96 and
 // a spill), so the count is checked after the build (awsm_renderer_amd/build.py).
-constexpr uint32_t kTodoBlocks = 1024;
+// MSAA: sample 0 of the pixel by the general code, routed like k_shade_lean<.., MSAA> routes its own (compute.wgsl:118-170,303-318 around the edge
+// test that k_msaa_edges already ran): hud meshes and debug views are written before the edge test and never resolved — an edge pixel of theirs
+// leaves a marker in msaa_color0 that k_shade_msaa_resolve skips.
 template <bool GRAD>
+AWSM_DI void shade_pixel_msaa0(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, uint32_t tid) {
+    const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
+    if (cx >= (int)f.width || cy >= (int)f.sy1) return;
+    const size_t pv = (size_t)cy * f.width + (size_t)cx;
+    const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;
+    const bool is_edge = ((f.msaa_edge_bits[(size_t)b.blk * 4u + (tid >> 6)] >> (tid & 63u)) & 1ull) != 0ull;
+    const unsigned long long key = f.vis[pv * 4];
+    if (key == ~0ull) {
+        const f4 sky = skybox_color(sc, f, cx, cy);
+        if (is_edge) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w); else store_pixel(f, p, sky);
+        return;
+    }
+    const uint32_t rank = key_rank(key);
+    const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
+    const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
+    if (o.kind != 0u) {
+        store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);
+        if (is_edge) f.msaa_color0[pv] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+    } else if (is_edge) f.msaa_color0[pv] = make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
+    else store_pixel(f, p, o.color);
+}
+constexpr uint32_t kTodoBlocks = 1024;
+template <bool GRAD, bool MSAA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_todo(const DevScene* __restrict__ sc, FrameDev f) {
     // This kernel starting means this frame's k_shade_lean has ended (same stream): the next frame's opaque pass, gated on that, goes ahead
     // while the list is shaded (k_handoff_wait, kernels_geometry.hip; the two frames write different images).
@@ -1625,7 +1650,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.shade_todo[4u + i]);
         ShadeBlock b;
         if (!shade_block(f, b, e >> 2)) continue;
-        shade_pixel<GRAD>(sc, f, b, ((e & 3u) << 6) | lane);
+        if (MSAA) shade_pixel_msaa0<GRAD>(sc, f, b, ((e & 3u) << 6) | lane);
+        else shade_pixel<GRAD>(sc, f, b, ((e & 3u) << 6) | lane);
     }
 }
 
@@ -1836,7 +1862,9 @@ template <int BYTE> AWSM_DI float channel(const TapG& t, const Weights& wl, cons
 }
 }  // namespace lean
 
-template <bool GRAD>
+// MSAA (x4, the reference's default AntiAliasing): the kernel shades sample 0 of every pixel — keys sit four to a pixel — and routes the colour by the
+// strip's edge mask (k_msaa_edges ran first): an edge pixel's goes to msaa_color0, where k_shade_msaa_resolve picks it up, any other to the image.
+template <bool GRAD, bool MSAA>
 AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
     const uint32_t lane = tid & 63u;
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
@@ -1845,10 +1873,15 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     const uint32_t p = f.out_compact ? (((b.brow >> 1) << kTileShift) + ((uint32_t)cy & (uint32_t)(kTile - 1))) * f.width + (uint32_t)cx : pv;
 
     u32x2 key = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (inside) key = gload<u32x2>(f.vis, pv << 3);
+    if (inside) key = gload<u32x2>(f.vis, MSAA ? pv << 5 : pv << 3);     // MSAA: [pixel][4 samples], sample 0
     const bool hit = inside && (key.x & key.y) != 0xFFFFFFFFu;
-    if (inside && !hit)                                                   // compute.wgsl:149-153: no hit -> skybox (uniform cube)
-        store_pixel(f, p, {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]});
+    bool is_edge = false;
+    if (MSAA) is_edge = ((cload<unsigned long long>(f.msaa_edge_bits, (b.blk * 4u + (tid >> 6)) * 8u) >> lane) & 1ull) != 0ull;
+    if (inside && !hit) {                                                 // compute.wgsl:149-153: no hit -> skybox (uniform cube)
+        const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+        if (MSAA && is_edge) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w);      // compute.wgsl:155-170: sample 0 is background, others are not
+        else store_pixel(f, p, sky);
+    }
     unsigned long long rem = __builtin_amdgcn_ballot_w64(hit);
     if (rem == 0ull) return;                                              // wave-uniform
     const uint32_t rank = hit ? ~key.x : 0xFFFFFFFFu;                     // 0xFFFFFFFF - low word; no triangle has the sentinel's rank
@@ -2101,7 +2134,8 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         lean::direct(lit, light_dir, radiance, color);
     }
     asm volatile("; MARK store");
-    store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
+    if (MSAA && is_edge) f.msaa_color0[pv] = make_float4(color.x, color.y, color.z, 1.0f);
+    else store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
 }
 // k_shade_lean<false>: a wavefront per 16x4-pixel strip.  k_shade_lean<true>: a persistent grid (lean_grid workgroups; workgroup w
 // runs on XCD w & 7, as the hardware deals them) whose wavefronts take strips from counters until the XCD's share is used up —
@@ -2119,7 +2153,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
 // GRAD: MipmapMode::Gradient (the reference's default): barycentric derivatives, isotropic LOD, two levels per texture — a separate instantiation, as the
 // reference keeps separate pipelines; its ten footprints in flight want more registers than six waves per SIMD leave.
-template <bool PERSIST, bool GRAD>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
+template <bool PERSIST, bool GRAD, bool MSAA>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : (PERSIST ? 5 : AWSM_LEAN_WAVES)))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ LeanStage stage[4];                                         // one per wavefront (no barrier anywhere: the four are independent)
     if (frame_poisoned(f)) return;
@@ -2150,7 +2184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
         if (bcol < bx_n && j < share) {
             ShadeBlock b;
             shade_block_at(f, b, brow, bcol);
-            lean_block<GRAD>(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane, st);
+            lean_block<GRAD, MSAA>(sc, f, b, ((kb >> lp) * bx_n + bcol) * 8u + xcd, ((j & 3u) << 6) | lane, st);
         }
         if (!PERSIST) break;
     }
@@ -2192,7 +2226,11 @@ AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& 
     cells[(ly + 1) * 18 + (lx + 1)] = c;
 }
 
-template <bool GRAD>
+// EDGES_ONLY (k_msaa_edges, first kernel of the lean MSAA route): phase 1 and the edge detector alone — nothing is shaded or stored but the block's
+// edge list and, per 16x4 strip, the mask of its edge pixels (FrameDev.msaa_edge_bits), which k_shade_lean<.., MSAA> / k_shade_todo<.., MSAA> route their
+// sample-0 colours by: an edge pixel's goes to msaa_color0 for k_shade_msaa_resolve, any other straight to the image.  The detector is STRICT arithmetic
+// on keys, normals and depths: it does not need the colours.
+template <bool GRAD, bool EDGES_ONLY>
 __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ NeighbourCell cells[18 * 18];
     __shared__ uint32_t n_edges;
@@ -2238,7 +2276,42 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     const size_t po = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : p;   // output pixel (compact band layout)
     uint8_t* edge_rec = reinterpret_cast<uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     bool is_edge = false;
-    if (inside) {
+    if (inside && EDGES_ONLY) {
+        const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
+        if (f.has_opaque && any_hit) {
+            if (k4[0] == ~0ull) is_edge = true;                             // compute.wgsl:155-170: sample 0 is background, others are not
+            else {
+                const m4 inv_proj = load_m4(reinterpret_cast<const float*>(f.camera + 256));
+                const float W = (float)f.width, H = (float)f.height, pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
+                is_edge = edge_mask_depth_msaa(inv_proj, k4, pcx, pcy, W, H);
+                if (!is_edge) {   // msaa.wgsl:42-112
+                    const NeighbourCell me = cells[(ly + 1) * 18 + (lx + 1)];
+                    const f3 center_normal = {me.nx, me.ny, me.nz};
+                    bool center_loaded = false; float view_depth_c = 0.0f, depth_threshold = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ox = i == 0 ? 1 : (i == 1 ? -1 : 0), oy = i == 2 ? 1 : (i == 3 ? -1 : 0);
+                        const NeighbourCell nb = cells[(ly + 1 + oy) * 18 + (lx + 1 + ox)];
+                        if (is_edge || nb.state == 0u) continue;
+                        if (nb.state == 1u) { is_edge = true; continue; }          // neighbour is background
+                        if (dot(center_normal, mk3(nb.nx, nb.ny, nb.nz)) < kEdgeNormalThreshold) { is_edge = true; continue; }
+                        if (!center_loaded) {
+                            view_depth_c = view_space_depth(inv_proj, key_depth(k4[0]), pcx, pcy, W, H);
+                            depth_threshold = kEdgeDepthThreshold * fabsf(view_depth_c);
+                            center_loaded = true;
+                        }
+                        const float nvd = view_space_depth(inv_proj, __uint_as_float(nb.depth_bits), pcx + (float)ox, pcy + (float)oy, W, H);
+                        if (fabsf(view_depth_c - nvd) > depth_threshold) is_edge = true;
+                    }
+                }
+            }
+        }
+    }
+    if (EDGES_ONLY && f.msaa_edge_bits) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(is_edge);
+        if ((tid & 63u) == 0u) f.msaa_edge_bits[(size_t)b.blk * 4u + (tid >> 6)] = m;
+    }
+    if (inside && !EDGES_ONLY) {
         const f4 sky = skybox_color(sc, f, cx, cy);
         const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
         if (!f.has_opaque || !any_hit) {
@@ -2304,6 +2377,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __re
     const float depth0 = key_depth(k4[0]);
     const f4 sky = skybox_color(sc, f, cx, cy);
     const float4 c0v = f.msaa_color0[p];
+    if (__float_as_uint(c0v.w) == 0xFFFFFFFFu) return;        // k_shade_todo<.., MSAA>: a hud mesh or a debug view — written before the edge test, never resolved
     f4 col[4];
     col[0] = {c0v.x, c0v.y, c0v.z, c0v.w};
     for (int s = 1; s < 4; s++) {                 // not unrolled: one copy of the shading code
@@ -2445,36 +2519,48 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 extern "C" void awsm_launch_resolve_draws(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
 }
+extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f);
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (!nb) return;
     const bool grad = f->mipmap != 0u;      // MipmapMode::Gradient vs None: separate instantiations, as the reference keeps separate pipelines
-    if (f->msaa == 4u) {
-        if (grad) { hipLaunchKernelGGL(awsm::k_shade_msaa<true>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
-        else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
-    } else {
-        if (f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws) {
-            // MipmapMode::None: the lean kernel over the screen, then the general code for the wavefronts it declined (k_resolve_draws reset the list)
-            // strip ids sit on a power-of-two block pitch: a wavefront per id (the padding exits), or the persistent grid
-            uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
-            const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
-            if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
-            else if (f->lean_grid && f->lean_next) hipLaunchKernelGGL((awsm::k_shade_lean<true, false>), dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
-            else hipLaunchKernelGGL((awsm::k_shade_lean<false, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);      // awsm_launch_shade_todo follows
-        } else if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
-        else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
+    const bool msaa = f->msaa == 4u;
+    if (awsm_shade_is_lean(f)) {
+        // the lean kernel over the screen (a wavefront per strip id on a power-of-two block pitch: the padding exits), then the general code for the
+        // wavefronts it declined (awsm_launch_shade_todo; k_deform_transform / k_resolve_draws reset the list).  MSAA: the edge detector first.
+        uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
+        const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
+        if (msaa) {
+            if (grad) { hipLaunchKernelGGL((awsm::k_shade_msaa<true, true>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL((awsm::k_shade_lean<false, true, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f); }
+            else { hipLaunchKernelGGL((awsm::k_shade_msaa<false, true>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL((awsm::k_shade_lean<false, false, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f); }
+        } else if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+        else if (f->lean_grid && f->lean_next) hipLaunchKernelGGL((awsm::k_shade_lean<true, false, false>), dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_shade_lean<false, false, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+        return;
     }
+    if (msaa) {
+        if (grad) { hipLaunchKernelGGL((awsm::k_shade_msaa<true, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
+        else { hipLaunchKernelGGL((awsm::k_shade_msaa<false, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
+    } else if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
+    else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
 }
 // second half of the lean route; returns 0 when the frame did not take it
 extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
-    return (bx_n * by_n) && f->msaa != 4u && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
+    return (bx_n * by_n) && (f->msaa != 4u || f->msaa_edge_bits) && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
 }
 extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     if (!awsm_shade_is_lean(f)) return 0;
-    if (f->mipmap) hipLaunchKernelGGL(awsm::k_shade_todo<true>, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
-    else hipLaunchKernelGGL(awsm::k_shade_todo<false>, dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+    if (f->msaa == 4u) {      // ... and the edge pixels' remaining samples, once every sample-0 colour is in place
+        const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
+        const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;
+        if (f->mipmap) { hipLaunchKernelGGL((awsm::k_shade_todo<true, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
+        else { hipLaunchKernelGGL((awsm::k_shade_todo<false, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
+        return 1;
+    }
+    if (f->mipmap) hipLaunchKernelGGL((awsm::k_shade_todo<true, false>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+    else hipLaunchKernelGGL((awsm::k_shade_todo<false, false>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
     return 1;
 }
 // f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;
