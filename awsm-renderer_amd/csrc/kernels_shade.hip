@@ -76,6 +76,23 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
     return reconstruct_core<DERIVS>(t, n0, n1, n2, t0, t1, t2, cx, cy);
 }
 
+// The decoded normal of the pixel's G-buffer texel alone — decode_octahedral(packed_nt.xy) — for the MSAA edge detector: the same operations on the
+// same values as reconstruct_core + pack_normal_tangent's octahedral half, without the tangent (its interpolation, normalisation, basis and atan2: a
+// third of the reconstruction) and without the tangents' 48 bytes per lane.  Bit-identical to unpack_normal_tangent(g.packed_nt).N by construction.
+AWSM_DI f3 strict_normal_of(const FrameDev& f, uint32_t rank, int cx, int cy) {
+    TriSetup t;
+    tri_rec_load(f.tri_rec + rank, t);
+    const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
+    const double Xc = sample_coord((cx << 8) + 128), Yc = sample_coord((cy << 8) + 128);
+    const EdgeVals ev = tri_edges_d(t, Xc, Yc);
+    const float e0 = (float)ev.E[0] * t.iw[0], e1 = (float)ev.E[1] * t.iw[1], e2 = (float)ev.E[2] * t.iw[2];
+    const float inv_esum = 1.0f / ((e0 + e1) + e2);
+    const float b0 = e0 * inv_esum, b1 = e1 * inv_esum, b2 = e2 * inv_esum;
+    const f3 Ni = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y, (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
+    const f2 oct = encode_octahedral(normalize(Ni));
+    return decode_octahedral(mk2(round_f16(oct.x), round_f16(oct.y)));
+}
+
 // Is pixel row `py` one this shard shades (row strip: [sy0, sy1); bands: the 32-row tile rows r, r + n, ...)?
 AWSM_DI bool row_owned(const FrameDev& f, int py) {
     if (py < (int)f.sy0 || py >= (int)f.sy1) return false;
@@ -86,6 +103,11 @@ AWSM_DI bool row_owned(const FrameDev& f, int py) {
 // pixel between one-sample and four-sample shading, so every value feeding a threshold follows the arithmetic contract ----
 constexpr float kEdgeNormalThreshold = 0.95f, kEdgeDepthThreshold = 0.02f, kEdgeMsaaDepthThreshold = 0.02f;
 AWSM_DI float view_space_depth(const m4& inv_proj, float depth, float px, float py, float W, float H) {   // msaa.wgsl:185-199
+    // A projection whose view-space z and w depend on the depth alone (every perspective_rh / orthographic_rh: glam's matrices have exact zeros there) makes
+    // the x and y terms of those two rows exact zeros, and ((0 x + 0 y) + c2 d) + c3 IS c2 d + c3 bit for bit: the NDC divisions and two thirds of the
+    // product drop out (the detector calls this up to nine times per pixel).  Wave-uniform test; anything else takes the full product.
+    if (inv_proj.c[0].z == 0.0f && inv_proj.c[1].z == 0.0f && inv_proj.c[0].w == 0.0f && inv_proj.c[1].w == 0.0f)
+        return (inv_proj.c[2].z * depth + inv_proj.c[3].z) / (inv_proj.c[2].w * depth + inv_proj.c[3].w);
     const f4 view_pos = mul(inv_proj, mk4((px / W) * 2.0f - 1.0f, 1.0f - (py / H) * 2.0f, depth, 1.0f));
     return view_pos.z / view_pos.w;
 }
@@ -2218,8 +2240,7 @@ AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& 
         } else k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
         c.state = 1u;
         if (k != ~0ull) {
-            const GBufferTexel g = reconstruct_gbuffer<false>(f, key_rank(k), px, py);
-            const f3 n = decode_octahedral(mk2(g.packed_nt.x, g.packed_nt.y));     // strict unpack_normal_tangent(..).N
+            const f3 n = strict_normal_of(f, key_rank(k), px, py);                  // strict unpack_normal_tangent(..).N
             c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k >> 32); c.state = 2u;
         }
     }
@@ -2254,8 +2275,12 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
             k4[0] = ka.x; k4[1] = ka.y; k4[2] = kb.x; k4[3] = kb.y;
             c.state = 1u;
             if (k4[0] != ~0ull) {
-                g0 = reconstruct_gbuffer<GRAD>(f, key_rank(k4[0]), cx, cy);   // STRICT
-                const f3 n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
+                f3 n;
+                if (EDGES_ONLY) n = strict_normal_of(f, key_rank(k4[0]), cx, cy);     // the detector needs the normal only
+                else {
+                    g0 = reconstruct_gbuffer<GRAD>(f, key_rank(k4[0]), cx, cy);   // STRICT
+                    n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
+                }
                 c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k4[0] >> 32); c.state = 2u;
             }
         }
@@ -2358,42 +2383,96 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     if (tid == 0) *reinterpret_cast<uint32_t*>(edge_rec) = n_edges;
 }
 
-// One thread per edge pixel of the block: the colours of samples 1..3 (material_shading.wgsl:170-210), shading each
-// distinct triangle once, then the average of the four.
+// The edge pixels' samples 1..3 (material_shading.wgsl:170-210) and the average of the four.  Item-parallel: the block's edge pixels (k_shade_msaa's /
+// k_msaa_edges' list) are first expanded into work items — (pixel, sample) pairs whose triangle no earlier sample of the pixel shows: all samples a
+// triangle covers in a pixel carry the same G-buffer texel and the same standard coordinates (sample 0's depth), hence the same colour — then every
+// thread shades ONE item (the shading call sits in the code once, and a block with 30 edge pixels keeps 40 lanes busy for one shading instead of 30
+// lanes for three in a row), then the threads of the edge pixels gather their four colours.  Up to 768 items per block, in LDS.
 template <bool GRAD>
-__global__ __launch_bounds__(256) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
+__global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
+    // One WAVEFRONT per block: the shading is a long dependent chain for a few dozen lanes, and what bounds the kernel is how many blocks are in flight —
+    // a 256-thread workgroup parked three idle wavefronts' registers behind every busy one (177 us at 4K; 18 M VALU instructions: 83 % of the wave-cycles waiting).
+    __shared__ uint32_t items[768];          // pixel slot | sample << 8
+    __shared__ float4 icolor[768];
+    __shared__ uint16_t first_of[256];       // first item of the block's e-th edge pixel
+    __shared__ uint32_t n_items;
     ShadeBlock b;
     if (frame_poisoned(f) || !shade_block(f, b)) return;
     const uint8_t* edge_rec = reinterpret_cast<const uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     const uint32_t n = *reinterpret_cast<const uint32_t*>(edge_rec);
-    if (threadIdx.x >= n) return;
-    const uint32_t slot = edge_rec[4u + threadIdx.x];
-    const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
-    const size_t p = (size_t)cy * f.width + (size_t)cx;
-    const size_t po = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : p;
-    const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + p * 4);
-    const ulonglong2 ka = kp[0], kb = kp[1];
-    const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
-    const float depth0 = key_depth(k4[0]);
-    const f4 sky = skybox_color(sc, f, cx, cy);
-    const float4 c0v = f.msaa_color0[p];
-    if (__float_as_uint(c0v.w) == 0xFFFFFFFFu) return;        // k_shade_todo<.., MSAA>: a hud mesh or a debug view — written before the edge test, never resolved
-    f4 col[4];
-    col[0] = {c0v.x, c0v.y, c0v.z, c0v.w};
-    for (int s = 1; s < 4; s++) {                 // not unrolled: one copy of the shading code
-        f4 c = sky;
-        if (k4[s] != ~0ull) {
-            const uint32_t r = key_rank(k4[s]);
-            int same = -1;
-            for (int t = 0; t < s; t++) if (k4[t] != ~0ull && key_rank(k4[t]) == r) same = t;
-            if (same >= 0) c = col[same];
-            else c = shade_surface<GRAD>(sc, f, r, cx, cy, depth0, reconstruct_gbuffer<GRAD>(f, r, cx, cy), false).color;
+    if (n == 0u) return;                                                   // wave-uniform
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0u) n_items = 0u;
+    __syncthreads();
+    // ---- phase 1: every edge pixel -> its items ----
+    for (uint32_t e = lane; e < n; e += 64u) {
+        const uint32_t slot = edge_rec[4u + e];
+        const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
+        const size_t p = (size_t)cy * f.width + (size_t)cx;
+        uint32_t cnt = 0u, which = 0u;
+        if (__float_as_uint(f.msaa_color0[p].w) != 0xFFFFFFFFu) {          // (marker: a hud mesh or a debug view of k_shade_todo<.., MSAA> — written before the edge test, never resolved)
+            const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + p * 4);
+            const ulonglong2 ka = kp[0], kb = kp[1];
+            const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
+#pragma unroll
+            for (int sidx = 1; sidx < 4; sidx++) {
+                if (k4[sidx] == ~0ull) continue;
+                const uint32_t r = key_rank(k4[sidx]);
+                bool same = false;
+#pragma unroll
+                for (int t = 0; t < sidx; t++) same = same || (k4[t] != ~0ull && key_rank(k4[t]) == r);
+                if (!same) { which |= (uint32_t)sidx << (2u * cnt); cnt++; }
+            }
         }
-        col[s] = c;
+        const uint32_t first = atomicAdd(&n_items, cnt);
+        first_of[e] = (uint16_t)first;
+        for (uint32_t j = 0; j < cnt; j++) items[first + j] = slot | (((which >> (2u * j)) & 3u) << 8);
     }
-    const f4 sum = {((col[0].x + col[1].x) + col[2].x) + col[3].x, ((col[0].y + col[1].y) + col[2].y) + col[3].y,
-                    ((col[0].z + col[1].z) + col[2].z) + col[3].z, ((col[0].w + col[1].w) + col[2].w) + col[3].w};
-    store_pixel(f, po, {sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f});
+    __syncthreads();
+    // ---- phase 2: one item per lane and turn ----
+    const uint32_t ni = n_items;
+    for (uint32_t i = lane; i < ni; i += 64u) {
+        const uint32_t it = items[i], isl = it & 255u, sidx = it >> 8;
+        const int ix = b.x0 + (int)(isl & 15u), iy = b.y0 + (int)(isl >> 4);
+        const unsigned long long* kq = f.vis + ((size_t)iy * f.width + (size_t)ix) * 4;
+        const unsigned long long ks = kq[sidx], k0 = kq[0];
+        const uint32_t r = key_rank(ks);
+        const f4 c = shade_surface<GRAD>(sc, f, r, ix, iy, key_depth(k0), reconstruct_gbuffer<GRAD>(f, r, ix, iy), false).color;
+        icolor[i] = make_float4(c.x, c.y, c.z, c.w);
+    }
+    __syncthreads();
+    // ---- phase 3: the four colours of every edge pixel, averaged ----
+    for (uint32_t e = lane; e < n; e += 64u) {
+        const uint32_t slot = edge_rec[4u + e];
+        const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
+        const size_t p = (size_t)cy * f.width + (size_t)cx;
+        const float4 c0v = f.msaa_color0[p];
+        if (__float_as_uint(c0v.w) == 0xFFFFFFFFu) continue;
+        const size_t po = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : p;
+        const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(f.vis + p * 4);
+        const ulonglong2 ka = kp[0], kb = kp[1];
+        const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
+        const f4 sky = skybox_color(sc, f, cx, cy);
+        f4 col[4];
+        col[0] = {c0v.x, c0v.y, c0v.z, c0v.w};
+        uint32_t j = first_of[e];
+#pragma unroll
+        for (int sidx = 1; sidx < 4; sidx++) {
+            f4 c = sky;
+            if (k4[sidx] != ~0ull) {
+                const uint32_t r = key_rank(k4[sidx]);
+                int same = -1;
+#pragma unroll
+                for (int t = 0; t < sidx; t++) if (k4[t] != ~0ull && key_rank(k4[t]) == r) same = t;
+                if (same >= 0) c = (same == 0) ? col[0] : ((same == 1) ? col[1] : col[2]);
+                else { const float4 q = icolor[j]; j++; c = {q.x, q.y, q.z, q.w}; }
+            }
+            col[sidx] = c;
+        }
+        const f4 sum = {((col[0].x + col[1].x) + col[2].x) + col[3].x, ((col[0].y + col[1].y) + col[2].y) + col[3].y,
+                        ((col[0].z + col[1].z) + col[2].z) + col[3].z, ((col[0].w + col[1].w) + col[2].w) + col[3].w};
+        store_pixel(f, po, {sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f});
+    }
 }
 #pragma clang fp contract(off)
 
@@ -2540,8 +2619,8 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         return;
     }
     if (msaa) {
-        if (grad) { hipLaunchKernelGGL((awsm::k_shade_msaa<true, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
-        else { hipLaunchKernelGGL((awsm::k_shade_msaa<false, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
+        if (grad) { hipLaunchKernelGGL((awsm::k_shade_msaa<true, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f); }
+        else { hipLaunchKernelGGL((awsm::k_shade_msaa<false, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f); }
     } else if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
     else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
 }
@@ -2555,8 +2634,8 @@ extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::Fram
     if (f->msaa == 4u) {      // ... and the edge pixels' remaining samples, once every sample-0 colour is in place
         const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
         const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;
-        if (f->mipmap) { hipLaunchKernelGGL((awsm::k_shade_todo<true, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(256), 0, s, sc, *f); }
-        else { hipLaunchKernelGGL((awsm::k_shade_todo<false, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(256), 0, s, sc, *f); }
+        if (f->mipmap) { hipLaunchKernelGGL((awsm::k_shade_todo<true, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f); }
+        else { hipLaunchKernelGGL((awsm::k_shade_todo<false, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f); }
         return 1;
     }
     if (f->mipmap) hipLaunchKernelGGL((awsm::k_shade_todo<true, false>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
