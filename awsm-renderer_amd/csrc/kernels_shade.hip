@@ -1899,8 +1899,8 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     const bool hit = inside && (key.x & key.y) != 0xFFFFFFFFu;
     bool is_edge = false;
     if (MSAA) is_edge = ((cload<unsigned long long>(f.msaa_edge_bits, (b.blk * 4u + (tid >> 6)) * 8u) >> lane) & 1ull) != 0ull;
-    if (inside && !hit) {                                                 // compute.wgsl:149-153: no hit -> skybox (uniform cube)
-        const f4 sky = {sc->skybox_rgba[0], sc->skybox_rgba[1], sc->skybox_rgba[2], sc->skybox_rgba[3]};
+    if (inside && !hit) {                                                 // compute.wgsl:149-153: no hit -> skybox (skybox.wgsl:1-41: the uniform colour or the texel cube)
+        const f4 sky = skybox_color(sc, f, cx, cy);
         if (MSAA && is_edge) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w);      // compute.wgsl:155-170: sample 0 is background, others are not
         else store_pixel(f, p, sky);
     }
@@ -2113,9 +2113,10 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     lit.occlusion = occlusion;
     f3 color;
     asm volatile("; MARK ibl");
-    {   // brdf_ibl with the uniform cubes
-        const f3 prefiltered = {sc->prefiltered_rgb[0], sc->prefiltered_rgb[1], sc->prefiltered_rgb[2]};
-        const f3 irradiance = {sc->irradiance_rgb[0], sc->irradiance_rgb[1], sc->irradiance_rgb[2]};
+    {   // brdf_ibl (brdf.wgsl:517-576): the uniform cubes of the builder default, or texel cubes (brdf.wgsl:268-290: irradiance at level 0 along N,
+        // prefiltered at roughness * (mips - 1) along R) through the shared seam-aware sampler
+        const f3 prefiltered = sample_prefiltered(sc, reflect3(-sf.v, sf.n), sf.roughness);
+        const f3 irradiance = sample_irradiance(sc, sf.n);
         const float n_dot_v = sf.n_dot_v_ibl;
         const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
         const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);

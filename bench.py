@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="after the timed loop, compare the gathered image with an unsharded render of the same frame")
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4), help="BASELINE.json config: 4 = configs[3] the 4K Sponza-class frame (the metric's), "
                     "2 = configs[1] helmet-class 15k triangles / 2048^2 textures at 1920x1080, 3 = configs[2] skinned rig + morph cube at 1920x1080")
+    ap.add_argument("--env", choices=("uniform", "procedural"), default="uniform", help="environment: the builder-default uniform cubes (BASELINE), or texel cubemaps — a procedural HDR "
+                    "skybox / prefiltered chain / irradiance cube (scenes.procedural_environment) sampled by skybox.wgsl:37 and brdf.wgsl:268-290")
     ap.add_argument("--static-camera", action="store_true", help="re-submit the same camera every step (default: a small orbit, so cull / sort / draw-list upload run)")
     ap.add_argument("--trace", action="store_true", help="add `frame_trace` to the JSON line: per frame of warm-up + timed loop the host time at which step() returned and the "
                     "device-clock times of geometry begin / geometry done / shading done (awsm_hip_frame_trace), ms from the first")
@@ -208,6 +210,10 @@ def main():
         else:
             scene = scenes.skinned_morph_scene(W, H)
             workload_name = "BrainStem-class skinned rig + AnimatedMorphCube-class morph cube (configs[2])"
+    if args.env == "procedural":
+        scene.env_cubes = scenes.procedural_environment(256, 32)
+        scene.prefiltered_mip_count = len(scene.env_cubes["prefiltered"])
+        scene.irradiance_mip_count = 1
     n_tris = scenes.total_triangles(scene)
     # One explicit HIP stream for everything: the library launches its kernels on it, and torch (RCCL collectives, barrier
     # tensors) orders against it as its current stream.  (torch's default stream has handle 0, which the C-ABI reads as
@@ -512,6 +518,7 @@ def main():
                        "frame_overlap": not args.no_overlap,
                        "stream_handoff": ("device flags (k_handoff_signal / k_handoff_wait)" if dev.stream_handoff() == 1 else "hipEvents" + (" (a device-flag gate timed out: measurement repeated)" if handoff_fault else "")) if not args.no_overlap else "none (one stream)",
                        "camera": "static" if args.static_camera else "orbit, one turn per 240 frames",
+                       "environment": "uniform cubes (builder default)" if args.env == "uniform" else "texel cubemaps (procedural HDR, 256^2 x 9 levels + 32^2 irradiance)",
                        "opaque_route": "lean (k_shade_lean + k_shade_todo)" if lean else "general (k_shade)",
                        "library": os.path.relpath(hip_backend_path(), ROOT)},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels", "shade_general_wavefronts",

@@ -971,6 +971,8 @@ def test_texel_cubemaps_skybox_and_ibl(name, msaa, oracle_lut):
     r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
     dev.close()
     assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["alpha_mismatch"] == 0 and r["f16_max_ulp"] <= 2, r
+    if name == "atrium":
+        assert stats["shade_general_wavefronts"] == 0, stats                            # texel cubes ride the lean route (round 2: any cube sent the frame to k_shade)
     if name == "helmet":
         assert r["covered"] < sc.width * sc.height * 0.6                                # sky pixels are in the comparison
     # through the host layer: Renderer uploads the cubes with awsm_host_env_cube
