@@ -148,6 +148,11 @@ struct AwsmHipCtx {
     uint32_t handoff_test_drop = 0;             // AWSM_TEST_HANDOFF_DROP: that many geometry-done signals are withheld (tests of the timeout path)
     FrameBufs fb[kSlots];             // per-frame device state; two slots when frames overlap (AWSM_CFG_OVERLAP_FRAMES), else slot 0 only
     FrameBufs tr[kSlots];             // the same for the transparent pass's own draws (vertices, setup records, bins); no visibility buffer
+    FrameBufs hud[kSlots];            // ... and for the HUD geometry pass (render.rs:169-178): its own vertices, bins and visibility keys (= hud_depth + the hud triangles)
+    std::vector<DrawDev> hud_draws_host;
+    uint32_t hud_total_tris = 0, hud_n_blocks = 0;
+    bool hud_geometry_done = false;   // this frame has hud geometry: the opaque pass leaves its pixels cleared
+    bool hud_transparent = false;     // the transparent pass being enqueued is the HUD one (depth cleared, colours loaded from the composite)
     std::vector<DrawDev> tr_draws_host;
     uint32_t tr_total_tris = 0, tr_n_blocks = 0;
     bool transparent_done = false;
@@ -441,6 +446,9 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
     f->msaa_edge_bits = (lean_ok && c->msaa == 4) ? (unsigned long long*)c->msaa_edge_bits.ptr : nullptr;
+    f->hud_vis = c->hud_geometry_done ? (const unsigned long long*)c->hud[c->slot].vis.ptr : nullptr;
+    f->hud_draws = (const DrawDev*)c->hud[c->slot].draws_dev.ptr; f->hud_tri_info = (const uint32_t*)c->hud[c->slot].tri_flags.ptr;
+    f->hud_pass = 0;
     f->msaa_halo = (const unsigned long long*)c->msaa_halo;
     f->halo_bands = c->band_n > 1 ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
     f->out_rgba16f = (uint16_t*)(c->bound_out ? (uint8_t*)c->bound_out - (size_t)c->out_first_row * c->width * 8 : c->out16[c->slot].ptr);   // kernels address by absolute row
@@ -657,6 +665,10 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->out_rgba32f = (float*)c->comp32.ptr;
     f->has_opaque = c->last_opaque.has_opaque;
     f->mipmap = c->last_opaque.mipmap;
+    if (c->hud_transparent) {      // the HUD pass: depth starts cleared, the colours it blends over are the composite's own (in place, a pixel per thread)
+        f->hud_pass = 1;
+        f->opaque_rgba16f = f->out_rgba16f;
+    }
 }
 
 int enqueue_transparent(AwsmHipCtx* c) {
@@ -803,7 +815,7 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
         const size_t tri_bound = forward || instanced ? ~size_t(0) : c->bufs[AWSM_BUF_VIS_GEOM_DATA].size / 168u;
         const size_t tri_cap = std::max<size_t>(std::min<size_t>((size_t)total_tris + total_tris / 4 + 4096, std::max<size_t>(tri_bound, total_tris)), b.tri_cap);
         const size_t draw_cap = std::max<size_t>(draws_host.size() + draws_host.size() / 4 + 64, b.draw_cap);
-        FrameBufs* set = forward ? c->tr : c->fb;
+        FrameBufs* set = forward ? c->tr : ((&b >= c->hud && &b < c->hud + kSlots) ? c->hud : c->fb);
         for (int sl = 0; sl < n_slots(c); sl++) {
             // (the slot in use first: if memory runs out half-way the current frame still has its buffers)
             FrameBufs& t = set[(c->slot + sl) % kSlots];
@@ -873,6 +885,8 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         c->fb[s].counters.size = 16 * sizeof(uint32_t);
         if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
         c->tr[s].counters.size = 16 * sizeof(uint32_t);
+        if (hipMalloc(&c->hud[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        c->hud[s].counters.size = 16 * sizeof(uint32_t);
     }
 
     if (c->overlap) {
@@ -931,8 +945,8 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
     fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->msaa_edge_bits); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
-    for (int k = 0; k < 2 * kSlots; k++) {
-        FrameBufs& b = k < kSlots ? c->fb[k] : c->tr[k - kSlots];
+    for (int k = 0; k < 3 * kSlots; k++) {
+        FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : c->hud[k - 2 * kSlots]);
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
@@ -1264,7 +1278,61 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
     ht.mark("geometry_pass: reserve + draw-list upload");
     if ((rc = enqueue_geometry(c))) return rc;
-    c->geometry_done = true; c->opaque_done = false; c->transparent_done = false;
+    c->geometry_done = true; c->opaque_done = false; c->transparent_done = false; c->hud_geometry_done = false;
+    return AWSM_OK;
+}
+
+// GeometryRenderPass::render(ctx, &renderables.hud, true) (render.rs:169-178, geometry/render_pass.rs:51-157 with is_hud): the hud meshes are drawn
+// over the visibility targets (LoadOp::Load) with a depth buffer of their own, cleared — they hide the world whatever its depth, and depth-test among
+// themselves.  Here: the same kernels into the slot's hud key buffer; the world's keys and depth stay as they are (the world transparent pass tests
+// against them), and the opaque pass, the picker and the HUD transparent pass look at the hud keys.
+int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
+    if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->geometry_done || c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "hud_geometry_pass goes between the geometry pass and the opaque pass of a frame");
+    if (c->msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass with MSAA: the edge detector would have to mix hud normals with world depths as the reference's targets do; single-sampled frames only");
+    if (c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height))) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass on a sharded context");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t tris = 0, blocks = 0;
+    int rc = build_draw_list(c, "hud_geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, c->hud_draws_host, &tris, &blocks);
+    if (rc) return rc;
+    c->hud_total_tris = (uint32_t)tris; c->hud_n_blocks = (uint32_t)blocks;
+    if (!tris) { c->hud_geometry_done = false; return AWSM_OK; }
+    FrameBufs& hb = c->hud[c->slot];
+    const size_t px = (size_t)c->width * c->height;
+    if ((rc = dev_reserve(c, hb.vis, px * 8))) return rc;
+    if ((rc = reserve_pass_buffers(c, hb, c->hud_draws_host, c->hud_total_tris, false))) return rc;
+    FrameDev f;
+    fill_frame(c, &f);
+    f.n_draws = (uint32_t)c->hud_draws_host.size();
+    f.total_tris = c->hud_total_tris; f.total_verts = 3u * c->hud_total_tris;
+    f.bin_capacity = hb.bin_capacity;
+    f.draws = (const DrawDev*)hb.draws_dev.ptr;
+    f.clip = (float4*)hb.clip.ptr; f.nrm = (float4*)hb.nrm.ptr; f.tan = (float4*)hb.tan.ptr;
+    f.tri_info = (uint32_t*)hb.tri_flags.ptr;
+    f.tri_shade = nullptr; f.draw_lean = nullptr; f.shade_todo = nullptr; f.shade_todo_cap = 0; f.lean_next = nullptr; f.lean_grid = 0;
+    f.tri_rec = (TriRec*)hb.tri_rec.ptr;
+    f.tile_count = (uint32_t*)hb.tile_count.ptr; f.tile_offset = (uint32_t*)hb.tile_offset.ptr;
+    f.tile_cursor = (uint32_t*)hb.tile_cursor.ptr; f.bin_list = (uint32_t*)hb.bin_list.ptr;
+    f.tile_order = (uint32_t*)hb.tile_order.ptr; f.scan_tmp = (uint32_t*)hb.scan_tmp.ptr;
+    f.tile_split = (uint32_t*)hb.tile_split.ptr; f.raster_scratch = (unsigned long long*)hb.raster_scratch.ptr;
+    f.raster_extra_cap = hb.raster_extra_cap; f.raster_slot_cap = hb.raster_slot_cap;
+    f.big_list = (uint32_t*)hb.big_list.ptr;
+    f.counters = (uint32_t*)hb.counters.ptr;
+    f.host_bin_status = nullptr;                 // the world pass's status words are not this pass's to write
+    f.camera_snap = nullptr; f.camera_snap_words = 0;
+    f.vis = (unsigned long long*)hb.vis.ptr;     // every tile of the frame is written: a tile without hud triangles becomes "no hit"
+    f.hud_vis = nullptr;
+    if ((rc = sync_scene(c))) return rc;
+    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
+    awsm_launch_transform(c->scene_dev, &f, c->hud_n_blocks, c->stream);
+    if (n_tiles) {
+        awsm_launch_bin_count(&f, c->stream); awsm_launch_bin_big(&f, 0, c->stream);
+        awsm_launch_bin_scan(&f, c->stream);
+        awsm_launch_bin_fill(&f, c->stream); awsm_launch_bin_big(&f, 1, c->stream);
+        awsm_launch_raster(&f, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->hud_geometry_done = true;
     return AWSM_OK;
 }
 
@@ -1292,9 +1360,12 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
     return AWSM_OK;
 }
 
-int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
+static int transparent_pass_impl(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n, bool hud) {
     if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->geometry_done || !c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass needs the geometry and opaque passes of the same frame first");
+    if (hud && !c->transparent_done) return fail(c, AWSM_ERR_NOT_READY, "hud_transparent_pass draws over the composite: call transparent_pass first (n_draws = 0 is valid)");
+    if (hud && c->msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_transparent_pass with MSAA (the HUD passes are single-sampled here)");
+    c->hud_transparent = hud;
     const bool sharded = c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height));
     if (sharded && !c->opaque_src)
         return fail(c, AWSM_ERR_UNSUPPORTED, "transparent_pass on a sharded context: screen-space transmission reads the whole opaque image — gather it and bind it with awsm_hip_bind_opaque_source first");
@@ -1326,6 +1397,10 @@ int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) 
     c->transparent_done = true;
     return AWSM_OK;
 }
+int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) { return transparent_pass_impl(c, draws, n, false); }
+// MaterialTransparentRenderPass::render(ctx, renderables.hud, true) (render.rs:301-312, begin_hud_transparent_pass :490-521): the hud meshes drawn
+// forward over what the frame holds so far (colours LoadOp::Load -> the composite, in place), depth-tested among themselves against hud_depth, cleared.
+int awsm_hip_hud_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) { return transparent_pass_impl(c, draws, n, true); }
 
 int awsm_hip_set_stage_timers(AwsmHipCtx* c, int enabled) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
@@ -1394,6 +1469,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
         const bool frag_over = c->transparent_done && c->counters_host[14] != 0;      // a pixel's fragment list did not fit
         if ((!geom_over && !fwd_over && !frag_over) || attempt >= 4) break;
+        if (c->hud_transparent && (fwd_over || frag_over))      // the HUD pass blends into the composite in place: it cannot be replayed on top of itself
+            return fail(c, AWSM_ERR_DEVICE, "the HUD transparent pass overflowed its lists (%u list entries, %u fragment slots needed): render the frame again", c->counters_host[9], c->counters_host[13]);
         // a (triangle, tile) list overflowed: grow to the measured need and replay from the pass that lost entries
         int rc;
         c->overflow_retries++;

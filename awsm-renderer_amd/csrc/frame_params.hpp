@@ -208,6 +208,13 @@ struct FrameDev {
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
     unsigned long long* msaa_edge_bits;   // MSAA, lean route: per 16x4-pixel strip (block * 4 + wavefront) the lanes whose pixel is an edge pixel (k_msaa_edges ->
                                   // k_shade_lean<.., MSAA>, k_shade_todo<.., MSAA>); null = the fused general kernel (k_shade_msaa)
+    // HUD passes (render.rs:169-178,301-312).  The HUD geometry pass rasterises the hud meshes with a depth buffer of its own (hud_depth, cleared):
+    // hud_vis holds its keys (no hit = all ones), or is null when the frame has no hud geometry.  The opaque pass leaves a pixel a hud mesh covers
+    // as cleared (compute.wgsl:176-179: is_hud -> return); the world's own keys and depth stay intact for the world transparent pass.
+    const unsigned long long* hud_vis;
+    const DrawDev* hud_draws;     // picker: the mesh under a hud-covered pixel
+    const uint32_t* hud_tri_info;
+    uint32_t hud_pass;            // transparent pass: 1 = MaterialTransparentRenderPass::render(.., is_hud = true): depth starts cleared (hud_depth), colours load the composite
     const unsigned long long* msaa_halo;   // MSAA + bands: sample-0 keys of the first / last row of EVERY rank's bands, [rank][band][2][width] (gathered)
     uint32_t halo_bands;          // bands per rank in that array
     const uint16_t* opaque_rgba16f;   // transparent pass: the opaque pass's image (blit source and transmission background); out_rgba16f/32f = composite

@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
 
     float depth[S];                            // depth LoadOp::Load: the geometry pass's depth; out-of-frame lanes fail every test
 #pragma unroll
-    for (int s = 0; s < S; s++) depth[s] = in_frame ? key_depth(f.vis[p * S + s]) : -1.0f;
+    for (int s = 0; s < S; s++) depth[s] = in_frame ? (f.hud_pass ? 1.0f : key_depth(f.vis[p * S + s])) : -1.0f;      // hud pass: hud_depth, cleared (render.rs:490-521)
     uint32_t first = kFragNone, last = kFragNone;
     // Fragment slots: same-address device atomics cost ~6 ns each on this part and serialise, so the tile's workgroup takes kFragPool
     // slots with ONE global atomic; its wavefronts carve exact runs out of that pool with LDS atomics, and only when the pool is dry
@@ -1613,6 +1613,7 @@ AWSM_DI void shade_pixel(const DevScene* __restrict__ sc, const FrameDev& f, con
     const size_t pv = (size_t)cy * f.width + (size_t)cx;                  // visibility buffer: always addressed by absolute row
     const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;   // output pixel
     const unsigned long long key = f.vis[pv];
+    if (f.hud_vis && f.has_opaque && f.hud_vis[pv] != ~0ull) { store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f}); return; }   // a hud mesh's triangle is what the visibility target holds here: compute.wgsl:176-179 returns, the pixel stays cleared
     if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, skybox_color(sc, f, cx, cy)); return; }   // compute.wgsl:149-153 / empty.wgsl, skybox.wgsl:1-41
     const uint32_t rank = key_rank(key);
     const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
@@ -1896,10 +1897,13 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 
     u32x2 key = {0xFFFFFFFFu, 0xFFFFFFFFu};
     if (inside) key = gload<u32x2>(f.vis, MSAA ? pv << 5 : pv << 3);     // MSAA: [pixel][4 samples], sample 0
+    bool hud = false;                                                     // a hud mesh covers the pixel: it stays cleared (compute.wgsl:176-179)
+    if (!MSAA && f.hud_vis && inside) { const u32x2 hk = gload<u32x2>(f.hud_vis, pv << 3); hud = (hk.x & hk.y) != 0xFFFFFFFFu; }
+    if (hud) { store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f}); key = {0xFFFFFFFFu, 0xFFFFFFFFu}; }
     const bool hit = inside && (key.x & key.y) != 0xFFFFFFFFu;
     bool is_edge = false;
     if (MSAA) is_edge = ((cload<unsigned long long>(f.msaa_edge_bits, (b.blk * 4u + (tid >> 6)) * 8u) >> lane) & 1ull) != 0ull;
-    if (inside && !hit) {                                                 // compute.wgsl:149-153: no hit -> skybox (skybox.wgsl:1-41: the uniform colour or the texel cube)
+    if (inside && !hit && !hud) {                                         // compute.wgsl:149-153: no hit -> skybox (skybox.wgsl:1-41: the uniform colour or the texel cube)
         const f4 sky = skybox_color(sc, f, cx, cy);
         if (MSAA && is_edge) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w);      // compute.wgsl:155-170: sample 0 is background, others are not
         else store_pixel(f, p, sky);
@@ -2578,10 +2582,15 @@ __global__ void k_pick(const DevScene* __restrict__ sc, FrameDev f, int x, int y
     out[0] = 0u; out[1] = 0u; out[2] = 0u; out[3] = 0xFFFFFFFFu;
     if (x < 0 || y < 0 || x >= (int)f.width || y < (int)f.sy0 || y >= (int)f.sy1) return;
     if (f.band_n > 1u && (((uint32_t)y >> kTileShift) % f.band_n) != f.band_r) return;
-    const unsigned long long key = f.vis[((size_t)y * f.width + (size_t)x) * (f.msaa == 4u ? 4u : 1u)];   // MSAA: sample 0, as the picker's textureLoad(.., 0)
+    unsigned long long key = f.vis[((size_t)y * f.width + (size_t)x) * (f.msaa == 4u ? 4u : 1u)];   // MSAA: sample 0, as the picker's textureLoad(.., 0)
+    const DrawDev* draws = f.draws; const uint32_t* tri_info = f.tri_info;
+    if (f.hud_vis) {      // the HUD geometry pass drew over the visibility target (LoadOp::Load): its triangle is what the picker reads
+        const unsigned long long hk = f.hud_vis[((size_t)y * f.width + (size_t)x) * (f.msaa == 4u ? 4u : 1u)];
+        if (hk != ~0ull) { key = hk; draws = f.hud_draws; tri_info = f.hud_tri_info; }
+    }
     if (key == ~0ull) return;
     const uint32_t rank = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
-    const DrawDev dr = f.draws[f.tri_info[rank] & 0x00FFFFFFu];
+    const DrawDev dr = draws[tri_info[rank] & 0x00FFFFFFu];
     const uint32_t material_meta_offset = *reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + dr.geom_meta_off + 36);
     const uint32_t* mm = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_MATERIAL_META] + (size_t)(material_meta_offset / 256u) * 256u);
     out[0] = 1u; out[1] = mm[0]; out[2] = mm[1]; out[3] = rank - dr.first_tri;

@@ -31,7 +31,7 @@ EXPORTS = ["awsm_hip_create", "awsm_hip_destroy", "awsm_hip_last_error", "awsm_h
            "awsm_hip_read_visibility_unpacked", "awsm_hip_read_opaque", "awsm_hip_read_opaque_f32", "awsm_hip_read_transformed",
            "awsm_hip_device_info", "awsm_hip_transparent_pass", "awsm_hip_read_composite", "awsm_hip_read_composite_f32", "awsm_hip_bind_composite",
            "awsm_hip_read_transformed_forward", "awsm_hip_visibility_digest", "awsm_hip_bind_output_rows", "awsm_hip_env_cube_upload", "awsm_hip_bind_opaque_source", "awsm_hip_msaa_halo_bands", "awsm_hip_msaa_halo_export", "awsm_hip_msaa_halo_bind",
-           "awsm_hip_frame_trace", "awsm_hip_read_frame_trace"]
+           "awsm_hip_frame_trace", "awsm_hip_read_frame_trace", "awsm_hip_hud_geometry_pass", "awsm_hip_hud_transparent_pass"]
 
 
 class AwsmConfig(C.Structure):
@@ -130,6 +130,8 @@ def load_library():
     lib.awsm_hip_msaa_halo_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.awsm_hip_msaa_halo_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.awsm_hip_read_transformed_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.awsm_hip_hud_geometry_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.awsm_hip_hud_transparent_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.awsm_hip_frame_trace.argtypes = [C.c_void_p, C.c_uint32]
     lib.awsm_hip_read_frame_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     _lib = lib
@@ -294,6 +296,16 @@ class HipDevice:
             n = len(draws)
             draws = self.make_draws(draws)
         self._chk(self.lib.awsm_hip_transparent_pass(self.ctx, draws, n if n is not None else len(draws)), "transparent_pass")
+
+    def hud_geometry_pass(self, draws):
+        """The hud meshes' visibility geometry, between geometry_pass and opaque_pass (render.rs:169-178)."""
+        arr = self.make_draws(draws)
+        self._chk(self.lib.awsm_hip_hud_geometry_pass(self.ctx, arr, len(draws)), "hud_geometry_pass")
+
+    def hud_transparent_pass(self, draws):
+        """The hud meshes' transparency geometry over the composite, after transparent_pass (render.rs:301-312)."""
+        arr = self.make_draws(draws)
+        self._chk(self.lib.awsm_hip_hud_transparent_pass(self.ctx, arr, len(draws)), "hud_transparent_pass")
 
     def frame_end(self) -> dict:
         st = AwsmFrameStats()

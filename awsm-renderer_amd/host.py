@@ -85,7 +85,8 @@ def load_library():
         "awsm_host_texture_transform_insert": (u64, [vp, F32P, F32P, C.c_float, F32P]),
         "awsm_host_material_insert": (u64, [vp, vp]), "awsm_host_material_update": (C.c_int, [vp, u64, vp]), "awsm_host_material_offset": (i64, [vp, u64]),
         "awsm_host_skin_insert": (u64, [vp, C.POINTER(u64), C.c_uint32, F32P, C.c_uint32, C.POINTER(U32P), C.POINTER(F32P), C.c_uint32]),
-        "awsm_host_mesh_insert": (u64, [vp, vp, u64, u64, u64, C.c_uint32]), "awsm_host_mesh_remove": (C.c_int, [vp, u64]),
+        "awsm_host_mesh_insert": (u64, [vp, vp, u64, u64, u64, C.c_uint32]), "awsm_host_mesh_insert_hud": (u64, [vp, vp, u64, u64, u64, C.c_uint32]),
+        "awsm_host_hud_draw_lists": (C.c_int, [vp, vp, vp, C.c_uint32, U32P]), "awsm_host_mesh_remove": (C.c_int, [vp, u64]),
         "awsm_host_light_insert": (u64, [vp, vp]), "awsm_host_light_remove": (C.c_int, [vp, u64]),
         "awsm_host_set_ibl_mip_counts": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "awsm_host_camera_update": (C.c_int, [vp, F32P, F32P, F32P]), "awsm_host_env": (C.c_int, [vp, vp]),
@@ -217,6 +218,16 @@ class Host:
             self._chk(-1, "skin_insert")
         return k
 
+    def hud_draw_lists(self):
+        """(HUD geometry pass draws, HUD transparent pass draws): the hud meshes, back to front (render.rs:169-178,301-312)."""
+        n = C.c_uint32()
+        self._chk(self.lib.awsm_host_hud_draw_lists(self.h, None, None, 0, C.byref(n)), "hud_draw_lists")
+        g, t = (AwsmDraw * max(1, n.value))(), (AwsmDraw * max(1, n.value))()
+        self._chk(self.lib.awsm_host_hud_draw_lists(self.h, g, t, n.value, C.byref(n)), "hud_draw_lists")
+        conv = lambda arr: [{"geom_meta_off": d.geom_meta_off, "vis_data_off": d.vis_data_off, "tri_count": d.tri_count, "flags": d.flags,
+                             **({"inst_off": d.inst_off, "inst_count": d.inst_count} if d.inst_count else {})} for d in arr[: n.value]]     # noqa: E731
+        return conv(g), conv(t)
+
     def mesh_insert(self, p, transform: int, material: int, skin: int = 0, hidden: bool = False, front_face_cw: bool = False) -> int:
         keep = []
 
@@ -249,7 +260,8 @@ class Host:
             hp.morph_weights = fp(p.morph_weights)
             hp.animated_morph_weights = fp(p.animated_morph_weights)
         hp.front_face_cw = 1 if front_face_cw else 0
-        k = self.lib.awsm_host_mesh_insert(self.h, C.byref(hp), transform, material, skin, 1 if hidden else 0)
+        insert = self.lib.awsm_host_mesh_insert_hud if getattr(p, "hud", False) else self.lib.awsm_host_mesh_insert
+        k = insert(self.h, C.byref(hp), transform, material, skin, 1 if hidden else 0)
         if not k:
             self._chk(-1, "mesh_insert")
         return k

@@ -59,6 +59,8 @@ struct Backend {
     int (*geometry_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
     int (*opaque_pass)(AwsmHipCtx*, const AwsmOpaqueParams*) = nullptr;
     int (*transparent_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
+    int (*hud_geometry_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
+    int (*hud_transparent_pass)(AwsmHipCtx*, const AwsmDraw*, uint32_t) = nullptr;
     int (*frame_end)(AwsmHipCtx*, AwsmFrameStats*) = nullptr;
 };
 
@@ -194,7 +196,8 @@ struct AwsmHost {
 
     bool created[AWSM_BUF_COUNT] = {};
     uint64_t upload_bytes = 0;
-    std::vector<AwsmDraw> last_draws, last_transparent_draws;
+    std::vector<AwsmDraw> last_draws, last_transparent_draws, last_hud_geometry_draws, last_hud_transparent_draws;
+    bool has_hud_meshes = false;
     bool has_transparent_meshes = false;
 };
 
@@ -401,9 +404,12 @@ bool is_transparency_pass(const AwsmHostMaterial& m) {   // pbr.rs:213-224, unli
     return m.shader != 2u && m.has_transmission && (m.transmission_factor > 0.0f || m.transmission_tex.texture >= 0);
 }
 
-void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out_opaque, std::vector<AwsmDraw>* transparent_out = nullptr) {   // renderable.rs:38-150
+void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out_opaque, std::vector<AwsmDraw>* transparent_out = nullptr,
+                   std::vector<AwsmDraw>* hud_geometry_out = nullptr, std::vector<AwsmDraw>* hud_transparent_out = nullptr) {   // renderable.rs:38-150
     out_opaque.clear();
     if (transparent_out) transparent_out->clear();
+    if (hud_geometry_out) hud_geometry_out->clear();
+    if (hud_transparent_out) hud_transparent_out->clear();
     struct Item { SlotKey key; const MeshRec* rec; int pipeline; float closest; bool has_aabb; };
     std::vector<Item> items;
     const Mat4 view_proj = mat4_mul(h->cam_proj, h->cam_view);
@@ -415,7 +421,6 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out_opaque, std::vector<A
         const MeshRec& m = vals[i];
         if (m.hidden) continue;
         if (fr && m.has_world_aabb && !fr->intersects(m.world_aabb)) continue;
-        if (m.hud) continue;   // HUD meshes go to their own pass (out of scope)
         // pipeline key creation order (G/pipeline.rs:179-265): no_instancing {no_cull, back_cull, front_cull}, instancing {no_cull, back_cull, front_cull}
         Item it{keys[i], &m, (m.instanced ? 3 : 0) + (m.double_sided ? 0 : 1), 0.0f, m.has_world_aabb};
         if (m.has_world_aabb) {
@@ -424,10 +429,10 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out_opaque, std::vector<A
         }
         items.push_back(it);
     }
-    std::vector<Item> tr_items;   // renderable.rs:78-84: hud, else transparent by material, else opaque
+    std::vector<Item> tr_items, hud_items;   // renderable.rs:77-84: hud, else transparent by material, else opaque
     {
         std::vector<Item> op;
-        for (const Item& it : items) (it.rec->transparent ? tr_items : op).push_back(it);
+        for (const Item& it : items) (it.rec->hud ? hud_items : (it.rec->transparent ? tr_items : op)).push_back(it);
         items.swap(op);
     }
     if (h->have_camera) {
@@ -437,20 +442,25 @@ void collect_draws(AwsmHost* h, std::vector<AwsmDraw>& out_opaque, std::vector<A
             if (a.has_aabb != b.has_aabb) return a.has_aabb;                                     // (Some, None) => Less
             return false;
         });
-        std::stable_sort(tr_items.begin(), tr_items.end(), [](const Item& a, const Item& b) {   // same pipeline grouping, then back to front (renderable.rs:90,131-135)
+        auto back_to_front = [](const Item& a, const Item& b) {   // same pipeline grouping, then back to front (renderable.rs:89-90,131-135)
             if (a.pipeline != b.pipeline) return a.pipeline < b.pipeline;
             if (a.has_aabb && b.has_aabb) return total_key(b.closest) < total_key(a.closest);
             if (a.has_aabb != b.has_aabb) return a.has_aabb;
             return false;
-        });
+        };
+        std::stable_sort(tr_items.begin(), tr_items.end(), back_to_front);
+        std::stable_sort(hud_items.begin(), hud_items.end(), back_to_front);
     }
-    for (int pass = 0; pass < 2; pass++)
-    for (const Item& it : (pass == 0 ? items : tr_items)) {
-        if (pass == 1 && !transparent_out) break;
-        std::vector<AwsmDraw>& out = pass == 0 ? *(&out_opaque) : *transparent_out;
+    // pass 0: the geometry pass's list; 1: the world transparent pass's; 2 / 3: the hud list through the HUD geometry pass (visibility geometry)
+    // and the HUD transparent pass (transparency geometry) — render.rs:169-178,301-312
+    for (int pass = 0; pass < 4; pass++)
+    for (const Item& it : (pass == 0 ? items : (pass == 1 ? tr_items : hud_items))) {
+        std::vector<AwsmDraw>* outp = pass == 0 ? &out_opaque : (pass == 1 ? transparent_out : (pass == 2 ? hud_geometry_out : hud_transparent_out));
+        if (!outp) break;
+        std::vector<AwsmDraw>& out = *outp;
         AwsmDraw d{};
         d.geom_meta_off = (uint32_t)h->geom_meta.offset(it.key);
-        d.vis_data_off = (uint32_t)(pass == 0 ? it.rec->vis_off : it.rec->tr_off);
+        d.vis_data_off = (uint32_t)((pass == 0 || pass == 2) ? it.rec->vis_off : it.rec->tr_off);
         d.tri_count = it.rec->tri_count;
         d.flags = it.rec->double_sided ? 0u : AWSM_DRAW_CULL_BACK;
         if (it.rec->instanced) {   // meshes/mesh.rs:91-121: instance buffer bound at the transform key's offset, draw_indexed_with_instance_count
@@ -487,6 +497,7 @@ int awsm_host_create(const char* backend_path, int device, void* stream, uint32_
               load_sym(h.get(), b.texture_array_upload, "awsm_hip_texture_array_upload") && load_sym(h.get(), b.texture_array_generate_mips, "awsm_hip_texture_array_generate_mips") && load_sym(h.get(), b.sampler_set, "awsm_hip_sampler_set") &&
               load_sym(h.get(), b.env_upload, "awsm_hip_env_upload") && load_sym(h.get(), b.env_cube_upload, "awsm_hip_env_cube_upload") && load_sym(h.get(), b.brdf_lut_generate, "awsm_hip_brdf_lut_generate") &&
               load_sym(h.get(), b.geometry_pass, "awsm_hip_geometry_pass") && load_sym(h.get(), b.opaque_pass, "awsm_hip_opaque_pass") && load_sym(h.get(), b.transparent_pass, "awsm_hip_transparent_pass") &&
+              load_sym(h.get(), b.hud_geometry_pass, "awsm_hip_hud_geometry_pass") && load_sym(h.get(), b.hud_transparent_pass, "awsm_hip_hud_transparent_pass") &&
               load_sym(h.get(), b.frame_end, "awsm_hip_frame_end");
     if (!ok) { fprintf(stderr, "awsm_host: %s\n", h->last_error.c_str()); dlclose(b.dl); return AWSM_ERR_NOT_READY; }
     if (b.abi_version() != AWSM_HIP_ABI_VERSION) { dlclose(b.dl); return AWSM_ERR_INVALID_ARGUMENT; }
@@ -694,7 +705,16 @@ AwsmKey awsm_host_skin_insert(AwsmHost* h, const AwsmKey* joints, uint32_t n_joi
 }
 
 // ------------------------------------------------------------------------------------------------ meshes
+static AwsmKey mesh_insert_impl(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden, bool hud);
 AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden) {
+    return mesh_insert_impl(h, p, transform, material, skin, hidden, false);
+}
+// Mesh.hud = true (meshes/mesh.rs:28; the glTF loader's hints.hud): the mesh carries BOTH geometries (gltf/buffers/mesh.rs:37-39), its
+// MaterialMeshMeta says is_hud (material_meta.rs:181-182), and render() draws it in the two HUD passes instead of the world's.
+AwsmKey awsm_host_mesh_insert_hud(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden) {
+    return mesh_insert_impl(h, p, transform, material, skin, hidden, true);
+}
+static AwsmKey mesh_insert_impl(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden, bool hud) {
     if (!p || !p->positions || !p->normals || !p->indices || !p->vertex_count) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "mesh_insert: bad primitive"); return 0; }
     if (!h->locals.contains(transform) || transform == h->root) { fail(h, AWSM_ERR_INVALID_ARGUMENT, "[transform] buffer slot missing"); return 0; }
     const AwsmHostMaterial* mat = h->materials.get(material);
@@ -731,11 +751,12 @@ AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey t
 
     // ---- gltf/buffers/mesh.rs:33-57: visibility geometry XOR transparency geometry, by the material ----
     const bool transparent = is_transparency_pass(*mat);
+    const bool need_vis = !transparent || hud, need_tr = transparent || hud;
     // ---- gltf/buffers/mesh/visibility.rs:35-165: vertex explosion, 56 B / corner ----
-    std::vector<uint8_t> vis(transparent ? 0 : (size_t)T * 3 * 56);
+    std::vector<uint8_t> vis(need_vis ? (size_t)T * 3 * 56 : 0);
     static const float kBary[3][2] = {{1.0f, 0.0f}, {0.0f, 1.0f}, {0.0f, 0.0f}};
     const float default_tangent[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-    for (uint32_t t = 0; t < T && !transparent; t++) {
+    for (uint32_t t = 0; t < T && need_vis; t++) {
         uint32_t vi[3] = {p->indices[t * 3], p->indices[t * 3 + 1], p->indices[t * 3 + 2]};
         int bi[3] = {0, 1, 2};
         if (p->front_face_cw) { std::swap(vi[1], vi[2]); std::swap(bi[1], bi[2]); }
@@ -760,12 +781,13 @@ AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey t
     // ---- meshes.rs:486-560 insert_resource: vis index, vis data, attr index, attr data ----
     SlotKey rk = h->resources.insert(0);
     size_t vis_off = 0, tr_off = 0;
-    if (!transparent) {
+    if (need_vis) {
         std::vector<uint32_t> ident((size_t)T * 3);
         for (size_t i = 0; i < ident.size(); i++) ident[i] = (uint32_t)i;
         h->vis_index.update(rk, reinterpret_cast<const uint8_t*>(ident.data()), ident.size() * 4);
         vis_off = h->vis_data.update(rk, vis.data(), vis.size());
-    } else {   // gltf/buffers/mesh/transparency.rs:31-175: 40 B per ORIGINAL vertex, drawn through the custom-attribute indices
+    }
+    if (need_tr) {   // gltf/buffers/mesh/transparency.rs:31-175: 40 B per ORIGINAL vertex, drawn through the custom-attribute indices
         std::vector<uint8_t> tv((size_t)V * 40);
         for (uint32_t v = 0; v < V; v++) {
             uint8_t* dst = tv.data() + (size_t)v * 40;
@@ -783,7 +805,9 @@ AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey t
     MeshRec rec;
     rec.transform_key = transform; rec.material_key = material; rec.resource_key = rk; rec.skin_key = skin; rec.morph_key = morph_key;
     rec.double_sided = mat->double_sided != 0; rec.hidden = hidden != 0; rec.tri_count = T; rec.vis_off = vis_off; rec.transparent = transparent; rec.tr_off = tr_off;
-    if (transparent) h->has_transparent_meshes = true;
+    rec.hud = hud;
+    if (transparent && !hud) h->has_transparent_meshes = true;
+    if (hud) h->has_hud_meshes = true;
     Vec3 mn = {p->positions[0], p->positions[1], p->positions[2]}, mx = mn;   // accessor min/max (populate/mesh.rs try_position_aabb)
     for (uint32_t v = 1; v < V; v++) {
         const Vec3 q = {p->positions[(size_t)v * 3], p->positions[(size_t)v * 3 + 1], p->positions[(size_t)v * 3 + 2]};
@@ -798,7 +822,7 @@ AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey t
     const uint32_t hi = (uint32_t)(mk >> 32), lo = (uint32_t)(mk & 0xFFFFFFFFull);
     const uint32_t mm[17] = {hi, lo, 0, 0, 0, 0, (uint32_t)h->materials_buf.offset(material), (uint32_t)h->transforms_buf.offset(transform),
                              (uint32_t)h->normals_buf.offset(transform), (uint32_t)attr_index_off, (uint32_t)attr_data_off, stride_f * 4,
-                             p->n_color_sets * 4, p->n_uv_sets, p->n_color_sets, (uint32_t)vis_off, 0u};
+                             p->n_color_sets * 4, p->n_uv_sets, p->n_color_sets, (uint32_t)vis_off, hud ? 1u : 0u};      // last: is_hud
     h->material_meta.update(mk, reinterpret_cast<const uint8_t*>(mm), 68);
     uint32_t gm[10] = {hi, lo, 0, 0, 0, 0, 0, 0, (uint32_t)h->transforms_buf.offset(transform), (uint32_t)h->material_meta.offset(mk)};
     if (morph_key) { gm[2] = p->n_morph_targets; gm[3] = (uint32_t)h->morph_weights.offset(morph_key); gm[4] = (uint32_t)h->morph_values.offset(morph_key); }
@@ -813,7 +837,7 @@ int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh) {
     if (!rec) return fail(h, AWSM_ERR_INVALID_ARGUMENT, "[mesh] not found");
     const SlotKey rk = rec->resource_key, tk = rec->transform_key, mk = rec->morph_key;
     h->vis_index.remove(rk); h->vis_data.remove(rk); h->tr_data.remove(rk); h->attr_index.remove(rk); h->attr_data.remove(rk);
-    if (rec->transparent) h->tr_data_dirty = true;
+    if (rec->transparent || rec->hud) h->tr_data_dirty = true;
     h->resources.remove(rk);
     if (mk) { h->morph_weights.remove(mk); h->morph_values.remove(mk); h->morphs.remove(mk); h->morph_weights_dirty = h->morph_values_dirty = true; }
     auto& v = h->transform_to_meshes[tk];
@@ -1045,8 +1069,9 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
         a.dirty = false;
     }
     // ---- collect_renderables -> geometry pass -> opaque pass (render.rs:144-221) ----
-    collect_draws(h, h->last_draws, &h->last_transparent_draws);
+    collect_draws(h, h->last_draws, &h->last_transparent_draws, &h->last_hud_geometry_draws, &h->last_hud_transparent_draws);
     if ((rc = h->be.geometry_pass(h->ctx, h->last_draws.data(), (uint32_t)h->last_draws.size()))) return dev_fail(h, rc, "geometry_pass");
+    if (h->has_hud_meshes && (rc = h->be.hud_geometry_pass(h->ctx, h->last_hud_geometry_draws.data(), (uint32_t)h->last_hud_geometry_draws.size()))) return dev_fail(h, rc, "hud_geometry_pass");   // render.rs:169-178
     if (h->after_geometry && (rc = h->after_geometry(h->after_geometry_user))) { h->last_error = "after_geometry_pass hook failed"; return rc; }   // hooks.after_geometry_pass (render.rs:181-190)
     AwsmOpaqueParams op{};
     op.mipmap = h->mipmap ? 1u : 0u; op.has_opaque = h->last_draws.empty() ? 0u : 1u;   // material_opaque/render_pass.rs:64-71
@@ -1054,7 +1079,9 @@ int awsm_host_render(AwsmHost* h, int sync, AwsmFrameStats* stats) {   // render
     if (h->after_opaque && (rc = h->after_opaque(h->after_opaque_user))) { h->last_error = "after_opaque_pass hook failed"; return rc; }
     // ---- opaque -> transparent blit + world transparent pass (render.rs:224-297).  A scene without transparent meshes skips it:
     // the composite image then IS the opaque image (the reference would copy it). ----
-    if (h->has_transparent_meshes) { if ((rc = h->be.transparent_pass(h->ctx, h->last_transparent_draws.data(), (uint32_t)h->last_transparent_draws.size()))) return dev_fail(h, rc, "transparent_pass"); }
+    if (h->has_transparent_meshes || h->has_hud_meshes) { if ((rc = h->be.transparent_pass(h->ctx, h->last_transparent_draws.data(), (uint32_t)h->last_transparent_draws.size()))) return dev_fail(h, rc, "transparent_pass"); }
+    // ---- the HUD transparent pass over the composite (render.rs:301-312) ----
+    if (h->has_hud_meshes && (rc = h->be.hud_transparent_pass(h->ctx, h->last_hud_transparent_draws.data(), (uint32_t)h->last_hud_transparent_draws.size()))) return dev_fail(h, rc, "hud_transparent_pass");
     if (sync) { if ((rc = h->be.frame_end(h->ctx, stats))) return dev_fail(h, rc, "frame_end"); }   // gpu.submit_commands (render.rs:370)
     return AWSM_OK;
 }
@@ -1098,6 +1125,15 @@ int awsm_host_transparent_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, ui
     collect_draws(h, d, &t);
     *n = (uint32_t)t.size();
     if (out) memcpy(out, t.data(), std::min<size_t>(cap, t.size()) * sizeof(AwsmDraw));
+    return AWSM_OK;
+}
+
+int awsm_host_hud_draw_lists(AwsmHost* h, AwsmDraw* geometry_out, AwsmDraw* transparent_out, uint32_t cap, uint32_t* n) {
+    std::vector<AwsmDraw> d, t, hg, ht;
+    collect_draws(h, d, &t, &hg, &ht);
+    *n = (uint32_t)hg.size();      // the same meshes through both passes
+    if (geometry_out) memcpy(geometry_out, hg.data(), std::min<size_t>(cap, hg.size()) * sizeof(AwsmDraw));
+    if (transparent_out) memcpy(transparent_out, ht.data(), std::min<size_t>(cap, ht.size()) * sizeof(AwsmDraw));
     return AWSM_OK;
 }
 

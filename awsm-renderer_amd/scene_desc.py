@@ -76,6 +76,8 @@ class PrimitiveDesc:
     morph_targets: List[dict] = field(default_factory=list)  # {positions?, normals?, tangents?} each (V,3) f32
     morph_weights: Optional[np.ndarray] = None               # (targets,) f32  (glTF mesh.weights)
     animated_morph_weights: Optional[np.ndarray] = None      # written through the animation path ([1..n+1))
+    hud: bool = False                # Mesh.hud (meshes/mesh.rs:28): drawn by the two HUD passes (render.rs:169-178,301-312) over the world, with a depth buffer of its own;
+                                     # carries visibility AND transparency geometry (gltf/buffers/mesh.rs:33-39)
 
 
 @dataclass

@@ -633,3 +633,25 @@ def transparent_scene(width=640, height=360, tex_size=64, seed=0xA35A0007, detai
     return SceneDesc(nodes=nodes, materials=mats, textures=textures, samplers=[dict(REPEAT_LINEAR), dict(CLAMP_LINEAR)], lights=lights, width=width, height=height,
                      view=look_at_rh(eye, (0, 0, 0)), proj=perspective_rh(math.radians(50), width / height, 0.1, 100.0), camera_position=eye,
                      skybox_rgba=(0.02, 0.03, 0.05, 1.0), prefiltered_rgb=(0.9, 0.95, 1.0), irradiance_rgb=(0.8, 0.85, 0.9))
+
+
+def hud_scene(width=640, height=360, tex_size=64) -> SceneDesc:
+    """transparent_scene's world plus four hud meshes (Mesh.hud: render.rs:169-178,301-312) in front of the camera: an opaque-material panel,
+    a half-transparent quad overlapping it (their mutual order is decided by hud_depth), a textured panel, and a quad that lies BEHIND the
+    world's back wall — a hud mesh hides the world whatever the world's depth, so it must still show.  Not a BASELINE config."""
+    sc = transparent_scene(width, height, tex_size=tex_size)
+
+    def quad_fn(w, h):
+        def quad(U, V):
+            return np.stack([(U - 0.5) * w, (V - 0.5) * h, np.zeros_like(U)], axis=-1)
+        return quad
+
+    def hud_prim(w, h, material):
+        pos, nrm, tan, uvs, idx = grid_patch(quad_fn(w, h), 5, 4, uv_scale=(1.0, 1.0))
+        return PrimitiveDesc(positions=pos, normals=nrm, tangents=tan, uvs=[uvs], indices=idx, material=material, hud=True)
+
+    sc.nodes.append(NodeDesc(parent=0, translation=(-1.3, 0.9, 3.6), rotation=quat_axis_angle((0, 1, 0), 0.25), primitives=[hud_prim(1.3, 0.7, 1)]))      # opaque material
+    sc.nodes.append(NodeDesc(parent=0, translation=(-0.9, 0.7, 3.9), rotation=quat_axis_angle((0, 1, 0), -0.2), primitives=[hud_prim(1.2, 0.8, 12)]))     # blend 0.5, overlaps the first
+    sc.nodes.append(NodeDesc(parent=0, translation=(1.5, -0.6, 3.4), rotation=quat_axis_angle((1, 0, 0), 0.3), primitives=[hud_prim(1.1, 0.8, 2)]))       # textured alpha
+    sc.nodes.append(NodeDesc(parent=0, translation=(2.6, 1.6, -6.0), primitives=[hud_prim(4.0, 2.5, 13)]))                                                # behind the wall (z = -3)
+    return sc

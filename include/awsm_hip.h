@@ -267,6 +267,21 @@ int awsm_hip_opaque_pass(AwsmHipCtx* ctx, const AwsmOpaqueParams* params);
  * pipelined loop that never calls frame_end must call it at least once after the transparent workload changes size (the lists then stay
  * sized for it), or check AwsmFrameStats.bin_overflow_retries from time to time — an overflowed enqueue-only frame drops fragments. ---- */
 int awsm_hip_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
+/* ---- the HUD passes (crates/renderer/src/render.rs:169-178,301-312; Mesh.hud, MaterialMeshMeta.is_hud):
+ *   awsm_hip_hud_geometry_pass    GeometryRenderPass::render(ctx, &renderables.hud, true) — between awsm_hip_geometry_pass and awsm_hip_opaque_pass.  The
+ *                                 hud meshes' visibility geometry (draws as in awsm_hip_geometry_pass) is rasterised over the visibility targets with a
+ *                                 depth buffer of its own, cleared (geometry/render_pass.rs:51-157 with is_hud): they hide the world whatever its depth.
+ *                                 The opaque pass then leaves every pixel a hud mesh covers cleared, (0, 0, 0, 0) (compute.wgsl:176-179), and
+ *                                 awsm_hip_pick reports the hud mesh.  The world's keys and depth are not touched (the world transparent pass tests
+ *                                 against them, as the reference's does against `depth`).
+ *   awsm_hip_hud_transparent_pass MaterialTransparentRenderPass::render(ctx, renderables.hud, true) — after awsm_hip_transparent_pass (call that with
+ *                                 n_draws = 0 when the frame has no world-transparent mesh).  The hud meshes' transparency geometry, back to front,
+ *                                 forward-shaded and blended over the composite (colour LoadOp::Load), depth-tested against hud_depth, cleared
+ *                                 (render.rs:490-521).  A hud mesh carries both geometries (gltf/buffers/mesh.rs:33-39).
+ * Single-sampled, unsharded frames only (AWSM_ERR_UNSUPPORTED otherwise): with MSAA the reference's edge detector mixes the hud meshes' normals with
+ * the world's depths, which this library's separate hud keys do not reproduce. ---- */
+int awsm_hip_hud_geometry_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
+int awsm_hip_hud_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
 /* the full-frame opaque image the transparent pass of a sharded context blits from and refracts through (device memory, width*height*8
  * bytes, kept by reference until replaced; NULL = this context's own opaque output, which is complete only when unsharded) */
 int awsm_hip_bind_opaque_source(AwsmHipCtx* ctx, const void* device_ptr, size_t bytes);

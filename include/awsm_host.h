@@ -122,6 +122,9 @@ typedef struct AwsmHostPrimitive {
 } AwsmHostPrimitive;
 
 AwsmKey awsm_host_mesh_insert(AwsmHost* h, const AwsmHostPrimitive* prim, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden);
+/* Mesh.hud = true (meshes/mesh.rs:28; what the glTF loader's hints.hud sets): both geometries (gltf/buffers/mesh.rs:37-39), is_hud in the mesh's
+ * MaterialMeshMeta, drawn by render() in the two HUD passes (render.rs:169-178,301-312) instead of the world's */
+AwsmKey awsm_host_mesh_insert_hud(AwsmHost* h, const AwsmHostPrimitive* prim, AwsmKey transform, AwsmKey material, AwsmKey skin, uint32_t hidden);
 int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh);
 
 /* ---- Lights (lights.rs:160-310) ---- */
@@ -192,6 +195,8 @@ int awsm_host_decode_image(const uint8_t* data, size_t len, uint8_t* rgba_out, s
 /* the world transparent pass's list (back to front), as awsm_host_draw_list gives the geometry pass's */
 int awsm_host_transparent_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);
 int awsm_host_draw_list(AwsmHost* h, AwsmDraw* out, uint32_t cap, uint32_t* n);   /* the list render() would submit */
+/* the hud meshes (back to front) as the HUD geometry pass and the HUD transparent pass receive them: n entries in each array */
+int awsm_host_hud_draw_lists(AwsmHost* h, AwsmDraw* geometry_out, AwsmDraw* transparent_out, uint32_t cap, uint32_t* n);
 uint32_t awsm_host_texture_array_count(AwsmHost* h);
 int awsm_host_texture_array_info(AwsmHost* h, uint32_t array_idx, uint32_t* width, uint32_t* height, uint32_t* layers, const uint8_t** texels);
 uint64_t awsm_host_upload_bytes_last_frame(AwsmHost* h);

@@ -124,6 +124,9 @@ def lut_rg_to_rgba16f(rg: np.ndarray) -> np.ndarray:
     return out
 
 
+NO_HIT_KEY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
 class OracleFrame:
     """Holds the numpy arrays an OracleScene points at and runs the three oracle stages."""
 
@@ -232,9 +235,28 @@ class OracleFrame:
             self.rgba16f[...] = base16
         return worst
 
-    def forward(self, draws: List[dict], threads=8):
+    def hud_geometry(self, model, threads=8) -> np.ndarray:
+        """GeometryRenderPass::render(.., &renderables.hud, true) (render.rs:169-178): the hud meshes rasterised with a depth buffer of their own.
+        Returns their keys (no hit = all ones) and keeps them (self.hud_keys); shade() then leaves the pixels they cover cleared
+        (compute.wgsl:176-179).  A second OracleFrame over the same mirrors with the hud draw list does the work."""
+        sc = model.scene
+        draws = model.hud_geometry_draws
+        hud = OracleFrame(model.mirrors(), draws, sc.width, sc.height, model.texture_arrays(), sc.samplers, self.lut) if draws else None
+        self.hud_keys = hud.transform().raster(threads).keys.copy() if hud else np.full(self.keys.shape, NO_HIT_KEY, dtype=np.uint64)
+        return self.hud_keys
+
+    def apply_hud_clear(self):
+        """after shade(): the opaque pass returns at a pixel whose visibility texel belongs to a hud mesh — it stays as clear_opaque left it"""
+        covered = self.hud_keys != NO_HIT_KEY
+        self.rgba32f[covered] = 0.0
+        self.rgba16f[covered] = 0
+        return self
+
+    def forward(self, draws: List[dict], threads=8, hud=False):
         """World transparent pass over `draws` (HostModel.collect_transparent_draws()), after run(): fills fwd_clip / fwd_nt / fwd_wpos
-        and the composite image (composite32f holds the f16 values, composite16f their bits)."""
+        and the composite image (composite32f holds the f16 values, composite16f their bits).
+        hud=True: the HUD transparent pass (render.rs:301-312, :490-521) over the composite a previous forward() left — colours LoadOp::Load
+        (the composite is the image blended over), depth against hud_depth, cleared (every key reads as no hit = depth 1.0)."""
         L = lib()
         arr = (AwsmDraw * max(1, len(draws)))()
         for i, d in enumerate(draws):
@@ -242,6 +264,7 @@ class OracleFrame:
         n = len(draws)
         L.oracle_forward_total_vertices.restype = C.c_uint32
         nv = int(L.oracle_forward_total_vertices(arr, C.c_uint32(n)))
+        prev_composite16 = self.composite16f.copy() if hud else None
         self.fwd_n_verts = nv
         self.fwd_clip = np.zeros((max(1, nv), 4), dtype=np.float32)
         self.fwd_nt = np.zeros((max(1, nv), 8), dtype=np.float32)
@@ -250,8 +273,12 @@ class OracleFrame:
         self.composite16f = np.zeros((self.height, self.width, 4), dtype=np.uint16)
         self.fwd_touched = np.zeros((self.height, self.width), dtype=np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        keys, source = self.keys, self.rgba16f
+        if hud:
+            keys = np.full(self.keys.shape, NO_HIT_KEY, dtype=np.uint64)
+            source = prev_composite16
         assert L.oracle_forward_transform(C.byref(self.scene), arr, C.c_uint32(n), p(self.fwd_clip), p(self.fwd_nt), p(self.fwd_wpos)) == 0
-        assert L.oracle_forward(C.byref(self.scene), arr, C.c_uint32(n), p(self.fwd_clip), p(self.fwd_nt), p(self.fwd_wpos), p(self.keys), p(self.rgba16f),
+        assert L.oracle_forward(C.byref(self.scene), arr, C.c_uint32(n), p(self.fwd_clip), p(self.fwd_nt), p(self.fwd_wpos), p(keys), p(source),
                                 p(self.composite32f), p(self.composite16f), p(self.fwd_touched), C.c_int(threads)) == 0
         return self
 

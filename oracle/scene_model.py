@@ -533,17 +533,18 @@ class HostModel:
         material_key = self.material_keys_by_index[p.material]
         mdesc = sc.materials[p.material]
 
-        # gltf/buffers/mesh.rs:33-57: a primitive gets visibility geometry XOR transparency geometry, by its material
+        # gltf/buffers/mesh.rs:33-57: a primitive gets visibility geometry XOR transparency geometry, by its material — a hud mesh both (:37-39)
+        hud = bool(getattr(p, "hud", False))
         transparent = mdesc.is_transparency_pass()
         attr, stride = pack_vertex_attributes(p.colors, p.uvs)
         T = int(np.asarray(p.indices).reshape(-1, 3).shape[0])
         rk = self.resources.insert(())
         vis_off, tr_off = 0, None
-        if not transparent:
+        if not transparent or hud:
             vis = create_visibility_vertices(p.positions, p.normals, p.tangents, p.indices)
             self.vis_index.update(rk, np.arange(T * 3, dtype=np.uint32).tobytes())        # meshes.rs:514-520
             vis_off = self.vis_data.update(rk, vis)
-        else:
+        if transparent or hud:
             tr_off = self.tr_data.update(rk, create_transparency_vertices(p.positions, p.normals, p.tangents))   # meshes.rs:538-545
         attr_index_off = self.attr_index.update(rk, np.asarray(p.indices, dtype=np.uint32).tobytes())
         attr_data_off = self.attr_data.update(rk, attr)
@@ -552,7 +553,7 @@ class HostModel:
         mesh_key = self.meshes.insert(rec)
         self.transform_to_meshes.setdefault(transform_key, []).append(mesh_key)
         rec.vis_off, rec.skin_key, rec.morph_key = vis_off, skin_key, morph_key
-        rec.transparent, rec.tr_off = transparent, tr_off
+        rec.transparent, rec.tr_off, rec.hud = transparent, tr_off, hud
         rec.instanced = False
         if getattr(p, "instances", None) is not None:      # Meshes::enable_mesh_instancing -> Instances::transform_insert (meshes.rs:176-218, instances.rs:49-57)
             rec.instanced = True
@@ -565,7 +566,7 @@ class HostModel:
         uv_sets_index = sum(4 for _ in p.colors)
         mm = struct.pack("<17I", hi, lo, 0, 0, 0, 0, self.materials.offset(material_key), self.transforms.buffer.offset(transform_key),
                          self.transforms.normals_buffer.offset(transform_key), attr_index_off, attr_data_off, stride, uv_sets_index,
-                         len(p.uvs), len(p.colors), vis_off, 0)
+                         len(p.uvs), len(p.colors), vis_off, 1 if hud else 0)      # last word: is_hud (material_meta.rs:181-182)
         self.material_meta.update(mesh_key, mm)
         if morph_key is not None:
             morph = (self.morph_targets_len[morph_key], self.morph_weights.offset(morph_key), self.morph_values.offset(morph_key))
@@ -608,13 +609,16 @@ class HostModel:
         sc = self.scene
         view_proj = hm.mat4_mul(np.asarray(sc.proj, dtype=F), np.asarray(sc.view, dtype=F))
         frustum = Frustum(view_proj)
-        opaque, transparent = [], []
+        opaque, transparent, hud = [], [], []
         for mk, rec in self.meshes.items():
             if rec.hidden:
                 continue
             if rec.world_aabb is not None and not frustum.intersects_aabb(rec.world_aabb):
                 continue
-            (transparent if getattr(rec, "transparent", False) else opaque).append((mk, rec))   # renderable.rs:78-84
+            if getattr(rec, "hud", False):      # renderable.rs:77-84: hud first, then by the material
+                hud.append((mk, rec))
+            else:
+                (transparent if getattr(rec, "transparent", False) else opaque).append((mk, rec))
 
         def pipeline_rank(rec):   # G/pipeline.rs:179-265 creation order: no_instancing {no_cull, back_cull, front_cull}, instancing {...}
             return (3 if getattr(rec, "instanced", False) else 0) + (0 if rec.double_sided else 1)
@@ -640,6 +644,7 @@ class HostModel:
         opaque.sort(key=functools.cmp_to_key(cmp))   # Python's sort is stable, like slice::sort_by
         # renderable.rs:90: grouped by the GEOMETRY pipeline key like the opaque list, then back to front
         transparent.sort(key=functools.cmp_to_key(lambda a, b: cmp(a, b, True)))
+        hud.sort(key=functools.cmp_to_key(lambda a, b: cmp(a, b, True)))      # renderable.rs:90
 
         def to_draws(lst, forward):
             draws = []
@@ -655,6 +660,7 @@ class HostModel:
             return draws
 
         self.transparent_draws = to_draws(transparent, True)
+        self.hud_geometry_draws, self.hud_transparent_draws = to_draws(hud, False), to_draws(hud, True)      # render.rs:169-178 / :301-312: the same list through both passes
         return to_draws(opaque, False)
 
     def collect_transparent_draws(self) -> List[dict]:

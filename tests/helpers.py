@@ -19,7 +19,7 @@ def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0, mi
     return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap).run(threads)
 
 
-def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False, transparent=False):
+def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False, transparent=False, hud=False):
     """Drive one frame through the C-ABI exactly as the host layer does: create+write every mirror, then the passes."""
     from awsm_renderer_amd.hip_backend import HipDevice
     sc = model.scene
@@ -42,9 +42,13 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap
         dev.set_shard_rows(*rows)
     draws = model.collect_draws()
     dev.geometry_pass(draws)
+    if hud:      # render.rs:169-178
+        dev.hud_geometry_pass(model.hud_geometry_draws)
     dev.opaque_pass(has_opaque=has_opaque, mipmap=1 if mipmap else 0)
-    if transparent:
+    if transparent or hud:
         dev.transparent_pass(model.collect_transparent_draws())
+    if hud:      # render.rs:301-312
+        dev.hud_transparent_pass(model.hud_transparent_draws)
     stats = dev.frame_end()
     return dev, stats
 

@@ -53,6 +53,8 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) {
 }
 int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) { c->has_opaque = p->has_opaque; logc(c, 8, 0, p->has_opaque, p->mipmap); return 0; }
 int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) { (void)d; logc(c, 15, 0, n, 0); return 0; }
+int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) { (void)d; logc(c, 17, 0, n, 0); return 0; }
+int awsm_hip_hud_transparent_pass(AwsmHipCtx* c, const AwsmDraw* d, uint32_t n) { (void)d; logc(c, 18, 0, n, 0); return 0; }
 int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* s) { if (s) { uint32_t n = s->struct_size < sizeof *s ? s->struct_size : (uint32_t)sizeof *s; memset(s, 0, n); s->struct_size = n; } logc(c, 9, 0, 0, 0); return 0; }
 /* ---- inspection ---- */
 size_t mock_log_count(AwsmHipCtx* c) { return c->n_log; }

@@ -1167,3 +1167,55 @@ def test_frames_rendered_from_a_glb_file(name, oracle_lut, tmp_path):
         c = helpers.compare_composite(orc, dev)
         assert c["clip_mismatch"] == 0 and c["untouched_changed"] == 0 and c["pixels_over_2ulp"] <= c["touched_pixels"] // 200, c
     r.close()
+
+
+@pytest.mark.gpu
+def test_hud_passes(oracle_lut):
+    """The two HUD passes (render.rs:169-178,301-312): hud meshes rasterised over the visibility targets with a depth buffer of their own, the opaque
+    pass leaving the pixels they cover cleared (compute.wgsl:176-179), the world transparent pass still depth-tested against the WORLD's depth, then the
+    hud meshes forward-shaded over the composite against hud_depth, cleared.  Against the oracle: world keys bit-exact, the opaque image within the
+    shading tolerance with exact zeros under the hud meshes, the composite within two f16 steps; the picker reports the hud mesh; a hud quad that
+    lies behind the world's back wall still shows."""
+    from oracle.host_mirror import key_as_ffi
+    sc = scenes.hud_scene(480, 270)
+    model = helpers.build_model(sc)
+    orc = oracle_lib.frame_from_model(model, oracle_lut).transform().raster(16)
+    hud_keys = orc.hud_geometry(model, 16)
+    covered = hud_keys != helpers.NO_HIT
+    assert 2000 < int(covered.sum()) < sc.width * sc.height // 2
+    orc.shade(16).apply_hud_clear()
+    dev, _ = helpers.hip_frame(model, oracle_lut, hud=True)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert r["key_mismatch"] == 0 and r["clip_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["f16_max_ulp"] <= 2, r
+    opaque = dev.read_opaque()
+    assert (opaque[covered] == 0).all()                                     # cleared, alpha included
+    assert (opaque[~covered][:, 3] == 0x3C00).all()                          # everything else was shaded (or sky): alpha 1
+    # the composite: world transparent pass, then the hud meshes over it
+    orc.forward(model.collect_transparent_draws(), 16)
+    world_comp = orc.composite16f.copy()
+    orc.forward(model.hud_transparent_draws, 16, hud=True)
+    h16 = dev.read_composite()
+    ulp = helpers.f16_ulp_distance(h16, orc.composite16f)
+    assert int((ulp > 2).any(axis=-1).sum()) <= 4, int((ulp > 2).any(axis=-1).sum())
+    touched = orc.fwd_touched != 0
+    assert int(helpers.f16_ulp_distance(h16, world_comp)[~touched].max()) <= 2       # pixels no hud fragment reached keep the world's composite
+    assert int(touched.sum()) >= int(covered.sum())                          # every hud-covered pixel received a hud fragment (hud_depth starts cleared)
+    # the quad behind the wall: the world is in front of it everywhere, and it still shows (its pixels changed the composite)
+    wall_in_front = covered & (orc.keys != helpers.NO_HIT) & ((orc.keys >> np.uint64(32)) < (hud_keys >> np.uint64(32)))
+    assert int(wall_in_front.sum()) > 500 and (h16[wall_in_front] != world_comp[wall_in_front]).any(axis=-1).mean() > 0.9
+    # picker: a hud-covered pixel reports the hud mesh whose triangle the hud keys hold
+    first = np.concatenate([[0], np.cumsum([d["tri_count"] for d in model.hud_geometry_draws])])
+    ys, xs = np.nonzero(covered)
+    for i in range(0, len(ys), max(1, len(ys) // 24)):
+        y, x = int(ys[i]), int(xs[i])
+        rank = 0xFFFFFFFF - int(hud_keys[y, x] & np.uint64(0xFFFFFFFF))
+        di = int(np.searchsorted(first, rank, side="right") - 1)
+        got = dev.pick(x, y)
+        assert got is not None and got[0] == key_as_ffi(model.hud_geometry_draws[di]["mesh_key"]) and got[1] == rank - int(first[di]), (x, y, got)
+    dev.close()
+    # through the C++ host layer: awsm_host_mesh_insert_hud + render() issue the same five passes
+    rr, hdev, _ = helpers.host_frame(sc, oracle_lut)
+    ulp = helpers.f16_ulp_distance(hdev.read_composite(), orc.composite16f)
+    assert int((ulp > 2).any(axis=-1).sum()) <= 4
+    assert (hdev.read_opaque()[covered] == 0).all()
+    rr.close()

@@ -15,7 +15,7 @@ from tests import helpers
 
 MOCK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock")
 MOCK = os.path.join(MOCK_DIR, "libmock_backend.so")
-OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips", 15: "transparent", 16: "stage_timers"}
+OPS = {1: "create", 2: "write", 3: "resize", 4: "texture", 5: "sampler", 6: "env", 7: "geometry", 8: "opaque", 9: "frame_end", 10: "lut", 11: "shard", 12: "shard_bands", 13: "pick", 14: "generate_mips", 15: "transparent", 16: "stage_timers", 17: "hud_geometry", 18: "hud_transparent"}
 
 
 @pytest.fixture(scope="module")
@@ -165,6 +165,37 @@ def test_transparent_meshes_get_transparency_geometry_and_their_own_pass(mock):
     log = log_of(mock, ctx)
     assert [op for op, _, _, _ in log if op in ("geometry", "opaque", "transparent", "frame_end")] == ["geometry", "opaque", "transparent", "frame_end"]
     assert [a for op, _, a, _ in log if op == "transparent"] == [len(want_tr)]
+    r.close()
+
+
+def test_hud_meshes_carry_both_geometries_and_get_the_two_hud_passes(mock):
+    """Mesh.hud (meshes/mesh.rs:28): both geometries (gltf/buffers/mesh.rs:37-39), is_hud in the MaterialMeshMeta (material_meta.rs:181-182), a list of
+    its own sorted back to front (renderable.rs:77-90), drawn by the HUD geometry pass between the world's geometry and opaque passes and by the HUD
+    transparent pass after the world's (render.rs:169-178,301-312)."""
+    scene = scenes.hud_scene(96, 64, tex_size=16)
+    model = helpers.build_model(scene)
+    r = H.Renderer(scene, backend_path=MOCK, lut_rgba16f=np.zeros((4, 4, 4), dtype=np.uint16))
+    ctx = r.host.device_ctx
+    mock.mock_log_clear(ctx)
+    r.render()
+    for which in (sm.BUF_VIS_GEOM_DATA, sm.BUF_TRANSPARENCY_GEOM_DATA, sm.BUF_ATTR_INDEX, sm.BUF_ATTR_DATA, sm.BUF_MATERIAL_META, sm.BUF_GEOM_META):
+        assert r.host.mirror(which) == bytes(model.mirrors()[which]), f"mirror {which} differs"
+        assert device_bytes(mock, ctx, which) == bytes(model.mirrors()[which])
+    strip = lambda ds: [{k: v for k, v in d.items() if k != "mesh_key"} for d in ds]   # noqa: E731
+    assert r.host.draw_list() == strip(model.collect_draws())
+    assert r.host.transparent_draw_list() == strip(model.collect_transparent_draws())
+    hud_g, hud_t = r.host.hud_draw_lists()
+    assert len(hud_g) == 4 and hud_g == strip(model.hud_geometry_draws) and hud_t == strip(model.hud_transparent_draws)
+    assert all(g["geom_meta_off"] == t["geom_meta_off"] for g, t in zip(hud_g, hud_t))       # the same meshes through both passes
+    mm = model.mirrors()[sm.BUF_MATERIAL_META]
+    gm = model.mirrors()[sm.BUF_GEOM_META]
+    for d in hud_g:      # geometry meta -> material meta offset -> is_hud word
+        mmo = int.from_bytes(gm[d["geom_meta_off"] + 36:d["geom_meta_off"] + 40], "little")
+        assert int.from_bytes(mm[mmo + 64:mmo + 68], "little") == 1
+    log = log_of(mock, ctx)
+    order = [op for op, _, _, _ in log if op in ("geometry", "hud_geometry", "opaque", "transparent", "hud_transparent", "frame_end")]
+    assert order == ["geometry", "hud_geometry", "opaque", "transparent", "hud_transparent", "frame_end"]
+    assert [a for op, _, a, _ in log if op in ("hud_geometry", "hud_transparent")] == [4, 4]
     r.close()
 
 
