@@ -1835,13 +1835,22 @@ AWSM_DI void fetch_s(const TexS& x, float u, float v, Tap& t) {
 }
 // MipmapMode::Gradient: textureSampleGrad by the contract of sample_slot<true> (isotropic LOD from the larger of the two gradient lengths, min / mipmap
 // filters linear, repeat addressing), on a square power-of-two pool array whose record sits in scalar registers (LeanDrawDev.gtex).
-struct TexG { const void* base; uint32_t lw, levels, layer, layers; };
+// BASE: const void* — the record sits in scalar registers (a strip inside one draw: loads are 32-bit offsets from an SGPR pair); unsigned long long — per
+// lane (a strip over several draws)
+template <typename BASE> struct TexGT { BASE base; uint32_t lw, levels, layer, layers; };
+typedef TexGT<const void*> TexG;
+typedef TexGT<unsigned long long> TexGL;
 AWSM_DI TexG decode_g(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
     return {reinterpret_cast<const void*>(((unsigned long long)(w1 & 0xFFFFu) << 32) | w0), w1 >> 24, (w1 >> 16) & 15u, w2, w3};
 }
+AWSM_DI TexGL decode_gl(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return {((unsigned long long)(w1 & 0xFFFFu) << 32) | w0, w1 >> 24, (w1 >> 16) & 15u, w2, w3};
+}
+template <typename T> AWSM_DI T gload_any(const void* base, uint32_t off) { return gload<T>(base, off); }
+template <typename T> AWSM_DI T gload_any(unsigned long long base, uint32_t off) { return gload64<T>(base, off); }
 struct Lod { uint32_t lo, hi; float f; };
 // m2 = max(|d uv / dx|^2, |d uv / dy|^2) in uv units; scaling by the extent is exact (a power of two), so rho2 has sample_slot<true>'s bits
-AWSM_DI Lod select_lod(const TexG& x, float m2) {
+template <typename BASE> AWSM_DI Lod select_lod(const TexGT<BASE>& x, float m2) {
     const float rho2 = __builtin_amdgcn_ldexpf(m2, (int)(2u * x.lw));
     float lod = 0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1e-12f));      // log2(max(rho, 1e-6))
     Lod r = {0u, 0u, 0.0f};
@@ -1853,7 +1862,7 @@ AWSM_DI Lod select_lod(const TexG& x, float m2) {
     return r;
 }
 // the bilinear footprint on level `level` (per lane) of the layer
-AWSM_DI void fetch_g(const TexG& x, uint32_t level, float u, float v, Tap& t) {
+template <typename BASE> AWSM_DI void fetch_g(const TexGT<BASE>& x, uint32_t level, float u, float v, Tap& t) {
     const uint32_t lwl = x.lw - level;                                       // log2 of the level's extent
     // first texel of the level: layers * (G(lw + 1) - G(lwl + 1)); of the layer inside it: layer << 2 lwl
     const uint32_t g_all = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (x.lw + 1u)), g_rest = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (lwl + 1u));
@@ -1864,15 +1873,15 @@ AWSM_DI void fetch_g(const TexG& x, uint32_t level, float u, float v, Tap& t) {
     const uint32_t xi = (uint32_t)(int)flx, yi = (uint32_t)(int)fly;
     const uint32_t i0 = __builtin_amdgcn_ubfe(xi, 0u, lwl), j0 = __builtin_amdgcn_ubfe(yi, 0u, lwl), j1 = __builtin_amdgcn_ubfe(yi + 1u, 0u, lwl);
     const uint32_t r0 = (first + (j0 << lwl)) << 2, r1 = (first + (j1 << lwl)) << 2, i0b = i0 << 2;
-    const u32x2a4 p0 = gload<u32x2a4>(x.base, r0 + i0b), p1 = gload<u32x2a4>(x.base, r1 + i0b);
+    const u32x2a4 p0 = gload_any<u32x2a4>(x.base, r0 + i0b), p1 = gload_any<u32x2a4>(x.base, r1 + i0b);
     t.t00 = p0.x; t.t10 = p0.y; t.t01 = p1.x; t.t11 = p1.y;
     if (__builtin_amdgcn_ubfe(xi + 1u, 0u, lwl) == 0u) {      // i1 wrapped to column 0 (always on the 1 x 1 level)
-        t.t10 = gload<uint32_t>(x.base, r0); t.t11 = gload<uint32_t>(x.base, r1);
+        t.t10 = gload_any<uint32_t>(x.base, r0); t.t11 = gload_any<uint32_t>(x.base, r1);
     }
 }
 struct TapG { Tap lo, hi; float f; };
 // both levels of a texture: the second only when some lane of the wavefront blends (f > 0) — a magnified strip fetches level 0 once
-AWSM_DI void fetch_trilinear(const TexG& x, float m2, float u, float v, TapG& t) {
+template <typename BASE> AWSM_DI void fetch_trilinear(const TexGT<BASE>& x, float m2, float u, float v, TapG& t) {
     const Lod l = select_lod(x, m2);
     t.f = l.f;
     fetch_g(x, l.lo, u, v, t.lo);
@@ -1983,7 +1992,6 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     uint32_t exists;
     lean::Tap tp0, tp1, tp2, tp3, tp4;
     lean::TapG tg0, tg1, tg2, tg3, tg4;                                   // MipmapMode::Gradient: two levels per texture
-    if (GRAD && !one_draw) todo = true;                                   // (a strip over several draws, with mipmaps: the general kernel)
     if (one_draw) {
         const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
         const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
@@ -2010,19 +2018,29 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
         base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
         emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
-    } else if (!GRAD) {
+    } else {
         const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
         const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
         const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
         const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u), L5s = gload<u32x2>(f.draw_lean, lo + 88u);
-        todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & 1u) == 0u) != 0ull;
+        todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & (GRAD ? 3u : 1u)) != (GRAD ? 3u : 1u)) != 0ull;
         const uint32_t ex = (todo || !hit) ? 0u : L0.x >> 8;
-        const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
-        if (ex & 1u) lean::fetch(x0, u, v, tp0);
-        if (ex & 2u) lean::fetch(x1, u, v, tp1);
-        if (ex & 4u) lean::fetch(x2, u, v, tp2);
-        if (ex & 8u) lean::fetch(x3, u, v, tp3);
-        if (ex & 16u) lean::fetch(x4, u, v, tp4);
+        if (GRAD) {
+            const u32x4 G0 = gload<u32x4>(f.draw_lean, lo + 96u), G1 = gload<u32x4>(f.draw_lean, lo + 112u), G2 = gload<u32x4>(f.draw_lean, lo + 128u);
+            const u32x4 G3 = gload<u32x4>(f.draw_lean, lo + 144u), G4 = gload<u32x4>(f.draw_lean, lo + 160u);
+            if (ex & 1u) lean::fetch_trilinear(lean::decode_gl(G0.x, G0.y, G0.z, G0.w), m2, u, v, tg0);
+            if (ex & 2u) lean::fetch_trilinear(lean::decode_gl(G1.x, G1.y, G1.z, G1.w), m2, u, v, tg1);
+            if (ex & 4u) lean::fetch_trilinear(lean::decode_gl(G2.x, G2.y, G2.z, G2.w), m2, u, v, tg2);
+            if (ex & 8u) lean::fetch_trilinear(lean::decode_gl(G3.x, G3.y, G3.z, G3.w), m2, u, v, tg3);
+            if (ex & 16u) lean::fetch_trilinear(lean::decode_gl(G4.x, G4.y, G4.z, G4.w), m2, u, v, tg4);
+        } else {
+            const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
+            if (ex & 1u) lean::fetch(x0, u, v, tp0);
+            if (ex & 2u) lean::fetch(x1, u, v, tp1);
+            if (ex & 4u) lean::fetch(x2, u, v, tp2);
+            if (ex & 8u) lean::fetch(x3, u, v, tp3);
+            if (ex & 16u) lean::fetch(x4, u, v, tp4);
+        }
         exists = ex;
         metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
         base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
