@@ -109,7 +109,8 @@ struct AwsmHipCtx {
     uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
     DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
     DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
-    DevBuf msaa_edge_bits;            // MSAA, lean route: one u64 per 16x4 strip (FrameDev.msaa_edge_bits)
+    DevBuf msaa_edge_bits;            // MSAA, lean route: two u64 per 16x4 strip (FrameDev.msaa_edge_bits)
+    DevBuf msaa_cells;                // MSAA, lean route: normal + depth of sample 0 per pixel (FrameDev.msaa_cells)
     DevBuf out16[kSlots], out32[kSlots];        // the opaque image (+ f32 parity tap) per frame slot: with two images two frames' opaque passes need no order between them
     DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
     uint32_t lean_grid = 0;           // persistent k_shade_lean grid (workgroups), 0 = one workgroup per block
@@ -407,7 +408,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (c->msaa == 0 || c->msaa_edge_bits.ptr) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (c->msaa == 0 || (c->msaa_edge_bits.ptr && c->msaa_cells.ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->attr_data_bytes = (uint32_t)std::min<size_t>(c->bufs[AWSM_BUF_ATTR_DATA].size, 0xFFFFFFFFu);
@@ -446,6 +447,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa_color0 = (float4*)c->msaa_color0.ptr;
     f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
     f->msaa_edge_bits = (lean_ok && c->msaa == 4) ? (unsigned long long*)c->msaa_edge_bits.ptr : nullptr;
+    f->msaa_cells = (uint2*)c->msaa_cells.ptr;
     f->hud_vis = c->hud_geometry_done ? (const unsigned long long*)c->hud[c->slot].vis.ptr : nullptr;
     f->hud_draws = (const DrawDev*)c->hud[c->slot].draws_dev.ptr; f->hud_tri_info = (const uint32_t*)c->hud[c->slot].tri_flags.ptr;
     f->hud_pass = 0;
@@ -944,7 +946,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->msaa_edge_bits); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->msaa_edge_bits); fr(c->msaa_cells); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
     for (int k = 0; k < 3 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : c->hud[k - 2 * kSlots]);
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -1022,7 +1024,8 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
         if ((rc = dev_realloc(c, c->fb[s].vis, px * samples * 8, false))) return rc;
         HIPCHK(c, hipMemsetAsync(c->fb[s].vis.ptr, 0xFF, px * samples * 8, c->stream));
     }
-    if (msaa == 4 && (rc = dev_realloc(c, c->msaa_edge_bits, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 * 8, true))) return rc;
+    if (msaa == 4 && (rc = dev_realloc(c, c->msaa_edge_bits, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 * 16, true))) return rc;
+    if (msaa == 4 && (rc = dev_realloc(c, c->msaa_cells, px * 8, false))) return rc;
     if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
     c->msaa = msaa;
     for (int sl = 0; sl < n_slots(c); sl++) if ((rc = dev_realloc(c, c->shade_todo[sl], ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4 + 1024) * 4, true))) return rc;   // one entry per wavefront of the opaque grid

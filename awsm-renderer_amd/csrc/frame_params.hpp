@@ -206,8 +206,11 @@ struct FrameDev {
     float* out_rgba32f;           // optional parity tap (may be null)
     float4* msaa_color0;          // MSAA: width*height, f32 colour of sample 0 for the pixels in msaa_edges
     uint32_t* msaa_edges;         // MSAA: [0] = count, then pixel indices (y * width + x) whose four samples are resolved
-    unsigned long long* msaa_edge_bits;   // MSAA, lean route: per 16x4-pixel strip (block * 4 + wavefront) the lanes whose pixel is an edge pixel (k_msaa_edges ->
-                                  // k_shade_lean<.., MSAA>, k_shade_todo<.., MSAA>); null = the fused general kernel (k_shade_msaa)
+    unsigned long long* msaa_edge_bits;   // MSAA, lean route: per 16x4-pixel strip (block * 4 + wavefront) TWO lane masks, written by k_shade_lean<.., MSAA> from the
+                                  // pixel's four keys: [0] an edge whatever the neighbours show, [1] the neighbours decide (k_msaa_detect); a pixel in
+                                  // neither is final.  null = the fused general kernel (k_shade_msaa)
+    uint2* msaa_cells;            // MSAA, lean route: per pixel {octahedral normal of sample 0's G-buffer texel as two f16, depth bits; 0xFFFFFFFF: background} —
+                                  // what the edge detector compares between neighbours (msaa.wgsl:42-112), left by the kernel that reconstructed it anyway
     // HUD passes (render.rs:169-178,301-312).  The HUD geometry pass rasterises the hud meshes with a depth buffer of its own (hud_depth, cleared):
     // hud_vis holds its keys (no hit = all ones), or is null when the frame has no hud geometry.  The opaque pass leaves a pixel a hud mesh covers
     // as cleared (compute.wgsl:176-179: is_hud -> return); the world's own keys and depth stay intact for the world transparent pass.

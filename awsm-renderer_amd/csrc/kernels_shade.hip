@@ -79,7 +79,7 @@ AWSM_DI GBufferTexel reconstruct_gbuffer(const FrameDev& f, uint32_t rank, int c
 // The decoded normal of the pixel's G-buffer texel alone — decode_octahedral(packed_nt.xy) — for the MSAA edge detector: the same operations on the
 // same values as reconstruct_core + pack_normal_tangent's octahedral half, without the tangent (its interpolation, normalisation, basis and atan2: a
 // third of the reconstruction) and without the tangents' 48 bytes per lane.  Bit-identical to unpack_normal_tangent(g.packed_nt).N by construction.
-AWSM_DI f3 strict_normal_of(const FrameDev& f, uint32_t rank, int cx, int cy) {
+AWSM_DI f2 strict_oct_of(const FrameDev& f, uint32_t rank, int cx, int cy) {
     TriSetup t;
     tri_rec_load(f.tri_rec + rank, t);
     const float4 n0 = f.nrm[(size_t)rank * 3], n1 = f.nrm[(size_t)rank * 3 + 1], n2 = f.nrm[(size_t)rank * 3 + 2];
@@ -90,8 +90,12 @@ AWSM_DI f3 strict_normal_of(const FrameDev& f, uint32_t rank, int cx, int cy) {
     const float b0 = e0 * inv_esum, b1 = e1 * inv_esum, b2 = e2 * inv_esum;
     const f3 Ni = {(b0 * n0.x + b1 * n1.x) + b2 * n2.x, (b0 * n0.y + b1 * n1.y) + b2 * n2.y, (b0 * n0.z + b1 * n1.z) + b2 * n2.z};
     const f2 oct = encode_octahedral(normalize(Ni));
-    return decode_octahedral(mk2(round_f16(oct.x), round_f16(oct.y)));
+    return mk2(round_f16(oct.x), round_f16(oct.y));
 }
+AWSM_DI f3 strict_normal_of(const FrameDev& f, uint32_t rank, int cx, int cy) { return decode_octahedral(strict_oct_of(f, rank, cx, cy)); }
+// An octahedral pair as two f16 in a word (its values ARE f16 values: exact both ways)
+AWSM_DI uint32_t oct_word(f2 oct) { return (uint32_t)f16_bits(oct.x) | ((uint32_t)f16_bits(oct.y) << 16); }
+AWSM_DI f2 oct_of_word(uint32_t w) { return mk2(__half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(w >> 16)))); }
 
 // Is pixel row `py` one this shard shades (row strip: [sy0, sy1); bands: the 32-row tile rows r, r + n, ...)?
 AWSM_DI bool row_owned(const FrameDev& f, int py) {
@@ -124,6 +128,30 @@ AWSM_DI bool edge_mask_depth_msaa(const m4& inv_proj, const unsigned long long k
     }
     if (count < 2u) return false;
     return fabsf(dmax - dmin) > (kEdgeMsaaDepthThreshold * fabsf((dmax + dmin) * 0.5f));
+}
+
+// The two depth predicates with the division behind a filter: a projection whose view depth is (a d + b) / (c d + e) (view_space_depth's first form) is
+// evaluated with the hardware reciprocal — numerator and denominator as the strict form computes them, so the quotient is within 2 ulps of the IEEE one —
+// and the comparison is accepted when it clears the threshold by more than 4e-6 of the larger depth (ten times that error); anything closer, and any
+// other projection, takes the strict form.  Same decisions, a fifth of the instructions (an IEEE division is ten, and the detector makes up to nine).
+AWSM_DI bool depth_only_projection(const m4& inv_proj) { return inv_proj.c[0].z == 0.0f && inv_proj.c[1].z == 0.0f && inv_proj.c[0].w == 0.0f && inv_proj.c[1].w == 0.0f; }
+AWSM_DI float view_depth_approx(const m4& inv_proj, float depth) { return (inv_proj.c[2].z * depth + inv_proj.c[3].z) * __builtin_amdgcn_rcpf(inv_proj.c[2].w * depth + inv_proj.c[3].w); }
+AWSM_DI bool edge_mask_depth_msaa_filtered(const m4& inv_proj, const unsigned long long k4[4], float pcx, float pcy, float W, float H) {
+    if (depth_only_projection(inv_proj)) {      // wave-uniform
+        uint32_t count = 0; float dmin = 1e9f, dmax = -1e9f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (k4[s] == ~0ull) continue;
+            count++;
+            const float vd = view_depth_approx(inv_proj, key_depth(k4[s]));
+            dmin = fminf(dmin, vd); dmax = fmaxf(dmax, vd);
+        }
+        if (count < 2u) return false;
+        const float lhs = fabsf(dmax - dmin), rhs = kEdgeMsaaDepthThreshold * fabsf((dmax + dmin) * 0.5f), margin = 4e-6f * fmaxf(fabsf(dmax), fabsf(dmin));
+        if (lhs > rhs + margin) return true;
+        if (lhs < rhs - margin) return false;     // (a NaN falls through to the strict form)
+    }
+    return edge_mask_depth_msaa(inv_proj, k4, pcx, pcy, W, H);
 }
 
 // ================================================================================================
@@ -178,6 +206,7 @@ AWSM_DI TBN funpack_normal_tangent(f4 rgba) {  // math.wgsl:104-116
     r.B = fnormalize(cross(r.N, r.T)) * s;
     return r;
 }
+
 }  // namespace fm
 
 // ---------------- textures.wgsl ----------------
@@ -1634,30 +1663,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
 // lean workgroup leaves free on each SIMD (32 + 80).  At 120 (114 used) this kernel waited for the whole lean kernel to drain — 228 us for an
 // empty list — and held up everything ordered behind the frame.  No occupancy step of the compiler yields a 112 budget (waves_per_eu(5): 96 and
 // a spill), so the count is checked after the build (awsm_renderer_amd/build.py).
-// MSAA: sample 0 of the pixel by the general code, routed like k_shade_lean<.., MSAA> routes its own (compute.wgsl:118-170,303-318 around the edge
-// test that k_msaa_edges already ran): hud meshes and debug views are written before the edge test and never resolved — an edge pixel of theirs
-// leaves a marker in msaa_color0 that k_shade_msaa_resolve skips.
+// MSAA: sample 0 of the pixel by the general code, stored as k_shade_lean<.., MSAA> stores its own (the strip's masks and cells are already there: the lean
+// kernel wrote them before it handed the strip over).  Hud meshes and debug views are written before the edge test and never resolved
+// (compute.wgsl:118-170,303-318) — a pixel of theirs that the masks name leaves a marker in msaa_color0 that k_shade_msaa_resolve skips.
 template <bool GRAD>
 AWSM_DI void shade_pixel_msaa0(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, uint32_t tid) {
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
     if (cx >= (int)f.width || cy >= (int)f.sy1) return;
     const size_t pv = (size_t)cy * f.width + (size_t)cx;
     const size_t p = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : pv;
-    const bool is_edge = ((f.msaa_edge_bits[(size_t)b.blk * 4u + (tid >> 6)] >> (tid & 63u)) & 1ull) != 0ull;
+    const unsigned long long* masks = f.msaa_edge_bits + (size_t)(b.blk * 4u + (tid >> 6)) * 2u;
+    const bool want_c0 = (((masks[0] | masks[1]) >> (tid & 63u)) & 1ull) != 0ull;
     const unsigned long long key = f.vis[pv * 4];
-    if (key == ~0ull) {
-        const f4 sky = skybox_color(sc, f, cx, cy);
-        if (is_edge) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w); else store_pixel(f, p, sky);
-        return;
-    }
+    if (key == ~0ull) return;                                              // background: the lean kernel stored it
     const uint32_t rank = key_rank(key);
     const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
     const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
-    if (o.kind != 0u) {
-        store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);
-        if (is_edge) f.msaa_color0[pv] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-    } else if (is_edge) f.msaa_color0[pv] = make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
-    else store_pixel(f, p, o.color);
+    store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);
+    if (want_c0) f.msaa_color0[pv] = o.kind != 0u ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)) : make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
 }
 constexpr uint32_t kTodoBlocks = 1024;
 template <bool GRAD, bool MSAA>
@@ -1894,8 +1917,14 @@ template <int BYTE> AWSM_DI float channel(const TapG& t, const Weights& wl, cons
 }
 }  // namespace lean
 
-// MSAA (x4, the reference's default AntiAliasing): the kernel shades sample 0 of every pixel — keys sit four to a pixel — and routes the colour by the
-// strip's edge mask (k_msaa_edges ran first): an edge pixel's goes to msaa_color0, where k_shade_msaa_resolve picks it up, any other to the image.
+// MSAA (x4, the reference's default AntiAliasing): the kernel shades sample 0 of every pixel — keys sit four to a pixel — and leaves what the edge
+// decision (compute.wgsl:155-170,303-318, msaa.wgsl) needs behind, so that nothing is reconstructed twice:
+//   * from the pixel's four keys, per strip two lane masks (FrameDev.msaa_edge_bits): "an edge whatever the neighbours show" (sample 0 is background and
+//     another sample is not; or the samples differ and their view depths spread, msaa.wgsl:116-146) and "the samples differ, the neighbours decide".
+//     A pixel whose four samples show ONE triangle is in neither: resolving it would average four copies of one colour (all samples a triangle covers in
+//     a pixel carry the same centre-evaluated G-buffer texel and sample 0's coordinates), i.e. give the colour back to within one f32 rounding of 3c;
+//   * per pixel the STRICT normal and the depth of sample 0 (FrameDev.msaa_cells) for k_msaa_detect's neighbour comparison;
+//   * the colour in the image, and for a pixel in either mask also as f32 in msaa_color0, where k_shade_msaa_resolve picks it up if the pixel is resolved.
 template <bool GRAD, bool MSAA>
 AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
     const uint32_t lane = tid & 63u;
@@ -1905,17 +1934,38 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     const uint32_t p = f.out_compact ? (((b.brow >> 1) << kTileShift) + ((uint32_t)cy & (uint32_t)(kTile - 1))) * f.width + (uint32_t)cx : pv;
 
     u32x2 key = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (inside) key = gload<u32x2>(f.vis, MSAA ? pv << 5 : pv << 3);     // MSAA: [pixel][4 samples], sample 0
+    bool want_c0 = false;                                                 // MSAA: the pixel may be resolved — its colour also goes to msaa_color0
+    if (!MSAA) { if (inside) key = gload<u32x2>(f.vis, pv << 3); }
+    else {
+        u32x4 ka = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, kb = ka;     // [pixel][4 samples]: {lo, hi} of samples 0, 1 and 2, 3
+        if (inside) { ka = gload<u32x4>(f.vis, pv << 5); kb = gload<u32x4>(f.vis, (pv << 5) + 16u); }
+        key = {ka.x, ka.y};
+        const bool bg0 = (ka.x & ka.y) == 0xFFFFFFFFu, bg1 = (ka.z & ka.w) == 0xFFFFFFFFu, bg2 = (kb.x & kb.y) == 0xFFFFFFFFu, bg3 = (kb.z & kb.w) == 0xFFFFFFFFu;
+        bool sure = false, test = false;
+        if (!(bg0 && bg1 && bg2 && bg3)) {                                // (lanes outside the frame hold four background keys)
+            if (bg0) sure = true;                                         // compute.wgsl:155-170: sample 0 is background, others are not
+            else if (bg1 || bg2 || bg3 || ka.z != ka.x || kb.x != ka.x || kb.z != ka.x) {      // some sample shows something else than sample 0's triangle
+                const m4 inv_proj = cload_m4(f.camera, 256u);
+                const unsigned long long k4[4] = {((unsigned long long)ka.y << 32) | ka.x, ((unsigned long long)ka.w << 32) | ka.z, ((unsigned long long)kb.y << 32) | kb.x, ((unsigned long long)kb.w << 32) | kb.z};
+                sure = edge_mask_depth_msaa_filtered(inv_proj, k4, (float)cx + 0.5f, (float)cy + 0.5f, (float)f.width, (float)f.height);      // STRICT decisions
+                test = !sure;
+            }
+        }
+        const unsigned long long m_sure = __builtin_amdgcn_ballot_w64(sure), m_test = __builtin_amdgcn_ballot_w64(test);
+        if (lane == 0u) *reinterpret_cast<ulonglong2*>(f.msaa_edge_bits + (size_t)(b.blk * 4u + (tid >> 6)) * 2u) = make_ulonglong2(m_sure, m_test);
+        want_c0 = sure || test;
+    }
     bool hud = false;                                                     // a hud mesh covers the pixel: it stays cleared (compute.wgsl:176-179)
     if (!MSAA && f.hud_vis && inside) { const u32x2 hk = gload<u32x2>(f.hud_vis, pv << 3); hud = (hk.x & hk.y) != 0xFFFFFFFFu; }
     if (hud) { store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f}); key = {0xFFFFFFFFu, 0xFFFFFFFFu}; }
     const bool hit = inside && (key.x & key.y) != 0xFFFFFFFFu;
-    bool is_edge = false;
-    if (MSAA) is_edge = ((cload<unsigned long long>(f.msaa_edge_bits, (b.blk * 4u + (tid >> 6)) * 8u) >> lane) & 1ull) != 0ull;
     if (inside && !hit && !hud) {                                         // compute.wgsl:149-153: no hit -> skybox (skybox.wgsl:1-41: the uniform colour or the texel cube)
         const f4 sky = skybox_color(sc, f, cx, cy);
-        if (MSAA && is_edge) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w);      // compute.wgsl:155-170: sample 0 is background, others are not
-        else store_pixel(f, p, sky);
+        store_pixel(f, p, sky);
+        if (MSAA) {
+            f.msaa_cells[pv] = make_uint2(0u, 0xFFFFFFFFu);
+            if (want_c0) f.msaa_color0[pv] = make_float4(sky.x, sky.y, sky.z, sky.w);
+        }
     }
     unsigned long long rem = __builtin_amdgcn_ballot_w64(hit);
     if (rem == 0ull) return;                                              // wave-uniform
@@ -1962,6 +2012,8 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     TriSetup t;
     tri_rec_unpack(raw, t);
     const GBufferTexel g = reconstruct_core<GRAD>(t, n0, n1, n2, t0, t1, t2, cx, cy);
+    // the detector's operands, before the wavefront may leave for the general kernel: the cells are this kernel's
+    if (MSAA && hit) f.msaa_cells[pv] = make_uint2(oct_word(mk2(g.packed_nt.x, g.packed_nt.y)), key.y);
     const float bz = (1.0f - g.bx) - g.by;                               // compute.wgsl:185-186
     const float u = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.z), __uint_as_float(ts1.x), __uint_as_float(ts1.z));
     const float v = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.w), __uint_as_float(ts1.y), __uint_as_float(ts1.w));
@@ -2179,8 +2231,8 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         lean::direct(lit, light_dir, radiance, color);
     }
     asm volatile("; MARK store");
-    if (MSAA && is_edge) f.msaa_color0[pv] = make_float4(color.x, color.y, color.z, 1.0f);
-    else store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
+    store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
+    if (MSAA && want_c0) f.msaa_color0[pv] = make_float4(color.x, color.y, color.z, 1.0f);
 }
 // k_shade_lean<false>: a wavefront per 16x4-pixel strip.  k_shade_lean<true>: a persistent grid (lean_grid workgroups; workgroup w
 // runs on XCD w & 7, as the hardware deals them) whose wavefronts take strips from counters until the XCD's share is used up —
@@ -2270,11 +2322,129 @@ AWSM_DI void publish_cell(NeighbourCell* cells, int lx, int ly, const FrameDev& 
     cells[(ly + 1) * 18 + (lx + 1)] = c;
 }
 
-// EDGES_ONLY (k_msaa_edges, first kernel of the lean MSAA route): phase 1 and the edge detector alone — nothing is shaded or stored but the block's
-// edge list and, per 16x4 strip, the mask of its edge pixels (FrameDev.msaa_edge_bits), which k_shade_lean<.., MSAA> / k_shade_todo<.., MSAA> route their
-// sample-0 colours by: an edge pixel's goes to msaa_color0 for k_shade_msaa_resolve, any other straight to the image.  The detector is STRICT arithmetic
-// on keys, normals and depths: it does not need the colours.
-template <bool GRAD, bool EDGES_ONLY>
+// msaa.wgsl:42-112: the pixel against its four neighbours (sample 0 each) — a background neighbour, a normal that turns away, a view depth that jumps.
+// STRICT.  `cell(ox, oy)` hands out the neighbour's NeighbourCell.
+template <typename CellAt>
+AWSM_DI bool edge_by_neighbours(const m4& inv_proj, f3 center_normal, float center_depth, float pcx, float pcy, float W, float H, CellAt cell) {
+    bool is_edge = false, center_loaded = false;
+    float view_depth_c = 0.0f, depth_threshold = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ox = i == 0 ? 1 : (i == 1 ? -1 : 0), oy = i == 2 ? 1 : (i == 3 ? -1 : 0);
+        if (is_edge) continue;
+        const NeighbourCell nb = cell(ox, oy);
+        if (nb.state == 0u) continue;
+        if (nb.state == 1u) { is_edge = true; continue; }          // neighbour is background
+        if (dot(center_normal, mk3(nb.nx, nb.ny, nb.nz)) < kEdgeNormalThreshold) { is_edge = true; continue; }
+        if (!center_loaded) {
+            view_depth_c = view_space_depth(inv_proj, center_depth, pcx, pcy, W, H);
+            depth_threshold = kEdgeDepthThreshold * fabsf(view_depth_c);
+            center_loaded = true;
+        }
+        const float nvd = view_space_depth(inv_proj, __uint_as_float(nb.depth_bits), pcx + (float)ox, pcy + (float)oy, W, H);
+        if (fabsf(view_depth_c - nvd) > depth_threshold) is_edge = true;
+    }
+    return is_edge;
+}
+
+// Edge detection of the lean MSAA route (k_msaa_detect, after k_shade_lean<.., MSAA> and k_shade_todo<.., MSAA>): the block's
+// edge list from the two masks per strip and the 8-byte cells — {octahedral normal as two f16 (the G-buffer texel's own bits), depth bits; 0xFFFFFFFF = background} — the lean
+// kernel left.  Everything heavy, the reconstruction, happened where it had to happen anyway; what is left is latency, so the pixel's cell and its four
+// neighbours' are requested together with the masks, before anything is known.  Decisions are msaa.wgsl:42-112's, STRICT, behind filters: the normals are
+// decoded with rsq and compared with a margin of 1e-5 around the threshold (the fast decode is within 1e-6), the depths as depth_only_projection's
+// comment says; whatever lands inside a margin is redone with the strict operations.  A neighbour in a halo row (the row above / below a row strip,
+// another rank's band) has no cell: its normal is reconstructed from its key, as k_shade_msaa does for its ring.
+AWSM_DI uint2 halo_cell(const FrameDev& f, int px, int py) {
+    unsigned long long k;
+    if (f.band_n > 1u && (((uint32_t)py >> kTileShift) % f.band_n) != f.band_r) {
+        const uint32_t ty = (uint32_t)py >> kTileShift, which = ((uint32_t)py & (uint32_t)(kTile - 1)) == 0u ? 0u : 1u;
+        k = f.msaa_halo ? f.msaa_halo[((((size_t)(ty % f.band_n) * f.halo_bands + ty / f.band_n) * 2u + which) * f.width) + (size_t)px] : ~0ull;
+    } else k = f.vis[((size_t)py * f.width + (size_t)px) * 4];
+    if (k == ~0ull) return make_uint2(0u, 0xFFFFFFFFu);
+    return make_uint2(oct_word(strict_oct_of(f, key_rank(k), px, py)), (uint32_t)(k >> 32));
+}
+// One test pixel of the block (slot = ly * 16 + lx): msaa.wgsl:42-112 against the cells.
+AWSM_DI bool detect_pixel(const FrameDev& f, const ShadeBlock& b, uint32_t slot, const m4& inv_proj, bool fastp) {
+    const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
+    // state 0: outside the frame / the rasterised rows (contributes nothing), 1: a cell, 2: a halo row (reconstructed on demand)
+    uint2 nb[4];
+    uint32_t state[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int px = cx + (i == 0 ? 1 : (i == 1 ? -1 : 0)), py = cy + (i == 2 ? 1 : (i == 3 ? -1 : 0));
+        nb[i] = make_uint2(0u, 0xFFFFFFFFu); state[i] = 0u;
+        if (px >= 0 && px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) {
+            if (i < 2 || row_owned(f, py)) { nb[i] = f.msaa_cells[(size_t)py * f.width + (size_t)px]; state[i] = 1u; }
+            else state[i] = 2u;
+        }
+    }
+    const uint2 me = f.msaa_cells[(size_t)cy * f.width + (size_t)cx];
+    const float W = (float)f.width, H = (float)f.height, pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
+    const f2 oct_c = oct_of_word(me.x);
+    const f3 nc = fm::fdecode_octahedral(oct_c);
+    const float dc = __uint_as_float(me.y);
+    const float vdc = fastp ? view_depth_approx(inv_proj, dc) : view_space_depth(inv_proj, dc, pcx, pcy, W, H);
+    bool is_edge = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ox = i == 0 ? 1 : (i == 1 ? -1 : 0), oy = i == 2 ? 1 : (i == 3 ? -1 : 0);
+        if (is_edge || state[i] == 0u) continue;
+        uint2 c = nb[i];
+        if (state[i] == 2u) c = halo_cell(f, cx + ox, cy + oy);
+        if (c.y == 0xFFFFFFFFu) { is_edge = true; continue; }          // neighbour is background
+        const f2 oct_n = oct_of_word(c.x);
+        const f3 nn = fm::fdecode_octahedral(oct_n);
+        const float d = (nc.x * nn.x + nc.y * nn.y) + nc.z * nn.z;
+        bool turned = d < kEdgeNormalThreshold - 1e-5f;
+        if (!turned && !(d > kEdgeNormalThreshold + 1e-5f)) turned = dot(decode_octahedral(oct_c), decode_octahedral(oct_n)) < kEdgeNormalThreshold;
+        if (turned) { is_edge = true; continue; }
+        const float dn = __uint_as_float(c.y);
+        bool decided = false, jump = false;
+        if (fastp) {
+            const float vdn = view_depth_approx(inv_proj, dn);
+            const float lhs = fabsf(vdc - vdn), rhs = kEdgeDepthThreshold * fabsf(vdc), margin = 4e-6f * fmaxf(fabsf(vdc), fabsf(vdn));
+            if (lhs > rhs + margin) { decided = true; jump = true; }
+            else if (lhs < rhs - margin) decided = true;
+        }
+        if (!decided) {
+            const float svc = view_space_depth(inv_proj, dc, pcx, pcy, W, H);
+            jump = fabsf(svc - view_space_depth(inv_proj, dn, pcx + (float)ox, pcy + (float)oy, W, H)) > kEdgeDepthThreshold * fabsf(svc);
+        }
+        if (jump) is_edge = true;
+    }
+    return is_edge;
+}
+// The block's edge list (one-byte pixel slots, in LDS) from the strips' masks, by ONE wavefront: the sure pixels as they are, the test pixels compacted
+// first — a wavefront per strip would run the test with a quarter of its lanes — then tested 64 at a time.  Returns the number of edge pixels.
+AWSM_DI uint32_t detect_edges(const FrameDev& f, const ShadeBlock& b, uint8_t* eslot, uint8_t* tslot, uint32_t lane) {
+    const ulonglong2* masks = reinterpret_cast<const ulonglong2*>(f.msaa_edge_bits) + (size_t)b.blk * 4u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t n = 0u, nt = 0u;
+#pragma unroll
+    for (uint32_t sidx = 0; sidx < 4u; sidx++) {
+        const ulonglong2 m = masks[sidx];          // wave-uniform
+        if ((m.x >> lane) & 1ull) eslot[n + (uint32_t)__popcll(m.x & below)] = (uint8_t)(sidx * 64u + lane);
+        if ((m.y >> lane) & 1ull) tslot[nt + (uint32_t)__popcll(m.y & below)] = (uint8_t)(sidx * 64u + lane);
+        n += (uint32_t)__popcll(m.x); nt += (uint32_t)__popcll(m.y);
+    }
+    if (nt == 0u) return n;                        // wave-uniform
+    __syncthreads();                               // (one wavefront: orders the LDS writes before the reads)
+    const m4 inv_proj = cload_m4(f.camera, 256u);
+    const bool fastp = depth_only_projection(inv_proj);
+    for (uint32_t i0 = 0; i0 < nt; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t slot = i < nt ? tslot[i] : 0u;
+        const bool e = i < nt && detect_pixel(f, b, slot, inv_proj, fastp);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
+        if (e) eslot[n + (uint32_t)__popcll(m & below)] = (uint8_t)slot;
+        n += (uint32_t)__popcll(m);
+    }
+    return n;
+}
+
+// k_shade_msaa: the general route's MSAA kernel — sample 0 of every pixel by the general code and the whole edge decision in one kernel (normals of the
+// block + a halo ring in LDS).
+template <bool GRAD>
 __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ NeighbourCell cells[18 * 18];
     __shared__ uint32_t n_edges;
@@ -2298,12 +2468,8 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
             k4[0] = ka.x; k4[1] = ka.y; k4[2] = kb.x; k4[3] = kb.y;
             c.state = 1u;
             if (k4[0] != ~0ull) {
-                f3 n;
-                if (EDGES_ONLY) n = strict_normal_of(f, key_rank(k4[0]), cx, cy);     // the detector needs the normal only
-                else {
-                    g0 = reconstruct_gbuffer<GRAD>(f, key_rank(k4[0]), cx, cy);   // STRICT
-                    n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
-                }
+                g0 = reconstruct_gbuffer<GRAD>(f, key_rank(k4[0]), cx, cy);   // STRICT
+                const f3 n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
                 c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k4[0] >> 32); c.state = 2u;
             }
         }
@@ -2324,42 +2490,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
     const size_t po = f.out_compact ? (size_t)(((b.brow >> 1) << kTileShift) + (uint32_t)(cy & (kTile - 1))) * f.width + (size_t)cx : p;   // output pixel (compact band layout)
     uint8_t* edge_rec = reinterpret_cast<uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     bool is_edge = false;
-    if (inside && EDGES_ONLY) {
-        const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
-        if (f.has_opaque && any_hit) {
-            if (k4[0] == ~0ull) is_edge = true;                             // compute.wgsl:155-170: sample 0 is background, others are not
-            else {
-                const m4 inv_proj = load_m4(reinterpret_cast<const float*>(f.camera + 256));
-                const float W = (float)f.width, H = (float)f.height, pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
-                is_edge = edge_mask_depth_msaa(inv_proj, k4, pcx, pcy, W, H);
-                if (!is_edge) {   // msaa.wgsl:42-112
-                    const NeighbourCell me = cells[(ly + 1) * 18 + (lx + 1)];
-                    const f3 center_normal = {me.nx, me.ny, me.nz};
-                    bool center_loaded = false; float view_depth_c = 0.0f, depth_threshold = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int ox = i == 0 ? 1 : (i == 1 ? -1 : 0), oy = i == 2 ? 1 : (i == 3 ? -1 : 0);
-                        const NeighbourCell nb = cells[(ly + 1 + oy) * 18 + (lx + 1 + ox)];
-                        if (is_edge || nb.state == 0u) continue;
-                        if (nb.state == 1u) { is_edge = true; continue; }          // neighbour is background
-                        if (dot(center_normal, mk3(nb.nx, nb.ny, nb.nz)) < kEdgeNormalThreshold) { is_edge = true; continue; }
-                        if (!center_loaded) {
-                            view_depth_c = view_space_depth(inv_proj, key_depth(k4[0]), pcx, pcy, W, H);
-                            depth_threshold = kEdgeDepthThreshold * fabsf(view_depth_c);
-                            center_loaded = true;
-                        }
-                        const float nvd = view_space_depth(inv_proj, __uint_as_float(nb.depth_bits), pcx + (float)ox, pcy + (float)oy, W, H);
-                        if (fabsf(view_depth_c - nvd) > depth_threshold) is_edge = true;
-                    }
-                }
-            }
-        }
-    }
-    if (EDGES_ONLY && f.msaa_edge_bits) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(is_edge);
-        if ((tid & 63u) == 0u) f.msaa_edge_bits[(size_t)b.blk * 4u + (tid >> 6)] = m;
-    }
-    if (inside && !EDGES_ONLY) {
+    if (inside) {
         const f4 sky = skybox_color(sc, f, cx, cy);
         const bool any_hit = (k4[0] & k4[1] & k4[2] & k4[3]) != ~0ull;
         if (!f.has_opaque || !any_hit) {
@@ -2376,25 +2507,10 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
                 const m4 inv_proj = load_m4(reinterpret_cast<const float*>(f.camera + 256));
                 const float W = (float)f.width, H = (float)f.height, pcx = (float)cx + 0.5f, pcy = (float)cy + 0.5f;
                 is_edge = edge_mask_depth_msaa(inv_proj, k4, pcx, pcy, W, H);
-                if (!is_edge) {   // msaa.wgsl:42-112
+                if (!is_edge) {
                     const NeighbourCell me = cells[(ly + 1) * 18 + (lx + 1)];
-                    const f3 center_normal = {me.nx, me.ny, me.nz};
-                    bool center_loaded = false; float view_depth_c = 0.0f, depth_threshold = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int ox = i == 0 ? 1 : (i == 1 ? -1 : 0), oy = i == 2 ? 1 : (i == 3 ? -1 : 0);
-                        const NeighbourCell nb = cells[(ly + 1 + oy) * 18 + (lx + 1 + ox)];
-                        if (is_edge || nb.state == 0u) continue;
-                        if (nb.state == 1u) { is_edge = true; continue; }          // neighbour is background
-                        if (dot(center_normal, mk3(nb.nx, nb.ny, nb.nz)) < kEdgeNormalThreshold) { is_edge = true; continue; }
-                        if (!center_loaded) {
-                            view_depth_c = view_space_depth(inv_proj, key_depth(k4[0]), pcx, pcy, W, H);
-                            depth_threshold = kEdgeDepthThreshold * fabsf(view_depth_c);
-                            center_loaded = true;
-                        }
-                        const float nvd = view_space_depth(inv_proj, __uint_as_float(nb.depth_bits), pcx + (float)ox, pcy + (float)oy, W, H);
-                        if (fabsf(view_depth_c - nvd) > depth_threshold) is_edge = true;
-                    }
+                    is_edge = edge_by_neighbours(inv_proj, mk3(me.nx, me.ny, me.nz), key_depth(k4[0]), pcx, pcy, W, H,
+                                                 [&](int ox, int oy) { return cells[(ly + 1 + oy) * 18 + (lx + 1 + ox)]; });
                 }
                 if (is_edge) f.msaa_color0[p] = make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
                 else store_pixel(f, po, o.color);
@@ -2411,6 +2527,21 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 // triangle covers in a pixel carry the same G-buffer texel and the same standard coordinates (sample 0's depth), hence the same colour — then every
 // thread shades ONE item (the shading call sits in the code once, and a block with 30 edge pixels keeps 40 lanes busy for one shading instead of 30
 // lanes for three in a row), then the threads of the edge pixels gather their four colours.  Up to 768 items per block, in LDS.
+// The lean MSAA route's edge detector: one wavefront per block writes the block's edge list (count + one-byte pixel slots) for k_shade_msaa_resolve.
+// (Not the first phase of that kernel: with it inside, the register allocation of the shading code behind it came out at 155 instead of 127.)
+__global__ __launch_bounds__(64) void k_msaa_detect(FrameDev f) {
+    __shared__ __attribute__((aligned(16))) uint8_t eslot[256];
+    __shared__ uint8_t tslot[256];
+    ShadeBlock b;
+    if (frame_poisoned(f) || !shade_block(f, b)) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = detect_edges(f, b, eslot, tslot, lane);
+    __syncthreads();
+    uint32_t* edge_rec = f.msaa_edges + (size_t)b.blk * (kEdgeRecBytes / 4u);
+    if (lane == 0u) edge_rec[0] = n;
+    for (uint32_t w = lane; w * 4u < n; w += 64u) edge_rec[1u + w] = reinterpret_cast<const uint32_t*>(eslot)[w];      // (slots beyond n in the last word: never read)
+}
+
 template <bool GRAD>
 __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
     // One WAVEFRONT per block: the shading is a long dependent chain for a few dozen lanes, and what bounds the kernel is how many blocks are in flight —
@@ -2423,8 +2554,8 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
     if (frame_poisoned(f) || !shade_block(f, b)) return;
     const uint8_t* edge_rec = reinterpret_cast<const uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
     const uint32_t n = *reinterpret_cast<const uint32_t*>(edge_rec);
-    if (n == 0u) return;                                                   // wave-uniform
     const uint32_t lane = threadIdx.x;
+    if (n == 0u) return;                                                   // wave-uniform
     if (lane == 0u) n_items = 0u;
     __syncthreads();
     // ---- phase 1: every edge pixel -> its items ----
@@ -2639,31 +2770,34 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
         const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
         if (msaa) {
-            if (grad) { hipLaunchKernelGGL((awsm::k_shade_msaa<true, true>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL((awsm::k_shade_lean<false, true, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f); }
-            else { hipLaunchKernelGGL((awsm::k_shade_msaa<false, true>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL((awsm::k_shade_lean<false, false, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f); }
+            if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+            else hipLaunchKernelGGL((awsm::k_shade_lean<false, false, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
         } else if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
         else if (f->lean_grid && f->lean_next) hipLaunchKernelGGL((awsm::k_shade_lean<true, false, false>), dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
         else hipLaunchKernelGGL((awsm::k_shade_lean<false, false, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
         return;
     }
     if (msaa) {
-        if (grad) { hipLaunchKernelGGL((awsm::k_shade_msaa<true, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f); }
-        else { hipLaunchKernelGGL((awsm::k_shade_msaa<false, false>), dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f); }
+        if (grad) { hipLaunchKernelGGL(awsm::k_shade_msaa<true>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f); }
+        else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f); }
     } else if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
     else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
 }
 // second half of the lean route; returns 0 when the frame did not take it
 extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
-    return (bx_n * by_n) && (f->msaa != 4u || f->msaa_edge_bits) && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
+    return (bx_n * by_n) && (f->msaa != 4u || (f->msaa_edge_bits && f->msaa_cells)) && f->draw_lean && f->tri_shade && f->shade_todo && f->has_opaque && f->n_draws;
 }
 extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     if (!awsm_shade_is_lean(f)) return 0;
     if (f->msaa == 4u) {      // ... and the edge pixels' remaining samples, once every sample-0 colour is in place
         const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
         const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;
-        if (f->mipmap) { hipLaunchKernelGGL((awsm::k_shade_todo<true, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f); }
-        else { hipLaunchKernelGGL((awsm::k_shade_todo<false, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f); }
+        if (f->mipmap) hipLaunchKernelGGL((awsm::k_shade_todo<true, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_shade_todo<false, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+        hipLaunchKernelGGL(awsm::k_msaa_detect, dim3(nb), dim3(64), 0, s, *f);
+        if (f->mipmap) hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f);
+        else hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f);
         return 1;
     }
     if (f->mipmap) hipLaunchKernelGGL((awsm::k_shade_todo<true, false>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
