@@ -108,9 +108,10 @@ struct AwsmHipCtx {
     uint32_t band_n = 1, band_r = 0, band_compact = 0;   // shard bands (awsm_hip_set_shard_bands)
     uint32_t msaa = 0;           // 0 or 4 (awsm_hip_resize)
     DevBuf mip_kinds;                 // scratch for awsm_hip_texture_array_generate_mips
-    DevBuf msaa_color0, msaa_edges;   // MSAA: f32 colour of sample 0 per pixel; [count, pixel indices...] of edge pixels
-    DevBuf msaa_edge_bits;            // MSAA, lean route: two u64 per 16x4 strip (FrameDev.msaa_edge_bits)
-    DevBuf msaa_cells;                // MSAA, lean route: normal + depth of sample 0 per pixel (FrameDev.msaa_cells)
+    // MSAA scratch, per frame slot (frame i + 1's k_shade_lean may run beside frame i's k_msaa_detect / k_shade_msaa_resolve):
+    DevBuf msaa_color0[kSlots], msaa_edges[kSlots];   // f32 colour of sample 0 per pixel; per block [count, one-byte pixel slots...] of edge pixels
+    DevBuf msaa_edge_bits[kSlots];    // lean route: two u64 per 16x4 strip (FrameDev.msaa_edge_bits)
+    DevBuf msaa_cells[kSlots];        // lean route: normal + depth of sample 0 per pixel (FrameDev.msaa_cells)
     DevBuf out16[kSlots], out32[kSlots];        // the opaque image (+ f32 parity tap) per frame slot: with two images two frames' opaque passes need no order between them
     DevBuf digest;                    // 2 x u64 (awsm_hip_visibility_digest)
     uint32_t lean_grid = 0;           // persistent k_shade_lean grid (workgroups), 0 = one workgroup per block
@@ -208,7 +209,7 @@ inline hipError_t mark_shade_done(AwsmHipCtx* c, hipStream_t ss) {
     c->shade_pending[c->slot] = true; c->shade_recorded[c->slot] = true;
     return e;
 }
-// a shade stream goes on once the OTHER slot's passes have finished (shared MSAA scratch, one bound image for both frames, the composite) —
+// a shade stream goes on once the OTHER slot's passes have finished (one bound image for both frames, bound halo keys, the composite) —
 // or, main_kernel_only, once its k_shade_lean has (its k_shade_todo may still run: per-slot images and lists)
 inline hipError_t wait_prev_slot(AwsmHipCtx* c, hipStream_t ss, bool main_kernel_only = false) {
     const int p = prev_slot(c);
@@ -408,7 +409,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (c->msaa == 0 || (c->msaa_edge_bits.ptr && c->msaa_cells.ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (c->msaa == 0 || (c->msaa_edge_bits[c->slot].ptr && c->msaa_cells[c->slot].ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->attr_data_bytes = (uint32_t)std::min<size_t>(c->bufs[AWSM_BUF_ATTR_DATA].size, 0xFFFFFFFFu);
@@ -444,10 +445,10 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     memcpy(f->pix2view, FB(c).pix2view, sizeof f->pix2view); memcpy(f->view_rot, FB(c).view_rot, sizeof f->view_rot); memcpy(f->cam_pos, FB(c).cam_pos, sizeof f->cam_pos);
     memcpy(f->ortho_view_dir, FB(c).ortho_view_dir, sizeof f->ortho_view_dir); f->cam_ortho = FB(c).cam_ortho;
     f->msaa = c->msaa;
-    f->msaa_color0 = (float4*)c->msaa_color0.ptr;
-    f->msaa_edges = (uint32_t*)c->msaa_edges.ptr;
-    f->msaa_edge_bits = (lean_ok && c->msaa == 4) ? (unsigned long long*)c->msaa_edge_bits.ptr : nullptr;
-    f->msaa_cells = (uint2*)c->msaa_cells.ptr;
+    f->msaa_color0 = (float4*)c->msaa_color0[c->slot].ptr;
+    f->msaa_edges = (uint32_t*)c->msaa_edges[c->slot].ptr;
+    f->msaa_edge_bits = (lean_ok && c->msaa == 4) ? (unsigned long long*)c->msaa_edge_bits[c->slot].ptr : nullptr;
+    f->msaa_cells = (uint2*)c->msaa_cells[c->slot].ptr;
     f->hud_vis = c->hud_geometry_done ? (const unsigned long long*)c->hud[c->slot].vis.ptr : nullptr;
     f->hud_draws = (const DrawDev*)c->hud[c->slot].draws_dev.ptr; f->hud_tri_info = (const uint32_t*)c->hud[c->slot].tri_flags.ptr;
     f->hud_pass = 0;
@@ -597,8 +598,8 @@ int enqueue_opaque(AwsmHipCtx* c) {
             HIPCHK(c, hipEventRecord(c->ev_geom_done[c->slot], c->stream));
             HIPCHK(c, hipStreamWaitEvent(ss, c->ev_geom_done[c->slot], 0));
         }
-        // ... and behind the previous frame's opaque pass on the other slot's shade stream.  Where the two share something — the MSAA scratch
-        // (per context), one bound output image for both — behind all of it.  Otherwise (the library's own images, or a caller alternating
+        // ... and behind the previous frame's opaque pass on the other slot's shade stream.  Where the two share something — one bound output image
+        // for both, the halo keys a caller bound for MSAA + bands — behind all of it.  Otherwise (the library's own images, or a caller alternating
         // between two bound ones: images, per-draw records and todo lists are per slot) behind its main kernel only: frame i + 1's
         // k_shade_lean starts when frame i's has ended, beside frame i's k_shade_todo.  Not earlier, although nothing shared would forbid it:
         // with two frame slots the geometry pass of frame i + 2 waits for frame i's shading, and two opaque passes running into each other
@@ -607,7 +608,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
         const uint8_t* lo = (const uint8_t*)c->bound_out; const uint8_t* hi = lo ? lo + c->bound_out_bytes : nullptr;
         const int p = prev_slot(c);
         const bool same_image = lo && c->slot_out_lo[p] && lo < c->slot_out_hi[p] && c->slot_out_lo[p] < hi;
-        if (c->shade_recorded[p]) HIPCHK(c, wait_prev_slot(c, ss, !(c->msaa != 0 || same_image)));
+        if (c->shade_recorded[p]) HIPCHK(c, wait_prev_slot(c, ss, !(same_image || (c->msaa != 0 && c->msaa_halo))));
         c->slot_out_lo[c->slot] = lo; c->slot_out_hi[c->slot] = hi;
     }
     ht.mark("opaque: hand-off launches");
@@ -946,7 +947,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); fr(c->msaa_color0); fr(c->msaa_edges); fr(c->msaa_edge_bits); fr(c->msaa_cells); fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); for (int sl = 0; sl < kSlots; sl++) { fr(c->msaa_color0[sl]); fr(c->msaa_edges[sl]); fr(c->msaa_edge_bits[sl]); fr(c->msaa_cells[sl]); } fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
     for (int k = 0; k < 3 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : c->hud[k - 2 * kSlots]);
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -1024,9 +1025,13 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
         if ((rc = dev_realloc(c, c->fb[s].vis, px * samples * 8, false))) return rc;
         HIPCHK(c, hipMemsetAsync(c->fb[s].vis.ptr, 0xFF, px * samples * 8, c->stream));
     }
-    if (msaa == 4 && (rc = dev_realloc(c, c->msaa_edge_bits, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 * 16, true))) return rc;
-    if (msaa == 4 && (rc = dev_realloc(c, c->msaa_cells, px * 8, false))) return rc;
-    if (msaa == 4) { if ((rc = dev_realloc(c, c->msaa_color0, px * 16, false))) return rc; if ((rc = dev_realloc(c, c->msaa_edges, (size_t)((width + 15) / 16) * ((height + 15) / 16) * 260, false))) return rc; }   // per 16x16 block: count + 256 one-byte slots
+    if (msaa == 4) for (int sl = 0; sl < n_slots(c); sl++) {
+        const size_t blocks = (size_t)((width + 15) / 16) * ((height + 15) / 16);
+        if ((rc = dev_realloc(c, c->msaa_edge_bits[sl], blocks * 4 * 16, true))) return rc;
+        if ((rc = dev_realloc(c, c->msaa_cells[sl], px * 8, false))) return rc;
+        if ((rc = dev_realloc(c, c->msaa_color0[sl], px * 16, false))) return rc;
+        if ((rc = dev_realloc(c, c->msaa_edges[sl], blocks * 260, false))) return rc;      // per 16x16 block: count + 256 one-byte slots
+    }
     c->msaa = msaa;
     for (int sl = 0; sl < n_slots(c); sl++) if ((rc = dev_realloc(c, c->shade_todo[sl], ((size_t)((width + 15) / 16) * ((height + 15) / 16) * 4 + 4 + 1024) * 4, true))) return rc;   // one entry per wavefront of the opaque grid
     for (int sl = 0; sl < n_slots(c); sl++) {

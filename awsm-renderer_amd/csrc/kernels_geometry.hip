@@ -765,10 +765,23 @@ AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, i
         }
 }
 
+#ifndef AWSM_RASTER_BATCH4
+#define AWSM_RASTER_BATCH4 96u
+#endif
+#ifndef AWSM_RASTER_BATCH1
+#define AWSM_RASTER_BATCH1 128u
+#endif
+#ifndef AWSM_RASTER_WAVES1
+#define AWSM_RASTER_WAVES1 7
+#endif
 template <int S>
-__global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 : AWSM_RASTER_WAVES1))) void k_raster_tile(FrameDev f) {
     __shared__ unsigned long long keys[kTile * kTile * S];   // 8 KB, or 32 KB with 4 samples per pixel: [pixel][sample]
-    __shared__ WorkTri work[256];      // mid triangles from the front, big triangles from the back
+    // Triangles per batch: fewer than threads, for occupancy — most tiles hold fewer than a hundred anyway.  Four samples per pixel: 96, so that keys +
+    // list fit a CU's LDS four times instead of three (32 KB + 6.75 KB against 32 KB + 18 KB; k_raster_tile<4> 281 -> 240 us at 4K).  One sample:
+    // 128 and a 72-register budget, seven workgroups per CU instead of six (75 -> 72 us; an eighth needs 64 registers and spills).
+    constexpr uint32_t kBatch = S == 4 ? (AWSM_RASTER_BATCH4 ? AWSM_RASTER_BATCH4 : 256u) : AWSM_RASTER_BATCH1;
+    __shared__ WorkTri work[kBatch];   // mid triangles from the front, big triangles from the back
     __shared__ uint32_t n_mid, n_big, next_mid, next_big;
 
     // Heaviest tiles first (tile_order, k_bin_scan).  Consecutive ids go to different XCDs (blockIdx & 7), which also
@@ -799,12 +812,12 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
     const uint32_t count = split ? min((slice + 1u) * kRasterSlice, count_fit) : count_fit;
     const int lane = tid & 63, wave = tid >> 6;
 
-    for (uint32_t base = first; base < count; base += 256u) {
+    for (uint32_t base = first; base < count; base += kBatch) {
         if (tid == 0) { n_mid = 0; n_big = 0; next_mid = 16u; next_big = 4u; }
         __syncthreads();
         const uint32_t idx = base + tid;
         if (base == first) AWSM_STAMP_AT(f, 3, 1);
-        if (idx < count) {
+        if (idx < count && tid < kBatch) {
             const uint32_t r = f.bin_list[off + idx];
             TriSetup t;
             if (tri_rec_load(f.tri_rec + r, t)) {       // setup done once per frame by k_bin<count>
@@ -816,7 +829,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
                         for (int py = y0; py <= y1; py++)
                             for (int px = x0; px <= x1; px++) raster_pixel<S>(keys, t, tpx, tpy, px - tpx, py - tpy, r);
                     } else {
-                        const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : 255u - atomicAdd(&n_big, 1u);
+                        const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : (kBatch - 1u) - atomicAdd(&n_big, 1u);
                         const uint32_t bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
                         if (S == 1 && area <= 256 && t.small) {
                             WorkSmall& g = reinterpret_cast<WorkSmall&>(work[slot]);
@@ -865,7 +878,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(FrameDev f) {
             }
         }
         for (uint32_t j = wave; j < nb; ) {   // big: one wavefront per triangle, 8x8 pixel blocks
-            const WorkTri& g = work[255u - j];
+            const WorkTri& g = work[(kBatch - 1u) - j];
             TriSetup t;
             load_work_tri(g, t);
             const uint32_t bb = g.bbox, r = g.rank;
