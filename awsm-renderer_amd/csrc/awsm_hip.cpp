@@ -50,7 +50,10 @@ namespace {
 
 // Frame slots of the overlap mode: frame i's opaque pass reads slot i % kSlots while the geometry pass of frame i + 1 fills the next.  (Three
 // slots — the geometry pass of frame i + 2 no longer waiting for frame i's opaque pass — measured no different, and cost a fifth stream.)
-constexpr int kSlots = 2;
+#ifndef AWSM_SLOTS
+#define AWSM_SLOTS 2
+#endif
+constexpr int kSlots = AWSM_SLOTS;
 constexpr int kLeanWgsPerCu = 0;   // measured: the one-wavefront-per-strip grid wins once the geometry kernels fit beside it
 struct DevBuf {
     void* ptr = nullptr;
