@@ -561,6 +561,7 @@ int enqueue_opaque(AwsmHipCtx* c) {
     fill_frame(c, &f);
     f.has_opaque = c->last_opaque.has_opaque;
     f.mipmap = c->last_opaque.mipmap;
+    f.aniso = (c->flags & AWSM_CFG_ANISOTROPIC) ? 1u : 0u;
     if (c->bound_out) {
         if (c->out_rows_mode) {   // a row strip's own buffer: rows [first_row, first_row + bytes / (width * 8))
             if (f.out_compact || f.sy0 < c->out_first_row || (size_t)(f.sy1 - c->out_first_row) * c->width * 8 > c->bound_out_bytes)
@@ -671,6 +672,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->out_rgba32f = (float*)c->comp32.ptr;
     f->has_opaque = c->last_opaque.has_opaque;
     f->mipmap = c->last_opaque.mipmap;
+    f->aniso = (c->flags & AWSM_CFG_ANISOTROPIC) ? 1u : 0u;
     if (c->hud_transparent) {      // the HUD pass: depth starts cleared, the colours it blends over are the composite's own (in place, a pixel per thread)
         f->hud_pass = 1;
         f->opaque_rgba16f = f->out_rgba16f;

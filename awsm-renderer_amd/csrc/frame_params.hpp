@@ -143,6 +143,7 @@ struct FrameDev {
     uint32_t bin_capacity;        // entries in the (triangle,tile) list
     uint32_t has_opaque;
     uint32_t mipmap;              // 0: MipmapMode::None (level 0 only), 1: MipmapMode::Gradient
+    uint32_t aniso;               // MipmapMode::Gradient: 1 = the samplers' max_anisotropy counts (AWSM_CFG_ANISOTROPIC; grad_footprint, kernels_shade.hip)
     uint32_t msaa;                // 0: one sample per pixel (pixel centre); 4: vis holds [pixel][4 samples]
     const uint8_t* camera;        // the camera UBO this frame is shaded with (a per-frame snapshot in overlap mode)
     // The lean opaque kernel's view of that camera, composed on the host in f64 from the UBO as submitted (awsm_hip.cpp: compose_pixel_to_view):

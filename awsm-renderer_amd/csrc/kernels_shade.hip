@@ -299,6 +299,63 @@ AWSM_DI f4 sample_level_fast(const uint32_t* base, uint32_t W, uint32_t H, float
     return r;
 }
 
+// textureSampleGrad's footprint.  WebGPU leaves level selection and anisotropy to the implementation; the contract here:
+//   * max_anisotropy 1 (or a context without AWSM_CFG_ANISOTROPIC — the default, the rule the reference itself documents as "mimics the hardware mip
+//     selection", helpers/mipmap.wgsl:419-439): rho = max(|ddx * size|, |ddy * size|), lod = log2(max(rho, 1e-6));
+//   * max_anisotropy A > 1 (gltf samplers ask for 16, gltf/populate/material.rs:892-902): N = clamp(rho_max / rho_min, 1, A) — a real number — the
+//     level is chosen for rho_max / N, and the footprint is covered by probes along the major axis at t_j = j / N, j = -m..m, m = ceil((N - 1) / 2),
+//     each weighted by the part of [-1/2, 1/2] its cell [t_j - 1/2N, t_j + 1/2N] covers (a box filter of the footprint's length sampled at the chosen
+//     level's spacing), normalised.  Continuous in N — a probe enters with weight zero — so two implementations that disagree in the last bit of a
+//     gradient agree in the colour; N = 1 is the isotropic rule bit for bit.
+struct GradFootprint { float lod, n, major_u, major_v; int m; };
+AWSM_DI GradFootprint grad_footprint(float dxu, float dxv, float dyu, float dyv, float W, float H, uint32_t max_aniso) {
+    const float ax = dxu * W, ay = dxv * H, bx = dyu * W, by = dyv * H;
+    const float rx2 = ax * ax + ay * ay, ry2 = bx * bx + by * by;
+    const float r2max = fmaxf(rx2, ry2);
+    GradFootprint fp;
+    fp.lod = 0.5f * __builtin_amdgcn_logf(fmaxf(r2max, 1e-12f));      // log2(max(rho, 1e-6))
+    fp.n = 1.0f; fp.major_u = 0.0f; fp.major_v = 0.0f; fp.m = 0;
+    if (max_aniso > 1u && r2max > 0.0f) {
+        const float r2min = fminf(rx2, ry2), A = (float)min(max_aniso, 16u);
+        float nf = r2min * (A * A) <= r2max ? A : __builtin_sqrtf(r2max / r2min);
+        nf = fminf(fmaxf(nf, 1.0f), A);
+        if (nf > 1.0f) {
+            fp.n = nf;
+            fp.lod = fp.lod - __builtin_amdgcn_logf(nf);
+            fp.m = (int)ceilf((nf - 1.0f) * 0.5f);
+            const bool xmajor = rx2 >= ry2;
+            fp.major_u = xmajor ? dxu : dyu; fp.major_v = xmajor ? dxv : dyv;
+        }
+    }
+    return fp;
+}
+
+// grad_footprint's probes: 2 m + 1 trilinear samples along the major axis, weighted and normalised.  levels_modes: lo | hi << 8 | address mode u << 16 |
+// v << 18 | linear << 20.  Out of line, per lane: only pixels with an anisotropic footprint on an AWSM_CFG_ANISOTROPIC context come here.
+__device__ __attribute__((noinline)) f4 sample_probes(const uint32_t* texels, const uint32_t* level_off, uint32_t W, uint32_t H, uint32_t layer, uint32_t levels_modes, float f,
+                                                      float u, float v, float major_u, float major_v, float nf, int m) {
+    const uint32_t lo = levels_modes & 255u, hi = (levels_modes >> 8) & 255u, mode_u = (levels_modes >> 16) & 3u, mode_v = (levels_modes >> 18) & 3u, linear = (levels_modes >> 20) & 1u;
+    const float inv_n = 1.0f / nf;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float wsum = 0.0f;
+    const int n = f > 0.0f ? 2 : 1;
+    for (int j = -m; j <= m; j++) {
+        const float t = (float)j * inv_n, wp = saturate((0.5f - fabsf(t)) * nf + 0.5f);
+        const float pu = u + major_u * t, pv = v + major_v * t;
+        for (int k = 0; k < n; k++) {
+            const uint32_t level = k ? hi : lo;
+            const float w = (k ? f : 1.0f - f) * wp;
+            const uint32_t Wl = max(W >> level, 1u), Hl = max(H >> level, 1u);
+            const uint32_t* base = texels + level_off[level] + (size_t)layer * Wl * Hl;
+            const f4 c = sample_level_generic(reinterpret_cast<const uint8_t*>(base), Wl, Hl, mode_u, mode_v, linear, pu, pv);
+            acc = {acc.x + c.x * w, acc.y + c.y * w, acc.z + c.z * w, acc.w + c.w * w};
+        }
+        wsum += wp;
+    }
+    const float iw = 1.0f / wsum;
+    return {acc.x * iw, acc.y * iw, acc.z * iw, acc.w * iw};
+}
+
 // ---------------- per-pixel attribute context ----------------
 struct Attr {
     const DevScene* sc;
@@ -312,7 +369,7 @@ struct Attr {
     f2 duv0_dx, duv0_dy;      // ... and d(TEXCOORD_0)/d(screen), alongside uv0
 };
 // texture_uvs.wgsl:64-84 (+ helpers/mipmap.wgsl:113-205 get_uv_derivatives when GRAD: chain rule over the vertex UVs)
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI f2 attr_uv(const Attr& a, uint32_t set, f2& ddx, f2& ddy) {
     const uint32_t o = a.uv_sets_index + set * 2u;
     const float x0 = a.ad[a.v0 + o], y0 = a.ad[a.v0 + o + 1], x1 = a.ad[a.v1 + o], y1 = a.ad[a.v1 + o + 1];
@@ -332,7 +389,7 @@ AWSM_DI f2 attr_uv(const Attr& a, uint32_t set, f2& ddx, f2& ddy) {
 // reference documents as "mimics the hardware mip selection" (helpers/mipmap.wgsl:419-439): rho = max(|ddx*size|, |ddy*size|),
 // lod = log2(max(rho, 1e-6)) clamped to the chain; magnification -> mag filter on level 0; otherwise min filter on
 // floor(lod) and floor(lod)+1 blended by the fraction (mipmap filter linear) or round(lod) (nearest).  Isotropic.
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
     f2 uv = a.uv0, ddx = a.duv0_dx, ddy = a.duv0_dy;
     if (!(a.has_uv0 && t.uv_set_index == 0u)) uv = attr_uv<GRAD>(a, t.uv_set_index, ddx, ddy);
@@ -356,20 +413,20 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
     // ---- level selection ----
     const float dxu = tt[0] * ddx.x + tt[1] * ddx.y, dxv = tt[2] * ddx.x + tt[3] * ddx.y;     // texture_uvs.wgsl:27-35
     const float dyu = tt[0] * ddy.x + tt[1] * ddy.y, dyv = tt[2] * ddy.x + tt[3] * ddy.y;
-    const float ax = dxu * (float)W, ay = dxv * (float)H, bx = dyu * (float)W, by = dyv * (float)H;
-    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    GradFootprint fp = grad_footprint(dxu, dxv, dyu, dyv, (float)W, (float)H, (GRAD == 2 && smp.mag_filter != 0u && smp.min_filter != 0u && smp.mipmap_filter != 0u) ? smp.max_anisotropy : 1u);
     const uint32_t levels = max(arr.mips, 1u);
-    float lod = 0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1e-12f));      // log2(max(rho, 1e-6))
     uint32_t lo = 0u, hi = 0u, linear = smp.mag_filter;
     float f = 0.0f;
-    if (lod > 0.0f && levels > 1u) {
-        lod = fminf(lod, (float)(levels - 1u));
+    if (fp.lod > 0.0f && levels > 1u) {
+        const float lod = fminf(fp.lod, (float)(levels - 1u));
         linear = smp.min_filter;
         if (smp.mipmap_filter == 0u) { lo = hi = (uint32_t)floorf(lod + 0.5f); }
         else { const float fl = floorf(lod); lo = (uint32_t)fl; hi = min(lo + 1u, levels - 1u); f = (hi != lo) ? lod - fl : 0.0f; }
     }
     const bool fast = common && linear != 0u;
     const bool all_fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;
+    if (GRAD == 2 && fp.m > 0)      // anisotropic footprint on a context that honours max_anisotropy (the kernels' <2> instantiations): the probes, out of line
+        return sample_probes(reinterpret_cast<const uint32_t*>(texels), arr.level_off, W, H, layer, lo | (hi << 8) | (smp.address_mode_u << 16) | (smp.address_mode_v << 18) | (linear << 20), f, u, v, fp.major_u, fp.major_v, fp.n, fp.m);
     f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int n = f > 0.0f ? 2 : 1;
     for (int k = 0; k < n; k++) {            // not unrolled: one copy of the samplers per call site
@@ -386,7 +443,7 @@ AWSM_DI f4 sample_tex(const Attr& a, const TexInfo& t) {
 // A core texture through its per-draw slot.  MipmapMode::None: the fast path needs nothing but the slot; any other sampler / size falls
 // back to the general route through the material words.  MipmapMode::Gradient: level selection as sample_tex<true>, with the array's
 // layout and the sampler's modes taken from the slot.
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI f4 sample_slot(const Attr& a, const TexSlotDev* __restrict__ slot, const uint32_t* __restrict__ M, uint32_t word) {
     const uint4* q = reinterpret_cast<const uint4*>(slot);
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2];        // base lo/hi, width, height | flags, tt0, tt1, tt2 | tt3, tt4, tt5, layer_levels
@@ -411,24 +468,23 @@ AWSM_DI f4 sample_slot(const Attr& a, const TexSlotDev* __restrict__ slot, const
     const uint4 q3 = q[3];                              // level_off pointer, array base
     const uint32_t* level_off = reinterpret_cast<const uint32_t*>(((unsigned long long)q3.y << 32) | q3.x);
     const uint32_t* texels = reinterpret_cast<const uint32_t*>(((unsigned long long)q3.w << 32) | q3.z);
-    const uint32_t W = q0.z, H = q0.w, layer = q2.w & 0xFFFFFFu, levels = q2.w >> 24;
+    const uint32_t W = q0.z, H = q0.w, layer = q2.w & 0xFFFFu, levels = q2.w >> 24;
     const uint32_t mode_u = (flags >> 13) & 3u, mode_v = (flags >> 21) & 3u;
-    // ---- level selection (texture_uvs.wgsl:27-35 + the isotropic LOD contract) ----
+    // ---- level selection (texture_uvs.wgsl:27-35 + the LOD contract, grad_footprint) ----
     const float dxu = t0 * ddx.x + t1 * ddx.y, dxv = t2 * ddx.x + t3 * ddx.y;
     const float dyu = t0 * ddy.x + t1 * ddy.y, dyv = t2 * ddy.x + t3 * ddy.y;
-    const float ax = dxu * (float)W, ay = dxv * (float)H, bx = dyu * (float)W, by = dyv * (float)H;
-    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
-    float lod = 0.5f * __builtin_amdgcn_logf(fmaxf(rho2, 1e-12f));      // log2(max(rho, 1e-6))
+    GradFootprint fp = grad_footprint(dxu, dxv, dyu, dyv, (float)W, (float)H, GRAD == 2 ? max((q2.w >> 16) & 31u, 1u) : 1u);
     uint32_t lo = 0u, hi = 0u, linear = (flags >> 4) & 1u;
     float f = 0.0f;
-    if (lod > 0.0f && levels > 1u) {
-        lod = fminf(lod, (float)(levels - 1u));
+    if (fp.lod > 0.0f && levels > 1u) {
+        const float lod = fminf(fp.lod, (float)(levels - 1u));
         linear = (flags >> 5) & 1u;
         if (!(flags & 64u)) { lo = hi = (uint32_t)floorf(lod + 0.5f); }
         else { const float fl = floorf(lod); lo = (uint32_t)fl; hi = min(lo + 1u, levels - 1u); f = (hi != lo) ? lod - fl : 0.0f; }
     }
     const bool fast = (flags & 8u) != 0u && linear != 0u;
     const bool all_fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;
+    if (GRAD == 2 && fp.m > 0) return sample_probes(texels, level_off, W, H, layer, lo | (hi << 8) | (mode_u << 16) | (mode_v << 18) | (linear << 20), f, u, v, fp.major_u, fp.major_v, fp.n, fp.m);
     f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int n = f > 0.0f ? 2 : 1;
     for (int k = 0; k < n; k++) {            // not unrolled: one copy of the samplers per call site
@@ -463,7 +519,7 @@ struct PbrColor {
     f3 sheen_color; float sheen_roughness;
 };
 
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI f3 normal_map(const Attr& a, const TexInfo& t, float scale, const TBN& tbn) {   // material_color_calc.wgsl:301-322
     if (!t.exists) return tbn.N;
     const f4 s = sample_tex<GRAD>(a, t);
@@ -809,7 +865,9 @@ AWSM_DI TexSlotDev resolve_tex_slot(const DevScene* __restrict__ sc, const uint3
                     if (common) s.flags |= 8u;
                     s.flags |= (smp.mag_filter != 0u ? 16u : 0u) | (smp.min_filter != 0u ? 32u : 0u) | (smp.mipmap_filter != 0u ? 64u : 0u);
                     s.flags |= ((smp.address_mode_u & 3u) << 13) | ((smp.address_mode_v & 3u) << 21);
-                    s.layer_levels = layer | (max(arr.mips, 1u) << 24);
+                    // layer (< 65536) | max_anisotropy 1..16, counted only with three linear filters (SamplerCacheKey::allowed_ansiotropy) << 16 | levels << 24
+                    const uint32_t an = (smp.mag_filter != 0u && smp.min_filter != 0u && smp.mipmap_filter != 0u) ? min(max(smp.max_anisotropy, 1u), 16u) : 1u;
+                    s.layer_levels = (layer & 0xFFFFu) | (an << 16) | (max(arr.mips, 1u) << 24);
                     s.level_off = &sc->tex[t.array_index].level_off[0];
                     s.array_base = reinterpret_cast<const uint32_t*>(arr.texels);
                 }
@@ -882,12 +940,12 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                     const TexInfo ti = tex_load(M, words[k]);
                     const TexArrayDev& arr = sc->tex[ti.array_index];
                     const unsigned long long abase = (unsigned long long)s.array_base;
-                    const uint32_t levels = s.layer_levels >> 24, layer = s.layer_levels & 0xFFFFFFu, lw = (uint32_t)(31 - __clz((int)s.width));
+                    const uint32_t levels = s.layer_levels >> 24, layer = s.layer_levels & 0xFFFFu, lw = (uint32_t)(31 - __clz((int)s.width));
                     unsigned long long chain_texels = 0ull;
                     for (uint32_t l = 0; l < levels; l++) chain_texels += (unsigned long long)arr.layers * max(arr.width >> l, 1u) * max(arr.height >> l, 1u);
                     const bool ok = s.width == s.height && (s.flags & (32u | 64u)) == (32u | 64u) && levels >= 1u && levels <= 15u && levels <= lw + 1u && arr.layers < 4096u &&
                                     chain_texels * 4ull < 0xFFFFFFF0ull && (abase >> 48) == 0ull && (abase & 3ull) == 0ull;
-                    if (!ok) lean_grad = false;
+                    if (!ok || (f.aniso && ((s.layer_levels >> 16) & 31u) > 1u)) lean_grad = false;      // (anisotropic probes: the general sampler)
                     L.gtex[k][0] = (uint32_t)abase; L.gtex[k][1] = (uint32_t)(abase >> 32) | (levels << 16) | (lw << 24);
                     L.gtex[k][2] = layer; L.gtex[k][3] = arr.layers;
                 }
@@ -1016,7 +1074,7 @@ __device__ __attribute__((noinline)) f3 sample_transmission_background(const Dev
 // material_transparent): same textures, factors and lighting; they differ in the alpha rules, the vertex-colour rule and
 // where the transmission background comes from.  out.color.w = alpha.
 struct SurfaceOut { f4 color; uint32_t kind; bool discard; };
-template <bool GRAD, bool FWD>
+template <int GRAD, bool FWD>
 AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDev& f, Attr& a, uint32_t material_word, const TexSlotDev* __restrict__ slots,
                                   const DrawMatDev* __restrict__ draw_mat, const TBN& tbn,
                                   f3 world_position, f3 surface_to_camera, uint32_t color_sets, float frag_x, float frag_y, bool mask_resolved = false) {
@@ -1193,7 +1251,7 @@ AWSM_DI SurfaceOut shade_material(const DevScene* __restrict__ sc, const FrameDe
 // (triangle `rank`, pixel), `depth_sample` the depth the standard coordinates are built from (always sample 0's,
 // standard.wgsl:17).  kind: 0 lit/unlit colour, 1 PBR debug view, 2 hud mesh (only reported when check_hud).
 // ------------------------------------------------------------------------------------------------
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI SurfaceOut shade_surface(const DevScene* __restrict__ sc, const FrameDev& f, uint32_t rank, int cx, int cy, float depth_sample,
                                  const GBufferTexel& g, bool check_hud) {
     SurfaceOut out;
@@ -1274,7 +1332,7 @@ constexpr uint32_t kFragChunk = 64;          // fragment slots a wavefront reser
 struct FwdVary { float b0, b1, b2; f4 derivs; uint4 ds0, ds1; uint32_t draw; };
 
 // STRICT: barycentrics (and their quad differences) exactly as the oracle derives them from the setup record; then the attribute context
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI FwdVary forward_attr(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py, Attr& a) {
     FwdVary o;
     const double Xc = sample_coord((px << 8) + 128), Yc = sample_coord((py << 8) + 128);
@@ -1315,7 +1373,7 @@ AWSM_DI FwdVary forward_attr(const DevScene* __restrict__ sc, const FrameDev& f,
 
 // ALPHA_MODE_MASK (transparent material_color_calc.wgsl:38-52,344-362): the base colour's alpha against the cutoff, nothing else of the
 // material.  The coverage kernel decides with this; the shading kernel then treats the fragment's alpha as 1 without testing again.
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI bool forward_alpha_test(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py) {
     Attr a;
     const FwdVary vy = forward_attr<GRAD>(sc, f, t, rank, px, py, a);
@@ -1332,7 +1390,7 @@ AWSM_DI bool forward_alpha_test(const DevScene* __restrict__ sc, const FrameDev&
     return !(alpha < dm->alpha_cutoff);
 }
 
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI SurfaceOut forward_fragment(const DevScene* __restrict__ sc, const FrameDev& f, const TriSetup& t, uint32_t rank, int px, int py, bool mask_resolved) {
     Attr a;
     const FwdVary vy = forward_attr<GRAD>(sc, f, t, rank, px, py, a);
@@ -1383,7 +1441,7 @@ constexpr uint32_t kFwdWords = kFwdWindow / 32;
 constexpr uint32_t kFwdRecCap = 320;         // setup records staged per window (25 KB); triangles beyond that are fetched from HBM by the walk
 constexpr uint32_t kFragPool = 64u * kFwdNB; // fragment slots a workgroup reserves up front (one global atomic per non-empty rectangle)
 
-template <int S, bool GRAD>
+template <int S, int GRAD>
 __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ uint32_t bitmap[kFwdNB][kFwdWords];
     __shared__ uint32_t ubits[kFwdWords];          // union of the block bitmaps: the rectangle's triangles of this window
@@ -1557,7 +1615,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
     if (in_frame) f.frag_first[p] = first;
 }
 
-template <bool GRAD>
+template <int GRAD>
 __global__ __launch_bounds__(256) void k_forward_shade(const DevScene* __restrict__ sc, FrameDev f) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (frame_poisoned(f)) return;
@@ -1635,7 +1693,7 @@ AWSM_DI void shade_block_at(const FrameDev& f, ShadeBlock& b, uint32_t brow, uin
 // k_shade: single-sampled opaque pass, 16x16 pixels per workgroup (compute.wgsl uses 8x8; a 64-wide wavefront covers
 // 16x4 here).  5 waves/SIMD (<= 96 VGPRs): measured faster than the 4 the register allocator picks on its own, 6 spills.
 // ------------------------------------------------------------------------------------------------
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI void shade_pixel(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, uint32_t tid) {
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
     if (cx >= (int)f.width || cy >= (int)f.sy1) return;                  // compute.wgsl:111-113
@@ -1645,11 +1703,11 @@ AWSM_DI void shade_pixel(const DevScene* __restrict__ sc, const FrameDev& f, con
     if (f.hud_vis && f.has_opaque && f.hud_vis[pv] != ~0ull) { store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f}); return; }   // a hud mesh's triangle is what the visibility target holds here: compute.wgsl:176-179 returns, the pixel stays cleared
     if (!f.has_opaque || key == ~0ull) { store_pixel(f, p, skybox_color(sc, f, cx, cy)); return; }   // compute.wgsl:149-153 / empty.wgsl, skybox.wgsl:1-41
     const uint32_t rank = key_rank(key);
-    const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
+    const GBufferTexel g = reconstruct_gbuffer<(GRAD != 0)>(f, rank, cx, cy);    // STRICT
     const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
     store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);   // hud: stays cleared (compute.wgsl:176-179)
 }
-template <bool GRAD>
+template <int GRAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 5))) void k_shade(const DevScene* __restrict__ sc, FrameDev f) {
     ShadeBlock b;
     if (frame_poisoned(f) || !shade_block(f, b)) return;
@@ -1666,7 +1724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : 
 // MSAA: sample 0 of the pixel by the general code, stored as k_shade_lean<.., MSAA> stores its own (the strip's masks and cells are already there: the lean
 // kernel wrote them before it handed the strip over).  Hud meshes and debug views are written before the edge test and never resolved
 // (compute.wgsl:118-170,303-318) — a pixel of theirs that the masks name leaves a marker in msaa_color0 that k_shade_msaa_resolve skips.
-template <bool GRAD>
+template <int GRAD>
 AWSM_DI void shade_pixel_msaa0(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, uint32_t tid) {
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
     if (cx >= (int)f.width || cy >= (int)f.sy1) return;
@@ -1677,13 +1735,13 @@ AWSM_DI void shade_pixel_msaa0(const DevScene* __restrict__ sc, const FrameDev& 
     const unsigned long long key = f.vis[pv * 4];
     if (key == ~0ull) return;                                              // background: the lean kernel stored it
     const uint32_t rank = key_rank(key);
-    const GBufferTexel g = reconstruct_gbuffer<GRAD>(f, rank, cx, cy);    // STRICT
+    const GBufferTexel g = reconstruct_gbuffer<(GRAD != 0)>(f, rank, cx, cy);    // STRICT
     const SurfaceOut o = shade_surface<GRAD>(sc, f, rank, cx, cy, key_depth(key), g, true);
     store_pixel(f, p, o.kind == 2u ? f4{0.0f, 0.0f, 0.0f, 0.0f} : o.color);
     if (want_c0) f.msaa_color0[pv] = o.kind != 0u ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)) : make_float4(o.color.x, o.color.y, o.color.z, o.color.w);
 }
 constexpr uint32_t kTodoBlocks = 1024;
-template <bool GRAD, bool MSAA>
+template <int GRAD, bool MSAA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_todo(const DevScene* __restrict__ sc, FrameDev f) {
     // This kernel starting means this frame's k_shade_lean has ended (same stream): the next frame's opaque pass, gated on that, goes ahead
     // while the list is shaded (k_handoff_wait, kernels_geometry.hip; the two frames write different images).
@@ -2444,7 +2502,7 @@ AWSM_DI uint32_t detect_edges(const FrameDev& f, const ShadeBlock& b, uint8_t* e
 
 // k_shade_msaa: the general route's MSAA kernel — sample 0 of every pixel by the general code and the whole edge decision in one kernel (normals of the
 // block + a halo ring in LDS).
-template <bool GRAD>
+template <int GRAD>
 __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ NeighbourCell cells[18 * 18];
     __shared__ uint32_t n_edges;
@@ -2468,7 +2526,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
             k4[0] = ka.x; k4[1] = ka.y; k4[2] = kb.x; k4[3] = kb.y;
             c.state = 1u;
             if (k4[0] != ~0ull) {
-                g0 = reconstruct_gbuffer<GRAD>(f, key_rank(k4[0]), cx, cy);   // STRICT
+                g0 = reconstruct_gbuffer<(GRAD != 0)>(f, key_rank(k4[0]), cx, cy);   // STRICT
                 const f3 n = decode_octahedral(mk2(g0.packed_nt.x, g0.packed_nt.y));
                 c.nx = n.x; c.ny = n.y; c.nz = n.z; c.depth_bits = (uint32_t)(k4[0] >> 32); c.state = 2u;
             }
@@ -2542,7 +2600,7 @@ __global__ __launch_bounds__(64) void k_msaa_detect(FrameDev f) {
     for (uint32_t w = lane; w * 4u < n; w += 64u) edge_rec[1u + w] = reinterpret_cast<const uint32_t*>(eslot)[w];      // (slots beyond n in the last word: never read)
 }
 
-template <bool GRAD>
+template <int GRAD>
 __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
     // One WAVEFRONT per block: the shading is a long dependent chain for a few dozen lanes, and what bounds the kernel is how many blocks are in flight —
     // a 256-thread workgroup parked three idle wavefronts' registers behind every busy one (177 us at 4K; 18 M VALU instructions: 83 % of the wave-cycles waiting).
@@ -2591,7 +2649,7 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
         const unsigned long long* kq = f.vis + ((size_t)iy * f.width + (size_t)ix) * 4;
         const unsigned long long ks = kq[sidx], k0 = kq[0];
         const uint32_t r = key_rank(ks);
-        const f4 c = shade_surface<GRAD>(sc, f, r, ix, iy, key_depth(k0), reconstruct_gbuffer<GRAD>(f, r, ix, iy), false).color;
+        const f4 c = shade_surface<GRAD>(sc, f, r, ix, iy, key_depth(k0), reconstruct_gbuffer<(GRAD != 0)>(f, r, ix, iy), false).color;
         icolor[i] = make_float4(c.x, c.y, c.z, c.w);
     }
     __syncthreads();
@@ -2757,16 +2815,26 @@ __global__ void k_rgba16f_to_rg16f(const uint16_t* __restrict__ in, uint32_t* __
 extern "C" void awsm_launch_resolve_draws(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     if (f->n_draws) hipLaunchKernelGGL(awsm::k_resolve_draws, dim3((8u * f->n_draws + 255u) / 256u), dim3(256), 0, s, sc, *f);
 }
+// A kernel's instantiation by mip mode: 0 MipmapMode::None, 1 MipmapMode::Gradient, 2 Gradient on a context that honours max_anisotropy
+// (AWSM_CFG_ANISOTROPIC; separate instantiations: the probes cost the isotropic sampler registers it would pay for on every frame)
+#define AWSM_LAUNCH_G(g, K, grid, block, ...) do { if ((g) == 2) hipLaunchKernelGGL((K<2>), grid, block, 0, s, __VA_ARGS__); else if ((g) == 1) hipLaunchKernelGGL((K<1>), grid, block, 0, s, __VA_ARGS__); \
+                                                   else hipLaunchKernelGGL((K<0>), grid, block, 0, s, __VA_ARGS__); } while (0)
+#define AWSM_LAUNCH_G2(g, K, B, grid, block, ...) do { if ((g) == 2) hipLaunchKernelGGL((K<2, B>), grid, block, 0, s, __VA_ARGS__); else if ((g) == 1) hipLaunchKernelGGL((K<1, B>), grid, block, 0, s, __VA_ARGS__); \
+                                                       else hipLaunchKernelGGL((K<0, B>), grid, block, 0, s, __VA_ARGS__); } while (0)
+#define AWSM_LAUNCH_SG(g, K, S, grid, block, ...) do { if ((g) == 2) hipLaunchKernelGGL((K<S, 2>), grid, block, 0, s, __VA_ARGS__); else if ((g) == 1) hipLaunchKernelGGL((K<S, 1>), grid, block, 0, s, __VA_ARGS__); \
+                                                       else hipLaunchKernelGGL((K<S, 0>), grid, block, 0, s, __VA_ARGS__); } while (0)
+static inline int mip_mode(const awsm::FrameDev* f) { return f->mipmap ? (f->aniso ? 2 : 1) : 0; }
 extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f);
 extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (!nb) return;
     const bool grad = f->mipmap != 0u;      // MipmapMode::Gradient vs None: separate instantiations, as the reference keeps separate pipelines
+    const int g = mip_mode(f);
     const bool msaa = f->msaa == 4u;
     if (awsm_shade_is_lean(f)) {
         // the lean kernel over the screen (a wavefront per strip id on a power-of-two block pitch: the padding exits), then the general code for the
-        // wavefronts it declined (awsm_launch_shade_todo; k_deform_transform / k_resolve_draws reset the list).  MSAA: the edge detector first.
+        // wavefronts it declined (awsm_launch_shade_todo; k_deform_transform / k_resolve_draws reset the list)
         uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
         const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
         if (msaa) {
@@ -2778,10 +2846,9 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         return;
     }
     if (msaa) {
-        if (grad) { hipLaunchKernelGGL(awsm::k_shade_msaa<true>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f); }
-        else { hipLaunchKernelGGL(awsm::k_shade_msaa<false>, dim3(nb), dim3(256), 0, s, sc, *f); hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f); }
-    } else if (grad) hipLaunchKernelGGL(awsm::k_shade<true>, dim3(nb), dim3(256), 0, s, sc, *f);
-    else hipLaunchKernelGGL(awsm::k_shade<false>, dim3(nb), dim3(256), 0, s, sc, *f);
+        AWSM_LAUNCH_G(g, awsm::k_shade_msaa, dim3(nb), dim3(256), sc, *f);
+        AWSM_LAUNCH_G(g, awsm::k_shade_msaa_resolve, dim3(nb), dim3(64), sc, *f);
+    } else AWSM_LAUNCH_G(g, awsm::k_shade, dim3(nb), dim3(256), sc, *f);
 }
 // second half of the lean route; returns 0 when the frame did not take it
 extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f) {
@@ -2790,18 +2857,16 @@ extern "C" int awsm_shade_is_lean(const awsm::FrameDev* f) {
 }
 extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     if (!awsm_shade_is_lean(f)) return 0;
+    const int g = mip_mode(f);
     if (f->msaa == 4u) {      // ... and the edge pixels' remaining samples, once every sample-0 colour is in place
         const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
         const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;
-        if (f->mipmap) hipLaunchKernelGGL((awsm::k_shade_todo<true, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
-        else hipLaunchKernelGGL((awsm::k_shade_todo<false, true>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+        AWSM_LAUNCH_G2(g, awsm::k_shade_todo, true, dim3(awsm::kTodoBlocks), dim3(256), sc, *f);
         hipLaunchKernelGGL(awsm::k_msaa_detect, dim3(nb), dim3(64), 0, s, *f);
-        if (f->mipmap) hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<true>, dim3(nb), dim3(64), 0, s, sc, *f);
-        else hipLaunchKernelGGL(awsm::k_shade_msaa_resolve<false>, dim3(nb), dim3(64), 0, s, sc, *f);
+        AWSM_LAUNCH_G(g, awsm::k_shade_msaa_resolve, dim3(nb), dim3(64), sc, *f);
         return 1;
     }
-    if (f->mipmap) hipLaunchKernelGGL((awsm::k_shade_todo<true, false>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
-    else hipLaunchKernelGGL((awsm::k_shade_todo<false, false>), dim3(awsm::kTodoBlocks), dim3(256), 0, s, sc, *f);
+    AWSM_LAUNCH_G2(g, awsm::k_shade_todo, false, dim3(awsm::kTodoBlocks), dim3(256), sc, *f);
     return 1;
 }
 // f: the transparent pass's frame (its own draws / vertices / bins; vis = the geometry pass's keys; opaque_rgba16f = the opaque image;
@@ -2809,11 +2874,12 @@ extern "C" int awsm_launch_shade_todo(const awsm::DevScene* sc, const awsm::Fram
 extern "C" void awsm_launch_forward(const awsm::DevScene* sc, const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (!n_tiles) return;
-    const bool grad = f->mipmap != 0u, ms = f->msaa == 4u;
+    const bool ms = f->msaa == 4u;
+    const int g = mip_mode(f);
     const uint32_t nb_shade = (f->frag_cap + 255u) / 256u, nb_blend = (f->width * f->height + 255u) / 256u;
-    if (ms) { if (grad) hipLaunchKernelGGL((awsm::k_forward_cover<4, true>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); else hipLaunchKernelGGL((awsm::k_forward_cover<4, false>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); }
-    else { if (grad) hipLaunchKernelGGL((awsm::k_forward_cover<1, true>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); else hipLaunchKernelGGL((awsm::k_forward_cover<1, false>), dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), 0, s, sc, *f); }
-    if (nb_shade) { if (grad) hipLaunchKernelGGL(awsm::k_forward_shade<true>, dim3(nb_shade), dim3(256), 0, s, sc, *f); else hipLaunchKernelGGL(awsm::k_forward_shade<false>, dim3(nb_shade), dim3(256), 0, s, sc, *f); }
+    if (ms) AWSM_LAUNCH_SG(g, awsm::k_forward_cover, 4, dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), sc, *f);
+    else AWSM_LAUNCH_SG(g, awsm::k_forward_cover, 1, dim3(n_tiles * awsm::kFwdSubs), dim3(awsm::kFwdThreads), sc, *f);
+    if (nb_shade) AWSM_LAUNCH_G(g, awsm::k_forward_shade, dim3(nb_shade), dim3(256), sc, *f);
     if (ms) hipLaunchKernelGGL(awsm::k_forward_blend<4>, dim3(nb_blend), dim3(256), 0, s, *f); else hipLaunchKernelGGL(awsm::k_forward_blend<1>, dim3(nb_blend), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_msaa_halo_export(const awsm::FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s) {

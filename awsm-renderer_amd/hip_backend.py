@@ -18,6 +18,7 @@ AWSM_CFG_PARITY_TAP = 1
 AWSM_CFG_SMALL_BIN_LIST = 2
 AWSM_CFG_OVERLAP_FRAMES = 4
 AWSM_CFG_GENERAL_SHADE_ONLY = 8
+AWSM_CFG_ANISOTROPIC = 16
 
 BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", "CAMERA", "SKIN_MATRICES", "SKIN_INDEX_WEIGHTS",
              "MORPH_WEIGHTS", "MORPH_VALUES", "GEOM_META", "MATERIAL_META", "VIS_GEOM_DATA", "VIS_GEOM_INDEX", "ATTR_DATA", "ATTR_INDEX",
@@ -142,9 +143,9 @@ class HipDevice:
     """One AwsmHipCtx: one HIP device + stream."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False, small_bin_list: bool = False, overlap_frames: bool = False,
-                 general_shade_only: bool = False):
+                 general_shade_only: bool = False, anisotropic: bool = False):
         self.lib = load_library()
-        flags = (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0) | (AWSM_CFG_OVERLAP_FRAMES if overlap_frames else 0) | (AWSM_CFG_GENERAL_SHADE_ONLY if general_shade_only else 0)
+        flags = (AWSM_CFG_ANISOTROPIC if anisotropic else 0) | (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0) | (AWSM_CFG_OVERLAP_FRAMES if overlap_frames else 0) | (AWSM_CFG_GENERAL_SHADE_ONLY if general_shade_only else 0)
         cfg = AwsmConfig(C.sizeof(AwsmConfig), self.lib.awsm_hip_abi_version(), device, flags, stream)
         ctx = C.c_void_p()
         rc = self.lib.awsm_hip_create(C.byref(cfg), C.byref(ctx))

@@ -58,7 +58,7 @@ def algorithmic_bytes(scene, stats, rows):
     }
 
 
-SHADE_KERNELS = ("k_shade_lean<false, false, false>", "k_shade_lean<false>", "k_shade_lean", "k_shade", "k_shade<false>")      # profile names of the single-sample, MipmapMode::None opaque kernel
+SHADE_KERNELS = ("k_shade_lean<false, false, false>", "k_shade_lean<false>", "k_shade_lean", "k_shade", "k_shade<false>", "k_shade<0>")      # profile names of the single-sample, MipmapMode::None opaque kernel
 
 
 def pmc_profile(n_tris, W, H):
@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=30)
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the opaque pass of frame i with the geometry pass of frame i+1")
     ap.add_argument("--mipmap", action="store_true", help="MipmapMode::Gradient (the reference's default; not the BASELINE config)")
+    ap.add_argument("--anisotropic", action="store_true", help="with --mipmap: honour the samplers' max_anisotropy (16 in this scene, as the reference's glTF ingest sets it; AWSM_CFG_ANISOTROPIC)")
     ap.add_argument("--msaa", type=int, default=0, choices=(0, 4), help="MSAA x4 geometry + edge resolve (the reference's default AntiAliasing; not the BASELINE config)")
     ap.add_argument("--strips", action="store_true", help="with --msaa 4 and N > 1: shard by contiguous row strips (each carries its own halo rows) instead of bands + halo exchange")
     ap.add_argument("--gather", choices=("all", "root"), default="all", help="N > 1: how the image leaves the ranks — 'all': RCCL all-gather, every rank ends up with the frame "
@@ -221,7 +222,8 @@ def main():
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa, mipmap=args.mipmap, overlap_frames=not args.no_overlap)
+    r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa, mipmap=args.mipmap, overlap_frames=not args.no_overlap,
+                 anisotropic=args.anisotropic)
     from awsm_renderer_amd.hip_backend import HipDevice
     dev = HipDevice.from_ctx(r.host.device_ctx, W, H)
     # N > 1: 32-row bands dealt round-robin over the ranks (rank r owns tile rows r, r+N, ...: every rank gets 1/N of the
@@ -511,7 +513,7 @@ def main():
             "data": "synthetic (procedural scene generated in-repo; no glTF asset is available offline)",
             "shaded_mpix_per_s": W * H * fps / 1e6,
             "config": {"workload": f"{workload_name}: {n_tris} triangles, {len(scene.materials)} materials, "
-                                   f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + (", MipmapMode::Gradient" if args.mipmap else ", MipmapMode::None"),
+                                   f"{len(scene.textures)} textures, {W}x{H}, geometry pass + opaque pass, " + ("MSAA x4 + edge resolve" if args.msaa else "single-sample") + (", MipmapMode::Gradient" + (" + max_anisotropy 16" if args.anisotropic else "") if args.mipmap else ", MipmapMode::None"),
                        "triangles": n_tris, "width": W, "height": H,
                        "sharding": sharding_desc,
                        "draws": len(r.host.draw_list()),

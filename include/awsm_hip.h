@@ -89,6 +89,12 @@ typedef struct AwsmConfig {
                                      and the read-back calls wait for everything. */
 #define AWSM_CFG_GENERAL_SHADE_ONLY 8u /* never take the lean opaque route (k_shade_lean): every pixel through the general kernel.  For A/B
                                          measurements and for tests that compare the two routes; results must agree within the shading tolerance. */
+#define AWSM_CFG_ANISOTROPIC 16u /* MipmapMode::Gradient honours AwsmSampler.max_anisotropy (gltf samplers ask for 16,
+                                  * gltf/populate/material.rs:892-902): up to 17 weighted trilinear probes along the footprint's major axis,
+                                  * the level chosen for rho_max / N (the contract: DESIGN.md §2, grad_footprint in kernels_shade.hip).  Off by
+                                  * default: textureSampleGrad's anisotropy is implementation-defined in WebGPU, and the default here is the
+                                  * isotropic rule the reference itself documents (helpers/mipmap.wgsl:419-439).  Draws whose core textures
+                                  * ask for anisotropy leave the lean opaque route under this flag. */
 #define AWSM_CFG_SMALL_BIN_LIST 2u /* start with a 4096-entry (triangle, tile) list instead of sizing it from the triangle count:
                                      exercises the overflow -> grow -> replay path of awsm_hip_frame_end (tests) */
 
@@ -122,7 +128,7 @@ typedef struct AwsmSampler {
     uint32_t mag_filter;      /* 0 nearest, 1 linear (level-0 sampling uses the mag filter) */
     uint32_t min_filter;
     uint32_t mipmap_filter;
-    uint32_t max_anisotropy;  /* accepted, unused while mipmap == None */
+    uint32_t max_anisotropy;  /* 1..16; counts under MipmapMode::Gradient on a context created with AWSM_CFG_ANISOTROPIC, and only with three linear filters */
 } AwsmSampler;
 
 /* Environment: skybox + IBL cubes + BRDF LUT (opaque bind group 0, bindings 14-21:

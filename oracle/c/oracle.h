@@ -92,6 +92,9 @@ int oracle_unpack_visibility(const OracleScene* s, const uint64_t* keys, uint32_
 size_t oracle_mip_chain_bytes(uint32_t width, uint32_t height, uint32_t layers, uint32_t levels);
 uint32_t oracle_mip_levels(uint32_t width, uint32_t height);
 int oracle_generate_mips(uint32_t width, uint32_t height, uint32_t layers, const uint32_t* kinds, uint32_t levels, uint8_t* chain);
+/* textureSampleGrad by the sampling contract (oracle_shade.c: sample_array_grad); anisotropic = 1: max_anisotropy counts (AWSM_CFG_ANISOTROPIC's twin) */
+void oracle_set_anisotropic(int on);
+void oracle_sample_grad(const OracleTexArray* arr, const AwsmSampler* smp, uint32_t layer, const float* uv, const float* ddx, const float* ddy, uint32_t n, int anisotropic, float* rgba_out);
 
 /* BRDF LUT: rg16f_out[h*w*2].  Row j, column i == fragment (i+0.5, j+0.5) of the reference's
  * full-screen triangle (renderer-core/src/brdf_lut/shader.wgsl). */

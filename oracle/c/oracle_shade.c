@@ -160,18 +160,20 @@ static ovec4 sample_array_level(const OracleTexArray* arr, const AwsmSampler* sm
 static ovec4 sample_array_level0(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer) {
     return sample_array_level(arr, smp, uv, layer, 0u, smp->mag_filter != 0u);
 }
-/* textureSampleGrad(tex, sampler, uv, layer, ddx, ddy).  WebGPU leaves LOD selection and anisotropy to the hardware;
- * the contract is the isotropic rule the reference itself documents as "mimics the hardware mip selection"
- * (helpers/mipmap.wgsl:419-439): rho = max(|ddx * size|, |ddy * size|), lod = log2(max(rho, 1e-6)), clamped to the
- * chain, magnification (lod <= 0) uses the mag filter on level 0, otherwise the min filter on floor(lod) and
- * floor(lod) + 1 blended by the fraction (mipmap filter linear) or on round(lod) (nearest).  No anisotropic probes. */
-static ovec4 sample_array_grad(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer, ovec2 ddx, ovec2 ddy) {
+/* textureSampleGrad(tex, sampler, uv, layer, ddx, ddy).  WebGPU leaves LOD selection and anisotropy to the hardware; the contract:
+ *  - max_anisotropy 1, or anisotropy not enabled (oracle_set_anisotropic(0), the default): the isotropic rule the reference itself documents as
+ *    "mimics the hardware mip selection" (helpers/mipmap.wgsl:419-439): rho = max(|ddx * size|, |ddy * size|), lod = log2(max(rho, 1e-6)), clamped
+ *    to the chain, magnification (lod <= 0) uses the mag filter on level 0, otherwise the min filter on floor(lod) and floor(lod) + 1 blended by the
+ *    fraction (mipmap filter linear) or on round(lod) (nearest);
+ *  - max_anisotropy A > 1 with three linear filters (gltf samplers: 16, gltf/populate/material.rs:892-902; SamplerCacheKey::allowed_ansiotropy):
+ *    N = clamp(rho_max / rho_min, 1, A), a real number; the level is chosen for rho_max / N; probes along the major axis at t_j = j / N,
+ *    j = -m..m, m = ceil((N - 1) / 2), each a trilinear sample weighted by the part of [-1/2, 1/2] its cell [t_j - 1/2N, t_j + 1/2N] covers,
+ *    normalised by the sum of the weights.  Continuous in N (a probe enters with weight zero); N = 1 is the isotropic rule. */
+static int g_anisotropic = 0;
+void oracle_set_anisotropic(int on) { g_anisotropic = on; }
+static ovec4 sample_array_trilinear(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer, float lod_in) {
     const uint32_t levels = arr->mips > 1u ? arr->mips : 1u;
-    const float W = (float)arr->width, H = (float)arr->height;
-    const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
-    const float rho_x = sqrtf(ax * ax + ay * ay), rho_y = sqrtf(bx * bx + by * by);
-    const float rho = fmaxf(rho_x, rho_y);
-    float lod = log2f(fmaxf(rho, 1e-6f));
+    float lod = lod_in;
     if (!(lod > 0.0f) || levels == 1u) return sample_array_level(arr, smp, uv, layer, 0u, smp->mag_filter != 0u);
     const float max_lod = (float)(levels - 1u);
     if (lod > max_lod) lod = max_lod;
@@ -184,6 +186,51 @@ static ovec4 sample_array_grad(const OracleTexArray* arr, const AwsmSampler* smp
     ovec4 b = sample_array_level(arr, smp, uv, layer, hi, lin);
     const float g = 1.0f - f;
     return ov4(a.x * g + b.x * f, a.y * g + b.y * f, a.z * g + b.z * f, a.w * g + b.w * f);
+}
+static ovec4 sample_array_grad(const OracleTexArray* arr, const AwsmSampler* smp, ovec2 uv, uint32_t layer, ovec2 ddx, ovec2 ddy) {
+    const float W = (float)arr->width, H = (float)arr->height;
+    const float ax = ddx.x * W, ay = ddx.y * H, bx = ddy.x * W, by = ddy.y * H;
+    const float rx2 = ax * ax + ay * ay, ry2 = bx * bx + by * by;
+    const float rho_x = sqrtf(rx2), rho_y = sqrtf(ry2);
+    const float rho = fmaxf(rho_x, rho_y);
+    float lod = log2f(fmaxf(rho, 1e-6f));
+    uint32_t A = 1u;
+    if (g_anisotropic && smp->mag_filter != 0u && smp->min_filter != 0u && smp->mipmap_filter != 0u) A = smp->max_anisotropy < 1u ? 1u : (smp->max_anisotropy > 16u ? 16u : smp->max_anisotropy);
+    const float r2max = fmaxf(rx2, ry2), r2min = fminf(rx2, ry2);
+    if (A > 1u && r2max > 0.0f) {
+        const float Af = (float)A;
+        float nf = r2min * (Af * Af) <= r2max ? Af : sqrtf(r2max / r2min);
+        nf = fminf(fmaxf(nf, 1.0f), Af);
+        if (nf > 1.0f) {
+            lod = lod - log2f(nf);
+            const int m = (int)ceilf((nf - 1.0f) * 0.5f);
+            const ovec2 major = rx2 >= ry2 ? ddx : ddy;
+            ovec4 acc = ov4(0.0f, 0.0f, 0.0f, 0.0f);
+            float wsum = 0.0f;
+            for (int j = -m; j <= m; j++) {
+                const float t = (float)j / nf;
+                float w = (0.5f - fabsf(t)) * nf + 0.5f;
+                w = w < 0.0f ? 0.0f : (w > 1.0f ? 1.0f : w);
+                const ovec4 c = sample_array_trilinear(arr, smp, ov2(uv.x + major.x * t, uv.y + major.y * t), layer, lod);
+                acc = ov4(acc.x + c.x * w, acc.y + c.y * w, acc.z + c.z * w, acc.w + c.w * w);
+                wsum += w;
+            }
+            const float iw = 1.0f / wsum;
+            return ov4(acc.x * iw, acc.y * iw, acc.z * iw, acc.w * iw);
+        }
+    }
+    return sample_array_trilinear(arr, smp, uv, layer, lod);
+}
+
+/* test hook: n textureSampleGrad calls on one array — uv / ddx / ddy as (n, 2) f32, rgba_out (n, 4) f32; `anisotropic` as oracle_set_anisotropic */
+void oracle_sample_grad(const OracleTexArray* arr, const AwsmSampler* smp, uint32_t layer, const float* uv, const float* ddx, const float* ddy, uint32_t n, int anisotropic, float* rgba_out) {
+    const int before = g_anisotropic;
+    g_anisotropic = anisotropic;
+    for (uint32_t i = 0; i < n; i++) {
+        const ovec4 c = sample_array_grad(arr, smp, ov2(uv[i * 2], uv[i * 2 + 1]), layer, ov2(ddx[i * 2], ddx[i * 2 + 1]), ov2(ddy[i * 2], ddy[i * 2 + 1]));
+        rgba_out[i * 4] = c.x; rgba_out[i * 4 + 1] = c.y; rgba_out[i * 4 + 2] = c.z; rgba_out[i * 4 + 3] = c.w;
+    }
+    g_anisotropic = before;
 }
 
 /* texture_uvs.wgsl:144-187 + textures.wgsl:131-150 */

@@ -209,6 +209,7 @@ class OracleFrame:
         return out
 
     def shade(self, threads=8):
+        lib().oracle_set_anisotropic(C.c_int(1 if getattr(self, "anisotropic", False) else 0))      # AWSM_CFG_ANISOTROPIC's twin (oracle_shade.c: sample_array_grad)
         assert lib().oracle_shade(C.byref(self.scene), self.clip.ctypes.data_as(C.c_void_p), self.nt.ctypes.data_as(C.c_void_p),
                                   self.keys.ctypes.data_as(C.c_void_p), self.rgba32f.ctypes.data_as(C.c_void_p),
                                   self.rgba16f.ctypes.data_as(C.c_void_p), C.c_int(threads)) == 0
@@ -258,6 +259,7 @@ class OracleFrame:
         hud=True: the HUD transparent pass (render.rs:301-312, :490-521) over the composite a previous forward() left — colours LoadOp::Load
         (the composite is the image blended over), depth against hud_depth, cleared (every key reads as no hit = depth 1.0)."""
         L = lib()
+        L.oracle_set_anisotropic(C.c_int(1 if getattr(self, "anisotropic", False) else 0))
         arr = (AwsmDraw * max(1, len(draws)))()
         for i, d in enumerate(draws):
             arr[i] = AwsmDraw(d["geom_meta_off"], d["vis_data_off"], d["tri_count"], d["flags"], d.get("inst_off", 0), d.get("inst_count", 0))
@@ -291,11 +293,27 @@ class OracleFrame:
         return tri, meta, depth
 
 
-def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0, mipmap=False) -> OracleFrame:
+def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0, mipmap=False, anisotropic=False) -> OracleFrame:
     sc = model.scene
-    return OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,
+    fr = OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,
                        skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap,
                        env_cubes=sc.env_cubes)
+    fr.anisotropic = anisotropic
+    return fr
+
+
+def sample_grad(texels: np.ndarray, sampler: dict, uv, ddx, ddy, layer=0, anisotropic=False, kinds=None) -> np.ndarray:
+    """textureSampleGrad on an RGBA8 array [layers, h, w, 4] (its chain generated here) by the oracle's contract: uv / ddx / ddy (n, 2) -> (n, 4) f32."""
+    chain, levels = mip_chain(texels, kinds)
+    layers, h, w, _ = texels.shape
+    arr = OracleTexArray(chain.ctypes.data, w, h, layers, levels)
+    smp = AwsmSampler(sampler.get("address_mode_u", 1), sampler.get("address_mode_v", 1), sampler.get("mag_filter", 1), sampler.get("min_filter", 1),
+                      sampler.get("mipmap_filter", 1), sampler.get("max_anisotropy", 1))
+    a = [np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 2) for x in (uv, ddx, ddy)]
+    out = np.zeros((a[0].shape[0], 4), dtype=np.float32)
+    lib().oracle_sample_grad(C.byref(arr), C.byref(smp), C.c_uint32(layer), a[0].ctypes.data_as(C.c_void_p), a[1].ctypes.data_as(C.c_void_p), a[2].ctypes.data_as(C.c_void_p),
+                             C.c_uint32(a[0].shape[0]), C.c_int(1 if anisotropic else 0), out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def sample_cube(levels, dirs: np.ndarray, lods: np.ndarray) -> np.ndarray:

@@ -15,15 +15,15 @@ def build_model(scene):
     return m
 
 
-def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0, mipmap=False):
-    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap).run(threads)
+def oracle_frame(model, lut, rows=(0, 0), has_opaque=True, threads=8, msaa=0, mipmap=False, anisotropic=False):
+    return oracle_lib.frame_from_model(model, lut, rows=rows, has_opaque=has_opaque, msaa=msaa, mipmap=mipmap, anisotropic=anisotropic).run(threads)
 
 
-def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False, transparent=False, hud=False):
+def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap=False, transparent=False, hud=False, anisotropic=False, general_shade_only=False):
     """Drive one frame through the C-ABI exactly as the host layer does: create+write every mirror, then the passes."""
     from awsm_renderer_amd.hip_backend import HipDevice
     sc = model.scene
-    dev = dev or HipDevice(parity_tap=True)
+    dev = dev or HipDevice(parity_tap=True, anisotropic=anisotropic, general_shade_only=general_shade_only)
     dev.resize(sc.width, sc.height, msaa)
     dev.upload_mirrors(model.mirrors())
     for i, t in enumerate(model.texture_arrays()):

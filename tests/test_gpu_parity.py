@@ -518,6 +518,36 @@ def test_gradient_mipmaps(name, msaa, oracle_lut):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,msaa,transparent", [("atrium", 0, False), ("zoo", 0, True), ("atrium", 4, False), ("helmet", 0, False)])
+def test_anisotropic_probes(name, msaa, transparent, oracle_lut):
+    """AWSM_CFG_ANISOTROPIC: MipmapMode::Gradient honours the samplers' max_anisotropy (16 on every linear sampler of these scenes, as the reference's glTF
+    ingest sets it) — N = clamp(rho_max / rho_min, 1, 16), the level for rho_max / N, weighted probes along the major axis (tests/test_anisotropic_cpu.py
+    holds the rule's properties; here the HIP samplers against the oracle's, same parity bar, opaque and transparent pass).  Draws with such samplers
+    leave the lean route under the flag: the general kernels' <2> instantiations carry the probes."""
+    sc = {"helmet": lambda: scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=256),
+          "atrium": lambda: scenes.atrium_scene(641, 363, detail=0.25, tex_scale=1 / 8),
+          "zoo": lambda: scenes.material_zoo_scene(400, 300)}[name]()
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut, msaa=msaa, mipmap=True, anisotropic=True)
+    dev, stats = helpers.hip_frame(model, oracle_lut, msaa=msaa, mipmap=True, anisotropic=True, transparent=transparent)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["alpha_mismatch"] == 0 and r["f16_max_ulp"] <= 2, r
+    if transparent:
+        orc.forward(model.collect_transparent_draws())
+        c = helpers.compare_composite(orc, dev)
+        assert c["pixels_over_2ulp"] <= c["touched_pixels"] // 200 and c["pixels_over_bound"] <= c["touched_pixels"] // 200, c
+    if name == "atrium" and msaa == 0:      # the probes must matter: a visible share of the frame differs from the isotropic rule's
+        iso = helpers.oracle_frame(model, oracle_lut, mipmap=True)
+        assert float((np.abs(iso.rgba32f - orc.rgba32f).max(axis=-1) > 2e-3).mean()) > 0.02
+        # ... and a context without the flag still renders the isotropic frame with the same samplers
+        dev2, _ = helpers.hip_frame(model, oracle_lut, mipmap=True)
+        r2 = helpers.compare_frames(iso, dev2, rgb_tol=RGB_TOL)
+        assert r2["rgb_over_tol"] == 0, r2
+        dev2.close()
+    dev.close()
+
+
+@pytest.mark.gpu
 def test_reference_default_anti_aliasing_through_host_layer(oracle_lut):
     """AntiAliasing::default() = {msaa_sample_count: Some(4), mipmap: true} (anti_alias.rs:28-38) through the C++ host: the
     host generates every array's mip chain with the per-role kinds and selects the MSAA + gradient pipeline."""

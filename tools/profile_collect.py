@@ -1,12 +1,14 @@
 """Turn gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/.
+Usage: tools/profile_collect.py <tag> [<name under profiles/> mode]   ("mode": a tools/profile_mode.sh directory of another bench mode — not copied to latest_pmc.json)
 
   profiles/<tag>_bench.json            the bench line
   profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of the same command
   profiles/<tag>_pmc.json              per-kernel mean counters per launch + derived HBM traffic
 """
 import csv, glob, json, os, shutil, sys, collections
-tag = sys.argv[1]
-src = f"gpurun_out/{tag}"
+src = f"gpurun_out/{sys.argv[1]}"
+tag = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
+mode_only = len(sys.argv) > 3 and sys.argv[3] == "mode"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
@@ -38,13 +40,14 @@ doc = {"tag": tag, "workload": bench["config"], "kernels": out}
 # weighted by the issue classes tools/valu_probe.hip measured on gfx950: full rate 1 (= 2 cycles per wave64 instruction: the part's
 # 157 TFLOP/s of vector FP32 are 32 FMA lanes per SIMD and clock), half rate 1.8, transcendental 3.5 (tools/isa_cost.py).
 try:
+    if mode_only: raise RuntimeError("mode profile")
     import subprocess, tempfile
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import isa_cost
     mix = {}
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "awsm-renderer_amd", "csrc")
     flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function --cuda-device-only -S".split()
-    for src, kernels in (("kernels_shade.hip", {"awsm::k_shade_lean<false, false, false>": "k_shade_leanILb0ELb0ELb0", "awsm::k_shade<false>": "k_shadeILb0"}),
+    for src, kernels in (("kernels_shade.hip", {"awsm::k_shade_lean<false, false, false>": "k_shade_leanILb0ELb0ELb0", "awsm::k_shade<0>": "k_shadeILi0"}),
                          ("kernels_geometry.hip", {"awsm::k_raster_tile<1>": "k_raster_tileILi1"})):
         with tempfile.TemporaryDirectory() as td:
             asm = os.path.join(td, "k.s")
@@ -57,5 +60,5 @@ try:
 except Exception as e:      # no compiler here: the bench falls back to 4 cycles per instruction
     print("valu_mix not computed:", e)
 json.dump(doc, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
-shutil.copy(f"profiles/{tag}_pmc.json", "profiles/latest_pmc.json")
+if not mode_only: shutil.copy(f"profiles/{tag}_pmc.json", "profiles/latest_pmc.json")
 print(json.dumps({k: {n: v[n] for n in ("hbm_traffic_bytes", "FETCH_SIZE", "WRITE_SIZE") if n in v} for k, v in out.items()}, indent=1))
