@@ -48,7 +48,7 @@ def build_hip(jobs: int = 3, arch: str = "gfx950") -> str:
 # Kernels that must be placed beside a running k_shade_lean (80 VGPRs x 6 waves per SIMD: one exiting lean workgroup leaves 112 registers per
 # SIMD free) — the next frame's geometry kernels and the previous frame's k_shade_todo — keep within that, or the overlapped pipeline falls back
 # to running them after the lean kernel has drained (kernels_shade.hip: k_shade_todo).  Read from the code object's metadata after every build.
-VGPR_BUDGETS = {"kernels_shade.o": {"k_shade_leanILb0ELb0ELb0E": 80, "k_shade_todoILi0ELb0E": 112},
+VGPR_BUDGETS = {"kernels_shade.o": {"k_shade_leanILb0ELi0ELb0E": 80, "k_shade_todoILi0ELb0E": 112},
                 "kernels_geometry.o": {"k_deform_transformILb0E": 80, "k_binILb0E": 112, "k_binILb1E": 112, "k_bin_bigILb0E": 112, "k_bin_scan": 112, "k_raster_tileILi1E": 112,
                                        "k_handoff_signal": 32, "k_handoff_wait": 32}}
 

@@ -919,7 +919,8 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
         L.metallic = 0.0f; L.roughness = 0.0f; L.normal_scale = 1.0f; L.occlusion_strength = 1.0f;
         for (int j = 0; j < 3; j++) { L.base_color[j] = 0.0f; L.emissive[j] = 0.0f; }
         for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; for (int j = 0; j < 4; j++) L.gtex[k][j] = 0u; }
-        bool lean_grad = true;
+        bool lean_grad = true, lean_aniso = true;      // ... under MipmapMode::Gradient; ... with anisotropic probes too: one max_anisotropy for all its textures
+        uint32_t aniso = 0u;
         bool lean = shader_id == 1u && (mm[16] & 1u) == 0u && M[b + 38] == 0u;     // PBR, not a hud mesh, no debug view
         if (lean) {
             const uint32_t fi = b + 39u;
@@ -945,13 +946,17 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                     for (uint32_t l = 0; l < levels; l++) chain_texels += (unsigned long long)arr.layers * max(arr.width >> l, 1u) * max(arr.height >> l, 1u);
                     const bool ok = s.width == s.height && (s.flags & (32u | 64u)) == (32u | 64u) && levels >= 1u && levels <= 15u && levels <= lw + 1u && arr.layers < 4096u &&
                                     chain_texels * 4ull < 0xFFFFFFF0ull && (abase >> 48) == 0ull && (abase & 3ull) == 0ull;
-                    if (!ok || (f.aniso && ((s.layer_levels >> 16) & 31u) > 1u)) lean_grad = false;      // (anisotropic probes: the general sampler)
+                    if (!ok) lean_grad = false;
+                    const uint32_t an = max((s.layer_levels >> 16) & 31u, 1u);
+                    if (aniso != 0u && an != aniso) lean_aniso = false;
+                    aniso = an;
                     L.gtex[k][0] = (uint32_t)abase; L.gtex[k][1] = (uint32_t)(abase >> 32) | (levels << 16) | (lw << 24);
                     L.gtex[k][2] = layer; L.gtex[k][3] = arr.layers;
                 }
             }
             if (lean) {
-                L.flags = 1u | (lean_grad ? 2u : 0u) | (exists << 8);
+                L.flags = 1u | (lean_grad ? 2u : 0u) | (lean_grad && lean_aniso ? 4u : 0u) | (exists << 8);
+                L.pad1 = f.aniso ? max(aniso, 1u) : 1u;      // max_anisotropy of the draw's textures (k_shade_lean<.., 2, ..>)
                 // factors ready for raw 0..255 bilinear sums wherever the texture exists (LeanDrawDev)
                 const float k255 = 1.0f / 255.0f;
                 const float s_base = (exists & 1u) ? k255 : 1.0f, s_mr = (exists & 2u) ? k255 : 1.0f, s_em = (exists & 16u) ? k255 : 1.0f;
@@ -1983,7 +1988,7 @@ template <int BYTE> AWSM_DI float channel(const TapG& t, const Weights& wl, cons
 //     a pixel carry the same centre-evaluated G-buffer texel and sample 0's coordinates), i.e. give the colour back to within one f32 rounding of 3c;
 //   * per pixel the STRICT normal and the depth of sample 0 (FrameDev.msaa_cells) for k_msaa_detect's neighbour comparison;
 //   * the colour in the image, and for a pixel in either mask also as f32 in msaa_color0, where k_shade_msaa_resolve picks it up if the pixel is resolved.
-template <bool GRAD, bool MSAA>
+template <int GRAD, bool MSAA>
 AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
     const uint32_t lane = tid & 63u;
     const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
@@ -2069,13 +2074,14 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     // ---- STRICT: what fs_main wrote for this pixel ----
     TriSetup t;
     tri_rec_unpack(raw, t);
-    const GBufferTexel g = reconstruct_core<GRAD>(t, n0, n1, n2, t0, t1, t2, cx, cy);
+    const GBufferTexel g = reconstruct_core<(GRAD != 0)>(t, n0, n1, n2, t0, t1, t2, cx, cy);
     // the detector's operands, before the wavefront may leave for the general kernel: the cells are this kernel's
     if (MSAA && hit) f.msaa_cells[pv] = make_uint2(oct_word(mk2(g.packed_nt.x, g.packed_nt.y)), key.y);
     const float bz = (1.0f - g.bx) - g.by;                               // compute.wgsl:185-186
     const float u = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.z), __uint_as_float(ts1.x), __uint_as_float(ts1.z));
     const float v = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.w), __uint_as_float(ts1.y), __uint_as_float(ts1.w));
     float m2 = 0.0f;      // MipmapMode::Gradient: max(|d uv / dx|^2, |d uv / dy|^2), get_uv_derivatives (helpers/mipmap.wgsl:113-205) as attr_uv<true> forms it
+    float r2min = 0.0f; f2 major = {0.0f, 0.0f};      // GRAD == 2 (AWSM_CFG_ANISOTROPIC): the smaller of the two and the longer derivative (grad_footprint)
     if (GRAD) {
         const float x0 = __uint_as_float(ts0.z), y0 = __uint_as_float(ts0.w), x1 = __uint_as_float(ts1.x), y1 = __uint_as_float(ts1.y), x2 = __uint_as_float(ts1.z), y2 = __uint_as_float(ts1.w);
         const float dAlphaDx = g.bary_derivs.x, dAlphaDy = g.bary_derivs.y, dBetaDx = g.bary_derivs.z, dBetaDy = g.bary_derivs.w;
@@ -2085,9 +2091,12 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         const bool tiny = (fabsf(dAlphaDx) + fabsf(dAlphaDy) + fabsf(dBetaDx) + fabsf(dBetaDy)) < 1e-20f;
         const bool ok = (ddx.x == ddx.x) && (ddx.y == ddx.y) && (ddy.x == ddy.x) && (ddy.y == ddy.y);   // NaN guard
         if (tiny || !ok) { ddx = {0.0f, 0.0f}; ddy = {0.0f, 0.0f}; }
-        m2 = fmaxf(ddx.x * ddx.x + ddx.y * ddx.y, ddy.x * ddy.x + ddy.y * ddy.y);
+        const float rx2 = ddx.x * ddx.x + ddx.y * ddx.y, ry2 = ddy.x * ddy.x + ddy.y * ddy.y;
+        m2 = fmaxf(rx2, ry2);
+        if (GRAD == 2) { r2min = fminf(rx2, ry2); major = rx2 >= ry2 ? ddx : ddy; }
     }
-    // beyond +-32768 the general sampler's range guard decides (also NaN): the wavefront goes to the general kernel
+    // beyond +-32768 the general sampler's range guard decides (also NaN): the wavefront goes to the general kernel (the probes of an anisotropic
+    // footprint stay within 1 / 2 of the major axis of the centre: a footprint that long is beyond every chain's last level anyway)
     bool todo = __builtin_amdgcn_ballot_w64(hit && !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f)) != 0ull;
 
     asm volatile("; MARK fetch");
@@ -2102,60 +2111,76 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     uint32_t exists;
     lean::Tap tp0, tp1, tp2, tp3, tp4;
     lean::TapG tg0, tg1, tg2, tg3, tg4;                                   // MipmapMode::Gradient: two levels per texture
-    if (one_draw) {
-        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
-        const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
-        const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
-        const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u), L5s = cload<u32x2>(f.draw_lean, lo + 88u);
-        todo = todo || (L0.x & (GRAD ? 3u : 1u)) != (GRAD ? 3u : 1u);
-        const uint32_t ex = todo ? 0u : L0.x >> 8;                        // scalar
-        if (GRAD) {
-            const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
-            const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
-            if (ex & 1u) lean::fetch_trilinear(lean::decode_g(G0.x, G0.y, G0.z, G0.w), m2, u, v, tg0);
-            if (ex & 2u) lean::fetch_trilinear(lean::decode_g(G1.x, G1.y, G1.z, G1.w), m2, u, v, tg1);
-            if (ex & 4u) lean::fetch_trilinear(lean::decode_g(G2.x, G2.y, G2.z, G2.w), m2, u, v, tg2);
-            if (ex & 8u) lean::fetch_trilinear(lean::decode_g(G3.x, G3.y, G3.z, G3.w), m2, u, v, tg3);
-            if (ex & 16u) lean::fetch_trilinear(lean::decode_g(G4.x, G4.y, G4.z, G4.w), m2, u, v, tg4);
+    constexpr uint32_t kNeed = GRAD == 2 ? 7u : (GRAD ? 3u : 1u);        // LeanDrawDev.flags: lean, ... under MipmapMode::Gradient, ... with anisotropic probes
+    // One probe of the footprint: every texel fetch of the pixel at (uu, vv) with the level chosen for m2e.  Called once (the centre) — and, on a context
+    // that honours max_anisotropy, once more for every further probe (below).
+    auto fetch_all = [&](float uu, float vv, float m2e) {
+        if (one_draw) {
+            const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
+            const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
+            const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
+            const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u), L5s = cload<u32x2>(f.draw_lean, lo + 88u);
+            todo = todo || (L0.x & kNeed) != kNeed;
+            const uint32_t ex = todo ? 0u : L0.x >> 8;                        // scalar
+            if (GRAD) {
+                const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
+                const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
+                if (ex & 1u) lean::fetch_trilinear(lean::decode_g(G0.x, G0.y, G0.z, G0.w), m2e, uu, vv, tg0);
+                if (ex & 2u) lean::fetch_trilinear(lean::decode_g(G1.x, G1.y, G1.z, G1.w), m2e, uu, vv, tg1);
+                if (ex & 4u) lean::fetch_trilinear(lean::decode_g(G2.x, G2.y, G2.z, G2.w), m2e, uu, vv, tg2);
+                if (ex & 8u) lean::fetch_trilinear(lean::decode_g(G3.x, G3.y, G3.z, G3.w), m2e, uu, vv, tg3);
+                if (ex & 16u) lean::fetch_trilinear(lean::decode_g(G4.x, G4.y, G4.z, G4.w), m2e, uu, vv, tg4);
+            } else {
+                if (ex & 1u) lean::fetch_s(lean::decode_s(L3.x, L3.y), uu, vv, tp0);
+                if (ex & 2u) lean::fetch_s(lean::decode_s(L3.z, L3.w), uu, vv, tp1);
+                if (ex & 4u) lean::fetch_s(lean::decode_s(L4.x, L4.y), uu, vv, tp2);
+                if (ex & 8u) lean::fetch_s(lean::decode_s(L4.z, L4.w), uu, vv, tp3);
+                if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), uu, vv, tp4);
+            }
+            exists = ex;
+            metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
+            base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
+            emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
         } else {
-            if (ex & 1u) lean::fetch_s(lean::decode_s(L3.x, L3.y), u, v, tp0);
-            if (ex & 2u) lean::fetch_s(lean::decode_s(L3.z, L3.w), u, v, tp1);
-            if (ex & 4u) lean::fetch_s(lean::decode_s(L4.x, L4.y), u, v, tp2);
-            if (ex & 8u) lean::fetch_s(lean::decode_s(L4.z, L4.w), u, v, tp3);
-            if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), u, v, tp4);
+            const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
+            const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
+            const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
+            const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u), L5s = gload<u32x2>(f.draw_lean, lo + 88u);
+            todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & kNeed) != kNeed) != 0ull;
+            const uint32_t ex = (todo || !hit) ? 0u : L0.x >> 8;
+            if (GRAD) {
+                const u32x4 G0 = gload<u32x4>(f.draw_lean, lo + 96u), G1 = gload<u32x4>(f.draw_lean, lo + 112u), G2 = gload<u32x4>(f.draw_lean, lo + 128u);
+                const u32x4 G3 = gload<u32x4>(f.draw_lean, lo + 144u), G4 = gload<u32x4>(f.draw_lean, lo + 160u);
+                if (ex & 1u) lean::fetch_trilinear(lean::decode_gl(G0.x, G0.y, G0.z, G0.w), m2e, uu, vv, tg0);
+                if (ex & 2u) lean::fetch_trilinear(lean::decode_gl(G1.x, G1.y, G1.z, G1.w), m2e, uu, vv, tg1);
+                if (ex & 4u) lean::fetch_trilinear(lean::decode_gl(G2.x, G2.y, G2.z, G2.w), m2e, uu, vv, tg2);
+                if (ex & 8u) lean::fetch_trilinear(lean::decode_gl(G3.x, G3.y, G3.z, G3.w), m2e, uu, vv, tg3);
+                if (ex & 16u) lean::fetch_trilinear(lean::decode_gl(G4.x, G4.y, G4.z, G4.w), m2e, uu, vv, tg4);
+            } else {
+                const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
+                if (ex & 1u) lean::fetch(x0, uu, vv, tp0);
+                if (ex & 2u) lean::fetch(x1, uu, vv, tp1);
+                if (ex & 4u) lean::fetch(x2, uu, vv, tp2);
+                if (ex & 8u) lean::fetch(x3, uu, vv, tp3);
+                if (ex & 16u) lean::fetch(x4, uu, vv, tp4);
+            }
+            exists = ex;
+            metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
+            base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
+            emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
         }
-        exists = ex;
-        metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
-        base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
-        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
-    } else {
-        const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
-        const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
-        const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
-        const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u), L5s = gload<u32x2>(f.draw_lean, lo + 88u);
-        todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & (GRAD ? 3u : 1u)) != (GRAD ? 3u : 1u)) != 0ull;
-        const uint32_t ex = (todo || !hit) ? 0u : L0.x >> 8;
-        if (GRAD) {
-            const u32x4 G0 = gload<u32x4>(f.draw_lean, lo + 96u), G1 = gload<u32x4>(f.draw_lean, lo + 112u), G2 = gload<u32x4>(f.draw_lean, lo + 128u);
-            const u32x4 G3 = gload<u32x4>(f.draw_lean, lo + 144u), G4 = gload<u32x4>(f.draw_lean, lo + 160u);
-            if (ex & 1u) lean::fetch_trilinear(lean::decode_gl(G0.x, G0.y, G0.z, G0.w), m2, u, v, tg0);
-            if (ex & 2u) lean::fetch_trilinear(lean::decode_gl(G1.x, G1.y, G1.z, G1.w), m2, u, v, tg1);
-            if (ex & 4u) lean::fetch_trilinear(lean::decode_gl(G2.x, G2.y, G2.z, G2.w), m2, u, v, tg2);
-            if (ex & 8u) lean::fetch_trilinear(lean::decode_gl(G3.x, G3.y, G3.z, G3.w), m2, u, v, tg3);
-            if (ex & 16u) lean::fetch_trilinear(lean::decode_gl(G4.x, G4.y, G4.z, G4.w), m2, u, v, tg4);
-        } else {
-            const lean::Tex x0 = lean::decode(L3.x, L3.y), x1 = lean::decode(L3.z, L3.w), x2 = lean::decode(L4.x, L4.y), x3 = lean::decode(L4.z, L4.w), x4 = lean::decode(L5.x, L5.y);
-            if (ex & 1u) lean::fetch(x0, u, v, tp0);
-            if (ex & 2u) lean::fetch(x1, u, v, tp1);
-            if (ex & 4u) lean::fetch(x2, u, v, tp2);
-            if (ex & 8u) lean::fetch(x3, u, v, tp3);
-            if (ex & 16u) lean::fetch(x4, u, v, tp4);
+    };
+    float nf = 1.0f;                                                       // grad_footprint's N; the level is chosen for rho_max / N
+    if (GRAD == 2) {
+        const uint32_t A = one_draw ? cload<uint32_t>(f.draw_lean, d0 * (uint32_t)sizeof(LeanDrawDev) + 92u) : gload<uint32_t>(f.draw_lean, draw * (uint32_t)sizeof(LeanDrawDev) + 92u);
+        if (A > 1u && m2 > 0.0f) {
+            const float Af = (float)min(A, 16u);
+            nf = r2min * (Af * Af) <= m2 ? Af : __builtin_sqrtf(m2 / r2min);
+            nf = fminf(fmaxf(nf, 1.0f), Af);
         }
-        exists = ex;
-        metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
-        base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
-        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
     }
+    const float m2c = GRAD == 2 ? m2 * fm::rcp(nf * nf) : m2;
+    fetch_all(u, v, m2c);
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
         if (lane == 0u) {
             const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
@@ -2164,6 +2189,44 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         return;
     }
     if (!hit) return;
+
+    // ---- AWSM_CFG_ANISOTROPIC: the twelve raw channel values (0..255) the material reads, averaged over grad_footprint's probes — the centre (weight 1),
+    // then pairs at +-j / N along the major axis, each weighted by the part of the footprint its cell covers (zero beyond the lane's own
+    // m = ceil((N - 1) / 2): the wavefront walks to its longest footprint), normalised.  Before anything else of the pixel is computed: the loop is where
+    // the registers go. ----
+    float ch[12] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (GRAD == 2) {
+#define AWSM_LEAN_ACC(I, K, BYTE) ch[I] += lean::channel<BYTE>(tg##K, wl, wh) * wj
+        auto accumulate = [&](float wj) {
+            if (exists & 1u) { const lean::Weights wl = lean::weights(tg0.lo), wh = lean::weights(tg0.hi); AWSM_LEAN_ACC(0, 0, 0); AWSM_LEAN_ACC(1, 0, 1); AWSM_LEAN_ACC(2, 0, 2); }
+            if (exists & 2u) { const lean::Weights wl = lean::weights(tg1.lo), wh = lean::weights(tg1.hi); AWSM_LEAN_ACC(3, 1, 2); AWSM_LEAN_ACC(4, 1, 1); }
+            if (exists & 4u) { const lean::Weights wl = lean::weights(tg2.lo), wh = lean::weights(tg2.hi); AWSM_LEAN_ACC(5, 2, 0); AWSM_LEAN_ACC(6, 2, 1); AWSM_LEAN_ACC(7, 2, 2); }
+            if (exists & 8u) { const lean::Weights wl = lean::weights(tg3.lo), wh = lean::weights(tg3.hi); AWSM_LEAN_ACC(8, 3, 0); }
+            if (exists & 16u) { const lean::Weights wl = lean::weights(tg4.lo), wh = lean::weights(tg4.hi); AWSM_LEAN_ACC(9, 4, 0); AWSM_LEAN_ACC(10, 4, 1); AWSM_LEAN_ACC(11, 4, 2); }
+        };
+#undef AWSM_LEAN_ACC
+        accumulate(1.0f);
+        const float mf_ = ceilf((nf - 1.0f) * 0.5f);
+        int wave_m = 0;
+#pragma unroll
+        for (int j = 1; j <= 8; j++) if (__builtin_amdgcn_ballot_w64(mf_ >= (float)j) != 0ull) wave_m = j;
+        if (wave_m) {
+            const float inv_n = fm::rcp(nf);
+            float wsum = 1.0f;
+            for (int j = 1; j <= wave_m; j++) {
+                const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f);
+                for (int sgn = 0; sgn < 2; sgn++) {
+                    const float ts = sgn ? -tj : tj;
+                    fetch_all(u + major.x * ts, v + major.y * ts, m2c);
+                    accumulate(wj);
+                }
+                wsum += 2.0f * wj;
+            }
+            const float iw = fm::rcp(wsum);
+#pragma unroll
+            for (int i = 0; i < 12; i++) ch[i] *= iw;
+        }
+    }
 
     asm volatile("; MARK standard");
     // ---- standard.wgsl:11-62 (as shade_surface) ----
@@ -2200,18 +2263,29 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     // one texture's channel BYTE: bilinear on level 0 (MipmapMode::None) or the blend of two levels' bilinear values (MipmapMode::Gradient)
 #define AWSM_LEAN_TEX(K, W0, W1) const lean::Weights W0 = lean::weights(GRAD ? tg##K.lo : tp##K), W1 = lean::weights(GRAD ? tg##K.hi : tp##K)
 #define AWSM_LEAN_CH(K, BYTE, W0, W1) (GRAD ? lean::channel<BYTE>(tg##K, W0, W1) : lean::channel<BYTE>(tp##K, W0))
-    if (exists & 1u) { AWSM_LEAN_TEX(0, w, wh); base = {base.x * AWSM_LEAN_CH(0, 0, w, wh), base.y * AWSM_LEAN_CH(0, 1, w, wh), base.z * AWSM_LEAN_CH(0, 2, w, wh)}; }
-    if (exists & 2u) { AWSM_LEAN_TEX(1, w, wh); metallic_in = metallic_in * AWSM_LEAN_CH(1, 2, w, wh); roughness_in = roughness_in * AWSM_LEAN_CH(1, 1, w, wh); }
     f3 normal = tbn.N;
-    if (exists & 4u) {   // material_color_calc.wgsl:301-322
-        AWSM_LEAN_TEX(2, w, wh);
-        // (c * 2 - 1) * scale on raw texels: raw * (2 scale / 255) - scale (LeanDrawDev)
-        const float ntx = AWSM_LEAN_CH(2, 0, w, wh) * normal_scale - normal_bias, nty = AWSM_LEAN_CH(2, 1, w, wh) * normal_scale - normal_bias, ntz = AWSM_LEAN_CH(2, 2, w, wh) * (2.0f / 255.0f) - 1.0f;
-        normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
-    }
     float occlusion = 1.0f;
-    if (exists & 8u) { AWSM_LEAN_TEX(3, w, wh); occlusion = AWSM_LEAN_CH(3, 0, w, wh) * occlusion_strength + occlusion_bias; }      // mix(1, r, s)
-    if (exists & 16u) { AWSM_LEAN_TEX(4, w, wh); emissive = {emissive.x * AWSM_LEAN_CH(4, 0, w, wh), emissive.y * AWSM_LEAN_CH(4, 1, w, wh), emissive.z * AWSM_LEAN_CH(4, 2, w, wh)}; }
+    if (GRAD != 2) {
+        if (exists & 1u) { AWSM_LEAN_TEX(0, w, wh); base = {base.x * AWSM_LEAN_CH(0, 0, w, wh), base.y * AWSM_LEAN_CH(0, 1, w, wh), base.z * AWSM_LEAN_CH(0, 2, w, wh)}; }
+        if (exists & 2u) { AWSM_LEAN_TEX(1, w, wh); metallic_in = metallic_in * AWSM_LEAN_CH(1, 2, w, wh); roughness_in = roughness_in * AWSM_LEAN_CH(1, 1, w, wh); }
+        if (exists & 4u) {   // material_color_calc.wgsl:301-322
+            AWSM_LEAN_TEX(2, w, wh);
+            // (c * 2 - 1) * scale on raw texels: raw * (2 scale / 255) - scale (LeanDrawDev)
+            const float ntx = AWSM_LEAN_CH(2, 0, w, wh) * normal_scale - normal_bias, nty = AWSM_LEAN_CH(2, 1, w, wh) * normal_scale - normal_bias, ntz = AWSM_LEAN_CH(2, 2, w, wh) * (2.0f / 255.0f) - 1.0f;
+            normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
+        }
+        if (exists & 8u) { AWSM_LEAN_TEX(3, w, wh); occlusion = AWSM_LEAN_CH(3, 0, w, wh) * occlusion_strength + occlusion_bias; }      // mix(1, r, s)
+        if (exists & 16u) { AWSM_LEAN_TEX(4, w, wh); emissive = {emissive.x * AWSM_LEAN_CH(4, 0, w, wh), emissive.y * AWSM_LEAN_CH(4, 1, w, wh), emissive.z * AWSM_LEAN_CH(4, 2, w, wh)}; }
+    } else {
+        if (exists & 1u) base = {base.x * ch[0], base.y * ch[1], base.z * ch[2]};
+        if (exists & 2u) { metallic_in = metallic_in * ch[3]; roughness_in = roughness_in * ch[4]; }
+        if (exists & 4u) {
+            const float ntx = ch[5] * normal_scale - normal_bias, nty = ch[6] * normal_scale - normal_bias, ntz = ch[7] * (2.0f / 255.0f) - 1.0f;
+            normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
+        }
+        if (exists & 8u) occlusion = ch[8] * occlusion_strength + occlusion_bias;
+        if (exists & 16u) emissive = {emissive.x * ch[9], emissive.y * ch[10], emissive.z * ch[11]};
+    }
 #undef AWSM_LEAN_TEX
 #undef AWSM_LEAN_CH
 
@@ -2302,14 +2376,19 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 // has kLeanCounters of them on separate cache lines, counter c handing out the strips c, c + kLeanCounters, ...; a wavefront
 // starts on counter w % kLeanCounters and moves on when it runs dry.  The request for the next strip is issued before the current
 // one is shaded.  No barrier, no LDS.
+// k_shade_lean<.., 2, ..> (anisotropic probes): 200 registers as compiled.  Two wavefronts per SIMD without a spill beat three with 51-72 spilled
+// registers (975 against 823 frames/s at 4K, 707 against 558 with MSAA).
+#ifndef AWSM_ANISO_WAVES
+#define AWSM_ANISO_WAVES 2
+#endif
 #ifndef AWSM_LEAN_COUNTERS
 #define AWSM_LEAN_COUNTERS 8
 #endif
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
 // GRAD: MipmapMode::Gradient (the reference's default): barycentric derivatives, isotropic LOD, two levels per texture — a separate instantiation, as the
 // reference keeps separate pipelines; its ten footprints in flight want more registers than six waves per SIMD leave.
-template <bool PERSIST, bool GRAD, bool MSAA>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD ? 4 : (PERSIST ? 5 : AWSM_LEAN_WAVES)))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+template <bool PERSIST, int GRAD, bool MSAA>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? AWSM_ANISO_WAVES : (GRAD ? 4 : (PERSIST ? 5 : AWSM_LEAN_WAVES))))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ LeanStage stage[4];                                         // one per wavefront (no barrier anywhere: the four are independent)
     if (frame_poisoned(f)) return;
     LeanStage* const st = &stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
@@ -2829,8 +2908,7 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
     const uint32_t bx_n = (f->width + 15u) >> 4, by_n = f->band_n > 1u ? 2u * f->tiles_y : ((f->sy1 - f->sy0) + 15u) >> 4;
     const uint32_t nb = 8u * ((by_n + 7u) / 8u) * bx_n;   // every XCD gets ceil(by_n / 8) rows of ids; surplus ids exit
     if (!nb) return;
-    const bool grad = f->mipmap != 0u;      // MipmapMode::Gradient vs None: separate instantiations, as the reference keeps separate pipelines
-    const int g = mip_mode(f);
+    const int g = mip_mode(f);      // MipmapMode::None / Gradient / Gradient + anisotropy: separate instantiations, as the reference keeps separate pipelines
     const bool msaa = f->msaa == 4u;
     if (awsm_shade_is_lean(f)) {
         // the lean kernel over the screen (a wavefront per strip id on a power-of-two block pitch: the padding exits), then the general code for the
@@ -2838,11 +2916,13 @@ extern "C" void awsm_launch_shade(const awsm::DevScene* sc, const awsm::FrameDev
         uint32_t pitch = 1; while (pitch < bx_n) pitch <<= 1;
         const uint32_t nb_ids = 8u * ((by_n + 7u) / 8u) * pitch;
         if (msaa) {
-            if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
-            else hipLaunchKernelGGL((awsm::k_shade_lean<false, false, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
-        } else if (grad) hipLaunchKernelGGL((awsm::k_shade_lean<false, true, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
-        else if (f->lean_grid && f->lean_next) hipLaunchKernelGGL((awsm::k_shade_lean<true, false, false>), dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
-        else hipLaunchKernelGGL((awsm::k_shade_lean<false, false, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+            if (g == 2) hipLaunchKernelGGL((awsm::k_shade_lean<false, 2, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+            else if (g == 1) hipLaunchKernelGGL((awsm::k_shade_lean<false, 1, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+            else hipLaunchKernelGGL((awsm::k_shade_lean<false, 0, true>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+        } else if (g == 2) hipLaunchKernelGGL((awsm::k_shade_lean<false, 2, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+        else if (g == 1) hipLaunchKernelGGL((awsm::k_shade_lean<false, 1, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
+        else if (f->lean_grid && f->lean_next) hipLaunchKernelGGL((awsm::k_shade_lean<true, 0, false>), dim3(min(f->lean_grid, nb_ids)), dim3(256), 0, s, sc, *f);
+        else hipLaunchKernelGGL((awsm::k_shade_lean<false, 0, false>), dim3(nb_ids), dim3(256), 0, s, sc, *f);
         return;
     }
     if (msaa) {

@@ -58,7 +58,7 @@ def algorithmic_bytes(scene, stats, rows):
     }
 
 
-SHADE_KERNELS = ("k_shade_lean<false, false, false>", "k_shade_lean<false>", "k_shade_lean", "k_shade", "k_shade<false>", "k_shade<0>")      # profile names of the single-sample, MipmapMode::None opaque kernel
+SHADE_KERNELS = ("k_shade_lean<false, 0, false>", "k_shade_lean<false, false, false>", "k_shade_lean<false>", "k_shade_lean", "k_shade", "k_shade<false>", "k_shade<0>")      # profile names of the single-sample, MipmapMode::None opaque kernel
 
 
 def pmc_profile(n_tris, W, H):

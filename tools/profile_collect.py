@@ -47,7 +47,7 @@ try:
     mix = {}
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "awsm-renderer_amd", "csrc")
     flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function --cuda-device-only -S".split()
-    for src, kernels in (("kernels_shade.hip", {"awsm::k_shade_lean<false, false, false>": "k_shade_leanILb0ELb0ELb0", "awsm::k_shade<0>": "k_shadeILi0"}),
+    for src, kernels in (("kernels_shade.hip", {"awsm::k_shade_lean<false, 0, false>": "k_shade_leanILb0ELi0ELb0", "awsm::k_shade<0>": "k_shadeILi0"}),
                          ("kernels_geometry.hip", {"awsm::k_raster_tile<1>": "k_raster_tileILi1"})):
         with tempfile.TemporaryDirectory() as td:
             asm = os.path.join(td, "k.s")
