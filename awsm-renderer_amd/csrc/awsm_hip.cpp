@@ -43,6 +43,7 @@ void awsm_launch_count_covered(const FrameDev* f, hipStream_t s);
 void awsm_launch_msaa_halo_export(const FrameDev* f, unsigned long long* dst, uint32_t bands_out, hipStream_t s);
 void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, unsigned long long* out, hipStream_t s);
 void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s);
+void awsm_launch_cube_border(const awsm::CubeDev* cd, uint2* out, uint32_t total, hipStream_t s);
 void awsm_launch_rgba16f_to_rg16f(const uint16_t* in, uint32_t* out, uint32_t n, hipStream_t s);
 }
 
@@ -103,7 +104,7 @@ struct AwsmHipCtx {
     bool scene_dirty = true;
     DevBuf tex[kMaxTexArrays];
     DevBuf lut;
-    DevBuf cube_tex[3];
+    DevBuf cube_tex[3], cube_bordered[3];      // the uploaded chains; the same with a one-texel apron per face (CubeDev.bordered)
 
     // frame targets
     uint32_t width = 0, height = 0;
@@ -952,7 +953,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    fr(c->lut); for (auto& b : c->cube_tex) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); for (int sl = 0; sl < kSlots; sl++) { fr(c->msaa_color0[sl]); fr(c->msaa_edges[sl]); fr(c->msaa_edge_bits[sl]); fr(c->msaa_cells[sl]); } fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
+    fr(c->lut); for (auto& b : c->cube_tex) fr(b); for (auto& b : c->cube_bordered) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); for (int sl = 0; sl < kSlots; sl++) { fr(c->msaa_color0[sl]); fr(c->msaa_edges[sl]); fr(c->msaa_edge_bits[sl]); fr(c->msaa_cells[sl]); } fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
     for (int k = 0; k < 3 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : c->hud[k - 2 * kSlots]);
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
@@ -1197,6 +1198,7 @@ int awsm_hip_env_cube_upload(AwsmHipCtx* c, AwsmCube which, uint32_t size, uint3
         int rc = sync_all(c);
         if (rc) return rc;
         rc = dev_realloc(c, c->cube_tex[which], 0, false);
+        if (!rc) rc = dev_realloc(c, c->cube_bordered[which], 0, false);
         if (rc) return rc;
         c->scene.cube[which] = cd;
         c->scene_dirty = true;
@@ -1208,9 +1210,16 @@ int awsm_hip_env_cube_upload(AwsmHipCtx* c, AwsmCube which, uint32_t size, uint3
     for (uint32_t l = 0; l < mips; l++) { cd.level_off[l] = (uint32_t)total; const size_t n = std::max(1u, size >> l); total += 6 * n * n; }
     int rc = dev_realloc(c, c->cube_tex[which], total * 8, false);
     if (rc) return rc;
+    size_t b_total = 0;
+    for (uint32_t l = 0; l < mips; l++) { cd.b_level_off[l] = (uint32_t)b_total; const size_t n = std::max(1u, size >> l) + 2; b_total += 6 * n * n; }
+    if (b_total >= (1ull << 29)) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_cube_upload: the chain does not fit 32-bit byte offsets");
+    rc = dev_realloc(c, c->cube_bordered[which], b_total * 8, false);
+    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->cube_tex[which].ptr, texels, total * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // `texels` is not retained
     cd.texels = (const uint2*)c->cube_tex[which].ptr; cd.size = size; cd.mips = mips;
+    awsm_launch_cube_border(&cd, (uint2*)c->cube_bordered[which].ptr, (uint32_t)b_total, c->stream);      // the apron, from the faces across the edges
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // `texels` is not retained
+    cd.bordered = (const uint2*)c->cube_bordered[which].ptr;
     c->scene.cube[which] = cd;
     c->scene_dirty = true;
     return AWSM_OK;

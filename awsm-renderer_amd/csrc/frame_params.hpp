@@ -110,6 +110,11 @@ struct CubeDev {
     const uint2* texels;              // 4 halfs per texel
     uint32_t size, mips;
     uint32_t level_off[kMaxMipLevels];    // first texel of each level
+    // The same chain with a one-texel apron around every face ((N + 2)^2 texels per face), filled from the faces across the edges by the seam rule of
+    // sample_cube (k_cube_border): a bilinear footprint never leaves its face's array, so the lean kernels sample with two 16-byte loads per level and
+    // no adjacency logic (lean::cube_sample).  Null until k_cube_border has run.
+    const uint2* bordered;
+    uint32_t b_level_off[kMaxMipLevels];
 };
 enum { kCubeSkybox = 0, kCubePrefiltered = 1, kCubeIrradiance = 2 };
 

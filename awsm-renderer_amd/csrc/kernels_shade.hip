@@ -594,7 +594,7 @@ AWSM_DI f2 sample_brdf_lut(const DevScene* sc, float n_dot_v, float roughness) {
 // kCubeEdge[face][edge: 0 left (i = -1), 1 right (i = N), 2 up (j = -1), 3 down (j = N)] = face' | swap << 3 | flip << 4 | far << 5:
 // the running coordinate k (j for left / right, i for up / down), reversed if flip, becomes j' (swap) or i'; the other one is N - 1 (far) or 0.
 __device__ const uint8_t kCubeEdge[6][4] = {{44, 13, 58, 43}, {45, 12, 10, 27}, {1, 16, 21, 4}, {49, 32, 36, 53}, {41, 8, 34, 3}, {40, 9, 18, 51}};
-AWSM_DI f4 cube_texel(const CubeDev& c, uint32_t level_base, int N, uint32_t face, int i, int j) {
+AWSM_DI uint2 cube_texel_raw(const CubeDev& c, uint32_t level_base, int N, uint32_t face, int i, int j) {
     if (i < 0 || i >= N) j = min(max(j, 0), N - 1);     // corner taps keep their row
     if (i < 0 || i >= N || j < 0 || j >= N) {
         const uint32_t e = i < 0 ? 0u : (i >= N ? 1u : (j < 0 ? 2u : 3u));
@@ -605,8 +605,19 @@ AWSM_DI f4 cube_texel(const CubeDev& c, uint32_t level_base, int N, uint32_t fac
         face = t & 7u;
         if (t & 8u) { i = far; j = k; } else { i = k; j = far; }
     }
-    const uint2 h = c.texels[level_base + ((size_t)face * (size_t)N + (size_t)j) * (size_t)N + (size_t)i];
-    return {f16_bits_to_f32((unsigned short)(h.x & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.x >> 16)), f16_bits_to_f32((unsigned short)(h.y & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.y >> 16))};
+    return c.texels[level_base + ((size_t)face * (size_t)N + (size_t)j) * (size_t)N + (size_t)i];
+}
+AWSM_DI f4 half4(uint2 h) { return {f16_bits_to_f32((unsigned short)(h.x & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.x >> 16)), f16_bits_to_f32((unsigned short)(h.y & 0xFFFFu)), f16_bits_to_f32((unsigned short)(h.y >> 16))}; }
+AWSM_DI f4 cube_texel(const CubeDev& c, uint32_t level_base, int N, uint32_t face, int i, int j) { return half4(cube_texel_raw(c, level_base, N, face, i, j)); }
+// CubeDev.bordered: one thread per texel of the aproned chain
+__global__ __launch_bounds__(256) void k_cube_border(CubeDev c, uint2* __restrict__ out, uint32_t total) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total) return;
+    uint32_t level = 0u;
+    while (level + 1u < c.mips && idx >= c.b_level_off[level + 1u]) level++;
+    const int N = (int)max(c.size >> level, 1u), P = N + 2;
+    const uint32_t r = idx - c.b_level_off[level], face = r / (uint32_t)(P * P), q = r % (uint32_t)(P * P);
+    out[idx] = cube_texel_raw(c, c.level_off[level], N, face, (int)(q % (uint32_t)P) - 1, (int)(q / (uint32_t)P) - 1);
 }
 AWSM_DI f4 cube_level(const CubeDev& c, uint32_t level, f3 d) {
     const int N = (int)max(c.size >> level, 1u);
@@ -1965,6 +1976,58 @@ template <typename BASE> AWSM_DI void fetch_g(const TexGT<BASE>& x, uint32_t lev
         t.t10 = gload_any<uint32_t>(x.base, r0); t.t11 = gload_any<uint32_t>(x.base, r1);
     }
 }
+// textureSampleLevel on a cube through its aproned chain (CubeDev.bordered; k_cube_border filled the apron by sample_cube's seam rule, so the values and
+// the weights are sample_cube's): the cube's record by scalar loads, the face by sample_cube's table, then per level two 16-byte loads (two adjacent
+// RGBA16F texels of a row each) and the lerps.  `which` is a compile-time cube id.
+AWSM_DI f4 cube_level_b(const void* base, const void* scene, uint32_t which, uint32_t size, uint32_t level, uint32_t face, float sn, float tn) {
+    const uint32_t N = max(size >> level, 1u), P = N + 2u;
+    const uint32_t lvl0 = gload<uint32_t>(scene, (uint32_t)(offsetof(DevScene, cube) + which * sizeof(CubeDev) + offsetof(CubeDev, b_level_off)) + level * 4u);
+    float x = sn * (float)N - 0.5f, y = tn * (float)N - 0.5f;                 // sn, tn = 0.5 (sc / ma) + 0.5
+    if (!(x >= -0.5f)) x = -0.5f;                 // also NaN (zero / non-finite direction): the face's first texel
+    if (!(y >= -0.5f)) y = -0.5f;
+    x = fminf(x, (float)N - 0.5f); y = fminf(y, (float)N - 0.5f);
+    const float flx = floorf(x), fly = floorf(y), fx = x - flx, fy = y - fly;
+    const uint32_t ib = (uint32_t)((int)flx + 1), jb = (uint32_t)((int)fly + 1);      // apron coordinates of the footprint's first texel: 0 .. N
+    const uint32_t t0 = (lvl0 + (face * P + jb) * P + ib) << 3;
+    typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+    const u32x4a8 r0 = gload<u32x4a8>(base, t0), r1 = gload<u32x4a8>(base, t0 + (P << 3));
+    const f4 c00 = half4(make_uint2(r0.x, r0.y)), c10 = half4(make_uint2(r0.z, r0.w)), c01 = half4(make_uint2(r1.x, r1.y)), c11 = half4(make_uint2(r1.z, r1.w));
+    return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
+}
+template <uint32_t WHICH>
+AWSM_DI f4 cube_sample(const DevScene* sc, f3 d, float level) {
+    const uint32_t o = (uint32_t)(offsetof(DevScene, cube) + WHICH * sizeof(CubeDev));
+    const u32x2 bp = cload<u32x2>(sc, o + (uint32_t)offsetof(CubeDev, bordered));
+    const u32x2 sm = cload<u32x2>(sc, o + (uint32_t)offsetof(CubeDev, size));
+    const void* base = reinterpret_cast<const void*>(((unsigned long long)bp.y << 32) | bp.x);
+    const uint32_t size = sm.x, mips = sm.y;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    uint32_t face; float scd, tcd, ma;
+    if (az >= ax && az >= ay) { face = d.z < 0.0f ? 5u : 4u; scd = d.z < 0.0f ? -d.x : d.x; tcd = -d.y; ma = az; }
+    else if (ay >= ax) { face = d.y < 0.0f ? 3u : 2u; scd = d.x; tcd = d.y < 0.0f ? -d.z : d.z; ma = ay; }
+    else { face = d.x < 0.0f ? 1u : 0u; scd = d.x < 0.0f ? d.z : -d.z; tcd = -d.y; ma = ax; }
+    const float inv = fm::rcp(ma);
+    const float sn = 0.5f * (scd * inv) + 0.5f, tn = 0.5f * (tcd * inv) + 0.5f;
+    const float top = (float)(mips - 1u);
+    float lod = level > 0.0f ? level : 0.0f;          // also NaN
+    lod = fminf(lod, top);
+    const float fl = floorf(lod), fr = lod - fl;
+    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, mips - 1u);
+    f4 r = cube_level_b(base, sc, WHICH, size, l0, face, sn, tn);
+    if (__builtin_amdgcn_ballot_w64(fr > 0.0f && l1 != l0) != 0ull) { const f4 h = cube_level_b(base, sc, WHICH, size, l1, face, sn, tn); if (fr > 0.0f && l1 != l0) r = lerp4(r, h, fr); }
+    return r;
+}
+AWSM_DI f3 irradiance(const DevScene* sc, f3 n) {          // brdf.wgsl:268-276
+    if (!sc->cube[kCubeIrradiance].bordered) return sample_irradiance(sc, n);      // (uniform colour; scalar branch)
+    const f4 c = cube_sample<kCubeIrradiance>(sc, n, 0.0f);
+    return {c.x, c.y, c.z};
+}
+AWSM_DI f3 prefiltered(const DevScene* sc, f3 dir, float roughness) {      // brdf.wgsl:278-290
+    if (!sc->cube[kCubePrefiltered].bordered) return sample_prefiltered(sc, dir, roughness);
+    const uint32_t mip_count = cload<uint32_t>(sc->buf[AWSM_BUF_LIGHTS_INFO], 4u);      // IblInfo.prefiltered_env_mip_count (lights.rs:300-305)
+    const f4 c = cube_sample<kCubePrefiltered>(sc, dir, roughness * (float)(mip_count - 1u));
+    return {c.x, c.y, c.z};
+}
 struct TapG { Tap lo, hi; float f; };
 // both levels of a texture: the second only when some lane of the wavefront blends (f > 0) — a magnified strip fetches level 0 once
 template <typename BASE> AWSM_DI void fetch_trilinear(const TexGT<BASE>& x, float m2, float u, float v, TapG& t) {
@@ -2321,8 +2384,8 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     asm volatile("; MARK ibl");
     {   // brdf_ibl (brdf.wgsl:517-576): the uniform cubes of the builder default, or texel cubes (brdf.wgsl:268-290: irradiance at level 0 along N,
         // prefiltered at roughness * (mips - 1) along R) through the shared seam-aware sampler
-        const f3 prefiltered = sample_prefiltered(sc, reflect3(-sf.v, sf.n), sf.roughness);
-        const f3 irradiance = sample_irradiance(sc, sf.n);
+        const f3 prefiltered = lean::prefiltered(sc, reflect3(-sf.v, sf.n), sf.roughness);
+        const f3 irradiance = lean::irradiance(sc, sf.n);
         const float n_dot_v = sf.n_dot_v_ibl;
         const f3 F_view = fresnel_schlick_f90(n_dot_v, sf.F0, sf.f90);
         const float F_view_max = fmaxf(fmaxf(F_view.x, F_view.y), F_view.z);
@@ -2978,6 +3041,10 @@ extern "C" void awsm_launch_vis_digest(const unsigned long long* vis, size_t n, 
 }
 extern "C" void awsm_launch_pick(const awsm::DevScene* sc, const awsm::FrameDev* f, int x, int y, uint32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_pick, dim3(1), dim3(1), 0, s, sc, *f, x, y, out);
+}
+// cd: the cube with b_level_off filled and `texels` uploaded; out: room for `total` texels (the aproned chain)
+extern "C" void awsm_launch_cube_border(const awsm::CubeDev* cd, uint2* out, uint32_t total, hipStream_t s) {
+    if (total) hipLaunchKernelGGL(awsm::k_cube_border, dim3((total + 255u) / 256u), dim3(256), 0, s, *cd, out, total);
 }
 extern "C" void awsm_launch_brdf_lut(uint32_t* out_rg16f, uint32_t w, uint32_t h, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_brdf_lut, dim3((w + 15u) / 16u, (h + 15u) / 16u), dim3(256), 0, s, out_rg16f, w, h);
