@@ -2177,14 +2177,15 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     constexpr uint32_t kNeed = GRAD == 2 ? 7u : (GRAD ? 3u : 1u);        // LeanDrawDev.flags: lean, ... under MipmapMode::Gradient, ... with anisotropic probes
     // One probe of the footprint: every texel fetch of the pixel at (uu, vv) with the level chosen for m2e.  Called once (the centre) — and, on a context
     // that honours max_anisotropy, once more for every further probe (below).
-    auto fetch_all = [&](float uu, float vv, float m2e) {
+    auto fetch_all = [&](float uu, float vv, float m2e, bool act) {      // act: this lane takes the probe (always true for the centre)
         if (one_draw) {
             const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
             const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
             const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
             const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u), L5s = cload<u32x2>(f.draw_lean, lo + 88u);
             todo = todo || (L0.x & kNeed) != kNeed;
-            const uint32_t ex = todo ? 0u : L0.x >> 8;                        // scalar
+            const uint32_t exs = todo ? 0u : L0.x >> 8;                       // scalar
+            const uint32_t ex = act ? exs : 0u;
             if (GRAD) {
                 const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
                 const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
@@ -2200,7 +2201,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
                 if (ex & 8u) lean::fetch_s(lean::decode_s(L4.z, L4.w), uu, vv, tp3);
                 if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), uu, vv, tp4);
             }
-            exists = ex;
+            exists = exs;
             metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
             base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
             emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
@@ -2210,7 +2211,8 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
             const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
             const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u), L5s = gload<u32x2>(f.draw_lean, lo + 88u);
             todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & kNeed) != kNeed) != 0ull;
-            const uint32_t ex = (todo || !hit) ? 0u : L0.x >> 8;
+            const uint32_t exs = (todo || !hit) ? 0u : L0.x >> 8;
+            const uint32_t ex = act ? exs : 0u;
             if (GRAD) {
                 const u32x4 G0 = gload<u32x4>(f.draw_lean, lo + 96u), G1 = gload<u32x4>(f.draw_lean, lo + 112u), G2 = gload<u32x4>(f.draw_lean, lo + 128u);
                 const u32x4 G3 = gload<u32x4>(f.draw_lean, lo + 144u), G4 = gload<u32x4>(f.draw_lean, lo + 160u);
@@ -2227,7 +2229,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
                 if (ex & 8u) lean::fetch(x3, uu, vv, tp3);
                 if (ex & 16u) lean::fetch(x4, uu, vv, tp4);
             }
-            exists = ex;
+            exists = exs;
             metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
             base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
             emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
@@ -2243,7 +2245,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         }
     }
     const float m2c = GRAD == 2 ? m2 * fm::rcp(nf * nf) : m2;
-    fetch_all(u, v, m2c);
+    fetch_all(u, v, m2c, true);
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
         if (lane == 0u) {
             const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
@@ -2280,7 +2282,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
                 const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f);
                 for (int sgn = 0; sgn < 2; sgn++) {
                     const float ts = sgn ? -tj : tj;
-                    fetch_all(u + major.x * ts, v + major.y * ts, m2c);
+                    fetch_all(u + major.x * ts, v + major.y * ts, m2c, wj > 0.0f);
                     accumulate(wj);
                 }
                 wsum += 2.0f * wj;
