@@ -734,6 +734,52 @@ AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int
     }
 }
 
+// raster_walk_i32<4, 4> from a WorkSmall record whose e is E - bias at the CORNER of the first pixel of the first 4x4 block: a sample adds its own
+// constant (a ox + b oy) / 256 (a, b: multiples of 256), three adds, one OR3 and one compare per sample.
+AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, int lx, int ly) {
+    const uint32_t bb = g.bbox, r = g.rank, bw = g.bias;
+    const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+    int e[3], bias[3], sx[3], sy[3], d[4][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int a = g.a[i], b = g.b[i];      // |.| < 2^23
+        bias[i] = (int)((bw >> i) & 1u);
+        e[i] = g.e[i] + __mul24(lx, a) + __mul24(ly, b);
+        sx[i] = a << 2; sy[i] = b << 2;
+        const int ai = a >> 8, bi = b >> 8;    // exact: multiples of 256
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k][i] = __mul24(ai, msaa4_x(k)) + __mul24(bi, msaa4_y(k));
+    }
+    const float zq0 = g.zq[0], zq1 = g.zq[1], zq2 = g.zq[2];
+    const uint32_t dx = (uint32_t)(x1 - x0);
+    const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
+    for (int by = y0 & ~3; by <= y1; by += 4) {
+        const int py = by + ly;
+        const bool row_in = py >= y0 && py <= y1;
+        int r0 = e[0], r1 = e[1], r2 = e[2];
+        uint32_t ux = (uint32_t)((x0 & ~3) + lx - x0);
+        unsigned long long* row = keys + (py * kTile + x0) * 4;
+        for (int bx = x0 & ~3; bx <= x1; bx += 4) {
+            if (ux <= dx && row_in) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
+                    if ((q0 | q1 | q2) >= 0) {
+                        const float e0 = (float)(q0 + bias[0]), e1 = (float)(q1 + bias[1]), e2 = (float)(q2 + bias[2]);
+                        float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
+                        if (zn >= 0.0f && zn <= 1.0f) {
+                            if (zn == 0.0f) zn = 0.0f;
+                            atomicMin(&row[ux * 4u + (uint32_t)k], ((unsigned long long)__float_as_uint(zn) << 32) | key_lo);
+                        }
+                    }
+                }
+            }
+            r0 += sx[0]; r1 += sx[1]; r2 += sx[2]; ux += 4u;
+        }
+        e[0] += sy[0]; e[1] += sy[1]; e[2] += sy[2];
+    }
+}
+
 template <int S, int STEP>
 AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
     if (t.small) { raster_walk_i32<S, STEP>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r); return; }
@@ -831,9 +877,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
                     } else {
                         const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : (kBatch - 1u) - atomicAdd(&n_big, 1u);
                         const uint32_t bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
-                        if (S == 1 && area <= 256 && t.small) {
+                        if (area <= 256 && t.small) {
                             WorkSmall& g = reinterpret_cast<WorkSmall&>(work[slot]);
-                            const double X = (double)(tpx + ((x0 - tpx) & ~3)) + 0.5, Y = (double)(tpy + ((y0 - tpy) & ~3)) + 0.5;
+                            const double half = S == 1 ? 0.5 : 0.0;      // one sample: the pixel's centre; four: its corner, the samples add their own offsets
+                            const double X = (double)(tpx + ((x0 - tpx) & ~3)) + half, Y = (double)(tpy + ((y0 - tpy) & ~3)) + half;
                             uint32_t bw = 0u;
 #pragma unroll
                             for (int i = 0; i < 3; i++) {
@@ -847,7 +894,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
                             WorkTri& g = work[slot];
 #pragma unroll
                             for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
-                            g.rank = r; g.exact = (t.small && !(S == 1 && area <= 256)) ? 2u : (t.exact ? 1u : 0u);
+                            g.rank = r; g.exact = (t.small && !(area <= 256)) ? 2u : (t.exact ? 1u : 0u);
                             g.bbox = bbox;
                         }
                     }
@@ -864,7 +911,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
             const int lx = (int)(tid & 3u), ly = (int)((tid >> 2) & 3u);
             for (uint32_t j = group; j < nm; ) {
                 const WorkTri& g = work[j];
-                if (S == 1 && g.exact == 2u) raster_walk_small(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly);      // (every mid entry marked 2 is a WorkSmall)
+                if (g.exact == 2u) { if (S == 1) raster_walk_small(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly); else raster_walk_small4(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly); }      // (every mid entry marked 2 is a WorkSmall)
                 else {
                 TriSetup t;
                 load_work_tri(g, t);
