@@ -1103,7 +1103,15 @@ extern "C" void awsm_launch_bin_big(const awsm::FrameDev* f, int fill, hipStream
     if (fill) return;       // the fill pass walks them inside k_bin<true> (awsm_launch_bin_fill)
     hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
 }
+// experiment (AWSM_DEBUG_CHAIN_PAD_US): one idle wavefront that holds its stream for so many microseconds — is the frame bound by the length of the
+// geometry stream's chain of launches, or by what the kernels of both streams need of the machine?
+__global__ void k_debug_pad(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
+    static const long pad_us = getenv("AWSM_DEBUG_CHAIN_PAD_US") ? atol(getenv("AWSM_DEBUG_CHAIN_PAD_US")) : 0;
+    if (pad_us > 0) hipLaunchKernelGGL(k_debug_pad, dim3(1), dim3(64), 0, s, (unsigned long long)pad_us * 100ull);      // wall_clock64: 100 MHz
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (n_tiles) hipLaunchKernelGGL(awsm::k_bin_scan, dim3((n_tiles + awsm::kScanThreads - 1u) / awsm::kScanThreads), dim3(awsm::kScanThreads), 0, s, *f, n_tiles);
 }
