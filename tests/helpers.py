@@ -53,11 +53,11 @@ def hip_frame(model, lut, rows=(0, 0), has_opaque=True, dev=None, msaa=0, mipmap
     return dev, stats
 
 
-def host_frame(scene, lut, rows=(0, 0), msaa=0, mipmap=False, gltf=None):
+def host_frame(scene, lut, rows=(0, 0), msaa=0, mipmap=False, gltf=None, anisotropic=False):
     """The product path: SceneDesc (or a glTF file) -> C++ host layer (key API, mirrors, dirty uploads) -> C-ABI -> HIP kernels."""
     from awsm_renderer_amd.hip_backend import HipDevice
     from awsm_renderer_amd.host import Renderer
-    r = Renderer(scene, parity_tap=True, lut_rgba16f=oracle_lib.lut_rg_to_rgba16f(lut), msaa=msaa, mipmap=mipmap, gltf=gltf)
+    r = Renderer(scene, parity_tap=True, lut_rgba16f=oracle_lib.lut_rg_to_rgba16f(lut), msaa=msaa, mipmap=mipmap, gltf=gltf, anisotropic=anisotropic)
     if rows != (0, 0):
         r.host.set_shard_rows(*rows)
     stats = r.render(sync=True)

@@ -548,6 +548,22 @@ def test_anisotropic_probes(name, msaa, transparent, oracle_lut):
 
 
 @pytest.mark.gpu
+def test_anisotropic_probes_through_the_host_layer_and_a_glb_file(oracle_lut, tmp_path):
+    """The product path with AWSM_CFG_ANISOTROPIC: SceneDesc -> .glb (samplers carry max_anisotropy) -> native reader -> C++ host layer -> HIP kernels,
+    against the oracle fed from the same scene."""
+    from awsm_renderer_amd import gltf_export
+    sc = scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=256)
+    path = str(tmp_path / "helmet.glb")
+    gltf_export.write_glb(sc, path)
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut, mipmap=True, anisotropic=True)
+    r, dev, stats = helpers.host_frame(sc, oracle_lut, mipmap=True, gltf=path, anisotropic=True)
+    res = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert res["key_mismatch"] == 0 and res["rgb_over_tol"] == 0 and res["f16_max_ulp"] <= 2, res
+    r.close()
+
+
+@pytest.mark.gpu
 def test_reference_default_anti_aliasing_through_host_layer(oracle_lut):
     """AntiAliasing::default() = {msaa_sample_count: Some(4), mipmap: true} (anti_alias.rs:28-38) through the C++ host: the
     host generates every array's mip chain with the per-role kinds and selects the MSAA + gradient pipeline."""
