@@ -59,6 +59,11 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, int n, float 
         if (KIND == 45) { REP8(asm volatile("v_fma_f32 %0, %0, %0, s4\n v_fma_f32 %1, %1, s5, %1\n v_mul_f32 %2, s6, %2\n v_add_f32 %3, s7, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
         if (KIND == 46) { REP8(asm volatile("v_fma_f32 %0, |%0|, %0, -%1\n v_fma_f32 %1, %1, %1, %2 clamp\n v_mul_f32_e64 %2, %2, %3 clamp\n v_add_f32_e64 %3, |%3|, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
         if (KIND == 47) { REP8(asm volatile("v_perm_b32 %0, %0, %1, %2\n v_alignbit_b32 %1, %1, %2, 8\n v_perm_b32 %2, %2, %3, %0\n v_alignbit_b32 %3, %3, %0, 16" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+        if (KIND == 51) { REP8(asm volatile("v_perm_b32 %0, %0, %1, %2\n v_perm_b32 %1, %1, %2, %3\n v_perm_b32 %2, %2, %3, %0\n v_perm_b32 %3, %3, %0, %1" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+        if (KIND == 52) { REP8(asm volatile("v_dot2_u32_u16 %0, %0, %1, %2\n v_dot2_u32_u16 %1, %1, %2, %3\n v_dot2_u32_u16 %2, %2, %3, %0\n v_dot2_u32_u16 %3, %3, %0, %1" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+        if (KIND == 53) { REP8(asm volatile("v_dot4_u32_u8 %0, %0, %1, %2\n v_dot4_u32_u8 %1, %1, %2, %3\n v_dot4_u32_u8 %2, %2, %3, %0\n v_dot4_u32_u8 %3, %3, %0, %1" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+        if (KIND == 54) { REP8(asm volatile("v_mad_u32_u16 %0, %0, %1, %2\n v_mad_u32_u16 %1, %1, %2, %3\n v_mad_u32_u16 %2, %2, %3, %0\n v_mad_u32_u16 %3, %3, %0, %1" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
+        if (KIND == 55) { REP8(asm volatile("v_dot2_f32_f16 %0, %4, %5, %0\n v_dot2_f32_f16 %1, %5, %6, %1\n v_dot2_f32_f16 %2, %6, %7, %2\n v_dot2_f32_f16 %3, %7, %4, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));) }
         if (KIND == 48) { REP8(asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_i32 %1, %5\n v_cvt_u32_f32 %6, %2\n v_cvt_f32_u32 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
         if (KIND == 49) { REP8(asm volatile("v_sub_u32 %0, %0, %1\n v_subrev_u32 %1, %1, %2\n v_min_u32 %2, %2, %3\n v_max_i32 %3, %3, %0" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));) }
         if (KIND == 50) { REP8(asm volatile("v_readfirstlane_b32 s4, %0\n v_readfirstlane_b32 s5, %1\n v_readfirstlane_b32 s6, %2\n v_readfirstlane_b32 s7, %3" : : "v"(u0), "v"(u1), "v"(u2), "v"(u3) : "s4", "s5", "s6", "s7");) }
@@ -135,6 +140,11 @@ int main() {
     run<45>("v_fma/mul/add with SGPR operand", dout);
     run<46>("fma/mul/add with abs/neg/clamp modifiers", dout);
     run<47>("v_perm_b32 / v_alignbit_b32", dout);
+    run<51>("v_perm_b32", dout);
+    run<52>("v_dot2_u32_u16", dout);
+    run<53>("v_dot4_u32_u8", dout);
+    run<54>("v_mad_u32_u16", dout);
+    run<55>("v_dot2_f32_f16", dout);
     run<48>("v_cvt_f32_u32/i32, v_cvt_u32_f32", dout);
     run<49>("v_sub_u32 / v_min_u32 / v_max_i32", dout);
     run<50>("v_readfirstlane_b32", dout);
