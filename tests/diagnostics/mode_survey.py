@@ -40,6 +40,9 @@ MODES = {
     "atrium_mips": (lambda: scenes.atrium_scene(640, 360, detail=0.35, tex_scale=1 / 16), inside_atrium, {"mipmap": True}),
     "atrium_msaa_mips": (lambda: scenes.atrium_scene(640, 360, detail=0.35, tex_scale=1 / 16), inside_atrium, {"msaa": 4, "mipmap": True}),
     "zoo_mips": (lambda: scenes.material_zoo_scene(640, 360), lambda: orbit_eye((0, 0, 0), 1.2, 6.0), {"mipmap": True}),
+    "atrium_aniso": (lambda: scenes.atrium_scene(640, 360, detail=0.35, tex_scale=1 / 8), inside_atrium, {"mipmap": True, "anisotropic": True}),
+    "atrium_msaa_aniso": (lambda: scenes.atrium_scene(640, 360, detail=0.35, tex_scale=1 / 8), inside_atrium, {"msaa": 4, "mipmap": True, "anisotropic": True}),
+    "zoo_aniso": (lambda: scenes.material_zoo_scene(640, 360), lambda: orbit_eye((0, 0, 0), 1.2, 6.0), {"mipmap": True, "anisotropic": True}),
     "transparent": (lambda: scenes.transparent_scene(640, 360), lambda: orbit_eye((0, -0.3, 0), 1.5, 7.0), {"transparent": True}),
     "transparent_msaa": (lambda: scenes.transparent_scene(640, 360), lambda: orbit_eye((0, -0.3, 0), 1.5, 7.0), {"transparent": True, "msaa": 4}),
 }
@@ -55,7 +58,7 @@ def survey(n_views, only=(), lut=None, seed=20260105):
         kw = dict(kw)
         sc = make()
         transparent = kw.pop("transparent", False)
-        dev = HipDevice(parity_tap=True)
+        dev = HipDevice(parity_tap=True, anisotropic=bool(kw.get("anisotropic")))      # AWSM_CFG_ANISOTROPIC is a property of the context
         for k in range(n_views):
             eye, tgt = viewpoint()
             sc.view, sc.camera_position = look_at_rh(eye, tgt), eye

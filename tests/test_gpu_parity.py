@@ -950,7 +950,8 @@ def test_random_viewpoints_gbuffer_exact_and_routes_agree(oracle_lut):
 def test_random_viewpoints_in_every_mode(oracle_lut):
     """The same idea through the other modes (tests/diagnostics/mode_survey.py): three random viewpoints each around the material zoo (every optional
     PBR block, unlit, debug views, sampler modes, point + spot lights; single-sampled and with gradient mipmaps), the helmet, the skinned + morphed
-    strip, inside the atrium with MSAA x4 / gradient mipmaps / both, and around the transparent scene with its forward pass (single-sampled, MSAA).
+    strip, inside the atrium with MSAA x4 / gradient mipmaps / both / anisotropic probes, and around the transparent scene with its forward pass
+    (single-sampled, MSAA).
     Vertices, keys and (single-sampled modes) the reconstructed G-buffer texel bit-exact in every view; colours within the CONDITIONED bound in every
     pixel (1e-4 * max(1, |ref|) + what 16 ulps of input noise do to the oracle's own colour there: helpers.compare_frames, OracleFrame.conditioning), the
     RGBA16F image within two f16 steps wherever the pixel is well conditioned, and at most a handful of pixels per view needing their condition number;
