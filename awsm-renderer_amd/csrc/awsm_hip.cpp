@@ -412,8 +412,8 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->draw_mat = (DrawMatDev*)FB(c).draw_mat.ptr;
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
-    // The lean opaque route (k_shade_lean): single-sampled frames whose per-triangle / per-vertex / attribute byte offsets fit 32 bits
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (c->msaa == 0 || (c->msaa_edge_bits[c->slot].ptr && c->msaa_cells[c->slot].ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    // The lean opaque route (k_shade_lean): frames whose per-pixel key / per-triangle / per-vertex / attribute byte offsets fit 32 bits
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (uint64_t)c->width * c->height * (c->msaa == 4 ? 32u : 8u) < (1ull << 32) && (c->msaa == 0 || (c->msaa_edge_bits[c->slot].ptr && c->msaa_cells[c->slot].ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->attr_data_bytes = (uint32_t)std::min<size_t>(c->bufs[AWSM_BUF_ATTR_DATA].size, 0xFFFFFFFFu);
