@@ -1212,14 +1212,14 @@ int awsm_hip_env_cube_upload(AwsmHipCtx* c, AwsmCube which, uint32_t size, uint3
     if (rc) return rc;
     size_t b_total = 0;
     for (uint32_t l = 0; l < mips; l++) { cd.b_level_off[l] = (uint32_t)b_total; const size_t n = std::max(1u, size >> l) + 2; b_total += 6 * n * n; }
-    if (b_total >= (1ull << 29)) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "env_cube_upload: the chain does not fit 32-bit byte offsets");
-    rc = dev_realloc(c, c->cube_bordered[which], b_total * 8, false);
+    const bool aproned = b_total < (1ull << 29);      // byte offsets into the aproned chain are 32-bit; a larger cube keeps the general sampler on the lean route too
+    rc = dev_realloc(c, c->cube_bordered[which], aproned ? b_total * 8 : 0, false);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->cube_tex[which].ptr, texels, total * 8, hipMemcpyHostToDevice, c->stream));
     cd.texels = (const uint2*)c->cube_tex[which].ptr; cd.size = size; cd.mips = mips;
-    awsm_launch_cube_border(&cd, (uint2*)c->cube_bordered[which].ptr, (uint32_t)b_total, c->stream);      // the apron, from the faces across the edges
+    if (aproned) awsm_launch_cube_border(&cd, (uint2*)c->cube_bordered[which].ptr, (uint32_t)b_total, c->stream);      // the apron, from the faces across the edges
     HIPCHK(c, hipStreamSynchronize(c->stream));      // `texels` is not retained
-    cd.bordered = (const uint2*)c->cube_bordered[which].ptr;
+    cd.bordered = aproned ? (const uint2*)c->cube_bordered[which].ptr : nullptr;
     c->scene.cube[which] = cd;
     c->scene_dirty = true;
     return AWSM_OK;
