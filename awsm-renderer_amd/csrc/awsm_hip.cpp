@@ -1103,6 +1103,7 @@ int awsm_hip_texture_array_upload(AwsmHipCtx* c, uint32_t array_idx, uint32_t wi
     if (!c || array_idx >= (uint32_t)kMaxTexArrays || !texels || width == 0 || height == 0 || layers == 0)
         return fail(c, AWSM_ERR_INVALID_ARGUMENT, "texture_array_upload: bad argument");
     if (fmt != AWSM_TEX_RGBA8_UNORM) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: only RGBA8_UNORM");
+    if (layers > 65536u) return fail(c, AWSM_ERR_UNSUPPORTED, "texture_array_upload: %u layers (the per-draw texture records hold a 16-bit layer; WebGPU's maxTextureArrayLayers is 256..2048)", layers);
     const uint32_t full = mip_levels_full(width, height);
     if (mips == 0) mips = 1;
     if (mips > full || mips > (uint32_t)kMaxMipLevels) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "texture_array_upload: %u mip levels, a %ux%u texture has at most %u", mips, width, height, full);
