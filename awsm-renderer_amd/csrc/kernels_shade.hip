@@ -10,6 +10,13 @@
 //       materialised; the interpolants of the visible triangle are recomputed here and rounded to the
 //       reference's RG16F / RGBA16F storage formats before use, crates/renderer/src/render_textures.rs:49-54)
 //
+// In this file, in order: the STRICT G-buffer reconstruction and MSAA edge predicates; the samplers (2D arrays: level 0 / gradient mips / anisotropic
+// probes; cubes; the BRDF LUT); the material and lighting code of the general route (shade_material, shade_surface) with the transparent pass's three
+// kernels (k_forward_cover / shade / blend); k_resolve_draws; the general opaque kernels (k_shade, k_shade_todo); the lean route (k_shade_lean: level-1
+// records staged through LDS, scalar draw records, lean::fetch*, the aproned cube sampler); the MSAA kernels (k_shade_msaa, k_msaa_detect,
+// k_shade_msaa_resolve); k_brdf_lut, k_cube_border and the small service kernels; the launch wrappers.  Kernels that sample are instantiated per mip mode
+// (0 MipmapMode::None, 1 Gradient, 2 Gradient with anisotropic probes), the lean kernel also per MSAA.
+//
 // Pure gather + ALU: no MFMA.  Compulsory HBM traffic per pixel is the 8-byte key read and the 8-byte
 // RGBA16F write; everything else (vertices, metas, materials, texels) is reused across neighbouring pixels
 // and served by L1 / the XCD's L2 — workgroups are dealt to XCDs in contiguous screen runs for that.
