@@ -71,16 +71,16 @@ struct DrawMatDev {
 };
 static_assert(sizeof(DrawMatDev) == 64, "DrawMatDev must be 64 bytes");
 
-// A draw the lean opaque kernel (k_shade_lean) can shade, in 96 bytes (six 16-byte loads instead of the 21 of DrawShadeDev +
+// A draw the lean opaque kernel (k_shade_lean) can shade, in one record (instead of the 21 16-byte loads of DrawShadeDev +
 // DrawMatDev + five TexSlotDev): a PBR material with no optional block and no debug view, not a hud mesh, every core texture it
-// has on TEXCOORD_0 with an identity transform, a repeat / repeat linear sampler and power-of-two extent.  k_resolve_draws decides
+// has on TEXCOORD_0 with the same texture transform, a repeat / repeat linear sampler and power-of-two extent.  k_resolve_draws decides
 // (flags bit 0); draws that do not qualify keep the general route.
 // The factors come READY FOR RAW TEXELS: where a texture exists its factor is pre-multiplied by 1/255, so the kernel multiplies the bilinear sum of
 // the 0..255 texel values straight in — base colour, metallic / roughness, emissive: factor / 255; occlusion mix(1, r, s) = occlusion_bias + raw *
 // occlusion_strength with bias = 1 - s, strength = s / 255 (no texture: bias 1); normal map (c * 2 - 1) * scale = raw * normal_scale - normal_bias with
 // normal_scale = 2 * scale / 255, normal_bias = scale (z: raw * (2 / 255) - 1).
 struct LeanDrawDev {
-    uint32_t flags;               // bit 0: lean; bit 1: lean under MipmapMode::Gradient too (gtex valid); bits 8..12: which of the five core textures exist
+    uint32_t flags;               // bit 0: lean; bit 1: lean under MipmapMode::Gradient too (gtex valid); bit 2: ... with anisotropic probes too; bit 3: tt; bits 8..12: which of the five core textures exist
     float metallic, roughness, normal_scale;
     float base_color[3]; float occlusion_strength;
     float emissive[3];            // factor * emissive_strength
@@ -92,8 +92,12 @@ struct LeanDrawDev {
     // level l is layers * (G(lw + 1) - G(lw + 1 - l)) with G(k) = (4^k - 1) / 3 = 0x55555555 & (4^k - 1), and level l of layer i starts i << 2 (lw - l)
     // texels further: {array address bits 0..31, bits 32..47 | levels << 16 | log2(width) << 24, layer, layers}
     uint32_t gtex[kCoreTextures][4];
+    // flags bit 3: the draw's textures share ONE texture transform that is not the identity (KHR_texture_transform on every texture of a material, the
+    // usual way to tile one): m00 m01 m10 m11 bx by, applied to the pixel's TEXCOORD_0 (and its derivatives) once, before all fetches
+    float tt[6];
+    uint32_t pad2[2];
 };
-static_assert(sizeof(LeanDrawDev) == 176, "LeanDrawDev must be 176 bytes");
+static_assert(sizeof(LeanDrawDev) == 208, "LeanDrawDev must be 208 bytes");
 
 constexpr int kMaxMipLevels = 16;
 struct TexArrayDev {

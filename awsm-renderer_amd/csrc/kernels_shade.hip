@@ -933,7 +933,9 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
     if (role == 6u) {   // the lean route's record (LeanDrawDev)
         if (!f.draw_lean) return;
         LeanDrawDev L;
-        L.flags = 0u; L.normal_bias = 1.0f; L.occlusion_bias = 1.0f; L.pad1 = 0u;
+        L.flags = 0u; L.normal_bias = 1.0f; L.occlusion_bias = 1.0f; L.pad1 = 0u; L.pad2[0] = 0u; L.pad2[1] = 0u;
+        L.tt[0] = 1.0f; L.tt[1] = 0.0f; L.tt[2] = 0.0f; L.tt[3] = 1.0f; L.tt[4] = 0.0f; L.tt[5] = 0.0f;
+        bool have_tt = false;
         L.metallic = 0.0f; L.roughness = 0.0f; L.normal_scale = 1.0f; L.occlusion_strength = 1.0f;
         for (int j = 0; j < 3; j++) { L.base_color[j] = 0.0f; L.emissive[j] = 0.0f; }
         for (int k = 0; k < kCoreTextures; k++) { L.tex[k][0] = 0u; L.tex[k][1] = 0u; for (int j = 0; j < 4; j++) L.gtex[k][j] = 0u; }
@@ -950,8 +952,10 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                 const TexSlotDev s = resolve_tex_slot(sc, M, words, k, false);
                 if (!(s.flags & 1u)) continue;
                 const unsigned long long addr = (unsigned long long)s.base;
-                const bool identity = s.tt[0] == 1.0f && s.tt[1] == 0.0f && s.tt[2] == 0.0f && s.tt[3] == 1.0f && s.tt[4] == 0.0f && s.tt[5] == 0.0f;
-                if ((s.flags & 6u) != 2u || (s.flags >> 24) != 0u || !identity || s.width > 32768u || s.height > 32768u || (addr >> 48) != 0ull || (addr & 3ull) != 0ull) { lean = false; break; }
+                bool same_tt = true;      // one transform for all of the draw's textures (bit for bit; the first one's)
+                for (int j = 0; j < 6; j++) { if (!have_tt) L.tt[j] = s.tt[j]; else if (__float_as_uint(L.tt[j]) != __float_as_uint(s.tt[j])) same_tt = false; }
+                have_tt = true;
+                if ((s.flags & 6u) != 2u || (s.flags >> 24) != 0u || !same_tt || s.width > 32768u || s.height > 32768u || (addr >> 48) != 0ull || (addr & 3ull) != 0ull) { lean = false; break; }
                 exists |= 1u << k;
                 L.tex[k][0] = (uint32_t)addr;
                 L.tex[k][1] = (uint32_t)(addr >> 32) | ((uint32_t)(31 - __clz((int)s.width)) << 16) | ((uint32_t)(31 - __clz((int)s.height)) << 20);
@@ -973,7 +977,8 @@ __global__ __launch_bounds__(256) void k_resolve_draws(const DevScene* __restric
                 }
             }
             if (lean) {
-                L.flags = 1u | (lean_grad ? 2u : 0u) | (lean_grad && lean_aniso ? 4u : 0u) | (exists << 8);
+                const bool identity = L.tt[0] == 1.0f && L.tt[1] == 0.0f && L.tt[2] == 0.0f && L.tt[3] == 1.0f && L.tt[4] == 0.0f && L.tt[5] == 0.0f;
+                L.flags = 1u | (lean_grad ? 2u : 0u) | (lean_grad && lean_aniso ? 4u : 0u) | (identity ? 0u : 8u) | (exists << 8);
                 L.pad1 = f.aniso ? max(aniso, 1u) : 1u;      // max_anisotropy of the draw's textures (k_shade_lean<.., 2, ..>)
                 // factors ready for raw 0..255 bilinear sums wherever the texture exists (LeanDrawDev)
                 const float k255 = 1.0f / 255.0f;
@@ -2148,34 +2153,59 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     // the detector's operands, before the wavefront may leave for the general kernel: the cells are this kernel's
     if (MSAA && hit) f.msaa_cells[pv] = make_uint2(oct_word(mk2(g.packed_nt.x, g.packed_nt.y)), key.y);
     const float bz = (1.0f - g.bx) - g.by;                               // compute.wgsl:185-186
-    const float u = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.z), __uint_as_float(ts1.x), __uint_as_float(ts1.z));
-    const float v = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.w), __uint_as_float(ts1.y), __uint_as_float(ts1.w));
+    float u = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.z), __uint_as_float(ts1.x), __uint_as_float(ts1.z));
+    float v = interp3_strict(g.bx, g.by, bz, __uint_as_float(ts0.w), __uint_as_float(ts1.y), __uint_as_float(ts1.w));
+    const uint32_t draw = ts0.x & 0x00FFFFFFu;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)draw, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(hit)));
+    const bool one_draw = __builtin_amdgcn_ballot_w64(hit && draw != d0) == 0ull;
+    f2 ddx = {0.0f, 0.0f}, ddy = {0.0f, 0.0f};
     float m2 = 0.0f;      // MipmapMode::Gradient: max(|d uv / dx|^2, |d uv / dy|^2), get_uv_derivatives (helpers/mipmap.wgsl:113-205) as attr_uv<true> forms it
     float r2min = 0.0f; f2 major = {0.0f, 0.0f};      // GRAD == 2 (AWSM_CFG_ANISOTROPIC): the smaller of the two and the longer derivative (grad_footprint)
     if (GRAD) {
         const float x0 = __uint_as_float(ts0.z), y0 = __uint_as_float(ts0.w), x1 = __uint_as_float(ts1.x), y1 = __uint_as_float(ts1.y), x2 = __uint_as_float(ts1.z), y2 = __uint_as_float(ts1.w);
         const float dAlphaDx = g.bary_derivs.x, dAlphaDy = g.bary_derivs.y, dBetaDx = g.bary_derivs.z, dBetaDy = g.bary_derivs.w;
         const float dGammaDx = -dAlphaDx - dBetaDx, dGammaDy = -dAlphaDy - dBetaDy;
-        f2 ddx = {x0 * dAlphaDx + x1 * dBetaDx + x2 * dGammaDx, y0 * dAlphaDx + y1 * dBetaDx + y2 * dGammaDx};
-        f2 ddy = {x0 * dAlphaDy + x1 * dBetaDy + x2 * dGammaDy, y0 * dAlphaDy + y1 * dBetaDy + y2 * dGammaDy};
+        ddx = {x0 * dAlphaDx + x1 * dBetaDx + x2 * dGammaDx, y0 * dAlphaDx + y1 * dBetaDx + y2 * dGammaDx};
+        ddy = {x0 * dAlphaDy + x1 * dBetaDy + x2 * dGammaDy, y0 * dAlphaDy + y1 * dBetaDy + y2 * dGammaDy};
         const bool tiny = (fabsf(dAlphaDx) + fabsf(dAlphaDy) + fabsf(dBetaDx) + fabsf(dBetaDy)) < 1e-20f;
         const bool ok = (ddx.x == ddx.x) && (ddx.y == ddx.y) && (ddy.x == ddy.x) && (ddy.y == ddy.y);   // NaN guard
         if (tiny || !ok) { ddx = {0.0f, 0.0f}; ddy = {0.0f, 0.0f}; }
+    }
+    // The draw's shared texture transform (LeanDrawDev.tt, flags bit 3; texture_uvs.wgsl:27-35,64-84 as sample_slot applies it per texture): scalar
+    // for a strip inside one draw — a draw without one costs a scalar branch — per lane otherwise.  Here for MipmapMode::Gradient, whose level
+    // selection needs the transformed derivatives; MipmapMode::None applies it inside fetch_all, where the record's flags are loaded anyway.
+    if (GRAD == 0) {
+    } else if (one_draw) {
+        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
+        if (cload<uint32_t>(f.draw_lean, lo) & 8u) {
+            const f32x4 ta = cload<f32x4>(f.draw_lean, lo + 176u); const f32x2a4 tb = cload<f32x2a4>(f.draw_lean, lo + 192u);
+            const float u2 = affine2_strict(ta.x, ta.y, tb.x, u, v), v2 = affine2_strict(ta.z, ta.w, tb.y, u, v);
+            u = u2; v = v2;
+            if (GRAD) { ddx = {ta.x * ddx.x + ta.y * ddx.y, ta.z * ddx.x + ta.w * ddx.y}; ddy = {ta.x * ddy.x + ta.y * ddy.y, ta.z * ddy.x + ta.w * ddy.y}; }
+        }
+    } else {
+        const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
+        const bool xf = (gload<uint32_t>(f.draw_lean, lo) & 8u) != 0u;
+        if (__builtin_amdgcn_ballot_w64(xf) != 0ull) {
+            const f32x4 ta = gload<f32x4>(f.draw_lean, lo + 176u); const f32x2a4 tb = gload<f32x2a4>(f.draw_lean, lo + 192u);      // (the identity where the draw has none)
+            const float u2 = affine2_strict(ta.x, ta.y, tb.x, u, v), v2 = affine2_strict(ta.z, ta.w, tb.y, u, v);
+            if (xf) { u = u2; v = v2; }
+            if (GRAD && xf) { ddx = {ta.x * ddx.x + ta.y * ddx.y, ta.z * ddx.x + ta.w * ddx.y}; ddy = {ta.x * ddy.x + ta.y * ddy.y, ta.z * ddy.x + ta.w * ddy.y}; }
+        }
+    }
+    if (GRAD) {
         const float rx2 = ddx.x * ddx.x + ddx.y * ddx.y, ry2 = ddy.x * ddy.x + ddy.y * ddy.y;
         m2 = fmaxf(rx2, ry2);
         if (GRAD == 2) { r2min = fminf(rx2, ry2); major = rx2 >= ry2 ? ddx : ddy; }
     }
     // beyond +-32768 the general sampler's range guard decides (also NaN): the wavefront goes to the general kernel (the probes of an anisotropic
     // footprint stay within 1 / 2 of the major axis of the centre: a footprint that long is beyond every chain's last level anyway)
-    bool todo = __builtin_amdgcn_ballot_w64(hit && !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f)) != 0ull;
+    bool todo = GRAD != 0 && __builtin_amdgcn_ballot_w64(hit && !(fabsf(u) <= 32768.0f && fabsf(v) <= 32768.0f)) != 0ull;      // (MipmapMode::None: in fetch_all)
 
     asm volatile("; MARK fetch");
     // ---- levels 2 and 3: the draw's 96-byte lean record and all texel fetches of the pixel.  A strip almost always lies inside ONE draw: the record
     // then comes in by scalar loads — texture bases, extents and flags sit in scalar registers, texel addresses are 32-bit offsets from an SGPR
     // base, the branches on what the material has are scalar.  A strip that straddles draws takes the per-lane form of the same loads. ----
-    const uint32_t draw = ts0.x & 0x00FFFFFFu;
-    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)draw, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(hit)));
-    const bool one_draw = __builtin_amdgcn_ballot_w64(hit && draw != d0) == 0ull;
     f3 base, emissive;
     float metallic_in, roughness_in, normal_scale, occlusion_strength, normal_bias, occlusion_bias;
     uint32_t exists;
@@ -2190,6 +2220,14 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
             const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
             const u32x4 L3 = cload<u32x4>(f.draw_lean, lo + 48u), L4 = cload<u32x4>(f.draw_lean, lo + 64u);
             const u32x2 L5 = cload<u32x2>(f.draw_lean, lo + 80u), L5s = cload<u32x2>(f.draw_lean, lo + 88u);
+            if (GRAD == 0) {
+                if (L0.x & 8u) {
+                    const f32x4 ta = cload<f32x4>(f.draw_lean, lo + 176u); const f32x2a4 tb = cload<f32x2a4>(f.draw_lean, lo + 192u);
+                    const float u2 = affine2_strict(ta.x, ta.y, tb.x, uu, vv), v2 = affine2_strict(ta.z, ta.w, tb.y, uu, vv);
+                    uu = u2; vv = v2;
+                }
+                todo = todo || __builtin_amdgcn_ballot_w64(hit && !(fabsf(uu) <= 32768.0f && fabsf(vv) <= 32768.0f)) != 0ull;
+            }
             todo = todo || (L0.x & kNeed) != kNeed;
             const uint32_t exs = todo ? 0u : L0.x >> 8;                       // scalar
             const uint32_t ex = act ? exs : 0u;
@@ -2217,6 +2255,14 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
             const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
             const u32x4 L3 = gload<u32x4>(f.draw_lean, lo + 48u), L4 = gload<u32x4>(f.draw_lean, lo + 64u);
             const u32x2 L5 = gload<u32x2>(f.draw_lean, lo + 80u), L5s = gload<u32x2>(f.draw_lean, lo + 88u);
+            if (GRAD == 0) {
+                if (__builtin_amdgcn_ballot_w64((L0.x & 8u) != 0u) != 0ull) {
+                    const f32x4 ta = gload<f32x4>(f.draw_lean, lo + 176u); const f32x2a4 tb = gload<f32x2a4>(f.draw_lean, lo + 192u);      // (the identity where the draw has none)
+                    const float u2 = affine2_strict(ta.x, ta.y, tb.x, uu, vv), v2 = affine2_strict(ta.z, ta.w, tb.y, uu, vv);
+                    if (L0.x & 8u) { uu = u2; vv = v2; }
+                }
+                todo = todo || __builtin_amdgcn_ballot_w64(hit && !(fabsf(uu) <= 32768.0f && fabsf(vv) <= 32768.0f)) != 0ull;
+            }
             todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & kNeed) != kNeed) != 0ull;
             const uint32_t exs = (todo || !hit) ? 0u : L0.x >> 8;
             const uint32_t ex = act ? exs : 0u;

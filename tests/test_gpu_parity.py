@@ -548,6 +548,32 @@ def test_anisotropic_probes(name, msaa, transparent, oracle_lut):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["none", "mips", "msaa_mips", "aniso"])
+def test_shared_texture_transform_stays_on_the_lean_route(mode, oracle_lut):
+    """KHR_texture_transform on every texture of a material (the usual way to tile one): the lean kernel applies the draw's ONE transform to the pixel's
+    TEXCOORD_0 and its derivatives before all fetches (LeanDrawDev.tt) — no wavefront goes to the general kernel, colours within the parity bar.  With two
+    different transforms in one material the draw is not lean and the general route shades it, same bar."""
+    from awsm_renderer_amd.scene_desc import TextureRef
+    xf = {"offset": (0.13, -0.21), "origin": (0.5, 0.5), "rotation": 0.4, "scale": (2.7, 1.6)}
+    xf2 = {"offset": (0.0, 0.3), "origin": (0.0, 0.0), "rotation": -0.2, "scale": (1.5, 1.5)}
+    kw = {"none": {}, "mips": {"mipmap": True}, "msaa_mips": {"mipmap": True, "msaa": 4}, "aniso": {"mipmap": True, "anisotropic": True}}[mode]
+    for shared in (True, False):
+        ov = {"base_color_tex": TextureRef(0, transform=xf), "metallic_roughness_tex": TextureRef(1, transform=xf), "normal_tex": TextureRef(2, transform=xf),
+              "occlusion_tex": TextureRef(3, transform=xf), "emissive_tex": TextureRef(4, transform=xf if shared else xf2)}
+        sc = scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=256, material_overrides=ov)
+        model = helpers.build_model(sc)
+        orc = helpers.oracle_frame(model, oracle_lut, **kw)
+        dev, stats = helpers.hip_frame(model, oracle_lut, **kw)
+        r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+        assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["alpha_mismatch"] == 0 and r["f16_max_ulp"] <= 2, (shared, r)
+        assert (stats["shade_general_wavefronts"] == 0) == shared, (shared, stats)
+        if shared and mode == "none":      # the transform must matter: the untransformed frame differs visibly
+            base = helpers.oracle_frame(helpers.build_model(scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=256)), oracle_lut)
+            assert float(np.abs(base.rgba32f - orc.rgba32f).max()) > 0.02
+        dev.close()
+
+
+@pytest.mark.gpu
 def test_anisotropic_probes_through_the_host_layer_and_a_glb_file(oracle_lut, tmp_path):
     """The product path with AWSM_CFG_ANISOTROPIC: SceneDesc -> .glb (samplers carry max_anisotropy) -> native reader -> C++ host layer -> HIP kernels,
     against the oracle fed from the same scene."""
