@@ -571,6 +571,26 @@ def test_shared_texture_transform_stays_on_the_lean_route(mode, oracle_lut):
             base = helpers.oracle_frame(helpers.build_model(scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=256)), oracle_lut)
             assert float(np.abs(base.rgba32f - orc.rgba32f).max()) > 0.02
         dev.close()
+    # two meshes side by side, each material with a shared transform of its own (and a third without): strips that straddle draws take the per-lane
+    # form of the same code
+    import copy
+    from awsm_renderer_amd.scene_desc import NodeDesc
+    sc = scenes.helmet_scene(320, 180, segments=48, rings=36, tex_size=256, material_overrides={k: TextureRef(i, transform=xf) for i, k in enumerate(
+        ("base_color_tex", "metallic_roughness_tex", "normal_tex", "occlusion_tex", "emissive_tex"))})
+    for j, t in enumerate((xf2, None)):
+        m = copy.deepcopy(sc.materials[0])
+        for k in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "occlusion_tex", "emissive_tex"):
+            getattr(m, k).transform = t
+        sc.materials.append(m)
+        prim = copy.copy(sc.nodes[0].primitives[0]); prim.material = j + 1
+        sc.nodes.append(NodeDesc(translation=(0.55 * (j + 1), 0.1 * j, -0.3 * (j + 1)), rotation=sc.nodes[0].rotation, scale=(0.8, 0.8, 0.8), primitives=[prim]))
+    model = helpers.build_model(sc)
+    orc = helpers.oracle_frame(model, oracle_lut, **kw)
+    dev, stats = helpers.hip_frame(model, oracle_lut, **kw)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["alpha_mismatch"] == 0 and r["f16_max_ulp"] <= 2, r
+    assert stats["shade_general_wavefronts"] == 0, stats
+    dev.close()
 
 
 @pytest.mark.gpu
