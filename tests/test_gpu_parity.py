@@ -790,11 +790,13 @@ def test_device_brdf_lut_against_the_oracle(oracle_lut):
 
 
 @pytest.mark.gpu
-def test_overlapped_frames_shade_what_was_submitted(oracle_lut):
+@pytest.mark.parametrize("aa", [dict(), dict(msaa=4, mipmap=True)], ids=["single", "msaa_mips"])
+def test_overlapped_frames_shade_what_was_submitted(aa, oracle_lut):
     """AWSM_CFG_OVERLAP_FRAMES: the opaque pass of frame i runs on the library's shade stream while the geometry pass of frame
     i+1 is already enqueued.  Six frames with a moving camera (and a material change half-way) are submitted without any
     synchronisation in between, each into its own output image; every image must be bit-identical to the same frame
-    rendered on a plain (non-overlapping) context."""
+    rendered on a plain (non-overlapping) context.  Also with MSAA x4 + mipmaps: the MSAA scratch is per frame slot, so frame i + 1's lean kernel runs
+    beside frame i's edge detector and resolve."""
     import ctypes as C
     from awsm_renderer_amd.hip_backend import HipDevice
     from awsm_renderer_amd.host import Renderer, material_struct
@@ -809,7 +811,7 @@ def test_overlapped_frames_shade_what_was_submitted(oracle_lut):
     nbytes = sc.height * sc.width * 8
 
     def run(overlap, timers=True):
-        r = Renderer(sc, lut_rgba16f=lut, overlap_frames=overlap)
+        r = Renderer(sc, lut_rgba16f=lut, overlap_frames=overlap, **aa)
         r.host.set_render_timings(timers)      # off: no stage events, and the per-draw resolve moves ahead of the wait for the geometry pass
         dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
         outs = []
@@ -846,7 +848,7 @@ def test_overlapped_frames_shade_what_was_submitted(oracle_lut):
 
     # The same six frames into the library's own images (one per frame slot: nothing orders two frames' opaque passes then, and the per-draw
     # records are reused while only the camera moves): after any number of frames read_opaque is the last one submitted.
-    r = Renderer(sc, lut_rgba16f=lut, overlap_frames=True)
+    r = Renderer(sc, lut_rgba16f=lut, overlap_frames=True, **aa)
     r.host.set_render_timings(False)
     dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
     for i, eye in enumerate(eyes):
