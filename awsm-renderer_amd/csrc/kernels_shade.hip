@@ -2778,7 +2778,7 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 }
 
 // The edge pixels' samples 1..3 (material_shading.wgsl:170-210) and the average of the four.  Item-parallel: the block's edge pixels (k_shade_msaa's /
-// k_msaa_edges' list) are first expanded into work items — (pixel, sample) pairs whose triangle no earlier sample of the pixel shows: all samples a
+// k_msaa_detect's list) are first expanded into work items — (pixel, sample) pairs whose triangle no earlier sample of the pixel shows: all samples a
 // triangle covers in a pixel carry the same G-buffer texel and the same standard coordinates (sample 0's depth), hence the same colour — then every
 // thread shades ONE item (the shading call sits in the code once, and a block with 30 edge pixels keeps 40 lanes busy for one shading instead of 30
 // lanes for three in a row), then the threads of the edge pixels gather their four colours.  Up to 768 items per block, in LDS.
