@@ -1917,7 +1917,10 @@ AWSM_DI void direct(const Lit& s, f3 l, f3 radiance, f3& color) {
 // nothing waits inside the loop, and after one s_waitcnt every lane reads its triangle's record from LDS (ds_read_b128, lanes of one triangle
 // read one address: a broadcast).  kLeanSlots distinct triangles per wavefront are staged; the lanes of a busier strip (distant, finely
 // tessellated geometry) load theirs directly as before.
-constexpr uint32_t kLeanSlots = 16u, kLeanChunks = 13u, kLeanNone = 0xFFFFFFFFu;
+#ifndef AWSM_LEAN_SLOTS
+#define AWSM_LEAN_SLOTS 16u
+#endif
+constexpr uint32_t kLeanSlots = AWSM_LEAN_SLOTS, kLeanChunks = 13u, kLeanNone = 0xFFFFFFFFu;
 struct LeanStage { uint4 q[kLeanSlots][kLeanChunks]; };      // one per wavefront: 3,328 bytes
 #define AWSM_AS3 __attribute__((address_space(3)))
 AWSM_DI float4 bits_float4(uint4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
