@@ -140,6 +140,57 @@ def backend_is_rehearsal():
     return os.environ.get("AWSM_BENCH_BACKEND", "nccl") != "nccl"
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` typed as is (no launcher in front, WORLD_SIZE unset): start the N ranks as child processes of this one — which has
+    not imported torch and makes no HIP call, before or after — with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set
+    them, one GPU each.  Rank 0 inherits stdout (its JSON line is this command's JSON line); the other ranks' stdout goes to stderr.  Returns the
+    worst return code; when a rank fails, the others get a grace period (they normally leave through the collective's own error) and are then
+    ended by PID."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), AWSM_BENCH_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    kids = []
+    for i in range(n):
+        env = dict(base, RANK=str(i), LOCAL_RANK=str(i), GROUP_RANK="0")
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if i == 0 else sys.stderr))
+    rcs = [None] * n
+    failed_at = None
+    grace = float(os.environ.get("AWSM_BENCH_RANK_GRACE_S", "60"))
+    try:
+        while any(rc is None for rc in rcs):
+            for i, k in enumerate(kids):
+                if rcs[i] is None:
+                    rcs[i] = k.poll()
+                    if rcs[i] not in (None, 0) and failed_at is None:
+                        failed_at = time.monotonic()
+                        print(f"bench.py: rank {i} exited with code {rcs[i]}; waiting up to {grace:.0f} s for the other ranks", file=sys.stderr)
+            if failed_at is not None and time.monotonic() - failed_at > grace:
+                break
+            time.sleep(0.05)
+    finally:
+        for i, k in enumerate(kids):
+            if k.poll() is None:
+                k.terminate()
+        for i, k in enumerate(kids):
+            if rcs[i] is None:
+                try:
+                    rcs[i] = k.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    k.kill()
+                    rcs[i] = k.wait()
+    worst = 0
+    for rc in rcs:
+        if rc:
+            worst = max(worst, rc if rc > 0 else 128 - rc)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +222,11 @@ def main():
     args = ap.parse_args()
     if os.environ.get("AWSM_HIP_LIB") and not args.allow_variant_lib:
         raise SystemExit("AWSM_HIP_LIB is set: bench.py measures awsm-renderer_amd/libawsm_hip.so; pass --allow-variant-lib for an A/B build")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed without a launcher: this process becomes the launcher (nothing GPU-related has been imported or called yet, and never is)
+        sys.exit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -180,11 +236,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or unset WORLD_SIZE and let "
+                         f"`python bench.py --gpus {args.gpus}` start its own ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback for the product path")
     if backend_is_rehearsal():
         local_rank = 0                     # rehearsal: all ranks share GPU 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} HIP device(s): one rank per GPU "
+                         f"(AWSM_BENCH_BACKEND=gloo rehearses the N > 1 path with every rank on GPU 0)")
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("AWSM_BENCH_BACKEND", "nccl")
     if world > 1:
@@ -327,10 +387,33 @@ def main():
         eye = eye0 + orbit_r * (math.cos(a) * right + math.sin(a) * up)
         r.host.camera_update(scenes.look_at_rh(tuple(eye), tuple(eye + 30.0 * fwd)), scene.proj, tuple(eye))
 
+    handoff_in_loop = [0]
+
+    def render_frame():
+        """One frame enqueued.  ABI 2 reports a hand-off gate that timed out at the next awsm_hip_geometry_pass / frame_flush / frame_end — which, in an
+        enqueue-only loop, is a call inside this loop.  The library has then already switched the context to events and the refused call did nothing:
+        note the fault (the measurement is repeated) and issue the frame again, so that every rank still runs the same sequence of collectives."""
+        try:
+            r.host.render(sync=False)
+        except Exception as e:
+            if "hand-off" not in str(e):
+                raise
+            handoff_in_loop[0] += 1
+            r.host.render(sync=False)
+
+    def flush_frame():
+        try:
+            dev.frame_flush()
+        except Exception as e:
+            if "hand-off" not in str(e):
+                raise
+            handoff_in_loop[0] += 1
+            dev.frame_flush()
+
     def step():
         move_camera()
         if world == 1:
-            r.host.render(sync=False)
+            render_frame()
             return
         b = frame_no[0] % n_buf
         frame_no[0] += 1
@@ -339,8 +422,8 @@ def main():
             dev.bind_output_rows(mine[b].data_ptr(), rows_out * W * 8, y0s)
         else:
             dev.bind_output(mine[b].data_ptr(), rows_out * W * 8)
-        r.host.render(sync=False)
-        dev.frame_flush()              # the opaque pass ran on the library's shade stream: order it before the collective
+        render_frame()
+        flush_frame()                  # the opaque pass ran on the library's shade stream: order it before the collective
         pending[b] = all_gather(gathered[b].view(world * rows_out, W, 4), mine[b])
 
     def drain():
@@ -369,22 +452,24 @@ def main():
         if args.trace:
             dev.frame_trace(args.warmup + args.steps + 8)
         host_t.append(("loop_begin", time.perf_counter()))
-        for _ in range(args.warmup):
-            step()
-            if args.trace:
-                host_t.append(("w", time.perf_counter()))
-        barrier()
-        t0 = time.perf_counter()
-        host_t.append(("t0", t0))
-        for _ in range(args.steps):
-            step()
-            if args.trace:
-                host_t.append(("s", time.perf_counter()))
-        host_t.append(("enqueued", time.perf_counter()))
-        barrier()
-        dt = time.perf_counter() - t0
-        host_t.append(("t1", t0 + dt))
-        gc.enable()
+        try:
+            for _ in range(args.warmup):
+                step()
+                if args.trace:
+                    host_t.append(("w", time.perf_counter()))
+            barrier()
+            t0 = time.perf_counter()
+            host_t.append(("t0", t0))
+            for _ in range(args.steps):
+                step()
+                if args.trace:
+                    host_t.append(("s", time.perf_counter()))
+            host_t.append(("enqueued", time.perf_counter()))
+            barrier()
+            dt = time.perf_counter() - t0
+            host_t.append(("t1", t0 + dt))
+        finally:
+            gc.enable()
         return dt
 
     handoff_mode = dev.stream_handoff()
@@ -400,10 +485,10 @@ def main():
     # A device-side hand-off gate that gave up during the loop (kernels of two streams not running side by side: a profiler that serialises
     # them attached after the context's probe, a hardware queue shared with a stream created later) leaves frames that may be incomplete and
     # the context on events: the measurement is then repeated, on events, and the line says so.
-    handoff_fault = 0
+    handoff_fault = 1 if handoff_in_loop[0] else 0
     try:
         r.host.render(sync=True)
-    except Exception as e:      # HostError: the library reports the timed-out gate once, at the next awsm_hip_frame_end
+    except Exception as e:      # HostError: the library reports a timed-out gate once, at its next geometry_pass / frame_flush / frame_end
         if "hand-off" not in str(e):
             raise
         handoff_fault = 1
@@ -416,10 +501,28 @@ def main():
     if handoff_fault:
         print(f"rank {rank}: a stream hand-off gate timed out during the timed loop; repeating the measurement on hipEvents", file=sys.stderr)
         dt = timed_loop()
+    dt_local = dt
+    ranks_seen = 1
+    gather_alone_ms = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        coll_dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        t = torch.ones(1, dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)           # over RCCL (or the rehearsal backend): how many ranks really took part
+        ranks_seen = int(t.item())
+        # the frame's exchange step by itself (nothing rendering beside it): K collectives back to back on the image buffers
+        drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        K = 5
+        g0 = time.perf_counter()
+        for _ in range(K):
+            h = all_gather(gathered[0].view(world * rows_out, W, 4), mine[0])
+            h.wait()
+        torch.cuda.synchronize()
+        gather_alone_ms = (time.perf_counter() - g0) / K * 1e3
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
 
@@ -495,7 +598,13 @@ def main():
         half = max(8, H // 8)
         cpu = cpu_baseline(scene, lut_rg, (max(0, mid - half), min(H, mid + half)))
 
+    per_rank = None
     if world > 1:
+        me = {"rank": rank, "device": local_rank, "rows": rows_mine, "loop_s": dt_local, "gather_alone_ms": gather_alone_ms,
+              "kernel_ms": kernel_ms, "covered_pixels": st.get("covered_pixels"), "bin_entries": st.get("bin_entries"),
+              "handoff_faults_in_loop": handoff_in_loop[0]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
         dist.barrier()
     if world == 1:
         sharding_desc = "none"
@@ -508,7 +617,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "frames/sec + shaded Mpix/s, 4K Sponza glTF, 1/2/4/8 MI355X",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "value": fps, "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (procedural scene generated in-repo; no glTF asset is available offline)",
             "shaded_mpix_per_s": W * H * fps / 1e6,
@@ -527,6 +636,10 @@ def main():
                                                 "frames_with_dropped_bin_entries", "bin_overflow_retries")},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            **({"collective": {"backend": "rccl" if backend == "nccl" else backend + " (rehearsal: every rank on GPU 0, staged through the host)",
+                               "op": "gather to rank 0" if to_root else "all_gather_into_tensor", "bytes_per_rank": rows_out * W * 8,
+                               "alone_ms": max(p["gather_alone_ms"] for p in per_rank), "launcher": "bench.py (child processes)" if os.environ.get("AWSM_BENCH_SELF_LAUNCHED") else "external (WORLD_SIZE was set)"},
+                "per_rank": per_rank} if per_rank else {}),
             **({"check": check} if check else {}),
             **({"frame_trace": frame_trace} if frame_trace else {}),
         }

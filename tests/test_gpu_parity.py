@@ -150,23 +150,34 @@ def test_band_sharding_rows_identical_to_full_frame(oracle_lut, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
 @pytest.mark.parametrize("msaa,extra", [(0, []), (4, []), (4, ["--strips"]), (0, ["--gather", "root"])])
-def test_bench_two_rank_rehearsal_on_one_gpu(msaa, extra):
+def test_bench_two_rank_rehearsal_on_one_gpu(msaa, extra, launcher):
     """bench.py's N > 1 path (band sharding, compact outputs, double-buffered gather, de-interleave) run as two processes
     sharing this box's one GPU, with the collectives staged through gloo; --check compares the gathered image with an
-    unsharded render bit for bit (with --gather root: on rank 0, the only rank that holds the frame).  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)"""
+    unsharded render bit for bit (with --gather root: on rank 0, the only rank that holds the frame).  (RCCL itself needs one GPU per rank: the driver's 8-GPU node runs that.)
+    launcher "self": `python bench.py --gpus 2 ...` exactly as the driver types it — bench.py starts its own ranks as child processes before anything
+    touches the GPU; "torchrun": the same under torch.distributed.run (WORLD_SIZE set: bench.py is a rank).  One case of the latter is enough."""
     import json, os, socket, subprocess, sys
+    if launcher == "torchrun" and (msaa or extra):
+        pytest.skip("the external launcher is covered by the plain bands case")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, AWSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--width", "640", "--height", "363", "--detail", "0.125",
-           "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1", "--msaa", str(msaa)] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(AWSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable]
+    if launcher == "torchrun":
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--width", "640", "--height", "363", "--detail", "0.125",
+            "--tex-scale", "0.0625", "--no-cpu-baseline", "--check", "--profile-frames", "1", "--msaa", str(msaa)] + extra
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["check"] == "ok" and out["n_gpus"] == 2 and out["value"] > 0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # ONE JSON line on stdout, rank 0's
+    out = json.loads(lines[0])
+    assert out["check"] == "ok" and out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["value"] > 0
+    assert [pr["rank"] for pr in out["per_rank"]] == [0, 1] and all(pr["kernel_ms"]["k_raster_tile"] > 0 for pr in out["per_rank"])
+    assert out["collective"]["alone_ms"] > 0 and ("child processes" in out["collective"]["launcher"]) == (launcher == "self")
     assert ("gather to rank 0" in out["config"]["sharding"]) == ("root" in extra)
     assert ("row strips" in out["config"]["sharding"]) == ("--strips" in extra) and ("boundary sample-0 keys" in out["config"]["sharding"]) == (msaa == 4 and not extra)
 

@@ -143,3 +143,33 @@ def test_band_rows_partition_the_frame():
                 g[r, : len(rows), 0, 0] = rows
             img = bands_to_image(g.reshape(n, L, 32, 1, 1), h, n)
             assert img[:, 0, 0].tolist() == list(range(h))
+
+
+def test_bench_starts_its_own_ranks_and_never_touches_the_gpu_itself(tmp_path):
+    """`python bench.py --gpus 2` as the driver types it (no launcher, WORLD_SIZE unset): the process must become a launcher — two children with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — without importing torch (a process that has initialised the GPU must not start or become
+    another program on this pool).  Without a GPU each rank refuses to run (no CPU fallback) and the launcher hands the failure on."""
+    probe = tmp_path / "sitecustomize.py"
+    probe.write_text(
+        "import os, sys, atexit\n"
+        "def _report():\n"
+        "    with open(os.environ['AWSM_PROBE_OUT'] + '.' + str(os.getpid()), 'w') as f:\n"
+        "        f.write(repr({'rank': os.environ.get('RANK'), 'local_rank': os.environ.get('LOCAL_RANK'), 'world': os.environ.get('WORLD_SIZE'),\n"
+        "                      'addr': os.environ.get('MASTER_ADDR'), 'port': os.environ.get('MASTER_PORT'), 'torch': 'torch' in sys.modules, 'argv': sys.argv}))\n"
+        "atexit.register(_report)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""), AWSM_PROBE_OUT=str(tmp_path / "probe"), AWSM_BENCH_RANK_GRACE_S="30")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the N > 1 path itself is what test_gpu_parity.py's rehearsal runs")
+    assert p.returncode != 0
+    assert p.stderr.count("needs an MI355X") == 2, p.stderr[-3000:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    reports = [eval(f.read_text()) for f in tmp_path.glob("probe.*")]
+    parent = [r for r in reports if r["rank"] is None]
+    ranks = sorted((r for r in reports if r["rank"] is not None), key=lambda r: r["rank"])
+    assert len(parent) == 1 and parent[0]["torch"] is False
+    assert [(r["rank"], r["local_rank"], r["world"], r["addr"]) for r in ranks] == [("0", "0", "2", "127.0.0.1"), ("1", "1", "2", "127.0.0.1")]
+    assert ranks[0]["port"] == ranks[1]["port"] and all(r["torch"] for r in ranks) and all(r["argv"][1:] == parent[0]["argv"][1:] for r in ranks)
