@@ -124,6 +124,7 @@ def compare_frames(orc, dev, rows=None, rgb_tol=1e-4, cond=None):
     base = rgb_tol * np.maximum(1.0, np.abs(ref))
     over_base = (diff[..., :3] > base[..., :3]).any(axis=-1)
     out["rgb_over_base"] = int(over_base.sum())
+    out["rgb_over_abs"] = int((diff[..., :3] > rgb_tol).any(axis=-1).sum())      # the ABSOLUTE bar (north_star's 1e-4 read literally): reported, so that the relative bar above 1.0 is quantified
     if cond is None and out["rgb_over_base"] and out["key_mismatch"] == 0:
         import os
         cond = orc.conditioning(os.cpu_count() or 16)

@@ -7,13 +7,14 @@ from tests import helpers
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+msaa = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 t0 = time.time()
 sc = scenes.atrium_scene(W, H)
 model = helpers.build_model(sc)
 print("scene+model %.1fs" % (time.time() - t0), flush=True)
 dev = HipDevice()
 print(dev.device_info())
-dev.resize(W, H)
+dev.resize(W, H, msaa)
 dev.upload_mirrors(model.mirrors())
 for i, t in enumerate(model.texture_arrays()):
     dev.texture_array_upload(i, t["texels"])

@@ -40,6 +40,15 @@ for k in range(4):
         print(f"    start -> triangle loaded / set up: median {np.nanmedian(d):.2f} us, p95 {np.nanpercentile(d, 95):.2f}, max {np.nanmax(d):.2f};  -> end of phase 0: median {np.nanmedian(e):.2f}, p95 {np.nanpercentile(e, 95):.2f}, max {np.nanmax(e):.2f}")
         slow = np.argsort(-(s[:, 1] - s[:, 0]))[:12]
         print("    slowest workgroups in phase 0:", [(int(i), round(float(s[i, 7] - s[i, 0]), 1), round(float(s[i, 1] - s[i, 7]), 1)) for i in slow])
+    if k == 3:      # how full the machine is over the kernel's life: workgroups alive per 5-us bin (256 CUs x up to 7), and where the time of a workgroup goes
+        t_begin, t_end = np.nanmin(s[:, 0]), np.nanmax(last)
+        edges = np.arange(t_begin, t_end + 5.0, 5.0)
+        alive = [int(((s[:, 0] < e + 5.0) & (last > e)).sum()) for e in edges[:-1]]
+        print(f"    kernel {t_end - t_begin:.1f} us; sum of workgroup lives {np.nansum(last - s[:, 0]):.0f} us = {np.nansum(last - s[:, 0]) / (t_end - t_begin):.0f} workgroups alive on average; alive per 5-us bin: {alive}")
+        order = np.argsort(-(last - s[:, 0]))[:8]
+        print("    longest workgroups (id, start, life):", [(int(i), round(float(s[i, 0] - t_begin), 1), round(float(last[i] - s[i, 0]), 1)) for i in order])
+        ends = np.sort(last)[-8:] - t_begin
+        print("    last workgroups end at:", [round(float(e), 1) for e in ends])
     for j in range(1, 7):
         d = s[:, j] - s[:, j - 1]
         if np.isfinite(d).any():
