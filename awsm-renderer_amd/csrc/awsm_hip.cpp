@@ -12,7 +12,6 @@
 #include <cstring>
 #include <ctime>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "frame_params.hpp"
@@ -172,20 +171,10 @@ struct AwsmHipCtx {
     const void* opaque_src = nullptr;      // awsm_hip_bind_opaque_source: the gathered full-frame opaque image (sharded transparent pass)
     size_t opaque_src_bytes = 0;
     int slot = 0;
-    // Occluder hints for k_raster_tile: one byte per triangle of a geometry pass, two buffers used in turn (the pass reads the previous pass's, writes its
-    // own); occ_prev_first maps this frame's draws to the same draws' first triangle in the previous frame (device copy uploaded when it changes).
-    DevBuf occ[2], occ_prev_first;
-    int occ_idx = 0;
-    uint32_t raster_experiment = 0;            // AWSM_RASTER_EXPERIMENT (measurement switches: 1 = k_raster_tile leaves no hints)
-    bool occ_prev_valid = false;               // occ[occ_idx ^ 1] was written by the previous geometry pass, for the draw list in occ_prev_draws
-    std::vector<DrawDev> occ_prev_draws;
-    std::vector<uint32_t> occ_prev_first_host, occ_prev_first_uploaded;
-    const void* occ_prev_first_uploaded_ptr = nullptr;
     std::vector<DrawDev> draws_host;
     std::vector<AwsmDraw> draws_api;
     uint32_t total_tris = 0, total_verts = 0, n_blocks = 0;
     bool geometry_done = false, opaque_done = false;
-    bool geometry_ever = false;      // a geometry pass has run on this context (its occluder bytes exist)
     AwsmOpaqueParams last_opaque{};
     uint32_t overflow_retries = 0;
     bool has_opaque_for_stats() const { return !opaque_done || last_opaque.has_opaque != 0; }
@@ -215,7 +204,6 @@ inline hipStream_t shade_stream_of(AwsmHipCtx* c) { return c->overlap ? c->shade
 inline int n_slots(const AwsmHipCtx* c) { return c->overlap ? kSlots : 1; }
 inline int prev_slot(const AwsmHipCtx* c) { return (c->slot + kSlots - 1) % kSlots; }
 inline uint32_t* handoff_timeouts(AwsmHipCtx* c) { return c->counters_host + 16 + 2 * kSlots; }
-inline uint32_t* cull_stats(AwsmHipCtx* c) { return c->counters_host + 16 + 2 * kSlots + 1; }
 inline unsigned long long* trace_slot(AwsmHipCtx* c, int which) { return c->trace_dev ? c->trace_dev + (size_t)which * c->trace_cap + c->frame_serial % c->trace_cap : nullptr; }
 // the slot's shading is finished: for the host and the rarely taken waits an event, for the next user of the slot's buffers the flag
 inline hipError_t mark_shade_done(AwsmHipCtx* c, hipStream_t ss) {
@@ -437,13 +425,6 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->tri_rec = (TriRec*)FB(c).tri_rec.ptr;
     f->tile_count = (uint32_t*)FB(c).tile_count.ptr; f->tile_offset = (uint32_t*)FB(c).tile_offset.ptr;
     f->tile_cursor = (uint32_t*)FB(c).tile_cursor.ptr; f->bin_list = (uint32_t*)FB(c).bin_list.ptr;
-    // occlusion inside the raster tiles (kernels_geometry.hip, "occlusion inside a tile"); the hints: this frame's bytes, the previous geometry pass's
-    f->raster_cull = (c->flags & AWSM_CFG_NO_OCCLUSION_CULL) ? 0u : ((c->flags & AWSM_CFG_VERIFY_OCCLUSION_CULL) ? 2u : 1u);
-    if (f->raster_cull) f->raster_cull |= c->raster_experiment << 8;
-    const bool hints = f->raster_cull && c->occ[c->occ_idx].ptr && c->occ[c->occ_idx].size >= c->total_tris;
-    f->occ_cur = hints ? (uint8_t*)c->occ[c->occ_idx].ptr : nullptr;
-    f->occ_prev = (hints && c->occ_prev_valid && c->occ_prev_first.ptr) ? (const uint8_t*)c->occ[c->occ_idx ^ 1].ptr : nullptr;
-    f->occ_prev_first = (const uint32_t*)c->occ_prev_first.ptr;
     f->tile_order = (uint32_t*)FB(c).tile_order.ptr;
     f->scan_tmp = (uint32_t*)FB(c).scan_tmp.ptr;
     f->tile_split = (uint32_t*)FB(c).tile_split.ptr; f->raster_scratch = (unsigned long long*)FB(c).raster_scratch.ptr;
@@ -554,7 +535,6 @@ int enqueue_geometry(AwsmHipCtx* c) {
     if (!has_geometry) {   // otherwise k_deform_transform clears counters + tile_count and k_bin_scan clears tile_cursor
         HIPCHK(c, hipMemsetAsync(FB(c).counters.ptr, 0, 8 * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 12, 0, 2 * sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 16, 0, 4 * sizeof(uint32_t), c->stream));
         if (n_tiles) HIPCHK(c, hipMemsetAsync(FB(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), c->stream));
     }
     if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 0), c->stream);
@@ -680,7 +660,6 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     f->tri_rec = (TriRec*)t.tri_rec.ptr;
     f->tile_count = (uint32_t*)t.tile_count.ptr; f->tile_offset = (uint32_t*)t.tile_offset.ptr;
     f->tile_cursor = (uint32_t*)t.tile_cursor.ptr; f->bin_list = (uint32_t*)t.bin_list.ptr;
-    f->occ_cur = nullptr; f->occ_prev = nullptr; f->occ_prev_first = nullptr; f->raster_cull = 0u;      // the world geometry pass's
     f->tile_order = (uint32_t*)t.tile_order.ptr;
     f->scan_tmp = (uint32_t*)t.scan_tmp.ptr;
     f->tile_split = (uint32_t*)t.tile_split.ptr; f->raster_scratch = nullptr;      // the transparent pass has its own tile kernel: nothing is split
@@ -904,11 +883,6 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     for (int i = 0; i < EV_COUNT; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(AWSM_ERR_DEVICE);
     if (hipMalloc((void**)&c->scene_dev, sizeof(DevScene)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
     c->overlap = (cfg->flags & AWSM_CFG_OVERLAP_FRAMES) != 0;
-    if (const char* e = getenv("AWSM_OCCLUSION_CULL")) {      // A/B and checking runs of an unchanged caller: "0" = AWSM_CFG_NO_OCCLUSION_CULL, "verify" = AWSM_CFG_VERIFY_OCCLUSION_CULL
-        if (!strcmp(e, "0")) c->flags |= AWSM_CFG_NO_OCCLUSION_CULL;
-        else if (!strcmp(e, "verify")) c->flags |= AWSM_CFG_VERIFY_OCCLUSION_CULL;
-    }
-    if (const char* e = getenv("AWSM_RASTER_EXPERIMENT")) c->raster_experiment = (uint32_t)atoi(e);
     {   // k_shade_lean as a persistent grid of N workgroups per CU (it is VALU-bound from 4 waves/SIMD up): the rest of each CU's
         // wave slots, registers and LDS stays free for the next frame's geometry kernels on the other stream
         const char* e = getenv("AWSM_LEAN_WGS_PER_CU");
@@ -916,12 +890,12 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         c->lean_grid = per_cu > 0 ? (uint32_t)(per_cu * prop.multiProcessorCount) & ~7u : 0u;
     }
     for (int s = 0; s < n_slots(c); s++) {
-        if (hipMalloc(&c->fb[s].counters.ptr, 24 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13] + k_raster_tile's cull statistics [16..19)
-        c->fb[s].counters.size = 24 * sizeof(uint32_t);
-        if (hipMalloc(&c->tr[s].counters.ptr, 24 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-        c->tr[s].counters.size = 24 * sizeof(uint32_t);
-        if (hipMalloc(&c->hud[s].counters.ptr, 24 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-        c->hud[s].counters.size = 24 * sizeof(uint32_t);
+        if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13]
+        c->fb[s].counters.size = 16 * sizeof(uint32_t);
+        if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        c->tr[s].counters.size = 16 * sizeof(uint32_t);
+        if (hipMalloc(&c->hud[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        c->hud[s].counters.size = 16 * sizeof(uint32_t);
     }
 
     if (c->overlap) {
@@ -938,7 +912,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             c->fb[s].camera.size = 512;
         }
     }
-    if (hipHostMalloc((void**)&c->counters_host, (16 + 2 * kSlots + 1 + 4) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // then: hand-off gates that timed out; then 4 words: k_raster_tile's cull statistics (device counters [8..12))
+    if (hipHostMalloc((void**)&c->counters_host, (16 + 2 * kSlots + 1) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // last word: hand-off gates that timed out
     memset(c->counters_host, 0, (16 + 2 * kSlots + 1) * sizeof(uint32_t));
     if (c->overlap) {
         const char* e = getenv("AWSM_DEVICE_HANDOFF");      // "0": cross-stream events instead (for a profiler that serialises kernels: tools/pmc_*.sh)
@@ -979,7 +953,6 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
-    for (auto& b : c->occ) fr(b); fr(c->occ_prev_first);
     fr(c->lut); for (auto& b : c->cube_tex) fr(b); for (auto& b : c->cube_bordered) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); for (int sl = 0; sl < kSlots; sl++) { fr(c->msaa_color0[sl]); fr(c->msaa_edges[sl]); fr(c->msaa_edge_bits[sl]); fr(c->msaa_cells[sl]); } fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
     for (int k = 0; k < 3 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : c->hud[k - 2 * kSlots]);
@@ -1303,33 +1276,6 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     }
     ht.mark("geometry_pass: slot-free wait");
     c->draws_api.assign(draws, draws + n);
-    {   // occluder hints: which triangle of the previous frame is triangle k of draw i?  Draws are told apart by (vertex data, meta slot, instance).
-        // The usual frame repeats the previous list: identity, one memcmp.
-        c->occ_prev_draws.swap(c->draws_host);      // the list the previous geometry pass ran with (it wrote occ[occ_idx])
-        c->occ_prev_valid = c->geometry_ever && !c->occ_prev_draws.empty();
-        c->occ_idx ^= 1;
-        const std::vector<DrawDev>& prev = c->occ_prev_draws;
-        std::vector<uint32_t>& pf = c->occ_prev_first_host;
-        pf.resize(new_draws.size());
-        if (prev.size() == new_draws.size() && (prev.empty() || memcmp(prev.data(), new_draws.data(), prev.size() * sizeof(DrawDev)) == 0)) {
-            for (size_t i = 0; i < new_draws.size(); i++) pf[i] = new_draws[i].first_tri;
-        } else {
-            auto key = [](const DrawDev& d) { return ((uint64_t)d.vis_data_off << 32) ^ ((uint64_t)d.geom_meta_off << 8) ^ ((uint64_t)d.inst_off * 0x9E3779B97F4A7C15ull); };
-            std::unordered_map<uint64_t, uint32_t> where;
-            where.reserve(prev.size() * 2);
-            for (const DrawDev& d : prev) where.emplace(key(d), d.first_tri);
-            for (size_t i = 0; i < new_draws.size(); i++) {
-                const auto it = c->occ_prev_valid ? where.find(key(new_draws[i])) : where.end();
-                pf[i] = it == where.end() ? 0xFFFFFFFFu : it->second;      // (a collision of the key could only mislabel a hint)
-            }
-            // a draw found in the previous list has the same triangle count there only if it is the same mesh: check, or drop the hint
-            if (c->occ_prev_valid) {
-                std::unordered_map<uint32_t, uint32_t> count_at;
-                for (const DrawDev& d : prev) count_at.emplace(d.first_tri, d.tri_count);
-                for (size_t i = 0; i < new_draws.size(); i++) if (pf[i] != 0xFFFFFFFFu && count_at[pf[i]] != new_draws[i].tri_count) pf[i] = 0xFFFFFFFFu;
-            }
-        }
-    }
     c->draws_host.swap(new_draws);
     {   // What earlier frames needed in their (triangle, tile) lists, as far as the GPU has reported it (pinned words written by k_bin_scan;
         // no wait).  A frame rendered without frame_end cannot be replayed: size the list ahead of the need instead, and count the
@@ -1353,20 +1299,9 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     ht.mark("geometry_pass: bin capacity");
     compose_pixel_to_view(c, FB(c));
     if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
-    if (!(c->flags & AWSM_CFG_NO_OCCLUSION_CULL)) {
-        for (DevBuf& ob : c->occ)
-            if (ob.size < FB(c).tri_cap || !ob.ptr) { if ((rc = dev_reserve(c, ob, std::max<size_t>(FB(c).tri_cap, 1)))) return rc; c->occ_prev_valid = false; }      // (re-allocated: last frame's bytes are gone)
-        if (c->occ_prev_first.size < FB(c).draw_cap * 4 || !c->occ_prev_first.ptr) { if ((rc = dev_reserve(c, c->occ_prev_first, std::max<size_t>(FB(c).draw_cap, 1) * 4))) return rc; c->occ_prev_first_uploaded_ptr = nullptr; }
-        if (!c->occ_prev_first_host.empty() && (c->occ_prev_first_uploaded_ptr != c->occ_prev_first.ptr || c->occ_prev_first_uploaded != c->occ_prev_first_host)) {
-            const size_t bytes = c->occ_prev_first_host.size() * 4;
-            if (bytes <= (1u << 20)) { if ((rc = upload_small(c, c->occ_prev_first.ptr, c->occ_prev_first_host.data(), bytes))) return rc; }
-            else { HIPCHK(c, hipMemcpyAsync(c->occ_prev_first.ptr, c->occ_prev_first_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-            c->occ_prev_first_uploaded = c->occ_prev_first_host; c->occ_prev_first_uploaded_ptr = c->occ_prev_first.ptr;
-        }
-    }
     ht.mark("geometry_pass: reserve + draw-list upload");
     if ((rc = enqueue_geometry(c))) return rc;
-    c->geometry_done = true; c->geometry_ever = true; c->opaque_done = false; c->transparent_done = false; c->hud_geometry_done = false;
+    c->geometry_done = true; c->opaque_done = false; c->transparent_done = false; c->hud_geometry_done = false;
     return AWSM_OK;
 }
 
@@ -1401,7 +1336,6 @@ int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n)
     f.tri_rec = (TriRec*)hb.tri_rec.ptr;
     f.tile_count = (uint32_t*)hb.tile_count.ptr; f.tile_offset = (uint32_t*)hb.tile_offset.ptr;
     f.tile_cursor = (uint32_t*)hb.tile_cursor.ptr; f.bin_list = (uint32_t*)hb.bin_list.ptr;
-    f.occ_cur = nullptr; f.occ_prev = nullptr; f.occ_prev_first = nullptr;      // no hints for the hud meshes (the later batches of a tile are still tested against what the earlier ones left)
     f.tile_order = (uint32_t*)hb.tile_order.ptr; f.scan_tmp = (uint32_t*)hb.scan_tmp.ptr;
     f.tile_split = (uint32_t*)hb.tile_split.ptr; f.raster_scratch = (unsigned long long*)hb.raster_scratch.ptr;
     f.raster_extra_cap = hb.raster_extra_cap; f.raster_slot_cap = hb.raster_slot_cap;
@@ -1550,7 +1484,6 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             awsm_launch_count_covered(&f, c->stream);
         }
         HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(cull_stats(c), (uint32_t*)FB(c).counters.ptr + 16, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
         { int rch = handoff_check(c); if (rch) return rch; }      // a gate ended unopened: the frame it guarded was dropped
@@ -1599,7 +1532,6 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->bin_overflow_retries = c->overflow_retries;
         out->frames_with_dropped_bin_entries = c->dropped_frames;
         out->handoff_gate_timeouts = c->handoff_dropped_frames;
-        if (c->geometry_done) { out->raster_entries_culled = cull_stats(c)[0]; out->raster_cull_verify_wins = cull_stats(c)[1]; out->raster_entries_tested = cull_stats(c)[2]; }
         if (c->opaque_done && c->shade_todo[c->slot].ptr && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
             HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo[c->slot].ptr, 4, hipMemcpyDeviceToHost));
         out->struct_size = (uint32_t)std::min<size_t>(caller_size, sizeof(AwsmFrameStats));

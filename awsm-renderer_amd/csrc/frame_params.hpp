@@ -209,17 +209,7 @@ struct FrameDev {
                                   // every kernel of that frame exits at once (frame_poisoned).  null: no device-side hand-off
     uint32_t* host_bin_status;    // pinned host memory, 2 words per frame slot: (triangle, tile) entries this frame needed, the frame's serial (k_bin_scan)
     uint32_t frame_serial;
-    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles, [7] extra raster items,
-                                  // [8..12) pick words, [12] [13] k_bin_scan, [16] (triangle, tile) entries k_raster_tile culled against its depth grid, [17]
-                                  // samples of culled entries that would have won (raster_cull = 2 only: must stay 0), [18] entries tested (2 only)
-    // Occlusion hints (k_raster_tile): one byte per triangle of THIS frame — k_deform_transform writes 2 where the same triangle of the same draw won a
-    // pixel in the previous geometry pass (occ_prev through occ_prev_first: per draw of this frame, first_tri of that draw in the previous frame or
-    // 0xFFFFFFFF), else 0; k_raster_tile reads it beside the setup record (hinted entries are walked first, untested) and stores 1 for the triangles
-    // it finds on a 4 x 4 pixel lattice of the finished tile.  Null = no hints (a tile's first batch is walked untested, its later ones tested).
-    uint8_t* occ_cur;
-    const uint8_t* occ_prev;
-    const uint32_t* occ_prev_first;
-    uint32_t raster_cull;         // (bits 8..: experiment switches, AWSM_RASTER_EXPERIMENT) 0: never cull; 1: drop (triangle, tile) entries that lie behind what the tile holds; 2: evaluate them anyway and count the samples they win
+    uint32_t* counters;           // [0] binned triangles, [1] bin entries, [2] overflow flag, [3] covered pixels, [4] big triangles, [7] extra raster items
     // targets
     unsigned long long* vis;      // width*height packed keys
     uint16_t* out_rgba16f;        // width*height*4

@@ -51,7 +51,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
         for (uint32_t i = g0; i < n_tiles; i += gsz) f.tile_count[i] = 0u;
         if (g0 < 8u) f.counters[g0] = 0u;
         if (g0 == 12u || g0 == 13u) f.counters[g0] = 0u;      // k_bin_scan's arrival counter and ready flag
-        if (g0 >= 16u && g0 < 20u) f.counters[g0] = 0u;       // k_raster_tile's cull statistics
         // the opaque pass's lean route (same slot, after this frame's raster): its list for the general kernel and the persistent grid's strip
         // counters start empty — here and not in k_resolve_draws, which is skipped when nothing but the camera changed
         if (!FWD && f.shade_todo && g0 == 14u) f.shade_todo[0] = 0u;
@@ -195,11 +194,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
     if (lv % 3u == 0u) {
         const uint32_t info = lo | ((d.flags & 0x7Fu) << 24) /* 0x80 = kDrawInstanced, internal */ | ((FWD && (f.draw_shade[lo].flags & 2u)) ? 0x80000000u : 0u);
         f.tri_info[d.first_tri + lv / 3u] = info;
-        if (!FWD && f.occ_cur) {      // occluder hint for k_raster_tile: did this triangle of this draw win a pixel in the previous geometry pass?
-            uint32_t hint = 0u;
-            if (f.occ_prev) { const uint32_t pf = f.occ_prev_first[lo]; if (pf != 0xFFFFFFFFu) hint = (f.occ_prev[pf + lv / 3u] & 1u) << 1; }
-            f.occ_cur[d.first_tri + lv / 3u] = (uint8_t)hint;
-        }
         if (!FWD && f.tri_shade) {
             // compute.wgsl:182-197 + texture_uvs.wgsl:64-84, once per triangle instead of once per pixel: where each corner's TEXCOORD_0 lives.
             // Byte offsets into the attribute data (the reference's offsets are u32 as well).
@@ -584,102 +578,26 @@ struct WorkTri {
     float a[3], b[3];
     float zq[3];
     uint32_t rank;
-    uint32_t bbox;   // x0 | x1 << 5 | y0 << 10 | y1 << 15 (tile-local, inclusive) | kind << 20 — 0: edge values by FMA per sample; 1: TriSetup::exact (stepped in
-                     // f64); 2: TriSetup::small (stepped in 32-bit integers; a mid entry of kind 2 is a WorkSmall)
-    uint32_t zlo;    // bits of a depth no sample of the triangle can lie in front of (tri_depth_floor_bits); 0 = unknown, never culled
+    uint32_t bbox;   // x0 | x1<<8 | y0<<16 | y1<<24, tile-local, inclusive
+    uint32_t exact;  // 0: edge values by FMA per sample; 1: TriSetup::exact (stepped in f64); 2: TriSetup::small (stepped in 32-bit integers)
 };
 static_assert(sizeof(WorkTri) == 72, "WorkTri");
 // A `small` mid triangle of a single-sampled frame, set up for the integer walk by the thread that classified it (one pass over the batch,
 // instead of once per 16-lane group inside the walk phase): e = E - bias at the centre of the first pixel of its first 4x4 block, the
-// per-pixel steps.  Same size as WorkTri, rank / bbox / zlo at the same offsets.
+// per-pixel steps.  Same size as WorkTri, rank / bbox / exact (= 2) at the same offsets.
 struct WorkSmall {
     int e[3], a[3], b[3];
     float zq[3];
     uint32_t bias;   // bit i: edge i does not own its zero line (accepts E >= 1)
     uint32_t pad[2];
-    uint32_t rank, bbox, zlo;
+    uint32_t rank, bbox, exact;
 };
-static_assert(sizeof(WorkSmall) == sizeof(WorkTri) && offsetof(WorkSmall, rank) == offsetof(WorkTri, rank) && offsetof(WorkSmall, zlo) == offsetof(WorkTri, zlo), "WorkSmall");
-AWSM_DI uint32_t work_bbox(int x0, int x1, int y0, int y1, uint32_t kind) { return (uint32_t)x0 | ((uint32_t)x1 << 5) | ((uint32_t)y0 << 10) | ((uint32_t)y1 << 15) | (kind << 20); }
-#define AWSM_WORK_BBOX(bb, x0, x1, y0, y1) const int x0 = (int)((bb) & 31u), x1 = (int)(((bb) >> 5) & 31u), y0 = (int)(((bb) >> 10) & 31u), y1 = (int)(((bb) >> 15) & 31u)
+static_assert(sizeof(WorkSmall) == sizeof(WorkTri) && offsetof(WorkSmall, rank) == offsetof(WorkTri, rank) && offsetof(WorkSmall, exact) == offsetof(WorkTri, exact), "WorkSmall");
 
 AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 #pragma unroll
     for (int i = 0; i < 3; i++) { t.a[i] = g.a[i]; t.b[i] = g.b[i]; t.c[i] = g.c[i]; t.zq[i] = g.zq[i]; }
-    const uint32_t kind = g.bbox >> 20;
-    t.exact = kind != 0u; t.small = kind == 2u;
-}
-
-// ---- occlusion inside a tile ----
-// A (triangle, tile) entry whose every possible sample lies strictly behind what the tile already holds changes no key: key = depth bits << 32 | ~rank
-// and min() over keys, so a larger depth loses whatever the ranks are (pipeline.rs:337-344: LessEqual, later wins — ties are never culled).  The tile
-// keeps an 8 x 8 grid: per 4x4-pixel block the LARGEST depth word among its samples when the block was last looked at (all ones while any sample
-// is still "no hit"); an entry is dropped when, in every block its clamped bounding box touches, that word is below the triangle's depth floor:
-//
-//   depth of a covered sample  zn = fl(fl(fl(e0 zq0) + fl(e1 zq1)) + fl(e2 zq2)),  e_i = fl(E_i),  E_i >= 0 integers with E0 + E1 + E2 = A = c0 + c1 + c2
-//   (kind 0 setup: a_i and b_i sum to zero, the c_i to twice the area, all exact).  With zq_min = min zq_i > 0 every product is >= zq_min E_i (1 - u)^2
-//   and the two sums lose at most (1 - u) each, u = 2^-24 (round to nearest is monotone):  zn >= zq_min A (1 - u)^4  >  zq_min A (1 - 2^-21).
-//   floor = fl(t - fl(t 2^-19)), t = fl(zq_min fl(A))  <=  zq_min A (1 + u)^3 (1 - 2^-19)  <  zq_min A (1 - 2^-21): below every zn.
-//
-// No barrier is spent on any of it.  Keys only ever decrease (ds_min_u64), so a depth word read while other wavefronts are still rasterising is an upper
-// bound of what the sample will end up with, the grid built from such reads is an upper bound per block, and an older grid is a weaker one: the test
-// can only err towards walking.  Within a batch every wavefront first takes the entries hinted as last frame's visible triangles (FrameDev.occ_cur;
-// untested), then the rest (tested); the last wavefront to run out of hinted entries rebuilds the grid on its way.
-// Triangles that cross w <= 0 (kind 1), or with a vertex in front of the near plane (zq_min <= 0), have floor 0 and are never dropped.  The result
-// does not depend on which entries are dropped or in which order the list is walked: tests/test_gpu_parity.py compares the keys with the oracle (which
-// knows nothing of this) bit for bit, and the VERIFY instantiation re-evaluates every sample of every dropped entry against the tile (counters[17]
-// must stay 0).
-AWSM_DI uint32_t tri_depth_floor_bits(const TriSetup& t) {
-    if (!t.exact) return 0u;
-    const float zq_min = fminf(fminf(t.zq[0], t.zq[1]), t.zq[2]);      // a NaN or infinite zq makes every zn fail 0 <= zn <= 1: no sample, nothing to lose
-    if (!(zq_min > 0.0f)) return 0u;
-    const float tz = zq_min * (float)((t.c[0] + t.c[1]) + t.c[2]);
-    const float lo = tz - tz * 1.9073486328125e-6f;
-    return lo > 0.0f ? __float_as_uint(lo) : 0u;
-}
-// A per-thread constant used in one rarely executed place: recomputed there from a copy of the thread id the optimiser cannot see through, instead of
-// being hoisted out of the batch loops into a register that lives for the whole kernel — k_raster_tile<1> runs at 72 VGPRs (seven workgroups per CU)
-// and has none to spare; a spill gives the kernel a scratch segment (slower dispatch).
-AWSM_DI uint32_t not_hoisted(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
-// The grid, by ONE wavefront: lane = block; sixteen pixels (x S samples) per lane.
-template <int S>
-AWSM_DI void build_depth_grid(const unsigned long long* keys, uint32_t* grid, uint32_t lane) {
-    const uint2* k = reinterpret_cast<const uint2*>(keys + (((lane >> 3) * 4u) * kTile + (lane & 7u) * 4u) * S);
-    uint32_t m = 0u;
-#pragma unroll
-    for (int row = 0; row < 4; row++)
-#pragma unroll
-        for (int i = 0; i < 4 * S; i++) m = max(m, k[row * kTile * S + i].y);
-    grid[lane] = m;
-}
-// this lane's share of "may the entry still win a sample": blocks (bx0 + lx + NX i, by0 + ly + NY j) of the box, (lx, ly) in [0, NX) x [0, NY)
-template <int NX, int NY>
-AWSM_DI bool grid_may_win(const uint32_t* grid, uint32_t bb, uint32_t zlo, int lx, int ly) {
-    const int bx0 = (int)((bb & 31u) >> 2), bx1 = (int)(((bb >> 5) & 31u) >> 2), by0 = (int)(((bb >> 10) & 31u) >> 2), by1 = (int)(((bb >> 15) & 31u) >> 2);
-    bool vis = false;
-    for (int by = by0 + ly; by <= by1; by += NY)
-        for (int bx = bx0 + lx; bx <= bx1; bx += NX) vis |= grid[by * 8 + bx] >= zlo;
-    return vis;
-}
-// VERIFY: every sample of a dropped entry, evaluated the way every walk evaluates it, against the tile as it stands; returns the samples it would have won
-template <int S>
-AWSM_DI uint32_t verify_dropped(const FrameDev& f, const unsigned long long* keys, uint32_t rank, uint32_t bb, int tpx, int tpy, int lane, int lanes) {
-    TriSetup t;
-    tri_rec_load(f.tri_rec + rank, t);
-    AWSM_WORK_BBOX(bb, x0, x1, y0, y1);
-    const int w = x1 - x0 + 1, n = w * (y1 - y0 + 1);
-    uint32_t wins = 0u;
-    for (int i = lane; i < n; i += lanes) {
-        const int px = x0 + i % w, py = y0 + i / w;
-        const int sx = (tpx + px) << 8, sy = (tpy + py) << 8;
-#pragma unroll
-        for (int sm = 0; sm < S; sm++) {
-            const unsigned long long k = S == 1 ? tri_sample_key_at(t, sample_coord(sx + 128), sample_coord(sy + 128), rank)
-                                                : tri_sample_key_at(t, sample_coord(sx + msaa4_x(sm)), sample_coord(sy + msaa4_y(sm)), rank);
-            if (k < keys[(py * kTile + px) * S + sm]) wins++;
-        }
-    }
-    return wins;
+    t.exact = g.exact != 0u; t.small = g.exact == 2u;
 }
 
 // One pixel of the tile against one triangle: S = 1 samples the pixel centre, S = 4 the four standard MSAA positions
@@ -783,7 +701,7 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
 // raster_walk_i32<1, 4> from a WorkSmall record
 AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int lx, int ly) {
     const uint32_t bb = g.bbox, r = g.rank, bw = g.bias;
-    AWSM_WORK_BBOX(bb, x0, x1, y0, y1);
+    const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
     int e[3], bias[3], sx[3], sy[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -820,7 +738,7 @@ AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int
 // constant (a ox + b oy) / 256 (a, b: multiples of 256), three adds, one OR3 and one compare per sample.
 AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, int lx, int ly) {
     const uint32_t bb = g.bbox, r = g.rank, bw = g.bias;
-    AWSM_WORK_BBOX(bb, x0, x1, y0, y1);
+    const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
     int e[3], bias[3], sx[3], sy[3], d[4][3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -902,25 +820,15 @@ AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, i
 #ifndef AWSM_RASTER_WAVES1
 #define AWSM_RASTER_WAVES1 7
 #endif
-#ifndef AWSM_STAMP_LATTICE
-#define AWSM_STAMP_LATTICE 3      // hints from every 4th pixel of every 4th row (7: every 8th)
-#endif
-template <int S, bool VERIFY>
+template <int S>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 : AWSM_RASTER_WAVES1))) void k_raster_tile(FrameDev f) {
     __shared__ unsigned long long keys[kTile * kTile * S];   // 8 KB, or 32 KB with 4 samples per pixel: [pixel][sample]
     // Triangles per batch: fewer than threads, for occupancy — most tiles hold fewer than a hundred anyway.  Four samples per pixel: 96, so that keys +
     // list fit a CU's LDS four times instead of three (32 KB + 6.75 KB against 32 KB + 18 KB; k_raster_tile<4> 281 -> 240 us at 4K).  One sample:
     // 128 and a 72-register budget, seven workgroups per CU instead of six (75 -> 72 us; an eighth needs 64 registers and spills).
     constexpr uint32_t kBatch = S == 4 ? (AWSM_RASTER_BATCH4 ? AWSM_RASTER_BATCH4 : 256u) : AWSM_RASTER_BATCH1;
-    __shared__ WorkTri work[kBatch];   // the batch's set-up triangles, each in the slot of the thread that set it up
-    // who walks what, in which order: four lists of slot numbers — mid / big triangles, hinted ("front": last frame's visible triangles, walked first and
-    // untested) / not ("back": tested against the tile before a walk) — and the counters that hand their entries out
-    __shared__ uint8_t lists[4][kBatch];
-    __shared__ uint32_t ctr[12];       // list lengths [0] mid front, [1] mid back, [2] big front, [3] big back; next entry [4] mid front, [5] mid back, [6] big front, [7] big
-                                       // back; [8] wavefronts of this batch that have finished their front entries
-    __shared__ uint32_t grid[64];      // per 4x4-pixel block: an upper bound of the depth words of its samples (build_depth_grid)
-    __shared__ uint32_t grid_ready;    // a grid has been built for this tile
-    __shared__ uint32_t n_culled, n_wins, n_tested;
+    __shared__ WorkTri work[kBatch];   // mid triangles from the front, big triangles from the back
+    __shared__ uint32_t n_mid, n_big, next_mid, next_big;
 
     // Heaviest tiles first (tile_order, k_bin_scan).  Consecutive ids go to different XCDs (blockIdx & 7), which also
     // spreads the dense band of the screen over all eight of them.
@@ -940,7 +848,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
 
 #pragma unroll
     for (int i = 0; i < 4 * S; i++) keys[tid + i * 256] = ~0ull;   // render_pass.rs:22-30,107-114: "no hit", depth 1.0
-    if (tid == 0) { n_culled = 0u; n_wins = 0u; n_tested = 0u; grid_ready = 0u; }
     const uint32_t off = f.tile_offset[tile];
     const uint32_t count_all = f.tile_count[tile];
     const uint32_t slot0 = (count_all > kRasterSlice && f.raster_scratch) ? f.tile_split[2u * tile] : 0xFFFFFFFFu;
@@ -950,41 +857,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
     const uint32_t first = split ? min(slice * kRasterSlice, count_fit) : 0u;
     const uint32_t count = split ? min((slice + 1u) * kRasterSlice, count_fit) : count_fit;
     const int lane = tid & 63, wave = tid >> 6;
-    const bool cull = (f.raster_cull & 0xFFu) != 0u;
 
-#pragma unroll 1
     for (uint32_t base = first; base < count; base += kBatch) {
-        if (tid < 9u) { const uint32_t k = not_hoisted(tid); ctr[k] = (k == 4u) ? 16u : (k == 6u ? 4u : 0u); }      // (k: a per-thread address the register allocator would otherwise keep through the loops, and spill)
+        if (tid == 0) { n_mid = 0; n_big = 0; next_mid = 16u; next_big = 4u; }
         __syncthreads();
         const uint32_t idx = base + tid;
         if (base == first) AWSM_STAMP_AT(f, 3, 1);
         if (idx < count && tid < kBatch) {
             const uint32_t r = f.bin_list[off + idx];
-            // the hint and the setup record travel together (no dependent load); no hints at all = everything "front", in later batches tested all the same
-            const uint32_t back = f.occ_cur ? ((f.occ_cur[r] & 2u) ? 0u : 1u) : (base > first ? 1u : 0u);
             TriSetup t;
             if (tri_rec_load(f.tri_rec + r, t)) {       // setup done once per frame by k_bin<count>
                 const int x0 = max(t.minx, tpx), x1 = min(t.maxx, tpx + kTile - 1);
                 const int y0 = max(t.miny, tpy), y1 = min(t.maxy, tpy + kTile - 1);
                 if (x0 <= x1 && y0 <= y1) {
                     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-                    const uint32_t zlo = (cull && back && !(f.raster_cull & 0x400u)) ? tri_depth_floor_bits(t) : 0u;      // 0 = walk without asking
                     if (area <= 4) {
-                        const uint32_t bbox = work_bbox(x0 - tpx, x1 - tpx, y0 - tpy, y1 - tpy, 0u);
-                        bool walk = true;
-                        if (zlo && grid_ready) {
-                            walk = grid_may_win<1, 1>(grid, bbox, zlo, 0, 0);
-                            if (VERIFY) atomicAdd(&n_tested, 1u);
-                            if (!walk) { atomicAdd(&n_culled, 1u); if (VERIFY) { const uint32_t w = verify_dropped<S>(f, keys, r, bbox, tpx, tpy, 0, 1); if (w) atomicAdd(&n_wins, w); walk = true; } }
-                        }
-                        if (walk)
-                            for (int py = y0; py <= y1; py++)
-                                for (int px = x0; px <= x1; px++) raster_pixel<S>(keys, t, tpx, tpy, px - tpx, py - tpy, r);
+                        for (int py = y0; py <= y1; py++)
+                            for (int px = x0; px <= x1; px++) raster_pixel<S>(keys, t, tpx, tpy, px - tpx, py - tpy, r);
                     } else {
-                        const uint32_t which = (area <= 256 ? 0u : 2u) + back;
-                        lists[which][atomicAdd(&ctr[which], 1u)] = (uint8_t)tid;
+                        const uint32_t slot = (area <= 256) ? atomicAdd(&n_mid, 1u) : (kBatch - 1u) - atomicAdd(&n_big, 1u);
+                        const uint32_t bbox = (uint32_t)(x0 - tpx) | ((uint32_t)(x1 - tpx) << 8) | ((uint32_t)(y0 - tpy) << 16) | ((uint32_t)(y1 - tpy) << 24);
                         if (area <= 256 && t.small) {
-                            WorkSmall& g = reinterpret_cast<WorkSmall&>(work[tid]);
+                            WorkSmall& g = reinterpret_cast<WorkSmall&>(work[slot]);
                             const double half = S == 1 ? 0.5 : 0.0;      // one sample: the pixel's centre; four: its corner, the samples add their own offsets
                             const double X = (double)(tpx + ((x0 - tpx) & ~3)) + half, Y = (double)(tpy + ((y0 - tpy) & ~3)) + half;
                             uint32_t bw = 0u;
@@ -995,13 +889,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
                                 g.a[i] = (int)t.a[i]; g.b[i] = (int)t.b[i]; g.zq[i] = t.zq[i];
                                 bw |= (uint32_t)bias << i;
                             }
-                            g.bias = bw; g.rank = r; g.bbox = work_bbox(x0 - tpx, x1 - tpx, y0 - tpy, y1 - tpy, 2u); g.zlo = zlo;
+                            g.bias = bw; g.rank = r; g.bbox = bbox; g.exact = 2u;
                         } else {
-                            WorkTri& g = work[tid];
+                            WorkTri& g = work[slot];
 #pragma unroll
                             for (int i = 0; i < 3; i++) { g.a[i] = t.a[i]; g.b[i] = t.b[i]; g.c[i] = t.c[i]; g.zq[i] = t.zq[i]; }
-                            g.rank = r; g.zlo = zlo;
-                            g.bbox = work_bbox(x0 - tpx, x1 - tpx, y0 - tpy, y1 - tpy, (t.small && !(area <= 256)) ? 2u : (t.exact ? 1u : 0u));
+                            g.rank = r; g.exact = (t.small && !(area <= 256)) ? 2u : (t.exact ? 1u : 0u);
+                            g.bbox = bbox;
                         }
                     }
                 }
@@ -1009,95 +903,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
         }
         __syncthreads();
         if (base == first) AWSM_STAMP_AT(f, 3, 2);
-#pragma unroll 1
-        for (uint32_t pass = 0; pass < 2u; pass++) {      // 0: the hinted entries, untested; 1: the rest, tested against the grid when there is one
-        const volatile uint32_t* ready = &grid_ready;      // asked per entry: the grid appears while the back entries are being handed out
+        const uint32_t nm = n_mid, nb = n_big;
         {   // mid: 16 groups of 16 lanes, 4x4 pixel blocks.  The first triangle of a group is its own number; the next ones come from a
             // shared counter, so a group that drew small triangles takes more of them (they differ 60x in area: a static deal leaves
             // most of the workgroup waiting at the barrier for the group that drew the large ones).
-            const uint32_t nm = ctr[pass];
             const uint32_t group = tid >> 4;
             const int lx = (int)(tid & 3u), ly = (int)((tid >> 2) & 3u);
-            // (pass 0 starts every group on the entry of its own number; in pass 1 even the first entry comes from the counter: a group still walking a
-            // hinted triangle must not keep an entry reserved that an idle group could take)
-            uint32_t j = group;
-            if (pass) { uint32_t nx = 0u; if ((tid & 15u) == 0u) nx = atomicAdd(&ctr[5], 1u); j = (uint32_t)__shfl((int)nx, 0, 16); }
-            for (; j < nm; ) {
-                const WorkTri& g = work[lists[pass][j]];
-                bool walk = true;
-                const uint32_t zlo = g.zlo;
-                if (zlo && *ready) {      // the group asks the grid first: its 16 lanes take the (at most 5 x 5) blocks of the box, any lane's "may win" keeps the entry
-                    const unsigned long long m = __ballot(grid_may_win<4, 4>(grid, g.bbox, zlo, lx, ly));
-                    walk = ((m >> (not_hoisted(tid) & 48u)) & 0xFFFFull) != 0ull;
-                    if (VERIFY && (tid & 15u) == 0u) atomicAdd(&n_tested, 1u);
-                    if (!walk) {
-                        if ((tid & 15u) == 0u) atomicAdd(&n_culled, 1u);
-                        if (VERIFY) { const uint32_t w = verify_dropped<S>(f, keys, g.rank, g.bbox, tpx, tpy, (int)(tid & 15u), 16); if (w) atomicAdd(&n_wins, w); walk = true; }
-                    }
-                }
-                if (walk) {
-                if ((g.bbox >> 20) == 2u) { if (S == 1) raster_walk_small(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly); else raster_walk_small4(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly); }      // (every mid entry of kind 2 is a WorkSmall)
+            for (uint32_t j = group; j < nm; ) {
+                const WorkTri& g = work[j];
+                if (g.exact == 2u) { if (S == 1) raster_walk_small(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly); else raster_walk_small4(keys, reinterpret_cast<const WorkSmall&>(g), lx, ly); }      // (every mid entry marked 2 is a WorkSmall)
                 else {
                 TriSetup t;
                 load_work_tri(g, t);
                 const uint32_t bb = g.bbox, r = g.rank;
-                AWSM_WORK_BBOX(bb, x0, x1, y0, y1);
+                const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
                 raster_walk<S, 4>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r);
                 }
-                }
                 uint32_t nx = 0u;
-                if ((tid & 15u) == 0u) nx = atomicAdd(&ctr[4u + pass], 1u);
+                if ((tid & 15u) == 0u) nx = atomicAdd(&next_mid, 1u);
                 j = (uint32_t)__shfl((int)nx, 0, 16);
             }
         }
-        {
-        const uint32_t nb = ctr[2u + pass];
-        uint32_t j = wave;
-        if (pass) { uint32_t nx = 0u; if (lane == 0) nx = atomicAdd(&ctr[7], 1u); j = (uint32_t)__shfl((int)nx, 0, 64); }
-        for (; j < nb; ) {   // big: one wavefront per triangle, 8x8 pixel blocks
-            const WorkTri& g = work[lists[2u + pass][j]];
+        for (uint32_t j = wave; j < nb; ) {   // big: one wavefront per triangle, 8x8 pixel blocks
+            const WorkTri& g = work[(kBatch - 1u) - j];
+            TriSetup t;
+            load_work_tri(g, t);
             const uint32_t bb = g.bbox, r = g.rank;
-            bool walk = true;
-            const uint32_t zlo = g.zlo;
-            if (zlo && *ready) {      // one grid block per lane
-                walk = __ballot(grid_may_win<8, 8>(grid, bb, zlo, lane & 7, lane >> 3)) != 0ull;
-                if (VERIFY && lane == 0) atomicAdd(&n_tested, 1u);
-                if (!walk) {
-                    if (lane == 0) atomicAdd(&n_culled, 1u);
-                    if (VERIFY) { const uint32_t w = verify_dropped<S>(f, keys, r, bb, tpx, tpy, lane, 64); if (w) atomicAdd(&n_wins, w); walk = true; }
-                }
-            }
-            if (walk) {
-                TriSetup t;
-                load_work_tri(g, t);
-                AWSM_WORK_BBOX(bb, x0, x1, y0, y1);
-                const int lx = lane & 7, ly = lane >> 3;
-                raster_walk<S, 8>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r);
-            }
+            const int x0 = (int)(bb & 255u), x1 = (int)((bb >> 8) & 255u), y0 = (int)((bb >> 16) & 255u), y1 = (int)(bb >> 24);
+            const int lx = lane & 7, ly = lane >> 3;
+            raster_walk<S, 8>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r);
             uint32_t nx = 0u;
-            if (lane == 0) nx = atomicAdd(&ctr[6u + pass], 1u);
+            if (lane == 0) nx = atomicAdd(&next_big, 1u);
             j = (uint32_t)__shfl((int)nx, 0, 64);
-        }
-        }
-        if (pass == 0u && cull && (ctr[1] | ctr[3]) && !(f.raster_cull & 0x200u)) {      // this wavefront has no hinted entry left: the first and the last of the four to get here look the tile over
-            uint32_t k = 0u;
-            if (lane == 0) k = atomicAdd(&ctr[8], 1u);
-            k = (uint32_t)__shfl((int)k, 0, 64);
-            if (k == 3u) {      // the last of the four: every hinted entry of the batch has been walked or is in its last walk
-                build_depth_grid<S>(keys, grid, not_hoisted(tid) & 63u);
-                if (lane == 0) grid_ready = 1u;
-            }
-        }
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        if (n_culled) atomicAdd(&f.counters[16], n_culled);
-        if (VERIFY) { if (n_wins) atomicAdd(&f.counters[17], n_wins); if (n_tested) atomicAdd(&f.counters[18], n_tested); }
-    }
     __syncthreads();
     AWSM_STAMP_AT(f, 3, 3);
-    const uint32_t tid_end = not_hoisted(tid);      // what follows runs once: its addresses need not live through the batch loops
     if (split) {
         // Partial tile of a split list: park it in its scratch slot; the slice that finishes last folds the others into its own
         // (min over packed keys, the same resolve as inside a tile) and writes the tile.  The slices run on different XCDs, whose L2s
@@ -1111,7 +953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
         __shared__ uint32_t arrived;
         unsigned long long* mine = f.raster_scratch + (size_t)(slot0 + slice) * (kTile * kTile * S);
 #pragma unroll
-        for (int i = 0; i < 4 * S; i++) __hip_atomic_store(mine + tid_end + i * 256, keys[tid_end + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 4 * S; i++) __hip_atomic_store(mine + tid + i * 256, keys[tid + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) arrived = __hip_atomic_fetch_add(&f.tile_split[2u * tile + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1122,9 +964,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
             const unsigned long long* other = f.raster_scratch + (size_t)(slot0 + k) * (kTile * kTile * S);
             unsigned long long v[4 * S];      // all loads of a slice in flight together, then the min
 #pragma unroll
-            for (int i = 0; i < 4 * S; i++) v[i] = __hip_atomic_load(other + tid_end + i * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 4 * S; i++) v[i] = __hip_atomic_load(other + tid + i * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int i = 0; i < 4 * S; i++) if (v[i] < keys[tid_end + i * 256]) keys[tid_end + i * 256] = v[i];
+            for (int i = 0; i < 4 * S; i++) if (v[i] < keys[tid + i * 256]) keys[tid + i * 256] = v[i];
         }
         __syncthreads();
     }
@@ -1132,17 +974,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
     // 32-pixel rows) or 512 B runs per step
 #pragma unroll
     for (int i = 0; i < 4 * S; i++) {
-        const int e = (int)tid_end + i * 256;
+        const int e = (int)tid + i * 256;
         const int p = e / S, s = e % S;
         const int px = tpx + (p & (kTile - 1)), py = tpy + (p >> kTileShift);
-        const unsigned long long key = keys[e];
-        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) __builtin_nontemporal_store(key, &f.vis[((size_t)py * f.width + px) * S + s]);      // written once, read by the next kernel
-        // next frame's occluder hints: every triangle that holds a sample of the finished tile gets its byte set — by the samples whose left and upper
-        // neighbours (same sample index) show another triangle, a few per triangle and tile instead of one per sample
-// next frame's occluder hints: the triangles that hold sample 0 of the pixels of a 4 x 4 lattice (64 of the tile's 1,024 pixels) get their byte set — a
-        // triangle a few pixels across is almost surely among them, a smaller one is no occluder worth an early turn; no comparing, no de-duplication
-        // (the stores all write the same 1)
-        if (f.occ_cur && s == 0 && (p & AWSM_STAMP_LATTICE) == 1 && ((p >> kTileShift) & AWSM_STAMP_LATTICE) == 2 && key != ~0ull && !(f.raster_cull & 0x100u)) f.occ_cur[0xFFFFFFFFu - (uint32_t)key] = (uint8_t)1;
+        if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) __builtin_nontemporal_store(keys[e], &f.vis[((size_t)py * f.width + px) * S + s]);      // written once, read by the next kernel
     }
     AWSM_STAMP_AT(f, 3, 4);
 }
@@ -1288,7 +1123,6 @@ extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (!n_tiles) return;
     const uint32_t nb = n_tiles + (f->raster_scratch ? f->raster_extra_cap : 0u);     // surplus ids exit at once
-    const bool verify = (f->raster_cull & 0xFFu) == 2u;      // the checking build of the same kernel (tests): dropped entries are evaluated sample by sample against the tile
-    if (f->msaa == 4u) { if (verify) hipLaunchKernelGGL((awsm::k_raster_tile<4, true>), dim3(nb), dim3(256), 0, s, *f); else hipLaunchKernelGGL((awsm::k_raster_tile<4, false>), dim3(nb), dim3(256), 0, s, *f); }
-    else { if (verify) hipLaunchKernelGGL((awsm::k_raster_tile<1, true>), dim3(nb), dim3(256), 0, s, *f); else hipLaunchKernelGGL((awsm::k_raster_tile<1, false>), dim3(nb), dim3(256), 0, s, *f); }
+    if (f->msaa == 4u) hipLaunchKernelGGL(awsm::k_raster_tile<4>, dim3(nb), dim3(256), 0, s, *f);
+    else hipLaunchKernelGGL(awsm::k_raster_tile<1>, dim3(nb), dim3(256), 0, s, *f);
 }

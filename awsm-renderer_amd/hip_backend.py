@@ -19,8 +19,6 @@ AWSM_CFG_SMALL_BIN_LIST = 2
 AWSM_CFG_OVERLAP_FRAMES = 4
 AWSM_CFG_GENERAL_SHADE_ONLY = 8
 AWSM_CFG_ANISOTROPIC = 16
-AWSM_CFG_NO_OCCLUSION_CULL = 32
-AWSM_CFG_VERIFY_OCCLUSION_CULL = 64
 
 BUF_NAMES = ["TRANSFORMS", "NORMAL_MATS", "MATERIALS", "LIGHTS", "LIGHTS_INFO", "CAMERA", "SKIN_MATRICES", "SKIN_INDEX_WEIGHTS",
              "MORPH_WEIGHTS", "MORPH_VALUES", "GEOM_META", "MATERIAL_META", "VIS_GEOM_DATA", "VIS_GEOM_INDEX", "ATTR_DATA", "ATTR_INDEX",
@@ -65,7 +63,7 @@ class AwsmFrameStats(C.Structure):
                 ("triangles_in", C.c_uint32), ("triangles_binned", C.c_uint32), ("bin_entries", C.c_uint32), ("covered_pixels", C.c_uint32),
                 ("bin_overflow_retries", C.c_uint32), ("ms_forward", C.c_float), ("forward_triangles", C.c_uint32), ("forward_fragment_slots", C.c_uint32),
                 ("ms_shade_lean", C.c_float), ("shade_general_wavefronts", C.c_uint32), ("frames_with_dropped_bin_entries", C.c_uint32),
-                ("handoff_gate_timeouts", C.c_uint32), ("raster_entries_culled", C.c_uint32), ("raster_cull_verify_wins", C.c_uint32), ("raster_entries_tested", C.c_uint32)]
+                ("handoff_gate_timeouts", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "struct_size")}
@@ -145,10 +143,9 @@ class HipDevice:
     """One AwsmHipCtx: one HIP device + stream."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False, small_bin_list: bool = False, overlap_frames: bool = False,
-                 general_shade_only: bool = False, anisotropic: bool = False, occlusion_cull="on"):
-        """occlusion_cull: "on" (default), "off" (AWSM_CFG_NO_OCCLUSION_CULL) or "verify" (AWSM_CFG_VERIFY_OCCLUSION_CULL: the checking build of k_raster_tile)."""
+                 general_shade_only: bool = False, anisotropic: bool = False):
         self.lib = load_library()
-        flags = {"on": 0, "off": AWSM_CFG_NO_OCCLUSION_CULL, "verify": AWSM_CFG_VERIFY_OCCLUSION_CULL}[occlusion_cull] | (AWSM_CFG_ANISOTROPIC if anisotropic else 0) | (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0) | (AWSM_CFG_OVERLAP_FRAMES if overlap_frames else 0) | (AWSM_CFG_GENERAL_SHADE_ONLY if general_shade_only else 0)
+        flags = (AWSM_CFG_ANISOTROPIC if anisotropic else 0) | (AWSM_CFG_PARITY_TAP if parity_tap else 0) | (AWSM_CFG_SMALL_BIN_LIST if small_bin_list else 0) | (AWSM_CFG_OVERLAP_FRAMES if overlap_frames else 0) | (AWSM_CFG_GENERAL_SHADE_ONLY if general_shade_only else 0)
         cfg = AwsmConfig(C.sizeof(AwsmConfig), self.lib.awsm_hip_abi_version(), device, flags, stream)
         ctx = C.c_void_p()
         rc = self.lib.awsm_hip_create(C.byref(cfg), C.byref(ctx))

@@ -125,14 +125,13 @@ class Host:
     """One AwsmHost: scene state + a device context reached through the awsm_hip_* C-ABI of `backend_path`."""
 
     def __init__(self, backend_path: Optional[str] = None, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False, overlap_frames: bool = False,
-                 anisotropic: bool = False, occlusion_cull: str = "on"):
+                 anisotropic: bool = False):
         self.lib = load_library()
         backend_path = backend_path or hip_backend.LIB_PATH
         if not os.path.exists(backend_path):
             raise FileNotFoundError(f"backend library {backend_path} not found (no CPU fallback exists for the product path)")
         h = C.c_void_p()
         flags = (hip_backend.AWSM_CFG_PARITY_TAP if parity_tap else 0) | (hip_backend.AWSM_CFG_OVERLAP_FRAMES if overlap_frames else 0) | (hip_backend.AWSM_CFG_ANISOTROPIC if anisotropic else 0)
-        flags |= {"on": 0, "off": hip_backend.AWSM_CFG_NO_OCCLUSION_CULL, "verify": hip_backend.AWSM_CFG_VERIFY_OCCLUSION_CULL}[occlusion_cull]
         rc = self.lib.awsm_host_create(backend_path.encode(), device, stream, flags, C.byref(h))
         if rc != 0:
             raise HostError(f"awsm_host_create({backend_path}) failed with status {rc}")
@@ -581,11 +580,11 @@ class Renderer:
 
     def __init__(self, scene: SceneDesc, backend_path: Optional[str] = None, device: int = 0, stream: Optional[int] = None, parity_tap: bool = False,
                  lut_rgba16f: Optional[np.ndarray] = None, lut_size: int = 1024, msaa: int = 0, mipmap: bool = False, overlap_frames: bool = False,
-                 gltf: Optional[str] = None, anisotropic: bool = False, occlusion_cull: str = "on"):
+                 gltf: Optional[str] = None, anisotropic: bool = False):
         """gltf: path of a .gltf / .glb file to populate from (AwsmRenderer::populate_gltf); `scene` then only supplies the frame size,
         the camera and the environment."""
         self.scene = scene
-        self.host = Host(backend_path, device, stream, parity_tap, overlap_frames, anisotropic, occlusion_cull)      # anisotropic: AWSM_CFG_ANISOTROPIC (include/awsm_hip.h)
+        self.host = Host(backend_path, device, stream, parity_tap, overlap_frames, anisotropic)      # anisotropic: AWSM_CFG_ANISOTROPIC (include/awsm_hip.h)
         self.host.set_anti_aliasing(msaa, mipmap)   # AwsmRendererBuilder::with_anti_aliasing (off unless asked: BASELINE configs are single-sampled, MipmapMode::None)
         self.host.resize(scene.width, scene.height)
         if gltf is not None:

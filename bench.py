@@ -633,7 +633,7 @@ def main():
                        "opaque_route": "lean (k_shade_lean + k_shade_todo)" if lean else "general (k_shade)",
                        "library": os.path.relpath(hip_backend_path(), ROOT)},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels", "shade_general_wavefronts",
-                                                "frames_with_dropped_bin_entries", "bin_overflow_retries", "raster_entries_culled") if k in st},
+                                                "frames_with_dropped_bin_entries", "bin_overflow_retries")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             **({"collective": {"backend": "rccl" if backend == "nccl" else backend + " (rehearsal: every rank on GPU 0, staged through the host)",

@@ -95,11 +95,6 @@ typedef struct AwsmConfig {
                                   * default: textureSampleGrad's anisotropy is implementation-defined in WebGPU, and the default here is the
                                   * isotropic rule the reference itself documents (helpers/mipmap.wgsl:419-439).  Draws whose core textures
                                   * ask for anisotropy leave the lean opaque route under this flag. */
-#define AWSM_CFG_NO_OCCLUSION_CULL 32u /* k_raster_tile walks every (triangle, tile) entry (A/B measurements).  By default an entry that lies wholly behind what its
-                                        * tile already holds is dropped before its walk, and each tile's list starts with the triangles that were visible in the
-                                        * previous frame; the keys are the same bit for bit either way. */
-#define AWSM_CFG_VERIFY_OCCLUSION_CULL 64u /* tests: every dropped entry is evaluated sample by sample against its tile after all
-                                        * (AwsmFrameStats.raster_cull_verify_wins must stay 0) */
 #define AWSM_CFG_SMALL_BIN_LIST 2u /* start with a 4096-entry (triangle, tile) list instead of sizing it from the triangle count:
                                      exercises the overflow -> grow -> replay path of awsm_hip_frame_end (tests) */
 
@@ -172,10 +167,6 @@ typedef struct AwsmFrameStats {
     uint32_t handoff_gate_timeouts;  /* AWSM_CFG_OVERLAP_FRAMES with device-side hand-off: gates that ran out of time since the context was created.  Each one
                                          dropped the frame it guarded whole (its kernels exit at once: the image is not written, nothing is shaded from
                                          half-written buffers) and was reported once with AWSM_ERR_DEVICE. */
-    uint32_t raster_entries_culled;  /* (triangle, tile) entries of the last geometry pass that k_raster_tile dropped before their walk: every sample they could
-                                         produce lay behind the tile's depth grid (of bin_entries) */
-    uint32_t raster_cull_verify_wins; /* AWSM_CFG_VERIFY_OCCLUSION_CULL: samples of dropped entries that would have changed a key — 0, or the cull is wrong */
-    uint32_t raster_entries_tested;  /* AWSM_CFG_VERIFY_OCCLUSION_CULL: entries that met a depth grid (the rest were walked before their tile had one) */
 } AwsmFrameStats;
 
 /* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */

@@ -1326,76 +1326,3 @@ def test_hud_passes(oracle_lut):
     assert (hdev.read_opaque()[covered] == 0).all()
     rr.close()
 
-
-# ---- occlusion inside the raster tiles (kernels_geometry.hip "occlusion inside a tile"; VERDICT r3 "next" #2) ----
-def _orbit(sc, k, n=24, radius=0.6):
-    """camera k of a small orbit around the scene's own camera, looking the same way (bench.py's motion, larger steps)"""
-    import math
-    inv_view = np.linalg.inv(np.asarray(sc.view, dtype=np.float64).T)
-    eye0 = np.asarray(sc.camera_position, dtype=np.float64)
-    fwd, right, up = -inv_view[:3, 2], inv_view[:3, 0], inv_view[:3, 1]
-    a = 2.0 * math.pi * k / n
-    eye = eye0 + radius * (math.cos(a) * right + math.sin(a) * up)
-    return scenes.look_at_rh(tuple(eye), tuple(eye + 30.0 * fwd)), tuple(eye)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("msaa", [0, 4])
-def test_occlusion_cull_leaves_every_key_as_the_oracle_has_it(oracle_lut, msaa):
-    """k_raster_tile drops (triangle, tile) entries that lie behind its depth grid and starts every tile with last frame's visible triangles.  Neither
-    may change a key: four frames of a moving camera (frame 0 has no hints, the later ones do) against the oracle, which walks everything; the checking
-    build of the kernel (AWSM_CFG_VERIFY_OCCLUSION_CULL) evaluates every sample of every dropped entry against its tile and must find none that wins."""
-    import copy
-    from awsm_renderer_amd.hip_backend import HipDevice
-    from awsm_renderer_amd.host import Renderer
-    sc = scenes.atrium_scene(960, 540, detail=0.25, tex_scale=1 / 32)
-    r = Renderer(sc, lut_rgba16f=oracle_lib.lut_rg_to_rgba16f(oracle_lut), msaa=msaa, occlusion_cull="verify")
-    dev = HipDevice.from_ctx(r.host.device_ctx, sc.width, sc.height)
-    dev.msaa = msaa
-    culled = []
-    for k in range(4):
-        cam = copy.copy(sc)
-        cam.view, cam.camera_position = _orbit(sc, k)
-        r.host.camera_update(cam.view, cam.proj, cam.camera_position)
-        st = r.host.render(sync=True)
-        fr = oracle_lib.frame_from_model(helpers.build_model(cam), oracle_lut, msaa=msaa)
-        fr.transform(); fr.raster(os.cpu_count() or 8)
-        assert int((dev.read_visibility() != fr.keys).sum()) == 0, f"frame {k}"
-        assert st["raster_cull_verify_wins"] == 0, st
-        assert st["raster_entries_tested"] >= st["raster_entries_culled"]
-        culled.append(st["raster_entries_culled"] / max(1, st["bin_entries"]))
-    dev.close(); r.close()
-    assert min(culled[1:]) > 0.1, culled      # with hints a good part of the hidden entries goes (the atrium hides most of what it bins)
-
-
-@pytest.mark.gpu
-def test_occlusion_cull_with_changing_draw_lists_shards_and_small_lists(oracle_lut):
-    """The hints follow a draw through a re-sorted, shortened or lengthened draw list (occ_prev_first), survive a list overflow + replay, and mean nothing
-    more than an order: a context that culls, one that does not and one that checks hold the same keys frame after frame, on the full frame, on a row
-    strip and on bands."""
-    from awsm_renderer_amd.hip_backend import HipDevice
-    sc = scenes.atrium_scene(640, 360, detail=0.25, tex_scale=1 / 64)
-    model = helpers.build_model(sc)
-    draws = model.collect_draws()
-    n = len(draws)
-    rng = np.random.default_rng(11)
-    lists = [draws, draws[::-1], [draws[i] for i in rng.permutation(n)[: n // 2]], draws, [draws[i] for i in rng.permutation(n)], draws[: n // 3] + draws[: n // 3]]
-    devs = {mode: HipDevice(occlusion_cull=mode, small_bin_list=(mode == "verify")) for mode in ("on", "off", "verify")}
-    for d in devs.values():
-        d.resize(sc.width, sc.height, 0)
-        d.upload_mirrors(model.mirrors())
-    for shard in ("full", "rows", "bands"):
-        for d in devs.values():
-            if shard == "rows": d.set_shard_rows(100, 281)
-            if shard == "bands": d.set_shard_rows(0, 0); d.set_shard_bands(3, 1, 0)
-        for i, lst in enumerate(lists):
-            keys = {}
-            for mode, d in devs.items():
-                d.geometry_pass(lst)
-                st = d.frame_end()
-                keys[mode] = d.read_visibility()
-                if mode == "verify": assert st["raster_cull_verify_wins"] == 0, (shard, i, st)
-                if mode == "off": assert st["raster_entries_culled"] == 0
-            assert (keys["on"] == keys["off"]).all() and (keys["verify"] == keys["off"]).all(), (shard, i)
-    for d in devs.values():
-        d.close()
