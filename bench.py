@@ -577,14 +577,20 @@ def main():
     prof = pmc_profile(n_tris, W, H) if (world == 1 and args.config == 4 and not args.msaa and not args.mipmap) else None
     pk = pmc_kernel(prof, dom)
     valu = valu_issue(pk, kernel_ms[dom], pmc_mix(prof, dom))
+    # Calibrated (profiles/r04_traffic_calibration.txt, r04_traffic_request_sizes.txt; tools/traffic_calibration.sh, tools/traffic_sizes.sh): on gfx950 EVERY
+    # memory-side read request of these kernels is 128 bytes — an 8-byte scattered texel pair, a 13-lane 16-byte record gather and a streamed key
+    # read alike (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ; _32B = 0, _64B ~ 0) — while FETCH_SIZE tallies each at 64 bytes.  So traffic = 2 x FETCH_SIZE +
+    # WRITE_SIZE for every access pattern here, not only for wide streams; it is measured at the L2's fabric side and includes Infinity-Cache hits.
     traffic_raw = pk.get("hbm_read_bytes_raw", 0.0) + pk.get("hbm_write_bytes", 0.0) if pk else None
+    traffic_cal = 2.0 * pk.get("hbm_read_bytes_raw", 0.0) + pk.get("hbm_write_bytes", 0.0) if pk else None
     roofline = {"bound": "valu_issue" if (valu and valu["frac"] > achieved / HBM_PEAK_GBS) else "hbm",
                 "kernel": ("k_shade_lean" if lean else "k_shade") if dom == "k_shade" else dom,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "frac_hbm_low": achieved_low / HBM_PEAK_GBS, "frac_hbm_high": achieved / HBM_PEAK_GBS,
                 "frac_valu": valu["frac"] if valu else None,
-                "traffic": traffic_raw, "traffic_raw": traffic_raw,
-                "traffic_wide_corrected": (2.0 * pk.get("hbm_read_bytes_raw", 0.0) + pk.get("hbm_write_bytes", 0.0)) if pk else None,
+                "traffic": traffic_cal, "traffic_raw_counters": traffic_raw,
+                "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE: every read request is 128 B on gfx950 (TCC_EA0_RDREQ_128B), FETCH_SIZE counts 64; L2 fabric side, Infinity-Cache hits included",
+                "frac_fabric": (traffic_cal / (kernel_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic_cal and kernel_ms[dom] > 0) else None,
                 "profile_tag": prof.get("tag") if prof else None,
                 "algorithmic_bytes_per_launch": alg[dom], "algorithmic_bytes_per_launch_low": alg_low if dom == "k_shade" else alg[dom],
                 "launch_ms": kernel_ms[dom], "valu_issue": valu,
