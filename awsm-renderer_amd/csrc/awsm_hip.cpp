@@ -98,6 +98,7 @@ struct AwsmHipCtx {
     std::string last_error;
 
     DevBuf bufs[AWSM_BUF_COUNT];
+    bool camera_written_since_snapshot = false;      // awsm_hip_buffer_write(AWSM_BUF_CAMERA) since the last geometry pass took its snapshot
     uint8_t camera_host[512] = {};   // what the caller last wrote to AWSM_BUF_CAMERA (awsm_hip_buffer_write): compose_pixel_to_view reads it
     DevScene scene{};            // host copy
     DevScene* scene_dev = nullptr;
@@ -159,9 +160,12 @@ struct AwsmHipCtx {
     uint32_t hud_total_tris = 0, hud_n_blocks = 0;
     bool hud_geometry_done = false;   // this frame has hud geometry: the opaque pass leaves its pixels cleared
     bool hud_transparent = false;     // the transparent pass being enqueued is the HUD one (depth cleared, colours loaded from the composite)
-    std::vector<DrawDev> tr_draws_host;
-    uint32_t tr_total_tris = 0, tr_n_blocks = 0;
-    bool transparent_done = false;
+    // [0] the world transparent pass, [1] the HUD transparent pass: each with its own per-slot device state (tr / htr) — the HUD pass of a frame is enqueued
+    // while the world pass of the same frame may not have started on the shade stream, so they share neither a draw list nor counters
+    std::vector<DrawDev> tr_draws_host[2];
+    uint32_t tr_total_tris[2] = {0, 0}, tr_n_blocks[2] = {0, 0};
+    bool transparent_done = false, hud_transparent_done = false;
+    FrameBufs htr[kSlots];
     DevBuf comp16, comp32;       // composite image (after the transparent pass) + parity tap
     DevBuf lights_pre[kSlots];        // per frame slot: per-light constants (k_resolve_draws), sized with the lights buffer
     void* bound_comp = nullptr;
@@ -444,7 +448,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->host_bin_status = c->counters_host + 16 + 2 * c->slot;
     f->frame_serial = c->frame_serial;
     f->vis = (unsigned long long*)FB(c).vis.ptr;
-    f->camera = (const uint8_t*)(c->overlap ? FB(c).camera.ptr : c->bufs[AWSM_BUF_CAMERA].ptr);
+    f->camera = (const uint8_t*)FB(c).camera.ptr;      // the snapshot the geometry pass took: every kernel of a frame, lean or general, sees the camera the frame was submitted with
     f->camera_snap = nullptr; f->camera_snap_words = 0;
     memcpy(f->pix2view, FB(c).pix2view, sizeof f->pix2view); memcpy(f->view_rot, FB(c).view_rot, sizeof f->view_rot); memcpy(f->cam_pos, FB(c).cam_pos, sizeof f->cam_pos);
     memcpy(f->ortho_view_dir, FB(c).ortho_view_dir, sizeof f->ortho_view_dir); f->cam_ortho = FB(c).cam_ortho;
@@ -514,16 +518,18 @@ int enqueue_geometry(AwsmHipCtx* c) {
     int rc = sync_scene(c);
     if (rc) return rc;
     ht.mark("geometry: sync_scene");
+    // this slot's buffers were last read by the opaque pass kSlots frames ago (already ordered by awsm_hip_geometry_pass; a replay comes here directly)
+    if (c->overlap && c->shade_pending[c->slot]) { HIPCHK(c, wait_slot_free(c)); c->shade_pending[c->slot] = false; }
+    // the camera the frame is shaded with = the camera it was submitted with, in every mode: the lean kernel's pix2view was composed from the caller's
+    // bytes at awsm_hip_geometry_pass, the general kernels and the MSAA detector read this snapshot — a camera write between the two passes of a frame
+    // cannot give its strips two cameras
+    // (copied by k_deform_transform when the frame has geometry: a 512-byte hipMemcpyAsync costs the stream 18 us of gap + copy)
+    if (c->bufs[AWSM_BUF_CAMERA].ptr) {
+        const size_t cam_bytes = std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size);
+        if (c->total_tris && n_tiles) { f.camera_snap = (uint32_t*)FB(c).camera.ptr; f.camera_snap_words = (uint32_t)(cam_bytes / 4); }
+        else HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, cam_bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
     if (c->overlap) {
-        // this slot's buffers were last read by the opaque pass kSlots frames ago (already ordered by awsm_hip_geometry_pass; a replay comes here directly)
-        if (c->shade_pending[c->slot]) { HIPCHK(c, wait_slot_free(c)); c->shade_pending[c->slot] = false; }
-        // the camera the frame is shaded with = the camera it was submitted with
-        // (copied by k_deform_transform when the frame has geometry: a 512-byte hipMemcpyAsync costs the stream 18 us of gap + copy)
-        if (c->bufs[AWSM_BUF_CAMERA].ptr) {
-            const size_t cam_bytes = std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size);
-            if (c->total_tris && n_tiles) { f.camera_snap = (uint32_t*)FB(c).camera.ptr; f.camera_snap_words = (uint32_t)(cam_bytes / 4); }
-            else HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, cam_bytes, hipMemcpyDeviceToDevice, c->stream));
-        }
         // everything the per-draw resolve of this frame reads (draw list, scene buffers) is on the stream by now — an event only when a resolve
         // will run (resolve_key): a record packet costs the caller's stream ~19 us between the camera upload and the transform kernel
         c->uploads_recorded[c->slot] = false;
@@ -640,15 +646,16 @@ int enqueue_opaque(AwsmHipCtx* c) {
     return AWSM_OK;
 }
 
-inline FrameBufs& TR(AwsmHipCtx* c) { return c->tr[c->slot]; }
+inline FrameBufs& TR(AwsmHipCtx* c) { return (c->hud_transparent ? c->htr : c->tr)[c->slot]; }
 
 // The transparent pass's frame: its own draws / vertices / setup records / bins; the geometry pass's visibility keys for the depth
 // test; the opaque image as blit source and transmission background; the composite image as target.
 void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     fill_frame(c, f);
     FrameBufs& t = TR(c);
-    f->n_draws = (uint32_t)c->tr_draws_host.size();
-    f->total_tris = c->tr_total_tris; f->total_verts = 3u * c->tr_total_tris;
+    const int which = c->hud_transparent ? 1 : 0;
+    f->n_draws = (uint32_t)c->tr_draws_host[which].size();
+    f->total_tris = c->tr_total_tris[which]; f->total_verts = 3u * c->tr_total_tris[which];
     f->bin_capacity = t.bin_capacity;
     f->draws = (const DrawDev*)t.draws_dev.ptr;
     f->draw_shade = (DrawShadeDev*)t.draw_shade.ptr;
@@ -697,7 +704,7 @@ int enqueue_transparent(AwsmHipCtx* c) {
         if (n_tiles) HIPCHK(c, hipMemsetAsync(TR(c).tile_count.ptr, 0, n_tiles * sizeof(uint32_t), ss));
     } else {
         awsm_launch_resolve_draws(c->scene_dev, &f, ss);      // first: the transform tags each triangle with its draw's alpha mode
-        awsm_launch_transform_forward(c->scene_dev, &f, c->tr_n_blocks, ss);
+        awsm_launch_transform_forward(c->scene_dev, &f, c->tr_n_blocks[c->hud_transparent ? 1 : 0], ss);
     }
     if (n_tiles) {
         if (f.total_tris) { awsm_launch_bin_count(&f, ss); awsm_launch_bin_big(&f, 0, ss); }
@@ -824,7 +831,7 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
         const size_t tri_bound = forward || instanced ? ~size_t(0) : c->bufs[AWSM_BUF_VIS_GEOM_DATA].size / 168u;
         const size_t tri_cap = std::max<size_t>(std::min<size_t>((size_t)total_tris + total_tris / 4 + 4096, std::max<size_t>(tri_bound, total_tris)), b.tri_cap);
         const size_t draw_cap = std::max<size_t>(draws_host.size() + draws_host.size() / 4 + 64, b.draw_cap);
-        FrameBufs* set = forward ? c->tr : ((&b >= c->hud && &b < c->hud + kSlots) ? c->hud : c->fb);
+        FrameBufs* set = forward ? ((&b >= c->htr && &b < c->htr + kSlots) ? c->htr : c->tr) : ((&b >= c->hud && &b < c->hud + kSlots) ? c->hud : c->fb);
         for (int sl = 0; sl < n_slots(c); sl++) {
             // (the slot in use first: if memory runs out half-way the current frame still has its buffers)
             FrameBufs& t = set[(c->slot + sl) % kSlots];
@@ -894,8 +901,12 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         c->fb[s].counters.size = 16 * sizeof(uint32_t);
         if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
         c->tr[s].counters.size = 16 * sizeof(uint32_t);
+        if (hipMalloc(&c->htr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
+        c->htr[s].counters.size = 16 * sizeof(uint32_t);
         if (hipMalloc(&c->hud[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
         c->hud[s].counters.size = 16 * sizeof(uint32_t);
+        if (hipMalloc(&c->fb[s].camera.ptr, 512) != hipSuccess || hipMemset(c->fb[s].camera.ptr, 0, 512) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);      // per-frame camera snapshot (every mode)
+        c->fb[s].camera.size = 512;
     }
 
     if (c->overlap) {
@@ -908,8 +919,6 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
             if (hipEventCreateWithFlags(&c->ev_geom_done[s], ev_flags) != hipSuccess || hipEventCreateWithFlags(&c->ev_shade_done[s], ev_flags) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_uploads[s], ev_flags) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             if (s == 0 && hipEventCreateWithFlags(&c->ev_flush, hipEventDisableTiming) != hipSuccess) return bail(AWSM_ERR_DEVICE);
-            if (hipMalloc(&c->fb[s].camera.ptr, 512) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
-            c->fb[s].camera.size = 512;
         }
     }
     if (hipHostMalloc((void**)&c->counters_host, (16 + 2 * kSlots + 1) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // last word: hand-off gates that timed out
@@ -954,8 +963,8 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
     fr(c->lut); for (auto& b : c->cube_tex) fr(b); for (auto& b : c->cube_bordered) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); for (int sl = 0; sl < kSlots; sl++) { fr(c->msaa_color0[sl]); fr(c->msaa_edges[sl]); fr(c->msaa_edge_bits[sl]); fr(c->msaa_cells[sl]); } fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
-    for (int k = 0; k < 3 * kSlots; k++) {
-        FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : c->hud[k - 2 * kSlots]);
+    for (int k = 0; k < 4 * kSlots; k++) {
+        FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : (k < 3 * kSlots ? c->hud[k - 2 * kSlots] : c->htr[k - 3 * kSlots]));
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
         fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
@@ -990,12 +999,14 @@ int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     // +16 bytes of slack so 16-byte vector loads of the last record never leave the allocation (size = the logical size)
     if (bytes && c->bufs[which].ptr && c->bufs[which].size == bytes) {     // unchanged size: same allocation, cleared ("contents are NOT preserved")
+        if (which == AWSM_BUF_CAMERA) memset(c->camera_host, 0, sizeof c->camera_host);
         HIPCHK(c, hipMemsetAsync(c->bufs[which].ptr, 0, bytes + 16, c->stream));
         return AWSM_OK;
     }
     int rc = dev_realloc(c, c->bufs[which], bytes ? bytes + 16 : 0, true);
     if (rc) return rc;
     if (bytes) c->bufs[which].size = bytes;
+    if (which == AWSM_BUF_CAMERA) memset(c->camera_host, 0, sizeof c->camera_host);      // "contents are NOT preserved": the host shadow neither
     if (which == AWSM_BUF_LIGHTS) for (int sl = 0; sl < n_slots(c); sl++) if ((rc = dev_realloc(c, c->lights_pre[sl], std::max<size_t>(bytes / 64, 1) * 32, true))) return rc;   // 2 x float4 per 64-byte light
     c->scene_dirty = true;
     return AWSM_OK;
@@ -1010,7 +1021,7 @@ int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf which, size_t dst_off, const vo
     if (len == 0) return AWSM_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (which != AWSM_BUF_CAMERA) { int rcb = scene_write_barrier(c); if (rcb) return rcb; }   // the opaque pass reads a per-frame camera snapshot
-    else if (dst_off < 512) memcpy(c->camera_host + dst_off, src, std::min<size_t>(len, 512 - dst_off));
+    else { if (dst_off < 512) memcpy(c->camera_host + dst_off, src, std::min<size_t>(len, 512 - dst_off)); c->camera_written_since_snapshot = true; }
     uint8_t* dst = (uint8_t*)b.ptr + dst_off;
     if (len <= (1u << 20)) return upload_small(c, dst, src, len);
     // large (resize-time) uploads: the runtime stages pageable memory itself; wait so `src` is not retained
@@ -1047,7 +1058,7 @@ int awsm_hip_resize(AwsmHipCtx* c, uint32_t width, uint32_t height, uint32_t msa
     c->width = width; c->height = height;
     c->y0 = c->y1 = 0;
     c->band_n = 1; c->band_r = 0; c->band_compact = 0;
-    c->geometry_done = c->opaque_done = c->transparent_done = false;
+    c->geometry_done = c->opaque_done = c->transparent_done = c->hud_transparent_done = false;
     return AWSM_OK;
 }
 
@@ -1301,7 +1312,8 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if ((rc = reserve_pass_buffers(c, FB(c), c->draws_host, c->total_tris, false))) return rc;
     ht.mark("geometry_pass: reserve + draw-list upload");
     if ((rc = enqueue_geometry(c))) return rc;
-    c->geometry_done = true; c->opaque_done = false; c->transparent_done = false; c->hud_geometry_done = false;
+    c->camera_written_since_snapshot = false;
+    c->geometry_done = true; c->opaque_done = false; c->transparent_done = false; c->hud_transparent_done = false; c->hud_geometry_done = false;
     return AWSM_OK;
 }
 
@@ -1309,21 +1321,8 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
 // over the visibility targets (LoadOp::Load) with a depth buffer of their own, cleared — they hide the world whatever its depth, and depth-test among
 // themselves.  Here: the same kernels into the slot's hud key buffer; the world's keys and depth stay as they are (the world transparent pass tests
 // against them), and the opaque pass, the picker and the HUD transparent pass look at the hud keys.
-int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
-    if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
-    if (!c->geometry_done || c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "hud_geometry_pass goes between the geometry pass and the opaque pass of a frame");
-    if (c->msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass with MSAA: the edge detector would have to mix hud normals with world depths as the reference's targets do; single-sampled frames only");
-    if (c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height))) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass on a sharded context");
-    HIPCHK(c, hipSetDevice(c->device));
-    uint64_t tris = 0, blocks = 0;
-    int rc = build_draw_list(c, "hud_geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, c->hud_draws_host, &tris, &blocks);
-    if (rc) return rc;
-    c->hud_total_tris = (uint32_t)tris; c->hud_n_blocks = (uint32_t)blocks;
-    if (!tris) { c->hud_geometry_done = false; return AWSM_OK; }
+static int enqueue_hud_geometry(AwsmHipCtx* c) {
     FrameBufs& hb = c->hud[c->slot];
-    const size_t px = (size_t)c->width * c->height;
-    if ((rc = dev_reserve(c, hb.vis, px * 8))) return rc;
-    if ((rc = reserve_pass_buffers(c, hb, c->hud_draws_host, c->hud_total_tris, false))) return rc;
     FrameDev f;
     fill_frame(c, &f);
     f.n_draws = (uint32_t)c->hud_draws_host.size();
@@ -1345,6 +1344,7 @@ int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n)
     f.camera_snap = nullptr; f.camera_snap_words = 0;
     f.vis = (unsigned long long*)hb.vis.ptr;     // every tile of the frame is written: a tile without hud triangles becomes "no hit"
     f.hud_vis = nullptr;
+    int rc;
     if ((rc = sync_scene(c))) return rc;
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     awsm_launch_transform(c->scene_dev, &f, c->hud_n_blocks, c->stream);
@@ -1355,6 +1355,25 @@ int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n)
         awsm_launch_raster(&f, c->stream);
     }
     HIPCHK(c, hipGetLastError());
+    return AWSM_OK;
+}
+
+int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
+    if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
+    if (!c->geometry_done || c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "hud_geometry_pass goes between the geometry pass and the opaque pass of a frame");
+    if (c->msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass with MSAA: the edge detector would have to mix hud normals with world depths as the reference's targets do; single-sampled frames only");
+    if (c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height))) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass on a sharded context");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t tris = 0, blocks = 0;
+    int rc = build_draw_list(c, "hud_geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, c->hud_draws_host, &tris, &blocks);
+    if (rc) return rc;
+    c->hud_total_tris = (uint32_t)tris; c->hud_n_blocks = (uint32_t)blocks;
+    if (!tris) { c->hud_geometry_done = false; return AWSM_OK; }
+    FrameBufs& hb = c->hud[c->slot];
+    const size_t px = (size_t)c->width * c->height;
+    if ((rc = dev_reserve(c, hb.vis, px * 8))) return rc;
+    if ((rc = reserve_pass_buffers(c, hb, c->hud_draws_host, c->hud_total_tris, false))) return rc;
+    if ((rc = enqueue_hud_geometry(c))) return rc;
     c->hud_geometry_done = true;
     return AWSM_OK;
 }
@@ -1377,9 +1396,18 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
     }
     HIPCHK(c, hipSetDevice(c->device));
     c->last_opaque = *p;
+    if (!p->has_opaque && c->camera_written_since_snapshot && c->bufs[AWSM_BUF_CAMERA].ptr) {
+        // the "empty" pipeline (skybox only) may run without a geometry pass of its own: it then has no snapshot of the camera it was given.  Rare
+        // and cheap to make right: drain, copy, go on.
+        int rcs = sync_all(c);
+        if (rcs) return rcs;
+        compose_pixel_to_view(c, FB(c));
+        HIPCHK(c, hipMemcpy(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size), hipMemcpyDeviceToDevice));
+        c->camera_written_since_snapshot = false;
+    }
     int rc = enqueue_opaque(c);
     if (rc) return rc;
-    c->opaque_done = true; c->transparent_done = false;
+    c->opaque_done = true; c->transparent_done = false; c->hud_transparent_done = false;
     return AWSM_OK;
 }
 
@@ -1402,14 +1430,15 @@ static int transparent_pass_impl(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t 
     }
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t tris = 0, blocks = 0;
-    int rc = build_draw_list(c, "transparent_pass", draws, n, AWSM_BUF_TRANSPARENCY_GEOM_DATA, 0u, c->tr_draws_host, &tris, &blocks);
+    const int which = hud ? 1 : 0;
+    int rc = build_draw_list(c, hud ? "hud_transparent_pass" : "transparent_pass", draws, n, AWSM_BUF_TRANSPARENCY_GEOM_DATA, 0u, c->tr_draws_host[which], &tris, &blocks);
     if (rc) return rc;
-    c->tr_total_tris = (uint32_t)tris; c->tr_n_blocks = (uint32_t)blocks;
+    c->tr_total_tris[which] = (uint32_t)tris; c->tr_n_blocks[which] = (uint32_t)blocks;
     const size_t px = (size_t)c->width * c->height;
     if (!c->bound_comp && (rc = dev_reserve(c, c->comp16, px * 8))) return rc;
     if (c->bound_comp && c->bound_comp_bytes < px * 8) return fail(c, AWSM_ERR_INVALID_ARGUMENT, "transparent_pass: bound composite holds %zu bytes, the frame needs %zu", c->bound_comp_bytes, px * 8);
     if ((c->flags & AWSM_CFG_PARITY_TAP) && (rc = dev_reserve(c, c->comp32, px * 16))) return rc;
-    if ((rc = reserve_pass_buffers(c, TR(c), c->tr_draws_host, c->tr_total_tris, true))) return rc;
+    if ((rc = reserve_pass_buffers(c, TR(c), c->tr_draws_host[which], c->tr_total_tris[which], true))) return rc;
     if ((rc = dev_reserve(c, TR(c).frag_first, px * 4))) return rc;
     if ((rc = ensure_fragment_capacity(c, TR(c), (c->flags & AWSM_CFG_SMALL_BIN_LIST) ? 4096u : (uint32_t)std::max<size_t>(px / 2, 1u << 20)))) return rc;
     if (c->overlap) {   // the draw-list upload went to the caller's stream; the pass runs on the shade stream
@@ -1417,7 +1446,8 @@ static int transparent_pass_impl(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t 
         HIPCHK(c, hipStreamWaitEvent(shade_stream_of(c), c->ev_geom_done[c->slot], 0));
     }
     if ((rc = enqueue_transparent(c))) return rc;
-    c->transparent_done = true;
+    if (hud) c->hud_transparent_done = true; else { c->transparent_done = true; c->hud_transparent_done = false; }
+    c->hud_transparent = false;
     return AWSM_OK;
 }
 int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) { return transparent_pass_impl(c, draws, n, false); }
@@ -1476,6 +1506,7 @@ int awsm_hip_frame_flush(AwsmHipCtx* c) {
 int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->device));
+    bool still_over = false;
     for (int attempt = 0;; attempt++) {
         if (out && c->geometry_done && c->has_opaque_for_stats()) {   // stats only: count covered pixels from the visibility buffer
             FrameDev f;
@@ -1488,26 +1519,48 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
         { int rch = handoff_check(c); if (rch) return rch; }      // a gate ended unopened: the frame it guarded was dropped
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
-        if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, TR(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t hud_fwd[8] = {}, hud_geo[8] = {};      // the HUD transparent pass's and the HUD geometry pass's own counters (same layout)
+        if (c->transparent_done) HIPCHK(c, hipMemcpy(c->counters_host + 8, c->tr[c->slot].counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (c->hud_transparent_done) HIPCHK(c, hipMemcpy(hud_fwd, c->htr[c->slot].counters.ptr, sizeof hud_fwd, hipMemcpyDeviceToHost));
+        if (c->hud_geometry_done) HIPCHK(c, hipMemcpy(hud_geo, c->hud[c->slot].counters.ptr, sizeof hud_geo, hipMemcpyDeviceToHost));
         const bool geom_over = c->geometry_done && c->counters_host[2] != 0, fwd_over = c->transparent_done && c->counters_host[10] != 0;
         const bool frag_over = c->transparent_done && c->counters_host[14] != 0;      // a pixel's fragment list did not fit
-        if ((!geom_over && !fwd_over && !frag_over) || attempt >= 4) break;
-        if (c->hud_transparent && (fwd_over || frag_over))      // the HUD pass blends into the composite in place: it cannot be replayed on top of itself
-            return fail(c, AWSM_ERR_DEVICE, "the HUD transparent pass overflowed its lists (%u list entries, %u fragment slots needed): render the frame again", c->counters_host[9], c->counters_host[13]);
-        // a (triangle, tile) list overflowed: grow to the measured need and replay from the pass that lost entries
+        const bool hud_geo_over = c->hud_geometry_done && hud_geo[2] != 0, hud_fwd_over = c->hud_transparent_done && hud_fwd[2] != 0, hud_frag_over = c->hud_transparent_done && hud_fwd[6] != 0;
+        still_over = geom_over || fwd_over || frag_over || hud_geo_over || hud_fwd_over || hud_frag_over;
+        if (!still_over || attempt >= 4) break;
+        // a list overflowed: grow it to the measured need and replay from the first pass that lost entries.  The passes of a frame are replayed in their
+        // order — the HUD transparent pass blends into the composite in place, so it is never replayed by itself: the world transparent pass (which
+        // starts from the opaque image) always goes first.
         int rc;
         c->overflow_retries++;
         if (geom_over) {
             if ((rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024))) return rc;
             if ((rc = reserve_raster_items(c, FB(c), false))) return rc;
             if ((rc = enqueue_geometry(c))) return rc;
-            if (c->opaque_done && (rc = enqueue_opaque(c))) return rc;
         }
-        if (fwd_over && (rc = ensure_bin_capacity_of(c, TR(c), c->counters_host[9] + c->counters_host[9] / 4 + 1024))) return rc;
-        if (frag_over && (rc = ensure_fragment_capacity(c, TR(c), c->counters_host[13] + c->counters_host[13] / 4 + 1024))) return rc;
-        if (c->transparent_done && (rc = enqueue_transparent(c))) return rc;
+        if (hud_geo_over) {
+            FrameBufs& hb = c->hud[c->slot];
+            if ((rc = ensure_bin_capacity_of(c, hb, hud_geo[1] + hud_geo[1] / 4 + 1024))) return rc;
+            if ((rc = reserve_raster_items(c, hb, false))) return rc;
+            if ((rc = enqueue_hud_geometry(c))) return rc;
+        }
+        if ((geom_over || hud_geo_over) && c->opaque_done && (rc = enqueue_opaque(c))) return rc;
+        if (fwd_over && (rc = ensure_bin_capacity_of(c, c->tr[c->slot], c->counters_host[9] + c->counters_host[9] / 4 + 1024))) return rc;
+        if (frag_over && (rc = ensure_fragment_capacity(c, c->tr[c->slot], c->counters_host[13] + c->counters_host[13] / 4 + 1024))) return rc;
+        if (hud_fwd_over && (rc = ensure_bin_capacity_of(c, c->htr[c->slot], hud_fwd[1] + hud_fwd[1] / 4 + 1024))) return rc;
+        if (hud_frag_over && (rc = ensure_fragment_capacity(c, c->htr[c->slot], hud_fwd[5] + hud_fwd[5] / 4 + 1024))) return rc;
+        if (c->transparent_done) {
+            c->hud_transparent = false;
+            if ((rc = enqueue_transparent(c))) return rc;
+            if (c->hud_transparent_done) {
+                c->hud_transparent = true;
+                rc = enqueue_transparent(c);
+                c->hud_transparent = false;
+                if (rc) return rc;
+            }
+        }
     }
-    if ((c->geometry_done && c->counters_host[2] != 0) || (c->transparent_done && (c->counters_host[10] != 0 || c->counters_host[14] != 0))) return fail(c, AWSM_ERR_DEVICE, "bin / fragment list overflow persisted after retries");
+    if (still_over) return fail(c, AWSM_ERR_DEVICE, "bin / fragment list overflow persisted after retries");
     if (out) {
         // the caller says how much of the struct it knows (struct_size, ABI 2): nothing beyond that is written
         const uint32_t caller_size = out->struct_size;
@@ -1523,7 +1576,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             out->ms_raster = ms(EV_BIN, EV_RASTER);
         }
         if (c->opaque_done) { out->ms_shade = ms(EV_SHADE_BEGIN, EV_SHADE); out->ms_shade_lean = ms(EV_SHADE_BEGIN, EV_SHADE_LEAN); }
-        if (c->transparent_done) { out->ms_forward = ms(EV_FWD_BEGIN, EV_FWD); out->forward_triangles = c->tr_total_tris; out->forward_fragment_slots = c->counters_host[13]; }
+        if (c->transparent_done) { out->ms_forward = ms(EV_FWD_BEGIN, EV_FWD); out->forward_triangles = c->tr_total_tris[0] + (c->hud_transparent_done ? c->tr_total_tris[1] : 0u); out->forward_fragment_slots = c->counters_host[13]; }
         out->ms_total = (c->geometry_done ? ms(EV_START, EV_RASTER) : 0.0f) + out->ms_shade + out->ms_forward;   // the two passes may run on different streams
         out->triangles_in = c->total_tris;
         out->triangles_binned = c->counters_host[0];
@@ -1714,7 +1767,7 @@ int awsm_hip_read_composite_f32(AwsmHipCtx* c, float* out) {
 int awsm_hip_read_transformed_forward(AwsmHipCtx* c, float* clip_out, float* nt_out, float* wpos_out, uint32_t max_vertices) {
     if (!c) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->transparent_done) return fail(c, AWSM_ERR_NOT_READY, "read_transformed_forward before transparent_pass");
-    const uint32_t n = std::min(max_vertices, 3u * c->tr_total_tris);
+    const uint32_t n = std::min(max_vertices, 3u * c->tr_total_tris[0]);
     HIPCHK(c, hipSetDevice(c->device));
     { int rcs = sync_all(c); if (rcs) return rcs; }
     if (n == 0) return AWSM_OK;

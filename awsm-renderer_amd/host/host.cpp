@@ -198,6 +198,7 @@ struct AwsmHost {
     uint64_t upload_bytes = 0;
     std::vector<AwsmDraw> last_draws, last_transparent_draws, last_hud_geometry_draws, last_hud_transparent_draws;
     bool has_hud_meshes = false;
+    uint32_t n_hud_meshes = 0, n_world_transparent_meshes = 0;   // what the two flags are kept from (a removed mesh takes its pass with it: ADVICE r3)
     bool has_transparent_meshes = false;
 };
 
@@ -806,8 +807,8 @@ static AwsmKey mesh_insert_impl(AwsmHost* h, const AwsmHostPrimitive* p, AwsmKey
     rec.transform_key = transform; rec.material_key = material; rec.resource_key = rk; rec.skin_key = skin; rec.morph_key = morph_key;
     rec.double_sided = mat->double_sided != 0; rec.hidden = hidden != 0; rec.tri_count = T; rec.vis_off = vis_off; rec.transparent = transparent; rec.tr_off = tr_off;
     rec.hud = hud;
-    if (transparent && !hud) h->has_transparent_meshes = true;
-    if (hud) h->has_hud_meshes = true;
+    if (transparent && !hud) { h->n_world_transparent_meshes++; h->has_transparent_meshes = true; }
+    if (hud) { h->n_hud_meshes++; h->has_hud_meshes = true; }
     Vec3 mn = {p->positions[0], p->positions[1], p->positions[2]}, mx = mn;   // accessor min/max (populate/mesh.rs try_position_aabb)
     for (uint32_t v = 1; v < V; v++) {
         const Vec3 q = {p->positions[(size_t)v * 3], p->positions[(size_t)v * 3 + 1], p->positions[(size_t)v * 3 + 2]};
@@ -838,6 +839,8 @@ int awsm_host_mesh_remove(AwsmHost* h, AwsmKey mesh) {
     const SlotKey rk = rec->resource_key, tk = rec->transform_key, mk = rec->morph_key;
     h->vis_index.remove(rk); h->vis_data.remove(rk); h->tr_data.remove(rk); h->attr_index.remove(rk); h->attr_data.remove(rk);
     if (rec->transparent || rec->hud) h->tr_data_dirty = true;
+    if (rec->hud) { if (h->n_hud_meshes) h->n_hud_meshes--; h->has_hud_meshes = h->n_hud_meshes != 0; }
+    else if (rec->transparent) { if (h->n_world_transparent_meshes) h->n_world_transparent_meshes--; h->has_transparent_meshes = h->n_world_transparent_meshes != 0; }
     h->resources.remove(rk);
     if (mk) { h->morph_weights.remove(mk); h->morph_values.remove(mk); h->morphs.remove(mk); h->morph_weights_dirty = h->morph_values_dirty = true; }
     auto& v = h->transform_to_meshes[tk];

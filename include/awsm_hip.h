@@ -43,7 +43,7 @@ typedef enum AwsmStatus {
     AWSM_ERR_DEVICE = -3,          /* a HIP runtime call failed (text in last_error) */
     AWSM_ERR_NO_DEVICE = -4,       /* no gfx950 device visible */
     AWSM_ERR_NOT_READY = -5,       /* a required buffer / size / env was never provided */
-    AWSM_ERR_UNSUPPORTED = -6,     /* MSAA, gradient mip sampling, texel cubemaps: SURVEY §8f "next" */
+    AWSM_ERR_UNSUPPORTED = -6,     /* a combination this library does not implement; the message names it (awsm_hip_last_error) */
     AWSM_ERR_OUT_OF_RANGE = -7     /* an offset/size points outside the destination buffer */
 } AwsmStatus;
 
@@ -115,7 +115,8 @@ typedef struct AwsmDraw {
 
 /* MaterialOpaqueRenderPass::render (crates/renderer/src/render_passes/material_opaque/render_pass.rs:47-96). */
 typedef struct AwsmOpaqueParams {
-    uint32_t mipmap;        /* MipmapMode: 0 = None (textureSampleLevel 0). 1 = Gradient -> AWSM_ERR_UNSUPPORTED */
+    uint32_t mipmap;        /* MipmapMode: 0 = None (textureSampleLevel 0), 1 = Gradient (textureSampleGrad from the barycentric derivatives; the
+                               arrays must hold their mip chain: awsm_hip_texture_array_generate_mips) */
     uint32_t has_opaque;    /* 0 -> the "empty" pipeline: skybox only (render_pass.rs:64-71) */
 } AwsmOpaqueParams;
 

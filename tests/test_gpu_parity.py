@@ -1325,4 +1325,19 @@ def test_hud_passes(oracle_lut):
     assert int((ulp > 2).any(axis=-1).sum()) <= 4
     assert (hdev.read_opaque()[covered] == 0).all()
     rr.close()
+    # pipelined frames (AWSM_CFG_OVERLAP_FRAMES): the HUD transparent pass of a frame is enqueued — its draw list uploaded on the caller's stream — while the
+    # world transparent pass of the same frame may not have started on the shade stream.  The two have their own lists and counters (they used to
+    # share them, and the world pass could shade with the HUD pass's draw records); several frames in flight, then the last one against the oracle.
+    from awsm_renderer_amd.hip_backend import HipDevice
+    from awsm_renderer_amd.host import Renderer
+    assert len(model.collect_transparent_draws()) > 0 and model.collect_transparent_draws() != model.hud_transparent_draws
+    ro = Renderer(sc, parity_tap=True, lut_rgba16f=oracle_lib.lut_rg_to_rgba16f(oracle_lut), overlap_frames=True)
+    for _ in range(6):
+        ro.host.render(sync=False)
+    ro.host.render(sync=True)
+    odev = HipDevice.from_ctx(ro.host.device_ctx, sc.width, sc.height)
+    ulp = helpers.f16_ulp_distance(odev.read_composite(), orc.composite16f)
+    assert int((ulp > 2).any(axis=-1).sum()) <= 4, int((ulp > 2).any(axis=-1).sum())
+    assert (odev.read_opaque()[covered] == 0).all()
+    ro.close()
 

@@ -1,5 +1,5 @@
 """Static instruction mix of one kernel of an AMDGPU .s file, weighted by the issue classes tools/valu_probe.hip measured on gfx950
-(profiles/r02_valu_probe.txt): full rate = 1 (v_fma/add/mul/sub_f32, v_mov, v_add_u32, and/or/xor), half rate = 1.8 (conversions,
+(profiles/archive/r02_valu_probe.txt): full rate = 1 (v_fma/add/mul/sub_f32, v_mov, v_add_u32, and/or/xor), half rate = 1.8 (conversions,
 min/max, compares, selects, shifts, 3-operand integer, f64, packed f32, anything with an SGPR source operand — literal and inline
 constants cost nothing), transcendental = 3.5.
 
