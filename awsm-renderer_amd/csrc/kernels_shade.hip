@@ -2332,16 +2332,45 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 #pragma unroll
         for (int j = 1; j <= 8; j++) if (__builtin_amdgcn_ballot_w64(mf_ >= (float)j) != 0ull) wave_m = j;
         if (wave_m) {
+            // The further probes, ONE TEXTURE AT A TIME: per texture the pair of probes at +-j / N is in flight (two trilinear footprints, 26 registers) while
+            // the twelve sums wait — not the footprints of all five textures at once, as the centre probe has them (that loop held 200 registers: two
+            // wavefronts per SIMD).  Every channel still receives its terms in the order centre, +1, -1, +2, -2, ...: the same bits as before.
             const float inv_n = fm::rcp(nf);
             float wsum = 1.0f;
-            for (int j = 1; j <= wave_m; j++) {
-                const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f);
-                for (int sgn = 0; sgn < 2; sgn++) {
-                    const float ts = sgn ? -tj : tj;
-                    fetch_all(u + major.x * ts, v + major.y * ts, m2c, wj > 0.0f);
-                    accumulate(wj);
+            for (int j = 1; j <= wave_m; j++) { const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f); wsum += 2.0f * wj; }
+            auto probes = [&](const auto& tex, const bool has, auto&& acc) {
+                if (__builtin_amdgcn_ballot_w64(has) == 0ull) return;
+#pragma unroll 1
+                for (int j = 1; j <= wave_m; j++) {
+                    const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f);      // falls with j: once no lane has a weight left, none will
+                    const bool act = has && wj > 0.0f;
+                    if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                    if (act) {
+                        lean::TapG ta, tb;
+                        const float tn = -tj;
+                        lean::fetch_trilinear(tex, m2c, u + major.x * tj, v + major.y * tj, ta);
+                        lean::fetch_trilinear(tex, m2c, u + major.x * tn, v + major.y * tn, tb);
+                        acc(ta, wj); acc(tb, wj);
+                    }
                 }
-                wsum += 2.0f * wj;
+            };
+#define AWSM_LEAN_ACC(I, BYTE) ch[I] += lean::channel<BYTE>(t, wl, wh) * wj
+            auto acc0 = [&](const lean::TapG& t, float wj) { const lean::Weights wl = lean::weights(t.lo), wh = lean::weights(t.hi); AWSM_LEAN_ACC(0, 0); AWSM_LEAN_ACC(1, 1); AWSM_LEAN_ACC(2, 2); };
+            auto acc1 = [&](const lean::TapG& t, float wj) { const lean::Weights wl = lean::weights(t.lo), wh = lean::weights(t.hi); AWSM_LEAN_ACC(3, 2); AWSM_LEAN_ACC(4, 1); };
+            auto acc2 = [&](const lean::TapG& t, float wj) { const lean::Weights wl = lean::weights(t.lo), wh = lean::weights(t.hi); AWSM_LEAN_ACC(5, 0); AWSM_LEAN_ACC(6, 1); AWSM_LEAN_ACC(7, 2); };
+            auto acc3 = [&](const lean::TapG& t, float wj) { const lean::Weights wl = lean::weights(t.lo), wh = lean::weights(t.hi); AWSM_LEAN_ACC(8, 0); };
+            auto acc4 = [&](const lean::TapG& t, float wj) { const lean::Weights wl = lean::weights(t.lo), wh = lean::weights(t.hi); AWSM_LEAN_ACC(9, 0); AWSM_LEAN_ACC(10, 1); AWSM_LEAN_ACC(11, 2); };
+#undef AWSM_LEAN_ACC
+            if (one_draw) {
+                const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
+#define AWSM_LEAN_PROBE_TEX(K, ACC) { const u32x4 G = cload<u32x4>(f.draw_lean, lo + 96u + 16u * K); probes(lean::decode_g(G.x, G.y, G.z, G.w), (exists & (1u << K)) != 0u, ACC); }
+                AWSM_LEAN_PROBE_TEX(0, acc0) AWSM_LEAN_PROBE_TEX(1, acc1) AWSM_LEAN_PROBE_TEX(2, acc2) AWSM_LEAN_PROBE_TEX(3, acc3) AWSM_LEAN_PROBE_TEX(4, acc4)
+#undef AWSM_LEAN_PROBE_TEX
+            } else {
+                const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
+#define AWSM_LEAN_PROBE_TEX(K, ACC) { const u32x4 G = gload<u32x4>(f.draw_lean, lo + 96u + 16u * K); probes(lean::decode_gl(G.x, G.y, G.z, G.w), (exists & (1u << K)) != 0u, ACC); }
+                AWSM_LEAN_PROBE_TEX(0, acc0) AWSM_LEAN_PROBE_TEX(1, acc1) AWSM_LEAN_PROBE_TEX(2, acc2) AWSM_LEAN_PROBE_TEX(3, acc3) AWSM_LEAN_PROBE_TEX(4, acc4)
+#undef AWSM_LEAN_PROBE_TEX
             }
             const float iw = fm::rcp(wsum);
 #pragma unroll
@@ -2497,10 +2526,10 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 // has kLeanCounters of them on separate cache lines, counter c handing out the strips c, c + kLeanCounters, ...; a wavefront
 // starts on counter w % kLeanCounters and moves on when it runs dry.  The request for the next strip is issued before the current
 // one is shaded.  No barrier, no LDS.
-// k_shade_lean<.., 2, ..> (anisotropic probes): 200 registers as compiled.  Two wavefronts per SIMD without a spill beat three with 51-72 spilled
-// registers (975 against 823 frames/s at 4K, 707 against 558 with MSAA).
+// k_shade_lean<.., 2, ..> (anisotropic probes): 117 registers since the probes beyond the centre go one texture at a time (round 4; 200 before, two
+// wavefronts per SIMD): four wavefronts per SIMD like the isotropic gradient kernel.
 #ifndef AWSM_ANISO_WAVES
-#define AWSM_ANISO_WAVES 2
+#define AWSM_ANISO_WAVES 4
 #endif
 #ifndef AWSM_LEAN_COUNTERS
 #define AWSM_LEAN_COUNTERS 8
@@ -2804,9 +2833,12 @@ template <int GRAD>
 __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __restrict__ sc, FrameDev f) {
     // One WAVEFRONT per block: the shading is a long dependent chain for a few dozen lanes, and what bounds the kernel is how many blocks are in flight —
     // a 256-thread workgroup parked three idle wavefronts' registers behind every busy one (177 us at 4K; 18 M VALU instructions: 83 % of the wave-cycles waiting).
-    __shared__ uint32_t items[768];          // pixel slot | sample << 8
-    __shared__ float4 icolor[768];
-    __shared__ uint16_t first_of[256];       // first item of the block's e-th edge pixel
+    // The block's edge pixels are taken kRound at a time (most blocks have fewer): the item arrays then cost 8 KB instead of 16 and the kernel's occupancy is
+    // what its registers allow (four wavefronts per SIMD) instead of what the LDS allowed (ten per CU).
+    constexpr uint32_t kRound = 128u;
+    __shared__ uint32_t items[3 * kRound];   // pixel slot | sample << 8
+    __shared__ float4 icolor[3 * kRound];
+    __shared__ uint16_t first_of[kRound];    // first item of the round's e-th edge pixel
     __shared__ uint32_t n_items;
     ShadeBlock b;
     if (frame_poisoned(f) || !shade_block(f, b)) return;
@@ -2814,10 +2846,14 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
     const uint32_t n = *reinterpret_cast<const uint32_t*>(edge_rec);
     const uint32_t lane = threadIdx.x;
     if (n == 0u) return;                                                   // wave-uniform
+#pragma unroll 1
+    for (uint32_t e0 = 0; e0 < n; e0 += kRound) {
+    const uint32_t e1 = min(n, e0 + kRound);
+    __syncthreads();
     if (lane == 0u) n_items = 0u;
     __syncthreads();
     // ---- phase 1: every edge pixel -> its items ----
-    for (uint32_t e = lane; e < n; e += 64u) {
+    for (uint32_t e = e0 + lane; e < e1; e += 64u) {
         const uint32_t slot = edge_rec[4u + e];
         const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
         const size_t p = (size_t)cy * f.width + (size_t)cx;
@@ -2837,7 +2873,7 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
             }
         }
         const uint32_t first = atomicAdd(&n_items, cnt);
-        first_of[e] = (uint16_t)first;
+        first_of[e - e0] = (uint16_t)first;
         for (uint32_t j = 0; j < cnt; j++) items[first + j] = slot | (((which >> (2u * j)) & 3u) << 8);
     }
     __syncthreads();
@@ -2854,7 +2890,7 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
     }
     __syncthreads();
     // ---- phase 3: the four colours of every edge pixel, averaged ----
-    for (uint32_t e = lane; e < n; e += 64u) {
+    for (uint32_t e = e0 + lane; e < e1; e += 64u) {
         const uint32_t slot = edge_rec[4u + e];
         const int cx = b.x0 + (int)(slot & 15u), cy = b.y0 + (int)(slot >> 4);
         const size_t p = (size_t)cy * f.width + (size_t)cx;
@@ -2865,25 +2901,29 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
         const ulonglong2 ka = kp[0], kb = kp[1];
         const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
         const f4 sky = skybox_color(sc, f, cx, cy);
-        f4 col[4];
-        col[0] = {c0v.x, c0v.y, c0v.z, c0v.w};
-        uint32_t j = first_of[e];
-#pragma unroll
-        for (int sidx = 1; sidx < 4; sidx++) {
-            f4 c = sky;
-            if (k4[sidx] != ~0ull) {
-                const uint32_t r = key_rank(k4[sidx]);
-                int same = -1;
-#pragma unroll
-                for (int t = 0; t < sidx; t++) if (k4[t] != ~0ull && key_rank(k4[t]) == r) same = t;
-                if (same >= 0) c = (same == 0) ? col[0] : ((same == 1) ? col[1] : col[2]);
-                else { const float4 q = icolor[j]; j++; c = {q.x, q.y, q.z, q.w}; }
-            }
-            col[sidx] = c;
-        }
-        const f4 sum = {((col[0].x + col[1].x) + col[2].x) + col[3].x, ((col[0].y + col[1].y) + col[2].y) + col[3].y,
-                        ((col[0].z + col[1].z) + col[2].z) + col[3].z, ((col[0].w + col[1].w) + col[2].w) + col[3].w};
+        // (no array of colours here: picking "the colour of the earlier sample with the same triangle" out of one by a run-time index sent the
+        // array — and the kernel — to scratch memory, 80-96 bytes per lane; three named values and selects stay in registers)
+        const f4 col0 = {c0v.x, c0v.y, c0v.z, c0v.w};
+        uint32_t j = first_of[e - e0];
+        auto sample_colour = [&](int sidx, const f4& a1, const f4& a2) -> f4 {
+            if (k4[sidx] == ~0ull) return sky;
+            const uint32_t r = key_rank(k4[sidx]);
+            const bool s0 = k4[0] != ~0ull && key_rank(k4[0]) == r;
+            const bool s1 = sidx > 1 && k4[1] != ~0ull && key_rank(k4[1]) == r;
+            const bool s2 = sidx > 2 && k4[2] != ~0ull && key_rank(k4[2]) == r;
+            if (!(s0 || s1 || s2)) { const float4 q = icolor[j]; j++; return {q.x, q.y, q.z, q.w}; }
+            f4 c = col0;                     // the LAST earlier sample with this triangle (they all hold the same colour: one shading per distinct triangle)
+            if (s1) c = a1;
+            if (s2) c = a2;
+            return c;
+        };
+        const f4 col1 = sample_colour(1, col0, col0);
+        const f4 col2 = sample_colour(2, col1, col0);
+        const f4 col3 = sample_colour(3, col1, col2);
+        const f4 sum = {((col0.x + col1.x) + col2.x) + col3.x, ((col0.y + col1.y) + col2.y) + col3.y,
+                        ((col0.z + col1.z) + col2.z) + col3.z, ((col0.w + col1.w) + col2.w) + col3.w};
         store_pixel(f, po, {sum.x * 0.25f, sum.y * 0.25f, sum.z * 0.25f, sum.w * 0.25f});
+    }
     }
 }
 #pragma clang fp contract(off)
