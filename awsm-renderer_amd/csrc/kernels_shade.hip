@@ -2066,17 +2066,23 @@ template <int BYTE> AWSM_DI float channel(const TapG& t, const Weights& wl, cons
 //     a pixel carry the same centre-evaluated G-buffer texel and sample 0's coordinates), i.e. give the colour back to within one f32 rounding of 3c;
 //   * per pixel the STRICT normal and the depth of sample 0 (FrameDev.msaa_cells) for k_msaa_detect's neighbour comparison;
 //   * the colour in the image, and for a pixel in either mask also as f32 in msaa_color0, where k_shade_msaa_resolve picks it up if the pixel is resolved.
-template <int GRAD, bool MSAA>
-AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
+// ITEMS (k_shade_msaa_resolve): the lanes are not the pixels of a strip but (pixel, sample) items of a block's edge pixels — the triangle of sample s at
+// the pixel's centre, with the pixel's shared standard coordinates (sample 0's depth; material_shading.wgsl:186-189) — handed in through LeanItem; the
+// colour goes back the same way and nothing is stored.  Returns false when the wavefront has a lane this route cannot shade (wave-uniform): the caller then
+// takes the general code for these lanes, as k_shade_todo does for a strip.
+struct LeanItem { int cx, cy; uint32_t rank; float depth; bool live; f3 color; };
+template <int GRAD, bool MSAA, bool ITEMS>
+AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st, LeanItem* __restrict__ item) {
     const uint32_t lane = tid & 63u;
-    const int cx = b.x0 + (int)(tid & 15u), cy = b.y0 + (int)(tid >> 4);
-    const bool inside = cx < (int)f.width && cy < (int)f.sy1;            // compute.wgsl:111-113 (no early exit: lanes 0..12 stage records for the whole wavefront)
+    const int cx = ITEMS ? item->cx : b.x0 + (int)(tid & 15u), cy = ITEMS ? item->cy : b.y0 + (int)(tid >> 4);
+    const bool inside = ITEMS ? item->live : (cx < (int)f.width && cy < (int)f.sy1);            // compute.wgsl:111-113 (no early exit: lanes 0..12 stage records for the whole wavefront)
     const uint32_t pv = (uint32_t)cy * f.width + (uint32_t)cx;
     const uint32_t p = f.out_compact ? (((b.brow >> 1) << kTileShift) + ((uint32_t)cy & (uint32_t)(kTile - 1))) * f.width + (uint32_t)cx : pv;
 
     u32x2 key = {0xFFFFFFFFu, 0xFFFFFFFFu};
     bool want_c0 = false;                                                 // MSAA: the pixel may be resolved — its colour also goes to msaa_color0
-    if (!MSAA) { if (inside) key = gload<u32x2>(f.vis, pv << 3); }
+    if (ITEMS) { if (inside) key = {~item->rank, __float_as_uint(item->depth)}; }
+    else if (!MSAA) { if (inside) key = gload<u32x2>(f.vis, pv << 3); }
     else {
         u32x4 ka = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, kb = ka;     // [pixel][4 samples]: {lo, hi} of samples 0, 1 and 2, 3
         if (inside) { ka = gload<u32x4>(f.vis, pv << 5); kb = gload<u32x4>(f.vis, (pv << 5) + 16u); }
@@ -2097,10 +2103,10 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         want_c0 = sure || test;
     }
     bool hud = false;                                                     // a hud mesh covers the pixel: it stays cleared (compute.wgsl:176-179)
-    if (!MSAA && f.hud_vis && inside) { const u32x2 hk = gload<u32x2>(f.hud_vis, pv << 3); hud = (hk.x & hk.y) != 0xFFFFFFFFu; }
+    if (!ITEMS && !MSAA && f.hud_vis && inside) { const u32x2 hk = gload<u32x2>(f.hud_vis, pv << 3); hud = (hk.x & hk.y) != 0xFFFFFFFFu; }
     if (hud) { store_pixel(f, p, f4{0.0f, 0.0f, 0.0f, 0.0f}); key = {0xFFFFFFFFu, 0xFFFFFFFFu}; }
     const bool hit = inside && (key.x & key.y) != 0xFFFFFFFFu;
-    if (inside && !hit && !hud) {                                         // compute.wgsl:149-153: no hit -> skybox (skybox.wgsl:1-41: the uniform colour or the texel cube)
+    if (!ITEMS && inside && !hit && !hud) {                                         // compute.wgsl:149-153: no hit -> skybox (skybox.wgsl:1-41: the uniform colour or the texel cube)
         const f4 sky = skybox_color(sc, f, cx, cy);
         store_pixel(f, p, sky);
         if (MSAA) {
@@ -2109,7 +2115,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         }
     }
     unsigned long long rem = __builtin_amdgcn_ballot_w64(hit);
-    if (rem == 0ull) return;                                              // wave-uniform
+    if (rem == 0ull) return true;                                         // wave-uniform
     const uint32_t rank = hit ? ~key.x : 0xFFFFFFFFu;                     // 0xFFFFFFFF - low word; no triangle has the sentinel's rank
     const float depth = __uint_as_float(key.y);
 
@@ -2303,13 +2309,13 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
     const float m2c = GRAD == 2 ? m2 * fm::rcp(nf * nf) : m2;
     fetch_all(u, v, m2c, true);
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
-        if (lane == 0u) {
+        if (!ITEMS && lane == 0u) {
             const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
             if (slot < f.shade_todo_cap) f.shade_todo[4u + slot] = (wg << 2) | (tid >> 6);
         }
-        return;
+        return false;
     }
-    if (!hit) return;
+    if (!hit) return true;
 
     // ---- AWSM_CFG_ANISOTROPIC: the twelve raw channel values (0..255) the material reads, averaged over grad_footprint's probes — the centre (weight 1),
     // then pairs at +-j / N along the major axis, each weighted by the part of the footprint its cell covers (zero beyond the lane's own
@@ -2339,7 +2345,7 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
             float wsum = 1.0f;
             for (int j = 1; j <= wave_m; j++) { const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f); wsum += 2.0f * wj; }
             auto probes = [&](const auto& tex, const bool has, auto&& acc) {
-                if (__builtin_amdgcn_ballot_w64(has) == 0ull) return;
+                if (__builtin_amdgcn_ballot_w64(has) == 0ull) return;      // (out of the lambda)
 #pragma unroll 1
                 for (int j = 1; j <= wave_m; j++) {
                     const float tj = (float)j * inv_n, wj = saturate((0.5f - tj) * nf + 0.5f);      // falls with j: once no lane has a weight left, none will
@@ -2513,8 +2519,14 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
         lean::direct(lit, light_dir, radiance, color);
     }
     asm volatile("; MARK store");
+    if (ITEMS) { item->color = color; return true; }
     store_pixel(f, p, {color.x, color.y, color.z, 1.0f});
     if (MSAA && want_c0) f.msaa_color0[pv] = make_float4(color.x, color.y, color.z, 1.0f);
+    return true;
+}
+template <int GRAD, bool MSAA>
+AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, const ShadeBlock& b, const uint32_t wg, const uint32_t tid, LeanStage* __restrict__ st) {
+    (void)lean_core<GRAD, MSAA, false>(sc, f, b, wg, tid, st, nullptr);
 }
 // k_shade_lean<false>: a wavefront per 16x4-pixel strip.  k_shade_lean<true>: a persistent grid (lean_grid workgroups; workgroup w
 // runs on XCD w & 7, as the hardware deals them) whose wavefronts take strips from counters until the XCD's share is used up —
@@ -2840,6 +2852,7 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
     __shared__ float4 icolor[3 * kRound];
     __shared__ uint16_t first_of[kRound];    // first item of the round's e-th edge pixel
     __shared__ uint32_t n_items;
+    __shared__ LeanStage stage;              // the lean route's staged triangle records (one wavefront per workgroup here)
     ShadeBlock b;
     if (frame_poisoned(f) || !shade_block(f, b)) return;
     const uint8_t* edge_rec = reinterpret_cast<const uint8_t*>(f.msaa_edges) + (size_t)b.blk * kEdgeRecBytes;
@@ -2877,16 +2890,27 @@ __global__ __launch_bounds__(64) void k_shade_msaa_resolve(const DevScene* __res
         for (uint32_t j = 0; j < cnt; j++) items[first + j] = slot | (((which >> (2u * j)) & 3u) << 8);
     }
     __syncthreads();
-    // ---- phase 2: one item per lane and turn ----
+    // ---- phase 2: one item per lane and turn.  The lean route's body shades the turn when every item of it belongs to a lean draw (the record staging, the
+    // scalar draw record and the per-texture probes of k_shade_lean, on lanes that are items instead of the pixels of a strip); a turn with any other item
+    // takes the general code, as a strip of k_shade_lean goes to k_shade_todo. ----
     const uint32_t ni = n_items;
-    for (uint32_t i = lane; i < ni; i += 64u) {
-        const uint32_t it = items[i], isl = it & 255u, sidx = it >> 8;
+    const bool lean_route = f.draw_lean != nullptr && f.tri_shade != nullptr;      // (the frame's opaque pass took the lean route)
+    for (uint32_t i0 = 0; i0 < ni; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const bool live = i < ni;
+        const uint32_t it = live ? items[i] : 0u, isl = it & 255u, sidx = it >> 8;
         const int ix = b.x0 + (int)(isl & 15u), iy = b.y0 + (int)(isl >> 4);
         const unsigned long long* kq = f.vis + ((size_t)iy * f.width + (size_t)ix) * 4;
-        const unsigned long long ks = kq[sidx], k0 = kq[0];
+        const unsigned long long ks = live ? kq[sidx] : ~0ull, k0 = live ? kq[0] : ~0ull;
         const uint32_t r = key_rank(ks);
-        const f4 c = shade_surface<GRAD>(sc, f, r, ix, iy, key_depth(k0), reconstruct_gbuffer<(GRAD != 0)>(f, r, ix, iy), false).color;
-        icolor[i] = make_float4(c.x, c.y, c.z, c.w);
+        LeanItem item = {ix, iy, r, key_depth(k0), live, {0.0f, 0.0f, 0.0f}};
+        bool done = false;
+        if (lean_route) done = lean_core<GRAD, false, true>(sc, f, b, 0u, lane, &stage, &item);      // (wave-uniform result)
+        if (done) { if (live) icolor[i] = make_float4(item.color.x, item.color.y, item.color.z, 1.0f); }
+        else if (live) {
+            const f4 c = shade_surface<GRAD>(sc, f, r, ix, iy, key_depth(k0), reconstruct_gbuffer<(GRAD != 0)>(f, r, ix, iy), false).color;
+            icolor[i] = make_float4(c.x, c.y, c.z, c.w);
+        }
     }
     __syncthreads();
     // ---- phase 3: the four colours of every edge pixel, averaged ----
