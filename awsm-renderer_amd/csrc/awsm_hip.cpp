@@ -24,6 +24,7 @@ void awsm_launch_gen_mip_level(uint8_t* chain, uint32_t src_off, uint32_t dst_of
                                const uint32_t* kinds, hipStream_t s);
 void awsm_launch_pick(const DevScene* sc, const FrameDev* f, int x, int y, uint32_t* out, hipStream_t s);
 void awsm_launch_transform(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
+void awsm_launch_hud_merge(const unsigned long long* world, const unsigned long long* hud, unsigned long long* out, size_t first, size_t n, hipStream_t s);
 void awsm_launch_transform_forward(const DevScene* sc, const FrameDev* f, uint32_t n_blocks, hipStream_t s);
 void awsm_launch_forward(const DevScene* sc, const FrameDev* f, hipStream_t s);
 void awsm_launch_upload_words(void* dst, const void* src_pinned, uint32_t n_words, hipStream_t s);
@@ -159,6 +160,12 @@ struct AwsmHipCtx {
     std::vector<DrawDev> hud_draws_host;
     uint32_t hud_total_tris = 0, hud_n_blocks = 0;
     bool hud_geometry_done = false;   // this frame has hud geometry: the opaque pass leaves its pixels cleared
+    // MSAA frames: the hud draws follow the world's in ONE rank space (transformed into the world pass's vertex / setup arrays behind the world's, binned and
+    // rasterised by themselves into hud[slot].vis), and the opaque pass reads the merged keys (k_hud_merge: hud rank under world depth) — what the
+    // reference's targets hold after its HUD geometry pass.  hud_merged: this frame's hud pass went that way.
+    bool hud_merged = false;
+    DevBuf merged_vis[kSlots];
+    std::vector<DrawDev> hud_combined;   // world draws, then the hud draws with first_tri / first_block continued
     bool hud_transparent = false;     // the transparent pass being enqueued is the HUD one (depth cleared, colours loaded from the composite)
     // [0] the world transparent pass, [1] the HUD transparent pass: each with its own per-slot device state (tr / htr) — the HUD pass of a frame is enqueued
     // while the world pass of the same frame may not have started on the shade stream, so they share neither a draw list nor counters
@@ -459,6 +466,12 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->msaa_cells = (uint2*)c->msaa_cells[c->slot].ptr;
     f->hud_vis = c->hud_geometry_done ? (const unsigned long long*)c->hud[c->slot].vis.ptr : nullptr;
     f->hud_draws = (const DrawDev*)c->hud[c->slot].draws_dev.ptr; f->hud_tri_info = (const uint32_t*)c->hud[c->slot].tri_flags.ptr;
+    if (c->hud_geometry_done && c->hud_merged) {      // one rank space: the hud draws behind the world's; the opaque pass sees the merged keys
+        f->n_draws = (uint32_t)c->hud_combined.size();
+        f->total_tris = c->total_tris + c->hud_total_tris; f->total_verts = 3u * f->total_tris;
+        f->vis = (unsigned long long*)c->merged_vis[c->slot].ptr;
+        f->hud_draws = f->draws; f->hud_tri_info = f->tri_info;      // (the picker: hud keys name global ranks)
+    }
     f->hud_pass = 0;
     f->msaa_halo = (const unsigned long long*)c->msaa_halo;
     f->halo_bands = c->band_n > 1 ? ((c->height + kTile - 1) / kTile + c->band_n - 1) / c->band_n : 0u;
@@ -513,7 +526,7 @@ bool resolve_stale(AwsmHipCtx* c, const FrameDev& f) {
 int enqueue_geometry(AwsmHipCtx* c) {
     HostTrace ht(c->frame_serial);
     FrameDev f;
-    fill_frame(c, &f);
+    { const bool hd = c->hud_geometry_done; c->hud_geometry_done = false; fill_frame(c, &f); c->hud_geometry_done = hd; }      // the world pass's own view (no merged hud keys, no hud ranks)
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     int rc = sync_scene(c);
     if (rc) return rc;
@@ -654,6 +667,7 @@ void fill_frame_forward(AwsmHipCtx* c, FrameDev* f) {
     fill_frame(c, f);
     FrameBufs& t = TR(c);
     const int which = c->hud_transparent ? 1 : 0;
+    f->vis = (unsigned long long*)FB(c).vis.ptr;      // the WORLD's depth (render.rs:224-297), whatever the opaque pass read
     f->n_draws = (uint32_t)c->tr_draws_host[which].size();
     f->total_tris = c->tr_total_tris[which]; f->total_verts = 3u * c->tr_total_tris[which];
     f->bin_capacity = t.bin_capacity;
@@ -962,6 +976,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     auto fr = [](DevBuf& b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.size = 0; };
     for (auto& b : c->bufs) fr(b);
     for (auto& b : c->tex) fr(b);
+    for (auto& b : c->merged_vis) fr(b);
     fr(c->lut); for (auto& b : c->cube_tex) fr(b); for (auto& b : c->cube_bordered) fr(b); fr(c->digest); for (auto& b : c->shade_todo) fr(b); for (int sl = 0; sl < kSlots; sl++) { fr(c->msaa_color0[sl]); fr(c->msaa_edges[sl]); fr(c->msaa_edge_bits[sl]); fr(c->msaa_cells[sl]); } fr(c->mip_kinds); for (auto& b : c->out16) fr(b); for (auto& b : c->out32) fr(b); fr(c->comp16); fr(c->comp32); for (auto& b : c->lights_pre) fr(b);
     for (int k = 0; k < 4 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : (k < 3 * kSlots ? c->hud[k - 2 * kSlots] : c->htr[k - 3 * kSlots]));
@@ -1274,6 +1289,7 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if (rc) return rc;
     ht.mark("geometry_pass: draw list");
     if ((rc = handoff_check(c))) return rc;      // an earlier frame was dropped by a timed-out gate: said once, here or in frame_flush / frame_end
+    c->hud_geometry_done = false; c->hud_merged = false;      // (a new frame: no hud pass yet)
     c->frame_serial++;
     if (c->overlap) {
         c->slot = (c->slot + 1) % kSlots;    // the opaque passes of the previous frames may still be reading the other slots
@@ -1324,15 +1340,24 @@ int awsm_hip_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
 static int enqueue_hud_geometry(AwsmHipCtx* c) {
     FrameBufs& hb = c->hud[c->slot];
     FrameDev f;
-    fill_frame(c, &f);
+    { const bool hd = c->hud_geometry_done; c->hud_geometry_done = false; fill_frame(c, &f); c->hud_geometry_done = hd; }
+    f.bin_capacity = hb.bin_capacity;
+    f.shade_todo = nullptr; f.shade_todo_cap = 0; f.lean_next = nullptr; f.lean_grid = 0;      // (k_deform_transform's per-frame resets of the opaque pass's lists: the world pass's)
+    if (c->hud_merged) {
+        // MSAA: the hud draws in the world pass's rank space — vertices, setup records and per-triangle words go behind the world's in the SAME arrays
+        // (f keeps the world's pointers), only the tile tables, the lists and the keys are this pass's own
+        f.n_draws = (uint32_t)c->hud_combined.size();
+        f.total_tris = c->total_tris + c->hud_total_tris; f.total_verts = 3u * f.total_tris;
+        f.rank0 = c->total_tris; f.block0 = c->n_blocks;
+    } else {
     f.n_draws = (uint32_t)c->hud_draws_host.size();
     f.total_tris = c->hud_total_tris; f.total_verts = 3u * c->hud_total_tris;
-    f.bin_capacity = hb.bin_capacity;
     f.draws = (const DrawDev*)hb.draws_dev.ptr;
     f.clip = (float4*)hb.clip.ptr; f.nrm = (float4*)hb.nrm.ptr; f.tan = (float4*)hb.tan.ptr;
     f.tri_info = (uint32_t*)hb.tri_flags.ptr;
-    f.tri_shade = nullptr; f.draw_lean = nullptr; f.shade_todo = nullptr; f.shade_todo_cap = 0; f.lean_next = nullptr; f.lean_grid = 0;
+    f.tri_shade = nullptr; f.draw_lean = nullptr;
     f.tri_rec = (TriRec*)hb.tri_rec.ptr;
+    }
     f.tile_count = (uint32_t*)hb.tile_count.ptr; f.tile_offset = (uint32_t*)hb.tile_offset.ptr;
     f.tile_cursor = (uint32_t*)hb.tile_cursor.ptr; f.bin_list = (uint32_t*)hb.bin_list.ptr;
     f.tile_order = (uint32_t*)hb.tile_order.ptr; f.scan_tmp = (uint32_t*)hb.scan_tmp.ptr;
@@ -1354,6 +1379,10 @@ static int enqueue_hud_geometry(AwsmHipCtx* c) {
         awsm_launch_bin_fill(&f, c->stream); awsm_launch_bin_big(&f, 1, c->stream);
         awsm_launch_raster(&f, c->stream);
     }
+    if (c->hud_merged) {      // what the opaque pass reads: per sample the hud triangle (where one was drawn) under the world's depth
+        const size_t spp = c->msaa == 4 ? 4 : 1, first = (size_t)f.y0 * c->width * spp, n = (size_t)(f.y1 - f.y0) * c->width * spp;
+        awsm_launch_hud_merge((const unsigned long long*)FB(c).vis.ptr, (const unsigned long long*)hb.vis.ptr, (unsigned long long*)c->merged_vis[c->slot].ptr, first, n, c->stream);
+    }
     HIPCHK(c, hipGetLastError());
     return AWSM_OK;
 }
@@ -1361,18 +1390,33 @@ static int enqueue_hud_geometry(AwsmHipCtx* c) {
 int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) {
     if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->geometry_done || c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "hud_geometry_pass goes between the geometry pass and the opaque pass of a frame");
-    if (c->msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass with MSAA: the edge detector would have to mix hud normals with world depths as the reference's targets do; single-sampled frames only");
-    if (c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height))) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass on a sharded context");
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t tris = 0, blocks = 0;
     int rc = build_draw_list(c, "hud_geometry_pass", draws, n, AWSM_BUF_VIS_GEOM_DATA, 168u, c->hud_draws_host, &tris, &blocks);
     if (rc) return rc;
     c->hud_total_tris = (uint32_t)tris; c->hud_n_blocks = (uint32_t)blocks;
+    c->hud_merged = false;
     if (!tris) { c->hud_geometry_done = false; return AWSM_OK; }
     FrameBufs& hb = c->hud[c->slot];
-    const size_t px = (size_t)c->width * c->height;
-    if ((rc = dev_reserve(c, hb.vis, px * 8))) return rc;
-    if ((rc = reserve_pass_buffers(c, hb, c->hud_draws_host, c->hud_total_tris, false))) return rc;
+    const size_t px = (size_t)c->width * c->height, spp = c->msaa == 4 ? 4 : 1;
+    if ((rc = dev_reserve(c, hb.vis, px * 8 * spp))) return rc;
+    if ((rc = reserve_pass_buffers(c, hb, c->hud_draws_host, c->hud_total_tris, false))) return rc;      // tile tables, lists (and, single-sampled, the pass's own vertex arrays)
+    if (c->msaa == 4) {
+        // one rank space with the world pass (see AwsmHipCtx::hud_merged)
+        if ((uint64_t)c->total_tris + tris > 0x55555555ull) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass: more than 2^32/3 triangles in the frame");
+        c->hud_combined = c->draws_host;
+        for (DrawDev d : c->hud_draws_host) { d.first_tri += c->total_tris; d.first_block += c->n_blocks; c->hud_combined.push_back(d); }
+        if (c->hud_combined.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass: more than 2^24 draws in the frame");
+        FrameBufs& wb = FB(c);
+        const void* before[3] = {wb.clip.ptr, wb.tri_rec.ptr, wb.tri_flags.ptr};
+        if ((rc = reserve_pass_buffers(c, wb, c->hud_combined, c->total_tris + c->hud_total_tris, false))) return rc;      // room for the hud draws behind the world's; uploads the combined list
+        if ((rc = dev_reserve(c, c->merged_vis[c->slot], px * 8 * spp))) return rc;
+        if (before[0] != wb.clip.ptr || before[1] != wb.tri_rec.ptr || before[2] != wb.tri_flags.ptr) {
+            // the world pass's arrays moved (first frame with this much hud geometry): its results went with them — run it again into the new ones
+            if ((rc = enqueue_geometry(c))) return rc;
+        }
+        c->hud_merged = true;
+    }
     if ((rc = enqueue_hud_geometry(c))) return rc;
     c->hud_geometry_done = true;
     return AWSM_OK;
@@ -1415,7 +1459,6 @@ static int transparent_pass_impl(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t 
     if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->geometry_done || !c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass needs the geometry and opaque passes of the same frame first");
     if (hud && !c->transparent_done) return fail(c, AWSM_ERR_NOT_READY, "hud_transparent_pass draws over the composite: call transparent_pass first (n_draws = 0 is valid)");
-    if (hud && c->msaa != 0) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_transparent_pass with MSAA (the HUD passes are single-sampled here)");
     c->hud_transparent = hud;
     const bool sharded = c->band_n > 1 || (c->y1 != 0 && !(c->y0 == 0 && c->y1 >= c->height));
     if (sharded && !c->opaque_src)
@@ -1538,10 +1581,10 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             if ((rc = reserve_raster_items(c, FB(c), false))) return rc;
             if ((rc = enqueue_geometry(c))) return rc;
         }
-        if (hud_geo_over) {
+        if (hud_geo_over || (geom_over && c->hud_geometry_done && c->hud_merged)) {      // (merged keys: a new world pass needs a new merge)
             FrameBufs& hb = c->hud[c->slot];
-            if ((rc = ensure_bin_capacity_of(c, hb, hud_geo[1] + hud_geo[1] / 4 + 1024))) return rc;
-            if ((rc = reserve_raster_items(c, hb, false))) return rc;
+            if (hud_geo_over && (rc = ensure_bin_capacity_of(c, hb, hud_geo[1] + hud_geo[1] / 4 + 1024))) return rc;
+            if (hud_geo_over && (rc = reserve_raster_items(c, hb, false))) return rc;
             if ((rc = enqueue_hud_geometry(c))) return rc;
         }
         if ((geom_over || hud_geo_over) && c->opaque_done && (rc = enqueue_opaque(c))) return rc;

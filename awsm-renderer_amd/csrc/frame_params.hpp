@@ -147,8 +147,10 @@ struct FrameDev {
     uint32_t band_n, band_r;      // the shard owns the tile rows ty >= tile_row0 with ty % band_n == band_r (1, 0 = every row)
     uint32_t out_compact;         // band mode: output row = local band * 32 + (y & 31) instead of y
     uint32_t n_draws;
-    uint32_t total_tris;
+    uint32_t total_tris;          // ranks [0, total_tris) exist in the per-triangle arrays
     uint32_t total_verts;
+    uint32_t rank0, block0;       // the binning kernels take the ranks [rank0, total_tris), k_deform_transform the blocks from block0 on: 0 except for the HUD geometry
+                                  // pass of an MSAA frame, whose draws follow the world's in ONE rank space (awsm_hip.cpp: hud_geometry_merged)
     uint32_t bin_capacity;        // entries in the (triangle,tile) list
     uint32_t has_opaque;
     uint32_t mipmap;              // 0: MipmapMode::None (level 0 only), 1: MipmapMode::Gradient

@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6
     __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[FWD ? 4 : 256 * 14];
     if (frame_poisoned(f)) return;
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x + f.block0;
     {   // per-frame clears folded into the first kernel of the frame (saves three memset launches per frame)
-        const uint32_t n_tiles = f.tiles_x * f.tiles_y, gsz = gridDim.x * 256u, g0 = b * 256u + tid;
+        const uint32_t n_tiles = f.tiles_x * f.tiles_y, gsz = gridDim.x * 256u, g0 = blockIdx.x * 256u + tid;
         for (uint32_t i = g0; i < n_tiles; i += gsz) f.tile_count[i] = 0u;
         if (g0 < 8u) f.counters[g0] = 0u;
         if (g0 == 12u || g0 == 13u) f.counters[g0] = 0u;      // k_bin_scan's arrival counter and ready flag
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
     if (frame_poisoned(f)) return;
     AWSM_STAMP_AT(f, FILL ? 2 : 0, 0);
     if (FILL && blockIdx.x < kBinBigBlocks) { bin_big_walk<true>(f, blockIdx.x, kBinBigBlocks); AWSM_STAMP_AT(f, 2, 7); return; }     // workgroup-uniform
-    const uint32_t r0 = (blockIdx.x - (FILL ? kBinBigBlocks : 0u)) * (256u * kBinBatches) + tid;
+    const uint32_t r0 = f.rank0 + (blockIdx.x - (FILL ? kBinBigBlocks : 0u)) * (256u * kBinBatches) + tid;
     const int lane = tid & 63;
     if (tid == 0) { win[0] = 0x7fffffff; win[1] = 0x7fffffff; win[2] = -1; win[3] = -1; n_ok = 0; n_big_wg = 0; }
     __syncthreads();
@@ -982,6 +982,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
     AWSM_STAMP_AT(f, 3, 4);
 }
 
+// MSAA frames with hud meshes (render.rs:169-178 with render_passes/geometry/render_pass.rs:55-57,107-114): the HUD geometry pass draws over the four
+// visibility targets (LoadOp::Load) but tests and writes `hud_depth`, not `depth` — so after it a sample covered by a hud mesh shows the hud triangle in
+// the visibility, barycentric and normal targets and still the WORLD's depth in the depth target (1.0 where the world left none), and that mix is what
+// the opaque pass's edge detector and per-sample resolve read (helpers/msaa.wgsl:42-146, helpers/material_shading.wgsl:170-210).  The same thing as one key
+// per sample: the hud triangle's rank under the world's depth bits.  One thread per sample.
+__global__ __launch_bounds__(256) void k_hud_merge(const unsigned long long* __restrict__ world, const unsigned long long* __restrict__ hud, unsigned long long* __restrict__ out,
+                                                   size_t first, size_t n) {
+    const size_t i = first + (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= first + n) return;
+    const unsigned long long w = world[i], h = hud[i];
+    const unsigned long long depth = w == ~0ull ? 0x3F800000ull : (w >> 32);      // render_pass.rs:107-114: depth cleared to 1.0
+    out[i] = h == ~0ull ? w : ((depth << 32) | (h & 0xFFFFFFFFull));
+}
+
 // Small host->device uploads (dirty ranges of the scene mirrors, the draw list) read the pinned staging ring directly
 // from a kernel: the copy stays in the compute queue, where an SDMA copy would stall the in-order stream on a
 // cross-engine signal for longer than the whole transform kernel runs.
@@ -1088,6 +1102,9 @@ extern "C" void awsm_launch_handoff_wait(const uint32_t* flag, uint32_t serial, 
                                          uint32_t* poison, uint32_t poison_serial, hipStream_t s) {
     hipLaunchKernelGGL(awsm::k_handoff_wait, dim3(1), dim3(64), 0, s, flag, serial, budget_ticks, timeouts_host, timeouts_known, poison, poison_serial);
 }
+extern "C" void awsm_launch_hud_merge(const unsigned long long* world, const unsigned long long* hud, unsigned long long* out, size_t first, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(awsm::k_hud_merge, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, s, world, hud, out, first, n);
+}
 extern "C" void awsm_launch_transform(const awsm::DevScene* sc, const awsm::FrameDev* f, uint32_t n_blocks, hipStream_t s) {
     if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform<false>, dim3(n_blocks), dim3(256), 0, s, sc, *f);
 }
@@ -1095,11 +1112,11 @@ extern "C" void awsm_launch_transform_forward(const awsm::DevScene* sc, const aw
     if (n_blocks) hipLaunchKernelGGL(awsm::k_deform_transform<true>, dim3(n_blocks), dim3(256), 0, s, sc, *f);
 }
 extern "C" void awsm_launch_bin_count(const awsm::FrameDev* f, hipStream_t s) {
-    const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;
+    const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris - f->rank0 + per - 1u) / per;
     if (nb) hipLaunchKernelGGL(awsm::k_bin<false>, dim3(nb), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_bin_big(const awsm::FrameDev* f, int fill, hipStream_t s) {
-    if (!f->total_tris) return;
+    if (f->total_tris <= f->rank0) return;
     if (fill) return;       // the fill pass walks them inside k_bin<true> (awsm_launch_bin_fill)
     hipLaunchKernelGGL(awsm::k_bin_big<false>, dim3(512), dim3(256), 0, s, *f);
 }
@@ -1116,7 +1133,7 @@ extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
     if (n_tiles) hipLaunchKernelGGL(awsm::k_bin_scan, dim3((n_tiles + awsm::kScanThreads - 1u) / awsm::kScanThreads), dim3(awsm::kScanThreads), 0, s, *f, n_tiles);
 }
 extern "C" void awsm_launch_bin_fill(const awsm::FrameDev* f, hipStream_t s) {
-    const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris + per - 1u) / per;
+    const uint32_t per = 256u * awsm::kBinBatches, nb = (f->total_tris - f->rank0 + per - 1u) / per;
     if (nb) hipLaunchKernelGGL(awsm::k_bin<true>, dim3(nb + awsm::kBinBigBlocks), dim3(256), 0, s, *f);
 }
 extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {

@@ -285,8 +285,13 @@ int awsm_hip_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n
  *                                 n_draws = 0 when the frame has no world-transparent mesh).  The hud meshes' transparency geometry, back to front,
  *                                 forward-shaded and blended over the composite (colour LoadOp::Load), depth-tested against hud_depth, cleared
  *                                 (render.rs:490-521).  A hud mesh carries both geometries (gltf/buffers/mesh.rs:33-39).
- * Single-sampled, unsharded frames only (AWSM_ERR_UNSUPPORTED otherwise): with MSAA the reference's edge detector mixes the hud meshes' normals with
- * the world's depths, which this library's separate hud keys do not reproduce. ---- */
+ * With MSAA x4 (the reference's default AntiAliasing) the reference's quirk is reproduced, because its own opaque pass reads it: the HUD geometry pass
+ * draws over the multisampled visibility / barycentric / normal targets but tests and writes hud_depth, so a covered sample shows the hud triangle and
+ * still the WORLD's depth.  A pixel whose sample 0 is a hud triangle stays cleared; elsewhere the edge detector sees hud normals beside world depths
+ * and msaa_resolve_samples shades hud samples like any other (compute.wgsl:176-180: "this may bleed a little").  Internally the hud draws then share the
+ * world pass's rank space and the opaque pass reads merged keys (hud rank under world depth); awsm_hip_read_visibility still returns the world's.
+ * Sharded contexts (row strips, bands) rasterise and shade their own rows of the hud meshes; the two transparent passes need the gathered opaque
+ * image as usual (awsm_hip_bind_opaque_source).  MSAA with BAND sharding: the halo keys exported after this pass are the merged ones. ---- */
 int awsm_hip_hud_geometry_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
 int awsm_hip_hud_transparent_pass(AwsmHipCtx* ctx, const AwsmDraw* draws, uint32_t n_draws);
 /* the full-frame opaque image the transparent pass of a sharded context blits from and refracts through (device memory, width*height*8

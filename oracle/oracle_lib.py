@@ -293,6 +293,38 @@ class OracleFrame:
         return tri, meta, depth
 
 
+def frame_with_hud_msaa(model, lut_rg16f: np.ndarray, threads=8, msaa=4, mipmap=False) -> OracleFrame:
+    """An MSAA frame with hud meshes, as the reference's targets hold it when the opaque pass runs (render.rs:169-178; geometry/render_pass.rs:55-57,
+    107-114): the HUD geometry pass draws over the visibility / barycentric / normal targets (LoadOp::Load) but tests and writes hud_depth, so a sample a hud
+    mesh covers shows the HUD triangle and still the WORLD's depth (1.0 where the world left none).  The opaque pass (compute.wgsl:118-180,303-318,
+    helpers/msaa.wgsl, helpers/material_shading.wgsl:170-210) then: leaves a pixel whose sample 0 is a hud triangle cleared; feeds hud normals and world
+    depths to the edge detector; and shades hud samples like any other in msaa_resolve_samples ("this may bleed a little", compute.wgsl:180).
+
+    Built from three OracleFrames over the same mirrors, with no new arithmetic: the world draws alone (keys = the world's depth and ids), the hud draws alone
+    (their coverage, depth-tested among themselves), and both lists as ONE draw list (world first) whose keys are the merge — the hud triangle's rank in
+    that list under the world's depth bits — shaded by the ordinary MSAA code.  Returns the combined frame, shaded, with .keys set back to the WORLD's keys
+    (what the device keeps in its visibility buffer, what the world transparent pass tests against) and .n_verts / .clip / .nt to the world's, .hud_keys =
+    the hud pass's own keys, .merged_keys = what the opaque pass read."""
+    sc = model.scene
+    kw = dict(skybox=sc.skybox_rgba, prefiltered=sc.prefiltered_rgb, irradiance=sc.irradiance_rgb, msaa=msaa, mipmap=mipmap, env_cubes=sc.env_cubes)
+    world_draws, hud_draws = model.collect_draws(), model.hud_geometry_draws
+    mk = lambda draws: OracleFrame(model.mirrors(), draws, sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f, **kw)   # noqa: E731
+    world = mk(world_draws).transform().raster(threads)
+    hud = mk(hud_draws).transform().raster(threads)
+    comb = mk(world_draws + hud_draws).transform()
+    t_world = np.uint64(world.n_verts // 3)
+    no = hud.keys == NO_HIT_KEY
+    depth_w = np.where(world.keys == NO_HIT_KEY, np.uint64(0x3F800000), world.keys >> np.uint64(32))      # depth cleared to 1.0 (render_pass.rs:107-114)
+    merged = np.where(no, world.keys, (depth_w << np.uint64(32)) | ((hud.keys & np.uint64(0xFFFFFFFF)) - t_world))      # low word = 0xFFFFFFFF - rank
+    comb.keys[...] = merged
+    comb.shade(threads)
+    comb.merged_keys, comb.hud_keys = merged, hud.keys.copy()
+    comb.keys = world.keys.copy()
+    comb.n_verts, comb.clip, comb.nt = world.n_verts, world.clip, world.nt
+    comb._world, comb._hud = world, hud
+    return comb
+
+
 def frame_from_model(model, lut_rg16f: np.ndarray, rows=(0, 0), has_opaque=True, msaa=0, mipmap=False, anisotropic=False) -> OracleFrame:
     sc = model.scene
     fr = OracleFrame(model.mirrors(), model.collect_draws(), sc.width, sc.height, model.texture_arrays(), sc.samplers, lut_rg16f,

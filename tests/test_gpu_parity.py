@@ -1231,6 +1231,61 @@ def test_transparent_pass_on_sharded_contexts(mode, n, msaa, oracle_lut):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,n,msaa", [("bands", 2, 0), ("rows", 3, 0), ("rows", 2, 4)])
+def test_hud_passes_on_sharded_contexts(mode, n, msaa, oracle_lut):
+    """The five passes of a frame with hud meshes on N contexts that each own part of the rows (bands; row strips, also with MSAA x4, where a strip
+    rasterises its own halo rows — of the hud meshes too): the gathered composite must equal the unsharded one bit for bit."""
+    import torch
+    from awsm_renderer_amd import sharding
+    from awsm_renderer_amd.hip_backend import HipDevice
+    sc = scenes.hud_scene(480, 270)
+    W, H = sc.width, sc.height
+    model = helpers.build_model(sc)
+    world, tr = model.collect_draws(), model.collect_transparent_draws()
+    ref, _ = helpers.hip_frame(model, oracle_lut, msaa=msaa, hud=True)
+    want, want_opaque = ref.read_composite(), ref.read_opaque()
+    ref.close()
+    assert (want != want_opaque).any()
+    per = (H + n - 1) // n
+    rows_of = [np.array(sharding.band_rows(H, n, r)) if mode == "bands" else np.arange(min(r * per, H), min(r * per + per, H)) for r in range(n)]
+    devs, opaque, comp = [], [], []
+    gathered = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+    for r in range(n):
+        dev = HipDevice(parity_tap=False)
+        opaque.append(torch.zeros((H, W, 4), dtype=torch.float16, device="cuda"))
+        comp.append(torch.zeros((H, W, 4), dtype=torch.float16, device="cuda"))
+        dev.resize(W, H, msaa)
+        dev.upload_mirrors(model.mirrors())
+        for i, t in enumerate(model.texture_arrays()):
+            dev.texture_array_upload(i, t["texels"])
+        for i, smp in enumerate(sc.samplers):
+            dev.sampler_set(i, smp)
+        dev.env_upload(sc.skybox_rgba, sc.prefiltered_rgb, sc.irradiance_rgb, oracle_lib_rgba16f(oracle_lut))
+        if mode == "bands":
+            dev.set_shard_bands(n, r)
+        else:
+            dev.set_shard_rows(int(rows_of[r][0]), int(rows_of[r][-1]) + 1)
+        dev.bind_output(opaque[r].data_ptr(), H * W * 8)
+        dev.bind_composite(comp[r].data_ptr(), H * W * 8)
+        dev.geometry_pass(world); dev.hud_geometry_pass(model.hud_geometry_draws); dev.opaque_pass(); dev.frame_end()
+        idx = torch.as_tensor(rows_of[r], device="cuda")
+        gathered[idx] = opaque[r][idx]
+        devs.append(dev)
+    torch.cuda.synchronize()
+    assert (gathered.cpu().numpy().view(np.uint16) == want_opaque).all()
+    final = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+    for r, dev in enumerate(devs):
+        dev.bind_opaque_source(gathered.data_ptr(), H * W * 8)
+        dev.transparent_pass(tr); dev.hud_transparent_pass(model.hud_transparent_draws); dev.frame_end()
+        idx = torch.as_tensor(rows_of[r], device="cuda")
+        final[idx] = comp[r][idx]
+        dev.close()
+    torch.cuda.synchronize()
+    got = final.cpu().numpy().view(np.uint16)
+    assert (got == want).all(), int((got != want).any(axis=2).sum())
+
+
+@pytest.mark.gpu
 def test_transparent_pass_edge_cases(oracle_lut):
     """An empty transparent list copies the opaque image; a sharded context refuses; the pass needs the opaque pass first."""
     from awsm_renderer_amd.hip_backend import AwsmHipError
@@ -1273,6 +1328,46 @@ def test_frames_rendered_from_a_glb_file(name, oracle_lut, tmp_path):
         c = helpers.compare_composite(orc, dev)
         assert c["clip_mismatch"] == 0 and c["untouched_changed"] == 0 and c["pixels_over_2ulp"] <= c["touched_pixels"] // 200, c
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mipmap", [False, True])
+def test_hud_passes_with_msaa(oracle_lut, mipmap):
+    """The reference's default anti-aliasing with hud meshes (VERDICT r3 "next" #4), quirk included: after the HUD geometry pass a covered sample shows
+    the hud triangle and still the world's depth; a pixel whose sample 0 is a hud triangle stays cleared, the edge detector sees hud normals beside world
+    depths, and msaa_resolve_samples shades hud samples like any other (compute.wgsl:176-180: "this may bleed a little").  The oracle composes exactly
+    that from its ordinary MSAA code (oracle_lib.frame_with_hud_msaa); here: world keys bit-exact, every opaque pixel within the shading tolerance (the
+    bleeding ones included), cleared pixels exactly zero, the composite after both transparent passes within two f16 steps, the picker on hud pixels."""
+    from oracle.host_mirror import key_as_ffi
+    sc = scenes.hud_scene(480, 270)
+    model = helpers.build_model(sc)
+    orc = oracle_lib.frame_with_hud_msaa(model, oracle_lut, threads=16, msaa=4, mipmap=mipmap)
+    hud0 = orc.merged_keys[..., 0] != orc.keys[..., 0]                       # sample 0 is a hud triangle
+    bleed = (orc.merged_keys != orc.keys).any(axis=-1) & ~hud0               # some other sample is: the pixel is shaded, and may be resolved over a hud sample
+    assert int(hud0.sum()) > 2000 and int(bleed.sum()) > 50
+    dev, _ = helpers.hip_frame(model, oracle_lut, hud=True, msaa=4, mipmap=mipmap)
+    r = helpers.compare_frames(orc, dev, rgb_tol=RGB_TOL)
+    assert r["key_mismatch"] == 0 and r["clip_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["f16_max_ulp"] <= 2, r
+    opaque = dev.read_opaque()
+    assert (opaque[hud0] == 0).all()
+    assert (orc.rgba16f[bleed] != orc._world.shade(16).rgba16f[bleed]).any(axis=-1).sum() > 10      # the quirk is there to be matched: hud samples do change those pixels
+    orc.forward(model.collect_transparent_draws(), 16)
+    orc.forward(model.hud_transparent_draws, 16, hud=True)
+    ulp = helpers.f16_ulp_distance(dev.read_composite(), orc.composite16f)
+    assert int((ulp > 2).any(axis=-1).sum()) <= 4, int((ulp > 2).any(axis=-1).sum())
+    first = np.concatenate([[0], np.cumsum([d["tri_count"] for d in model.hud_geometry_draws])])
+    ys, xs = np.nonzero(hud0)
+    for i in range(0, len(ys), max(1, len(ys) // 16)):
+        y, x = int(ys[i]), int(xs[i])
+        rank = 0xFFFFFFFF - int(orc.hud_keys[y, x, 0] & np.uint64(0xFFFFFFFF))
+        di = int(np.searchsorted(first, rank, side="right") - 1)
+        got = dev.pick(x, y)
+        assert got is not None and got[0] == key_as_ffi(model.hud_geometry_draws[di]["mesh_key"]) and got[1] == rank - int(first[di]), (x, y, got)
+    dev.close()
+    rr, hdev, _ = helpers.host_frame(sc, oracle_lut, msaa=4, mipmap=mipmap)      # the C++ host layer: the reference's default AntiAliasing with a hud mesh renders
+    ulp = helpers.f16_ulp_distance(hdev.read_composite(), orc.composite16f)
+    assert int((ulp > 2).any(axis=-1).sum()) <= 4
+    rr.close()
 
 
 @pytest.mark.gpu
