@@ -8,8 +8,9 @@ from tests import helpers
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 msaa = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+tex_scale = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
 t0 = time.time()
-sc = scenes.atrium_scene(W, H)
+sc = scenes.atrium_scene(W, H, tex_scale=tex_scale)
 model = helpers.build_model(sc)
 print("scene+model %.1fs" % (time.time() - t0), flush=True)
 dev = HipDevice()
