@@ -1436,3 +1436,26 @@ def test_hud_passes(oracle_lut):
     assert (odev.read_opaque()[covered] == 0).all()
     ro.close()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["atrium", "zoo"])
+def test_camera_written_between_the_passes_does_not_split_the_frame(oracle_lut, scene_name):
+    """A frame is shaded with the camera it was submitted with: the lean kernel's pixel -> view matrix is composed at awsm_hip_geometry_pass,
+    the general kernels read the camera buffer — a snapshot the geometry pass takes, in every mode.  A camera write between the two passes of a frame
+    must therefore change nothing of that frame: neither the lean strips nor the general ones (the zoo's optional-block materials take the general code)."""
+    from awsm_renderer_amd.hip_backend import HipDevice
+    from oracle import scene_model as sm
+    sc = scenes.atrium_scene(640, 360, detail=0.125, tex_scale=1 / 32) if scene_name == "atrium" else scenes.material_zoo_scene(480, 270)
+    model = helpers.build_model(sc)
+    dev, _ = helpers.hip_frame(model, oracle_lut)
+    want = dev.read_opaque().copy()
+    other = bytearray(model.mirrors()[sm.BUF_CAMERA])
+    other[384:396] = np.asarray([100.0, -50.0, 25.0], dtype=np.float32).tobytes()      # CameraUniform.position (camera.rs:72-87): somewhere else entirely
+    other[256:320] = np.eye(4, dtype=np.float32).tobytes()                              # inv_proj
+    dev.geometry_pass(model.collect_draws())
+    dev.buffer_write(sm.BUF_CAMERA, 0, np.frombuffer(bytes(other), dtype=np.uint8))
+    dev.opaque_pass()
+    dev.frame_end()
+    assert (dev.read_opaque() == want).all()
+    dev.close()
