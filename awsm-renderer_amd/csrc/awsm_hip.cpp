@@ -1455,7 +1455,13 @@ int awsm_hip_opaque_pass(AwsmHipCtx* c, const AwsmOpaqueParams* p) {
     return AWSM_OK;
 }
 
+static int transparent_pass_body(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n, bool hud);
 static int transparent_pass_impl(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n, bool hud) {
+    const int rc = transparent_pass_body(c, draws, n, hud);
+    if (c) c->hud_transparent = false;      // (whatever the outcome: TR(c) names the world pass's buffers outside a HUD pass's own enqueue)
+    return rc;
+}
+static int transparent_pass_body(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n, bool hud) {
     if (!c || (!draws && n)) return AWSM_ERR_INVALID_ARGUMENT;
     if (!c->geometry_done || !c->opaque_done) return fail(c, AWSM_ERR_NOT_READY, "transparent_pass needs the geometry and opaque passes of the same frame first");
     if (hud && !c->transparent_done) return fail(c, AWSM_ERR_NOT_READY, "hud_transparent_pass draws over the composite: call transparent_pass first (n_draws = 0 is valid)");
@@ -1490,7 +1496,6 @@ static int transparent_pass_impl(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t 
     }
     if ((rc = enqueue_transparent(c))) return rc;
     if (hud) c->hud_transparent_done = true; else { c->transparent_done = true; c->hud_transparent_done = false; }
-    c->hud_transparent = false;
     return AWSM_OK;
 }
 int awsm_hip_transparent_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n) { return transparent_pass_impl(c, draws, n, false); }
