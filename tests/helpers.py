@@ -125,6 +125,7 @@ def compare_frames(orc, dev, rows=None, rgb_tol=1e-4, cond=None):
     over_base = (diff[..., :3] > base[..., :3]).any(axis=-1)
     out["rgb_over_base"] = int(over_base.sum())
     out["rgb_over_abs"] = int((diff[..., :3] > rgb_tol).any(axis=-1).sum())      # the ABSOLUTE bar (north_star's 1e-4 read literally): reported, so that the relative bar above 1.0 is quantified
+    out["px_ref_above_one"] = int((np.abs(ref[..., :3]) > 1.0).any(axis=-1).sum())      # the pixels for which the two bars differ at all
     if cond is None and out["rgb_over_base"] and out["key_mismatch"] == 0:
         import os
         cond = orc.conditioning(os.cpu_count() or 16)
@@ -141,3 +142,20 @@ def compare_frames(orc, dev, rows=None, rgb_tol=1e-4, cond=None):
         ulp = np.where((cond[y0:y1, :, :3].max(axis=-1) <= 1e-5)[..., None], ulp, 0)
     out["f16_max_ulp"] = int(ulp.max()) if ulp.size else 0
     return out
+
+
+def report_bars(name, rows, r):
+    """One line per full-size comparison: how many pixels sit over the ABSOLUTE 1e-4 bar next to the count over the relative one that the tests
+    assert on.  Printed (pytest -s / -rP shows it) and appended to gpurun_out/parity_bars.txt, which gpurun brings back from the GPU box."""
+    import os
+    line = "%s rows=%s covered=%d ref_above_1.0=%d over_abs_1e-4=%d over_rel_1e-4=%d over_conditioned=%d max_abs=%.3e f16_max_ulp=%d" % (
+        name, rows, r["covered"], r["px_ref_above_one"], r["rgb_over_abs"], r["rgb_over_base"], r["rgb_over_tol"], r["rgb_max_abs"], r["f16_max_ulp"])
+    print(line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_bars.txt"), "a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+    return line

@@ -262,6 +262,7 @@ def test_full_size_4k_frame_properties(oracle_lut):
     for rows in ((1040, 1104), (busiest * 32, busiest * 32 + 32)):
         orc = helpers.oracle_frame(model, oracle_lut, rows=rows, threads=16)
         r = helpers.compare_frames(orc, dev, rows=rows, rgb_tol=RGB_TOL)
+        helpers.report_bars("configs[3] atrium 3840x2160", rows, r)
         assert r["clip_mismatch"] == 0 and r["nt_mismatch"] == 0 and r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["f16_max_ulp"] <= 2, (rows, r)
     draws = model.collect_draws()
     dev.geometry_pass(draws); dev.opaque_pass(); dev.frame_end()
@@ -296,6 +297,7 @@ def test_full_size_configs_2_and_3(config, oracle_lut):
     for rows in ((524, 556), (min(busiest, 1080 - 32), min(busiest, 1080 - 32) + 32)):
         orc = helpers.oracle_frame(model, oracle_lut, rows=rows, threads=16)
         r = helpers.compare_frames(orc, dev, rows=rows, rgb_tol=RGB_TOL)
+        helpers.report_bars("configs[%d] %s 1920x1080" % (config - 1, "helmet" if config == 2 else "skinned+morph"), rows, r)
         assert r["clip_mismatch"] == 0 and r["nt_mismatch"] == 0 and r["key_mismatch"] == 0 and r["rgb_over_tol"] == 0 and r["f16_max_ulp"] <= 2, (rows, r)
     draws = model.collect_draws()
     dev.geometry_pass(draws); dev.opaque_pass(); dev.frame_end()
