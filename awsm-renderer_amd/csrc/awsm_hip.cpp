@@ -925,6 +925,11 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
 
     if (c->overlap) {
         for (int s = 0; s < kSlots; s++) {
+            if (const char* m = getenv("AWSM_SHADE_CU_MASK")) {      // experiment (tools/ab_cu_mask.sh): hex words, least significant first, comma separated
+                std::vector<uint32_t> words;
+                for (const char* p = m; *p; ) { char* end = nullptr; words.push_back((uint32_t)strtoul(p, &end, 16)); p = (*end == ',') ? end + 1 : end; if (end == p && *p) break; }
+                if (words.empty() || hipExtStreamCreateWithCUMask(&c->shade_streams[s], (uint32_t)words.size(), words.data()) != hipSuccess) return bail(AWSM_ERR_DEVICE);
+            } else
             if (hipStreamCreateWithFlags(&c->shade_streams[s], hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             // These events order streams of this device among themselves.  Recorded with the default (system-scope) release they write the
             // L2s back and invalidate them each time — behind a raster or shading kernel that is 66 MB of dirty lines: 8-28 us per record on

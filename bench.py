@@ -280,6 +280,15 @@ def main():
     # tensors) orders against it as its current stream.  (torch's default stream has handle 0, which the C-ABI reads as
     # "create a private stream" — that one would not be ordered with the collectives.)
     stream = torch.cuda.Stream(device=local_rank)
+    if os.environ.get("AWSM_BENCH_STREAM_CU_MASK"):      # experiment (tools/ab_cu_mask.sh): the caller's stream — the geometry passes — on a subset of the CUs
+        import ctypes
+        words = [int(x, 16) for x in os.environ["AWSM_BENCH_STREAM_CU_MASK"].split(",")]
+        hip = ctypes.CDLL("libamdhip64.so")
+        raw = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), ctypes.c_uint32(len(words)), (ctypes.c_uint32 * len(words))(*words))
+        if rc != 0:
+            raise SystemExit(f"hipExtStreamCreateWithCUMask: {rc}")
+        stream = torch.cuda.ExternalStream(raw.value, device=local_rank)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     r = Renderer(scene, device=local_rank, stream=stream.cuda_stream, lut_size=1024, msaa=args.msaa, mipmap=args.mipmap, overlap_frames=not args.no_overlap,
