@@ -558,17 +558,22 @@ int enqueue_geometry(AwsmHipCtx* c) {
     }
     if (c->trace_dev) awsm_launch_handoff_signal(nullptr, 0u, trace_slot(c, 0), c->stream);
     if ((rc = record(c, EV_START))) return rc;
-    if (c->total_tris && n_tiles) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
+    // Measurement aid (tools/knockout.sh; static camera only): from the ninth frame on leave out the raster (4), the binning launches as well (6) or
+    // the whole pass (7) — the slot's buffers then keep the previous frames' keys, the opaque pass does the same work, and the frame rate
+    // says what each stage's kernels take from the kernels they run beside.
+    static const int knockout_env = getenv("AWSM_DEBUG_KNOCKOUT") ? atoi(getenv("AWSM_DEBUG_KNOCKOUT")) : 0;
+    const int knockout = c->frame_serial > 8 ? knockout_env : 0;
+    if (c->total_tris && n_tiles && !(knockout & 1)) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
     if ((rc = record(c, EV_TRANSFORM))) return rc;
     ht.mark("geometry: transform launch");
-    if (n_tiles) {
+    if (n_tiles && !(knockout & 2)) {
         if (c->total_tris) { awsm_launch_bin_count(&f, c->stream); awsm_launch_bin_big(&f, 0, c->stream); }
         awsm_launch_bin_scan(&f, c->stream);
         if (c->total_tris) { awsm_launch_bin_fill(&f, c->stream); awsm_launch_bin_big(&f, 1, c->stream); }
     }
     if ((rc = record(c, EV_BIN))) return rc;
     ht.mark("geometry: bin launches");
-    if (n_tiles) awsm_launch_raster(&f, c->stream);
+    if (n_tiles && !(knockout & 4)) awsm_launch_raster(&f, c->stream);
     if ((rc = record(c, EV_RASTER))) return rc;
     ht.mark("geometry: raster launch");
     HIPCHK(c, hipGetLastError());

@@ -583,7 +583,7 @@ struct WorkTri {
 };
 static_assert(sizeof(WorkTri) == 72, "WorkTri");
 // A `small` mid triangle of a single-sampled frame, set up for the integer walk by the thread that classified it (one pass over the batch,
-// instead of once per 16-lane group inside the walk phase): e = E - bias at the centre of the first pixel of its first 4x4 block, the
+// instead of once per 16-lane group inside the walk phase): e = E - bias at the centre of the box's first pixel (where its first 4x4 block starts), the
 // per-pixel steps.  Same size as WorkTri, rank / bbox / exact (= 2) at the same offsets.
 struct WorkSmall {
     int e[3], a[3], b[3];
@@ -617,7 +617,9 @@ AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, 
     }
 }
 
-// The pixels of (bbox ∩ tile) in STEP x STEP blocks, this lane at (lx, ly) inside every block.  Single-sampled exact triangles (all but the
+// The pixels of (bbox ∩ tile) in STEP x STEP blocks, this lane at (lx, ly) inside every block; the first block sits in the box's own corner (blocks
+// aligned to multiples of STEP cover w / STEP + 0.75 columns of a box w wide on average, these ceil(w / STEP): a fifth fewer steps at the median
+// box of the 4K frame; what a pixel's key is does not depend on where the blocks lie).  Single-sampled exact triangles (all but the
 // near-plane crossers): E_i at the lane's pixel of the first block of a row by the two FMAs, then E_i += STEP * a_i from block to block —
 // integers below 2^49 throughout, so the sums are the values the FMAs would give, at one f64 add per edge and pixel instead of two FMAs and
 // the coordinate conversions.
@@ -630,7 +632,7 @@ AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, 
 template <int S, int STEP>
 AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int x0, int x1, int y0, int y1, int lx, int ly, uint32_t r) {
     if (S == 4) {
-        const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx), Y0 = (double)(tpy + (y0 & ~(STEP - 1)) + ly);
+        const double X0 = (double)(tpx + x0 + lx), Y0 = (double)(tpy + y0 + ly);      // blocks start at the box's corner, not at multiples of STEP (see raster_walk_small)
         int e[3], bias[3], sx[3], sy[3], d[4][3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -641,12 +643,12 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
 #pragma unroll
             for (int k = 0; k < 4; k++) d[k][i] = ai * msaa4_x(k) + bi * msaa4_y(k);
         }
-        for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
+        for (int by = y0; by <= y1; by += STEP) {
             const int py = by + ly;
             int r0 = e[0], r1 = e[1], r2 = e[2];
-            for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+            for (int bx = x0; bx <= x1; bx += STEP) {
                 const int px = bx + lx;
-                if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+                if (px <= x1 && py <= y1) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
@@ -666,7 +668,7 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
         }
         return;
     }
-    const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5, Y0 = (double)(tpy + (y0 & ~(STEP - 1)) + ly) + 0.5;
+    const double X0 = (double)(tpx + x0 + lx) + 0.5, Y0 = (double)(tpy + y0 + ly) + 0.5;
     int e[3], bias[3], sx[3], sy[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -677,13 +679,13 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
     // a lane outside the box in y sits out the whole row of blocks: the row test folds into the sign test as an all-ones word
     const uint32_t dx = (uint32_t)(x1 - x0);
     const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
-    for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
+    for (int by = y0; by <= y1; by += STEP) {
         const int py = by + ly;
-        const int row_out = (py >= y0 && py <= y1) ? 0 : -1;
+        const int row_out = (py <= y1) ? 0 : -1;
         int r0 = e[0], r1 = e[1], r2 = e[2];
-        uint32_t ux = (uint32_t)((x0 & ~(STEP - 1)) + lx - x0);      // px - x0 as unsigned: one compare for both sides of the box
+        uint32_t ux = (uint32_t)lx;      // px - x0
         unsigned long long* row = keys + py * kTile + x0;
-        for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+        for (int bx = x0; bx <= x1; bx += STEP) {
             if (ux <= dx && (r0 | r1 | r2 | row_out) >= 0) {
                 const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
                 float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
@@ -713,13 +715,13 @@ AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int
     const float zq0 = g.zq[0], zq1 = g.zq[1], zq2 = g.zq[2];
     const uint32_t dx = (uint32_t)(x1 - x0);
     const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
-    for (int by = y0 & ~3; by <= y1; by += 4) {
+    for (int by = y0; by <= y1; by += 4) {
         const int py = by + ly;
-        const int row_out = (py >= y0 && py <= y1) ? 0 : -1;
+        const int row_out = (py <= y1) ? 0 : -1;
         int r0 = e[0], r1 = e[1], r2 = e[2];
-        uint32_t ux = (uint32_t)((x0 & ~3) + lx - x0);
+        uint32_t ux = (uint32_t)lx;      // px - x0
         unsigned long long* row = keys + py * kTile + x0;
-        for (int bx = x0 & ~3; bx <= x1; bx += 4) {
+        for (int bx = x0; bx <= x1; bx += 4) {
             if (ux <= dx && (r0 | r1 | r2 | row_out) >= 0) {
                 const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
                 float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
@@ -734,7 +736,7 @@ AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int
     }
 }
 
-// raster_walk_i32<4, 4> from a WorkSmall record whose e is E - bias at the CORNER of the first pixel of the first 4x4 block: a sample adds its own
+// raster_walk_i32<4, 4> from a WorkSmall record whose e is E - bias at the CORNER of the box's first pixel: a sample adds its own
 // constant (a ox + b oy) / 256 (a, b: multiples of 256), three adds, one OR3 and one compare per sample.
 AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, int lx, int ly) {
     const uint32_t bb = g.bbox, r = g.rank, bw = g.bias;
@@ -753,13 +755,13 @@ AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, in
     const float zq0 = g.zq[0], zq1 = g.zq[1], zq2 = g.zq[2];
     const uint32_t dx = (uint32_t)(x1 - x0);
     const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
-    for (int by = y0 & ~3; by <= y1; by += 4) {
+    for (int by = y0; by <= y1; by += 4) {
         const int py = by + ly;
-        const bool row_in = py >= y0 && py <= y1;
+        const bool row_in = py <= y1;
         int r0 = e[0], r1 = e[1], r2 = e[2];
-        uint32_t ux = (uint32_t)((x0 & ~3) + lx - x0);
+        uint32_t ux = (uint32_t)lx;      // px - x0
         unsigned long long* row = keys + (py * kTile + x0) * 4;
-        for (int bx = x0 & ~3; bx <= x1; bx += 4) {
+        for (int bx = x0; bx <= x1; bx += 4) {
             if (ux <= dx && row_in) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -785,16 +787,16 @@ AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, i
     if (t.small) { raster_walk_i32<S, STEP>(keys, t, tpx, tpy, x0, x1, y0, y1, lx, ly, r); return; }
     if (S == 1 && t.exact) {
         const double step[3] = {(double)t.a[0] * (double)STEP, (double)t.a[1] * (double)STEP, (double)t.a[2] * (double)STEP};
-        const double X0 = (double)(tpx + (x0 & ~(STEP - 1)) + lx) + 0.5;
-        for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP) {
+        const double X0 = (double)(tpx + x0 + lx) + 0.5;
+        for (int by = y0; by <= y1; by += STEP) {
             const int py = by + ly;
             const double Y = (double)(tpy + py) + 0.5;
             EdgeVals ev;
 #pragma unroll
             for (int i = 0; i < 3; i++) ev.E[i] = fma((double)t.a[i], X0, fma((double)t.b[i], Y, t.c[i]));
-            for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+            for (int bx = x0; bx <= x1; bx += STEP) {
                 const int px = bx + lx;
-                if (px >= x0 && px <= x1 && py >= y0 && py <= y1) {
+                if (px <= x1 && py <= y1) {
                     const unsigned long long k = tri_key_from_edges(t, ev, r);
                     if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
                 }
@@ -804,10 +806,10 @@ AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, i
         }
         return;
     }
-    for (int by = y0 & ~(STEP - 1); by <= y1; by += STEP)
-        for (int bx = x0 & ~(STEP - 1); bx <= x1; bx += STEP) {
+    for (int by = y0; by <= y1; by += STEP)
+        for (int bx = x0; bx <= x1; bx += STEP) {
             const int px = bx + lx, py = by + ly;
-            if (px >= x0 && px <= x1 && py >= y0 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
+            if (px <= x1 && py <= y1) raster_pixel<S>(keys, t, tpx, tpy, px, py, r);
         }
 }
 
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
                         if (area <= 256 && t.small) {
                             WorkSmall& g = reinterpret_cast<WorkSmall&>(work[slot]);
                             const double half = S == 1 ? 0.5 : 0.0;      // one sample: the pixel's centre; four: its corner, the samples add their own offsets
-                            const double X = (double)(tpx + ((x0 - tpx) & ~3)) + half, Y = (double)(tpy + ((y0 - tpy) & ~3)) + half;
+                            const double X = (double)x0 + half, Y = (double)y0 + half;      // the first block starts at the box's corner
                             uint32_t bw = 0u;
 #pragma unroll
                             for (int i = 0; i < 3; i++) {
