@@ -654,11 +654,9 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
                         const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
                         if ((q0 | q1 | q2) >= 0) {
                             const float e0 = (float)(q0 + bias[0]), e1 = (float)(q1 + bias[1]), e2 = (float)(q2 + bias[2]);
-                            float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
-                            if (zn >= 0.0f && zn <= 1.0f) {
-                                if (zn == 0.0f) zn = 0.0f;
-                                atomicMin(&keys[(py * kTile + px) * 4 + k], ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - r));
-                            }
+                            const float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
+                            uint32_t zbits;
+                            if (depth_key_bits(zn, zbits)) atomicMin(&keys[(py * kTile + px) * 4 + k], ((unsigned long long)zbits << 32) | (unsigned long long)(0xFFFFFFFFu - r));
                         }
                     }
                 }
@@ -688,11 +686,9 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
         for (int bx = x0; bx <= x1; bx += STEP) {
             if (ux <= dx && (r0 | r1 | r2 | row_out) >= 0) {
                 const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
-                float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
-                if (zn >= 0.0f && zn <= 1.0f) {
-                    if (zn == 0.0f) zn = 0.0f;
-                    atomicMin(&row[ux], ((unsigned long long)__float_as_uint(zn) << 32) | key_lo);
-                }
+                const float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
+                uint32_t zbits;
+                if (depth_key_bits(zn, zbits)) atomicMin(&row[ux], ((unsigned long long)zbits << 32) | key_lo);
             }
             r0 += sx[0]; r1 += sx[1]; r2 += sx[2]; ux += (uint32_t)STEP;
         }
@@ -724,11 +720,9 @@ AWSM_DI void raster_walk_small(unsigned long long* keys, const WorkSmall& g, int
         for (int bx = x0; bx <= x1; bx += 4) {
             if (ux <= dx && (r0 | r1 | r2 | row_out) >= 0) {
                 const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
-                float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
-                if (zn >= 0.0f && zn <= 1.0f) {
-                    if (zn == 0.0f) zn = 0.0f;
-                    atomicMin(&row[ux], ((unsigned long long)__float_as_uint(zn) << 32) | key_lo);
-                }
+                const float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
+                uint32_t zbits;
+                if (depth_key_bits(zn, zbits)) atomicMin(&row[ux], ((unsigned long long)zbits << 32) | key_lo);
             }
             r0 += sx[0]; r1 += sx[1]; r2 += sx[2]; ux += 4u;
         }
@@ -768,11 +762,9 @@ AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, in
                     const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
                     if ((q0 | q1 | q2) >= 0) {
                         const float e0 = (float)(q0 + bias[0]), e1 = (float)(q1 + bias[1]), e2 = (float)(q2 + bias[2]);
-                        float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
-                        if (zn >= 0.0f && zn <= 1.0f) {
-                            if (zn == 0.0f) zn = 0.0f;
-                            atomicMin(&row[ux * 4u + (uint32_t)k], ((unsigned long long)__float_as_uint(zn) << 32) | key_lo);
-                        }
+                        const float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
+                        uint32_t zbits;
+                        if (depth_key_bits(zn, zbits)) atomicMin(&row[ux * 4u + (uint32_t)k], ((unsigned long long)zbits << 32) | key_lo);
                     }
                 }
             }

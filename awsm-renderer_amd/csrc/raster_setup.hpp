@@ -194,6 +194,11 @@ AWSM_DI double edge_threshold(float a, float b) {
     return (a > 0.0f || (a == 0.0f && b > 0.0f)) ? __longlong_as_double((long long)0x8000000000000001ull) : 0.0;
 }
 
+// "zn >= 0 && zn <= 1, and -0 is stored as +0" (the depth test of the key, as the oracle spells it) in two instructions instead of three comparisons and a
+// select: -0 + 0 = +0 and x + 0 = x for every other x (round to nearest; no fast-math, so the addition stays), and the bit patterns of the floats in
+// [+0, 1] are exactly the unsigned integers up to 0x3F800000 — negative numbers, numbers above 1, infinities and NaNs are all larger as unsigned integers.
+AWSM_DI bool depth_key_bits(float zn, uint32_t& bits) { bits = __float_as_uint(zn + 0.0f); return bits <= 0x3F800000u; }
+
 // Coverage + depth at the sample (X, Y) (pixels, f64).  Returns the packed 64-bit key or ~0 if not covered.
 AWSM_DI unsigned long long tri_key_from_edges(const TriSetup& t, const EdgeVals& ev, uint32_t rank);
 AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, double X, double Y, uint32_t rank) {
@@ -204,11 +209,11 @@ AWSM_DI unsigned long long tri_key_from_edges(const TriSetup& t, const EdgeVals&
     const bool in = ((int)(ev.E[0] > edge_threshold(t.a[0], t.b[0])) & (int)(ev.E[1] > edge_threshold(t.a[1], t.b[1])) & (int)(ev.E[2] > edge_threshold(t.a[2], t.b[2]))) != 0;
     if (!in) return ~0ull;
     const float e0 = (float)ev.E[0], e1 = (float)ev.E[1], e2 = (float)ev.E[2];
-    float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];
-    if (!(zn >= 0.0f && zn <= 1.0f)) return ~0ull;
-    if (zn == 0.0f) zn = 0.0f;   // -0 -> +0 so the bits order as an unsigned integer
+    const float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];
+    uint32_t zbits;
+    if (!depth_key_bits(zn, zbits)) return ~0ull;      // (-0 -> +0 so the bits order as an unsigned integer)
     // depth LessEqual + submission order: smaller depth wins, equal depth -> LATER primitive wins
-    return ((unsigned long long)__float_as_uint(zn) << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
+    return ((unsigned long long)zbits << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
 }
 
 // Conservative "tile can contain a covered sample" test: evaluates every edge at the tile corner that maximises it.
