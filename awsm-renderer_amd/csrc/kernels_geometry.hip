@@ -604,14 +604,17 @@ AWSM_DI void load_work_tri(const WorkTri& g, TriSetup& t) {
 // (per-sample coverage and per-sample depth, as the multisampled visibility / depth targets of the reference receive them).
 template <int S>
 AWSM_DI void raster_pixel(unsigned long long* keys, const TriSetup& t, int tpx, int tpy, int px, int py, uint32_t r) {
-    const int sx = (tpx + px) << 8, sy = (tpy + py) << 8;
     if (S == 1) {
+        const int sx = (tpx + px) << 8, sy = (tpy + py) << 8;
         const unsigned long long k = tri_sample_key_at(t, sample_coord(sx + 128), sample_coord(sy + 128), r);
         if (k != ~0ull) atomicMin(&keys[py * kTile + px], k);
     } else {
+        const float zc = tri_plane_depth(t, tri_edges_d(t, (double)(tpx + px), (double)(tpy + py))) + 0.0f;      // the depth plane at the pixel's corner (-0 -> +0: depth_key_bits_sum)
+        float dz[4];
+        msaa_depth_steps(t.a, t.b, t.zq, dz);
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const unsigned long long k = tri_sample_key_at(t, sample_coord(sx + msaa4_x(s)), sample_coord(sy + msaa4_y(s)), r);
+            const unsigned long long k = tri_msaa_sample_key(t, tpx + px, tpy + py, s, zc, dz, r);
             if (k != ~0ull) atomicMin(&keys[(py * kTile + px) * S + s], k);
         }
     }
@@ -634,6 +637,8 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
     if (S == 4) {
         const double X0 = (double)(tpx + x0 + lx), Y0 = (double)(tpy + y0 + ly);      // blocks start at the box's corner, not at multiples of STEP (see raster_walk_small)
         int e[3], bias[3], sx[3], sy[3], d[4][3];
+        float dz[4];
+        msaa_depth_steps(t.a, t.b, t.zq, dz);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             bias[i] = (t.a[i] > 0.0f || (t.a[i] == 0.0f && t.b[i] > 0.0f)) ? 0 : 1;
@@ -649,15 +654,14 @@ AWSM_DI void raster_walk_i32(unsigned long long* keys, const TriSetup& t, int tp
             for (int bx = x0; bx <= x1; bx += STEP) {
                 const int px = bx + lx;
                 if (px <= x1 && py <= y1) {
+                    const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
+                    const float zc = ((e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2]) + 0.0f;      // tri_plane_depth at the pixel's corner (-0 -> +0: depth_key_bits_sum)
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
-                        if ((q0 | q1 | q2) >= 0) {
-                            const float e0 = (float)(q0 + bias[0]), e1 = (float)(q1 + bias[1]), e2 = (float)(q2 + bias[2]);
-                            const float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];      // tri_key_from_edges
-                            uint32_t zbits;
-                            if (depth_key_bits(zn, zbits)) atomicMin(&keys[(py * kTile + px) * 4 + k], ((unsigned long long)zbits << 32) | (unsigned long long)(0xFFFFFFFFu - r));
-                        }
+                        uint32_t zbits;
+                        if ((q0 | q1 | q2) >= 0 && depth_key_bits_sum(zc, dz[k], zbits))
+                            atomicMin(&keys[(py * kTile + px) * 4 + k], ((unsigned long long)zbits << 32) | (unsigned long long)(0xFFFFFFFFu - r));
                     }
                 }
                 r0 += sx[0]; r1 += sx[1]; r2 += sx[2];
@@ -747,6 +751,11 @@ AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, in
         for (int k = 0; k < 4; k++) d[k][i] = __mul24(ai, msaa4_x(k)) + __mul24(bi, msaa4_y(k));
     }
     const float zq0 = g.zq[0], zq1 = g.zq[1], zq2 = g.zq[2];
+    float dz[4];
+    {
+        const float af[3] = {(float)g.a[0], (float)g.a[1], (float)g.a[2]}, bf[3] = {(float)g.b[0], (float)g.b[1], (float)g.b[2]}, zq[3] = {zq0, zq1, zq2};      // TriSetup's a, b: integers
+        msaa_depth_steps(af, bf, zq, dz);
+    }
     const uint32_t dx = (uint32_t)(x1 - x0);
     const unsigned long long key_lo = (unsigned long long)(0xFFFFFFFFu - r);
     for (int by = y0; by <= y1; by += 4) {
@@ -757,15 +766,13 @@ AWSM_DI void raster_walk_small4(unsigned long long* keys, const WorkSmall& g, in
         unsigned long long* row = keys + (py * kTile + x0) * 4;
         for (int bx = x0; bx <= x1; bx += 4) {
             if (ux <= dx && row_in) {
+                const float e0 = (float)(r0 + bias[0]), e1 = (float)(r1 + bias[1]), e2 = (float)(r2 + bias[2]);
+                const float zc = ((e0 * zq0 + e1 * zq1) + e2 * zq2) + 0.0f;      // tri_plane_depth at the pixel's corner (-0 -> +0: depth_key_bits_sum)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int q0 = r0 + d[k][0], q1 = r1 + d[k][1], q2 = r2 + d[k][2];
-                    if ((q0 | q1 | q2) >= 0) {
-                        const float e0 = (float)(q0 + bias[0]), e1 = (float)(q1 + bias[1]), e2 = (float)(q2 + bias[2]);
-                        const float zn = (e0 * zq0 + e1 * zq1) + e2 * zq2;      // tri_key_from_edges
-                        uint32_t zbits;
-                        if (depth_key_bits(zn, zbits)) atomicMin(&row[ux * 4u + (uint32_t)k], ((unsigned long long)zbits << 32) | key_lo);
-                    }
+                    uint32_t zbits;
+                    if ((q0 | q1 | q2) >= 0 && depth_key_bits_sum(zc, dz[k], zbits)) atomicMin(&row[ux * 4u + (uint32_t)k], ((unsigned long long)zbits << 32) | key_lo);
                 }
             }
             r0 += sx[0]; r1 += sx[1]; r2 += sx[2]; ux += 4u;

@@ -1588,10 +1588,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_forward_cover(const DevScene* _
                     if (!tri_rec_unpack(raw, t)) continue;
                     uint32_t mask = 0u;
                     float z[S];
+                    float zc = 0.0f, dz[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // S == 4: the depth plane at the pixel's corner and the samples' steps (raster_setup.hpp)
+                    if (S == 4) { zc = tri_plane_depth(t, tri_edges_d(t, (double)px, (double)py)) + 0.0f; msaa_depth_steps(t.a, t.b, t.zq, dz); }
 #pragma unroll
                     for (int s = 0; s < S; s++) {
-                        const int ox = S == 1 ? 128 : msaa4_x(s), oy = S == 1 ? 128 : msaa4_y(s);
-                        const unsigned long long k = tri_sample_key_at(t, sample_coord((px << 8) + ox), sample_coord((py << 8) + oy), rank);
+                        const unsigned long long k = S == 1 ? tri_sample_key_at(t, sample_coord((px << 8) + 128), sample_coord((py << 8) + 128), rank)
+                                                            : tri_msaa_sample_key(t, px, py, s, zc, dz, rank);
                         z[s] = __uint_as_float((uint32_t)(k >> 32));
                         if (k != ~0ull && z[s] <= depth[s]) mask |= 1u << s;       // CompareFunction::LessEqual
                     }

@@ -9,7 +9,8 @@
 //     them is exact), as in a hardware rasteriser: shared edges are watertight and small distant triangles keep their depth;
 //   kind 1 — triangles touching w <= 0 (crossing the near plane): homogeneous clip-less edge functions, f32 coefficients.
 // Both kinds evaluate a sample with the same instructions: E_i = fma(a_i, X, fma(b_i, Y, c_i)) in f64 with X, Y in pixels
-// (exact for kind 0), e_i = (float)E_i, depth = (e0*zq0 + e1*zq1) + e2*zq2 in f32, 0 <= depth <= 1 clip per sample;
+// (exact for kind 0), e_i = (float)E_i, depth = (e0*zq0 + e1*zq1) + e2*zq2 in f32, 0 <= depth <= 1 clip per sample (a sample of a
+// multisampled target: that form at the pixel's corner plus the sample's step along the plane's gradient, msaa_depth_steps below);
 // perspective-correct barycentrics for the opaque pass: u_i = e_i * iw_i, b_i = u_i * (1 / ((u0 + u1) + u2)).
 // Used by the binning, raster and shade kernels so that all three see bit-identical edge values.
 #pragma once
@@ -198,18 +199,42 @@ AWSM_DI double edge_threshold(float a, float b) {
 // select: -0 + 0 = +0 and x + 0 = x for every other x (round to nearest; no fast-math, so the addition stays), and the bit patterns of the floats in
 // [+0, 1] are exactly the unsigned integers up to 0x3F800000 — negative numbers, numbers above 1, infinities and NaNs are all larger as unsigned integers.
 AWSM_DI bool depth_key_bits(float zn, uint32_t& bits) { bits = __float_as_uint(zn + 0.0f); return bits <= 0x3F800000u; }
+// The same for a sum zc + dz whose first term has been through "+ 0.0f" already: a sum is -0 only when both terms are, so it needs no second one
+// (and if zc was -0, +0 + dz gives what the canonicalised -0 + dz would: dz, or +0 for dz = -0).
+AWSM_DI bool depth_key_bits_sum(float zc_canonical, float dz, uint32_t& bits) { bits = __float_as_uint(zc_canonical + dz); return bits <= 0x3F800000u; }
 
 // Coverage + depth at the sample (X, Y) (pixels, f64).  Returns the packed 64-bit key or ~0 if not covered.
 AWSM_DI unsigned long long tri_key_from_edges(const TriSetup& t, const EdgeVals& ev, uint32_t rank);
 AWSM_DI unsigned long long tri_sample_key_at(const TriSetup& t, double X, double Y, uint32_t rank) {
     return tri_key_from_edges(t, tri_edges_d(t, X, Y), rank);
 }
-AWSM_DI unsigned long long tri_key_from_edges(const TriSetup& t, const EdgeVals& ev, uint32_t rank) {
-    // all three edges, then one decision (no short-circuit: a nest of exec-masked branches costs more than the two FMAs it may skip)
-    const bool in = ((int)(ev.E[0] > edge_threshold(t.a[0], t.b[0])) & (int)(ev.E[1] > edge_threshold(t.a[1], t.b[1])) & (int)(ev.E[2] > edge_threshold(t.a[2], t.b[2]))) != 0;
-    if (!in) return ~0ull;
+// all three edges, then one decision (no short-circuit: a nest of exec-masked branches costs more than the two FMAs it may skip)
+AWSM_DI bool tri_covers(const TriSetup& t, const EdgeVals& ev) {
+    return ((int)(ev.E[0] > edge_threshold(t.a[0], t.b[0])) & (int)(ev.E[1] > edge_threshold(t.a[1], t.b[1])) & (int)(ev.E[2] > edge_threshold(t.a[2], t.b[2]))) != 0;
+}
+AWSM_DI float tri_plane_depth(const TriSetup& t, const EdgeVals& ev) {
     const float e0 = (float)ev.E[0], e1 = (float)ev.E[1], e2 = (float)ev.E[2];
-    const float zn = (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];
+    return (e0 * t.zq[0] + e1 * t.zq[1]) + e2 * t.zq[2];
+}
+// Multisampled targets (the contract of oracle_geometry.c, tri_sample_msaa): a sample's depth is the plane's value at the pixel's corner —
+// tri_plane_depth of the edge values there — plus the sample's increment along the plane's gradient, dz_k = gx fx_k + gy fy_k with
+// gx = (a0 zq0 + a1 zq1) + a2 zq2, gy likewise from b: one f32 rounding per operation, nothing contracted (the library is built with -ffp-contract=off).
+// One add per sample where the three-term form costs three conversions, three products and two sums.
+AWSM_DI void msaa_depth_steps(const float a[3], const float b[3], const float zq[3], float dz[4]) {
+    const float gx = (a[0] * zq[0] + a[1] * zq[1]) + a[2] * zq[2];
+    const float gy = (b[0] * zq[0] + b[1] * zq[1]) + b[2] * zq[2];
+    dz[0] = gx * 0.375f + gy * 0.125f; dz[1] = gx * 0.875f + gy * 0.375f; dz[2] = gx * 0.125f + gy * 0.625f; dz[3] = gx * 0.625f + gy * 0.875f;      // msaa4_x / 256, msaa4_y / 256
+}
+// The key of sample k of pixel (px, py), or ~0: zc = tri_plane_depth at the pixel's corner + 0.0f (depth_key_bits_sum), dz from msaa_depth_steps.
+AWSM_DI unsigned long long tri_msaa_sample_key(const TriSetup& t, int px, int py, int k, float zc, const float dz[4], uint32_t rank) {
+    if (!tri_covers(t, tri_edges_d(t, sample_coord((px << 8) + msaa4_x(k)), sample_coord((py << 8) + msaa4_y(k))))) return ~0ull;
+    uint32_t zbits;
+    if (!depth_key_bits_sum(zc, dz[k], zbits)) return ~0ull;
+    return ((unsigned long long)zbits << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
+}
+AWSM_DI unsigned long long tri_key_from_edges(const TriSetup& t, const EdgeVals& ev, uint32_t rank) {
+    if (!tri_covers(t, ev)) return ~0ull;
+    const float zn = tri_plane_depth(t, ev);
     uint32_t zbits;
     if (!depth_key_bits(zn, zbits)) return ~0ull;      // (-0 -> +0 so the bits order as an unsigned integer)
     // depth LessEqual + submission order: smaller depth wins, equal depth -> LATER primitive wins

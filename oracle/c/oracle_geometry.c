@@ -341,10 +341,41 @@ static inline int tri_sample(const TriSetup* t, int px, int py, int ox, int oy, 
     return 1;
 }
 
+/* One sample of a multisampled target (sample k of the standard 4x pattern).  Coverage: the edge values at the sample itself, exact, as above.
+ * Depth: the depth plane's value at the pixel's CORNER — the edge values there, rounded and weighted exactly as a single sample's are — plus the
+ * sample's increment along the plane's gradient, every operation rounded once in f32, nothing contracted:
+ *     gx = (a0 zq0 + a1 zq1) + a2 zq2,  gy = (b0 zq0 + b1 zq1) + b2 zq2     a_i, b_i: what E_i gains per pixel in x / y, as f32
+ *     dz_k = gx fx_k + gy fy_k                                              (fx_k, fy_k) = the sample's offset from the corner in pixels
+ *     zn_k = zc + dz_k                                                      zc = (e0 zq0 + e1 zq1) + e2 zq2 at (px, py)
+ * i.e. how a fixed-function unit steps a plane equation from a reference point (WebGPU leaves the evaluation to the implementation); until round 4
+ * every sample evaluated the three-term form itself (three conversions, three products, two sums per sample for bits nobody can tell apart: both
+ * forms are within 2 ulp of the plane).  The clip test 0 <= zn <= 1 stays per sample. */
+static inline int tri_sample_msaa(const TriSetup* t, int px, int py, int k, float* depth_out) {
+    float e[3], ec[3];
+    if (!tri_edges_sample(t, px, py, oracle_msaa4_x[k], oracle_msaa4_y[k], e)) return 0;
+    (void)tri_edges_sample(t, px, py, 0, 0, ec);
+    float a[3], b[3];
+    for (int i = 0; i < 3; i++) {
+        if (t->kind == 0) { a[i] = (float)t->a[i] * (float)SUBPIX; b[i] = (float)t->b[i] * (float)SUBPIX; }      /* |a|, |b| <= 2^24: exact */
+        else { a[i] = t->ha[i]; b[i] = t->hb[i]; }
+    }
+    const float zc = (ec[0] * t->zq[0] + ec[1] * t->zq[1]) + ec[2] * t->zq[2];
+    const float gx = (a[0] * t->zq[0] + a[1] * t->zq[1]) + a[2] * t->zq[2];
+    const float gy = (b[0] * t->zq[0] + b[1] * t->zq[1]) + b[2] * t->zq[2];
+    const float fx = (float)oracle_msaa4_x[k] * (1.0f / (float)SUBPIX), fy = (float)oracle_msaa4_y[k] * (1.0f / (float)SUBPIX);      /* exact */
+    const float dz = gx * fx + gy * fy;
+    float zn = zc + dz;
+    if (!(zn >= 0.0f && zn <= 1.0f)) return 0;
+    if (zn == 0.0f) zn = 0.0f;
+    *depth_out = zn;
+    return 1;
+}
+
 /* the setup and the per-sample test, for the forward pass in oracle_shade.c */
 void oracle_tri_setup(const float* v0, const float* v1, const float* v2, int cull_back, uint32_t width, uint32_t height,
                       uint32_t ry0, uint32_t ry1, TriSetup* t) { tri_setup(v0, v1, v2, cull_back, width, height, ry0, ry1, t); }
 int oracle_tri_sample(const TriSetup* t, int px, int py, int ox, int oy, float* depth_out) { return tri_sample(t, px, py, ox, oy, depth_out); }
+int oracle_tri_sample_msaa(const TriSetup* t, int px, int py, int k, float* depth_out) { return tri_sample_msaa(t, px, py, k, depth_out); }
 /* perspective-correct barycentrics of a pixel centre from an existing setup (what oracle_tri_bary_at computes) */
 void oracle_tri_bary(const TriSetup* t, int px, int py, float* b_out) {
     float e[3];
@@ -398,7 +429,7 @@ int oracle_raster(const OracleScene* s, const float* clip, uint64_t* keys, int t
                             if (zn <= depth[p]) { depth[p] = zn; rank_buf[p] = rank; }   /* CompareFunction::LessEqual */
                         } else {   /* per-sample coverage + per-sample depth (multisampled depth/visibility targets) */
                             for (uint32_t k = 0; k < 4u; k++) {
-                                if (!tri_sample(&ts, px, py, oracle_msaa4_x[k], oracle_msaa4_y[k], &zn)) continue;
+                                if (!tri_sample_msaa(&ts, px, py, (int)k, &zn)) continue;
                                 if (zn <= depth[p * 4 + k]) { depth[p * 4 + k] = zn; rank_buf[p * 4 + k] = rank; }
                             }
                         }

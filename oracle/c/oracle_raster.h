@@ -19,5 +19,6 @@ extern const int oracle_msaa4_x[4], oracle_msaa4_y[4];
 void oracle_tri_setup(const float* v0, const float* v1, const float* v2, int cull_back, uint32_t width, uint32_t height,
                       uint32_t ry0, uint32_t ry1, TriSetup* t);
 int oracle_tri_sample(const TriSetup* t, int px, int py, int ox, int oy, float* depth_out);
+int oracle_tri_sample_msaa(const TriSetup* t, int px, int py, int k, float* depth_out);      /* sample k of the 4x pattern: oracle_geometry.c */
 void oracle_tri_bary(const TriSetup* t, int px, int py, float* b_out);
 #endif

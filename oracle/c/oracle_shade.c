@@ -1464,8 +1464,8 @@ int oracle_forward(const OracleScene* s, const AwsmDraw* draws, uint32_t n_draws
                         const size_t p = (size_t)py * W + (size_t)px;
                         float z[4]; uint32_t mask = 0;
                         for (uint32_t k = 0; k < S; k++) {
-                            const int ox = S == 1u ? 128 : oracle_msaa4_x[k], oy = S == 1u ? 128 : oracle_msaa4_y[k];
-                            if (oracle_tri_sample(&ts, px, py, ox, oy, &z[k]) && z[k] <= depth[p * S + k]) mask |= 1u << k;   /* LessEqual */
+                            const int in = S == 1u ? oracle_tri_sample(&ts, px, py, 128, 128, &z[k]) : oracle_tri_sample_msaa(&ts, px, py, (int)k, &z[k]);
+                            if (in && z[k] <= depth[p * S + k]) mask |= 1u << k;   /* LessEqual */
                         }
                         if (!mask) continue;
                         float src[4];
