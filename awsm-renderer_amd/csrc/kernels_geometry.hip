@@ -821,9 +821,11 @@ AWSM_DI void raster_walk(unsigned long long* keys, const TriSetup& t, int tpx, i
 #ifndef AWSM_RASTER_WAVES1
 #define AWSM_RASTER_WAVES1 7
 #endif
+#ifndef AWSM_RASTER_WAVES4
+#define AWSM_RASTER_WAVES4 5
+#endif
 template <int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 : AWSM_RASTER_WAVES1))) void k_raster_tile(FrameDev f) {
-    __shared__ unsigned long long keys[kTile * kTile * S];   // 8 KB, or 32 KB with 4 samples per pixel: [pixel][sample]
+AWSM_DI void raster_tile_body(const FrameDev& f, unsigned long long* keys) {      // keys: 8 KB of LDS, or 32 KB with 4 samples per pixel: [pixel][sample]
     // Triangles per batch: fewer than threads, for occupancy — most tiles hold fewer than a hundred anyway.  Four samples per pixel: 96, so that keys +
     // list fit a CU's LDS four times instead of three (32 KB + 6.75 KB against 32 KB + 18 KB; k_raster_tile<4> 281 -> 240 us at 4K).  One sample:
     // 128 and a 72-register budget, seven workgroups per CU instead of six (75 -> 72 us; an eighth needs 64 registers and spills).
@@ -981,6 +983,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 4 ? 4 
         if (px < (int)f.width && py >= (int)f.y0 && py < (int)f.y1) __builtin_nontemporal_store(keys[e], &f.vis[((size_t)py * f.width + px) * S + s]);      // written once, read by the next kernel
     }
     AWSM_STAMP_AT(f, 3, 4);
+}
+// The two instantiations as explicit specialisations, because their register budgets differ in kind: one sample — seven workgroups per CU (72 registers);
+// four samples — the 32-KB tile allows four workgroups per CU whatever the registers, but at 104 registers four of its wavefronts leave a SIMD 96,
+// less than one wavefront of the gradient lean kernel needs (112): the two kernels then take turns on a CU instead of sharing it, and
+// k_raster_tile<4> adds its whole duration to the frame (tools/knockout.sh).  96: four of its wavefronts and one of the lean kernel's fit a SIMD's 512.
+// (The compiler drops a waves-per-SIMD request that the kernel's static LDS makes unreachable, and with it the register cap it implies; so <4>'s tile is
+// dynamic LDS — the launcher passes its 32 KB — and the request, 5 = at most 96 registers, stands.)
+template <int S> __global__ void k_raster_tile(FrameDev f);
+template <> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_RASTER_WAVES1))) void k_raster_tile<1>(FrameDev f) {
+    __shared__ unsigned long long keys[kTile * kTile];
+    raster_tile_body<1>(f, keys);
+}
+template <> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_RASTER_WAVES4))) void k_raster_tile<4>(FrameDev f) {
+    extern __shared__ unsigned long long keys_dynamic[];
+    raster_tile_body<4>(f, keys_dynamic);
 }
 
 // MSAA frames with hud meshes (render.rs:169-178 with render_passes/geometry/render_pass.rs:55-57,107-114): the HUD geometry pass draws over the four
@@ -1141,6 +1158,6 @@ extern "C" void awsm_launch_raster(const awsm::FrameDev* f, hipStream_t s) {
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (!n_tiles) return;
     const uint32_t nb = n_tiles + (f->raster_scratch ? f->raster_extra_cap : 0u);     // surplus ids exit at once
-    if (f->msaa == 4u) hipLaunchKernelGGL(awsm::k_raster_tile<4>, dim3(nb), dim3(256), 0, s, *f);
+    if (f->msaa == 4u) hipLaunchKernelGGL(awsm::k_raster_tile<4>, dim3(nb), dim3(256), awsm::kTile * awsm::kTile * 4 * sizeof(unsigned long long), s, *f);      // the tile: dynamic LDS
     else hipLaunchKernelGGL(awsm::k_raster_tile<1>, dim3(nb), dim3(256), 0, s, *f);
 }

@@ -9,7 +9,8 @@ from tests import helpers
 sc = scenes.atrium_scene(3840, 2160, tex_scale=1 / 16)
 model = helpers.build_model(sc)
 dev = HipDevice()
-dev.resize(3840, 2160)
+msaa = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 4: k_raster_tile<4>
+dev.resize(3840, 2160, msaa)
 dev.upload_mirrors(model.mirrors())
 for i, t in enumerate(model.texture_arrays()):
     dev.texture_array_upload(i, t["texels"])
