@@ -2830,7 +2830,10 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 // lanes for three in a row), then the threads of the edge pixels gather their four colours.  Up to 768 items per block, in LDS.
 // The lean MSAA route's edge detector: one wavefront per block writes the block's edge list (count + one-byte pixel slots) for k_shade_msaa_resolve.
 // (Not the first phase of that kernel: with it inside, the register allocation of the shading code behind it came out at 155 instead of 127.)
-__global__ __launch_bounds__(64) void k_msaa_detect(FrameDev f) {
+#ifndef AWSM_DETECT_WAVES
+#define AWSM_DETECT_WAVES 8
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AWSM_DETECT_WAVES))) void k_msaa_detect(FrameDev f) {      // 64 registers: fits beside four wavefronts of the gradient lean kernel (448 of a SIMD's 512)
     __shared__ __attribute__((aligned(16))) uint8_t eslot[256];
     __shared__ uint8_t tslot[256];
     ShadeBlock b;
