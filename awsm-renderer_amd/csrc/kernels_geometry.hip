@@ -38,10 +38,13 @@ struct GeomMetaDev {
 // FWD = the transparent pass's vert_main (material_transparent_wgsl/vertex.wgsl:40-72): an indexed draw of the mesh's 40-byte
 // vertices (AWSM_BUF_TRANSPARENCY_GEOM_DATA at draw.vis_data_off) through the custom-attribute index buffer
 // (meshes/mesh.rs:129-200); one thread per triangle corner, which also leaves the world position for the fragment stage.
+#ifndef AWSM_TRANSFORM_WAVES
+#define AWSM_TRANSFORM_WAVES 6
+#endif
 template <bool FWD>
 // FWD = false: capped at 80 VGPRs (122 uncapped; the spills sit in the skinning branch) so that two wavefronts per SIMD fit next to the
 // previous frame's persistent opaque-pass grid — with one, the kernel ran 209 us beside it (31 alone).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : 6))) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : AWSM_TRANSFORM_WAVES))) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[FWD ? 4 : 256 * 14];
     if (frame_poisoned(f)) return;
     const uint32_t tid = threadIdx.x;
