@@ -148,6 +148,58 @@ def test_raster_top_left_rule_and_depth_on_a_hand_computed_case():
         assert abs(float(depth[y, x]) - (0.25 + 0.5 * (x + 0.5) / 8.0)) < 1e-6          # z rises linearly along x
 
 
+def test_msaa_sample_depth_is_the_plane_at_the_sample():
+    """The multisampled raster rule (oracle_geometry.c tri_sample_msaa): coverage from the exact edge values at the sample, depth = the
+    plane at the pixel's corner + the sample's step along the gradient.  Against the planes themselves, in f64, at WebGPU's four standard positions: 120
+    random triangles with random depths in one 96x64 frame, identity view-projection.  Every sample's depth must be within a few f32 steps of its winning
+    triangle's plane (the three-term form this rule replaced did no better); a sample strictly inside some triangle is covered, one strictly outside all
+    of them is not."""
+    rng = np.random.default_rng(404)
+    W, H, N = 96, 64, 120
+    offs = np.array([[0.375, 0.125], [0.875, 0.375], [0.125, 0.625], [0.625, 0.875]])
+    pos, idx = [], []
+    while len(idx) < N:
+        p = rng.uniform([-4, -4], [W + 4, H + 4], size=(3, 2))
+        d1, d2 = p[1] - p[0], p[2] - p[0]
+        if abs(d1[0] * d2[1] - d1[1] * d2[0]) < 8.0:
+            continue
+        z = rng.uniform(0.05, 0.95, size=3)
+        o = len(pos)
+        pos += [[px / (W / 2) - 1.0, 1.0 - py / (H / 2), zz] for (px, py), zz in zip(p, z)]
+        idx.append([o, o + 1, o + 2])
+    pos = np.array(pos, dtype=F)
+    prim = PrimitiveDesc(positions=pos, normals=np.tile(np.array([[0, 0, 1]], dtype=F), (len(pos), 1)), indices=np.array(idx, dtype=np.uint32), material=0)
+    eye4 = np.eye(4, dtype=F)
+    sc = SceneDesc(nodes=[NodeDesc(), NodeDesc(parent=0, primitives=[prim])], materials=[MaterialDesc(double_sided=True)], samplers=[dict(scenes.REPEAT_LINEAR)],
+                   lights=[], width=W, height=H, view=eye4, proj=eye4, camera_position=(0, 0, 1))
+    fr = helpers.oracle_frame(helpers.build_model(sc), oracle_lib.brdf_lut(8, 8), msaa=4, threads=4)
+    keys = fr.keys                                                   # [H, W, 4]
+    depth = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    rank = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    hit = keys != helpers.NO_HIT
+    ys, xs = np.mgrid[0:H, 0:W]
+    any_inside = np.zeros((H, W, 4), dtype=bool)
+    all_outside = np.ones((H, W, 4), dtype=bool)
+    worst = 0.0
+    for t in range(N):
+        v = pos[3 * t:3 * t + 3]
+        # the snapped triangle, as the contract snaps it (1/256 px, round to nearest even), and its plane in f64
+        q = np.rint((np.stack([(v[:, 0] + F(1)) * F(W / 2), (F(1) - v[:, 1]) * F(H / 2)], axis=1) * F(256)).astype(np.float64)) / 256.0
+        plane = np.linalg.solve(np.array([[q[0, 0], q[0, 1], 1.0], [q[1, 0], q[1, 1], 1.0], [q[2, 0], q[2, 1], 1.0]]), v[:, 2].astype(np.float64))
+        sgn = np.sign((q[1, 0] - q[0, 0]) * (q[2, 1] - q[0, 1]) - (q[1, 1] - q[0, 1]) * (q[2, 0] - q[0, 0]))
+        for k in range(4):
+            sx, sy = xs + offs[k, 0], ys + offs[k, 1]
+            e = [sgn * ((q[(i + 2) % 3, 0] - q[(i + 1) % 3, 0]) * (sy - q[(i + 1) % 3, 1]) - (q[(i + 2) % 3, 1] - q[(i + 1) % 3, 1]) * (sx - q[(i + 1) % 3, 0])) for i in range(3)]
+            any_inside[..., k] |= np.all([ei > 1e-9 for ei in e], axis=0)
+            all_outside[..., k] &= np.any([ei < -1e-9 for ei in e], axis=0)
+            mine = hit[..., k] & (rank[..., k] == t)
+            if mine.any():
+                err = np.abs(depth[..., k].astype(np.float64) - (plane[0] * sx + plane[1] * sy + plane[2]))[mine]
+                worst = max(worst, float(err.max() / np.spacing(np.float32(1.0))))
+    assert hit[any_inside].all() and not hit[all_outside].any()
+    assert hit.mean() > 0.5 and worst < 4.0, (float(hit.mean()), worst)       # in steps of f32 at 1.0 (the depths lie in [0.05, 0.95])
+
+
 @pytest.mark.gpu
 def test_the_hip_path_meets_the_same_closed_forms_without_the_oracle():
     """The HIP path against the closed forms directly (no oracle between them): the directional, ranged point and tilted spot cases above,
