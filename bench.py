@@ -445,7 +445,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_first = time.perf_counter()
     first = r.render(sync=True)            # uploads everything, sizes the bin list
+    first_frame_ms = (time.perf_counter() - t_first) * 1e3
+    first_frame_upload = int(r.host.upload_bytes_last_frame())
     r.host.set_render_timings(bool(os.environ.get("AWSM_BENCH_STAGE_TIMERS")))   # the timed loop does not read per-stage times: no event bubbles between the kernels
     # No Python garbage collection inside the warm-up and the timed loop: a generation-2 pass over the scene's objects takes ~35 ms, and
     # whether one lands in a 25-70 ms loop depends on the allocation count of everything before it (seen: configs[1] at 3,100 or 8,300
@@ -651,6 +654,10 @@ def main():
                                                 "frames_with_dropped_bin_entries", "bin_overflow_retries")},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            # what crosses the boundary as host buffers: `value` is measured with the scene resident; a frame's own uploads are inside it
+            "host_to_device": {"first_frame_bytes": first_frame_upload, "first_frame_ms": round(first_frame_ms, 2),
+                               "texture_bytes_at_setup": int(sum(int(t.nbytes) for t in scene.textures)),
+                               "steady_state_bytes_per_frame": int(r.host.upload_bytes_last_frame())},
             **({"collective": {"backend": "rccl" if backend == "nccl" else backend + " (rehearsal: every rank on GPU 0, staged through the host)",
                                "op": "gather to rank 0" if to_root else "all_gather_into_tensor", "bytes_per_rank": rows_out * W * 8,
                                "alone_ms": max(p["gather_alone_ms"] for p in per_rank), "launcher": "bench.py (child processes)" if os.environ.get("AWSM_BENCH_SELF_LAUNCHED") else "external (WORLD_SIZE was set)"},
