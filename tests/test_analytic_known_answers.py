@@ -148,6 +148,36 @@ def test_raster_top_left_rule_and_depth_on_a_hand_computed_case():
         assert abs(float(depth[y, x]) - (0.25 + 0.5 * (x + 0.5) / 8.0)) < 1e-6          # z rises linearly along x
 
 
+def test_depth_key_test_as_one_add_and_one_unsigned_compare():
+    """raster_setup.hpp depth_key_bits: the key's depth test "zn >= 0 && zn <= 1, -0 stored as +0" (oracle_geometry.c tri_sample) is computed on the device as
+    bits(zn + 0.0f) <= 0x3F800000 — restated here in numpy and compared with the oracle's spelling over every special value, every binade boundary and
+    four million random bit patterns (both the decision and the stored bits)."""
+    rng = np.random.default_rng(7)
+    special = np.array([0x00000000, 0x80000000, 0x00000001, 0x80000001, 0x007FFFFF, 0x807FFFFF, 0x00800000, 0x80800000, 0x3F7FFFFF, 0x3F800000, 0x3F800001,
+                        0xBF800000, 0x7F7FFFFF, 0x7F800000, 0xFF800000, 0x7F800001, 0x7FC00000, 0xFFC00000, 0xFFFFFFFF], dtype=np.uint32)
+    edges = np.array([(e << 23) + d for e in range(256) for d in (0, 1, 0x7FFFFF)] + [0x80000000 + (e << 23) + d for e in range(256) for d in (0, 1, 0x7FFFFF)], dtype=np.uint64).astype(np.uint32)
+    bits = np.concatenate([special, edges, rng.integers(0, 1 << 32, size=4_000_000, dtype=np.uint64).astype(np.uint32),
+                           rng.integers(0x3F000000, 0x3F800010, size=200_000, dtype=np.uint64).astype(np.uint32)])
+    zn = bits.view(np.float32)
+    with np.errstate(invalid="ignore"):
+        want_in = (zn >= np.float32(0.0)) & (zn <= np.float32(1.0))
+        want_bits = np.where(zn == np.float32(0.0), np.float32(0.0), zn).view(np.uint32)        # -0 -> +0
+        got_bits = (zn + np.float32(0.0)).view(np.uint32)
+    got_in = got_bits <= np.uint32(0x3F800000)
+    assert (got_in == want_in).all()
+    assert (got_bits[want_in] == want_bits[want_in]).all()
+    # depth_key_bits_sum: with zc canonicalised once, zc0 + dz needs no second canonicalisation — a sum is -0 only when both terms are
+    a = np.concatenate([special, rng.integers(0, 1 << 32, size=500_000, dtype=np.uint64).astype(np.uint32)]).view(np.float32)
+    b = np.concatenate([special[::-1], rng.integers(0, 1 << 32, size=500_000, dtype=np.uint64).astype(np.uint32)]).view(np.float32)
+    b = np.where(rng.random(b.size) < 0.2, -a, b).astype(np.float32)                                       # cancellations too
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref = a + b
+        ref = np.where(ref == np.float32(0.0), np.float32(0.0), ref)                                       # the oracle: zn = zc + dz, then -0 -> +0
+        got = (a + np.float32(0.0)) + b
+    same = (ref.view(np.uint32) == got.view(np.uint32)) | (np.isnan(ref) & np.isnan(got))
+    assert same.all()
+
+
 def test_msaa_sample_depth_is_the_plane_at_the_sample():
     """The multisampled raster rule (oracle_geometry.c tri_sample_msaa): coverage from the exact edge values at the sample, depth = the
     plane at the pixel's corner + the sample's step along the gradient.  Against the planes themselves, in f64, at WebGPU's four standard positions: 120
