@@ -183,6 +183,19 @@ def test_bench_two_rank_rehearsal_on_one_gpu(msaa, extra, launcher):
 
 
 @pytest.mark.gpu
+def test_rccl_one_rank_carries_what_the_library_rendered():
+    """The collectives of bench.py's N > 1 loop on RCCL itself, as far as one GPU goes: world size 1 (tests/rccl_one_rank.py, in a process of its
+    own).  Frames rendered into torch tensors on the library's shade streams, flushed, gathered on RCCL's stream while the next frame renders:
+    every gathered frame equals the library's own image bit for bit.  What stays for the driver's 8-GPU node is more than one peer."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_one_rank.py")], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().splitlines()[-1] == "ok", p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_picker_matches_visibility_buffer(oracle_lut):
     """awsm_hip_pick / awsm_host_pick (picker.rs:55-121, picker_wgsl/compute.wgsl): the mesh key under a pixel is the one
     the oracle's visibility buffer attributes to it; background, out-of-frame and other-shard pixels miss."""
