@@ -2551,8 +2551,11 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
 // GRAD: MipmapMode::Gradient (the reference's default): barycentric derivatives, isotropic LOD, two levels per texture — a separate instantiation, as the
 // reference keeps separate pipelines; its ten footprints in flight want more registers than six waves per SIMD leave.
+#ifndef AWSM_LEAN_GRAD_WAVES
+#define AWSM_LEAN_GRAD_WAVES 4
+#endif
 template <bool PERSIST, int GRAD, bool MSAA>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? AWSM_ANISO_WAVES : (GRAD ? 4 : (PERSIST ? 5 : AWSM_LEAN_WAVES))))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? AWSM_ANISO_WAVES : (GRAD ? AWSM_LEAN_GRAD_WAVES : (PERSIST ? 5 : AWSM_LEAN_WAVES))))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ LeanStage stage[4];                                         // one per wavefront (no barrier anywhere: the four are independent)
     if (frame_poisoned(f)) return;
     LeanStage* const st = &stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
