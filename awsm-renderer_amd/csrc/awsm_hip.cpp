@@ -86,6 +86,21 @@ struct FrameBufs {
     void* draws_uploaded_ptr = nullptr;
     bool draws_uploaded_valid = false;
     uint64_t draws_version = 0;            // bumped whenever draws_dev receives a new list
+    // MSAA frames with hud meshes: the hud draws behind the world's in draws_dev (awsm_hip_hud_geometry_pass), cached by themselves so that the world
+    // list's own cache keeps hitting
+    std::vector<DrawDev> tail_uploaded;
+    void* tail_uploaded_ptr = nullptr;
+    size_t tail_uploaded_at = 0;
+    bool tail_uploaded_valid = false;
+    // Geometry cache (frame_params.hpp; the world geometry pass only): the draw list this slot's wcache / nrm / tan / tri_shade / tri_info were last
+    // computed for lives on in draws_prev when a new list arrives (the two buffers swap), so that k_deform_transform can compare draw by draw.
+    DevBuf wcache, draws_prev;
+    uint32_t cached_n_draws = 0;           // draws of the list the arrays were computed for
+    bool cache_valid = false;              // ... and whether they were (false after any re-allocation, a frame without geometry, a dropped frame)
+    bool cached_is_prev = false;           // that list is in draws_prev (a new list has been uploaded since), else it is draws_dev's
+    bool cache_had_tri_shade = false;
+    uint64_t cache_seq = 0;                // write_seq when that geometry pass was enqueued: dirty ranges logged after it apply
+    uint32_t cache_serial = 0;             // its frame serial
 };
 
 }  // namespace
@@ -139,6 +154,14 @@ struct AwsmHipCtx {
     hipEvent_t ev_geom_done[kSlots] = {}, ev_shade_done[kSlots] = {}, ev_uploads[kSlots] = {} ;
     hipEvent_t ev_flush = nullptr;             // awsm_hip_frame_flush: system-scope release in front of what the CALLER enqueues next (a collective, a peer / host copy)
     uint64_t write_seq = 0, geom_write_seq[kSlots] = {};     // scene writes so far / at the time the slot's geometry pass was enqueued
+    // Geometry cache: the byte ranges written (awsm_hip_buffer_write / buffer_create) to the buffers k_deform_transform reads, each with the write_seq it got;
+    // a slot's geometry pass hands the kernel those newer than the slot's cache_seq.  all_dirty_seq: everything up to that write_seq counts as "all
+    // written" (the log overflowed, or a buffer was written whose every write invalidates every draw).
+    struct DirtyRange { uint32_t buf, lo, hi; uint64_t seq; };
+    std::vector<DirtyRange> dirty_log;
+    uint64_t all_dirty_seq = 0;
+    bool geometry_cache = true;                 // AWSM_GEOMETRY_CACHE=0 turns it off (A/B measurements, tests)
+    uint32_t cache_blocks_last = 0;             // AwsmFrameStats.geometry_cache_blocks of the frame frame_end last looked at
     bool shade_pending[kSlots] = {};
     // Device-side hand-off between the streams (kernels_geometry.hip: k_handoff_signal / k_handoff_wait) in place of the two cross-stream events
     // on a frame's critical path: geometry pass -> opaque pass of the same frame, opaque pass of frame i -> geometry pass of frame i + kSlots.
@@ -285,6 +308,7 @@ int handoff_check(AwsmHipCtx* c) {
         c->handoff_timeouts_seen = now;
         c->handoff = false;
         c->handoff_error_pending = true;
+        for (FrameBufs& b : c->fb) b.cache_valid = false;      // a dropped frame's kernels wrote nothing: the geometry cache's book-keeping no longer describes the arrays
     }
     if (!c->handoff_error_pending) return AWSM_OK;
     c->handoff_error_pending = false;
@@ -367,6 +391,27 @@ void shard(const AwsmHipCtx* c, uint32_t* y0, uint32_t* y1) {
     if (*y0 > *y1) *y0 = *y1;
 }
 
+// Geometry cache: remember what was written to the buffers k_deform_transform reads (call after the write got its write_seq).
+void log_dirty(AwsmHipCtx* c, AwsmBuf which, size_t lo, size_t hi) {
+    switch (which) {
+    case AWSM_BUF_ATTR_DATA: case AWSM_BUF_ATTR_INDEX: case AWSM_BUF_MORPH_VALUES: case AWSM_BUF_SKIN_INDEX_WEIGHTS:
+        c->all_dirty_seq = c->write_seq; return;      // static per-mesh data whose blocks' extents the kernel does not know: every draw is recomputed once
+    case AWSM_BUF_TRANSFORMS: case AWSM_BUF_INSTANCES: case AWSM_BUF_GEOM_META: case AWSM_BUF_VIS_GEOM_DATA: case AWSM_BUF_MORPH_WEIGHTS:
+    case AWSM_BUF_SKIN_MATRICES: case AWSM_BUF_MATERIAL_META: break;
+    default: return;                                  // nothing the geometry pass reads (the camera is per frame by design)
+    }
+    if (!c->geometry_cache) return;
+    const uint32_t l = (uint32_t)std::min<size_t>(lo, 0xFFFFFFFFu), h = (uint32_t)std::min<size_t>(hi, 0xFFFFFFFFu);
+    if (!c->dirty_log.empty()) {
+        AwsmHipCtx::DirtyRange& last = c->dirty_log.back();
+        if (last.buf == (uint32_t)which && last.seq + 1 >= c->write_seq && l <= last.hi && last.lo <= h) {     // consecutive writes that touch: one range (the newer seq: seen by everyone who saw the older)
+            last.lo = std::min(last.lo, l); last.hi = std::max(last.hi, h); last.seq = c->write_seq; return;
+        }
+    }
+    if (c->dirty_log.size() >= 512) { c->all_dirty_seq = c->write_seq; c->dirty_log.clear(); return; }
+    c->dirty_log.push_back({(uint32_t)which, l, h, c->write_seq});
+}
+
 // Overlap mode: anything that writes scene state the opaque pass reads (every buffer but the camera, whose snapshot the
 // geometry pass takes; textures; samplers; environment; the DevScene table) is ordered after the opaque passes still in
 // flight on the shade stream.  A frame therefore always shades the scene as it was when it was submitted.
@@ -424,7 +469,7 @@ void fill_frame(AwsmHipCtx* c, FrameDev* f) {
     f->clip = (float4*)FB(c).clip.ptr; f->nrm = (float4*)FB(c).nrm.ptr; f->tan = (float4*)FB(c).tan.ptr;
     f->tri_info = (uint32_t*)FB(c).tri_flags.ptr;
     // The lean opaque route (k_shade_lean): frames whose per-pixel key / per-triangle / per-vertex / attribute byte offsets fit 32 bits
-    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (uint64_t)c->width * c->height * (c->msaa == 4 ? 32u : 8u) < (1ull << 32) && (c->msaa == 0 || (c->msaa_edge_bits[c->slot].ptr && c->msaa_cells[c->slot].ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && (uint64_t)c->total_tris * kTriRecBytes < (1ull << 32) &&
+    const bool lean_ok = !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && (uint64_t)c->width * c->height * (c->msaa == 4 ? 32u : 8u) < (1ull << 32) && (c->msaa == 0 || (c->msaa_edge_bits[c->slot].ptr && c->msaa_cells[c->slot].ptr)) && FB(c).tri_shade.ptr && FB(c).draw_lean.ptr && c->shade_todo[c->slot].ptr && ((uint64_t)c->total_tris + (c->hud_merged ? c->hud_total_tris : 0u)) * kTriRecBytes < (1ull << 32) &&
                          c->bufs[AWSM_BUF_ATTR_DATA].size < (1ull << 32) - 64;
     f->tri_shade = lean_ok ? (uint4*)FB(c).tri_shade.ptr : nullptr;
     f->attr_data_bytes = (uint32_t)std::min<size_t>(c->bufs[AWSM_BUF_ATTR_DATA].size, 0xFFFFFFFFu);
@@ -523,10 +568,43 @@ bool resolve_stale(AwsmHipCtx* c, const FrameDev& f) {
     return memcmp(&k, &c->resolved[c->slot], sizeof k) != 0;
 }
 
-int enqueue_geometry(AwsmHipCtx* c) {
+// The geometry cache's part of the world pass's frame: which draws may keep what the slot's arrays hold (frame_params.hpp).
+void fill_geometry_cache(AwsmHipCtx* c, FrameDev* f, bool replay) {
+    FrameBufs& b = FB(c);
+    f->wcache = (float4*)b.wcache.ptr;
+    f->cache_on = 0; f->prev_draws = nullptr; f->prev_n_draws = 0; f->n_dirty = 0; f->cache_serial = b.cache_serial;
+    if (!c->geometry_cache || replay || !b.cache_valid || !b.wcache.ptr || b.cache_had_tri_shade != (f->tri_shade != nullptr) || c->all_dirty_seq > b.cache_seq) return;
+    // the ranges written since the slot's arrays were computed, merged per buffer; too many: one bounding range per buffer; still too many: no cache this frame
+    std::vector<AwsmHipCtx::DirtyRange> r;
+    for (const AwsmHipCtx::DirtyRange& d : c->dirty_log) if (d.seq > b.cache_seq) r.push_back(d);
+    std::sort(r.begin(), r.end(), [](const AwsmHipCtx::DirtyRange& x, const AwsmHipCtx::DirtyRange& y) { return x.buf != y.buf ? x.buf < y.buf : x.lo < y.lo; });
+    auto merge = [&](bool whole_buffer) {
+        std::vector<AwsmHipCtx::DirtyRange> m;
+        for (const AwsmHipCtx::DirtyRange& d : r) {
+            if (!m.empty() && m.back().buf == d.buf && (whole_buffer || d.lo <= m.back().hi)) m.back().hi = std::max(m.back().hi, d.hi);
+            else m.push_back(d);
+        }
+        r.swap(m);
+    };
+    merge(false);
+    if (r.size() > kMaxDirtyRanges) merge(true);
+    if (r.size() > kMaxDirtyRanges) return;
+    for (size_t i = 0; i < r.size(); i++) { f->dirty[i][0] = r[i].buf; f->dirty[i][1] = r[i].lo; f->dirty[i][2] = r[i].hi; }
+    f->n_dirty = (uint32_t)r.size();
+    f->prev_draws = (const DrawDev*)(b.cached_is_prev ? b.draws_prev.ptr : b.draws_dev.ptr);
+    f->prev_n_draws = b.cached_n_draws;
+    f->cache_on = f->prev_draws ? 1u : 0u;
+}
+inline uint32_t cache_stat_word(const AwsmHipCtx* c) { return 14u + ((c->frame_serial / (uint32_t)kSlots) & 1u); }
+
+// replay: the frame's geometry pass is enqueued again (a bin list that overflowed, world arrays that moved under the hud pass): the camera snapshot the first
+// enqueue took stays — pix2view / cam_pos were composed from that camera at awsm_hip_geometry_pass — and the geometry cache is not consulted.
+int enqueue_geometry(AwsmHipCtx* c, bool replay = false) {
     HostTrace ht(c->frame_serial);
     FrameDev f;
-    { const bool hd = c->hud_geometry_done; c->hud_geometry_done = false; fill_frame(c, &f); c->hud_geometry_done = hd; }      // the world pass's own view (no merged hud keys, no hud ranks)
+    { const bool hd = c->hud_geometry_done, hm = c->hud_merged; c->hud_geometry_done = false; c->hud_merged = false; fill_frame(c, &f); c->hud_geometry_done = hd; c->hud_merged = hm; }      // the world pass's own view (no merged hud keys, no hud ranks)
+    fill_geometry_cache(c, &f, replay);
+    f.cache_stat = c->stage_timers ? cache_stat_word(c) : 0u;      // AwsmFrameStats.geometry_cache_blocks: counted only when stage times are asked for too
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     int rc = sync_scene(c);
     if (rc) return rc;
@@ -537,7 +615,7 @@ int enqueue_geometry(AwsmHipCtx* c) {
     // bytes at awsm_hip_geometry_pass, the general kernels and the MSAA detector read this snapshot — a camera write between the two passes of a frame
     // cannot give its strips two cameras
     // (copied by k_deform_transform when the frame has geometry: a 512-byte hipMemcpyAsync costs the stream 18 us of gap + copy)
-    if (c->bufs[AWSM_BUF_CAMERA].ptr) {
+    if (c->bufs[AWSM_BUF_CAMERA].ptr && !replay) {
         const size_t cam_bytes = std::min<size_t>(512, c->bufs[AWSM_BUF_CAMERA].size);
         if (c->total_tris && n_tiles) { f.camera_snap = (uint32_t*)FB(c).camera.ptr; f.camera_snap_words = (uint32_t)(cam_bytes / 4); }
         else HIPCHK(c, hipMemcpyAsync(FB(c).camera.ptr, c->bufs[AWSM_BUF_CAMERA].ptr, cam_bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -561,8 +639,12 @@ int enqueue_geometry(AwsmHipCtx* c) {
     // Measurement aid (tools/knockout.sh; static camera only): from the ninth frame on leave out the raster (4), the binning launches as well (6) or
     // the whole pass (7) — the slot's buffers then keep the previous frames' keys, the opaque pass does the same work, and the frame rate
     // says what each stage's kernels take from the kernels they run beside.
+#ifdef AWSM_DEBUG_SWITCHES      // tools/build_variants.sh h_debug "-DAWSM_DEBUG_SWITCHES": not in the product library
     static const int knockout_env = getenv("AWSM_DEBUG_KNOCKOUT") ? atoi(getenv("AWSM_DEBUG_KNOCKOUT")) : 0;
     const int knockout = c->frame_serial > 8 ? knockout_env : 0;
+#else
+    const int knockout = 0;
+#endif
     if (c->total_tris && n_tiles && !(knockout & 1)) awsm_launch_transform(c->scene_dev, &f, c->n_blocks, c->stream);
     if ((rc = record(c, EV_TRANSFORM))) return rc;
     ht.mark("geometry: transform launch");
@@ -577,6 +659,19 @@ int enqueue_geometry(AwsmHipCtx* c) {
     if ((rc = record(c, EV_RASTER))) return rc;
     ht.mark("geometry: raster launch");
     HIPCHK(c, hipGetLastError());
+    {   // the slot's arrays now hold this list's world positions / N / T / per-triangle words (all of them: hits kept theirs, misses were recomputed)
+        FrameBufs& b = FB(c);
+        b.cache_valid = has_geometry && !(knockout & 1) && b.wcache.ptr != nullptr;
+        b.cached_n_draws = (uint32_t)c->draws_host.size(); b.cached_is_prev = false;
+        b.cache_had_tri_shade = f.tri_shade != nullptr;
+        b.cache_seq = c->write_seq; b.cache_serial = c->frame_serial;
+        // entries every slot has seen are of no further use
+        uint64_t oldest = ~0ull;
+        for (int sl = 0; sl < n_slots(c); sl++) oldest = std::min(oldest, c->fb[sl].cache_valid ? c->fb[sl].cache_seq : c->write_seq);
+        size_t keep = 0;
+        for (const AwsmHipCtx::DirtyRange& d : c->dirty_log) if (d.seq > oldest) c->dirty_log[keep++] = d;
+        c->dirty_log.resize(keep);
+    }
     return AWSM_OK;
 }
 
@@ -811,6 +906,12 @@ int size_pass_buffers(AwsmHipCtx* c, FrameBufs& b, size_t tri_cap, size_t draw_c
     int rc;
     const size_t nd = std::max<size_t>(draw_cap, 1), nv = std::max<size_t>(3 * tri_cap, 1), nt = std::max<size_t>(tri_cap, 1);
     if ((rc = dev_reserve(c, b.draws_dev, nd * sizeof(DrawDev)))) return rc;
+    const bool world_pass = &b >= c->fb && &b < c->fb + kSlots;
+    if (world_pass && c->geometry_cache) {      // geometry cache: the previous list beside the current one, world positions per vertex
+        if ((rc = dev_reserve(c, b.draws_prev, nd * sizeof(DrawDev)))) return rc;
+        if ((rc = dev_reserve(c, b.wcache, nv * 16))) return rc;
+    }
+    b.cache_valid = false;      // the arrays may have moved
     if ((rc = dev_reserve(c, b.draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
     if ((rc = dev_reserve(c, b.tex_slots, nd * kCoreTextures * sizeof(TexSlotDev)))) return rc;
     if ((rc = dev_reserve(c, b.draw_mat, nd * sizeof(DrawMatDev)))) return rc;
@@ -836,13 +937,8 @@ int size_pass_buffers(AwsmHipCtx* c, FrameBufs& b, size_t tri_cap, size_t draw_c
     return AWSM_OK;
 }
 
-// Per-pass device state for `draws_host` / total_tris; uploads the draw list when it changed.  A frame that fits what the slot was sized for
-// touches nothing (the common case: one comparison).  When it does not fit, EVERY frame slot of the pass is re-sized at once and with
-// headroom — a re-allocation synchronises all streams, so a camera move that un-culls a few more triangles every frame must not pay it
-// per frame and per slot (seen in round 2's driver run: frames 9, 10 and 13 of the process stalled the host for 2.1 / 1.8 / 0.9 ms, a third
-// of a 20-frame measurement).  Triangles: need + 25 % + 4096, but no more than the vertex buffer can hold when no draw is instanced
-// (then the pass can never outgrow its buffers again); draws: need + 25 % + 64.
-int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
+// Sizes the pass's device state for `draws_host` / total_tris (see reserve_pass_buffers).
+int ensure_pass_capacity(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
     int rc;
     if (total_tris > b.tri_cap || draws_host.size() > b.draw_cap || b.sized_w != c->width || b.sized_h != c->height || !b.bin_list.ptr) {
         bool instanced = false;
@@ -857,17 +953,45 @@ int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>
             if ((rc = size_pass_buffers(c, t, std::max(tri_cap, t.tri_cap), std::max(draw_cap, t.draw_cap), forward))) return rc;
         }
     }
-    // The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
-    // (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
+    return AWSM_OK;
+}
+
+int upload_draws_at(AwsmHipCtx* c, FrameBufs& b, size_t at, const std::vector<DrawDev>& list) {
+    const size_t bytes = list.size() * sizeof(DrawDev);
+    uint8_t* dst = (uint8_t*)b.draws_dev.ptr + at * sizeof(DrawDev);
+    if (bytes <= (1u << 20)) return upload_small(c, dst, list.data(), bytes);
+    HIPCHK(c, hipMemcpyAsync(dst, list.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AWSM_OK;
+}
+
+// The sorted draw list of a static or slowly moving scene repeats frame after frame: upload it only when it changed
+// (an in-stream host-to-device copy costs more GPU idle time than the transform kernel takes).
+// keep_prev (the world geometry pass): a new list goes into the other one of the slot's two list buffers, so that the list the slot's arrays were
+// computed for stays readable beside it (geometry cache: k_deform_transform compares the two draw by draw).
+int upload_draw_list(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, bool keep_prev) {
     const bool same_draws = b.draws_uploaded_valid && b.draws_uploaded_ptr == b.draws_dev.ptr && b.draws_uploaded.size() == draws_host.size() &&
                             (draws_host.empty() || memcmp(b.draws_uploaded.data(), draws_host.data(), draws_host.size() * sizeof(DrawDev)) == 0);
-    if (!draws_host.empty() && !same_draws) {
-        b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true; b.draws_version++;
-        const size_t bytes = draws_host.size() * sizeof(DrawDev);
-        if (bytes <= (1u << 20)) { if ((rc = upload_small(c, b.draws_dev.ptr, draws_host.data(), bytes))) return rc; }
-        else { HIPCHK(c, hipMemcpyAsync(b.draws_dev.ptr, draws_host.data(), bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-    }
-    return AWSM_OK;
+    if (draws_host.empty() || same_draws) return AWSM_OK;
+    if (keep_prev && b.cache_valid && !b.cached_is_prev && b.draws_prev.ptr && b.draws_prev.size == b.draws_dev.size) {
+        std::swap(b.draws_dev, b.draws_prev);
+        b.cached_is_prev = true;
+    } else if (keep_prev && !b.cached_is_prev) b.cache_valid = false;      // the cached list is about to be overwritten
+    b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true; b.draws_version++;
+    b.tail_uploaded_valid = false;
+    return upload_draws_at(c, b, 0, draws_host);
+}
+
+// Per-pass device state for `draws_host` / total_tris; uploads the draw list when it changed.  A frame that fits what the slot was sized for
+// touches nothing (the common case: one comparison).  When it does not fit, EVERY frame slot of the pass is re-sized at once and with
+// headroom — a re-allocation synchronises all streams, so a camera move that un-culls a few more triangles every frame must not pay it
+// per frame and per slot (seen in round 2's driver run: frames 9, 10 and 13 of the process stalled the host for 2.1 / 1.8 / 0.9 ms, a third
+// of a 20-frame measurement).  Triangles: need + 25 % + 4096, but no more than the vertex buffer can hold when no draw is instanced
+// (then the pass can never outgrow its buffers again); draws: need + 25 % + 64.
+int reserve_pass_buffers(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, uint32_t total_tris, bool forward) {
+    int rc = ensure_pass_capacity(c, b, draws_host, total_tris, forward);
+    if (rc) return rc;
+    return upload_draw_list(c, b, draws_host, !forward && &b >= c->fb && &b < c->fb + kSlots);
 }
 
 uint32_t mip_levels_full(uint32_t w, uint32_t h) {   // calculate_mipmap_levels (renderer-core/src/texture/mipmap.rs:60-62)
@@ -909,6 +1033,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
     for (int i = 0; i < EV_COUNT; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(AWSM_ERR_DEVICE);
     if (hipMalloc((void**)&c->scene_dev, sizeof(DevScene)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
     c->overlap = (cfg->flags & AWSM_CFG_OVERLAP_FRAMES) != 0;
+    { const char* e = getenv("AWSM_GEOMETRY_CACHE"); c->geometry_cache = !(e && e[0] == '0'); }      // "0": k_deform_transform recomputes every draw every frame (A/B measurements, tests)
     {   // k_shade_lean as a persistent grid of N workgroups per CU (it is VALU-bound from 4 waves/SIMD up): the rest of each CU's
         // wave slots, registers and LDS stays free for the next frame's geometry kernels on the other stream
         const char* e = getenv("AWSM_LEAN_WGS_PER_CU");
@@ -916,7 +1041,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         c->lean_grid = per_cu > 0 ? (uint32_t)(per_cu * prop.multiProcessorCount) & ~7u : 0u;
     }
     for (int s = 0; s < n_slots(c); s++) {
-        if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13]
+        if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->fb[s].counters.ptr, 0, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13] + the geometry cache's hit counts [14], [15] (alternating frames of the slot)
         c->fb[s].counters.size = 16 * sizeof(uint32_t);
         if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
         c->tr[s].counters.size = 16 * sizeof(uint32_t);
@@ -930,11 +1055,13 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
 
     if (c->overlap) {
         for (int s = 0; s < kSlots; s++) {
+#ifdef AWSM_DEBUG_SWITCHES
             if (const char* m = getenv("AWSM_SHADE_CU_MASK")) {      // experiment (tools/ab_cu_mask.sh): hex words, least significant first, comma separated
                 std::vector<uint32_t> words;
                 for (const char* p = m; *p; ) { char* end = nullptr; words.push_back((uint32_t)strtoul(p, &end, 16)); p = (*end == ',') ? end + 1 : end; if (end == p && *p) break; }
                 if (words.empty() || hipExtStreamCreateWithCUMask(&c->shade_streams[s], (uint32_t)words.size(), words.data()) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             } else
+#endif
             if (hipStreamCreateWithFlags(&c->shade_streams[s], hipStreamNonBlocking) != hipSuccess) return bail(AWSM_ERR_DEVICE);
             // These events order streams of this device among themselves.  Recorded with the default (system-scope) release they write the
             // L2s back and invalidate them each time — behind a raster or shading kernel that is 66 MB of dirty lines: 8-28 us per record on
@@ -991,7 +1118,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (int k = 0; k < 4 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : (k < 3 * kSlots ? c->hud[k - 2 * kSlots] : c->htr[k - 3 * kSlots]));
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
-        fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
+        fr(b.wcache); fr(b.draws_prev); fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     for (hipStream_t st : c->shade_streams) if (st) (void)hipStreamDestroy(st);
     for (int i = 0; i < kSlots; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); }
@@ -1023,6 +1150,7 @@ int awsm_hip_buffer_create(AwsmHipCtx* c, AwsmBuf which, size_t bytes) {
     HIPCHK(c, hipSetDevice(c->device));
     { int rcb = scene_write_barrier(c); if (rcb) return rcb; }
     // +16 bytes of slack so 16-byte vector loads of the last record never leave the allocation (size = the logical size)
+    log_dirty(c, which, 0, ~size_t(0));
     if (bytes && c->bufs[which].ptr && c->bufs[which].size == bytes) {     // unchanged size: same allocation, cleared ("contents are NOT preserved")
         if (which == AWSM_BUF_CAMERA) memset(c->camera_host, 0, sizeof c->camera_host);
         HIPCHK(c, hipMemsetAsync(c->bufs[which].ptr, 0, bytes + 16, c->stream));
@@ -1045,7 +1173,7 @@ int awsm_hip_buffer_write(AwsmHipCtx* c, AwsmBuf which, size_t dst_off, const vo
     if (dst_off > b.size || len > b.size - dst_off) return fail(c, AWSM_ERR_OUT_OF_RANGE, "buffer_write: [%zu,+%zu) outside buffer %d of %zu bytes", dst_off, len, (int)which, b.size);
     if (len == 0) return AWSM_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    if (which != AWSM_BUF_CAMERA) { int rcb = scene_write_barrier(c); if (rcb) return rcb; }   // the opaque pass reads a per-frame camera snapshot
+    if (which != AWSM_BUF_CAMERA) { int rcb = scene_write_barrier(c); if (rcb) return rcb; log_dirty(c, which, dst_off, dst_off + len); }   // the opaque pass reads a per-frame camera snapshot
     else { if (dst_off < 512) memcpy(c->camera_host + dst_off, src, std::min<size_t>(len, 512 - dst_off)); c->camera_written_since_snapshot = true; }
     uint8_t* dst = (uint8_t*)b.ptr + dst_off;
     if (len <= (1u << 20)) return upload_small(c, dst, src, len);
@@ -1419,11 +1547,29 @@ int awsm_hip_hud_geometry_pass(AwsmHipCtx* c, const AwsmDraw* draws, uint32_t n)
         if (c->hud_combined.size() >= (1u << 24)) return fail(c, AWSM_ERR_UNSUPPORTED, "hud_geometry_pass: more than 2^24 draws in the frame");
         FrameBufs& wb = FB(c);
         const void* before[3] = {wb.clip.ptr, wb.tri_rec.ptr, wb.tri_flags.ptr};
-        if ((rc = reserve_pass_buffers(c, wb, c->hud_combined, c->total_tris + c->hud_total_tris, false))) return rc;      // room for the hud draws behind the world's; uploads the combined list
+        if ((rc = ensure_pass_capacity(c, wb, c->hud_combined, c->total_tris + c->hud_total_tris, false))) return rc;      // room for the hud draws behind the world's
+        // The world's list stays cached as the world pass uploaded it (re-uploaded only if the list buffer just moved); the hud draws go behind it with a
+        // cache of their own — a static scene with a hud mesh uploads nothing per frame and keeps its per-draw records (the combined list used to
+        // replace the world list's cache, so both were uploaded every frame and k_resolve_draws never rested).
+        if ((rc = upload_draw_list(c, wb, c->draws_host, true))) return rc;
+        {
+            const size_t at = c->draws_host.size();
+            const std::vector<DrawDev> tail(c->hud_combined.begin() + (long)at, c->hud_combined.end());
+            const bool same = wb.tail_uploaded_valid && wb.tail_uploaded_ptr == wb.draws_dev.ptr && wb.tail_uploaded_at == at && wb.tail_uploaded.size() == tail.size() &&
+                              memcmp(wb.tail_uploaded.data(), tail.data(), tail.size() * sizeof(DrawDev)) == 0;
+            if (!same) {
+                if ((rc = upload_draws_at(c, wb, at, tail))) return rc;
+                wb.tail_uploaded = tail; wb.tail_uploaded_ptr = wb.draws_dev.ptr; wb.tail_uploaded_at = at; wb.tail_uploaded_valid = true; wb.draws_version++;
+                // The upload sits on the caller's stream BEHIND the world geometry pass, after ev_uploads[slot] was recorded: a per-draw resolve that went
+                // ahead on that event would read hud entries that are not there yet (out-of-bounds meta offsets on a slot's first frame, the
+                // list of two frames ago afterwards).  The resolve of this frame takes the late order, behind the geometry pass's hand-off.
+                c->uploads_recorded[c->slot] = false;
+            }
+        }
         if ((rc = dev_reserve(c, c->merged_vis[c->slot], px * 8 * spp))) return rc;
         if (before[0] != wb.clip.ptr || before[1] != wb.tri_rec.ptr || before[2] != wb.tri_flags.ptr) {
             // the world pass's arrays moved (first frame with this much hud geometry): its results went with them — run it again into the new ones
-            if ((rc = enqueue_geometry(c))) return rc;
+            if ((rc = enqueue_geometry(c, true))) return rc;
         }
         c->hud_merged = true;
     }
@@ -1572,8 +1718,9 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 3, 0, sizeof(uint32_t), c->stream));
             awsm_launch_count_covered(&f, c->stream);
         }
-        HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cache_blocks_last = c->counters_host[cache_stat_word(c)];
         if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
         { int rch = handoff_check(c); if (rch) return rch; }      // a gate ended unopened: the frame it guarded was dropped
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));
@@ -1594,7 +1741,7 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         if (geom_over) {
             if ((rc = ensure_bin_capacity(c, c->counters_host[1] + c->counters_host[1] / 4 + 1024))) return rc;
             if ((rc = reserve_raster_items(c, FB(c), false))) return rc;
-            if ((rc = enqueue_geometry(c))) return rc;
+            if ((rc = enqueue_geometry(c, true))) return rc;
         }
         if (hud_geo_over || (geom_over && c->hud_geometry_done && c->hud_merged)) {      // (merged keys: a new world pass needs a new merge)
             FrameBufs& hb = c->hud[c->slot];
@@ -1643,6 +1790,8 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
         out->bin_overflow_retries = c->overflow_retries;
         out->frames_with_dropped_bin_entries = c->dropped_frames;
         out->handoff_gate_timeouts = c->handoff_dropped_frames;
+        out->geometry_cache_blocks = (c->geometry_done && c->stage_timers) ? c->cache_blocks_last : 0u;
+        out->geometry_blocks = c->geometry_done ? c->n_blocks : 0u;
         if (c->opaque_done && c->shade_todo[c->slot].ptr && c->last_opaque.has_opaque && !(c->flags & AWSM_CFG_GENERAL_SHADE_ONLY) && !c->draws_host.empty())
             HIPCHK(c, hipMemcpy(&out->shade_general_wavefronts, c->shade_todo[c->slot].ptr, 4, hipMemcpyDeviceToHost));
         out->struct_size = (uint32_t)std::min<size_t>(caller_size, sizeof(AwsmFrameStats));

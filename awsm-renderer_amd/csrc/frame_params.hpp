@@ -137,6 +137,7 @@ struct DevScene {
 
 struct TriRec;                                   // raster_setup.hpp (device side); 80 bytes
 constexpr size_t kTriRecBytes = 80;
+constexpr uint32_t kMaxDirtyRanges = 12;
 
 struct FrameDev {
     uint32_t width, height;
@@ -177,6 +178,19 @@ struct FrameDev {
     float4* nrm;                  // total_verts  (world normal xyz, 0)
     float4* tan;                  // total_verts  (world tangent xyz, handedness)
     float4* wpos;                 // total_verts  (world position xyz, 1): transparent pass only, else null
+    // Geometry cache (round 5): what of a draw's per-vertex / per-triangle outputs the camera does not touch — world position (wcache), world N / T (nrm, tan),
+    // tri_shade, tri_info — stays valid in the frame slot's arrays from one frame of the slot to the next as long as the draw sits at the same place of the
+    // draw list (same DrawDev, index and first_tri included: prev_draws is the list those arrays were computed for) and none of its inputs was written since
+    // (dirty: the byte ranges awsm_hip_buffer_write / buffer_create received since that frame, by buffer).  Such a draw's blocks only form
+    // clip = view_proj * wcache — the same operation on the same f32 values as the full path, so the same bits.  cache_on = 0: every block takes the full path.
+    float4* wcache;               // total_verts  (world position as apply_vertex.wgsl forms it, model * (pos, 1)); geometry pass only, may be null
+    const DrawDev* prev_draws;    // the draw list the slot's arrays were last computed for (== draws when the list did not change)
+    uint32_t prev_n_draws;
+    uint32_t cache_on;
+    uint32_t cache_serial;        // frame serial of that computation: if its frame was dropped by a timed-out gate (poison) the arrays are older than prev_draws says
+    uint32_t cache_stat;          // 0, or the word of `counters` (14 / 15, alternating between a slot's frames) that counts the workgroups taking the cached path; the kernel zeroes the other one
+    uint32_t n_dirty;             // ranges in dirty[] (<= kMaxDirtyRanges; more than that and the host turns the cache off for the frame)
+    uint32_t dirty[12][3];        // {AwsmBuf, first byte, one past the last byte (saturating)}
     TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)
     uint32_t* tri_info;           // total_tris   (draw index in bits 0..23, AWSM_DRAW_* flags of the owning draw in bits 24..30, bit 31: ALPHA_MODE_MASK draw — transparent pass)
     uint4* tri_shade;             // 2 x total_tris (geometry pass only, may be null: {info word, 0, TEXCOORD_0 of corner 0} {TEXCOORD_0 of corner 1, of corner 2}: what

@@ -31,6 +31,30 @@ struct GeomMetaDev {
     uint32_t transform_off, material_meta_off;
 };
 
+// Geometry cache: is draw `d` — at the same place of the list as `p`, the draw the slot's arrays were last computed for — also unchanged in everything
+// k_deform_transform reads for it except the camera?  Wave-uniform (one draw per workgroup): scalar loads and branches.  Conservative where a block's extent
+// is not known here (a skin's joint count, a morph's value block): any write at or behind the block's first byte counts.  Buffers whose every write
+// invalidates every draw (attribute data / indices, morph values, skin index-weights) are the host's business: it turns the cache off for the frame.
+AWSM_DI bool draw_unchanged(const DevScene* __restrict__ sc, const FrameDev& f, const DrawDev& d, const DrawDev& p, const uint32_t* __restrict__ gmp) {
+    if (d.geom_meta_off != p.geom_meta_off || d.vis_data_off != p.vis_data_off || d.tri_count != p.tri_count || d.flags != p.flags || d.first_tri != p.first_tri ||
+        d.first_block != p.first_block || d.inst_off != p.inst_off) return false;
+    if (f.poison != nullptr && *(const __attribute__((address_space(4))) uint32_t*)f.poison == f.cache_serial) return false;   // that frame never ran
+    if (f.n_dirty == 0u) return true;
+    auto hit = [&](uint32_t buf, uint32_t lo, uint32_t hi) {      // does a dirty range of `buf` overlap [lo, hi)?
+        for (uint32_t i = 0; i < f.n_dirty; i++) if (f.dirty[i][0] == buf && f.dirty[i][1] < hi && lo < f.dirty[i][2]) return true;
+        return false;
+    };
+    if (hit(AWSM_BUF_GEOM_META, d.geom_meta_off, d.geom_meta_off + 40u)) return false;
+    if (hit(AWSM_BUF_VIS_GEOM_DATA, d.vis_data_off, (uint32_t)min((unsigned long long)d.vis_data_off + 168ull * d.tri_count, 0xFFFFFFFFull))) return false;
+    if ((d.flags & kDrawInstanced) && hit(AWSM_BUF_INSTANCES, d.inst_off, d.inst_off + 64u)) return false;
+    const uint32_t toff = (gmp[8] / 64u) * 64u, mmoff = (gmp[9] / 256u) * 256u;
+    if (hit(AWSM_BUF_TRANSFORMS, toff, toff + 64u)) return false;
+    if (hit(AWSM_BUF_MATERIAL_META, mmoff, mmoff + 68u)) return false;
+    if (gmp[2] != 0u && hit(AWSM_BUF_MORPH_WEIGHTS, gmp[3], gmp[3] + 4u + 4u * gmp[2])) return false;
+    if (gmp[5] != 0u && hit(AWSM_BUF_SKIN_MATRICES, gmp[6], 0xFFFFFFFFu)) return false;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_deform_transform: one thread per exploded vertex, 256 vertices per workgroup.  The 56-byte vertex
 // records of a workgroup are one contiguous 14 KB run: staged through LDS with 16-byte coalesced loads.
@@ -58,6 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : A
         // counters start empty — here and not in k_resolve_draws, which is skipped when nothing but the camera changed
         if (!FWD && f.shade_todo && g0 == 14u) f.shade_todo[0] = 0u;
         if (!FWD && f.lean_next && g0 >= 64u && g0 < 128u) f.lean_next[(g0 - 64u) * 16u] = 0u;
+        if (!FWD && f.cache_stat && g0 == 15u) f.counters[29u - f.cache_stat] = 0u;      // the slot's next frame counts its cache hits there
         if (!FWD && g0 < f.camera_snap_words) f.camera_snap[g0] = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_CAMERA])[g0];   // overlap mode: the frame's camera
     }
     uint32_t lo = 0, hi = f.n_draws;
@@ -71,6 +96,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : A
     const uint32_t count = min(256u, nverts - local0);
 
     const uint32_t* gmp = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_GEOM_META] + d.geom_meta_off);
+    if (!FWD && f.cache_on && lo < f.prev_n_draws && draw_unchanged(sc, f, d, f.prev_draws[lo], gmp)) {
+        // Geometry cache hit (frame_params.hpp): the draw's world positions, normals, tangents and per-triangle words in this slot's arrays are still what the
+        // full path below would write — only the camera moved.  clip = view_proj * world, the full path's own last step on the same f32 values.
+        if (f.cache_stat && tid == 0u) atomicAdd(&f.counters[f.cache_stat], 1u);
+        if (tid < count) {
+            const size_t gv = (size_t)3u * d.first_tri + local0 + tid;
+            const float4 w = f.wcache[gv];
+            const m4 view_proj = load_m4(reinterpret_cast<const float*>(sc->buf[AWSM_BUF_CAMERA] + 128));
+            const f4 clip = mul(view_proj, {w.x, w.y, w.z, w.w});
+            f.clip[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+        }
+        return;
+    }
     GeomMetaDev gm;
     gm.morph_len = gmp[2]; gm.morph_weights_off = gmp[3]; gm.morph_values_off = gmp[4];
     gm.skin_sets = gmp[5]; gm.skin_matrices_off = gmp[6]; gm.skin_index_weights_off = gmp[7];
@@ -189,6 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : A
     const uint32_t lv = local0 + tid;
     const size_t gv = (size_t)3u * d.first_tri + lv;
     f.clip[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    if (!FWD && f.wcache) f.wcache[gv] = make_float4(world_pos.x, world_pos.y, world_pos.z, world_pos.w);
     f.nrm[gv] = make_float4(world_normal.x, world_normal.y, world_normal.z, 0.0f);
     f.tan[gv] = make_float4(tangent_ortho.x, tangent_ortho.y, tangent_ortho.z, tangent.w);
     if (FWD) f.wpos[gv] = make_float4(world_pos.x, world_pos.y, world_pos.z, 1.0f);

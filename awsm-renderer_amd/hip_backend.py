@@ -63,7 +63,7 @@ class AwsmFrameStats(C.Structure):
                 ("triangles_in", C.c_uint32), ("triangles_binned", C.c_uint32), ("bin_entries", C.c_uint32), ("covered_pixels", C.c_uint32),
                 ("bin_overflow_retries", C.c_uint32), ("ms_forward", C.c_float), ("forward_triangles", C.c_uint32), ("forward_fragment_slots", C.c_uint32),
                 ("ms_shade_lean", C.c_float), ("shade_general_wavefronts", C.c_uint32), ("frames_with_dropped_bin_entries", C.c_uint32),
-                ("handoff_gate_timeouts", C.c_uint32)]
+                ("handoff_gate_timeouts", C.c_uint32), ("geometry_cache_blocks", C.c_uint32), ("geometry_blocks", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "struct_size")}

@@ -28,6 +28,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_LINK_GBS_PER_DIRECTION = 76.5     # same guide: 7 links x ~153 GB/s bidirectional per GPU, point to point (one link per peer on an 8-GPU node)
+
+
+def collective_model(world, bytes_per_rank, to_root):
+    """What the frame's exchange step should take by link rates alone, so that the first run on more than one GPU can be read against a
+    prediction.  xGMI is point to point: every pair of GPUs has its own link.  all-gather: every rank sends its bands to each of the N-1 peers over that
+    peer's link and receives theirs the same way — N-1 links busy in both directions at once, each carrying bytes_per_rank per direction.  gather to rank 0:
+    the root's N-1 links each carry one rank's bands inwards.  Either way the step is bytes_per_rank / (one link, one direction), independent of N —
+    but bytes_per_rank = frame / N, so the step shrinks as 1 / N while at N = 2 it is half a frame over ONE link: 33 MB / 76.5 GB/s = 0.43 ms against a
+    0.31 ms single-GPU frame.  The curve is predicted to DIP at N = 2 (link-bound below the 1-GPU rate) and to become compute-bound from N = 4 on."""
+    ms = bytes_per_rank / (XGMI_LINK_GBS_PER_DIRECTION * 1e9) * 1e3
+    return {"model_ms": ms, "link_GBps_per_direction": XGMI_LINK_GBS_PER_DIRECTION, "links_used_per_rank": world - 1 if not to_root else 1,
+            "frames_per_s_if_link_bound": 1e3 / ms if ms > 0 else None,
+            "note": "point-to-point xGMI, one link per peer: the exchange takes bytes_per_rank / link rate whatever N is; the gather of frame i is overlapped with "
+                    "the render of frame i + 1, so the frame period is max(render, model_ms) at best; N = 2 is predicted link-bound below the 1-GPU rate"}
 
 
 def algorithmic_bytes(scene, stats, rows):
@@ -50,7 +65,9 @@ def algorithmic_bytes(scene, stats, rows):
     u_tex_low = min(tex_bytes, P_cov * n_tex * 4.0) * (150.0 / 333.0 if tex_bytes > 3.0e8 else 0.45)
     shade_fixed = P * 16.0 + P_cov * (12.0 + 3.0 * stride) + min(T_bin, P_cov) * 144.0
     return {
-        "k_deform_transform": V * 56.0 + V * 48.0 + T_in,
+        # geometry cache (round 5): a workgroup that keeps its draw's cached outputs reads the world position and writes clip (32 B / vertex); the others
+        # read the 56-byte record and write clip, world position, N, T (+ the per-triangle words)
+        "k_deform_transform": V * ((1.0 - stats.get("geometry_cache_frac", 0.0)) * (56.0 + 64.0) + stats.get("geometry_cache_frac", 0.0) * 32.0) + T_in * (1.0 - stats.get("geometry_cache_frac", 0.0)),
         "k_bin": 2.0 * (T_in * 49.0) + E * 4.0 * 2.0,
         "k_raster_tile": E * (4.0 + 48.0) + P * 8.0,
         "k_shade": shade_fixed + u_tex_high,
@@ -113,22 +130,47 @@ def pmc_mix(doc, kernel):
     return None
 
 
-def cpu_baseline(scene, lut_rg, rows_sample):
-    """Oracle (oracle/c/*.c, scalar f32, -O2) on a bounded strip of the same frame, all host cores (row bands)."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(scene, lut_rg, rows_sample, rows_one_thread):
+    """Oracle (oracle/c/*.c, scalar f32, -O2) on a bounded strip of the same frame: all host threads (row bands) on `rows_sample`, and ONE thread on the
+    smaller `rows_one_thread` (both figures, with the CPU model).  The vertex stage runs over the whole scene once (it is the
+    same work for any strip; its time is counted in both figures in full, as a whole frame would pay it)."""
     from oracle import oracle_lib
     from tests import helpers
-    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        threads = os.cpu_count() or 1
     model = helpers.build_model(scene)
-    fr = oracle_lib.frame_from_model(model, lut_rg, rows=rows_sample)
-    t0 = time.perf_counter()
-    fr.transform()
-    fr.raster(threads)
-    fr.shade(threads)
-    dt = time.perf_counter() - t0
-    frac = (rows_sample[1] - rows_sample[0]) / scene.height
-    return {"value": frac / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"rows [{rows_sample[0]},{rows_sample[1]}) of the {scene.width}x{scene.height} frame ({frac:.4f} frame, all vertices "
-                      f"transformed), {dt:.1f} s wall, scaled to whole frames"}
+
+    def timed(rows, n_threads):
+        fr = oracle_lib.frame_from_model(model, lut_rg, rows=rows)
+        t0 = time.perf_counter()
+        fr.transform()
+        t1 = time.perf_counter()
+        fr.raster(n_threads)
+        fr.shade(n_threads)
+        t2 = time.perf_counter()
+        frac = (rows[1] - rows[0]) / scene.height
+        # a whole frame = the vertex stage once + the per-row work scaled up
+        return 1.0 / ((t1 - t0) + (t2 - t1) / frac), frac, t2 - t0
+
+    all_v, all_frac, all_dt = timed(rows_sample, threads)
+    one_v, one_frac, one_dt = timed(rows_one_thread, 1)
+    return {"value": all_v, "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model_string(),
+            "one_thread": {"value": one_v, "unit": "frames/s", "cores": 1,
+                           "sample": f"rows [{rows_one_thread[0]},{rows_one_thread[1]}) ({one_frac:.4f} frame), {one_dt:.1f} s wall"},
+            "sample": f"rows [{rows_sample[0]},{rows_sample[1]}) of the {scene.width}x{scene.height} frame ({all_frac:.4f} frame; all vertices transformed once, "
+                      f"that time counted in full), {all_dt:.1f} s wall on {threads} threads, scaled to whole frames; one_thread: the same on a narrower strip"}
 
 
 def hip_backend_path():
@@ -449,6 +491,19 @@ def main():
     first = r.render(sync=True)            # uploads everything, sizes the bin list
     first_frame_ms = (time.perf_counter() - t_first) * 1e3
     first_frame_upload = int(r.host.upload_bytes_last_frame())
+    # ---- per-kernel launch durations: hipEvents recorded by the library on the kernels' own stream ----
+    # The synchronised profile frames (the scene's own camera: the frame the committed PMC passes profiled) run BEFORE the warm-up and the timed loop since
+    # round 5 (they used to follow it): the script does this work anyway, and done first it also brings the part out of the idle clock state the seconds of
+    # CPU-side scene set-up leave it in — the driver's 20-step run used to be measured on a part still ramping up.  `steps` and
+    # `warmup` are exactly what was passed; "frames_before_timed_loop" in the JSON line says what ran before them.
+    r.host.set_render_timings(True)
+    acc = {}
+    for _ in range(max(1, args.profile_frames)):
+        r.host.camera_update(scene.view, scene.proj, scene.camera_position)
+        st = r.host.render(sync=True)
+        for k, v in st.items():
+            acc[k] = acc.get(k, 0.0) + float(v)
+    st = {k: v / max(1, args.profile_frames) for k, v in acc.items()}
     r.host.set_render_timings(bool(os.environ.get("AWSM_BENCH_STAGE_TIMERS")))   # the timed loop does not read per-stage times: no event bubbles between the kernels
     # No Python garbage collection inside the warm-up and the timed loop: a generation-2 pass over the scene's objects takes ~35 ms, and
     # whether one lands in a 25-70 ms loop depends on the allocation count of everything before it (seen: configs[1] at 3,100 or 8,300
@@ -564,21 +619,14 @@ def main():
         if check != "ok":
             raise SystemExit(f"rank {rank}: gathered image differs from the unsharded frame")
 
-    # ---- per-kernel launch durations: hipEvents recorded by the library on the kernels' own stream ----
-    r.host.set_render_timings(True)
-    acc = {}
-    for _ in range(max(1, args.profile_frames)):       # the scene's own camera: the frame the committed PMC passes profiled
-        r.host.camera_update(scene.view, scene.proj, scene.camera_position)
-        st = r.host.render(sync=True)
-        for k, v in st.items():
-            acc[k] = acc.get(k, 0.0) + float(v)
-    st = {k: v / max(1, args.profile_frames) for k, v in acc.items()}
     lean = st.get("ms_shade_lean", 0.0) > 0.0
     kernel_ms = {"k_deform_transform": st["ms_transform"], "k_bin": st["ms_bin"], "k_raster_tile": st["ms_raster"], "k_shade": st["ms_shade_lean"] if lean else st["ms_shade"]}
     if st.get("frames_with_dropped_bin_entries", 0) or st.get("bin_overflow_retries", 0):
         raise SystemExit(f"rank {rank}: the timed loop lost geometry or had to replay frames: {st['frames_with_dropped_bin_entries']} dropped, {st['bin_overflow_retries']} replayed")
     rows_mine = H if world == 1 else (y1s - y0s if strips else len(band_rows(H, world, rank)))
-    alg = algorithmic_bytes(scene, {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}, rows_mine)
+    stats_i = {k: int(round(v)) for k, v in st.items() if not k.startswith("ms_")}
+    stats_i["geometry_cache_frac"] = (st.get("geometry_cache_blocks", 0.0) / st["geometry_blocks"]) if st.get("geometry_blocks") else 0.0
+    alg = algorithmic_bytes(scene, stats_i, rows_mine)
     dom = max(kernel_ms, key=kernel_ms.get)
     alg_low = alg.pop("k_shade_low")
     sec = kernel_ms[dom] * 1e-3
@@ -614,7 +662,7 @@ def main():
         lut_rg = oracle_lib.brdf_lut(64, 64)
         mid = H // 2
         half = max(8, H // 8)
-        cpu = cpu_baseline(scene, lut_rg, (max(0, mid - half), min(H, mid + half)))
+        cpu = cpu_baseline(scene, lut_rg, (max(0, mid - half), min(H, mid + half)), (mid - max(4, H // 270), mid + max(4, H // 270)))
 
     per_rank = None
     if world > 1:
@@ -636,6 +684,7 @@ def main():
         out = {
             "metric": "frames/sec + shaded Mpix/s, 4K Sponza glTF, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "frames_before_timed_loop": 1 + max(1, args.profile_frames),      # the first frame (uploads everything) + the synchronised per-kernel profile frames; then `warmup`, then `steps`
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (procedural scene generated in-repo; no glTF asset is available offline)",
             "shaded_mpix_per_s": W * H * fps / 1e6,
@@ -651,7 +700,7 @@ def main():
                        "opaque_route": "lean (k_shade_lean + k_shade_todo)" if lean else "general (k_shade)",
                        "library": os.path.relpath(hip_backend_path(), ROOT)},
             "frame_stats": {k: st[k] for k in ("triangles_in", "triangles_binned", "bin_entries", "covered_pixels", "shade_general_wavefronts",
-                                                "frames_with_dropped_bin_entries", "bin_overflow_retries")},
+                                                "frames_with_dropped_bin_entries", "bin_overflow_retries", "geometry_cache_blocks", "geometry_blocks")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             # what crosses the boundary as host buffers: `value` is measured with the scene resident; a frame's own uploads are inside it
@@ -660,7 +709,7 @@ def main():
                                "steady_state_bytes_per_frame": int(r.host.upload_bytes_last_frame())},
             **({"collective": {"backend": "rccl" if backend == "nccl" else backend + " (rehearsal: every rank on GPU 0, staged through the host)",
                                "op": "gather to rank 0" if to_root else "all_gather_into_tensor", "bytes_per_rank": rows_out * W * 8,
-                               "alone_ms": max(p["gather_alone_ms"] for p in per_rank), "launcher": "bench.py (child processes)" if os.environ.get("AWSM_BENCH_SELF_LAUNCHED") else "external (WORLD_SIZE was set)"},
+                               "alone_ms": max(p["gather_alone_ms"] for p in per_rank), **collective_model(world, rows_out * W * 8, to_root), "launcher": "bench.py (child processes)" if os.environ.get("AWSM_BENCH_SELF_LAUNCHED") else "external (WORLD_SIZE was set)"},
                 "per_rank": per_rank} if per_rank else {}),
             **({"check": check} if check else {}),
             **({"frame_trace": frame_trace} if frame_trace else {}),

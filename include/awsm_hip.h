@@ -168,6 +168,11 @@ typedef struct AwsmFrameStats {
     uint32_t handoff_gate_timeouts;  /* AWSM_CFG_OVERLAP_FRAMES with device-side hand-off: gates that ran out of time since the context was created.  Each one
                                          dropped the frame it guarded whole (its kernels exit at once: the image is not written, nothing is shaded from
                                          half-written buffers) and was reported once with AWSM_ERR_DEVICE. */
+    uint32_t geometry_cache_blocks;  /* k_deform_transform workgroups (256 exploded vertices of one draw each) of this frame's geometry pass that kept the frame
+                                         slot's cached world positions / normals / tangents / per-triangle words and only formed clip = view_proj * world,
+                                         because their draw sits where it sat in the slot's previous frame and nothing it reads but the camera was written
+                                         since (awsm_hip_buffer_write / buffer_create ranges).  Counted only while stage timers are on. */
+    uint32_t geometry_blocks;        /* ... out of this many */
 } AwsmFrameStats;
 
 /* ---- lifecycle: AwsmRendererBuilder::build() / Drop (crates/renderer/src/meshes.rs:1349-1357) ---- */

@@ -149,6 +149,9 @@ def test_bench_starts_its_own_ranks_and_never_touches_the_gpu_itself(tmp_path):
     """`python bench.py --gpus 2` as the driver types it (no launcher, WORLD_SIZE unset): the process must become a launcher — two children with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — without importing torch (a process that has initialised the GPU must not start or become
     another program on this pool).  Without a GPU each rank refuses to run (no CPU fallback) and the launcher hands the failure on."""
+    import torch
+    if torch.cuda.device_count() > 0:      # (counting devices does not initialise the GPU; asked BEFORE anything is started: ADVICE r4)
+        pytest.skip("a GPU is visible: the N > 1 path itself is what test_gpu_parity.py's rehearsal runs")
     probe = tmp_path / "sitecustomize.py"
     probe.write_text(
         "import os, sys, atexit\n"
@@ -161,9 +164,6 @@ def test_bench_starts_its_own_ranks_and_never_touches_the_gpu_itself(tmp_path):
     env.update(PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""), AWSM_PROBE_OUT=str(tmp_path / "probe"), AWSM_BENCH_RANK_GRACE_S="30")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is visible: the N > 1 path itself is what test_gpu_parity.py's rehearsal runs")
     assert p.returncode != 0
     assert p.stderr.count("needs an MI355X") == 2, p.stderr[-3000:]
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

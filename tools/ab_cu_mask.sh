@@ -1,4 +1,5 @@
 #!/bin/bash
+# (AWSM_SHADE_CU_MASK is read only by a debug build: tools/build_variants.sh h_debug "-DAWSM_DEBUG_SWITCHES" first)
 # Do the two streams of the overlapped frame run better on partly disjoint CUs?  (Round 4: the frame follows resource use, and the geometry
 # kernels — latency-bound, low issue rate — take wave slots from the lean kernel on every CU.)  hipExtStreamCreateWithCUMask on the caller's stream
 # (AWSM_BENCH_STREAM_CU_MASK: the geometry passes) and / or on the library's shade streams (AWSM_SHADE_CU_MASK).
@@ -20,7 +21,7 @@ run() {  # label, geometry mask, shade mask, extra args
   local g=$2 s=$3
   for rep in 1; do
     echo -n "$1 $4: "
-    env ${g:+AWSM_BENCH_STREAM_CU_MASK=$g} ${s:+AWSM_SHADE_CU_MASK=$s} timeout -k 10 200 python3 bench.py --gpus 1 --no-cpu-baseline --steps 200 --warmup 20 $4 2>/dev/null | fps || exit 1
+    env ${g:+AWSM_BENCH_STREAM_CU_MASK=$g} ${s:+AWSM_SHADE_CU_MASK=$s} AWSM_HIP_LIB=build/variants/lib_h_debug.so timeout -k 10 200 python3 bench.py --gpus 1 --no-cpu-baseline --allow-variant-lib --steps 200 --warmup 20 $4 2>/dev/null | fps || exit 1
   done
 }
 H=$F,$F,$F,$F                      # bits 0..127

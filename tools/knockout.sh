@@ -1,7 +1,9 @@
 #!/bin/bash
 # What does each stage of the geometry pass take from the opaque pass it runs beside?  AWSM_DEBUG_KNOCKOUT (awsm_hip.cpp, enqueue_geometry) leaves out
 # the raster (4), binning + raster (6) or the whole geometry pass (7) from the ninth frame on; with a static camera the slot's buffers keep the
-# same keys, so the opaque pass does identical work.  Usage: tools/knockout.sh <outdir>
+# same keys, so the opaque pass does identical work.  The switch is compiled only into a debug build of the library:
+#   tools/build_variants.sh h_debug "-DAWSM_DEBUG_SWITCHES"      (here, before gpurun)
+# Usage: tools/knockout.sh <outdir>
 OUT=${1:-gpurun_out/knockout}
 mkdir -p $OUT
 fps() { python3 -c "
@@ -11,7 +13,7 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'
 for mode in "" "--msaa 4 --mipmap"; do
   for ko in 0 4 6 7 0; do
     echo -n "knockout $ko $mode: "
-    AWSM_DEBUG_KNOCKOUT=$ko timeout -k 10 200 python3 bench.py --gpus 1 --no-cpu-baseline --static-camera --steps 200 --warmup 20 $mode 2>/dev/null | fps || exit 1
+    AWSM_DEBUG_KNOCKOUT=$ko AWSM_HIP_LIB=build/variants/lib_h_debug.so timeout -k 10 200 python3 bench.py --gpus 1 --no-cpu-baseline --allow-variant-lib --static-camera --steps 200 --warmup 20 $mode 2>/dev/null | fps || exit 1
   done
 done
 } > $OUT/fps.txt 2>&1
