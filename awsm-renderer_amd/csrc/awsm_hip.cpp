@@ -95,6 +95,9 @@ struct FrameBufs {
     // Geometry cache (frame_params.hpp; the world geometry pass only): the draw list this slot's wcache / nrm / tan / tri_shade / tri_info were last
     // computed for lives on in draws_prev when a new list arrives (the two buffers swap), so that k_deform_transform can compare draw by draw.
     DevBuf wcache, draws_prev;
+    DevBuf block_map;                      // world geometry pass: draw index of every k_deform_transform workgroup (uploaded with the draw list; spares each workgroup a binary search over the list = log2(n) dependent loads in front of everything else)
+    bool block_map_valid = false;
+    DevBuf cache_mark;                     // one word per k_deform_transform workgroup: the serial of the last frame in which it took the cached path (statistics only)
     uint32_t cached_n_draws = 0;           // draws of the list the arrays were computed for
     bool cache_valid = false;              // ... and whether they were (false after any re-allocation, a frame without geometry, a dropped frame)
     bool cached_is_prev = false;           // that list is in draws_prev (a new list has been uploaded since), else it is draws_dev's
@@ -595,7 +598,7 @@ void fill_geometry_cache(AwsmHipCtx* c, FrameDev* f, bool replay) {
     f->prev_n_draws = b.cached_n_draws;
     f->cache_on = f->prev_draws ? 1u : 0u;
 }
-inline uint32_t cache_stat_word(const AwsmHipCtx* c) { return 14u + ((c->frame_serial / (uint32_t)kSlots) & 1u); }
+
 
 // replay: the frame's geometry pass is enqueued again (a bin list that overflowed, world arrays that moved under the hud pass): the camera snapshot the first
 // enqueue took stays — pix2view / cam_pos were composed from that camera at awsm_hip_geometry_pass — and the geometry cache is not consulted.
@@ -604,7 +607,9 @@ int enqueue_geometry(AwsmHipCtx* c, bool replay = false) {
     FrameDev f;
     { const bool hd = c->hud_geometry_done, hm = c->hud_merged; c->hud_geometry_done = false; c->hud_merged = false; fill_frame(c, &f); c->hud_geometry_done = hd; c->hud_merged = hm; }      // the world pass's own view (no merged hud keys, no hud ranks)
     fill_geometry_cache(c, &f, replay);
-    f.cache_stat = c->stage_timers ? cache_stat_word(c) : 0u;      // AwsmFrameStats.geometry_cache_blocks: counted only when stage times are asked for too
+    f.block_draw = FB(c).block_map_valid ? (const uint32_t*)FB(c).block_map.ptr : nullptr;
+    // AwsmFrameStats.geometry_cache_blocks: marked only when stage times are asked for too (a plain store per workgroup, counted by frame_end on the host)
+    f.cache_mark = (c->stage_timers && FB(c).cache_mark.size >= (size_t)c->n_blocks * 4) ? (uint32_t*)FB(c).cache_mark.ptr : nullptr;
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     int rc = sync_scene(c);
     if (rc) return rc;
@@ -910,6 +915,10 @@ int size_pass_buffers(AwsmHipCtx* c, FrameBufs& b, size_t tri_cap, size_t draw_c
     if (world_pass && c->geometry_cache) {      // geometry cache: the previous list beside the current one, world positions per vertex
         if ((rc = dev_reserve(c, b.draws_prev, nd * sizeof(DrawDev)))) return rc;
         if ((rc = dev_reserve(c, b.wcache, nv * 16))) return rc;
+        const size_t blocks_bound = nv / 256 + nd + 1;
+        if ((rc = dev_reserve(c, b.block_map, blocks_bound * 4))) return rc;
+        b.block_map_valid = false;
+        if (b.cache_mark.size < blocks_bound * 4) { if ((rc = dev_realloc(c, b.cache_mark, (blocks_bound + blocks_bound / 2) * 4, true))) return rc; }
     }
     b.cache_valid = false;      // the arrays may have moved
     if ((rc = dev_reserve(c, b.draw_shade, nd * sizeof(DrawShadeDev)))) return rc;
@@ -979,6 +988,16 @@ int upload_draw_list(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& dr
     } else if (keep_prev && !b.cached_is_prev) b.cache_valid = false;      // the cached list is about to be overwritten
     b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true; b.draws_version++;
     b.tail_uploaded_valid = false;
+    b.block_map_valid = false;
+    if (keep_prev && b.block_map.ptr) {      // the world pass: which draw each transform workgroup belongs to
+        std::vector<uint32_t> map;
+        for (size_t i = 0; i < draws_host.size(); i++) map.insert(map.end(), (3ull * draws_host[i].tri_count + 255) / 256, (uint32_t)i);
+        if (map.size() * 4 <= b.block_map.size && map.size() * 4 <= (1u << 20)) {
+            int rc = upload_small(c, b.block_map.ptr, map.data(), map.size() * 4);
+            if (rc) return rc;
+            b.block_map_valid = true;
+        }
+    }
     return upload_draws_at(c, b, 0, draws_host);
 }
 
@@ -1041,7 +1060,7 @@ int awsm_hip_create(const AwsmConfig* cfg, AwsmHipCtx** out) {
         c->lean_grid = per_cu > 0 ? (uint32_t)(per_cu * prop.multiProcessorCount) & ~7u : 0u;
     }
     for (int s = 0; s < n_slots(c); s++) {
-        if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->fb[s].counters.ptr, 0, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13] + the geometry cache's hit counts [14], [15] (alternating frames of the slot)
+        if (hipMalloc(&c->fb[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->fb[s].counters.ptr, 0, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);   // 8 frame counters + 4 pick words + k_bin_scan's arrival counter [12] and ready flag [13]
         c->fb[s].counters.size = 16 * sizeof(uint32_t);
         if (hipMalloc(&c->tr[s].counters.ptr, 16 * sizeof(uint32_t)) != hipSuccess) return bail(AWSM_ERR_OUT_OF_MEMORY);
         c->tr[s].counters.size = 16 * sizeof(uint32_t);
@@ -1118,7 +1137,7 @@ int awsm_hip_destroy(AwsmHipCtx* c) {
     for (int k = 0; k < 4 * kSlots; k++) {
         FrameBufs& b = k < kSlots ? c->fb[k] : (k < 2 * kSlots ? c->tr[k - kSlots] : (k < 3 * kSlots ? c->hud[k - 2 * kSlots] : c->htr[k - 3 * kSlots]));
         fr(b.vis); fr(b.wpos); fr(b.frag_rec); fr(b.frag_color); fr(b.frag_first); fr(b.tex_slots); fr(b.draw_mat); fr(b.clip); fr(b.nrm); fr(b.tan); fr(b.tri_rec); fr(b.tri_flags); fr(b.tri_shade); fr(b.draw_lean); fr(b.draws_dev); fr(b.draw_shade); fr(b.tile_count); fr(b.tile_offset);
-        fr(b.wcache); fr(b.draws_prev); fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
+        fr(b.wcache); fr(b.draws_prev); fr(b.cache_mark); fr(b.block_map); fr(b.tile_cursor); fr(b.tile_order); fr(b.scan_tmp); fr(b.tile_split); fr(b.raster_scratch); fr(b.bin_list); fr(b.big_list); fr(b.counters); fr(b.camera);
     }
     for (hipStream_t st : c->shade_streams) if (st) (void)hipStreamDestroy(st);
     for (int i = 0; i < kSlots; i++) { if (c->ev_geom_done[i]) (void)hipEventDestroy(c->ev_geom_done[i]); if (c->ev_shade_done[i]) (void)hipEventDestroy(c->ev_shade_done[i]); if (c->ev_uploads[i]) (void)hipEventDestroy(c->ev_uploads[i]); }
@@ -1718,9 +1737,14 @@ int awsm_hip_frame_end(AwsmHipCtx* c, AwsmFrameStats* out) {
             HIPCHK(c, hipMemsetAsync((uint32_t*)FB(c).counters.ptr + 3, 0, sizeof(uint32_t), c->stream));
             awsm_launch_count_covered(&f, c->stream);
         }
-        HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->counters_host, FB(c).counters.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->cache_blocks_last = c->counters_host[cache_stat_word(c)];
+        c->cache_blocks_last = 0;
+        if (out && c->geometry_done && c->stage_timers && c->n_blocks && FB(c).cache_mark.size >= (size_t)c->n_blocks * 4) {
+            std::vector<uint32_t> marks(c->n_blocks);
+            HIPCHK(c, hipMemcpy(marks.data(), FB(c).cache_mark.ptr, marks.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t m : marks) c->cache_blocks_last += m == c->frame_serial ? 1u : 0u;
+        }
         if (c->overlap) { HIPCHK(c, sync_shade_streams(c)); for (bool& b : c->shade_pending) b = false; }
         { int rch = handoff_check(c); if (rch) return rch; }      // a gate ended unopened: the frame it guarded was dropped
         memset(c->counters_host + 8, 0, 8 * sizeof(uint32_t));

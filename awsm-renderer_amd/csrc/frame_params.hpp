@@ -183,12 +183,13 @@ struct FrameDev {
     // draw list (same DrawDev, index and first_tri included: prev_draws is the list those arrays were computed for) and none of its inputs was written since
     // (dirty: the byte ranges awsm_hip_buffer_write / buffer_create received since that frame, by buffer).  Such a draw's blocks only form
     // clip = view_proj * wcache — the same operation on the same f32 values as the full path, so the same bits.  cache_on = 0: every block takes the full path.
+    const uint32_t* block_draw;   // world geometry pass: the draw index of every k_deform_transform workgroup (null: the kernel searches the list)
     float4* wcache;               // total_verts  (world position as apply_vertex.wgsl forms it, model * (pos, 1)); geometry pass only, may be null
     const DrawDev* prev_draws;    // the draw list the slot's arrays were last computed for (== draws when the list did not change)
     uint32_t prev_n_draws;
     uint32_t cache_on;
     uint32_t cache_serial;        // frame serial of that computation: if its frame was dropped by a timed-out gate (poison) the arrays are older than prev_draws says
-    uint32_t cache_stat;          // 0, or the word of `counters` (14 / 15, alternating between a slot's frames) that counts the workgroups taking the cached path; the kernel zeroes the other one
+    uint32_t* cache_mark;         // null, or one word per workgroup of the launch: a workgroup that takes the cached path stores frame_serial there (AwsmFrameStats.geometry_cache_blocks)
     uint32_t n_dirty;             // ranges in dirty[] (<= kMaxDirtyRanges; more than that and the host turns the cache off for the frame)
     uint32_t dirty[12][3];        // {AwsmBuf, first byte, one past the last byte (saturating)}
     TriRec* tri_rec;              // total_tris   (k_bin<count> -> k_bin<fill>, k_raster_tile, k_shade)

@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : A
         // counters start empty — here and not in k_resolve_draws, which is skipped when nothing but the camera changed
         if (!FWD && f.shade_todo && g0 == 14u) f.shade_todo[0] = 0u;
         if (!FWD && f.lean_next && g0 >= 64u && g0 < 128u) f.lean_next[(g0 - 64u) * 16u] = 0u;
-        if (!FWD && f.cache_stat && g0 == 15u) f.counters[29u - f.cache_stat] = 0u;      // the slot's next frame counts its cache hits there
         if (!FWD && g0 < f.camera_snap_words) f.camera_snap[g0] = reinterpret_cast<const uint32_t*>(sc->buf[AWSM_BUF_CAMERA])[g0];   // overlap mode: the frame's camera
     }
     uint32_t lo = 0, hi = f.n_draws;
-    while (hi - lo > 1) {
+    if (!FWD && f.block_draw) lo = f.block_draw[blockIdx.x];      // (block0 = 0 whenever the map is given)
+    else while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (f.draws[mid].first_block <= b) lo = mid; else hi = mid;
     }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : A
     if (!FWD && f.cache_on && lo < f.prev_n_draws && draw_unchanged(sc, f, d, f.prev_draws[lo], gmp)) {
         // Geometry cache hit (frame_params.hpp): the draw's world positions, normals, tangents and per-triangle words in this slot's arrays are still what the
         // full path below would write — only the camera moved.  clip = view_proj * world, the full path's own last step on the same f32 values.
-        if (f.cache_stat && tid == 0u) atomicAdd(&f.counters[f.cache_stat], 1u);
+        if (f.cache_mark && tid == 0u) f.cache_mark[blockIdx.x] = f.frame_serial;
         if (tid < count) {
             const size_t gv = (size_t)3u * d.first_tri + local0 + tid;
             const float4 w = f.wcache[gv];

@@ -161,11 +161,12 @@ def report_bars(name, rows, r):
     return line
 
 
-# The composite's allowance (the transparent / HUD passes).  Both sides store f16 at every blend, so the comparison is in f16 steps; what is left over two steps
-# is the screen-space transmission background: an integer texel fetch at a position computed by relaxed arithmetic, so an isolated pixel may pick the
-# neighbouring texel of the opaque image (bounded in number, not in value).  Round 5 measured how much of the former blanket (0.5 % of the touched pixels)
-# the tests use (profiles/r05_composite_bars.txt) and cut it to that plus a margin: COMPOSITE_ALLOW_FRACTION of the touched pixels, at least COMPOSITE_ALLOW_MIN.
-COMPOSITE_ALLOW_FRACTION = 1.0 / 200.0
+# The composite's allowance (the transparent / HUD passes).  Both sides store f16 at every blend, so the comparison is in f16 steps; what may be left over two
+# steps is the screen-space transmission background: an integer texel fetch at a position computed by relaxed arithmetic, so an isolated pixel may pick the
+# neighbouring texel of the opaque image (bounded in number, not in value).  Until round 5 the tests allowed 0.5 % of the touched pixels — a population.
+# Measured (profiles/r05_composite_bars.txt, every composite comparison of the GPU suite: 14,000 - 45,000 touched pixels each): NO pixel is over two f16
+# steps or over the f32 bound, the worst distance is 2 steps.  The allowance is now what the mode survey always used: at most 4 pixels, whatever the size.
+COMPOSITE_ALLOW_FRACTION = 0.0
 COMPOSITE_ALLOW_MIN = 4
 
 
