@@ -2058,6 +2058,39 @@ template <int BYTE> AWSM_DI float channel(const TapG& t, const Weights& wl, cons
     const float a = channel<BYTE>(t.lo, wl), b = channel<BYTE>(t.hi, wh);
     return a * (1.0f - t.f) + b * t.f;                                        // sample_slot<true>: acc = c_lo (1 - f) + c_hi f
 }
+// ---- One footprint for all of a pixel's textures (round 5).  The isotropic rule picks, for every texture, the level whose texels match the pixel's
+// footprint: lod_t = log2(rho * W_t) = L + lw_t with L = log2(rho) in uv units the same for every texture of the pixel (they share TEXCOORD_0 and its
+// derivatives on this route) — so wherever the level is not clamped (0 < lod_t < levels_t - 1) the chosen level's extent, 2^(lw_t - floor(lod_t)) =
+// 2^(-floor(L)), the blend factor frac(L) and with them the texel coordinates and all eight weights are THE SAME for all five textures.  A minified
+// frame (the 4K atrium samples its textures two to three levels down) is entirely in that regime.  The coordinates are formed once per level
+// (footprint: sample_slot<true>'s own operations, so the same bits), a texture then costs its two level bases and four loads, and a channel is one sum
+// over eight taps with weights formed once.  (L + lw_t instead of one hardware log2 per texture: the same value to within an ulp of the logarithm, far
+// inside what RELAXED allows; on a level boundary the blend is continuous.)  Strips with a magnified or top-clamped texture take the per-texture code.
+struct Foot { uint32_t i0b, row0, row1, g_rest, sh2; bool wrap; };
+AWSM_DI void footprint(uint32_t lwl, float u, float v, Foot& ft, float& fx, float& fy) {      // the level whose extent is 2^lwl: fetch_g's coordinates
+    const float xf = __builtin_amdgcn_ldexpf(u, (int)lwl) - 0.5f, yf = __builtin_amdgcn_ldexpf(v, (int)lwl) - 0.5f;
+    const float flx = floorf(xf), fly = floorf(yf);
+    fx = xf - flx; fy = yf - fly;
+    const uint32_t xi = (uint32_t)(int)flx, yi = (uint32_t)(int)fly;
+    const uint32_t i0 = __builtin_amdgcn_ubfe(xi, 0u, lwl), j0 = __builtin_amdgcn_ubfe(yi, 0u, lwl), j1 = __builtin_amdgcn_ubfe(yi + 1u, 0u, lwl);
+    ft.i0b = i0 << 2; ft.row0 = j0 << lwl; ft.row1 = j1 << lwl;
+    ft.wrap = __builtin_amdgcn_ubfe(xi + 1u, 0u, lwl) == 0u;
+    ft.g_rest = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (lwl + 1u)); ft.sh2 = 2u * lwl;
+}
+struct Quad { uint32_t t00, t10, t01, t11; };
+AWSM_DI void fetch_q(const TexG& x, const Foot& ft, Quad& q) {
+    const uint32_t g_all = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (x.lw + 1u));                    // scalar
+    const uint32_t first = x.layers * (g_all - ft.g_rest) + (x.layer << ft.sh2);
+    const uint32_t r0 = (first + ft.row0) << 2, r1 = (first + ft.row1) << 2;
+    const u32x2a4 p0 = gload<u32x2a4>(x.base, r0 + ft.i0b), p1 = gload<u32x2a4>(x.base, r1 + ft.i0b);
+    q.t00 = p0.x; q.t10 = p0.y; q.t01 = p1.x; q.t11 = p1.y;
+    if (ft.wrap) { q.t10 = gload<uint32_t>(x.base, r0); q.t11 = gload<uint32_t>(x.base, r1); }
+}
+struct W8 { float l00, l10, l01, l11, h00, h10, h01, h11; };
+template <int BYTE> AWSM_DI float channel8(const Quad& lo, const Quad& hi, const W8& w) {      // (c_lo (1 - f) + c_hi f with the level weights folded into the eight)
+    return ((ub<BYTE>(lo.t00) * w.l00 + ub<BYTE>(lo.t10) * w.l10) + (ub<BYTE>(lo.t01) * w.l01 + ub<BYTE>(lo.t11) * w.l11)) +
+           ((ub<BYTE>(hi.t00) * w.h00 + ub<BYTE>(hi.t10) * w.h10) + (ub<BYTE>(hi.t01) * w.h01 + ub<BYTE>(hi.t11) * w.h11));
+}
 }  // namespace lean
 
 // MSAA (x4, the reference's default AntiAliasing): the kernel shades sample 0 of every pixel — keys sit four to a pixel — and leaves what the edge
@@ -2309,6 +2342,104 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
         }
     }
     const float m2c = GRAD == 2 ? m2 * fm::rcp(nf * nf) : m2;
+    // what follows the texel fetches while they are in flight: the pixel's position and its tangent frame (defined below, run inside either branch)
+    f3 world_position, surface_to_camera;
+    TBN tbn;
+    f3 normal;
+    float occlusion = 1.0f;
+    auto mid = [&]() {
+    asm volatile("; MARK standard");
+    // ---- standard.wgsl:11-62 (as shade_surface) ----
+    // pixel -> NDC, inv_proj and inv_view as ONE matrix, composed on the host in f64 from the camera this frame was submitted with (FrameDev.pix2world):
+    // sixteen multiply-adds and one reciprocal instead of two matrix products, two uniform reciprocals and the NDC arithmetic per pixel.
+    // standard.wgsl:11-62.  pixel -> NDC and inv_proj are ONE matrix, composed on the host in f64 from the camera this frame was submitted with
+    // (FrameDev.pix2view); world = view_rot * view + cam_pos.  (One matrix for all of it, inv_view folded in as well, was measured: the translation
+    // then sits inside the cancellation of view_h and a far surface's view vector moves by 1e-5 rad.)
+    const float pxf = (float)cx, pyf = (float)cy;
+    const float* M = f.pix2view;
+    const float hx = M[0] * pxf + (M[4] * pyf + (M[8] * depth + M[12])), hy = M[1] * pxf + (M[5] * pyf + (M[9] * depth + M[13]));
+    const float hz = M[2] * pxf + (M[6] * pyf + (M[10] * depth + M[14])), hw = M[3] * pxf + (M[7] * pyf + (M[11] * depth + M[15]));
+    const float ivw = fm::rcp(fmaxf(hw, 1e-8f));
+    const f3 vp = {hx * ivw, hy * ivw, hz * ivw};                          // view_position
+    const float* R = f.view_rot;
+    const f3 rel = {R[0] * vp.x + (R[3] * vp.y + R[6] * vp.z), R[1] * vp.x + (R[4] * vp.y + R[7] * vp.z), R[2] * vp.x + (R[5] * vp.y + R[8] * vp.z)};   // world_position - camera
+    world_position = {rel.x + f.cam_pos[0], rel.y + f.cam_pos[1], rel.z + f.cam_pos[2]};
+    if (f.cam_ortho) {
+        surface_to_camera = mk3(f.ortho_view_dir[0], f.ortho_view_dir[1], f.ortho_view_dir[2]);
+    } else {
+        // cam - world, as standard.wgsl:41-47 forms it (not -rel, which is the same vector without the rounding of the two camera-sized terms: the
+        // oracle's result carries that rounding, and a near-mirror texel sees the difference)
+        const f3 to_camera = mk3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]) - world_position;
+        surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
+    }
+    asm volatile("; MARK tbn");
+    // (Not a leaner unpack without the normalisations of T and B: canonical_tb's 1 / (1 + N.z) makes (t, b) orthonormal only as far as N is a unit
+    // vector to the last bit — measured: 7 pixels of a random view 15x out of bounds, all on surfaces facing -z.)
+    tbn = fm::funpack_normal_tangent(g.packed_nt);
+    normal = tbn.N;
+    };
+    // ---- MipmapMode::Gradient, a strip inside one draw, every texture of the pixel in the unclamped regime for every lane: ONE footprint (lean::footprint) ----
+    bool shared_fp = false;
+    float Lm = 0.0f;
+    if (GRAD == 1 && one_draw && !todo) {
+        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
+        const uint32_t fl = cload<uint32_t>(f.draw_lean, lo);
+        const uint32_t exs = (fl & kNeed) == kNeed ? (fl >> 8) & 31u : 0u;
+        if (exs) {
+            // scalar bounds over the draw's textures: every lod_t = L + lw_t in (0, levels_t - 1)  <=>  -min lw_t < L < min (levels_t - 1 - lw_t)
+            int lw_min = 15, top_min = 15;
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)kCoreTextures; k++) if (exs & (1u << k)) {
+                const uint32_t w1 = cload<uint32_t>(f.draw_lean, lo + 96u + 16u * k + 4u);
+                const int lw = (int)(w1 >> 24), lv = (int)((w1 >> 16) & 15u);
+                lw_min = min(lw_min, lw); top_min = min(top_min, lv - 1 - lw);
+            }
+            Lm = 0.5f * __builtin_amdgcn_logf(fmaxf(m2c, 1e-30f));
+            const bool in = Lm > -(float)lw_min && Lm < (float)top_min;
+            shared_fp = __builtin_amdgcn_ballot_w64(hit && !in) == 0ull;
+        }
+    }
+    if (GRAD == 1 && shared_fp) {
+        asm volatile("; MARK fetch1");
+        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
+        const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
+        const u32x2 L5s = cload<u32x2>(f.draw_lean, lo + 88u);
+        const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
+        const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
+        exists = (L0.x >> 8) & 31u;
+        const float flL = floorf(Lm), ff = Lm - flL;
+        const uint32_t cl = hit ? (uint32_t)(-(int)flL) : 1u;                // log2 of the lower level's extent, >= 1 (L < 0 here); lanes without a hit fetch nothing that counts
+        lean::Foot f_lo, f_hi;
+        float fxl, fyl, fxh, fyh;
+        lean::footprint(cl, u, v, f_lo, fxl, fyl);
+        lean::footprint(cl - 1u, u, v, f_hi, fxh, fyh);
+        lean::Quad ql0, qh0, ql1, qh1, ql2, qh2, ql3, qh3, ql4, qh4;
+        if (exists & 1u) { const lean::TexG x = lean::decode_g(G0.x, G0.y, G0.z, G0.w); lean::fetch_q(x, f_lo, ql0); lean::fetch_q(x, f_hi, qh0); }
+        if (exists & 2u) { const lean::TexG x = lean::decode_g(G1.x, G1.y, G1.z, G1.w); lean::fetch_q(x, f_lo, ql1); lean::fetch_q(x, f_hi, qh1); }
+        if (exists & 4u) { const lean::TexG x = lean::decode_g(G2.x, G2.y, G2.z, G2.w); lean::fetch_q(x, f_lo, ql2); lean::fetch_q(x, f_hi, qh2); }
+        if (exists & 8u) { const lean::TexG x = lean::decode_g(G3.x, G3.y, G3.z, G3.w); lean::fetch_q(x, f_lo, ql3); lean::fetch_q(x, f_hi, qh3); }
+        if (exists & 16u) { const lean::TexG x = lean::decode_g(G4.x, G4.y, G4.z, G4.w); lean::fetch_q(x, f_lo, ql4); lean::fetch_q(x, f_hi, qh4); }
+        metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
+        base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
+        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
+        if (!hit) return true;
+        mid();
+        asm volatile("; MARK material1");
+        lean::W8 w8;
+        {
+            const float gl = 1.0f - ff, gxl = 1.0f - fxl, gyl = 1.0f - fyl, gxh = 1.0f - fxh, gyh = 1.0f - fyh;
+            const float a = gyl * gl, b = fyl * gl, c = gyh * ff, d = fyh * ff;
+            w8 = {gxl * a, fxl * a, gxl * b, fxl * b, gxh * c, fxh * c, gxh * d, fxh * d};
+        }
+        if (exists & 1u) base = {base.x * lean::channel8<0>(ql0, qh0, w8), base.y * lean::channel8<1>(ql0, qh0, w8), base.z * lean::channel8<2>(ql0, qh0, w8)};
+        if (exists & 2u) { metallic_in = metallic_in * lean::channel8<2>(ql1, qh1, w8); roughness_in = roughness_in * lean::channel8<1>(ql1, qh1, w8); }
+        if (exists & 4u) {   // material_color_calc.wgsl:301-322
+            const float ntx = lean::channel8<0>(ql2, qh2, w8) * normal_scale - normal_bias, nty = lean::channel8<1>(ql2, qh2, w8) * normal_scale - normal_bias, ntz = lean::channel8<2>(ql2, qh2, w8) * (2.0f / 255.0f) - 1.0f;
+            normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
+        }
+        if (exists & 8u) occlusion = lean::channel8<0>(ql3, qh3, w8) * occlusion_strength + occlusion_bias;      // mix(1, r, s)
+        if (exists & 16u) emissive = {emissive.x * lean::channel8<0>(ql4, qh4, w8), emissive.y * lean::channel8<1>(ql4, qh4, w8), emissive.z * lean::channel8<2>(ql4, qh4, w8)};
+    } else {
     fetch_all(u, v, m2c, true);
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
         if (!ITEMS && lane == 0u) {
@@ -2386,43 +2517,13 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
         }
     }
 
-    asm volatile("; MARK standard");
-    // ---- standard.wgsl:11-62 (as shade_surface) ----
-    // pixel -> NDC, inv_proj and inv_view as ONE matrix, composed on the host in f64 from the camera this frame was submitted with (FrameDev.pix2world):
-    // sixteen multiply-adds and one reciprocal instead of two matrix products, two uniform reciprocals and the NDC arithmetic per pixel.
-    // standard.wgsl:11-62.  pixel -> NDC and inv_proj are ONE matrix, composed on the host in f64 from the camera this frame was submitted with
-    // (FrameDev.pix2view); world = view_rot * view + cam_pos.  (One matrix for all of it, inv_view folded in as well, was measured: the translation
-    // then sits inside the cancellation of view_h and a far surface's view vector moves by 1e-5 rad.)
-    const float pxf = (float)cx, pyf = (float)cy;
-    const float* M = f.pix2view;
-    const float hx = M[0] * pxf + (M[4] * pyf + (M[8] * depth + M[12])), hy = M[1] * pxf + (M[5] * pyf + (M[9] * depth + M[13]));
-    const float hz = M[2] * pxf + (M[6] * pyf + (M[10] * depth + M[14])), hw = M[3] * pxf + (M[7] * pyf + (M[11] * depth + M[15]));
-    const float ivw = fm::rcp(fmaxf(hw, 1e-8f));
-    const f3 vp = {hx * ivw, hy * ivw, hz * ivw};                          // view_position
-    const float* R = f.view_rot;
-    const f3 rel = {R[0] * vp.x + (R[3] * vp.y + R[6] * vp.z), R[1] * vp.x + (R[4] * vp.y + R[7] * vp.z), R[2] * vp.x + (R[5] * vp.y + R[8] * vp.z)};   // world_position - camera
-    const f3 world_position = {rel.x + f.cam_pos[0], rel.y + f.cam_pos[1], rel.z + f.cam_pos[2]};
-    f3 surface_to_camera;
-    if (f.cam_ortho) {
-        surface_to_camera = mk3(f.ortho_view_dir[0], f.ortho_view_dir[1], f.ortho_view_dir[2]);
-    } else {
-        // cam - world, as standard.wgsl:41-47 forms it (not -rel, which is the same vector without the rounding of the two camera-sized terms: the
-        // oracle's result carries that rounding, and a near-mirror texel sees the difference)
-        const f3 to_camera = mk3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]) - world_position;
-        surface_to_camera = fm::fdot(to_camera, to_camera) > 0.0f ? fm::fsafe_normalize(to_camera) : mk3(0.0f, 0.0f, 1.0f);
-    }
-    asm volatile("; MARK tbn");
-    // (Not a leaner unpack without the normalisations of T and B: canonical_tb's 1 / (1 + N.z) makes (t, b) orthonormal only as far as N is a unit
-    // vector to the last bit — measured: 7 pixels of a random view 15x out of bounds, all on surfaces facing -z.)
-    const TBN tbn = fm::funpack_normal_tangent(g.packed_nt);
+    mid();
 
     asm volatile("; MARK material");
     // ---- material_color_calc.wgsl:25-265 for a material without optional blocks ----
     // one texture's channel BYTE: bilinear on level 0 (MipmapMode::None) or the blend of two levels' bilinear values (MipmapMode::Gradient)
 #define AWSM_LEAN_TEX(K, W0, W1) const lean::Weights W0 = lean::weights(GRAD ? tg##K.lo : tp##K), W1 = lean::weights(GRAD ? tg##K.hi : tp##K)
 #define AWSM_LEAN_CH(K, BYTE, W0, W1) (GRAD ? lean::channel<BYTE>(tg##K, W0, W1) : lean::channel<BYTE>(tp##K, W0))
-    f3 normal = tbn.N;
-    float occlusion = 1.0f;
     if (GRAD != 2) {
         if (exists & 1u) { AWSM_LEAN_TEX(0, w, wh); base = {base.x * AWSM_LEAN_CH(0, 0, w, wh), base.y * AWSM_LEAN_CH(0, 1, w, wh), base.z * AWSM_LEAN_CH(0, 2, w, wh)}; }
         if (exists & 2u) { AWSM_LEAN_TEX(1, w, wh); metallic_in = metallic_in * AWSM_LEAN_CH(1, 2, w, wh); roughness_in = roughness_in * AWSM_LEAN_CH(1, 1, w, wh); }
@@ -2446,6 +2547,7 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
     }
 #undef AWSM_LEAN_TEX
 #undef AWSM_LEAN_CH
+    }      // (the per-texture branch)
 
     asm volatile("; MARK surface");
     // ---- lights.wgsl:121-152 / brdf.wgsl (apply_lighting, brdf_ibl, brdf_direct above, with ior 1.5, specular 1, no transmission / clearcoat / sheen) ----

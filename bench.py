@@ -496,6 +496,11 @@ def main():
     # round 5 (they used to follow it): the script does this work anyway, and done first it also brings the part out of the idle clock state the seconds of
     # CPU-side scene set-up leave it in — the driver's 20-step run used to be measured on a part still ramping up.  `steps` and
     # `warmup` are exactly what was passed; "frames_before_timed_loop" in the JSON line says what ran before them.
+    # (Python's garbage collector is switched off from here to the end of the timed loop, after one collection now: a collection between the profile frames
+    # and the warm-up would leave the GPU idle for ~35 ms, and the part's clocks fall back within a few milliseconds of idling.)
+    import gc
+    gc.collect()
+    gc.disable()
     r.host.set_render_timings(True)
     acc = {}
     for _ in range(max(1, args.profile_frames)):
@@ -508,13 +513,12 @@ def main():
     # No Python garbage collection inside the warm-up and the timed loop: a generation-2 pass over the scene's objects takes ~35 ms, and
     # whether one lands in a 25-70 ms loop depends on the allocation count of everything before it (seen: configs[1] at 3,100 or 8,300
     # frames/s depending on an unrelated command-line flag).  The loop itself allocates a few tuples per step.
-    import gc
-
     host_t = []                            # --trace: perf_counter at every step() return (and around the barriers)
 
     def timed_loop():
-        gc.collect()
-        gc.disable()
+        if gc.isenabled():         # (a repeated measurement: the first one re-enabled it)
+            gc.collect()
+            gc.disable()
         del host_t[:]
         if args.trace:
             dev.frame_trace(args.warmup + args.steps + 8)
@@ -662,7 +666,7 @@ def main():
         lut_rg = oracle_lib.brdf_lut(64, 64)
         mid = H // 2
         half = max(8, H // 8)
-        cpu = cpu_baseline(scene, lut_rg, (max(0, mid - half), min(H, mid + half)), (mid - max(4, H // 270), mid + max(4, H // 270)))
+        cpu = cpu_baseline(scene, lut_rg, (max(0, mid - half), min(H, mid + half)), (mid - max(8, H // 16), mid + max(8, H // 16)))
 
     per_rank = None
     if world > 1:
