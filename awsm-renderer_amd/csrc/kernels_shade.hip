@@ -2653,8 +2653,12 @@ AWSM_DI void lean_block(const DevScene* __restrict__ sc, const FrameDev& f, cons
 constexpr uint32_t kLeanCounters = AWSM_LEAN_COUNTERS;     // <= 8 (lean_next holds 64 counter lines)
 // GRAD: MipmapMode::Gradient (the reference's default): barycentric derivatives, isotropic LOD, two levels per texture — a separate instantiation, as the
 // reference keeps separate pipelines; its ten footprints in flight want more registers than six waves per SIMD leave.
+// Five wavefronts per SIMD (96 registers) since round 5: the strips that share one footprint (lean::footprint: the bulk of a minified frame) need 96 without
+// a spill, and what the cap spills (48 bytes of scratch) sits in the per-texture branch that the other strips take.  Measured at 4K, MSAA x4 + mips: the
+// kernel 330 -> 301 us, the frame 1,777 -> 1,883 frames/s (profiles/r05_lean_grad_waves.txt).  Round 4 had measured five wavefronts as a loss — with
+// every strip on the per-texture code the spills sat in the texel-fetch burst of all of them.
 #ifndef AWSM_LEAN_GRAD_WAVES
-#define AWSM_LEAN_GRAD_WAVES 4
+#define AWSM_LEAN_GRAD_WAVES 5
 #endif
 template <bool PERSIST, int GRAD, bool MSAA>   // the loop state costs the persistent variant 5 VGPRs: 85 (-> 88 allocated) instead of 80; under an 80 cap it spills inside the texel-fetch burst
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? AWSM_ANISO_WAVES : (GRAD ? AWSM_LEAN_GRAD_WAVES : (PERSIST ? 5 : AWSM_LEAN_WAVES))))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
