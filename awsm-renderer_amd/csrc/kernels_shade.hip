@@ -20,6 +20,7 @@
 // Pure gather + ALU: no MFMA.  Compulsory HBM traffic per pixel is the 8-byte key read and the 8-byte
 // RGBA16F write; everything else (vertices, metas, materials, texels) is reused across neighbouring pixels
 // and served by L1 / the XCD's L2 — workgroups are dealt to XCDs in contiguous screen runs for that.
+#include <type_traits>
 #include "frame_params.hpp"
 #include "raster_setup.hpp"
 
@@ -2078,14 +2079,16 @@ AWSM_DI void footprint(uint32_t lwl, float u, float v, Foot& ft, float& fx, floa
     ft.g_rest = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (lwl + 1u)); ft.sh2 = 2u * lwl;
 }
 struct Quad { uint32_t t00, t10, t01, t11; };
-AWSM_DI void fetch_q(const TexG& x, const Foot& ft, Quad& q) {
-    const uint32_t g_all = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (x.lw + 1u));                    // scalar
+template <typename BASE> AWSM_DI void fetch_q(const TexGT<BASE>& x, const Foot& ft, Quad& q) {
+    const uint32_t g_all = __builtin_amdgcn_ubfe(0x55555555u, 0u, 2u * (x.lw + 1u));                    // (scalar when the record is)
     const uint32_t first = x.layers * (g_all - ft.g_rest) + (x.layer << ft.sh2);
     const uint32_t r0 = (first + ft.row0) << 2, r1 = (first + ft.row1) << 2;
-    const u32x2a4 p0 = gload<u32x2a4>(x.base, r0 + ft.i0b), p1 = gload<u32x2a4>(x.base, r1 + ft.i0b);
+    const u32x2a4 p0 = gload_any<u32x2a4>(x.base, r0 + ft.i0b), p1 = gload_any<u32x2a4>(x.base, r1 + ft.i0b);
     q.t00 = p0.x; q.t10 = p0.y; q.t01 = p1.x; q.t11 = p1.y;
-    if (ft.wrap) { q.t10 = gload<uint32_t>(x.base, r0); q.t11 = gload<uint32_t>(x.base, r1); }
+    if (ft.wrap) { q.t10 = gload_any<uint32_t>(x.base, r0); q.t11 = gload_any<uint32_t>(x.base, r1); }
 }
+AWSM_DI TexG decode_any(const void*, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return decode_g(w0, w1, w2, w3); }
+AWSM_DI TexGL decode_any(unsigned long long, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return decode_gl(w0, w1, w2, w3); }
 struct W8 { float l00, l10, l01, l11, h00, h10, h01, h11; };
 template <int BYTE> AWSM_DI float channel8(const Quad& lo, const Quad& hi, const W8& w) {      // (c_lo (1 - f) + c_hi f with the level weights folded into the eight)
     return ((ub<BYTE>(lo.t00) * w.l00 + ub<BYTE>(lo.t10) * w.l10) + (ub<BYTE>(lo.t01) * w.l01 + ub<BYTE>(lo.t11) * w.l11)) +
@@ -2378,59 +2381,64 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
     tbn = fm::funpack_normal_tangent(g.packed_nt);
     normal = tbn.N;
     };
-    // ---- MipmapMode::Gradient, a strip inside one draw, every texture of the pixel in the unclamped regime for every lane: ONE footprint (lean::footprint) ----
+    // ---- MipmapMode::Gradient, every texture of the pixel in the unclamped regime for every lane: ONE footprint per pixel (lean::footprint).  The draw's
+    // record by scalar loads for a strip inside one draw, per lane for a strip over several draws and for the resolve kernel's items. ----
     bool shared_fp = false;
     float Lm = 0.0f;
-    if (GRAD == 1 && one_draw && !todo) {
-        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
-        const uint32_t fl = cload<uint32_t>(f.draw_lean, lo);
+    auto lean_word = [&](auto one, uint32_t off) {      // one word of the lane's (or the strip's) LeanDrawDev
+        if constexpr (decltype(one)::value) return cload<uint32_t>(f.draw_lean, d0 * (uint32_t)sizeof(LeanDrawDev) + off);
+        else return gload<uint32_t>(f.draw_lean, draw * (uint32_t)sizeof(LeanDrawDev) + off);
+    };
+    auto lean_quad = [&](auto one, uint32_t off) {
+        if constexpr (decltype(one)::value) return cload<u32x4>(f.draw_lean, d0 * (uint32_t)sizeof(LeanDrawDev) + off);
+        else return gload<u32x4>(f.draw_lean, draw * (uint32_t)sizeof(LeanDrawDev) + off);
+    };
+    auto decide = [&](auto one) {
+        const uint32_t fl = lean_word(one, 0u);
         const uint32_t exs = (fl & kNeed) == kNeed ? (fl >> 8) & 31u : 0u;
-        if (exs) {
-            // scalar bounds over the draw's textures: every lod_t = L + lw_t in (0, levels_t - 1)  <=>  -min lw_t < L < min (levels_t - 1 - lw_t)
-            int lw_min = 15, top_min = 15;
+        // bounds over the draw's textures: every lod_t = L + lw_t in (0, levels_t - 1)  <=>  -min lw_t < L < min (levels_t - 1 - lw_t)
+        int lw_min = 15, top_min = 15;
 #pragma unroll
-            for (uint32_t k = 0; k < (uint32_t)kCoreTextures; k++) if (exs & (1u << k)) {
-                const uint32_t w1 = cload<uint32_t>(f.draw_lean, lo + 96u + 16u * k + 4u);
-                const int lw = (int)(w1 >> 24), lv = (int)((w1 >> 16) & 15u);
-                lw_min = min(lw_min, lw); top_min = min(top_min, lv - 1 - lw);
-            }
-            Lm = 0.5f * __builtin_amdgcn_logf(fmaxf(m2c, 1e-30f));
-            const bool in = Lm > -(float)lw_min && Lm < (float)top_min;
-            shared_fp = __builtin_amdgcn_ballot_w64(hit && !in) == 0ull;
+        for (uint32_t k = 0; k < (uint32_t)kCoreTextures; k++) {
+            const uint32_t w1 = lean_word(one, 96u + 16u * k + 4u);
+            const int lw = (int)(w1 >> 24), lv = (int)((w1 >> 16) & 15u);
+            if (exs & (1u << k)) { lw_min = min(lw_min, lw); top_min = min(top_min, lv - 1 - lw); }
         }
-    }
-    if (GRAD == 1 && shared_fp) {
-        asm volatile("; MARK fetch1");
-        const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
-        const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
-        const u32x2 L5s = cload<u32x2>(f.draw_lean, lo + 88u);
-        const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
-        const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
-        exists = (L0.x >> 8) & 31u;
+        Lm = 0.5f * __builtin_amdgcn_logf(fmaxf(m2c, 1e-30f));
+        const bool in = exs != 0u && Lm > -(float)lw_min && Lm < (float)top_min;
+        return __builtin_amdgcn_ballot_w64(hit && !in) == 0ull;
+    };
+    if (GRAD == 1 && !todo) shared_fp = one_draw ? decide(std::true_type{}) : decide(std::false_type{});
+    auto shared_path = [&](auto one) {      // -> false: no lane of the wavefront has anything more to do
+        if constexpr (decltype(one)::value) asm volatile("; MARK fetch1"); else asm volatile("; MARK fetch1v");
+        lean::W8 w8;
+        lean::Quad ql0, qh0, ql1, qh1, ql2, qh2, ql3, qh3, ql4, qh4;
+        const u32x4 L0 = lean_quad(one, 0u), L1 = lean_quad(one, 16u), L2 = lean_quad(one, 32u);
+        const uint32_t L5s = lean_word(one, 88u);
+        const u32x4 G0 = lean_quad(one, 96u), G1 = lean_quad(one, 112u), G2 = lean_quad(one, 128u), G3 = lean_quad(one, 144u), G4 = lean_quad(one, 160u);
+        exists = hit ? (L0.x >> 8) & 31u : 0u;
         const float flL = floorf(Lm), ff = Lm - flL;
-        const uint32_t cl = hit ? (uint32_t)(-(int)flL) : 1u;                // log2 of the lower level's extent, >= 1 (L < 0 here); lanes without a hit fetch nothing that counts
+        const uint32_t cl = hit ? (uint32_t)(-(int)flL) : 1u;                // log2 of the lower level's extent, >= 1 (L < 0 here)
         lean::Foot f_lo, f_hi;
         float fxl, fyl, fxh, fyh;
         lean::footprint(cl, u, v, f_lo, fxl, fyl);
         lean::footprint(cl - 1u, u, v, f_hi, fxh, fyh);
-        lean::Quad ql0, qh0, ql1, qh1, ql2, qh2, ql3, qh3, ql4, qh4;
-        if (exists & 1u) { const lean::TexG x = lean::decode_g(G0.x, G0.y, G0.z, G0.w); lean::fetch_q(x, f_lo, ql0); lean::fetch_q(x, f_hi, qh0); }
-        if (exists & 2u) { const lean::TexG x = lean::decode_g(G1.x, G1.y, G1.z, G1.w); lean::fetch_q(x, f_lo, ql1); lean::fetch_q(x, f_hi, qh1); }
-        if (exists & 4u) { const lean::TexG x = lean::decode_g(G2.x, G2.y, G2.z, G2.w); lean::fetch_q(x, f_lo, ql2); lean::fetch_q(x, f_hi, qh2); }
-        if (exists & 8u) { const lean::TexG x = lean::decode_g(G3.x, G3.y, G3.z, G3.w); lean::fetch_q(x, f_lo, ql3); lean::fetch_q(x, f_hi, qh3); }
-        if (exists & 16u) { const lean::TexG x = lean::decode_g(G4.x, G4.y, G4.z, G4.w); lean::fetch_q(x, f_lo, ql4); lean::fetch_q(x, f_hi, qh4); }
+        typedef decltype(lean::decode_any(std::conditional_t<decltype(one)::value, const void*, unsigned long long>{}, 0u, 0u, 0u, 0u)) TexT;
+        const std::conditional_t<decltype(one)::value, const void*, unsigned long long> tag{};
+        if (exists & 1u) { const TexT x = lean::decode_any(tag, G0.x, G0.y, G0.z, G0.w); lean::fetch_q(x, f_lo, ql0); lean::fetch_q(x, f_hi, qh0); }
+        if (exists & 2u) { const TexT x = lean::decode_any(tag, G1.x, G1.y, G1.z, G1.w); lean::fetch_q(x, f_lo, ql1); lean::fetch_q(x, f_hi, qh1); }
+        if (exists & 4u) { const TexT x = lean::decode_any(tag, G2.x, G2.y, G2.z, G2.w); lean::fetch_q(x, f_lo, ql2); lean::fetch_q(x, f_hi, qh2); }
+        if (exists & 8u) { const TexT x = lean::decode_any(tag, G3.x, G3.y, G3.z, G3.w); lean::fetch_q(x, f_lo, ql3); lean::fetch_q(x, f_hi, qh3); }
+        if (exists & 16u) { const TexT x = lean::decode_any(tag, G4.x, G4.y, G4.z, G4.w); lean::fetch_q(x, f_lo, ql4); lean::fetch_q(x, f_hi, qh4); }
         metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
         base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
-        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
-        if (!hit) return true;
+        emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s);
+        const float gl = 1.0f - ff, gxl = 1.0f - fxl, gyl = 1.0f - fyl, gxh = 1.0f - fxh, gyh = 1.0f - fyh;
+        const float a = gyl * gl, b = fyl * gl, c = gyh * ff, d = fyh * ff;
+        w8 = {gxl * a, fxl * a, gxl * b, fxl * b, gxh * c, fxh * c, gxh * d, fxh * d};
+        if (!hit) return false;
         mid();
-        asm volatile("; MARK material1");
-        lean::W8 w8;
-        {
-            const float gl = 1.0f - ff, gxl = 1.0f - fxl, gyl = 1.0f - fyl, gxh = 1.0f - fxh, gyh = 1.0f - fyh;
-            const float a = gyl * gl, b = fyl * gl, c = gyh * ff, d = fyh * ff;
-            w8 = {gxl * a, fxl * a, gxl * b, fxl * b, gxh * c, fxh * c, gxh * d, fxh * d};
-        }
+        if constexpr (decltype(one)::value) asm volatile("; MARK material1"); else asm volatile("; MARK material1v");
         if (exists & 1u) base = {base.x * lean::channel8<0>(ql0, qh0, w8), base.y * lean::channel8<1>(ql0, qh0, w8), base.z * lean::channel8<2>(ql0, qh0, w8)};
         if (exists & 2u) { metallic_in = metallic_in * lean::channel8<2>(ql1, qh1, w8); roughness_in = roughness_in * lean::channel8<1>(ql1, qh1, w8); }
         if (exists & 4u) {   // material_color_calc.wgsl:301-322
@@ -2439,6 +2447,10 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
         }
         if (exists & 8u) occlusion = lean::channel8<0>(ql3, qh3, w8) * occlusion_strength + occlusion_bias;      // mix(1, r, s)
         if (exists & 16u) emissive = {emissive.x * lean::channel8<0>(ql4, qh4, w8), emissive.y * lean::channel8<1>(ql4, qh4, w8), emissive.z * lean::channel8<2>(ql4, qh4, w8)};
+        return true;
+    };
+    if (GRAD == 1 && shared_fp) {
+        if (!(one_draw ? shared_path(std::true_type{}) : shared_path(std::false_type{}))) return true;
     } else {
     fetch_all(u, v, m2c, true);
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
