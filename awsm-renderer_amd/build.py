@@ -50,7 +50,7 @@ def build_hip(jobs: int = 3, arch: str = "gfx950") -> str:
 # SIMD free) — the next frame's geometry kernels and the previous frame's k_shade_todo — keep within that, or the overlapped pipeline falls back
 # to running them after the lean kernel has drained (kernels_shade.hip: k_shade_todo).  Read from the code object's metadata after every build.
 # The gradient-mip and MSAA instantiations run at four wavefronts per SIMD (128 registers): their budgets guard that step, not the 80 / 112 pair.
-# k_raster_tile<4>: 96, so that four of its wavefronts leave a SIMD the 112 registers one wavefront of the gradient lean kernel needs (kernels_geometry.hip).
+# k_raster_tile<4>: 96, the size of the gradient lean kernel's wavefronts since round 5 (kernels_geometry.hip has the measurement against 104).
 # tests/test_abi_and_oracle_units.py::test_register_budgets_hold asserts the list below against every build of this tree.
 VGPR_BUDGETS = {"kernels_shade.o": {"k_shade_leanILb0ELi0ELb0E": 80, "k_shade_todoILi0ELb0E": 112,
                                     "k_shade_leanILb0ELi0ELb1E": 80, "k_shade_leanILb0ELi1ELb0E": 96, "k_shade_leanILb0ELi1ELb1E": 96,

@@ -1037,7 +1037,18 @@ template <> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu
     __shared__ unsigned long long keys[kTile * kTile];
     raster_tile_body<1>(f, keys);
 }
+// Round 5: with the gradient lean kernel down to 96 registers, four wavefronts of this kernel could hold 104 each beside one of its (4 x 104 + 96 = 512) —
+// what the kernel uses uncapped, and the 96 cap's 12 bytes of scratch (two registers) would be gone.  Measured (profiles/r05_ab_register_caps.txt): the
+// kernel alone the same 174 us, the MSAA x4 + mips frame 1,845 frames/s against 1,908 with the 96 cap — every wavefront of the two kernels the same size
+// packs a SIMD better than sizes that only add up in one combination.  The cap stays (AWSM_RASTER_VGPRS4 = 104 is the experiment).
+#ifndef AWSM_RASTER_VGPRS4
+#define AWSM_RASTER_VGPRS4 0
+#endif
+#if AWSM_RASTER_VGPRS4
+template <> __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(AWSM_RASTER_VGPRS4))) void k_raster_tile<4>(FrameDev f) {
+#else
 template <> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AWSM_RASTER_WAVES4))) void k_raster_tile<4>(FrameDev f) {
+#endif
     extern __shared__ unsigned long long keys_dynamic[];
     raster_tile_body<4>(f, keys_dynamic);
 }

@@ -2261,7 +2261,10 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
     constexpr uint32_t kNeed = GRAD == 2 ? 7u : (GRAD ? 3u : 1u);        // LeanDrawDev.flags: lean, ... under MipmapMode::Gradient, ... with anisotropic probes
     // One probe of the footprint: every texel fetch of the pixel at (uu, vv) with the level chosen for m2e.  Called once (the centre) — and, on a context
     // that honours max_anisotropy, once more for every further probe (below).
-    auto fetch_all = [&](float uu, float vv, float m2e, bool act) {      // act: this lane takes the probe (always true for the centre)
+    // tex_mask / factors (MipmapMode::Gradient without probes): the per-texture branch fetches and consumes its textures in two batches — base colour,
+    // metallic-roughness, normal; then occlusion, emissive — so that at most three two-level footprints are live at once: that is what lets the kernel
+    // run at 96 registers without scratch (round 5).  The second call leaves the draw's factors alone (the first batch has already multiplied into them).
+    auto fetch_all = [&](float uu, float vv, float m2e, bool act, const uint32_t tex_mask = 31u, const bool factors = true) {      // act: this lane takes the probe (always true for the centre)
         if (one_draw) {
             const uint32_t lo = d0 * (uint32_t)sizeof(LeanDrawDev);
             const u32x4 L0 = cload<u32x4>(f.draw_lean, lo), L1 = cload<u32x4>(f.draw_lean, lo + 16u), L2 = cload<u32x4>(f.draw_lean, lo + 32u);
@@ -2277,7 +2280,7 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
             }
             todo = todo || (L0.x & kNeed) != kNeed;
             const uint32_t exs = todo ? 0u : L0.x >> 8;                       // scalar
-            const uint32_t ex = act ? exs : 0u;
+            const uint32_t ex = act ? exs & tex_mask : 0u;
             if (GRAD) {
                 const u32x4 G0 = cload<u32x4>(f.draw_lean, lo + 96u), G1 = cload<u32x4>(f.draw_lean, lo + 112u), G2 = cload<u32x4>(f.draw_lean, lo + 128u);
                 const u32x4 G3 = cload<u32x4>(f.draw_lean, lo + 144u), G4 = cload<u32x4>(f.draw_lean, lo + 160u);
@@ -2294,9 +2297,11 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
                 if (ex & 16u) lean::fetch_s(lean::decode_s(L5.x, L5.y), uu, vv, tp4);
             }
             exists = exs;
+            if (factors) {
             metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
             base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
             emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
+            }
         } else {
             const uint32_t lo = draw * (uint32_t)sizeof(LeanDrawDev);
             const u32x4 L0 = gload<u32x4>(f.draw_lean, lo), L1 = gload<u32x4>(f.draw_lean, lo + 16u), L2 = gload<u32x4>(f.draw_lean, lo + 32u);
@@ -2312,7 +2317,7 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
             }
             todo = todo || __builtin_amdgcn_ballot_w64(hit && (L0.x & kNeed) != kNeed) != 0ull;
             const uint32_t exs = (todo || !hit) ? 0u : L0.x >> 8;
-            const uint32_t ex = act ? exs : 0u;
+            const uint32_t ex = act ? exs & tex_mask : 0u;
             if (GRAD) {
                 const u32x4 G0 = gload<u32x4>(f.draw_lean, lo + 96u), G1 = gload<u32x4>(f.draw_lean, lo + 112u), G2 = gload<u32x4>(f.draw_lean, lo + 128u);
                 const u32x4 G3 = gload<u32x4>(f.draw_lean, lo + 144u), G4 = gload<u32x4>(f.draw_lean, lo + 160u);
@@ -2330,9 +2335,11 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
                 if (ex & 16u) lean::fetch(x4, uu, vv, tp4);
             }
             exists = exs;
+            if (factors) {
             metallic_in = __uint_as_float(L0.y); roughness_in = __uint_as_float(L0.z); normal_scale = __uint_as_float(L0.w);
             base = {__uint_as_float(L1.x), __uint_as_float(L1.y), __uint_as_float(L1.z)}; occlusion_strength = __uint_as_float(L1.w);
             emissive = {__uint_as_float(L2.x), __uint_as_float(L2.y), __uint_as_float(L2.z)}; normal_bias = __uint_as_float(L2.w); occlusion_bias = __uint_as_float(L5s.x);
+            }
         }
     };
     float nf = 1.0f;                                                       // grad_footprint's N; the level is chosen for rho_max / N
@@ -2452,7 +2459,7 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
     if (GRAD == 1 && shared_fp) {
         if (!(one_draw ? shared_path(std::true_type{}) : shared_path(std::false_type{}))) return true;
     } else {
-    fetch_all(u, v, m2c, true);
+    fetch_all(u, v, m2c, true, GRAD == 1 ? 7u : 31u);
     if (todo) {      // this wavefront goes to the general kernel (k_shade_todo): nothing of a hit pixel has been written
         if (!ITEMS && lane == 0u) {
             const uint32_t slot = atomicAdd(&f.shade_todo[0], 1u);
@@ -2545,6 +2552,7 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
             const float ntx = AWSM_LEAN_CH(2, 0, w, wh) * normal_scale - normal_bias, nty = AWSM_LEAN_CH(2, 1, w, wh) * normal_scale - normal_bias, ntz = AWSM_LEAN_CH(2, 2, w, wh) * (2.0f / 255.0f) - 1.0f;
             normal = fm::fnormalize(tbn.T * ntx + tbn.B * nty + tbn.N * ntz);
         }
+        if (GRAD == 1 && __builtin_amdgcn_ballot_w64((exists & 24u) != 0u) != 0ull) fetch_all(u, v, m2c, true, 24u, false);      // the second batch
         if (exists & 8u) { AWSM_LEAN_TEX(3, w, wh); occlusion = AWSM_LEAN_CH(3, 0, w, wh) * occlusion_strength + occlusion_bias; }      // mix(1, r, s)
         if (exists & 16u) { AWSM_LEAN_TEX(4, w, wh); emissive = {emissive.x * AWSM_LEAN_CH(4, 0, w, wh), emissive.y * AWSM_LEAN_CH(4, 1, w, wh), emissive.z * AWSM_LEAN_CH(4, 2, w, wh)}; }
     } else {
@@ -2954,7 +2962,15 @@ __global__ __launch_bounds__(256) void k_shade_msaa(const DevScene* __restrict__
 #ifndef AWSM_DETECT_WAVES
 #define AWSM_DETECT_WAVES 8
 #endif
+// Round 5: 72 registers instead of a 64 cap with one register in scratch — beside four wavefronts of the gradient lean kernel (now 96 each) a SIMD has 128 left.
+#ifndef AWSM_DETECT_VGPRS
+#define AWSM_DETECT_VGPRS 72
+#endif
+#if AWSM_DETECT_VGPRS
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AWSM_DETECT_VGPRS))) void k_msaa_detect(FrameDev f) {
+#else
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AWSM_DETECT_WAVES))) void k_msaa_detect(FrameDev f) {      // 64 registers: fits beside four wavefronts of the gradient lean kernel (448 of a SIMD's 512)
+#endif
     __shared__ __attribute__((aligned(16))) uint8_t eslot[256];
     __shared__ uint8_t tslot[256];
     ShadeBlock b;

@@ -513,6 +513,7 @@ def main():
     # No Python garbage collection inside the warm-up and the timed loop: a generation-2 pass over the scene's objects takes ~35 ms, and
     # whether one lands in a 25-70 ms loop depends on the allocation count of everything before it (seen: configs[1] at 3,100 or 8,300
     # frames/s depending on an unrelated command-line flag).  The loop itself allocates a few tuples per step.
+    steady_upload = [0]
     host_t = []                            # --trace: perf_counter at every step() return (and around the barriers)
 
     def timed_loop():
@@ -539,6 +540,7 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             host_t.append(("t1", t0 + dt))
+            steady_upload[0] = int(r.host.upload_bytes_last_frame())      # what the last timed frame sent over the boundary (the camera block)
         finally:
             gc.enable()
         return dt
@@ -710,7 +712,7 @@ def main():
             # what crosses the boundary as host buffers: `value` is measured with the scene resident; a frame's own uploads are inside it
             "host_to_device": {"first_frame_bytes": first_frame_upload, "first_frame_ms": round(first_frame_ms, 2),
                                "texture_bytes_at_setup": int(sum(int(t.nbytes) for t in scene.textures)),
-                               "steady_state_bytes_per_frame": int(r.host.upload_bytes_last_frame())},
+                               "steady_state_bytes_per_frame": steady_upload[0]},
             **({"collective": {"backend": "rccl" if backend == "nccl" else backend + " (rehearsal: every rank on GPU 0, staged through the host)",
                                "op": "gather to rank 0" if to_root else "all_gather_into_tensor", "bytes_per_rank": rows_out * W * 8,
                                "alone_ms": max(p["gather_alone_ms"] for p in per_rank), **collective_model(world, rows_out * W * 8, to_root), "launcher": "bench.py (child processes)" if os.environ.get("AWSM_BENCH_SELF_LAUNCHED") else "external (WORLD_SIZE was set)"},
