@@ -2660,7 +2660,7 @@ AWSM_DI bool lean_core(const DevScene* __restrict__ sc, const FrameDev& f, const
             light_dir = to_light;
             radiance = radiance * att;
 #ifndef AWSM_NO_LIGHT_SKIP
-            if (__builtin_amdgcn_ballot_w64(att > 0.0f) == 0ull) continue;      // out of the light's range (or cone) for the whole wavefront: the term is exactly zero
+            if (__builtin_amdgcn_ballot_w64(!(att == 0.0f)) == 0ull) continue;      // out of the light's range (or cone) for the whole wavefront: the term is exactly zero
 #endif
         } else if (kind != 1u) { light_dir = {0.0f, 0.0f, 0.0f}; radiance = {0.0f, 0.0f, 0.0f}; }
         lean::direct(lit, light_dir, radiance, color);

@@ -341,7 +341,12 @@ void* awsm_hip_output_device_ptr(AwsmHipCtx* ctx);
  * (depth_f32_bits << 32) | (0xFFFFFFFF - rank),
  * rank = index of the triangle in draw order over the whole draw list; all ones = no hit.
  * unpack gives the reference's visibility_data texel: triangle_index (primitive-local) and
- * material_mesh_meta_offset, plus the Depth32Float value. ---- */
+ * material_mesh_meta_offset, plus the Depth32Float value.
+ * "Bit-exact" for these keys means: bit-exact to the arithmetic contract of DESIGN.md section 3, which this repository defines where WebGPU leaves the
+ * implementation free — vertex snapping to 1/256 pixel, the top-left rule, the operation order of the depth interpolation, and the depth of an MSAA sample
+ * (the plane's value at the pixel's corner plus the sample's step: a rule CHANGED IN ROUND 4 FOR SPEED, oracle first, kernel second; within 1.25 f32 steps
+ * of the plane in f64).  The CPU oracle (oracle/) implements the same contract without shared code and the GPU tests compare every key.  What the
+ * reference's own tests pin are the buffer allocators, the dirty-range writer and the frustum — not these keys. ---- */
 int awsm_hip_read_visibility(AwsmHipCtx* ctx, uint64_t* keys_out);
 /* 128-bit position-dependent digest of the keys the last geometry pass left (the caller's stream; synchronous):
  * out2[0] = sum key_i * (2 i + 1) mod 2^64, out2[1] = xor rotl(key_i, i mod 64).  For tests that compare many frames
