@@ -14,6 +14,14 @@
 #include "frame_params.hpp"
 #include "raster_setup.hpp"
 
+// The geometry chain's wavefronts take issue priority over the opaque pass's on a SIMD they share (s_setprio; round 5).  The overlapped frame is as long as
+// its longer stream; with MSAA x4 that is the geometry stream (k_raster_tile<4> runs 380 us beside the lean kernel, 172 alone: profiles/r05_b_timeline_msaa_mips.txt),
+// and whatever its wavefronts do not issue the lean kernel's take anyway.  Measured, same box: MSAA x4 + mips 1,923 -> 1,943 frames/s, single-sampled
+// unchanged (3,418 / 3,419); the reverse — the lean kernel at priority — costs 1.3 % and 4 % (profiles/r05_wave_priority.txt).  0 = off.
+#ifndef AWSM_GEOM_PRIO
+#define AWSM_GEOM_PRIO 3
+#endif
+
 namespace awsm {
 
 // Diagnostic builds (-DAWSM_STAMP, tools/stamp_geometry.sh): where a geometry kernel's workgroups spend their time.  Stamps are the
@@ -71,6 +79,9 @@ template <bool FWD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD ? 4 : AWSM_TRANSFORM_WAVES))) void k_deform_transform(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_vtx[FWD ? 4 : 256 * 14];
     if (frame_poisoned(f)) return;
+#if AWSM_GEOM_PRIO
+    __builtin_amdgcn_s_setprio(AWSM_GEOM_PRIO);
+#endif
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x + f.block0;
     {   // per-frame clears folded into the first kernel of the frame (saves three memset launches per frame)
@@ -369,6 +380,9 @@ constexpr uint32_t kBinBigBlocks = 64;        // fill pass: the first workgroups
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(FrameDev f) {
+#if AWSM_GEOM_PRIO
+    __builtin_amdgcn_s_setprio(AWSM_GEOM_PRIO);
+#endif
     __shared__ int win[4];                       // tile window of the workgroup's small triangles: x0, y0, x1, y1
     __shared__ uint32_t n_ok, n_big_wg, big_base;
     __shared__ uint32_t lcount[kBinWindow];
@@ -507,6 +521,9 @@ constexpr uint32_t kScanThreads = 256, kScanWords = 40;     // per workgroup: [0
 AWSM_DI uint32_t ld_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 AWSM_DI void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ __launch_bounds__(kScanThreads) void k_bin_scan(FrameDev f, uint32_t n_tiles) {
+#if AWSM_GEOM_PRIO
+    __builtin_amdgcn_s_setprio(AWSM_GEOM_PRIO);
+#endif
     __shared__ uint32_t hist[36], part[3][4], base[kScanWords], last_flag;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, k = blockIdx.x, G = gridDim.x;
     const uint32_t i = k * kScanThreads + tid;
@@ -879,6 +896,9 @@ AWSM_DI void raster_tile_body(const FrameDev& f, unsigned long long* keys) {    
     // spreads the dense band of the screen over all eight of them.
     // The first counters[7] workgroups take the extra slices of the split tiles (the heaviest work of the frame), the rest one tile each.
     if (frame_poisoned(f)) return;
+#if AWSM_GEOM_PRIO
+    __builtin_amdgcn_s_setprio(AWSM_GEOM_PRIO);      // experiment: the geometry chain's wavefronts ahead of the opaque pass's on a shared SIMD
+#endif
     const uint32_t n_tiles = f.tiles_x * f.tiles_y, n_extra = min(f.counters[7], f.raster_extra_cap);
     uint32_t item;
     if (blockIdx.x < n_extra) item = f.tile_order[n_tiles + blockIdx.x];

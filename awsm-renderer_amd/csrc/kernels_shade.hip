@@ -2707,6 +2707,9 @@ template <bool PERSIST, int GRAD, bool MSAA>   // the loop state costs the persi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? AWSM_ANISO_WAVES : (GRAD ? AWSM_LEAN_GRAD_WAVES : (PERSIST ? 5 : AWSM_LEAN_WAVES))))) void k_shade_lean(const DevScene* __restrict__ sc, FrameDev f) {
     __shared__ LeanStage stage[4];                                         // one per wavefront (no barrier anywhere: the four are independent)
     if (frame_poisoned(f)) return;
+#ifdef AWSM_LEAN_PRIO
+    __builtin_amdgcn_s_setprio(AWSM_LEAN_PRIO);                            // experiment: issue priority over the geometry kernels' wavefronts on the same SIMD
+#endif
     LeanStage* const st = &stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     const uint32_t xcd = blockIdx.x & 7u, lane = threadIdx.x & 63u;
     const uint32_t bx_n = (f.width + 15u) >> 4, by_n = f.band_n > 1u ? 2u * f.tiles_y : ((f.sy1 - f.sy0) + 15u) >> 4;
