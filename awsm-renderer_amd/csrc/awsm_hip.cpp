@@ -981,23 +981,25 @@ int upload_draws_at(AwsmHipCtx* c, FrameBufs& b, size_t at, const std::vector<Dr
 int upload_draw_list(AwsmHipCtx* c, FrameBufs& b, const std::vector<DrawDev>& draws_host, bool keep_prev) {
     const bool same_draws = b.draws_uploaded_valid && b.draws_uploaded_ptr == b.draws_dev.ptr && b.draws_uploaded.size() == draws_host.size() &&
                             (draws_host.empty() || memcmp(b.draws_uploaded.data(), draws_host.data(), draws_host.size() * sizeof(DrawDev)) == 0);
-    if (draws_host.empty() || same_draws) return AWSM_OK;
+    auto upload_block_map = [&]() -> int {      // the world pass: which draw each transform workgroup belongs to
+        b.block_map_valid = false;
+        if (!keep_prev || !b.block_map.ptr) return AWSM_OK;
+        std::vector<uint32_t> map;
+        for (size_t i = 0; i < draws_host.size(); i++) map.insert(map.end(), (3ull * draws_host[i].tri_count + 255) / 256, (uint32_t)i);
+        if (map.size() * 4 > b.block_map.size || map.size() * 4 > (1u << 20)) return AWSM_OK;
+        const int rc = upload_small(c, b.block_map.ptr, map.data(), map.size() * 4);
+        if (!rc) b.block_map_valid = true;
+        return rc;
+    };
+    if (draws_host.empty()) return AWSM_OK;
+    if (same_draws) return (keep_prev && !b.block_map_valid) ? upload_block_map() : AWSM_OK;      // (the map's buffer was re-sized under an unchanged list)
     if (keep_prev && b.cache_valid && !b.cached_is_prev && b.draws_prev.ptr && b.draws_prev.size == b.draws_dev.size) {
         std::swap(b.draws_dev, b.draws_prev);
         b.cached_is_prev = true;
     } else if (keep_prev && !b.cached_is_prev) b.cache_valid = false;      // the cached list is about to be overwritten
     b.draws_uploaded = draws_host; b.draws_uploaded_ptr = b.draws_dev.ptr; b.draws_uploaded_valid = true; b.draws_version++;
     b.tail_uploaded_valid = false;
-    b.block_map_valid = false;
-    if (keep_prev && b.block_map.ptr) {      // the world pass: which draw each transform workgroup belongs to
-        std::vector<uint32_t> map;
-        for (size_t i = 0; i < draws_host.size(); i++) map.insert(map.end(), (3ull * draws_host[i].tri_count + 255) / 256, (uint32_t)i);
-        if (map.size() * 4 <= b.block_map.size && map.size() * 4 <= (1u << 20)) {
-            int rc = upload_small(c, b.block_map.ptr, map.data(), map.size() * 4);
-            if (rc) return rc;
-            b.block_map_valid = true;
-        }
-    }
+    { const int rc = upload_block_map(); if (rc) return rc; }
     return upload_draws_at(c, b, 0, draws_host);
 }
 
