@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "frame_params.hpp"
+#include "dirty_log.hpp"
 
 using namespace awsm;
 
@@ -160,9 +161,7 @@ struct AwsmHipCtx {
     // Geometry cache: the byte ranges written (awsm_hip_buffer_write / buffer_create) to the buffers k_deform_transform reads, each with the write_seq it got;
     // a slot's geometry pass hands the kernel those newer than the slot's cache_seq.  all_dirty_seq: everything up to that write_seq counts as "all
     // written" (the log overflowed, or a buffer was written whose every write invalidates every draw).
-    struct DirtyRange { uint32_t buf, lo, hi; uint64_t seq; };
-    std::vector<DirtyRange> dirty_log;
-    uint64_t all_dirty_seq = 0;
+    DirtyLog dirty_log;                         // (dirty_log.hpp)
     bool geometry_cache = true;                 // AWSM_GEOMETRY_CACHE=0 turns it off (A/B measurements, tests)
     uint32_t cache_blocks_last = 0;             // AwsmFrameStats.geometry_cache_blocks of the frame frame_end last looked at
     bool shade_pending[kSlots] = {};
@@ -396,23 +395,7 @@ void shard(const AwsmHipCtx* c, uint32_t* y0, uint32_t* y1) {
 
 // Geometry cache: remember what was written to the buffers k_deform_transform reads (call after the write got its write_seq).
 void log_dirty(AwsmHipCtx* c, AwsmBuf which, size_t lo, size_t hi) {
-    switch (which) {
-    case AWSM_BUF_ATTR_DATA: case AWSM_BUF_ATTR_INDEX: case AWSM_BUF_MORPH_VALUES: case AWSM_BUF_SKIN_INDEX_WEIGHTS:
-        c->all_dirty_seq = c->write_seq; return;      // static per-mesh data whose blocks' extents the kernel does not know: every draw is recomputed once
-    case AWSM_BUF_TRANSFORMS: case AWSM_BUF_INSTANCES: case AWSM_BUF_GEOM_META: case AWSM_BUF_VIS_GEOM_DATA: case AWSM_BUF_MORPH_WEIGHTS:
-    case AWSM_BUF_SKIN_MATRICES: case AWSM_BUF_MATERIAL_META: break;
-    default: return;                                  // nothing the geometry pass reads (the camera is per frame by design)
-    }
-    if (!c->geometry_cache) return;
-    const uint32_t l = (uint32_t)std::min<size_t>(lo, 0xFFFFFFFFu), h = (uint32_t)std::min<size_t>(hi, 0xFFFFFFFFu);
-    if (!c->dirty_log.empty()) {
-        AwsmHipCtx::DirtyRange& last = c->dirty_log.back();
-        if (last.buf == (uint32_t)which && last.seq + 1 >= c->write_seq && l <= last.hi && last.lo <= h) {     // consecutive writes that touch: one range (the newer seq: seen by everyone who saw the older)
-            last.lo = std::min(last.lo, l); last.hi = std::max(last.hi, h); last.seq = c->write_seq; return;
-        }
-    }
-    if (c->dirty_log.size() >= 512) { c->all_dirty_seq = c->write_seq; c->dirty_log.clear(); return; }
-    c->dirty_log.push_back({(uint32_t)which, l, h, c->write_seq});
+    if (c->geometry_cache) c->dirty_log.log((uint32_t)which, lo, hi, c->write_seq);
 }
 
 // Overlap mode: anything that writes scene state the opaque pass reads (every buffer but the camera, whose snapshot the
@@ -576,22 +559,11 @@ void fill_geometry_cache(AwsmHipCtx* c, FrameDev* f, bool replay) {
     FrameBufs& b = FB(c);
     f->wcache = (float4*)b.wcache.ptr;
     f->cache_on = 0; f->prev_draws = nullptr; f->prev_n_draws = 0; f->n_dirty = 0; f->cache_serial = b.cache_serial;
-    if (!c->geometry_cache || replay || !b.cache_valid || !b.wcache.ptr || b.cache_had_tri_shade != (f->tri_shade != nullptr) || c->all_dirty_seq > b.cache_seq) return;
-    // the ranges written since the slot's arrays were computed, merged per buffer; too many: one bounding range per buffer; still too many: no cache this frame
-    std::vector<AwsmHipCtx::DirtyRange> r;
-    for (const AwsmHipCtx::DirtyRange& d : c->dirty_log) if (d.seq > b.cache_seq) r.push_back(d);
-    std::sort(r.begin(), r.end(), [](const AwsmHipCtx::DirtyRange& x, const AwsmHipCtx::DirtyRange& y) { return x.buf != y.buf ? x.buf < y.buf : x.lo < y.lo; });
-    auto merge = [&](bool whole_buffer) {
-        std::vector<AwsmHipCtx::DirtyRange> m;
-        for (const AwsmHipCtx::DirtyRange& d : r) {
-            if (!m.empty() && m.back().buf == d.buf && (whole_buffer || d.lo <= m.back().hi)) m.back().hi = std::max(m.back().hi, d.hi);
-            else m.push_back(d);
-        }
-        r.swap(m);
-    };
-    merge(false);
-    if (r.size() > kMaxDirtyRanges) merge(true);
-    if (r.size() > kMaxDirtyRanges) return;
+    if (!c->geometry_cache || replay || !b.cache_valid || !b.wcache.ptr || b.cache_had_tri_shade != (f->tri_shade != nullptr)) return;
+    // the ranges written since the slot's arrays were computed, merged per buffer; too many: one bounding range per buffer; still too many (or a write that
+    // invalidates every draw): no cache this frame
+    std::vector<DirtyRange> r;
+    if (!c->dirty_log.ranges_since(b.cache_seq, kMaxDirtyRanges, r)) return;
     for (size_t i = 0; i < r.size(); i++) { f->dirty[i][0] = r[i].buf; f->dirty[i][1] = r[i].lo; f->dirty[i][2] = r[i].hi; }
     f->n_dirty = (uint32_t)r.size();
     f->prev_draws = (const DrawDev*)(b.cached_is_prev ? b.draws_prev.ptr : b.draws_dev.ptr);
@@ -673,9 +645,7 @@ int enqueue_geometry(AwsmHipCtx* c, bool replay = false) {
         // entries every slot has seen are of no further use
         uint64_t oldest = ~0ull;
         for (int sl = 0; sl < n_slots(c); sl++) oldest = std::min(oldest, c->fb[sl].cache_valid ? c->fb[sl].cache_seq : c->write_seq);
-        size_t keep = 0;
-        for (const AwsmHipCtx::DirtyRange& d : c->dirty_log) if (d.seq > oldest) c->dirty_log[keep++] = d;
-        c->dirty_log.resize(keep);
+        c->dirty_log.prune(oldest);
     }
     return AWSM_OK;
 }

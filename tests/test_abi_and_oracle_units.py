@@ -158,3 +158,28 @@ def test_register_budgets_hold():
             pytest.skip("no in-tree object files (run __graft_entry__.build() first)")
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     assert b.check_register_budgets(hipcc) == []
+
+
+def test_python_mirrors_of_the_abi_structs_match_the_header(tmp_path):
+    """The ctypes structures the Python drivers pass across the C-ABI (hip_backend.py) against include/awsm_hip.h as a C compiler lays it out: size and the
+    offset of every field — AwsmFrameStats grows by appending (struct_size: ABI 2), so a forgotten field on either side shows here, not as a shifted
+    counter on the GPU box."""
+    import subprocess
+    pairs = {"AwsmConfig": hip_backend.AwsmConfig, "AwsmDraw": hip_backend.AwsmDraw, "AwsmOpaqueParams": hip_backend.AwsmOpaqueParams,
+             "AwsmSampler": hip_backend.AwsmSampler, "AwsmEnv": hip_backend.AwsmEnv, "AwsmFrameStats": hip_backend.AwsmFrameStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "awsm_hip.h"', 'int main(void) {']
+    for cname, py in pairs.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in py._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, py in pairs.items():
+        assert int(out[cname]) == C.sizeof(py), (cname, out[cname], C.sizeof(py))
+        for fname, _ in py._fields_:
+            assert int(out["%s.%s" % (cname, fname)]) == getattr(py, fname).offset, (cname, fname)
+    assert "geometry_cache_blocks" in dict(hip_backend.AwsmFrameStats._fields_) and "geometry_blocks" in dict(hip_backend.AwsmFrameStats._fields_)
