@@ -1218,8 +1218,10 @@ __global__ void k_debug_pad(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 extern "C" void awsm_launch_bin_scan(const awsm::FrameDev* f, hipStream_t s) {
+#ifdef AWSM_DEBUG_SWITCHES      // tools/build_variants.sh g_debug "-DAWSM_DEBUG_SWITCHES": the product library reads no debug switch
     static const long pad_us = getenv("AWSM_DEBUG_CHAIN_PAD_US") ? atol(getenv("AWSM_DEBUG_CHAIN_PAD_US")) : 0;
     if (pad_us > 0) hipLaunchKernelGGL(k_debug_pad, dim3(1), dim3(64), 0, s, (unsigned long long)pad_us * 100ull);      // wall_clock64: 100 MHz
+#endif
     const uint32_t n_tiles = f->tiles_x * f->tiles_y;
     if (n_tiles) hipLaunchKernelGGL(awsm::k_bin_scan, dim3((n_tiles + awsm::kScanThreads - 1u) / awsm::kScanThreads), dim3(awsm::kScanThreads), 0, s, *f, n_tiles);
 }
