@@ -1752,3 +1752,43 @@ def test_overlapped_msaa_frames_with_hud_meshes_and_a_changing_world_list(oracle
     for i, (a, b) in enumerate(zip(plain, over)):
         assert (a == b).all(), f"frame {i}: {(a != b).sum()} values differ"
     assert not (plain[0] == plain[2]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["mips", "msaa"])
+def test_full_size_4k_other_modes(mode, oracle_lut):
+    """The 4K frame in the two modes between the BASELINE's and the reference's default — MipmapMode::Gradient alone (k_shade_lean<., 1, false>: the
+    shared-footprint route at full size) and MSAA x4 alone — every pixel against the oracle, as test_full_size_4k_frame_properties does for the others."""
+    kw = dict(mipmap=True) if mode == "mips" else dict(msaa=4)
+    sc = scenes.atrium_scene(3840, 2160)
+    model = helpers.build_model(sc)
+    dev, stats = helpers.hip_frame(model, oracle_lut, **kw)
+    orc = helpers.oracle_frame(model, oracle_lut, threads=_host_threads(), **kw)
+    _assert_full_frame("configs[3] atrium 3840x2160 " + ("gradient mips" if mode == "mips" else "MSAA x4"), orc, dev, stats)
+    assert stats["shade_general_wavefronts"] == 0
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_frame_stats_struct_size_is_honoured(oracle_lut):
+    """ABI 2: AwsmFrameStats grows by appending (round 5: geometry_cache_blocks, geometry_blocks) and awsm_hip_frame_end writes nothing beyond the size the
+    caller states — a caller compiled against the struct of an earlier round keeps working, its memory behind the struct untouched."""
+    import ctypes as C
+    from awsm_renderer_amd.hip_backend import AwsmFrameStats
+    model = helpers.build_model(scenes.box_scene(96, 64))
+    dev, full = helpers.hip_frame(model, oracle_lut)
+    old_size = AwsmFrameStats.geometry_cache_blocks.offset      # the struct as round 4 knew it
+    buf = (C.c_uint8 * (C.sizeof(AwsmFrameStats) + 64))()
+    C.memset(buf, 0xA5, len(buf))
+    st = AwsmFrameStats.from_buffer(buf)
+    st.struct_size = old_size
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass()
+    dev._chk(dev.lib.awsm_hip_frame_end(dev.ctx, C.byref(st)), "frame_end")
+    assert st.struct_size == old_size and st.triangles_in == full["triangles_in"] and st.covered_pixels == full["covered_pixels"]
+    assert bytes(buf[old_size:]) == b"\xA5" * (len(buf) - old_size)
+    st.struct_size = C.sizeof(AwsmFrameStats)
+    dev.geometry_pass(model.collect_draws()); dev.opaque_pass()
+    dev._chk(dev.lib.awsm_hip_frame_end(dev.ctx, C.byref(st)), "frame_end")
+    assert st.struct_size == C.sizeof(AwsmFrameStats) and st.geometry_blocks >= 1 and st.geometry_cache_blocks == st.geometry_blocks      # nothing moved: every workgroup kept its draw
+    assert bytes(buf[C.sizeof(AwsmFrameStats):]) == b"\xA5" * 64
+    dev.close()
